@@ -1,0 +1,98 @@
+/*
+ * ORACLE (test infrastructure, not product): public interface of the CPU restatement.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library. The product
+ * (libluminary_amd.so) never links, loads or calls it.
+ *
+ * The scene is handed over in the *device format* (what the kernels see): vertices with packed normals,
+ * 32-byte compressed materials, 32-byte instance transforms, the 8-wide quantised light tree, the blue-noise
+ * mask and the four BSDF energy LUTs. Those buffers are produced by the product's host layer
+ * (reference: device/device_structs.c, device/device_light.c) and are inputs here.
+ * Layout must stay identical to `LumDeviceSceneView` in include/lum_core.h (checked by tests/test_layouts.py).
+ */
+#ifndef ORACLE_ORACLE_H
+#define ORACLE_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OracleScene {
+  /* geometry: all meshes concatenated; mesh m owns triangles [mesh_tri_offset[m], mesh_tri_offset[m+1]) */
+  uint32_t num_meshes;
+  uint32_t num_instances;
+  uint32_t num_materials;
+  uint32_t num_lights;
+  const uint32_t* mesh_tri_offset;   /* num_meshes + 1 */
+  const float* vertices;             /* 3 per triangle, 16 B each: x,y,z, packed normal (as float bits) */
+  const uint32_t* tri_tex;           /* 16 B per triangle: uv0, uv1, uv2, material_id (low 16 bits) */
+  const uint32_t* instance_mesh_ids; /* num_instances */
+  const float* instance_transforms;  /* 32 B each: translation, scale, 4 x u16 quaternion */
+  const uint16_t* materials;         /* 32 B each */
+  /* light tree (device_utils.h:283-327) */
+  const uint8_t* light_tree_root;    /* 16-byte header + 48 bytes per section; NULL when there are no lights */
+  const uint8_t* light_tree_nodes;   /* 64 bytes per node */
+  const uint32_t* light_tri_handles; /* 2 per light: instance_id, tri_id */
+  const float* light_bvh_tris;       /* 12 floats per light: 3 x (x,y,z,pad) world space */
+  uint32_t num_light_tree_nodes;
+  uint32_t pad0;
+  /* sampler + LUTs */
+  const uint32_t* bluenoise_2d;      /* 65536 */
+  const uint16_t* lut_conductor;     /* 1024 */
+  const uint16_t* lut_glossy;        /* 1024 */
+  const uint16_t* lut_dielectric;    /* 32768 */
+  const uint16_t* lut_dielectric_inv;/* 32768 */
+  /* settings (device_structs.h:8-22), internal resolution */
+  uint32_t width, height, max_ray_depth, shading_mode;
+  /* camera (device_structs.h:38-82), thin lens only */
+  float cam_pos[3];
+  float cam_rotation[4]; /* quaternion x,y,z,w */
+  float cam_fov, cam_aperture_size, cam_object_distance, cam_scale, cam_rr_threshold;
+  uint32_t cam_aperture_shape, cam_aperture_blade_count;
+  /* sky (device_structs.h:100-124) */
+  uint32_t sky_mode;
+  float sky_constant_color[3];
+} OracleScene;
+
+/* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
+enum { ORACLE_CNT_TRACE = 0, ORACLE_CNT_SHADOW = 1, ORACLE_CNT_LIGHT_BVH = 2, ORACLE_CNT_VERTICES = 3, ORACLE_CNT_COUNT = 4 };
+
+/*
+ * Renders samples [first_sample, first_sample + num_samples) of the pixels listed in `pixels` (index = x + y*width;
+ * NULL = every pixel) and ADDS them into planar accumulators of `num_pixels` floats each:
+ * first_moment = [R | G | B], second_moment = luminance of the squared sample (accumulation.cuh:63-84).
+ * `threads` <= 0 uses every core. `use_bvh` = 0 intersects by brute force (small scenes only). Returns 0 on success.
+ */
+int oracle_render(
+  const OracleScene* scene, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples, int use_bvh,
+  int threads, float* first_moment, float* second_moment, uint64_t* counters);
+
+/* Closest-hit query used by the traversal parity tests: out = instance_id, tri_id, t bits per ray (HIT_TYPE_SKY on miss). */
+int oracle_trace_closest(
+  const OracleScene* scene, uint32_t num_rays, const float* origins, const float* dirs, const uint32_t* ignore_handles, int use_bvh,
+  uint32_t* out_hits);
+
+/* BSDF energy LUT generation (bsdf_lut.cuh). texel range [first, first+count) of the named table:
+ * 0 conductor, 1 glossy (needs conductor), 2 dielectric, 3 dielectric_inv. */
+int oracle_generate_lut(const uint32_t* bluenoise_2d, int table, uint32_t first, uint32_t count, const uint16_t* conductor, uint16_t* dst);
+
+/* Unit-level entry points for known-answer tests. */
+uint32_t oracle_squares32(uint32_t key, uint32_t counter);
+void oracle_sobol(uint32_t offset, uint32_t dimension, uint32_t out[2]);
+void oracle_random_2d(const uint32_t* bn, uint32_t target, uint32_t px, uint32_t py, uint32_t sample, uint32_t depth, uint32_t out[2]);
+void oracle_record_roundtrip(const float in[3], uint32_t packed[2], float out[3]);
+void oracle_ray_roundtrip(const float in[3], uint32_t packed[2], float out[3]);
+uint32_t oracle_normal_pack(const float in[3]);
+void oracle_normal_unpack(uint32_t packed, float out[3]);
+void oracle_sincos(float x, float out[2]);
+float oracle_atan2(float y, float x);
+void oracle_camera_ray(const OracleScene* scene, uint32_t x, uint32_t y, uint32_t sample_id, float out[6]);
+uint32_t oracle_scene_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif
