@@ -1,0 +1,424 @@
+/*
+ * ORACLE (test infrastructure, not product): the per-sample path loop.
+ * Follows the reference's kernel schedule, device/device_renderer.c:53-134 (one pass per depth 0..max_ray_depth):
+ *   tasks_create                 cuda/kernels.cuh:45-193, cuda/camera.cuh:11-38, cuda/camera_thin_lens.cuh:8-86
+ *   trace                        optix/optix_kernel_raytrace.cu:147-183          (o_trace.h)
+ *   geometry_process_tasks       cuda/geometry.cuh:11-180, cuda/geometry_utils.cuh:54-221, cuda/direct_lighting.cuh:352-443
+ *   shadow                       optix/optix_kernel_shadow.cu:15-100, cuda/direct_lighting.cuh:445-669
+ *   sky_process_tasks            cuda/sky.cuh:567-633 (constant-colour branch)
+ *   accumulate                   cuda/memory.cuh:359-368, cuda/accumulation.cuh:63-84
+ * Paths are independent (all randomness is a function of pixel, sample id, depth and target), so the oracle walks
+ * them one at a time instead of in wavefronts; per path the order of every floating-point operation is the reference's.
+ * Quirk kept: the depth constant the sampler sees is not advanced before the last pass (device_renderer.c:126-130).
+ * Out of scope: textures, volumes, ocean, particles, procedural sky/sun, physical camera.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "o_trace.h"
+
+enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
+enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
+#define GEOMETRY_DELTA_PATH_CUTOFF 0.05f
+#define BSDF_ROUGHNESS_CLAMP 2e-2f
+#define RUSSIAN_ROULETTE_CLAMP (1.0f / 8.0f)
+#define CAMERA_COMMON_SCALE 0.001f
+#define CAMERA_COMMON_INV_SCALE (1.0f / CAMERA_COMMON_SCALE)
+
+/* ---- camera (camera_thin_lens.cuh:8-86, camera.cuh:29-35) ---- */
+static void camera_sample(const OracleScene* s, const Sampler* smp, vec3* origin, vec3* ray) {
+  const uint2_t jq = rng_2d_u32(s->bluenoise_2d, RT_CAMERA_JITTER, 0, 0, smp->sample_id, 0); /* camera_utils.cuh:23-27 */
+  const float jx = u32_to_unit(jq.x), jy = u32_to_unit(jq.y);
+  const float step = 2.0f * (s->cam_fov / s->width);
+  const float vfov = step * s->height * 0.5f;
+  vec3 sp;
+  sp.x = s->cam_fov - step * (smp->px + jx);
+  sp.y = -vfov + step * (smp->py + jy);
+  sp.z = 1.0f;
+  const vec3 s2f = v_norm(v_sub(v3(0.0f, 0.0f, 0.0f), sp));
+  const float focal = fmaxf(s->cam_object_distance * CAMERA_COMMON_INV_SCALE, 0.01f);
+  const vec3 fp = v_scale(s2f, -focal / s2f.z);
+  vec3 ap = v3(0.0f, 0.0f, 0.0f);
+  if (s->cam_aperture_size != 0.0f) {
+    const float2_t r = rnd2(smp, RT_LENS);
+    const float asz = s->cam_aperture_size * CAMERA_COMMON_INV_SCALE;
+    float sx, sy;
+    if (s->cam_aperture_shape == 1) {
+      const int blade = (int) (rnd1(smp, RT_LENS_BLADE) * s->cam_aperture_blade_count);
+      const float alpha = sqrtf(r.x), beta = r.y;
+      const float u = 1.0f - alpha, v = alpha * beta;
+      const float astep = (2.0f * O_PI) / s->cam_aperture_blade_count;
+      float s1, c1, s2, c2;
+      o_sincos(astep * blade, &s1, &c1); o_sincos(astep * (blade + 1), &s2, &c2);
+      sx = (s1 * u + s2 * v) * asz; sy = (c1 * u + c2 * v) * asz;
+    }
+    else {
+      const float alpha = r.x * 2.0f * O_PI, beta = sqrtf(r.y) * asz;
+      float sa, ca; o_sincos(alpha, &sa, &ca);
+      sx = ca * beta; sy = sa * beta;
+    }
+    ap = v3(sx, sy, 0.0f);
+  }
+  const Quat q = {s->cam_rotation[0], s->cam_rotation[1], s->cam_rotation[2], s->cam_rotation[3]};
+  vec3 o = q_apply(q, ap);
+  o = v_scale(o, s->cam_scale * CAMERA_COMMON_SCALE);
+  o = v_add(o, v3(s->cam_pos[0], s->cam_pos[1], s->cam_pos[2]));
+  *origin = o;
+  *ray = q_apply(q, v_norm(v_sub(fp, ap)));
+}
+
+/* ---- geometry context (geometry_utils.cuh:13-221, untextured) ---- */
+static GeoCtx geometry_get_context(const OracleScene* s, vec3 hit_origin, vec3 task_ray, uint16_t state, uint32_t inst, uint32_t tri, uint32_t medium_ior) {
+  const uint32_t mesh = s->instance_mesh_ids[inst];
+  const OTransform tf = scene_transform(s, inst);
+  const OVertex a = scene_vertex(s, mesh, tri, 0), b = scene_vertex(s, mesh, tri, 1), c = scene_vertex(s, mesh, tri, 2);
+  const uint32_t* tt = scene_tritex(s, mesh, tri);
+  vec3 position = t_apply_inv(tf, hit_origin);
+  const vec3 ray = t_rot_inv(tf, task_ray);
+  const vec3 e1 = v_sub(b.pos, a.pos), e2 = v_sub(c.pos, a.pos);
+  vec3 face_normal = v_norm(v_cross(e1, e2));
+  const float2_t co = tri_coords(a.pos, e1, e2, position);
+  position = v_add(a.pos, v_add(v_scale(e1, co.x), v_scale(e2, co.y)));
+  position = t_apply(tf, position);
+  const OMaterial mat = scene_material(s, tt[3] & 0xFFFF);
+  const vec3 n0 = normal_unpack(a.normal), n1 = normal_unpack(b.normal), n2 = normal_unpack(c.normal);
+  const vec3 e1n = v_sub(n1, n0), e2n = v_sub(n2, n0);
+  /* geometry_compute_normal, geometry_utils.cuh:13-52 */
+  const bool is_inside = v_dot(face_normal, ray) > 0.0f;
+  if (is_inside) face_normal = v_scale(face_normal, -1.0f);
+  vec3 normal = lerp_normals(n0, e1n, e2n, co, face_normal);
+  normal = normal_adaptation_apply(v_scale(ray, -1.0f), normal, face_normal);
+
+  RGBAF albedo = mat.albedo;
+  const bool emissive_side = (!is_inside) || (mat.flags & DMAT_BIDIRECTIONAL_EMISSION);
+  const bool has_emission = (mat.flags & DMAT_EMISSION) && emissive_side;
+  const bool include_emission = has_emission && ((state & ST_ALLOW_EMISSION) != 0);
+  RGBF emission = c3(0.0f, 0.0f, 0.0f);
+  if (include_emission) emission = mat.emission;
+  float roughness = mat.roughness;
+  if (mat.flags & DMAT_ROUGHNESS_AS_SMOOTHNESS) roughness = 1.0f - roughness;
+  roughness = fmaxf(roughness, BSDF_ROUGHNESS_CLAMP);
+  if ((state & ST_DELTA_PATH) == 0) roughness = fmaxf(roughness, mat.roughness_clamp);
+  uint32_t flags = mat.flags & DMAT_SUBSTRATE_MASK;
+  if (mat.metallic_tex != TEXTURE_NONE) { /* stochastic metallic textures: not implemented in the reference either */ }
+  else if (mat.flags & DMAT_METALLIC) flags |= MAT_METALLIC;
+  if (mat.flags & DMAT_COLORED_TRANSPARENCY) flags |= MAT_COLORED_TRANSPARENCY;
+  if (is_inside) flags |= MAT_REFRACTION_IS_INSIDE;
+  const bool refr_inside = (flags & MAT_REFRACTION_IS_INSIDE) != 0;
+  const float other_ior = medium_ior_peek(medium_ior, refr_inside);
+  const float ior_in = refr_inside ? mat.refraction_index : other_ior;
+  const float ior_out = refr_inside ? other_ior : mat.refraction_index;
+  if (((flags & MAT_SUBSTRATE_MASK) == MAT_TRANSLUCENT) && (fabsf(1.0f - ior_in / ior_out) < 1e-4f)) {
+    if ((flags & MAT_COLORED_TRANSPARENCY) == 0) {
+      albedo.r = o_lerp(1.0f, albedo.r, albedo.a);
+      albedo.g = o_lerp(1.0f, albedo.g, albedo.a);
+      albedo.b = o_lerp(1.0f, albedo.b, albedo.a);
+    }
+    albedo.a = 0.0f;
+    flags |= MAT_COLORED_TRANSPARENCY;
+  }
+  GeoCtx g;
+  g.instance_id = inst; g.tri_id = tri;
+  g.normal = t_rot(tf, normal);
+  g.face_normal = normal_pack(face_normal);
+  g.position = position;
+  g.V = v_scale(task_ray, -1.0f);
+  g.state = state;
+  g.params.data[0] = g.params.data[1] = g.params.data[2] = 0;
+  g.params.flags = flags;
+  mp_set_albedo(&g.params, c3(albedo.r, albedo.g, albedo.b));
+  mp_set_opacity(&g.params, albedo.a);
+  mp_set_roughness(&g.params, roughness);
+  mp_set_emission(&g.params, emission);
+  mp_set_ior(&g.params, ior_in / ior_out);
+  return g;
+}
+
+static inline void beauty_add(RGBF* result, RGBF v) { if (c_any(v)) *result = c_add(*result, v); } /* memory.cuh:359-368 */
+
+/* directives.cuh:11-32 */
+static bool russian_roulette(const OracleScene* s, const Sampler* smp, uint16_t old_state, RGBF* record) {
+  if (old_state & ST_DELTA_PATH) return true;
+  const float value = c_importance(*record);
+  if (value < s->cam_rr_threshold) {
+    const float p = (value > 0.0f) ? fmaxf(value / s->cam_rr_threshold, RUSSIAN_ROULETTE_CLAMP) : 0.0f;
+    if (rnd1(smp, RT_RUSSIAN_ROULETTE) > p) return false;
+    *record = c_scale(*record, 1.0f / p);
+  }
+  return true;
+}
+
+static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
+  const OLuts luts = scene_luts(s);
+  const bool lights_present = s->light_tree_root != NULL && s->num_lights > 0;
+  Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
+  RGBF result = c_splat(0.0f);
+  vec3 origin, ray;
+  camera_sample(s, &smp, &origin, &ray);
+  uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
+  uint2_t record_p = record_pack(c_splat(1.0f));
+  uint32_t medium = medium_ior_modify(0, 1.0f, true); /* kernels.cuh:172-174 with bsdf_refraction_index_ambient == 1 */
+  uint32_t ign_inst = 0, ign_tri = 0;
+  const RGBF sky_color = (s->sky_mode == SKY_MODE_CONSTANT_COLOR) ? c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]) : c_splat(0.0f);
+
+  for (uint32_t depth = 0; depth <= s->max_ray_depth; depth++) {
+    smp.depth = (depth == s->max_ray_depth && depth > 0) ? depth - 1 : depth;
+    const OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
+    cnt[ORACLE_CNT_TRACE]++;
+    if (hit.instance_id == HIT_TYPE_SKY) {
+      if (state & ST_ALLOW_AMBIENT) beauty_add(&result, c_mul(sky_color, record_unpack(record_p)));
+      break;
+    }
+    cnt[ORACLE_CNT_VERTICES]++;
+    const vec3 hit_origin = v_add(origin, v_scale(ray, hit.t));
+    const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
+
+    /* ---- NEE task creation (geometry.cuh:31-74) ---- */
+    float root_sum = 0.0f;
+    LightSample ls; ls.light_id = LIGHT_ID_INVALID; ls.light_color = c_splat(0.0f); ls.ray = v3(0, 0, 0); ls.dist = 0.0f;
+    const bool geo_allowed = lights_present && ((state & ST_VOLUME_SCATTERED) == 0);
+    if (geo_allowed) { ls = light_sample(s, &g, &smp); root_sum = ls.root_sum; }
+    LightBSDFSample lb; lb.sampling_probability = 0.0f; lb.weight = c_splat(0.0f); lb.ray = v3(0, 0, 1);
+    const bool bsdf_allowed = geo_allowed;
+    if (bsdf_allowed) lb = light_bsdf_get_sample(&luts, &g, &smp);
+    const BSDFSample bounce = bsdf_sample(&luts, &g, &smp, 0);
+    const bool ambient_allowed = s->sky_mode != SKY_MODE_DEFAULT;
+    uint2_t amb_color = {0, 0}, amb_ray = {0, 0};
+    if (ambient_allowed) { /* direct_lighting.cuh:385-403 */
+      amb_color = record_pack(c_mul(sky_color, bounce.weight));
+      amb_ray = ray_pack(bounce.ray);
+    }
+
+    /* ---- delta-path classification (geometry.cuh:80-101) ---- */
+    const float roughness = mp_roughness(&g.params);
+    bool is_delta;
+    if (bounce.is_transparent_pass) {
+      const float ior = mp_ior(&g.params);
+      const float rs = (ior >= 1.0f) ? ior : 1.0f / ior;
+      is_delta = roughness * fminf(rs - 1.0f, 1.0f) <= GEOMETRY_DELTA_PATH_CUTOFF;
+    }
+    else is_delta = bounce.is_microfacet_based && (roughness <= GEOMETRY_DELTA_PATH_CUTOFF);
+    const bool pass_through = bsdf_is_pass_through_ray(&g, &bounce);
+
+    /* ---- emission and throughput (geometry.cuh:103-119) ---- */
+    const RGBF record_in = record_unpack(record_p);
+    RGBF record = record_in;
+    const RGBF emission = mp_emission(&g.params);
+    if (c_any(emission)) beauty_add(&result, c_mul(emission, record));
+    record = c_mul(record, bounce.weight);
+
+    /* ---- shadow pass for this vertex (optix_kernel_shadow.cu:15-100) ---- */
+    {
+      RGBF acc = c_splat(0.0f);
+      { /* direct_lighting.cuh:445-464 */
+        const bool valid = (ls.light_id != LIGHT_ID_INVALID) && geo_allowed;
+        RGBF vis = c_splat(0.0f);
+        if (valid) {
+          cnt[ORACLE_CNT_SHADOW]++;
+          vis = trace_shadow(tr, hit_origin, ls.ray, ls.dist, s->light_tri_handles[2 * ls.light_id], s->light_tri_handles[2 * ls.light_id + 1], hit.instance_id, hit.tri_id);
+        }
+        acc = c_add(acc, c_mul(ls.light_color, vis));
+      }
+      { /* direct_lighting.cuh:586-667 */
+        bool valid = bsdf_allowed && lb.sampling_probability != 0.0f;
+        uint32_t light_id = LIGHT_ID_INVALID, num_hits = 0;
+        if (valid) {
+          cnt[ORACLE_CNT_LIGHT_BVH]++;
+          light_id = trace_light_bvh(tr, hit_origin, lb.ray, hit.instance_id, hit.tri_id, rnd1(&smp, RT_LIGHT_BSDF_TRACE), &num_hits);
+        }
+        valid = valid && light_id != LIGHT_ID_INVALID;
+        float dist = FLT_MAX;
+        uint32_t lh_inst = 0xFFFFFFFFu, lh_tri = 0;
+        RGBF lc = c_splat(0.0f);
+        if (light_id != LIGHT_ID_INVALID) {
+          lh_inst = s->light_tri_handles[2 * light_id]; lh_tri = s->light_tri_handles[2 * light_id + 1];
+          uint32_t uvp[3];
+          TriLight tl = light_triangle_init(s, lh_inst, lh_tri, uvp);
+          if (light_triangle_finalize_dist(&tl, uvp, hit_origin, lb.ray, &dist)) {
+            lc = light_get_color(s, &tl);
+            const float mis = mis_weight_gi(hit_origin, &tl, lc, dist, lb.sampling_probability, root_sum);
+            lc = c_scale(lc, mis * num_hits);
+            lc = c_mul(lc, lb.weight);
+          }
+          else valid = false;
+        }
+        RGBF vis = c_splat(0.0f);
+        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, lb.ray, dist, lh_inst, lh_tri, hit.instance_id, hit.tri_id); }
+        acc = c_add(acc, c_mul(lc, vis));
+      }
+      /* sun: not allowed in constant-colour mode (direct_lighting.cuh:262) and out of scope otherwise -> contributes 0 */
+      { /* direct_lighting.cuh:521-584 */
+        const bool valid = (amb_color.x != 0 || amb_color.y != 0) && ambient_allowed;
+        const vec3 ar = ray_unpack(amb_ray);
+        RGBF vis = c_splat(0.0f);
+        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, ar, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, hit.tri_id); }
+        RGBF lc = c_mul(record_unpack(amb_color), vis);
+        if (!ambient_allowed) lc = c_splat(0.0f);
+        acc = c_add(acc, lc);
+      }
+      beauty_add(&result, c_mul(acc, record_in));
+    }
+
+    /* ---- bounce (geometry.cuh:121-176) ---- */
+    uint16_t new_state = state | ST_USE_IGNORE_HANDLE;
+    if (s->sky_mode != SKY_MODE_DEFAULT && !pass_through) new_state &= ~ST_ALLOW_AMBIENT;
+    else new_state |= ST_ALLOW_AMBIENT;
+    if (!is_delta) new_state &= ~ST_DELTA_PATH;
+    if (!pass_through) { new_state &= ~ST_CAMERA_DIRECTION; new_state &= ~ST_ALLOW_EMISSION; }
+    if (!russian_roulette(s, &smp, state, &record)) break;
+    record_p = record_pack(record);
+    if (bounce.is_transparent_pass) {
+      const bool refr_inside = (g.params.flags & MAT_REFRACTION_IS_INSIDE) != 0;
+      float new_ior = 1.0f;
+      if (!refr_inside) new_ior = medium_ior_peek(medium, refr_inside) / mp_ior(&g.params);
+      medium = medium_ior_modify(medium, new_ior, !refr_inside);
+    }
+    state = new_state;
+    origin = g.position;
+    ray = bounce.ray;
+    ign_inst = g.instance_id; ign_tri = g.tri_id;
+  }
+  return result;
+}
+
+int oracle_render(
+  const OracleScene* s, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples, int use_bvh, int threads,
+  float* first_moment, float* second_moment, uint64_t* counters) {
+  if (!s || !first_moment) return 1;
+  OTracer tr;
+  tracer_init(&tr, s, use_bvh);
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  uint64_t total[ORACLE_CNT_COUNT] = {0, 0, 0, 0};
+#pragma omp parallel
+  {
+    uint64_t cnt[ORACLE_CNT_COUNT] = {0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t) num_pixels; i++) {
+      const uint32_t index = pixels ? pixels[i] : (uint32_t) i;
+      const uint32_t y = index / s->width, x = index - y * s->width;
+      for (uint32_t k = 0; k < num_samples; k++) {
+        const uint32_t sample_id = first_sample + k;
+        if (sample_id >= MAX_GLOBAL_SAMPLES) continue;
+        const RGBF r = render_path(s, &tr, x, y, sample_id, cnt);
+        first_moment[i] += r.r;
+        first_moment[(size_t) num_pixels + i] += r.g;
+        first_moment[2 * (size_t) num_pixels + i] += r.b;
+        if (second_moment) second_moment[i] += c_luminance(c_mul(r, r));
+      }
+    }
+#pragma omp critical
+    for (int k = 0; k < ORACLE_CNT_COUNT; k++) total[k] += cnt[k];
+  }
+  if (counters) for (int k = 0; k < ORACLE_CNT_COUNT; k++) counters[k] += total[k];
+  tracer_free(&tr);
+  return 0;
+}
+
+int oracle_trace_closest(
+  const OracleScene* s, uint32_t num_rays, const float* origins, const float* dirs, const uint32_t* ignore_handles, int use_bvh, uint32_t* out_hits) {
+  OTracer tr;
+  tracer_init(&tr, s, use_bvh);
+#pragma omp parallel for schedule(dynamic, 256)
+  for (int64_t i = 0; i < (int64_t) num_rays; i++) {
+    const vec3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const bool ign = ignore_handles != NULL && ignore_handles[2 * i] != 0xFFFFFFFFu;
+    const OHit h = trace_closest(&tr, o, d, ign, ign ? ignore_handles[2 * i] : 0, ign ? ignore_handles[2 * i + 1] : 0);
+    out_hits[3 * i] = h.instance_id; out_hits[3 * i + 1] = h.tri_id; out_hits[3 * i + 2] = f2u(h.t);
+  }
+  tracer_free(&tr);
+  return 0;
+}
+
+/* ---- BSDF energy LUTs (bsdf_lut.cuh:20-211); pixel (0,0), depth 0, sample id = iteration ---- */
+#define LUT_ITER 0x10000u
+static uint16_t lut_quant(float sum) { return (uint16_t) (1 + (uint16_t) (ceilf(o_saturate(sum) * 0xFFFE))); }
+
+int oracle_generate_lut(const uint32_t* bn, int table, uint32_t first, uint32_t count, const uint16_t* conductor, uint16_t* dst) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int64_t k = 0; k < (int64_t) count; k++) {
+    const uint32_t id = first + (uint32_t) k;
+    uint32_t x, y, z = 0;
+    if (table < 2) { y = id / 32; x = id - y * 32; }
+    else { z = id / 1024; y = (id - z * 1024) / 32; x = id - y * 32 - z * 1024; }
+    const float NdotV = fmaxf(32.0f * O_EPS, x * (1.0f / 31));
+    const float roughness_in = y * (1.0f / 31);
+    /* the kernels pass the raw float roughness to the sampling functions, not the 10-bit quantised one */
+    const float roughness = roughness_in;
+    const vec3 V = v_norm(v3(0.0f, sqrtf(1.0f - NdotV * NdotV), NdotV));
+    Sampler smp = {bn, 0, 0, 0, 0};
+    float sum = 0.0f;
+    if (table == 0 || table == 1) {
+      const RGBF f0 = c3(0.04f, 0.04f, 0.04f);
+      for (uint32_t i = 0; i < LUT_ITER; i++) {
+        smp.sample_id = i;
+        const vec3 H = microfacet_sample_normal(V, roughness, rnd2(&smp, RT_BSDF_REFLECTION));
+        const vec3 R = v_reflect(V, H);
+        const float NdotL = R.z;
+        if (NdotL > 0.0f) {
+          float v = microfacet_eval_sampled_microfacet(V, roughness, NdotL, NdotV);
+          if (table == 1) v = v * c_luminance(bsdf_fresnel_schlick(f0, bsdf_shadowed_F90(f0), fabsf(v_dot(H, V))));
+          sum += v;
+        }
+      }
+      sum /= LUT_ITER;
+      if (table == 1) sum /= conductor[id] * (1.0f / 0xFFFF);
+    }
+    else {
+      const float ior_base = 1.0f + z * (1.0f / 31) * 2.0f;
+      const float ior = (table == 2) ? 1.0f / ior_base : ior_base;
+      for (uint32_t i = 0; i < LUT_ITER; i++) {
+        smp.sample_id = i;
+        bool tot;
+        vec3 H = microfacet_sample_normal(V, roughness, rnd2(&smp, RT_BSDF_REFLECTION));
+        vec3 R = v_reflect(V, H);
+        vec3 T = refract_vector(V, H, ior, &tot);
+        float fres = tot ? 1.0f : bsdf_fresnel(H, V, T, ior);
+        if (R.z > 0.0f) sum += microfacet_eval_sampled_microfacet(V, roughness, R.z, NdotV) * fres;
+        H = microfacet_refraction_sample_normal(V, roughness, rnd2(&smp, RT_BSDF_REFRACTION));
+        T = refract_vector(V, H, ior, &tot);
+        fres = tot ? ((table == 2) ? 1.0f : 0.0f) : bsdf_fresnel(H, V, T, ior);
+        const float HdotV = fabsf(v_dot(H, V));
+        const float NdotR = -T.z;
+        if (NdotR > 0.0f) {
+          const float r2 = roughness * roughness;
+          const float val = ggx_G2_over_G1(r2 * r2, NdotR, NdotV);
+          (void) HdotV;
+          sum += val * (1.0f - fres);
+        }
+      }
+      sum /= LUT_ITER;
+    }
+    dst[k] = lut_quant(sum);
+  }
+  return 0;
+}
+
+/* ---- unit-level entry points ---- */
+uint32_t oracle_squares32(uint32_t key, uint32_t counter) { return squares32(key, counter); }
+void oracle_sobol(uint32_t offset, uint32_t dimension, uint32_t out[2]) { const uint2_t r = rng_sobol(offset, dimension); out[0] = r.x; out[1] = r.y; }
+void oracle_random_2d(const uint32_t* bn, uint32_t target, uint32_t px, uint32_t py, uint32_t sample, uint32_t depth, uint32_t out[2]) {
+  const uint2_t r = rng_2d_u32(bn, target, px, py, sample, depth); out[0] = r.x; out[1] = r.y;
+}
+void oracle_record_roundtrip(const float in[3], uint32_t packed[2], float out[3]) {
+  const uint2_t p = record_pack(c3(in[0], in[1], in[2])); packed[0] = p.x; packed[1] = p.y;
+  const RGBF r = record_unpack(p); out[0] = r.r; out[1] = r.g; out[2] = r.b;
+}
+void oracle_ray_roundtrip(const float in[3], uint32_t packed[2], float out[3]) {
+  const uint2_t p = ray_pack(v3(in[0], in[1], in[2])); packed[0] = p.x; packed[1] = p.y;
+  const vec3 r = ray_unpack(p); out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+uint32_t oracle_normal_pack(const float in[3]) { return normal_pack(v3(in[0], in[1], in[2])); }
+void oracle_normal_unpack(uint32_t packed, float out[3]) { const vec3 n = normal_unpack(packed); out[0] = n.x; out[1] = n.y; out[2] = n.z; }
+void oracle_sincos(float x, float out[2]) { o_sincos(x, &out[0], &out[1]); }
+float oracle_atan2(float y, float x) { return o_atan2(y, x); }
+void oracle_camera_ray(const OracleScene* s, uint32_t x, uint32_t y, uint32_t sample_id, float out[6]) {
+  Sampler smp = {s->bluenoise_2d, x, y, sample_id, 0};
+  vec3 o, d; camera_sample(s, &smp, &o, &d);
+  out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z;
+}
+uint32_t oracle_scene_sizeof(void) { return (uint32_t) sizeof(OracleScene); }
