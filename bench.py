@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X path-tracing core on BASELINE.json's metric (Mrays/s at 1920x1080, 8 bounces).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+
+Step   = one sample per pixel (1 spp) of the workload over the whole 1920x1080 frame, all 9 depth passes (8 bounces).
+Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
+N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
+         rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+NODE_BYTES, TRI_BYTES = 128, 48  # BVH4 node = 128 B, triangle = 48 B (DESIGN.md "Algorithmic bytes")
+IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
+
+
+def tile_pixels(width, height, rank, world, tile=32):
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    ids = np.arange(tx * ty)
+    mine = ids[ids % world == rank]
+    ys, xs = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
+    px = (mine % tx)[:, None, None] * tile + xs[None]
+    py = (mine // tx)[:, None, None] * tile + ys[None]
+    ok = (px < width) & (py < height)
+    return (px + py * width)[ok].astype(np.uint32)
+
+
+def build_workload(name, width, height, bounces):
+    from luminary_amd import scenes
+    if name == "example":
+        return scenes.example_scene(width, height, bounces), "C2 Example-class scene (~100k triangles, 72 instances, 16 emissive quads)"
+    if name == "hall":
+        return scenes.hall_scene(width, height, bounces), "C3 Sponza-class hall (1M triangles, one mesh, 32 emissive panels)"
+    if name == "cornell":
+        return scenes.cornell_host("/tmp/lum_bench_cornell", width, height, bounces), "C1 Cornell box (36 triangles)"
+    raise SystemExit("unknown workload " + name)
+
+
+def cpu_baseline(view, budget_s):
+    """Times the oracle (CPU restatement, OpenMP over pixels) on a bounded sample of the same workload: a strided pixel subset at 1 spp."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    lib = oracle_lib.lib()
+    del lib
+    import ctypes as C
+    cores = os.cpu_count() or 1
+    # the energy tables the oracle reads come from the committed fixture (they do not influence the ray counts)
+    v = oracle_lib.with_luts(view)
+    n_total = view.width * view.height
+    stride = 257
+    best = None
+    spent = 0.0
+    while True:
+        pixels = np.arange(0, n_total, stride, dtype=np.uint32)
+        t0 = time.time()
+        _, _, cnt = oracle_lib.render(v, 0, 1, pixels=pixels, use_bvh=True, threads=cores)
+        dt = time.time() - t0
+        spent += dt
+        rays = float(cnt[0] + cnt[1] + cnt[2])
+        best = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+                "sample": "oracle (oracle/, OpenMP over pixels) on every %d-th pixel (%d pixels) of the same frame, 1 spp, all 9 depth passes, %.1f s; "
+                          "includes its BVH build" % (stride, pixels.size, dt)}
+        if dt > 0.35 * budget_s or stride <= 5 or spent > budget_s:
+            break
+        stride = max(5, int(stride * dt / (0.6 * budget_s)) | 1)
+    return best
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="example")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--samples-per-pass", type=int, default=1)
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from luminary_amd.core import Core, CNT_LIGHT_BVH, CNT_NODES, CNT_SHADOW, CNT_TRACE, CNT_TRIS
+    host, workload_name = build_workload(args.workload, args.width, args.height, args.bounces)
+    view = host.device_scene()
+    core = Core(local_rank)
+    t_up = time.time()
+    core.upload(view)  # builds the BVHs, generates the BSDF tables on the GPU
+    upload_s = time.time() - t_up
+    pixels = tile_pixels(view.width, view.height, rank, world) if world > 1 else None
+    core.set_pixels(pixels)
+    P = core.num_pixels
+    fm = torch.zeros(3 * P, dtype=torch.float32, device="cuda")
+    sm = torch.zeros(P, dtype=torch.float32, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        core.render(i * args.samples_per_pass, args.samples_per_pass, args.samples_per_pass, fm.data_ptr(), sm.data_ptr(), stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    core.synchronize()
+    core.reset_counters()
+    core.set_profiling(True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    if dist is not None:
+        # assemble the frame on rank 0: every rank scatters its pixels into a zero frame, one reduce over xGMI
+        full = torch.zeros(4, view.width * view.height, dtype=torch.float32, device="cuda")
+        idx = torch.from_numpy(pixels.astype(np.int64)).cuda()
+        full[0:3].index_copy_(1, idx, fm.view(3, P))
+        full[3].index_copy_(0, idx, sm)
+        dist.reduce(full, dst=0, op=dist.ReduceOp.SUM)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.time() - t0
+
+    cnt = core.counters()
+    times = core.kernel_times()
+    rays_local = cnt[CNT_TRACE] + cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]
+    stats = torch.tensor([float(rays_local), float(cnt[CNT_TRACE]), float(cnt[CNT_SHADOW]), float(cnt[CNT_LIGHT_BVH]), elapsed], dtype=torch.float64,
+                         device="cuda")
+    if dist is not None:
+        mx = stats.clone()
+        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        elapsed = float(mx[4])
+    rays_total = float(stats[0])
+    if rank != 0:
+        return
+
+    # roofline of the dominant traversal kernel on rank 0: algorithmic bytes = nodes*128 + triangles*48 + per-ray I/O
+    trace_ms, trace_n = times["trace"]
+    shadow_ms, shadow_n = times["shadow"]
+    nodes_trace, tris_trace, nodes_shadow, tris_shadow = cnt[CNT_NODES], cnt[CNT_TRIS], cnt[6], cnt[7]
+    bytes_trace = nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES
+    bytes_shadow = nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + (cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]) * (24 + 4 + 12)
+    dominant = "trace" if trace_ms >= shadow_ms else "shadow"
+    dom_bytes, dom_ms, dom_n = (bytes_trace, trace_ms, trace_n) if dominant == "trace" else (bytes_shadow, shadow_ms, shadow_n)
+    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
+                "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1)}
+    cpu = cpu_baseline(view, args.cpu_budget) if args.cpu_budget > 0 else None
+    out = {
+        "metric": "Mrays/s at 1920x1080, 8 bounces", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": workload_name, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth,
+                   "spp_per_step": args.samples_per_pass, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
+                   "samples_per_s": view.width * view.height * args.samples_per_pass * args.steps / elapsed,
+                   "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
+                   "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()}, "scene_upload_s": round(upload_s, 2)},
+        "roofline": roofline, "cpu_baseline": cpu,
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

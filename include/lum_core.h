@@ -1,0 +1,109 @@
+/*
+ * lum_core.h - C ABI of the MI355X path-tracing core (libluminary_amd.so), hot path only.
+ *
+ * This is the boundary a host layer binds to (cgo / ctypes / plain C). Plain pointers and sizes, no C++ or torch types.
+ * It replaces, for the triangle/BSDF/NEE path, the `device_*` surface the reference's device manager drives
+ * (/root/reference paths):
+ *   lumc_context_create/destroy     src/luminary/device/device.c:520-640 (device_create), :1700-1787 (device_destroy)
+ *   lumc_scene_upload               device/device_manager.c:281-513 (scene -> device sync), device/device_mesh.c:19-51,
+ *                                   device/optix_bvh.c:150-684 (acceleration structures, rebuilt here as BVH4),
+ *                                   device/device_light.c:2363-2428 (light tree upload), device/device_bsdf.c:64-130 (LUTs)
+ *   lumc_set_pixels                 replaces the sample partition of device/device_result_interface.c:107-175 by an
+ *                                   image partition: each process renders the pixels it is given
+ *   lumc_render                     device/device_renderer.c:488-575 (device_renderer_continue: the per-sample kernel queue)
+ *   lumc_download_accumulators      device/device_result_interface.c:154-162 (download of the four moment planes)
+ *   lumc_counters                   no reference equivalent (the reference does not count rays)
+ * Every function returns 0 on success; on failure a message is available from lumc_last_error().
+ */
+#ifndef LUM_CORE_H
+#define LUM_CORE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct LumContext LumContext;
+
+/*
+ * Scene in the device format of the reference (what its kernels read). All pointers are HOST pointers; the library
+ * copies what it needs. Layout is shared with the test oracle (oracle/oracle.h, checked by tests/test_layouts.py).
+ */
+typedef struct LumDeviceSceneView {
+  uint32_t num_meshes;
+  uint32_t num_instances;
+  uint32_t num_materials;
+  uint32_t num_lights;
+  const uint32_t* mesh_tri_offset;    /* num_meshes + 1 */
+  const float* vertices;              /* 3 per triangle, 16 B each (device_structs.h:270-273) */
+  const uint32_t* tri_tex;            /* 16 B per triangle (device_structs.h:275-281) */
+  const uint32_t* instance_mesh_ids;  /* num_instances */
+  const float* instance_transforms;   /* 32 B each (device_structs.h:295-300) */
+  const uint16_t* materials;          /* 32 B each (device_structs.h:202-223) */
+  const uint8_t* light_tree_root;     /* device_utils.h:304-327; NULL without lights */
+  const uint8_t* light_tree_nodes;    /* device_utils.h:283-302 */
+  const uint32_t* light_tri_handles;  /* 2 per light */
+  const float* light_bvh_tris;        /* 12 floats per light (device_light.h LightTreeBVHTriangle) */
+  uint32_t num_light_tree_nodes;
+  uint32_t pad0;
+  const uint32_t* bluenoise_2d;       /* 65536 texels */
+  const uint16_t* lut_conductor;      /* 4 BSDF energy tables; pass NULL to have the library generate them on the GPU */
+  const uint16_t* lut_glossy;
+  const uint16_t* lut_dielectric;
+  const uint16_t* lut_dielectric_inv;
+  uint32_t width, height, max_ray_depth, shading_mode;
+  float cam_pos[3];
+  float cam_rotation[4];
+  float cam_fov, cam_aperture_size, cam_object_distance, cam_scale, cam_rr_threshold;
+  uint32_t cam_aperture_shape, cam_aperture_blade_count;
+  uint32_t sky_mode;
+  float sky_constant_color[3];
+} LumDeviceSceneView;
+
+enum { LUMC_CNT_TRACE = 0, LUMC_CNT_SHADOW = 1, LUMC_CNT_LIGHT_BVH = 2, LUMC_CNT_VERTICES = 3, LUMC_CNT_NODES = 4, LUMC_CNT_TRIS = 5, LUMC_CNT_NODES_SHADOW = 6, LUMC_CNT_TRIS_SHADOW = 7, LUMC_CNT_COUNT = 8 };
+enum { LUMC_KERNEL_GENERATE = 0, LUMC_KERNEL_TRACE = 1, LUMC_KERNEL_SHADE = 2, LUMC_KERNEL_SHADOW = 3, LUMC_KERNEL_ACCUMULATE = 4, LUMC_KERNEL_COUNT = 5 };
+
+int lumc_context_create(int device_ordinal, LumContext** out);
+void lumc_context_destroy(LumContext* ctx);
+const char* lumc_last_error(const LumContext* ctx);
+
+int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* scene);
+/* Copies the four energy tables (1024, 1024, 32768, 32768 u16) the context renders with to host memory. */
+int lumc_download_luts(LumContext* ctx, uint16_t* conductor, uint16_t* glossy, uint16_t* dielectric, uint16_t* dielectric_inv);
+
+/* Pixels (x + y*width) this context renders; NULL = the whole frame. (Re)allocates and zeroes internal accumulators. */
+int lumc_set_pixels(LumContext* ctx, const uint32_t* pixels, uint32_t num_pixels);
+
+/*
+ * Renders sample ids [first_sample, first_sample + num_samples) of the context's pixels, `samples_per_pass` sample ids per
+ * wavefront pass, and adds them into planar accumulators (first moment [R|G|B], second moment of the luminance).
+ * d_first_moment/d_second_moment are DEVICE pointers owned by the caller (3*num_pixels and num_pixels floats) or NULL to use
+ * the context's own. `stream` is a hipStream_t (NULL = default stream). Asynchronous: returns after enqueueing.
+ */
+int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, uint32_t samples_per_pass, float* d_first_moment, float* d_second_moment,
+                void* stream);
+int lumc_synchronize(LumContext* ctx);
+int lumc_clear_accumulators(LumContext* ctx);
+int lumc_download_accumulators(LumContext* ctx, float* first_moment, float* second_moment);
+
+int lumc_counters(LumContext* ctx, uint64_t out[LUMC_CNT_COUNT]);
+int lumc_reset_counters(LumContext* ctx);
+/* With profiling on, every kernel launch of lumc_render is bracketed by HIP events on its own stream. */
+int lumc_set_profiling(LumContext* ctx, int enabled);
+int lumc_kernel_times(LumContext* ctx, double total_ms[LUMC_KERNEL_COUNT], uint32_t launches[LUMC_KERNEL_COUNT]);
+
+/* Closest-hit query on device buffers (float3 origins/dirs, optional uint2 ignore handles, uint3 out: instance, triangle, t bits). */
+int lumc_trace_closest(LumContext* ctx, uint32_t num_rays, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream);
+/* Same with host buffers (copies in and out); used by the parity tests. */
+int lumc_trace_closest_host(LumContext* ctx, uint32_t num_rays, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out);
+
+/* Sizes of the acceleration structures built by lumc_scene_upload: out[0] BLAS nodes, [1] BLAS triangles, [2] TLAS nodes, [3] light nodes. */
+int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]);
+uint32_t lumc_scene_view_sizeof(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

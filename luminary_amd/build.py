@@ -1,0 +1,74 @@
+"""Builds libluminary_amd.so (HIP kernels for gfx950 + C-ABI host layer) in-tree.
+
+Usage: python -m luminary_amd.build [--force]
+Host C++ is compiled with g++, the kernels with hipcc --offload-arch=gfx950, everything is linked by hipcc.
+-ffp-contract=off is part of the numerics contract (DESIGN.md "Determinism").
+"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(ROOT, "csrc")
+LIB_DIR = os.path.join(ROOT, "lib")
+LIB = os.path.join(LIB_DIR, "libluminary_amd.so")
+OBJ_DIR = os.path.join(ROOT, "lib", "obj")
+ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
+HIPCC = os.path.join(ROCM, "bin", "hipcc")
+
+HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp"]
+HIP_SOURCES = ["host/core.hip"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _all_sources():
+    out = []
+    for d, _, files in os.walk(CSRC):
+        out += [os.path.join(d, f) for f in files]
+    out.append(os.path.join(ROOT, "..", "include", "lum_core.h"))
+    out.append(os.path.join(ROOT, "..", "include", "luminary_amd.h"))
+    out.append(os.path.abspath(__file__))
+    return out
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build step failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def build(force=False, verbose=False):
+    if not force and not _newer(LIB, _all_sources()):
+        return LIB
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for s in HOST_SOURCES:
+        o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
+        _run(["g++", *COMMON, "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, s), "-o", o])
+        objs.append(o)
+    bn = os.path.join(ROOT, "data", "bluenoise_2D.bin")
+    o = os.path.join(OBJ_DIR, "embed.o")
+    _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, os.path.join(CSRC, "host", "embed.S"), "-o", o])
+    objs.append(o)
+    for s in HIP_SOURCES:
+        o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
+        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
+        with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w") as f:
+            f.write(out)
+        if verbose:
+            print(out)
+        objs.append(o)
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

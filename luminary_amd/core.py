@@ -1,0 +1,126 @@
+"""ctypes binding of the low-level core C ABI (include/lum_core.h): context, scene upload, wavefront passes, counters."""
+import ctypes as C
+
+import numpy as np
+
+from . import DeviceSceneView, _lib
+
+CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS = 0, 1, 2, 3, 4, 5
+KERNELS = ("generate", "trace", "shade", "shadow", "accumulate")
+
+
+class CoreError(RuntimeError):
+    pass
+
+
+class Core:
+    def __init__(self, device=0):
+        self._lib = _lib()
+        self._ctx = C.c_void_p()
+        self._lib.lumc_context_create.restype = C.c_int
+        rc = self._lib.lumc_context_create(C.c_int(device), C.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.lumc_last_error(self._ctx).decode() if self._ctx else "context allocation failed"
+            if self._ctx:
+                self._lib.lumc_context_destroy(self._ctx)
+                self._ctx = C.c_void_p()
+            raise CoreError("lumc_context_create failed (no CPU fallback exists): " + msg)
+        self.num_pixels = 0
+
+    def _call(self, name, *args):
+        fn = getattr(self._lib, name)
+        fn.restype = C.c_int
+        if fn(self._ctx, *args) != 0:
+            raise CoreError("%s failed: %s" % (name, self._lib.lumc_last_error(self._ctx).decode()))
+
+    def close(self):
+        if self._ctx:
+            self._lib.lumc_context_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, view):
+        self._view_keepalive = view
+        self._call("lumc_scene_upload", C.byref(view))
+        self.width, self.height = view.width, view.height
+
+    def download_luts(self):
+        out = {"conductor": np.zeros(1024, np.uint16), "glossy": np.zeros(1024, np.uint16), "dielectric": np.zeros(32768, np.uint16),
+               "dielectric_inv": np.zeros(32768, np.uint16)}
+        self._call("lumc_download_luts", *[out[k].ctypes.data_as(C.c_void_p) for k in ("conductor", "glossy", "dielectric", "dielectric_inv")])
+        return out
+
+    def set_pixels(self, pixels=None):
+        if pixels is None:
+            self._call("lumc_set_pixels", C.c_void_p(0), C.c_uint32(0))
+            self.num_pixels = self.width * self.height
+        else:
+            px = np.ascontiguousarray(pixels, dtype=np.uint32)
+            self._call("lumc_set_pixels", px.ctypes.data_as(C.c_void_p), C.c_uint32(px.size))
+            self.num_pixels = int(px.size)
+
+    def render(self, first_sample, num_samples, samples_per_pass=1, first_moment_ptr=0, second_moment_ptr=0, stream=0):
+        self._call("lumc_render", C.c_uint32(first_sample), C.c_uint32(num_samples), C.c_uint32(samples_per_pass), C.c_void_p(first_moment_ptr),
+                   C.c_void_p(second_moment_ptr), C.c_void_p(stream))
+
+    def synchronize(self):
+        self._call("lumc_synchronize")
+
+    def clear(self):
+        self._call("lumc_clear_accumulators")
+
+    def accumulators(self):
+        fm = np.zeros(3 * self.num_pixels, dtype=np.float32)
+        sm = np.zeros(self.num_pixels, dtype=np.float32)
+        self._call("lumc_download_accumulators", fm.ctypes.data_as(C.c_void_p), sm.ctypes.data_as(C.c_void_p))
+        return fm.reshape(3, -1), sm
+
+    def counters(self):
+        out = (C.c_uint64 * 8)()
+        self._call("lumc_counters", out)
+        return [int(x) for x in out]
+
+    def reset_counters(self):
+        self._call("lumc_reset_counters")
+
+    def set_profiling(self, on):
+        self._call("lumc_set_profiling", C.c_int(1 if on else 0))
+
+    def kernel_times(self):
+        ms = (C.c_double * 5)()
+        n = (C.c_uint32 * 5)()
+        self._call("lumc_kernel_times", ms, n)
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNELS)}
+
+    def bvh_stats(self):
+        out = (C.c_uint64 * 4)()
+        self._call("lumc_bvh_stats", out)
+        return [int(x) for x in out]
+
+    def trace_closest_host(self, origins, dirs, ignore=None):
+        origins = np.ascontiguousarray(origins, dtype=np.float32)
+        dirs = np.ascontiguousarray(dirs, dtype=np.float32)
+        n = origins.shape[0]
+        out = np.zeros((n, 3), dtype=np.uint32)
+        ip = C.c_void_p(0)
+        if ignore is not None:
+            ignore = np.ascontiguousarray(ignore, dtype=np.uint32)
+            ip = ignore.ctypes.data_as(C.c_void_p)
+        self._call("lumc_trace_closest_host", C.c_uint32(n), origins.ctypes.data_as(C.c_void_p), dirs.ctypes.data_as(C.c_void_p), ip,
+                   out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def trace_closest_device(self, n, origins_ptr, dirs_ptr, ignore_ptr, out_ptr, stream=0):
+        self._call("lumc_trace_closest", C.c_uint32(n), C.c_void_p(origins_ptr), C.c_void_p(dirs_ptr), C.c_void_p(ignore_ptr), C.c_void_p(out_ptr),
+                   C.c_void_p(stream))
+
+
+def scene_view_sizeof():
+    fn = _lib().lumc_scene_view_sizeof
+    fn.restype = C.c_uint32
+    return fn()

@@ -1,0 +1,68 @@
+// Sampler: Owen-scrambled Sobol points + R2-shifted blue-noise mask, keyed by the Squares counter RNG.
+// Integer-exact restatement of src/luminary/device/cuda/random.cuh (:24-66 target table, :172-194 Squares,
+// :232-287 Sobol/Owen, :309-368 blue noise + wrappers) and cuda/utils.cuh:147-178 (PathID is kept unpacked here).
+#pragma once
+
+#include "dev_math.h"
+
+namespace lum {
+
+// random.cuh:24-66 - every allocation skips one slot: START_next = START + count * sets + 1.
+enum RandomTarget : uint32_t {
+  kRndLens = 33, kRndLensBlade = 35,
+  kRndBsdfReflection = 39, kRndBsdfDiffuse = 43, kRndBsdfRefraction = 47, kRndBsdfResampling = 51, kRndBsdfOpacity = 55,
+  kRndRussianRoulette = 61, kRndCameraJitter = 63,
+  kRndLightGeoRay = 367, kRndLightGeoResampling = 384, kRndLightTreePrepass = 387, kRndLightTreePostpass = 404,
+  kRndLightBsdfChoice = 569, kRndLightBsdfDirection = 571, kRndLightBsdfTrace = 573, kRndLightBsdfRR = 575,
+  kRndTargetCount = 577
+};
+constexpr uint32_t kMaxGlobalSamples = 1u << 20;  // device_utils.h:37-39
+
+LUM_DEV uint32_t swap_halves(uint32_t a) { return (a >> 16) | (a << 16); }
+
+LUM_DEV uint32_t squares32(uint32_t key, uint32_t counter) {
+  uint32_t x = counter * key, y = counter * key, z = y + key;
+  x = x * x + y; x = swap_halves(x);
+  x = x * x + z; x = swap_halves(x);
+  x = x * x + y; x = swap_halves(x);
+  x = x * x + z; z = x; x = swap_halves(x);
+  return z ^ (x * x + y);
+}
+LUM_DEV uint32_t laine_karras(uint32_t x, uint32_t seed) {
+  x += seed;
+  x ^= x * 0x6c50b47cu; x ^= x * 0xb82f1e52u; x ^= x * 0xc7afe638u; x ^= x * 0x8d22f6e6u;
+  return x;
+}
+LUM_DEV uint32_t owen_scramble(uint32_t x, uint32_t seed) { return __brev(laine_karras(__brev(x), seed)); }
+LUM_DEV uint32_t hash_combine(uint32_t seed, uint32_t v) { return seed ^ (v + (seed << 6) + (seed >> 2)); }
+LUM_DEV uint32_t sobol_second_dim(uint32_t v) {
+  v ^= v << 16; v ^= (v & 0x00FF00FFu) << 8; v ^= (v & 0x0F0F0F0Fu) << 4; v ^= (v & 0x33333333u) << 2; v ^= (v & 0x55555555u) << 1;
+  return v;
+}
+LUM_DEV U2 sobol_owen(uint32_t index, uint32_t dimension) {
+  const uint32_t seed = squares32(0xfcbd6e15u, dimension);
+  const uint32_t j    = laine_karras(__brev(index), seed);
+  return U2{owen_scramble(j, hash_combine(seed, 0)), owen_scramble(sobol_second_dim(j), hash_combine(seed, 1))};
+}
+LUM_DEV float unit_float(uint32_t v) { return bitsf(0x3F800000u | (v >> 9)) - 1.0f; }
+LUM_DEV float clamp_random(float r) { return fminf(fmaxf(r, 0.0f), bitsf(0x3F7FFFFFu)); }
+
+struct Sampler {
+  const uint32_t* bluenoise;
+  uint32_t px, py, sample_id, depth;
+
+  LUM_DEV U2 raw2(uint32_t target) const { return raw2_at(target, px, py, depth); }
+  LUM_DEV U2 raw2_at(uint32_t target, uint32_t x, uint32_t y, uint32_t d) const {
+    const uint32_t dim = target + d * kRndTargetCount;
+    U2 q = sobol_owen(sample_id, dim);
+    const uint32_t ox = (1u + dim) * 3242174889u, oy = (1u + dim) * 2447445413u;
+    const uint32_t texel = bluenoise[((x + (ox >> 24)) & 0xFFu) + ((y + (oy >> 24)) & 0xFFu) * 256u];
+    q.x += texel & 0xFFFF0000u;
+    q.y += texel << 16;
+    return q;
+  }
+  LUM_DEV F2 next2(uint32_t target) const { const U2 q = raw2(target); return F2{unit_float(q.x), unit_float(q.y)}; }
+  LUM_DEV float next1(uint32_t target) const { return unit_float(raw2(target).x); }
+};
+
+}  // namespace lum

@@ -1,0 +1,193 @@
+// Software ray queries on the two-level BVH4 that replaces the reference's OptiX acceleration structures.
+// Semantics restated from the reference's OptiX programs:
+//   closest hit  optix/optix_kernel_raytrace.cu:82-95, cuda/optix_anyhit.cuh:15-31, cuda/optix_closesthit.cuh:15-26
+//   shadow       cuda/optix_common.cuh:76-106, cuda/optix_anyhit.cuh:49-139, cuda/optix_closesthit.cuh:44-58
+//   light query  cuda/optix_anyhit.cuh:145-205 (reservoir over all lights hit), cuda/direct_lighting.cuh:596-611
+// Triangle test: cuda/math.cuh:1337-1358 on the object-space ray (instance transform world = S*R*v + T, math.cuh:459-489),
+// so hit distances are the same numbers in world and object space.
+// Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
+// the candidate set only (see light_query).
+#pragma once
+
+#include "dev_light.h"
+
+namespace lum {
+
+constexpr uint32_t kHitSky = 0xFFFFFFFEu;  // cuda/utils.cuh:50-64
+constexpr int kStackSize   = 64;  // the host builder caps the BVH4 depth at 20 levels (<= 3 pushes per level)
+
+struct RayStats { uint32_t nodes, tris; };
+
+LUM_DEV float safe_inv(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d; }
+
+// Slab test of the four children of a node; returns a 4-bit mask and entry distances. Boxes are padded by the builder
+// and the comparison is relaxed by 2 ulp so that a triangle accepted by the exact test is never culled.
+LUM_DEV uint32_t test_children(const Bvh4Node& n, V3 o, V3 inv, float tmax, float tnear[4]) {
+  uint32_t mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float ax = (n.lo_x[k] - o.x) * inv.x, bx = (n.hi_x[k] - o.x) * inv.x;
+    const float ay = (n.lo_y[k] - o.y) * inv.y, by = (n.hi_y[k] - o.y) * inv.y;
+    const float az = (n.lo_z[k] - o.z) * inv.z, bz = (n.hi_z[k] - o.z) * inv.z;
+    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear[k] = t0;
+    if (n.child[k] != kBvhEmpty && t0 <= t1 * 1.0000005f + 1e-30f) mask |= 1u << k;
+  }
+  return mask;
+}
+
+// Generic stack traversal. `on_leaf(first, count, tmax)` may shrink tmax and returns true to stop the whole query.
+template <typename LeafFn>
+LUM_DEV bool traverse_bvh4(const Bvh4Node* __restrict__ nodes, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
+  const V3 inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
+  uint32_t stack[kStackSize];
+  int sp = 0;
+  uint32_t cur = 0;
+  while (true) {
+    if (cur & kBvhLeafBit) {
+      if (on_leaf(cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, tmax)) return true;
+    }
+    else {
+      const Bvh4Node& n = nodes[cur];
+      st.nodes++;
+      float tn[4];
+      uint32_t mask = test_children(n, o, inv, tmax, tn);
+      // push far children first so the nearest is visited next (selection by repeated min; at most 4 entries)
+      uint32_t next = kBvhEmpty;
+      float next_t = kFltMax;
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        if ((mask >> k) & 1u) { if (tn[k] < next_t) { next_t = tn[k]; next = k; } }
+      if (next != kBvhEmpty) {
+        mask &= ~(1u << next);
+        // remaining children: farthest pushed first
+        while (mask) {
+          int far = -1; float ft = -1.0f;
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (((mask >> k) & 1u) && tn[k] >= ft) { ft = tn[k]; far = k; }
+          mask &= ~(1u << far);
+          if (sp < kStackSize) stack[sp++] = n.child[far];
+        }
+        cur = n.child[next];
+        continue;
+      }
+    }
+    if (sp == 0) return false;
+    cur = stack[--sp];
+  }
+}
+
+struct Hit { uint32_t instance_id, tri_id; float t; };
+
+LUM_DEV V3 tri_p0(const BvhTri& t) { return v3(t.p0[0], t.p0[1], t.p0[2]); }
+LUM_DEV V3 tri_e1(const BvhTri& t) { return v3(t.e1[0], t.e1[1], t.e1[2]); }
+LUM_DEV V3 tri_e2(const BvhTri& t) { return v3(t.e2[0], t.e2[1], t.e2[2]); }
+
+// Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
+LUM_DEV Hit closest_hit(const DeviceScene& sc, V3 origin, V3 dir, bool use_ignore, uint32_t ign_inst, uint32_t ign_tri, RayStats& st) {
+  Hit best{kHitSky, 0u, kFltMax};
+  float tmax = kFltMax;
+  traverse_bvh4(sc.tlas_nodes, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float&) {
+    for (uint32_t k = 0; k < count; k++) {
+      const uint32_t inst = sc.tlas_prims[first + k];
+      const uint32_t mesh = sc.instance_mesh_ids[inst];
+      const Transform tf  = load_transform(sc, inst);
+      const V3 o = xf_point_inv(tf, origin), d = xf_rel_inv(tf, dir);
+      const BvhTri* __restrict__ tris = sc.blas_tris + sc.mesh_bvhtri_offset[mesh];
+      traverse_bvh4(sc.blas_nodes + sc.mesh_node_offset[mesh], o, d, tmax, st, [&](uint32_t f2, uint32_t c2, float& tm) {
+        for (uint32_t j = 0; j < c2; j++) {
+          const BvhTri tr = tris[f2 + j];
+          st.tris++;
+          if (use_ignore && inst == ign_inst && tr.id == ign_tri) continue;
+          F2 uv;
+          const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), o, d, uv);
+          if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && tr.id < best.tri_id)))) {
+            best.instance_id = inst; best.tri_id = tr.id; best.t = t; tm = t;
+          }
+        }
+        return false;
+      });
+    }
+    return false;
+  });
+  if (best.t == kFltMax) { best.instance_id = kHitSky; best.tri_id = 0; }
+  return best;
+}
+
+// Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light
+// (`target`) and the surface being shaded (`self`).
+LUM_DEV Col shadow_query(const DeviceScene& sc, V3 origin, V3 dir, float dist, uint32_t tgt_inst, uint32_t tgt_tri, uint32_t self_inst,
+                         uint32_t self_tri, RayStats& st) {
+  Col through = splat(1.0f);
+  float tmax = dist;
+  const bool blocked = traverse_bvh4(sc.tlas_nodes, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float&) {
+    for (uint32_t k = 0; k < count; k++) {
+      const uint32_t inst = sc.tlas_prims[first + k];
+      const uint32_t mesh = sc.instance_mesh_ids[inst];
+      const Transform tf  = load_transform(sc, inst);
+      const V3 o = xf_point_inv(tf, origin), d = xf_rel_inv(tf, dir);
+      const BvhTri* __restrict__ tris = sc.blas_tris + sc.mesh_bvhtri_offset[mesh];
+      const uint32_t tri_base = sc.mesh_tri_offset[mesh];
+      const bool stop = traverse_bvh4(sc.blas_nodes + sc.mesh_node_offset[mesh], o, d, tmax, st, [&](uint32_t f2, uint32_t c2, float&) {
+        for (uint32_t j = 0; j < c2; j++) {
+          const BvhTri tr = tris[f2 + j];
+          st.tris++;
+          if ((inst == tgt_inst && tr.id == tgt_tri) || (inst == self_inst && tr.id == self_tri)) continue;
+          F2 uv;
+          const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), o, d, uv);
+          if (!(t > kEps && t < dist)) continue;
+          const Material m = load_material(sc, sc.tri_tex[tri_base + tr.id].w & 0xFFFFu);
+          const bool colored = (m.flags & kDMatColoredTransparency) != 0;
+          if (m.alpha == 1.0f) return true;
+          if (m.alpha == 0.0f && !colored) continue;
+          const float tp = 1.0f - m.alpha;
+          through = through * (colored ? m.albedo * tp : splat(tp));
+        }
+        return false;
+      });
+      if (stop) return true;
+    }
+    return false;
+  });
+  return blocked ? splat(0.0f) : through;
+}
+
+// Light-BVH query on (eps, FLT_MAX). OptiX leaves the any-hit order unspecified, so the reference's reservoir is restated
+// order-independently: pass 0 finds t* = nearest opaque light; pass 1 counts the lights with eps < t <= t* (except `self`
+// and fully transparent uncoloured ones) and picks the one minimising squares32(0x9E3779B9*id + random bits), a uniform
+// choice driven by the same random number.
+LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t self_inst, uint32_t self_tri, float random, uint32_t& num_hits,
+                             RayStats& st) {
+  float tstar = kFltMax;
+  uint32_t best_id = kLightIdInvalid, best_key = 0xFFFFFFFFu, n = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    float tmax = tstar;
+    traverse_bvh4(sc.light_nodes, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float& tm) {
+      for (uint32_t j = 0; j < count; j++) {
+        const BvhTri tr = sc.light_tris[first + j];
+        st.tris++;
+        const uint2 handle = sc.light_tri_handles[tr.id];
+        if (handle.x == self_inst && handle.y == self_tri) continue;
+        F2 uv;
+        const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), origin, dir, uv);
+        if (!(t > kEps && t != kFltMax && t <= tstar)) continue;
+        const uint32_t mesh = sc.instance_mesh_ids[handle.x];
+        const Material m = load_material(sc, sc.tri_tex[sc.mesh_tri_offset[mesh] + handle.y].w & 0xFFFFu);
+        if (m.alpha == 0.0f && (m.flags & kDMatColoredTransparency) == 0) continue;
+        if (pass == 0) { if (m.alpha == 1.0f && t < tstar) { tstar = t; tm = t; } }
+        else {
+          n++;
+          const uint32_t key = squares32(0xfcbd6e15u, 0x9E3779B9u * tr.id + fbits(random));
+          if (key < best_key || (key == best_key && tr.id < best_id)) { best_key = key; best_id = tr.id; }
+        }
+      }
+      return false;
+    });
+  }
+  num_hits = n;
+  return best_id;
+}
+
+}  // namespace lum

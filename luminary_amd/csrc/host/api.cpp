@@ -1,0 +1,402 @@
+// Implementation of the Luminary C host API (include/luminary_amd.h) on top of the host scene store and the HIP core.
+// Reference behaviour: src/luminary/host/host.c (function by function, cited below), src/luminary/luminary.c:7-31,
+// src/luminary/path.c, src/luminary/error.c. The reference runs these calls through a Host queue thread and a Device queue
+// thread; this implementation applies scene edits immediately on the caller's thread and renders synchronously inside the
+// luminary_ext_* calls (one process drives one GPU; DESIGN.md "Threading").
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../../include/lum_core.h"
+#include "../../../include/luminary_amd.h"
+#include "loaders.h"
+#include "scene.h"
+
+extern "C" const unsigned char lum_embedded_bluenoise_2d[];
+extern "C" const unsigned char lum_embedded_bluenoise_2d_end[];
+
+struct LuminaryPath { std::string value; };
+
+struct LuminaryHost {
+  lum::HostScene scene;
+  lum::DeviceSceneBuffers device_scene;
+  bool device_scene_valid = false;
+  bool core_scene_valid = false;
+  LumContext* core = nullptr;
+  int device_ordinal = 0;
+  std::vector<uint32_t> pixels;  // pixel set of the current accumulation
+  bool pixels_all = true;
+  uint32_t num_pixels = 0;
+  uint32_t accumulated_samples = 0;
+  LuminaryOutputProperties output_props{false, 0, 0};
+  std::vector<std::string> log;
+  std::mutex mutex;
+};
+
+namespace {
+
+std::vector<uint32_t> embedded_bluenoise() {
+  const size_t bytes = (size_t) (lum_embedded_bluenoise_2d_end - lum_embedded_bluenoise_2d);
+  std::vector<uint32_t> v(bytes / 4);
+  std::memcpy(v.data(), lum_embedded_bluenoise_2d, v.size() * 4);
+  return v;
+}
+
+void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; }
+
+#define CHECK_NULL(p) do { if (!(p)) return LUMINARY_ERROR_ARGUMENT_NULL; } while (0)
+
+LuminaryResult ensure_device_scene(LuminaryHost* h) {
+  if (h->device_scene_valid) return LUMINARY_SUCCESS;
+  const std::string err = lum::build_device_scene(h->scene, embedded_bluenoise(), &h->device_scene);
+  if (!err.empty()) { h->log.push_back(err); std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
+  h->device_scene_valid = true;
+  h->core_scene_valid = false;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult ensure_core(LuminaryHost* h) {
+  if (!h->core) {
+    if (lumc_context_create(h->device_ordinal, &h->core)) {
+      std::fprintf(stderr, "[luminary_amd] no usable HIP device: %s\n", lumc_last_error(h->core));
+      lumc_context_destroy(h->core);
+      h->core = nullptr;
+      return LUMINARY_ERROR_CUDA;
+    }
+  }
+  const LuminaryResult r = ensure_device_scene(h);
+  if (r) return r;
+  if (!h->core_scene_valid) {
+    if (lumc_scene_upload(h->core, &h->device_scene.view)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(h->core)); return LUMINARY_ERROR_CUDA; }
+    h->core_scene_valid = true;
+    h->num_pixels = 0;
+  }
+  return LUMINARY_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---- error.c ----
+const char* luminary_result_to_string(LuminaryResult result) {
+  switch (result & ~LUMINARY_ERROR_PROPAGATED) {
+    case LUMINARY_SUCCESS: return "Success";
+    case LUMINARY_ERROR_ARGUMENT_NULL: return "Argument was NULL";
+    case LUMINARY_ERROR_NOT_IMPLEMENTED: return "Not implemented";
+    case LUMINARY_ERROR_INVALID_API_ARGUMENT: return "Invalid API argument";
+    case LUMINARY_ERROR_MEMORY_LEAK: return "Memory leak";
+    case LUMINARY_ERROR_OUT_OF_MEMORY: return "Out of memory";
+    case LUMINARY_ERROR_C_STD: return "C standard library error";
+    case LUMINARY_ERROR_API_EXCEPTION: return "API exception";
+    case LUMINARY_ERROR_CUDA: return "GPU runtime error";
+    case LUMINARY_ERROR_OPTIX: return "Acceleration structure error";
+    case LUMINARY_ERROR_PREVIOUS_ERROR: return "Previous error";
+    case LUMINARY_ERROR_DEBUG_ASSERT: return "Debug assert";
+    case LUMINARY_ERROR_MISSING_DATA: return "Missing data";
+    case LUMINARY_ERROR_INVALID_DEVICE: return "Invalid device";
+    default: return "Unknown";
+  }
+}
+
+// ---- luminary.c:7-31 ----
+void luminary_init(void) {}
+void luminary_shutdown(void) {}
+
+// ---- path.c ----
+LuminaryResult luminary_path_create(LuminaryPath** path) { CHECK_NULL(path); *path = new LuminaryPath(); return LUMINARY_SUCCESS; }
+LuminaryResult luminary_path_set_from_string(LuminaryPath* path, const char* string) { CHECK_NULL(path); CHECK_NULL(string); path->value = string; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_path_destroy(LuminaryPath** path) { CHECK_NULL(path); CHECK_NULL(*path); delete *path; *path = nullptr; return LUMINARY_SUCCESS; }
+
+// ---- host.c:292-404 ----
+LuminaryResult luminary_host_create(LuminaryHost** host, LuminaryHostCreateInfo info) {
+  CHECK_NULL(host);
+  LuminaryHost* h = new LuminaryHost();
+  // one process per GPU: the lowest set bit of the mask selects the ordinal (torch.distributed sets LOCAL_RANK for the launcher)
+  int ordinal = 0;
+  if (info.device_mask != 0) while (!((info.device_mask >> ordinal) & 1u) && ordinal < 31) ordinal++;
+  if (const char* lr = std::getenv("LOCAL_RANK")) { if (info.device_mask == LUMINARY_HOST_CREATE_INFO_DEVICE_MASK_ALL_DEVICES) ordinal = std::atoi(lr); }
+  h->device_ordinal = ordinal;
+  *host = h;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_destroy(LuminaryHost** host) {
+  CHECK_NULL(host); CHECK_NULL(*host);
+  if ((*host)->core) lumc_context_destroy((*host)->core);
+  delete *host;
+  *host = nullptr;
+  return LUMINARY_SUCCESS;
+}
+
+// host.c:406-414: restarts integration
+LuminaryResult luminary_host_start_new_render(LuminaryHost* host) {
+  CHECK_NULL(host);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  host->accumulated_samples = 0;
+  if (host->core && host->num_pixels) lumc_clear_accumulators(host->core);
+  return LUMINARY_SUCCESS;
+}
+
+// host.c:416-470 - this process drives exactly one device
+LuminaryResult luminary_host_get_device_count(LuminaryHost* host, uint32_t* device_count) { CHECK_NULL(host); CHECK_NULL(device_count); *device_count = 1; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_device_info(LuminaryHost* host, uint32_t device_id, LuminaryDeviceInfo* info) {
+  CHECK_NULL(host); CHECK_NULL(info);
+  if (device_id != 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  std::memset(info, 0, sizeof(*info));
+  info->is_main_device = true; info->is_enabled = true; info->is_unavailable = false;
+  std::snprintf(info->name, sizeof(info->name), "HIP device %d (gfx950 path-tracing core)", host->device_ordinal);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_set_device_enable(LuminaryHost* host, uint32_t device_id, bool enable) {
+  CHECK_NULL(host);
+  if (device_id != 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  return enable ? LUMINARY_SUCCESS : LUMINARY_ERROR_NOT_IMPLEMENTED;
+}
+LuminaryResult luminary_host_start_device(LuminaryHost* host, uint32_t index) { CHECK_NULL(host); return index == 0 ? LUMINARY_SUCCESS : LUMINARY_ERROR_INVALID_API_ARGUMENT; }
+LuminaryResult luminary_host_shutdown_device(LuminaryHost* host, uint32_t index) { CHECK_NULL(host); (void) index; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+
+// host.c:35-100 (+ :472-532)
+LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* path) {
+  CHECK_NULL(host); CHECK_NULL(path);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  lum::HostMesh mesh;
+  std::vector<LuminaryMaterial> mats;
+  std::vector<std::string> warnings;
+  std::string err;
+  if (!lum::load_obj(path->value, lum::ObjLoadArgs(), (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err)) {
+    std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
+    return LUMINARY_ERROR_API_EXCEPTION;
+  }
+  for (auto& w : warnings) std::fprintf(stderr, "[luminary_amd] warning: %s\n", w.c_str());
+  if (mesh.triangle_count() == 0 && mesh.name.empty()) return LUMINARY_SUCCESS;
+  host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
+  host->scene.meshes.push_back(std::move(mesh));
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+
+// host.c:534-605
+LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* path) {
+  CHECK_NULL(host); CHECK_NULL(path);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  lum::LumFileContent content;
+  lum::default_settings(&content.settings); lum::default_camera(&content.camera); lum::default_ocean(&content.ocean); lum::default_sky(&content.sky);
+  lum::default_cloud(&content.cloud); lum::default_fog(&content.fog); lum::default_particles(&content.particles);
+  std::vector<std::string> warnings;
+  std::string err;
+  if (!lum::load_lum_v4(path->value, &content, &warnings, &err)) { std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
+  const size_t slash = path->value.find_last_of("/\\");
+  const std::string dir = slash == std::string::npos ? std::string() : path->value.substr(0, slash + 1);
+  for (const std::string& obj : content.obj_files) {
+    lum::HostMesh mesh;
+    std::vector<LuminaryMaterial> mats;
+    if (!lum::load_obj(dir + obj, content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err)) {
+      std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
+      return LUMINARY_ERROR_API_EXCEPTION;
+    }
+    const uint32_t mesh_id = (uint32_t) host->scene.meshes.size();
+    host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
+    host->scene.meshes.push_back(std::move(mesh));
+    lum::HostInstance inst;
+    inst.mesh_id = mesh_id;
+    host->scene.instances.push_back(inst);
+  }
+  for (auto& w : warnings) std::fprintf(stderr, "[luminary_amd] warning: %s\n", w.c_str());
+  host->scene.settings = content.settings; host->scene.camera = content.camera; host->scene.ocean = content.ocean; host->scene.sky = content.sky;
+  host->scene.cloud = content.cloud; host->scene.fog = content.fog; host->scene.particles = content.particles;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult luminary_host_get_current_sample_time(LuminaryHost* host, double* time) { CHECK_NULL(host); CHECK_NULL(time); *time = 0.0; return LUMINARY_SUCCESS; }
+// host.c:615-703: no queue-worker threads exist in this implementation
+LuminaryResult luminary_host_get_num_queue_workers(const LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = 0; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_queue_worker_name(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_queue_worker_string(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_queue_worker_time(const LuminaryHost* host, uint32_t id, double* time) { CHECK_NULL(host); CHECK_NULL(time); (void) id; *time = 0.0; return LUMINARY_SUCCESS; }
+
+// Output chain (tone mapping to ARGB8, promises, PNG) is the next component after the radiance path.
+LuminaryResult luminary_host_set_output_properties(LuminaryHost* host, LuminaryOutputProperties p) { CHECK_NULL(host); host->output_props = p; return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_request_output(LuminaryHost* host, LuminaryOutputRequestProperties p, LuminaryOutputPromiseHandle* handle) { CHECK_NULL(host); CHECK_NULL(handle); (void) p; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_try_await_output(LuminaryHost* host, LuminaryOutputPromiseHandle handle, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); (void) handle; *out = LUMINARY_OUTPUT_HANDLE_INVALID; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_acquire_output(LuminaryHost* host, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); *out = LUMINARY_OUTPUT_HANDLE_INVALID; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_get_image(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryImage* image) { CHECK_NULL(host); CHECK_NULL(image); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_release_output(LuminaryHost* host, LuminaryOutputHandle handle) { CHECK_NULL(host); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_get_pixel_info(LuminaryHost* host, uint16_t x, uint16_t y, LuminaryPixelQueryResult* result) { CHECK_NULL(host); CHECK_NULL(result); (void) x; (void) y; result->pixel_query_is_valid = false; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryPath* path) { CHECK_NULL(host); CHECK_NULL(path); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) { CHECK_NULL(host); return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+
+// ---- entity getters / setters (host.c:705-900) ----
+#define ENTITY_ACCESSORS(NAME, TYPE, FIELD)                                                             \
+  LuminaryResult luminary_host_get_##NAME(LuminaryHost* host, TYPE* out) {                              \
+    CHECK_NULL(host); CHECK_NULL(out);                                                                  \
+    std::lock_guard<std::mutex> lock(host->mutex);                                                      \
+    *out = host->scene.FIELD;                                                                           \
+    return LUMINARY_SUCCESS;                                                                            \
+  }                                                                                                     \
+  LuminaryResult luminary_host_set_##NAME(LuminaryHost* host, const TYPE* in) {                         \
+    CHECK_NULL(host); CHECK_NULL(in);                                                                   \
+    std::lock_guard<std::mutex> lock(host->mutex);                                                      \
+    if (std::memcmp(&host->scene.FIELD, in, sizeof(TYPE)) != 0) { host->scene.FIELD = *in; invalidate(host); } \
+    return LUMINARY_SUCCESS;                                                                            \
+  }
+ENTITY_ACCESSORS(settings, LuminaryRendererSettings, settings)
+ENTITY_ACCESSORS(camera, LuminaryCamera, camera)
+ENTITY_ACCESSORS(ocean, LuminaryOcean, ocean)
+ENTITY_ACCESSORS(sky, LuminarySky, sky)
+ENTITY_ACCESSORS(cloud, LuminaryCloud, cloud)
+ENTITY_ACCESSORS(fog, LuminaryFog, fog)
+ENTITY_ACCESSORS(particles, LuminaryParticles, particles)
+
+LuminaryResult luminary_host_get_material(LuminaryHost* host, uint16_t id, LuminaryMaterial* material) {
+  CHECK_NULL(host); CHECK_NULL(material);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (id >= host->scene.materials.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  *material = host->scene.materials[id];
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_set_material(LuminaryHost* host, uint16_t id, const LuminaryMaterial* material) {
+  CHECK_NULL(host); CHECK_NULL(material);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (id >= host->scene.materials.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  host->scene.materials[id] = *material;
+  host->scene.materials[id].id = id;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_get_instance(LuminaryHost* host, uint32_t id, LuminaryInstance* instance) {
+  CHECK_NULL(host); CHECK_NULL(instance);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (id >= host->scene.instances.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  const lum::HostInstance& i = host->scene.instances[id];
+  instance->id = id; instance->mesh_id = i.mesh_id; instance->position = i.translation; instance->rotation = i.rotation; instance->scale = i.scale;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_set_instance(LuminaryHost* host, const LuminaryInstance* instance) {
+  CHECK_NULL(host); CHECK_NULL(instance);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (instance->id >= host->scene.instances.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  lum::HostInstance& i = host->scene.instances[instance->id];
+  i.mesh_id = instance->mesh_id; i.translation = instance->position; i.rotation = instance->rotation; i.scale = instance->scale; i.active = true;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+// host.c:902-930: writes defaults and the new id back to the caller
+LuminaryResult luminary_host_new_instance(LuminaryHost* host, LuminaryInstance* instance) {
+  CHECK_NULL(host); CHECK_NULL(instance);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  lum::HostInstance i;
+  i.mesh_id = 0;
+  host->scene.instances.push_back(i);
+  instance->id = (uint32_t) host->scene.instances.size() - 1; instance->mesh_id = i.mesh_id;
+  instance->position = i.translation; instance->rotation = i.rotation; instance->scale = i.scale;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_get_num_meshes(LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = (uint32_t) host->scene.meshes.size(); return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_num_materials(LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = (uint32_t) host->scene.materials.size(); return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_get_num_instances(LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = (uint32_t) host->scene.instances.size(); return LUMINARY_SUCCESS; }
+
+// ---- additive extension ----
+LuminaryResult luminary_ext_add_mesh(LuminaryHost* host, const float* positions, const float* normals, const float* uvs, const uint16_t* material_ids,
+                                     uint32_t triangle_count, uint32_t* mesh_id) {
+  CHECK_NULL(host); CHECK_NULL(positions); CHECK_NULL(material_ids);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  lum::HostMesh m;
+  m.positions.assign(positions, positions + 9 * (size_t) triangle_count);
+  m.material_ids.assign(material_ids, material_ids + triangle_count);
+  if (uvs) m.uvs.assign(uvs, uvs + 6 * (size_t) triangle_count); else m.uvs.assign(6 * (size_t) triangle_count, 0.0f);
+  if (normals) m.normals.assign(normals, normals + 9 * (size_t) triangle_count);
+  else {  // face normals, as the .obj path does for files without `vn` (wavefront.c:918-929)
+    m.normals.resize(9 * (size_t) triangle_count);
+    for (uint32_t t = 0; t < triangle_count; t++) {
+      const float* p = positions + 9 * (size_t) t;
+      const float e1[3] = {p[3] - p[0], p[4] - p[1], p[5] - p[2]}, e2[3] = {p[6] - p[0], p[7] - p[1], p[8] - p[2]};
+      float n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+      const float rl = 1.0f / std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+      if (!std::isnan(rl) && !std::isinf(rl)) { n[0] *= rl; n[1] *= rl; n[2] *= rl; }
+      for (int k = 0; k < 3; k++) std::memcpy(&m.normals[9 * (size_t) t + 3 * k], n, sizeof(n));
+    }
+  }
+  host->scene.meshes.push_back(std::move(m));
+  if (mesh_id) *mesh_id = (uint32_t) host->scene.meshes.size() - 1;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id) {
+  CHECK_NULL(host); CHECK_NULL(material);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (host->scene.materials.size() >= 0xFFFF) return LUMINARY_ERROR_API_EXCEPTION;
+  host->scene.materials.push_back(*material);
+  host->scene.materials.back().id = (uint32_t) host->scene.materials.size() - 1;
+  if (material_id) *material_id = (uint16_t) (host->scene.materials.size() - 1);
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const LumDeviceSceneView** view) {
+  CHECK_NULL(host); CHECK_NULL(view);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  const LuminaryResult r = ensure_device_scene(host);
+  if (r) return r;
+  *view = &host->device_scene.view;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
+                                           uint32_t samples_per_pass) {
+  CHECK_NULL(host);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  LuminaryResult r = ensure_core(host);
+  if (r) return r;
+  const bool all = pixels == nullptr;
+  bool same = (host->num_pixels != 0) && (all == host->pixels_all);
+  if (same && !all) same = (host->pixels.size() == num_pixels) && std::memcmp(host->pixels.data(), pixels, sizeof(uint32_t) * num_pixels) == 0;
+  if (!same) {
+    if (lumc_set_pixels(host->core, pixels, num_pixels)) return LUMINARY_ERROR_CUDA;
+    host->pixels_all = all;
+    if (!all) host->pixels.assign(pixels, pixels + num_pixels);
+    host->num_pixels = all ? host->device_scene.view.width * host->device_scene.view.height : num_pixels;
+    host->accumulated_samples = 0;
+  }
+  if (lumc_render(host->core, first_sample, num_samples, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+  if (lumc_synchronize(host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+  host->accumulated_samples += num_samples;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels) {
+  CHECK_NULL(host);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (num_pixels) *num_pixels = host->num_pixels;
+  if (!host->core || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  if ((first_moment || second_moment) && lumc_download_accumulators(host->core, first_moment, second_moment)) return LUMINARY_ERROR_CUDA;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_t* sample_count, uint32_t width, uint32_t height) {
+  CHECK_NULL(host); CHECK_NULL(rgb);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (!host->core || !host->pixels_all || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  const LumDeviceSceneView& v = host->device_scene.view;
+  if (width != v.width || height != v.height) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  std::vector<float> fm(3 * (size_t) host->num_pixels);
+  if (lumc_download_accumulators(host->core, fm.data(), nullptr)) return LUMINARY_ERROR_CUDA;
+  const float norm = host->accumulated_samples ? 1.0f / host->accumulated_samples : 0.0f;  // accumulation.cuh:149-153
+  for (size_t p = 0; p < host->num_pixels; p++)
+    for (int c = 0; c < 3; c++) rgb[3 * p + c] = fm[(size_t) c * host->num_pixels + p] * norm;
+  if (sample_count) *sample_count = host->accumulated_samples;
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_get_ray_counters(LuminaryHost* host, uint64_t out[8]) {
+  CHECK_NULL(host); CHECK_NULL(out);
+  if (!host->core) return LUMINARY_ERROR_API_EXCEPTION;
+  return lumc_counters(host->core, out) ? LUMINARY_ERROR_CUDA : LUMINARY_SUCCESS;
+}
+void* luminary_ext_get_core_context(LuminaryHost* host) {
+  if (!host) return nullptr;
+  std::lock_guard<std::mutex> lock(host->mutex);
+  if (ensure_core(host)) return nullptr;
+  return host->core;
+}
+
+}  // extern "C"

@@ -1,0 +1,25 @@
+// Host-side BVH4 builder for the software traversal that replaces the reference's OptiX acceleration structures
+// (reference: src/luminary/device/optix_bvh.c:150-684 builds GAS/IAS through optixAccelBuild).
+// Round-1 builder: binned-SAH binary tree on the CPU, collapsed into 128-byte 4-wide nodes. A GPU LBVH builder is the
+// planned replacement; the node/triangle layout consumed by the kernels does not depend on the builder.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "../device/dev_scene.h"
+
+namespace lum {
+
+struct Aabb { float lo[3], hi[3]; };
+
+struct Bvh4 {
+  std::vector<Bvh4Node> nodes;   // nodes[0] is the root and always an inner node
+  std::vector<uint32_t> prims;   // primitive ids in leaf order; leaves reference ranges of this array
+  uint32_t max_depth = 0;
+};
+
+// Builds a BVH4 over `count` boxes. Leaves hold at most kBvhLeafMaxTri primitives.
+Bvh4 build_bvh4(const Aabb* boxes, uint32_t count);
+
+}  // namespace lum

@@ -1,0 +1,527 @@
+// C ABI of the path-tracing core (include/lum_core.h): context, scene upload, BVH construction, pass scheduling.
+// Host-side counterpart of the reference's device layer for the hot path only:
+//   device/device.c (context, streams, constant memory), device/device_work_buffers.c:54-117 (task/result buffers),
+//   device/device_renderer.c:53-134, :488-575 (per-depth kernel queue), device/device_result_interface.c (moments).
+// There is deliberately no CPU fallback: every entry point fails with an error string when HIP is unavailable.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/lum_core.h"
+#include "../device/kernels.h"
+#include "bvh_build.h"
+
+using namespace lum;
+
+struct LumContext {
+  int device = 0;
+  std::string error;
+  std::vector<void*> scene_allocs;
+  DeviceScene scene{};
+  bool has_scene = false;
+  uint64_t bvh_stats[4] = {0, 0, 0, 0};
+  // LUTs owned by the context when generated here
+  uint16_t* d_luts[4] = {nullptr, nullptr, nullptr, nullptr};
+  // pixels and accumulators
+  uint32_t* d_pixels = nullptr;
+  uint32_t num_pixels = 0;
+  float* d_first_moment = nullptr;
+  float* d_second_moment = nullptr;
+  // work buffers (sized for capacity paths)
+  uint32_t capacity = 0;
+  void* work_block = nullptr;
+  PathQueue queue[2]{};
+  NeeQueue nee{};
+  float4* d_results = nullptr;
+  uint32_t* d_counts = nullptr;   // one per depth + 1
+  uint64_t* d_counters = nullptr;
+  // profiling
+  bool profiling = false;
+  struct Stamp { hipEvent_t a, b; int kernel; };
+  std::vector<Stamp> stamps;
+  double kernel_ms[LUMC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  uint32_t kernel_launches[LUMC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, expr)                                                                                          \
+  do {                                                                                                              \
+    const hipError_t e__ = (expr);                                                                                  \
+    if (e__ != hipSuccess) {                                                                                        \
+      (ctx)->error = std::string(#expr) + " failed: " + hipGetErrorString(e__);                                     \
+      return 1;                                                                                                     \
+    }                                                                                                               \
+  } while (0)
+
+template <typename T>
+int upload(LumContext* ctx, const T* host, size_t count, const T** out, bool scene_owned = true) {
+  *out = nullptr;
+  if (count == 0 || host == nullptr) return 0;
+  void* d = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d, sizeof(T) * count));
+  if (scene_owned) ctx->scene_allocs.push_back(d);
+  HIP_TRY(ctx, hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice));
+  *out = (const T*) d;
+  return 0;
+}
+
+void free_scene(LumContext* ctx) {
+  for (void* p : ctx->scene_allocs) (void) hipFree(p);
+  ctx->scene_allocs.clear();
+  for (int i = 0; i < 4; i++) { if (ctx->d_luts[i]) (void) hipFree(ctx->d_luts[i]); ctx->d_luts[i] = nullptr; }
+  ctx->has_scene = false;
+}
+
+void free_work(LumContext* ctx) {
+  if (ctx->work_block) (void) hipFree(ctx->work_block);
+  ctx->work_block = nullptr;
+  ctx->capacity = 0;
+}
+
+int ensure_work(LumContext* ctx, uint32_t paths) {
+  if (paths <= ctx->capacity) return 0;
+  free_work(ctx);
+  // per path: 2 queues x 64 B + NEE 80 B + result 16 B = 224 B
+  const size_t n = paths;
+  const size_t bytes = n * (2 * 64 + 80 + 16);
+  HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
+  char* p = (char*) ctx->work_block;
+  auto take = [&](size_t sz) { char* r = p; p += sz; return r; };
+  for (int k = 0; k < 2; k++) {
+    ctx->queue[k].origin_t = (float4*) take(n * 16);
+    ctx->queue[k].dir_slot = (float4*) take(n * 16);
+    ctx->queue[k].aux      = (uint4*) take(n * 16);
+    ctx->queue[k].hit_id   = (uint4*) take(n * 16);
+  }
+  ctx->nee.geo_ray_dist    = (float4*) take(n * 16);
+  ctx->nee.geo_color_light = (float4*) take(n * 16);
+  ctx->nee.bsdf_ray_prob   = (float4*) take(n * 16);
+  ctx->nee.bsdf_weight_sum = (float4*) take(n * 16);
+  ctx->nee.ambient         = (uint4*) take(n * 16);
+  ctx->d_results           = (float4*) take(n * 16);
+  ctx->capacity = paths;
+  return 0;
+}
+
+inline uint32_t grid_for(uint32_t n) {
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);  // 256 CUs x 8 resident blocks, grid-stride beyond that
+}
+
+struct Launch {
+  LumContext* ctx;
+  hipStream_t stream;
+  int kernel;
+  size_t idx = (size_t) -1;
+  Launch(LumContext* c, hipStream_t s, int k) : ctx(c), stream(s), kernel(k) {
+    if (!ctx->profiling) return;
+    LumContext::Stamp st;
+    st.kernel = k;
+    if (hipEventCreate(&st.a) != hipSuccess || hipEventCreate(&st.b) != hipSuccess) return;
+    (void) hipEventRecord(st.a, stream);
+    ctx->stamps.push_back(st);
+    idx = ctx->stamps.size() - 1;
+  }
+  ~Launch() {
+    if (idx != (size_t) -1) (void) hipEventRecord(ctx->stamps[idx].b, stream);
+  }
+};
+
+int resolve_stamps(LumContext* ctx) {
+  for (auto& st : ctx->stamps) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(st.b) == hipSuccess && hipEventElapsedTime(&ms, st.a, st.b) == hipSuccess) {
+      ctx->kernel_ms[st.kernel] += ms;
+      ctx->kernel_launches[st.kernel]++;
+    }
+    (void) hipEventDestroy(st.a);
+    (void) hipEventDestroy(st.b);
+  }
+  ctx->stamps.clear();
+  return 0;
+}
+
+Aabb tri_box(const float* a, const float* b, const float* c) {
+  Aabb box;
+  for (int k = 0; k < 3; k++) { box.lo[k] = std::min(a[k], std::min(b[k], c[k])); box.hi[k] = std::max(a[k], std::max(b[k], c[k])); }
+  return box;
+}
+
+// Host twin of the device transform (cuda/math.cuh:393-489) used to bound instances for the top-level BVH.
+struct HostXf { float t[3], s[3]; float q[4]; };
+HostXf host_transform(const float* p) {
+  HostXf x;
+  for (int k = 0; k < 3; k++) { x.t[k] = p[k]; x.s[k] = p[3 + k]; }
+  uint32_t a, b;
+  std::memcpy(&a, p + 6, 4); std::memcpy(&b, p + 7, 4);
+  x.q[0] = ((a & 0xFFFF) * (1.0f / 0x7FFF)) - 1.0f; x.q[1] = ((a >> 16) * (1.0f / 0x7FFF)) - 1.0f;
+  x.q[2] = ((b & 0xFFFF) * (1.0f / 0x7FFF)) - 1.0f; x.q[3] = ((b >> 16) * (1.0f / 0x7FFF)) - 1.0f;
+  return x;
+}
+void host_apply(const HostXf& x, const float v[3], float out[3]) {
+  const float ux = x.q[0], uy = x.q[1], uz = x.q[2], s = x.q[3];
+  const float duv = ux * v[0] + uy * v[1] + uz * v[2], duu = ux * ux + uy * uy + uz * uz;
+  const float cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
+  const float r[3] = {2.0f * duv * ux + (s * s - duu) * v[0] + 2.0f * s * cx, 2.0f * duv * uy + (s * s - duu) * v[1] + 2.0f * s * cy,
+                      2.0f * duv * uz + (s * s - duu) * v[2] + 2.0f * s * cz};
+  for (int k = 0; k < 3; k++) out[k] = r[k] * x.s[k] + x.t[k];
+}
+
+}  // namespace
+
+extern "C" {
+
+int lumc_context_create(int device_ordinal, LumContext** out) {
+  if (!out) return 1;
+  *out = nullptr;
+  LumContext* ctx = new LumContext();
+  ctx->device = device_ordinal;
+  *out = ctx;
+  int count = 0;
+  HIP_TRY(ctx, hipGetDeviceCount(&count));
+  if (device_ordinal < 0 || device_ordinal >= count) { ctx->error = "no such HIP device"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(device_ordinal));
+  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_counts, sizeof(uint32_t) * 128));
+  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_counters, sizeof(uint64_t) * LUMC_CNT_COUNT));
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(uint64_t) * LUMC_CNT_COUNT));
+  return 0;
+}
+
+void lumc_context_destroy(LumContext* ctx) {
+  if (!ctx) return;
+  (void) hipSetDevice(ctx->device);
+  (void) hipDeviceSynchronize();
+  resolve_stamps(ctx);
+  free_scene(ctx);
+  free_work(ctx);
+  if (ctx->d_pixels) (void) hipFree(ctx->d_pixels);
+  if (ctx->d_first_moment) (void) hipFree(ctx->d_first_moment);
+  if (ctx->d_second_moment) (void) hipFree(ctx->d_second_moment);
+  if (ctx->d_counts) (void) hipFree(ctx->d_counts);
+  if (ctx->d_counters) (void) hipFree(ctx->d_counters);
+  delete ctx;
+}
+
+const char* lumc_last_error(const LumContext* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
+uint32_t lumc_scene_view_sizeof(void) { return (uint32_t) sizeof(LumDeviceSceneView); }
+
+int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
+  if (!ctx || !v) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  free_scene(ctx);
+  DeviceScene& sc = ctx->scene;
+  std::memset(&sc, 0, sizeof(sc));
+  if (!v->bluenoise_2d) { ctx->error = "scene has no blue-noise mask"; return 1; }
+  if (v->max_ray_depth > 63) { ctx->error = "max_ray_depth exceeds 63 (6-bit field, device_structs.h:9)"; return 1; }
+  const uint32_t total_tris = v->num_meshes ? v->mesh_tri_offset[v->num_meshes] : 0;
+
+  if (upload(ctx, v->mesh_tri_offset, (size_t) v->num_meshes + 1, &sc.mesh_tri_offset)) return 1;
+  if (upload(ctx, (const float4*) v->vertices, (size_t) total_tris * 3, &sc.vertices)) return 1;
+  if (upload(ctx, (const uint4*) v->tri_tex, (size_t) total_tris, &sc.tri_tex)) return 1;
+  if (upload(ctx, v->instance_mesh_ids, v->num_instances, &sc.instance_mesh_ids)) return 1;
+  if (upload(ctx, (const float4*) v->instance_transforms, (size_t) v->num_instances * 2, &sc.instance_transforms)) return 1;
+  if (upload(ctx, (const uint4*) v->materials, (size_t) v->num_materials * 2, &sc.materials)) return 1;
+  if (v->light_tree_root && v->num_lights) {
+    const uint32_t sections = v->light_tree_root[10];
+    if (upload(ctx, (const uint4*) v->light_tree_root, (size_t) 1 + 3 * sections, &sc.light_tree_root)) return 1;
+    if (upload(ctx, (const uint4*) v->light_tree_nodes, (size_t) v->num_light_tree_nodes * 4, &sc.light_tree_nodes)) return 1;
+    if (upload(ctx, (const uint2*) v->light_tri_handles, v->num_lights, &sc.light_tri_handles)) return 1;
+  }
+  if (upload(ctx, v->bluenoise_2d, 65536, &sc.bluenoise_2d)) return 1;
+
+  // ---- bottom-level BVHs, one per mesh, concatenated ----
+  std::vector<Bvh4Node> blas_nodes;
+  std::vector<BvhTri> blas_tris((size_t) total_tris);
+  std::vector<uint32_t> node_off(v->num_meshes + 1, 0), tri_off(v->num_meshes + 1, 0);
+  std::vector<Aabb> mesh_box(v->num_meshes);
+  for (uint32_t m = 0; m < v->num_meshes; m++) {
+    const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
+    std::vector<Aabb> boxes(nt);
+    Aabb mb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    for (uint32_t t = 0; t < nt; t++) {
+      const float* p = v->vertices + (size_t) (t0 + t) * 12;
+      boxes[t] = tri_box(p, p + 4, p + 8);
+      for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], boxes[t].lo[k]); mb.hi[k] = std::max(mb.hi[k], boxes[t].hi[k]); }
+    }
+    mesh_box[m] = mb;
+    Bvh4 bvh = build_bvh4(boxes.data(), nt);
+    node_off[m] = (uint32_t) blas_nodes.size();
+    tri_off[m] = t0;
+    // leaf ranges index the per-mesh triangle array; inner child ids are relative to the mesh's first node
+    blas_nodes.insert(blas_nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
+    for (uint32_t i = 0; i < nt; i++) {
+      const uint32_t t = bvh.prims[i];
+      const float* p = v->vertices + (size_t) (t0 + t) * 12;
+      BvhTri& bt = blas_tris[(size_t) t0 + i];
+      for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
+      bt.id = t; bt.pad0 = 0; bt.pad1 = 0;
+    }
+  }
+  node_off[v->num_meshes] = (uint32_t) blas_nodes.size();
+  tri_off[v->num_meshes] = total_tris;
+  if (blas_nodes.empty()) { Bvh4 e = build_bvh4(nullptr, 0); blas_nodes = e.nodes; }
+  if (upload(ctx, blas_nodes.data(), blas_nodes.size(), &sc.blas_nodes)) return 1;
+  if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
+  if (upload(ctx, node_off.data(), node_off.size(), &sc.mesh_node_offset)) return 1;
+  if (upload(ctx, tri_off.data(), tri_off.size(), &sc.mesh_bvhtri_offset)) return 1;
+
+  // ---- top-level BVH over the world boxes of the instances ----
+  {
+    std::vector<Aabb> boxes;
+    std::vector<uint32_t> ids;
+    for (uint32_t i = 0; i < v->num_instances; i++) {
+      const uint32_t m = v->instance_mesh_ids[i];
+      if (m >= v->num_meshes || v->mesh_tri_offset[m + 1] == v->mesh_tri_offset[m]) continue;
+      const HostXf x = host_transform(v->instance_transforms + (size_t) i * 8);
+      Aabb wb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+      for (int c = 0; c < 8; c++) {
+        const float corner[3] = {(c & 1) ? mesh_box[m].hi[0] : mesh_box[m].lo[0], (c & 2) ? mesh_box[m].hi[1] : mesh_box[m].lo[1],
+                                 (c & 4) ? mesh_box[m].hi[2] : mesh_box[m].lo[2]};
+        float w[3];
+        host_apply(x, corner, w);
+        for (int k = 0; k < 3; k++) { wb.lo[k] = std::min(wb.lo[k], w[k]); wb.hi[k] = std::max(wb.hi[k], w[k]); }
+      }
+      // the host transform is evaluated with a different operation order than the kernels': widen a little
+      for (int k = 0; k < 3; k++) {
+        const float pad = 1e-4f * std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k])) + 1e-6f * (wb.hi[k] - wb.lo[k]) + 1e-30f;
+        wb.lo[k] -= pad; wb.hi[k] += pad;
+      }
+      boxes.push_back(wb);
+      ids.push_back(i);
+    }
+    Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size());
+    std::vector<uint32_t> prims(tlas.prims.size());
+    for (size_t i = 0; i < prims.size(); i++) prims[i] = ids[tlas.prims[i]];
+    if (prims.empty()) prims.push_back(0);
+    if (upload(ctx, tlas.nodes.data(), tlas.nodes.size(), &sc.tlas_nodes)) return 1;
+    if (upload(ctx, prims.data(), prims.size(), &sc.tlas_prims)) return 1;
+    sc.tlas_num_nodes = (uint32_t) tlas.nodes.size();
+    ctx->bvh_stats[2] = tlas.nodes.size();
+  }
+  // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
+  {
+    const uint32_t nl = (v->light_tree_root && v->light_bvh_tris) ? v->num_lights : 0;
+    std::vector<Aabb> boxes(nl);
+    for (uint32_t l = 0; l < nl; l++) { const float* p = v->light_bvh_tris + (size_t) l * 12; boxes[l] = tri_box(p, p + 4, p + 8); }
+    Bvh4 lb = build_bvh4(boxes.data(), nl);
+    std::vector<BvhTri> tris(nl ? nl : 1);
+    std::memset(tris.data(), 0, sizeof(BvhTri) * tris.size());
+    for (uint32_t i = 0; i < nl; i++) {
+      const uint32_t l = lb.prims[i];
+      const float* p = v->light_bvh_tris + (size_t) l * 12;
+      for (int k = 0; k < 3; k++) { tris[i].p0[k] = p[k]; tris[i].e1[k] = p[4 + k] - p[k]; tris[i].e2[k] = p[8 + k] - p[k]; }
+      tris[i].id = l;
+    }
+    if (upload(ctx, lb.nodes.data(), lb.nodes.size(), &sc.light_nodes)) return 1;
+    if (upload(ctx, tris.data(), tris.size(), &sc.light_tris)) return 1;
+    sc.light_num_nodes = (uint32_t) lb.nodes.size();
+    ctx->bvh_stats[3] = lb.nodes.size();
+  }
+  ctx->bvh_stats[0] = blas_nodes.size();
+  ctx->bvh_stats[1] = total_tris;
+
+  sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights;
+  sc.width = v->width; sc.height = v->height; sc.max_ray_depth = v->max_ray_depth; sc.shading_mode = v->shading_mode;
+  std::memcpy(sc.cam_pos, v->cam_pos, sizeof(sc.cam_pos));
+  std::memcpy(sc.cam_rotation, v->cam_rotation, sizeof(sc.cam_rotation));
+  sc.cam_fov = v->cam_fov; sc.cam_aperture_size = v->cam_aperture_size; sc.cam_object_distance = v->cam_object_distance;
+  sc.cam_scale = v->cam_scale; sc.cam_rr_threshold = v->cam_rr_threshold;
+  sc.cam_aperture_shape = v->cam_aperture_shape; sc.cam_aperture_blade_count = v->cam_aperture_blade_count;
+  sc.sky_mode = v->sky_mode;
+  std::memcpy(sc.sky_constant_color, v->sky_constant_color, sizeof(sc.sky_constant_color));
+
+  // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
+  const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
+  const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
+  for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_luts[t], sizeof(uint16_t) * lut_count[t]));
+  if (host_luts[0] && host_luts[1] && host_luts[2] && host_luts[3]) {
+    for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMemcpy(ctx->d_luts[t], host_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyHostToDevice));
+  }
+  else {
+    for (int t = 0; t < 4; t++) {
+      hipLaunchKernelGGL(k_generate_lut, dim3((lut_count[t] + 63) / 64), dim3(64), 0, 0, sc.bluenoise_2d, t, lut_count[t], ctx->d_luts[0], ctx->d_luts[t]);
+      HIP_TRY(ctx, hipGetLastError());
+    }
+    HIP_TRY(ctx, hipDeviceSynchronize());
+  }
+  sc.lut_conductor = ctx->d_luts[0]; sc.lut_glossy = ctx->d_luts[1]; sc.lut_dielectric = ctx->d_luts[2]; sc.lut_dielectric_inv = ctx->d_luts[3];
+  ctx->has_scene = true;
+  return 0;
+}
+
+int lumc_download_luts(LumContext* ctx, uint16_t* conductor, uint16_t* glossy, uint16_t* dielectric, uint16_t* dielectric_inv) {
+  if (!ctx || !ctx->has_scene) return 1;
+  uint16_t* dst[4] = {conductor, glossy, dielectric, dielectric_inv};
+  const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
+  for (int t = 0; t < 4; t++)
+    if (dst[t]) HIP_TRY(ctx, hipMemcpy(dst[t], ctx->d_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_set_pixels(LumContext* ctx, const uint32_t* pixels, uint32_t num_pixels) {
+  if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_set_pixels: no scene"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!pixels) num_pixels = ctx->scene.width * ctx->scene.height;
+  if (ctx->d_pixels) { (void) hipFree(ctx->d_pixels); ctx->d_pixels = nullptr; }
+  if (ctx->d_first_moment) { (void) hipFree(ctx->d_first_moment); ctx->d_first_moment = nullptr; }
+  if (ctx->d_second_moment) { (void) hipFree(ctx->d_second_moment); ctx->d_second_moment = nullptr; }
+  ctx->num_pixels = num_pixels;
+  if (num_pixels == 0) return 0;
+  if (pixels) {
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_pixels, sizeof(uint32_t) * num_pixels));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_pixels, pixels, sizeof(uint32_t) * num_pixels, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_first_moment, sizeof(float) * 3 * (size_t) num_pixels));
+  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_second_moment, sizeof(float) * (size_t) num_pixels));
+  return lumc_clear_accumulators(ctx);
+}
+
+int lumc_clear_accumulators(LumContext* ctx) {
+  if (!ctx || !ctx->d_first_moment) return 1;
+  HIP_TRY(ctx, hipMemset(ctx->d_first_moment, 0, sizeof(float) * 3 * (size_t) ctx->num_pixels));
+  HIP_TRY(ctx, hipMemset(ctx->d_second_moment, 0, sizeof(float) * (size_t) ctx->num_pixels));
+  return 0;
+}
+
+int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, uint32_t samples_per_pass, float* d_fm, float* d_sm, void* stream_) {
+  if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_render: no scene"; return 1; }
+  if (ctx->num_pixels == 0) return 0;
+  hipStream_t stream = (hipStream_t) stream_;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!d_fm) { d_fm = ctx->d_first_moment; d_sm = ctx->d_second_moment; }
+  if (samples_per_pass == 0) samples_per_pass = 1;
+  // sample ids beyond 2^20 would duplicate earlier ones (cuda/kernels.cuh:103-105)
+  if (first_sample >= kMaxGlobalSamples) return 0;
+  if (first_sample + (uint64_t) num_samples > kMaxGlobalSamples) num_samples = kMaxGlobalSamples - first_sample;
+  const uint32_t P = ctx->num_pixels;
+  const uint64_t want = (uint64_t) P * samples_per_pass;
+  if (want > 0x7FFFFFFFull) { ctx->error = "pass too large"; return 1; }
+  if (ensure_work(ctx, (uint32_t) want)) return 1;
+  const DeviceScene& sc = ctx->scene;
+  const uint32_t max_depth = sc.max_ray_depth;
+
+  for (uint32_t done = 0; done < num_samples; done += samples_per_pass) {
+    const uint32_t batch = std::min(samples_per_pass, num_samples - done);
+    const uint32_t N = P * batch;
+    PassParams pp{ctx->d_pixels, P, batch, first_sample + done};
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, sizeof(uint32_t) * (max_depth + 2), stream));
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_counts);
+    }
+    int cur = 0;
+    for (uint32_t depth = 0; depth <= max_depth; depth++) {
+      // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
+      const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
+      const uint32_t grid = grid_for(N);
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->d_counts + depth, ctx->d_counters);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->d_results,
+                           ctx->d_counts + depth, ctx->d_counts + depth + 1, depth_const, ctx->d_counters);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
+        hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->d_results, ctx->d_counts + depth, depth_const,
+                           ctx->d_counters);
+      }
+      cur ^= 1;
+    }
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_ACCUMULATE);
+      hipLaunchKernelGGL(k_accumulate, dim3(grid_for(P)), dim3(kBlock), 0, stream, (const float4*) ctx->d_results, P, batch, d_fm, d_sm);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return 0;
+}
+
+int lumc_synchronize(LumContext* ctx) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  return resolve_stamps(ctx);
+}
+
+int lumc_download_accumulators(LumContext* ctx, float* first_moment, float* second_moment) {
+  if (!ctx || !ctx->d_first_moment) return 1;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  if (first_moment) HIP_TRY(ctx, hipMemcpy(first_moment, ctx->d_first_moment, sizeof(float) * 3 * (size_t) ctx->num_pixels, hipMemcpyDeviceToHost));
+  if (second_moment) HIP_TRY(ctx, hipMemcpy(second_moment, ctx->d_second_moment, sizeof(float) * (size_t) ctx->num_pixels, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_counters(LumContext* ctx, uint64_t out[LUMC_CNT_COUNT]) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(out, ctx->d_counters, sizeof(uint64_t) * LUMC_CNT_COUNT, hipMemcpyDeviceToHost));
+  return 0;
+}
+int lumc_reset_counters(LumContext* ctx) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(uint64_t) * LUMC_CNT_COUNT));
+  return 0;
+}
+int lumc_set_profiling(LumContext* ctx, int enabled) {
+  if (!ctx) return 1;
+  ctx->profiling = enabled != 0;
+  for (int k = 0; k < LUMC_KERNEL_COUNT; k++) { ctx->kernel_ms[k] = 0.0; ctx->kernel_launches[k] = 0; }
+  return 0;
+}
+int lumc_kernel_times(LumContext* ctx, double total_ms[LUMC_KERNEL_COUNT], uint32_t launches[LUMC_KERNEL_COUNT]) {
+  if (!ctx) return 1;
+  if (lumc_synchronize(ctx)) return 1;
+  for (int k = 0; k < LUMC_KERNEL_COUNT; k++) { total_ms[k] = ctx->kernel_ms[k]; launches[k] = ctx->kernel_launches[k]; }
+  return 0;
+}
+
+int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream_) {
+  if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_trace_closest: no scene"; return 1; }
+  if (n == 0) return 0;
+  hipStream_t stream = (hipStream_t) stream_;
+  Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+  hipLaunchKernelGGL(k_trace_rays, dim3(grid_for(n)), dim3(kBlock), 0, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, ctx->d_counters);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int lumc_trace_closest_host(LumContext* ctx, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out) {
+  if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_trace_closest_host: no scene"; return 1; }
+  if (n == 0) return 0;
+  float *d_o = nullptr, *d_d = nullptr;
+  uint32_t *d_i = nullptr, *d_out = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**) &d_o, sizeof(float) * 3 * (size_t) n));
+  HIP_TRY(ctx, hipMalloc((void**) &d_d, sizeof(float) * 3 * (size_t) n));
+  HIP_TRY(ctx, hipMalloc((void**) &d_out, sizeof(uint32_t) * 3 * (size_t) n));
+  HIP_TRY(ctx, hipMemcpy(d_o, origins, sizeof(float) * 3 * (size_t) n, hipMemcpyHostToDevice));
+  HIP_TRY(ctx, hipMemcpy(d_d, dirs, sizeof(float) * 3 * (size_t) n, hipMemcpyHostToDevice));
+  if (ignore) {
+    HIP_TRY(ctx, hipMalloc((void**) &d_i, sizeof(uint32_t) * 2 * (size_t) n));
+    HIP_TRY(ctx, hipMemcpy(d_i, ignore, sizeof(uint32_t) * 2 * (size_t) n, hipMemcpyHostToDevice));
+  }
+  int rc = lumc_trace_closest(ctx, n, d_o, d_d, d_i, d_out, nullptr);
+  if (!rc) {
+    const hipError_t e = hipMemcpy(out, d_out, sizeof(uint32_t) * 3 * (size_t) n, hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { ctx->error = hipGetErrorString(e); rc = 1; }
+  }
+  (void) hipFree(d_o); (void) hipFree(d_d); (void) hipFree(d_out);
+  if (d_i) (void) hipFree(d_i);
+  return rc;
+}
+
+int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]) {
+  if (!ctx) return 1;
+  for (int k = 0; k < 4; k++) out[k] = ctx->bvh_stats[k];
+  return 0;
+}
+
+}  // extern "C"

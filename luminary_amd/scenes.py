@@ -1,0 +1,374 @@
+"""Deterministic synthetic scenes for tests and benchmarks (SURVEY.md §8d "Synthetic inputs").
+
+The reference ships no usable assets (`Example.lum` points at a missing `Example.obj`, no Cornell box, no Sponza), so every
+workload is generated here:
+  cornell_box_files  C1: 5 quads + 2 boxes + 1 emissive quad as .obj/.mtl/.lum files (exercises the scene pipeline)
+  example_scene      C2: "Example-class" scene, ~100 k triangles: ground, instanced spheres/boxes, emissive quads (seed 1)
+  hall_scene         C3: 1 M-triangle "Sponza-class" hall: arcade of columns/arches/curtains, emissive panels (seed 2)
+  scan_scene         C5: displaced icosphere "scan" on a ground plane (seed 3), triangle count by subdivision level
+Benchmark settings: supersampling 0, adaptive sampling off, constant-colour sky, thin lens, RR threshold 0.1.
+"""
+import math
+import os
+
+import numpy as np
+
+from . import RGBAF, RGBF, SKY_MODE_CONSTANT_COLOR, Host, Vec3, default_material
+
+
+def apply_benchmark_settings(host, width, height, max_ray_depth, sky=(1.0, 1.0, 1.0)):
+    s = host.get_settings()
+    s.width, s.height, s.max_ray_depth = width, height, max_ray_depth
+    s.supersampling = 0
+    s.undersampling = 0
+    s.enable_adaptive_sampling = False
+    s.shading_mode = 0
+    host.set_settings(s)
+    k = host.get_sky()
+    k.mode = SKY_MODE_CONSTANT_COLOR
+    k.constant_color = RGBF(*sky)
+    host.set_sky(k)
+
+
+def set_camera(host, pos, rotation, fov=1.0):
+    c = host.get_camera()
+    c.pos = Vec3(*pos)
+    c.rotation = Vec3(*rotation)
+    c.thin_lens.fov = fov
+    c.thin_lens.aperture_size = 0.0
+    c.russian_roulette_threshold = 0.1
+    host.set_camera(c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C1: Cornell box as files
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _quad(a, b, c, d):
+    return [a, b, c, d]
+
+
+def cornell_box_files(directory, width=64, height=64, bounces=1):
+    """Writes cornell.obj / cornell.mtl / cornell.lum into `directory` and returns the .lum path. 36 triangles."""
+    os.makedirs(directory, exist_ok=True)
+    verts = []
+    faces = []  # (material name, [indices 1-based])
+
+    def add_quad(mat, pts):
+        base = len(verts)
+        verts.extend(pts)
+        faces.append((mat, [base + 1, base + 2, base + 3, base + 4]))
+
+    def add_box(mat, lo, hi, angle):
+        cx, cz = 0.5 * (lo[0] + hi[0]), 0.5 * (lo[2] + hi[2])
+        ca, sa = math.cos(angle), math.sin(angle)
+
+        def rot(p):
+            x, z = p[0] - cx, p[2] - cz
+            return (cx + ca * x - sa * z, p[1], cz + sa * x + ca * z)
+        x0, y0, z0 = lo
+        x1, y1, z1 = hi
+        c = [rot(p) for p in [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1), (x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1)]]
+        for q in ([4, 7, 6, 5], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7]):
+            add_quad(mat, [c[i] for i in q])
+
+    # room: x in [-1,1], y in [0,2], z in [-1,1]; the camera looks down -z from z = 3.4
+    add_quad("white", [(-1, 0, 1), (1, 0, 1), (1, 0, -1), (-1, 0, -1)])      # floor
+    add_quad("white", [(-1, 2, -1), (1, 2, -1), (1, 2, 1), (-1, 2, 1)])      # ceiling
+    add_quad("white", [(-1, 0, -1), (1, 0, -1), (1, 2, -1), (-1, 2, -1)])    # back
+    add_quad("red", [(-1, 0, 1), (-1, 0, -1), (-1, 2, -1), (-1, 2, 1)])      # left
+    add_quad("green", [(1, 0, -1), (1, 0, 1), (1, 2, 1), (1, 2, -1)])        # right
+    add_quad("light", [(-0.3, 1.995, -0.3), (0.3, 1.995, -0.3), (0.3, 1.995, 0.3), (-0.3, 1.995, 0.3)])
+    add_box("white", (-0.7, 0.0, -0.65), (-0.1, 1.2, -0.05), 0.3)
+    add_box("metal", (0.1, 0.0, 0.05), (0.7, 0.6, 0.65), -0.3)
+
+    with open(os.path.join(directory, "cornell.mtl"), "w") as f:
+        f.write("newmtl white\nKd 0.73 0.73 0.73\nNs 300\n\n")
+        f.write("newmtl red\nKd 0.65 0.05 0.05\nNs 300\n\n")
+        f.write("newmtl green\nKd 0.12 0.45 0.15\nNs 300\n\n")
+        f.write("newmtl metal\nKd 0.9 0.8 0.5\nKs 1.0 1.0 1.0\nNs 700\n\n")
+        f.write("newmtl light\nKd 0.78 0.78 0.78\nKe 17.0 12.0 4.0\nNs 300\n")
+    with open(os.path.join(directory, "cornell.obj"), "w") as f:
+        f.write("mtllib cornell.mtl\no cornell\n")
+        for v in verts:
+            f.write("v %.6f %.6f %.6f\n" % v)
+        cur = None
+        for mat, idx in faces:
+            if mat != cur:
+                f.write("usemtl %s\n" % mat)
+                cur = mat
+            f.write("f %d %d %d %d\n" % tuple(idx))
+    with open(os.path.join(directory, "cornell.lum"), "w") as f:
+        f.write("Luminary\nVERSION 4\n# Cornell box, generated\n")
+        f.write("GENERAL WIDTH___ %d\nGENERAL HEIGHT__ %d\nGENERAL BOUNCES_ %d\nGENERAL MESHFILE cornell.obj\n" % (width, height, bounces))
+        f.write("CAMERA POSITION 0.0 1.0 3.4\nCAMERA ROTATION 0.0 0.0 0.0\nCAMERA FOV_____ 0.4\nCAMERA RUSSIANR 0.1\n")
+        f.write("SKY MODE____ 2\nSKY COLORCON 0.0 0.0 0.0\n")
+    return os.path.join(directory, "cornell.lum")
+
+
+def cornell_host(directory, width=64, height=64, bounces=1):
+    """Loads the generated Cornell box through the .lum/.obj pipeline and applies the benchmark overrides the v4 format cannot express."""
+    host = Host()
+    host.load_lum_file(cornell_box_files(directory, width, height, bounces))
+    s = host.get_settings()
+    s.supersampling = 0
+    s.undersampling = 0
+    s.enable_adaptive_sampling = False
+    host.set_settings(s)
+    return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mesh helpers
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _sphere(segments):
+    """UV sphere of radius 1: (9 floats per triangle positions, smooth normals)."""
+    tris = []
+    for i in range(segments):
+        t0, t1 = math.pi * i / segments, math.pi * (i + 1) / segments
+        for j in range(2 * segments):
+            p0, p1 = math.pi * j / segments, math.pi * (j + 1) / segments
+
+            def pt(t, p):
+                return (math.sin(t) * math.cos(p), math.cos(t), math.sin(t) * math.sin(p))
+            a, b, c, d = pt(t0, p0), pt(t1, p0), pt(t1, p1), pt(t0, p1)
+            if i != 0:
+                tris.append((a, b, d))
+            if i != segments - 1:
+                tris.append((b, c, d))
+    pos = np.array(tris, dtype=np.float32).reshape(-1, 9)
+    return pos, pos.copy()
+
+
+def _box():
+    c = [(-1, -1, -1), (1, -1, -1), (1, -1, 1), (-1, -1, 1), (-1, 1, -1), (1, 1, -1), (1, 1, 1), (-1, 1, 1)]
+    quads = [[4, 7, 6, 5], [0, 1, 2, 3], [0, 4, 5, 1], [1, 5, 6, 2], [2, 6, 7, 3], [3, 7, 4, 0]]
+    tris = []
+    for q in quads:
+        tris.append((c[q[0]], c[q[1]], c[q[2]]))
+        tris.append((c[q[0]], c[q[2]], c[q[3]]))
+    return np.array(tris, dtype=np.float32).reshape(-1, 9), None
+
+
+def _grid(nx, nz, x0, x1, z0, z1, height_fn=None):
+    xs = np.linspace(x0, x1, nx + 1, dtype=np.float32)
+    zs = np.linspace(z0, z1, nz + 1, dtype=np.float32)
+    X, Z = np.meshgrid(xs, zs, indexing="ij")
+    Y = np.zeros_like(X) if height_fn is None else height_fn(X, Z).astype(np.float32)
+    P = np.stack([X, Y, Z], axis=-1)
+    a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+    t1 = np.concatenate([a, c, b], axis=-1).reshape(-1, 9)
+    t2 = np.concatenate([a, d, c], axis=-1).reshape(-1, 9)
+    return np.concatenate([t1, t2], axis=0).astype(np.float32)
+
+
+def _material(albedo, roughness=0.7, metallic=False, emission=None, bidirectional=True, alpha=1.0):
+    m = default_material()
+    m.albedo = RGBAF(albedo[0], albedo[1], albedo[2], alpha)
+    m.roughness = roughness
+    m.metallic = metallic
+    if emission is not None:
+        m.emission = RGBF(*emission)
+        m.emission_active = True
+        m.bidirectional_emission = bidirectional
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C2: Example-class scene
+# ---------------------------------------------------------------------------------------------------------------------
+
+def example_scene(width=1920, height=1080, bounces=8, seed=1, sphere_segments=20, ground_res=64, num_objects=64, num_lights=16):
+    """~100 k triangles with the defaults: ground grid, instanced spheres and boxes, emissive quads."""
+    rng = np.random.RandomState(seed)
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces)
+    palette = []
+    for _ in range(12):
+        albedo = 0.2 + 0.7 * rng.rand(3)
+        rough = [0.05, 0.3, 0.7][rng.randint(3)]
+        palette.append(host.add_material(_material(albedo, rough, metallic=rng.rand() < 0.05)))
+    ground_mat = host.add_material(_material((0.6, 0.6, 0.6), 0.7))
+    light_mat = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(20.0, 18.0, 15.0)))
+
+    ground = _grid(ground_res, ground_res, -40, 40, -40, 40, lambda X, Z: 0.4 * np.sin(0.3 * X) * np.cos(0.25 * Z))
+    gid = host.add_mesh(ground, np.full(len(ground), ground_mat, dtype=np.uint16))
+    host.new_instance(gid)
+
+    sp_pos, sp_nrm = _sphere(sphere_segments)
+    bx_pos, _ = _box()
+    sphere_ids = [host.add_mesh(sp_pos, np.full(len(sp_pos), palette[k % len(palette)], dtype=np.uint16), normals=sp_nrm) for k in range(4)]
+    box_ids = [host.add_mesh(bx_pos, np.full(len(bx_pos), palette[(k + 5) % len(palette)], dtype=np.uint16)) for k in range(4)]
+    for k in range(num_objects):
+        x, z = rng.uniform(-30, 30), rng.uniform(-35, 10)
+        s = rng.uniform(0.8, 2.5)
+        if k % 2 == 0:
+            host.new_instance(sphere_ids[k % 4], (x, s + 0.5, z), (0, 0, 0), (s, s, s))
+        else:
+            host.new_instance(box_ids[k % 4], (x, s + 0.4, z), (0.0, rng.uniform(0, 3.14), 0.0), (s, s, 0.7 * s))
+    quads = []
+    for k in range(num_lights):
+        x, z, y = rng.uniform(-30, 30), rng.uniform(-35, 10), rng.uniform(6, 12)
+        w = rng.uniform(0.8, 2.0)
+        a, b, c, d = (x - w, y, z - w), (x + w, y, z - w), (x + w, y, z + w), (x - w, y, z + w)
+        quads.append(a + c + b)
+        quads.append(a + d + c)
+    lq = np.array(quads, dtype=np.float32)
+    lid = host.add_mesh(lq, np.full(len(lq), light_mat, dtype=np.uint16))
+    host.new_instance(lid)
+    set_camera(host, (0.0, 6.0, 28.0), (-0.18, 0.0, 0.0), fov=0.9)
+    return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C3: 1 M-triangle hall
+# ---------------------------------------------------------------------------------------------------------------------
+
+def hall_scene(width=1920, height=1080, bounces=8, seed=2, target_triangles=1_000_000):
+    """Sponza-class hall as ONE mesh: floor/walls/vault grids, rows of tessellated columns, arches and wavy curtains, emissive panels.
+    Mix of long thin, large and tiny triangles. `target_triangles` scales the tessellation."""
+    rng = np.random.RandomState(seed)
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.6, 0.7, 1.0))
+    mats = {
+        "stone": host.add_material(_material((0.7, 0.65, 0.6), 0.7)),
+        "floor": host.add_material(_material((0.5, 0.5, 0.52), 0.3)),
+        "column": host.add_material(_material((0.8, 0.78, 0.7), 0.3)),
+        "curtain_r": host.add_material(_material((0.7, 0.15, 0.12), 0.7)),
+        "curtain_b": host.add_material(_material((0.15, 0.2, 0.7), 0.7)),
+        "brass": host.add_material(_material((0.9, 0.7, 0.3), 0.05, metallic=True)),
+        "light": host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(30.0, 26.0, 20.0))),
+    }
+    scale = math.sqrt(target_triangles / 1_000_000.0)
+    parts, ids = [], []
+
+    def add(tris, mat):
+        parts.append(tris.astype(np.float32))
+        ids.append(np.full(len(tris), mats[mat], dtype=np.uint16))
+
+    L, W, H = 48.0, 14.0, 12.0
+    nf = max(4, int(180 * scale))
+    add(_grid(nf, nf // 3, -L, L, -W, W), "floor")
+    # side walls (grids rotated into the xy plane) and vault
+    wall = _grid(max(4, int(140 * scale)), max(2, int(40 * scale)), -L, L, 0.0, H)
+
+    def to_wall(t, z, flip):
+        q = t.reshape(-1, 3, 3).copy()
+        y = q[:, :, 2].copy()
+        q[:, :, 2] = z
+        q[:, :, 1] = y
+        if flip:
+            q = q[:, ::-1, :]
+        return q.reshape(-1, 9)
+    add(to_wall(wall, -W, False), "stone")
+    add(to_wall(wall, W, True), "stone")
+    nv = max(4, int(160 * scale))
+    vault = _grid(nv, max(4, int(60 * scale)), -L, L, -W, W, lambda X, Z: H + 3.0 * np.cos(Z / W * math.pi / 2))
+    add(vault.reshape(-1, 3, 3)[:, ::-1, :].reshape(-1, 9), "stone")
+    # columns: tessellated cylinders with fluting
+    ncol = 14
+    seg_a, seg_h = max(8, int(96 * scale)), max(4, int(160 * scale))
+    for side in (-1, 1):
+        for k in range(ncol):
+            cx, cz = -L + 4.0 + k * (2 * L - 8.0) / (ncol - 1), side * (W - 3.5)
+            ang = np.linspace(0, 2 * math.pi, seg_a + 1, dtype=np.float32)
+            hs = np.linspace(0, H - 2.5, seg_h + 1, dtype=np.float32)
+            A, Hh = np.meshgrid(ang, hs, indexing="ij")
+            R = 0.55 + 0.04 * np.cos(12 * A) + 0.08 * np.exp(-Hh * 2.0)
+            P = np.stack([cx + R * np.cos(A), Hh, cz + R * np.sin(A)], axis=-1)
+            a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+            t = np.concatenate([np.concatenate([a, c, b], -1).reshape(-1, 9), np.concatenate([a, d, c], -1).reshape(-1, 9)], 0)
+            add(t, "column" if k % 5 else "brass")
+    # curtains: wavy sheets between columns
+    nc_u, nc_v = max(6, int(120 * scale)), max(6, int(150 * scale))
+    for side in (-1, 1):
+        for k in range(0, ncol - 1, 2):
+            x0 = -L + 4.0 + k * (2 * L - 8.0) / (ncol - 1)
+            x1 = x0 + (2 * L - 8.0) / (ncol - 1)
+            us = np.linspace(x0 + 0.7, x1 - 0.7, nc_u + 1, dtype=np.float32)
+            vs = np.linspace(2.5, H - 3.0, nc_v + 1, dtype=np.float32)
+            U, V = np.meshgrid(us, vs, indexing="ij")
+            phase = rng.uniform(0, 6.28)
+            Z = side * (W - 3.5) + 0.25 * np.sin(6.0 * (U - x0) + phase) * (1.0 - (V - 2.5) / (H - 5.5) * 0.6)
+            P = np.stack([U, V, Z], axis=-1)
+            a, b, c, d = P[:-1, :-1], P[1:, :-1], P[1:, 1:], P[:-1, 1:]
+            t = np.concatenate([np.concatenate([a, c, b], -1).reshape(-1, 9), np.concatenate([a, d, c], -1).reshape(-1, 9)], 0)
+            add(t, "curtain_r" if (k // 2) % 2 == 0 else "curtain_b")
+    # emissive panels under the vault
+    quads = []
+    for k in range(32):
+        x = -L + 3.0 + (k % 16) * (2 * L - 6.0) / 15
+        z = (-1 if k < 16 else 1) * 3.0
+        w = 0.9
+        y = H + 1.2
+        a, b, c, d = (x - w, y, z - w), (x + w, y, z - w), (x + w, y, z + w), (x - w, y, z + w)
+        quads.append(a + b + c)
+        quads.append(a + c + d)
+    add(np.array(quads, dtype=np.float32), "light")
+    mesh = host.add_mesh(np.concatenate(parts, 0), np.concatenate(ids, 0))
+    host.new_instance(mesh)
+    set_camera(host, (-40.0, 4.0, 0.0), (0.0, 1.5707963, 0.0), fov=0.9)
+    return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# C5: displaced icosphere "scan"
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _icosphere(level):
+    t = (1.0 + math.sqrt(5.0)) / 2.0
+    v = np.array([(-1, t, 0), (1, t, 0), (-1, -t, 0), (1, -t, 0), (0, -1, t), (0, 1, t), (0, -1, -t), (0, 1, -t), (t, 0, -1), (t, 0, 1), (-t, 0, -1), (-t, 0, 1)], dtype=np.float64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    f = np.array([(0, 11, 5), (0, 5, 1), (0, 1, 7), (0, 7, 10), (0, 10, 11), (1, 5, 9), (5, 11, 4), (11, 10, 2), (10, 7, 6), (7, 1, 8), (3, 9, 4), (3, 4, 2),
+                  (3, 2, 6), (3, 6, 8), (3, 8, 9), (4, 9, 5), (2, 4, 11), (6, 2, 10), (8, 6, 7), (9, 8, 1)], dtype=np.int64)
+    tri = v[f]
+    for _ in range(level):
+        a, b, c = tri[:, 0], tri[:, 1], tri[:, 2]
+        ab, bc, ca = a + b, b + c, c + a
+        ab /= np.linalg.norm(ab, axis=1, keepdims=True)
+        bc /= np.linalg.norm(bc, axis=1, keepdims=True)
+        ca /= np.linalg.norm(ca, axis=1, keepdims=True)
+        tri = np.concatenate([np.stack([a, ab, ca], 1), np.stack([b, bc, ab], 1), np.stack([c, ca, bc], 1), np.stack([ab, bc, ca], 1)], 0)
+    return tri
+
+
+def scan_scene(width=1920, height=1080, bounces=8, seed=3, level=9):
+    """Displaced icosphere: 20 * 4**level triangles (level 9 = 5.2 M, level 10 = 21 M) plus ground and 8 area lights."""
+    rng = np.random.RandomState(seed)
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.8, 0.85, 1.0))
+    clay = host.add_material(_material((0.75, 0.6, 0.5), 0.3))
+    ground_mat = host.add_material(_material((0.5, 0.5, 0.5), 0.7))
+    light_mat = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(40.0, 36.0, 30.0)))
+    tri = _icosphere(level)
+    p = tri.reshape(-1, 3)
+    disp = np.zeros(len(p))
+    freq, amp = 1.5, 0.25
+    for _ in range(6):
+        d = rng.randn(3, 3)
+        ph = rng.uniform(0, 6.28, 3)
+        q = p @ d.T * freq
+        disp += amp * np.sin(q[:, 0] + ph[0]) * np.sin(q[:, 1] + ph[1]) * np.sin(q[:, 2] + ph[2])
+        freq *= 2.0
+        amp *= 0.5
+    p = p * (10.0 * (1.0 + 0.15 * disp))[:, None]
+    p[:, 1] += 11.0
+    pos = p.reshape(-1, 9).astype(np.float32)
+    mid = host.add_mesh(pos, np.full(len(pos), clay, dtype=np.uint16))
+    host.new_instance(mid)
+    g = _grid(64, 64, -60, 60, -60, 60)
+    gid = host.add_mesh(g, np.full(len(g), ground_mat, dtype=np.uint16))
+    host.new_instance(gid)
+    quads = []
+    for k in range(8):
+        ang = 2 * math.pi * k / 8
+        x, z, y, w = 25 * math.cos(ang), 25 * math.sin(ang), 30.0, 3.0
+        a, b, c, d = (x - w, y, z - w), (x + w, y, z - w), (x + w, y, z + w), (x - w, y, z + w)
+        quads.append(a + b + c)
+        quads.append(a + c + d)
+    lq = np.array(quads, dtype=np.float32)
+    lid = host.add_mesh(lq, np.full(len(lq), light_mat, dtype=np.uint16))
+    host.new_instance(lid)
+    set_camera(host, (0.0, 12.0, 38.0), (-0.05, 0.0, 0.0), fov=0.8)
+    return host

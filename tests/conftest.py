@@ -1,0 +1,26 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:
+        return os.path.exists("/dev/kfd")
+
+
+def pytest_collection_modifyitems(config, items):
+    # `-m gpu` on a box without a GPU must fail loudly rather than pass on a fallback; nothing is skipped here on purpose.
+    return
