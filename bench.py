@@ -26,15 +26,7 @@ NODE_BYTES, TRI_BYTES = 128, 48  # BVH4 node = 128 B, triangle = 48 B (DESIGN.md
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
 
 
-def tile_pixels(width, height, rank, world, tile=32):
-    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
-    ids = np.arange(tx * ty)
-    mine = ids[ids % world == rank]
-    ys, xs = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
-    px = (mine % tx)[:, None, None] * tile + xs[None]
-    py = (mine // tx)[:, None, None] * tile + ys[None]
-    ok = (px < width) & (py < height)
-    return (px + py * width)[ok].astype(np.uint32)
+from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402
 
 
 def build_workload(name, width, height, bounces):
@@ -49,33 +41,37 @@ def build_workload(name, width, height, bounces):
 
 
 def cpu_baseline(view, budget_s):
-    """Times the oracle (CPU restatement, OpenMP over pixels) on a bounded sample of the same workload: a strided pixel subset at 1 spp."""
+    """Times the oracle (CPU restatement, OpenMP over pixels) on a bounded sample of the same workload: a strided pixel subset of the
+    frame at k spp, sized from a short calibration run so that it takes about `budget_s` seconds. The oracle's own BVH build is timed
+    separately (one-pixel call) and subtracted."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    lib = oracle_lib.lib()
-    del lib
-    import ctypes as C
     cores = os.cpu_count() or 1
-    # the energy tables the oracle reads come from the committed fixture (they do not influence the ray counts)
-    v = oracle_lib.with_luts(view)
+    v = oracle_lib.with_luts(view)  # the energy tables come from the committed fixture
     n_total = view.width * view.height
-    stride = 257
-    best = None
-    spent = 0.0
-    while True:
-        pixels = np.arange(0, n_total, stride, dtype=np.uint32)
-        t0 = time.time()
-        _, _, cnt = oracle_lib.render(v, 0, 1, pixels=pixels, use_bvh=True, threads=cores)
-        dt = time.time() - t0
-        spent += dt
-        rays = float(cnt[0] + cnt[1] + cnt[2])
-        best = {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-                "sample": "oracle (oracle/, OpenMP over pixels) on every %d-th pixel (%d pixels) of the same frame, 1 spp, all 9 depth passes, %.1f s; "
-                          "includes its BVH build" % (stride, pixels.size, dt)}
-        if dt > 0.35 * budget_s or stride <= 5 or spent > budget_s:
-            break
-        stride = max(5, int(stride * dt / (0.6 * budget_s)) | 1)
-    return best
+    t0 = time.time()
+    oracle_lib.render(v, 0, 1, pixels=np.array([0], dtype=np.uint32), use_bvh=True, threads=cores)
+    t_build = time.time() - t0
+
+    def run(pixels, spp):
+        t = time.time()
+        _, _, cnt = oracle_lib.render(v, 0, spp, pixels=pixels, use_bvh=True, threads=cores)
+        return max(time.time() - t - t_build, 1e-6), float(cnt[0] + cnt[1] + cnt[2])
+
+    calib = np.arange(0, n_total, 97, dtype=np.uint32)
+    dt, rays = run(calib, 1)
+    rate_px = calib.size / dt  # pixel-samples per second
+    want = max(rate_px * budget_s, calib.size)
+    if want <= n_total:
+        stride = max(1, int(n_total / want))
+        pixels, spp = np.arange(0, n_total, stride, dtype=np.uint32), 1
+    else:
+        pixels, spp = None, max(1, min(64, int(want / n_total)))
+    dt, rays = run(pixels, spp)
+    npx = n_total if pixels is None else pixels.size
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+            "sample": "oracle/ (CPU restatement, OpenMP over pixels, %d threads) on %d pixels x %d spp of the same frame, all 9 depth passes: "
+                      "%.0f rays in %.1f s (its %.1f s BVH build excluded)" % (cores, npx, spp, rays, dt, t_build)}
 
 
 def main():
@@ -137,11 +133,7 @@ def main():
         step(args.warmup + i)
     if dist is not None:
         # assemble the frame on rank 0: every rank scatters its pixels into a zero frame, one reduce over xGMI
-        full = torch.zeros(4, view.width * view.height, dtype=torch.float32, device="cuda")
-        idx = torch.from_numpy(pixels.astype(np.int64)).cuda()
-        full[0:3].index_copy_(1, idx, fm.view(3, P))
-        full[3].index_copy_(0, idx, sm)
-        dist.reduce(full, dst=0, op=dist.ReduceOp.SUM)
+        assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

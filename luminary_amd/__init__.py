@@ -259,7 +259,9 @@ class Host:
         """Scene in the device format (valid until the next scene edit). Needs no GPU."""
         p = C.POINTER(DeviceSceneView)()
         _call("luminary_ext_build_device_scene", self._h, C.byref(p))
-        return p.contents
+        view = p.contents
+        view._owner = self  # the buffers behind the pointers live in the host
+        return view
 
     def render_samples(self, first_sample, num_samples, pixels=None, samples_per_pass=1):
         import numpy as np

@@ -69,7 +69,7 @@ def cornell_box_files(directory, width=64, height=64, bounces=1):
         x0, y0, z0 = lo
         x1, y1, z1 = hi
         c = [rot(p) for p in [(x0, y0, z0), (x1, y0, z0), (x1, y0, z1), (x0, y0, z1), (x0, y1, z0), (x1, y1, z0), (x1, y1, z1), (x0, y1, z1)]]
-        for q in ([4, 7, 6, 5], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7]):
+        for q in ([4, 7, 6, 5], [0, 1, 5, 4], [1, 2, 6, 5], [2, 3, 7, 6], [3, 0, 4, 7], [0, 3, 2, 1]):
             add_quad(mat, [c[i] for i in q])
 
     # room: x in [-1,1], y in [0,2], z in [-1,1]; the camera looks down -z from z = 3.4
@@ -308,7 +308,7 @@ def hall_scene(width=1920, height=1080, bounces=8, seed=2, target_triangles=1_00
     add(np.array(quads, dtype=np.float32), "light")
     mesh = host.add_mesh(np.concatenate(parts, 0), np.concatenate(ids, 0))
     host.new_instance(mesh)
-    set_camera(host, (-40.0, 4.0, 0.0), (0.0, 1.5707963, 0.0), fov=0.9)
+    set_camera(host, (-40.0, 4.0, 0.0), (0.0, -1.5707963, 0.0), fov=0.9)
     return host
 
 
