@@ -4,7 +4,8 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-Step   = one sample per pixel (1 spp) of the workload over the whole 1920x1080 frame, all 9 depth passes (8 bounces).
+Step   = one wavefront pass: --samples-per-pass (default 8) sample ids of every pixel of the 1920x1080 frame through all 9 depth
+         passes (8 bounces). Deep bounces keep few paths alive, so several sample ids share a pass to keep 256 CUs busy.
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
@@ -77,13 +78,13 @@ def cpu_baseline(view, budget_s):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="example")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--samples-per-pass", type=int, default=1)
+    ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     args = ap.parse_args()
 

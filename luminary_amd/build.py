@@ -18,6 +18,7 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp"]
 HIP_SOURCES = ["host/core.hip"]
+EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
 
@@ -60,7 +61,7 @@ def build(force=False, verbose=False):
     objs.append(o)
     for s in HIP_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
-        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
+        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
         with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w") as f:
             f.write(out)
         if verbose:

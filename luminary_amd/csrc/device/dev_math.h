@@ -146,6 +146,13 @@ LUM_DEV V3 xf_rel_inv(const Transform& t, V3 v) { return xf_rot_inv(t, v * vinv(
 LUM_DEV V3 xf_point(const Transform& t, V3 v) { return xf_rel(t, v) + t.translation; }
 LUM_DEV V3 xf_point_inv(const Transform& t, V3 v) { return xf_rel_inv(t, v - t.translation); }
 
+// Rows of the world->object matrix used by the ray queries: column j is the inverse-rotated unit vector e_j divided by the scale,
+// i.e. the linear part of xf_rel_inv written out once per instance instead of once per ray (the reference hands OptiX a 3x4
+// instance matrix for the same purpose, optix_bvh.c:16-66). The object ray is  M * (origin - T),  M * direction  with the fixed
+// evaluation order of `mat_row_apply`.
+struct Mat3 { V3 r0, r1, r2; };
+__host__ __device__ inline float mat_row_apply(float a, float b, float c, float x, float y, float z) { return (a * x + b * y) + c * z; }
+
 // math.cuh:203-214
 LUM_DEV F2 barycentric_in_triangle(V3 vertex, V3 e1, V3 e2, V3 p) {
   const V3 d = p - vertex;

@@ -56,6 +56,7 @@ struct DeviceScene {
   const uint32_t* mesh_bvhtri_offset;
   const Bvh4Node* tlas_nodes;      // leaves index tlas_prims
   const uint32_t* tlas_prims;      // instance ids in traversal order
+  const float4* instance_inv;      // 3 x float4 per instance: rows of the world->object matrix, .w = translation component
   const Bvh4Node* light_nodes;     // leaves index light_tris
   const BvhTri* light_tris;        // world space, id = light id
   uint32_t num_meshes, num_instances, num_materials, num_lights;

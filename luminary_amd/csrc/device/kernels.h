@@ -19,6 +19,9 @@ enum PathState : uint32_t {  // cuda/utils.cuh:114-121
 enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 constexpr int kBlock = 256;
+#ifndef LUM_SHADE_WAVES
+#define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
+#endif
 
 struct PassParams {
   const uint32_t* pixels;  // pixel index (x + y*width) per local pixel, or nullptr for identity
@@ -170,7 +173,7 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 }
 
 // ---- shading pass: cuda/geometry.cuh:11-180 (+ miss handling of cuda/sky.cuh:609-633, roulette cuda/directives.cuh:11-32) ----
-__global__ __launch_bounds__(kBlock) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, float4* results, const uint32_t* count_in,
+__global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, float4* results, const uint32_t* count_in,
                                                   uint32_t* count_out, uint32_t depth_const, uint64_t* counters) {
   const uint32_t n = *count_in;
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;

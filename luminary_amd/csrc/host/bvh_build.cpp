@@ -33,6 +33,7 @@ struct Builder {
   std::vector<uint32_t> order;
   std::vector<BinNode> nodes;
   bool balanced;
+  uint32_t max_leaf;
 
   uint32_t build(uint32_t first, uint32_t count, int depth) {
     const uint32_t idx = (uint32_t) nodes.size();
@@ -45,7 +46,7 @@ struct Builder {
     }
     nodes[idx].box = box;
     nodes[idx].first = first;
-    if (count <= kBvhLeafMaxTri) { nodes[idx].count = count; return idx; }
+    if (count <= max_leaf) { nodes[idx].count = count; return idx; }
 
     int axis = 0;
     if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
@@ -173,7 +174,7 @@ Bvh4 collapse(const Builder& b) {
 
 }  // namespace
 
-Bvh4 build_bvh4(const Aabb* boxes, uint32_t count) {
+Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf) {
   if (count == 0) {
     Bvh4 out;
     Bvh4Node n;
@@ -191,6 +192,7 @@ Bvh4 build_bvh4(const Aabb* boxes, uint32_t count) {
     Builder b;
     b.boxes = boxes;
     b.balanced = attempt == 1;
+    b.max_leaf = max_leaf < 1 ? 1 : (max_leaf > kBvhLeafMaxTri ? kBvhLeafMaxTri : max_leaf);
     b.centroid.resize(3 * (size_t) count);
     for (uint32_t i = 0; i < count; i++)
       for (int k = 0; k < 3; k++) b.centroid[3 * (size_t) i + k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);

@@ -19,7 +19,7 @@ struct Bvh4 {
   uint32_t max_depth = 0;
 };
 
-// Builds a BVH4 over `count` boxes. Leaves hold at most kBvhLeafMaxTri primitives.
-Bvh4 build_bvh4(const Aabb* boxes, uint32_t count);
+// Builds a BVH4 over `count` boxes. Leaves hold at most `max_leaf` (<= kBvhLeafMaxTri) primitives.
+Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri);
 
 }  // namespace lum

@@ -154,23 +154,55 @@ Aabb tri_box(const float* a, const float* b, const float* c) {
 }
 
 // Host twin of the device transform (cuda/math.cuh:393-489) used to bound instances for the top-level BVH.
-struct HostXf { float t[3], s[3]; float q[4]; };
-HostXf host_transform(const float* p) {
-  HostXf x;
-  for (int k = 0; k < 3; k++) { x.t[k] = p[k]; x.s[k] = p[3 + k]; }
+// World->object matrix of one instance, float arithmetic in the exact operation order of dev_math.h's xf_rel_inv applied to the
+// unit vectors (column j = xf_rel_inv(e_j)); rows[i] = (m_i0, m_i1, m_i2, translation_i). The kernels map rays with these rows
+// (dev_trace.h traverse_scene); the oracle derives the same 12 numbers on its own (oracle/o_trace.h tracer_init).
+void instance_inverse_rows(const float* p, float4 rows[3]) {
   uint32_t a, b;
   std::memcpy(&a, p + 6, 4); std::memcpy(&b, p + 7, 4);
-  x.q[0] = ((a & 0xFFFF) * (1.0f / 0x7FFF)) - 1.0f; x.q[1] = ((a >> 16) * (1.0f / 0x7FFF)) - 1.0f;
-  x.q[2] = ((b & 0xFFFF) * (1.0f / 0x7FFF)) - 1.0f; x.q[3] = ((b >> 16) * (1.0f / 0x7FFF)) - 1.0f;
-  return x;
+  const float ux = 1.0f - ((a & 0xFFFFu) * (1.0f / 0x7FFF)), uy = 1.0f - ((a >> 16) * (1.0f / 0x7FFF));
+  const float uz = 1.0f - ((b & 0xFFFFu) * (1.0f / 0x7FFF)), s = ((b >> 16) * (1.0f / 0x7FFF)) - 1.0f;
+  const float inv_scale[3] = {1.0f / p[3], 1.0f / p[4], 1.0f / p[5]};
+  float col[3][3];
+  for (int j = 0; j < 3; j++) {
+    const float vx = (j == 0 ? 1.0f : 0.0f) * inv_scale[0], vy = (j == 1 ? 1.0f : 0.0f) * inv_scale[1], vz = (j == 2 ? 1.0f : 0.0f) * inv_scale[2];
+    const float duv = ux * vx + uy * vy + uz * vz, duu = ux * ux + uy * uy + uz * uz;
+    const float cx = uy * vz - uz * vy, cy = uz * vx - ux * vz, cz = ux * vy - uy * vx;
+    const float k0 = 2.0f * duv, k1 = s * s - duu, k2 = 2.0f * s;
+    col[j][0] = (ux * k0 + vx * k1) + cx * k2;
+    col[j][1] = (uy * k0 + vy * k1) + cy * k2;
+    col[j][2] = (uz * k0 + vz * k1) + cz * k2;
+  }
+  for (int i = 0; i < 3; i++) rows[i] = make_float4(col[0][i], col[1][i], col[2][i], p[i]);
 }
-void host_apply(const HostXf& x, const float v[3], float out[3]) {
-  const float ux = x.q[0], uy = x.q[1], uz = x.q[2], s = x.q[3];
-  const float duv = ux * v[0] + uy * v[1] + uz * v[2], duu = ux * ux + uy * uy + uz * uz;
-  const float cx = uy * v[2] - uz * v[1], cy = uz * v[0] - ux * v[2], cz = ux * v[1] - uy * v[0];
-  const float r[3] = {2.0f * duv * ux + (s * s - duu) * v[0] + 2.0f * s * cx, 2.0f * duv * uy + (s * s - duu) * v[1] + 2.0f * s * cy,
-                      2.0f * duv * uz + (s * s - duu) * v[2] + 2.0f * s * cz};
-  for (int k = 0; k < 3; k++) out[k] = r[k] * x.s[k] + x.t[k];
+
+// World box of an object-space box under the inverse of the map above (double precision, then padded): the top-level BVH must
+// bound the geometry exactly where the ray mapping puts it.
+bool instance_world_box(const float4 rows[3], const Aabb& ob, Aabb& wb) {
+  const double m[3][3] = {{rows[0].x, rows[0].y, rows[0].z}, {rows[1].x, rows[1].y, rows[1].z}, {rows[2].x, rows[2].y, rows[2].z}};
+  const double det = m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+                     m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+  if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+  double f[3][3];
+  f[0][0] = (m[1][1] * m[2][2] - m[1][2] * m[2][1]) / det; f[0][1] = (m[0][2] * m[2][1] - m[0][1] * m[2][2]) / det; f[0][2] = (m[0][1] * m[1][2] - m[0][2] * m[1][1]) / det;
+  f[1][0] = (m[1][2] * m[2][0] - m[1][0] * m[2][2]) / det; f[1][1] = (m[0][0] * m[2][2] - m[0][2] * m[2][0]) / det; f[1][2] = (m[0][2] * m[1][0] - m[0][0] * m[1][2]) / det;
+  f[2][0] = (m[1][0] * m[2][1] - m[1][1] * m[2][0]) / det; f[2][1] = (m[0][1] * m[2][0] - m[0][0] * m[2][1]) / det; f[2][2] = (m[0][0] * m[1][1] - m[0][1] * m[1][0]) / det;
+  const double t[3] = {rows[0].w, rows[1].w, rows[2].w};
+  double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+  for (int c = 0; c < 8; c++) {
+    const double v[3] = {(c & 1) ? ob.hi[0] : ob.lo[0], (c & 2) ? ob.hi[1] : ob.lo[1], (c & 4) ? ob.hi[2] : ob.lo[2]};
+    for (int k = 0; k < 3; k++) {
+      const double w = f[k][0] * v[0] + f[k][1] * v[1] + f[k][2] * v[2] + t[k];
+      lo[k] = std::min(lo[k], w); hi[k] = std::max(hi[k], w);
+    }
+  }
+  for (int k = 0; k < 3; k++) {
+    // float rounding of the ray mapping (a few ulp of the coordinates involved) is covered by a relative pad
+    const double pad = 4e-6 * std::max(std::fabs(lo[k]), std::fabs(hi[k])) + 4e-6 * std::fabs(t[k]) + 1e-6 * (hi[k] - lo[k]) + 1e-30;
+    wb.lo[k] = (float) (lo[k] - pad); wb.hi[k] = (float) (hi[k] + pad);
+    wb.lo[k] = std::nextafter(wb.lo[k], -FLT_MAX); wb.hi[k] = std::nextafter(wb.hi[k], FLT_MAX);
+  }
+  return true;
 }
 
 }  // namespace
@@ -275,27 +307,18 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   {
     std::vector<Aabb> boxes;
     std::vector<uint32_t> ids;
+    std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
+    for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
+    if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_inv)) return 1;
     for (uint32_t i = 0; i < v->num_instances; i++) {
       const uint32_t m = v->instance_mesh_ids[i];
       if (m >= v->num_meshes || v->mesh_tri_offset[m + 1] == v->mesh_tri_offset[m]) continue;
-      const HostXf x = host_transform(v->instance_transforms + (size_t) i * 8);
-      Aabb wb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
-      for (int c = 0; c < 8; c++) {
-        const float corner[3] = {(c & 1) ? mesh_box[m].hi[0] : mesh_box[m].lo[0], (c & 2) ? mesh_box[m].hi[1] : mesh_box[m].lo[1],
-                                 (c & 4) ? mesh_box[m].hi[2] : mesh_box[m].lo[2]};
-        float w[3];
-        host_apply(x, corner, w);
-        for (int k = 0; k < 3; k++) { wb.lo[k] = std::min(wb.lo[k], w[k]); wb.hi[k] = std::max(wb.hi[k], w[k]); }
-      }
-      // the host transform is evaluated with a different operation order than the kernels': widen a little
-      for (int k = 0; k < 3; k++) {
-        const float pad = 1e-4f * std::max(std::fabs(wb.lo[k]), std::fabs(wb.hi[k])) + 1e-6f * (wb.hi[k] - wb.lo[k]) + 1e-30f;
-        wb.lo[k] -= pad; wb.hi[k] += pad;
-      }
+      Aabb wb;
+      if (!instance_world_box(&inv_rows[3 * (size_t) i], mesh_box[m], wb)) continue;  // degenerate transform: nothing to hit
       boxes.push_back(wb);
       ids.push_back(i);
     }
-    Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size());
+    Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1);  // one instance per top-level leaf (dev_trace.h)
     std::vector<uint32_t> prims(tlas.prims.size());
     for (size_t i = 0; i < prims.size(); i++) prims[i] = ids[tlas.prims[i]];
     if (prims.empty()) prims.push_back(0);

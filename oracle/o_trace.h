@@ -7,6 +7,9 @@
  *   shadow        cuda/optix_common.cuh:76-106, cuda/optix_anyhit.cuh:49-139, cuda/optix_closesthit.cuh:44-58
  *   light-BVH     cuda/optix_anyhit.cuh:145-205, cuda/direct_lighting.cuh:596-611
  * with the triangle test of cuda/math.cuh:1337-1358 on object-space rays (instance transform = S*R*v + T, math.cuh:459-489).
+ * The world->object map is applied as a 3x4 matrix per instance, like the instance matrices the reference hands to OptiX
+ * (device/optix_bvh.c:16-66): column j = transform_apply_relative_inv(e_j) (math.cuh:476-482), rows evaluated as
+ * (a*x + b*y) + c*z on (origin - T) and on the direction. Distances along the ray are preserved by the affine map.
  *
  * Two intersectors give the same answers: brute force over every triangle, and a median-split BVH per mesh with a
  * conservative slab test. Order-independent tie-breaks (lowest t, then instance id, then triangle id) make the result a
@@ -29,8 +32,17 @@ typedef struct {
   const OracleScene* scene;
   OBvh* mesh_bvh;  /* per mesh, NULL when brute force */
   OBvh light_bvh;  /* over world-space light triangles */
+  float* inst_inv; /* 12 per instance: rows (m_i0, m_i1, m_i2, T_i) of the world->object matrix */
   int use_bvh;
 } OTracer;
+
+static inline float mat_row_apply(const float* r, float x, float y, float z) { return (r[0] * x + r[1] * y) + r[2] * z; }
+static inline void inst_ray(const OTracer* tr, uint32_t inst, vec3 origin, vec3 dir, vec3* o, vec3* d) {
+  const float* m = tr->inst_inv + (size_t) inst * 12;
+  const float px = origin.x - m[3], py = origin.y - m[7], pz = origin.z - m[11];
+  *o = v3(mat_row_apply(m, px, py, pz), mat_row_apply(m + 4, px, py, pz), mat_row_apply(m + 8, px, py, pz));
+  *d = v3(mat_row_apply(m, dir.x, dir.y, dir.z), mat_row_apply(m + 4, dir.x, dir.y, dir.z), mat_row_apply(m + 8, dir.x, dir.y, dir.z));
+}
 
 typedef struct { vec3 p0, e1, e2; } OTri;
 static inline OTri mesh_tri(const OracleScene* s, uint32_t mesh, uint32_t tri) {
@@ -114,12 +126,22 @@ static OTri light_tri_adapter(const OracleScene* s, uint32_t mesh, uint32_t i) {
 static void tracer_init(OTracer* t, const OracleScene* s, int use_bvh) {
   t->scene = s; t->use_bvh = use_bvh; t->mesh_bvh = NULL;
   t->light_bvh.nodes = NULL; t->light_bvh.tri_ids = NULL; t->light_bvh.num_nodes = 0;
+  t->inst_inv = (float*) malloc(sizeof(float) * 12 * ((size_t) s->num_instances + 1));
+  for (uint32_t i = 0; i < s->num_instances; i++) {
+    const OTransform tf = scene_transform(s, i);
+    const vec3 c0 = t_rel_inv(tf, v3(1.0f, 0.0f, 0.0f)), c1 = t_rel_inv(tf, v3(0.0f, 1.0f, 0.0f)), c2 = t_rel_inv(tf, v3(0.0f, 0.0f, 1.0f));
+    float* m = t->inst_inv + (size_t) i * 12;
+    m[0] = c0.x; m[1] = c1.x; m[2] = c2.x; m[3] = tf.translation.x;
+    m[4] = c0.y; m[5] = c1.y; m[6] = c2.y; m[7] = tf.translation.y;
+    m[8] = c0.z; m[9] = c1.z; m[10] = c2.z; m[11] = tf.translation.z;
+  }
   if (!use_bvh) return;
   t->mesh_bvh = (OBvh*) calloc(s->num_meshes, sizeof(OBvh));
   for (uint32_t m = 0; m < s->num_meshes; m++) bvh_build(&t->mesh_bvh[m], s->mesh_tri_offset[m + 1] - s->mesh_tri_offset[m], mesh_tri, s, m);
   bvh_build(&t->light_bvh, s->num_lights, light_tri_adapter, s, 0);
 }
 static void tracer_free(OTracer* t) {
+  free(t->inst_inv);
   if (t->mesh_bvh) {
     for (uint32_t m = 0; m < t->scene->num_meshes; m++) { free(t->mesh_bvh[m].nodes); free(t->mesh_bvh[m].tri_ids); }
     free(t->mesh_bvh);
@@ -168,8 +190,8 @@ static inline OHit trace_closest(const OTracer* tr, vec3 origin, vec3 dir, bool 
   for (uint32_t inst = 0; inst < s->num_instances; inst++) {
     const uint32_t mesh = s->instance_mesh_ids[inst];
     if (mesh >= s->num_meshes) continue;
-    const OTransform tf = scene_transform(s, inst);
-    const vec3 o = t_apply_inv(tf, origin), d = t_rel_inv(tf, dir);
+    vec3 o, d;
+    inst_ray(tr, inst, origin, dir, &o, &d);
     const uint32_t ntri = s->mesh_tri_offset[mesh + 1] - s->mesh_tri_offset[mesh];
     const OBvh* bvh = tr->use_bvh ? &tr->mesh_bvh[mesh] : NULL;
     OBVH_FOREACH_TRI(bvh, ntri, o, d, best.t, tri, {
@@ -198,8 +220,8 @@ static inline RGBF trace_shadow(const OTracer* tr, vec3 origin, vec3 dir, float 
   for (uint32_t inst = 0; inst < s->num_instances && !blocked; inst++) {
     const uint32_t mesh = s->instance_mesh_ids[inst];
     if (mesh >= s->num_meshes) continue;
-    const OTransform tf = scene_transform(s, inst);
-    const vec3 o = t_apply_inv(tf, origin), d = t_rel_inv(tf, dir);
+    vec3 o, d;
+    inst_ray(tr, inst, origin, dir, &o, &d);
     const uint32_t ntri = s->mesh_tri_offset[mesh + 1] - s->mesh_tri_offset[mesh];
     const OBvh* bvh = tr->use_bvh ? &tr->mesh_bvh[mesh] : NULL;
     OBVH_FOREACH_TRI(bvh, ntri, o, d, dist, tri, {
