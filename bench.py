@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 NODE_BYTES, TRI_BYTES = 128, 48  # BVH4 node = 128 B, triangle = 48 B (DESIGN.md "Algorithmic bytes")
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
+IO_SHADOW_BYTES = 48 + 16  # visibility ray item + its transparency result
 
 
 from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402
@@ -160,7 +161,7 @@ def main():
     shadow_ms, shadow_n = times["shadow"]
     nodes_trace, tris_trace, nodes_shadow, tris_shadow = cnt[CNT_NODES], cnt[CNT_TRIS], cnt[6], cnt[7]
     bytes_trace = nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES
-    bytes_shadow = nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + (cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]) * (24 + 4 + 12)
+    bytes_shadow = nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES
     dominant = "trace" if trace_ms >= shadow_ms else "shadow"
     dom_bytes, dom_ms, dom_n = (bytes_trace, trace_ms, trace_n) if dominant == "trace" else (bytes_shadow, shadow_ms, shadow_n)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -176,6 +177,8 @@ def main():
                    "spp_per_step": args.samples_per_pass, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
                    "samples_per_s": view.width * view.height * args.samples_per_pass * args.steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
+                   "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
+                                     "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2)},
                    "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()}, "scene_upload_s": round(upload_s, 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }

@@ -5,8 +5,8 @@ import numpy as np
 
 from . import DeviceSceneView, _lib
 
-CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS = 0, 1, 2, 3, 4, 5
-KERNELS = ("generate", "trace", "shade", "shadow", "accumulate")
+CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT = range(10)
+KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve")
 
 
 class CoreError(RuntimeError):
@@ -81,7 +81,7 @@ class Core:
         return fm.reshape(3, -1), sm
 
     def counters(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 10)()
         self._call("lumc_counters", out)
         return [int(x) for x in out]
 
@@ -92,8 +92,8 @@ class Core:
         self._call("lumc_set_profiling", C.c_int(1 if on else 0))
 
     def kernel_times(self):
-        ms = (C.c_double * 5)()
-        n = (C.c_uint32 * 5)()
+        ms = (C.c_double * len(KERNELS))()
+        n = (C.c_uint32 * len(KERNELS))()
         self._call("lumc_kernel_times", ms, n)
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNELS)}
 

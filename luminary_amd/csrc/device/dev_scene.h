@@ -26,9 +26,10 @@ constexpr uint32_t kBvhEmpty      = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeafBit    = 0x80000000u;
 constexpr uint32_t kBvhLeafMaxTri = 4;
 
-// Triangle in traversal order, 48 bytes: v0.xyz + id | e1.xyz | e2.xyz (edges precomputed with the same float
-// subtraction the reference's intersection code performs, so hit distances are identical).
-struct BvhTri { float p0[3]; uint32_t id; float e1[3]; uint32_t pad0; float e2[3]; uint32_t pad1; };
+// Triangle in traversal order, 48 bytes: v0.xyz + id | e1.xyz + scene index | e2.xyz (edges precomputed with the same float
+// subtraction the reference's intersection code performs, so hit distances are identical). `id` is the triangle id inside its
+// mesh (what hits report), `scene_index` = mesh_tri_offset[mesh] + id indexes vertices/tri_tex directly.
+struct BvhTri { float p0[3]; uint32_t id; float e1[3]; uint32_t scene_index; float e2[3]; uint32_t pad1; };
 static_assert(sizeof(BvhTri) == 48, "48 bytes per triangle");
 
 struct DeviceScene {
@@ -49,12 +50,10 @@ struct DeviceScene {
   const uint16_t* lut_glossy;
   const uint16_t* lut_dielectric;
   const uint16_t* lut_dielectric_inv;
-  // acceleration structures
-  const Bvh4Node* blas_nodes;      // all meshes, concatenated
-  const BvhTri* blas_tris;         // all meshes, traversal order, id = triangle id inside its mesh
-  const uint32_t* mesh_node_offset;  // root node of mesh m = blas_nodes[mesh_node_offset[m]]
-  const uint32_t* mesh_bvhtri_offset;
-  const Bvh4Node* tlas_nodes;      // leaves index tlas_prims
+  // acceleration structures (node indices and leaf ranges are absolute, so one base pointer serves both levels)
+  const Bvh4Node* bvh_nodes;       // [0, tlas_num_nodes): top level over instances (leaves index tlas_prims); then every mesh's BVH
+  const BvhTri* blas_tris;         // all meshes, traversal order
+  const uint32_t* mesh_root;       // node index of mesh m's root
   const uint32_t* tlas_prims;      // instance ids in traversal order
   const float4* instance_inv;      // 3 x float4 per instance: rows of the world->object matrix, .w = translation component
   const Bvh4Node* light_nodes;     // leaves index light_tris
@@ -79,15 +78,27 @@ struct PathQueue {
   uint4* hit_id;      // hit (or ignore) instance, triangle | pixel x | y << 16 | sample id
 };
 
-// Next-event-estimation work produced by the shade kernel and consumed by the shadow kernel (80 B per vertex).
+// Next-event-estimation data of the vertices of one depth, indexed like the path queue they were shaded from.
 struct NeeQueue {
-  float4* geo_ray_dist;     // direction to the sampled light, distance
-  float4* geo_color_light;  // weighted radiance, light id (uint bits)
-  float4* bsdf_ray_prob;    // BSDF-sampled direction, its sampling probability
-  float4* bsdf_weight_sum;  // BSDF weight, light tree root sum
-  uint4* ambient;           // packed colour x,y | packed direction x,y
+  float4* geo_color_light;  // sampled light: radiance * weight rgb | light id (uint bits)
+  float4* bsdf_ray_prob;    // BSDF-sampled light direction xyz | its probability (0 = none)
+  float4* bsdf_weight_sum;  // shade: bsdf weight rgb | light-tree root sum; after the light query: light colour rgb | valid flag
+  uint4* ambient;           // packed colour (record format) xy | packed ray zw
 };
 
-enum Counter : uint32_t { kCntTrace = 0, kCntShadow = 1, kCntLightBvh = 2, kCntVertices = 3, kCntNodes = 4, kCntTris = 5, kCntNodesShadow = 6, kCntTrisShadow = 7, kCntCount = 8 };
+// Visibility rays, compacted: every entry is one any-hit ray whose transparency goes to vis[out].
+struct ShadowQueue {
+  float4* origin_dist;  // origin.xyz | distance
+  float4* dir_out;      // direction.xyz | output index (uint bits) = kind * capacity + path index
+  uint4* ids;           // target instance, target triangle (the sampled light) | self instance, self triangle
+  float4* vis;          // [3 * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient
+  uint32_t* light_items;  // path indices that need a light-BVH query
+  uint32_t capacity;
+};
+
+// Per-depth control words (zeroed once per pass).
+enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlStride = 8 };
+
+enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntCount };
 
 }  // namespace lum

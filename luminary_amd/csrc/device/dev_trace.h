@@ -7,162 +7,193 @@
 // so hit distances are the same numbers in world and object space.
 // Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
 // the candidate set only (see light_query).
+//
+// Execution model (gfx950): the ray kernels are instruction-issue bound (rocprofv3 PMC: <25% VALU lane utilisation with the
+// naive loop), so the traversal is written for few instructions per node and full lanes:
+//   * one node visit = 7 x 16-byte loads (near/far planes picked by the ray's direction signs, so no per-axis min/max),
+//     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and branch-free pushes;
+//   * "while-while" loop: all lanes walk inner nodes, then all lanes handle leaves;
+//   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing.
 #pragma once
 
 #include "dev_light.h"
 
 namespace lum {
 
-constexpr uint32_t kHitSky       = 0xFFFFFFFEu;  // cuda/utils.cuh:50-64
+constexpr uint32_t kHitSky        = 0xFFFFFFFEu;  // cuda/utils.cuh:50-64
 constexpr uint32_t kLeaveInstance = 0xFFFFFFFDu;  // stack marker: back from a bottom-level BVH to the top level
+constexpr uint32_t kTraversalDone = 0xFFFFFFFCu;
 constexpr uint32_t kNoInstance    = 0xFFFFFFFFu;
-constexpr int kStackSize          = 96;  // top level + marker + bottom level; the host builder caps each BVH4 at 20 levels
+// Stack bound: the host builder caps the top level at 16 and every bottom level at 26 BVH4 levels (core.hip); a level pushes at
+// most 3 entries and entering an instance pushes one marker: 3*16 + 1 + 3*26 = 127.
+constexpr int kStackSize = 128;
+#ifndef LUM_REFILL
+#define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
+#endif
 
 struct RayStats { uint32_t nodes, tris; };
 
 LUM_DEV float safe_inv(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d; }
 
-// Slab test of the four children of a node: t = lo * inv - o * inv as one fused multiply-add per plane (the box test only
-// decides what gets visited, never a result, so it does not have to follow the IEEE-only contract). Boxes are padded by the
-// builder and the comparison is relaxed so that a triangle accepted by the exact test is never culled.
-LUM_DEV uint32_t test_children(const Bvh4Node& n, V3 inv, V3 oi, float tmax, float tnear[4]) {
-  uint32_t mask = 0;
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const float ax = __builtin_fmaf(n.lo_x[k], inv.x, -oi.x), bx = __builtin_fmaf(n.hi_x[k], inv.x, -oi.x);
-    const float ay = __builtin_fmaf(n.lo_y[k], inv.y, -oi.y), by = __builtin_fmaf(n.hi_y[k], inv.y, -oi.y);
-    const float az = __builtin_fmaf(n.lo_z[k], inv.z, -oi.z), bz = __builtin_fmaf(n.hi_z[k], inv.z, -oi.z);
-    const float t0 = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-    const float t1 = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    tnear[k] = t0;
-    if (n.child[k] != kBvhEmpty && t0 <= t1 * 1.000004f + 1e-30f) mask |= 1u << k;
-  }
-  return mask;
-}
+// Raw three-operand min/max: the box test only decides what gets visited, never a result, so it is outside the IEEE-only contract
+// and does not need the NaN canonicalisation the compiler adds around fminf/fmaxf.
+LUM_DEV float vmax3(float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+LUM_DEV float vmin3(float a, float b, float c) { float r; asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+LUM_DEV float vmax0(float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; }
+LUM_DEV float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-struct TraversalStack {
-  uint32_t node[kStackSize];
-  float tnear[kStackSize];
-  int sp = 0;
-  LUM_DEV void push(uint32_t n, float t) { if (sp < kStackSize) { node[sp] = n; tnear[sp] = t; sp++; } }
+// Ray in the space of the BVH being walked, with the byte offsets of its near/far planes inside a node.
+struct TRay {
+  V3 o, d, inv, noi;  // noi = -(o * inv)
+  uint32_t nx, ny, nz, fx, fy, fz;
+  LUM_DEV void set(V3 origin, V3 dir) {
+    o = origin; d = dir;
+    inv = v3(safe_inv(dir.x), safe_inv(dir.y), safe_inv(dir.z));
+    noi = v3(-(origin.x * inv.x), -(origin.y * inv.y), -(origin.z * inv.z));
+    nx = (inv.x < 0.0f) ? 48u : 0u;  fx = 48u - nx;    // lo_x at 0, hi_x at 48
+    ny = (inv.y < 0.0f) ? 64u : 16u; fy = 80u - ny;    // lo_y at 16, hi_y at 64
+    nz = (inv.z < 0.0f) ? 80u : 32u; fz = 112u - nz;   // lo_z at 32, hi_z at 80
+  }
 };
 
-// Visits the children of `n` that the ray may touch: the nearest becomes `cur`, the others are pushed far-to-near.
-LUM_DEV bool descend(const Bvh4Node& n, V3 inv, V3 oi, float tmax, TraversalStack& stk, uint32_t& cur) {
-  float tn[4];
-  uint32_t mask = test_children(n, inv, oi, tmax, tn);
-  if (mask == 0) return false;
-  int near = -1;
-  float near_t = kFltMax;
-#pragma unroll
-  for (int k = 0; k < 4; k++)
-    if (((mask >> k) & 1u) && tn[k] < near_t) { near_t = tn[k]; near = k; }
-  if (near < 0) near = __ffs((int) mask) - 1;  // all entry distances are FLT_MAX/NaN: any order
-  mask &= ~(1u << near);
-  while (mask) {
-    int far = -1;
-    float ft = -1.0f;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if (((mask >> k) & 1u) && tn[k] >= ft) { ft = tn[k]; far = k; }
-    if (far < 0) far = __ffs((int) mask) - 1;
-    mask &= ~(1u << far);
-    stk.push(n.child[far], tn[far]);
-  }
-  cur = n.child[near];
-  return true;
+LUM_DEV float4 node_f4(const Bvh4Node* nodes, uint32_t byte_offset) {
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + byte_offset);
+}
+LUM_DEV uint4 node_u4(const Bvh4Node* nodes, uint32_t byte_offset) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(nodes) + byte_offset);
 }
 
-// Single-level traversal (light BVH). `on_leaf(first, count, tmax)` may shrink tmax and returns true to stop the query.
-template <typename LeafFn>
-LUM_DEV bool traverse_bvh4(const Bvh4Node* __restrict__ nodes, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
-  const V3 inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  const V3 oi = o * inv;
-  TraversalStack stk;
-  uint32_t cur = 0;
-  while (true) {
-    bool pop = true;
-    if (cur & kBvhLeafBit) {
-      if (on_leaf(cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, tmax)) return true;
-    }
-    else {
-      st.nodes++;
-      pop = !descend(nodes[cur], inv, oi, tmax, stk, cur);
-    }
-    if (pop) {
-      do {
-        if (stk.sp == 0) return false;
-        stk.sp--;
-        cur = stk.node[stk.sp];
-      } while (!(stk.tnear[stk.sp] <= tmax * 1.000004f + 1e-30f));
-    }
-  }
+// Entry distance of one child box, +inf when the segment [0, tmax] misses it. Empty children carry inverted boxes and fail the
+// test on their own. Boxes are padded by the builder and the comparison is relaxed, so a triangle accepted by the exact test is
+// never culled by rounding here.
+LUM_DEV float child_entry(float nx, float ny, float nz, float fx, float fy, float fz, const TRay& r, float tmax) {
+  const float ax = __builtin_fmaf(nx, r.inv.x, r.noi.x), ay = __builtin_fmaf(ny, r.inv.y, r.noi.y), az = __builtin_fmaf(nz, r.inv.z, r.noi.z);
+  const float bx = __builtin_fmaf(fx, r.inv.x, r.noi.x), by = __builtin_fmaf(fy, r.inv.y, r.noi.y), bz = __builtin_fmaf(fz, r.inv.z, r.noi.z);
+  const float tn = vmax3(ax, ay, vmax0(az));
+  const float tf = vmin3(bx, by, vmin2(bz, tmax));
+  return (tn <= __builtin_fmaf(tf, 1.000004f, 1e-30f)) ? tn : __builtin_inff();
 }
 
-LUM_DEV V3 tri_p0(const BvhTri& t) { return v3(t.p0[0], t.p0[1], t.p0[2]); }
-LUM_DEV V3 tri_e1(const BvhTri& t) { return v3(t.e1[0], t.e1[1], t.e1[2]); }
-LUM_DEV V3 tri_e2(const BvhTri& t) { return v3(t.e2[0], t.e2[1], t.e2[2]); }
+LUM_DEV void cswap(float& ka, uint32_t& ca, float& kb, uint32_t& cb) {
+  const bool s = kb < ka;
+  const float k0 = s ? kb : ka, k1 = s ? ka : kb;
+  const uint32_t c0 = s ? cb : ca, c1 = s ? ca : cb;
+  ka = k0; kb = k1; ca = c0; cb = c1;
+}
 
-// Two-level traversal, "while-while" form: every lane first walks inner nodes until it holds a leaf (or is done), then all lanes
-// handle their leaves together; lanes never wait inside a per-instance sub-loop. Top-level leaves hold exactly one instance;
-// entering it pushes a marker, switches the node base and maps the ray with the instance's world->object matrix (an affine map
-// preserves distances along the ray, so `tmax` and the stacked entry distances stay valid across levels).
-// `on_tris(inst, mesh, tris, first, count, o, d, tmax)` returns true to stop.
-constexpr uint32_t kTraversalDone = 0xFFFFFFFCu;
+LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tmax, 1.000004f, 1e-30f); }
 
-template <typename TriFn>
-LUM_DEV bool traverse_scene(const DeviceScene& sc, V3 wo, V3 wd, float& tmax, RayStats& st, TriFn&& on_tris) {
-  TraversalStack stk;
-  V3 o = wo, d = wd;
-  V3 inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-  V3 oi = o * inv;
-  const Bvh4Node* __restrict__ nodes = sc.tlas_nodes;
-  const BvhTri* __restrict__ tris = nullptr;
-  uint32_t inst = kNoInstance, mesh = 0;
-  uint32_t cur = 0;
+// Visits inner node `cur`: returns the nearest child the ray may touch after pushing the others far-to-near, or kBvhEmpty when
+// the ray misses all four (the caller pops).
+LUM_DEV uint32_t visit_node(const Bvh4Node* __restrict__ nodes, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp) {
+  const uint32_t b = cur << 7;
+  const float4 nx = node_f4(nodes, b + r.nx), ny = node_f4(nodes, b + r.ny), nz = node_f4(nodes, b + r.nz);
+  const float4 fx = node_f4(nodes, b + r.fx), fy = node_f4(nodes, b + r.fy), fz = node_f4(nodes, b + r.fz);
+  const uint4 ch = node_u4(nodes, b + 96u);
+  float k0 = child_entry(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, r, tmax);
+  float k1 = child_entry(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, r, tmax);
+  float k2 = child_entry(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, r, tmax);
+  float k3 = child_entry(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, r, tmax);
+  uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
+#ifdef LUM_EXPERIMENT_DOUBLE_LOADS  // measurement only: issue the node's seven loads a second time
+  {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 a0, a1, a2, a3, a4, a5, a6;
+    const uint32_t o0 = b + r.nx, o1 = b + r.ny, o2 = b + r.nz, o3 = b + r.fx, o4 = b + r.fy, o5 = b + r.fz, o6 = b + 96u;
+    asm volatile(
+        "global_load_dwordx4 %0, %7, %14\n global_load_dwordx4 %1, %8, %14\n global_load_dwordx4 %2, %9, %14\n global_load_dwordx4 %3, %10, %14\n"
+        "global_load_dwordx4 %4, %11, %14\n global_load_dwordx4 %5, %12, %14\n global_load_dwordx4 %6, %13, %14\n s_waitcnt vmcnt(0)"
+        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
+        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(o5), "v"(o6), "s"(nodes)
+        : "memory");
+    const f4 t = a0 + a1 + a2 + a3 + a4 + a5 + a6;
+    if (t.x + t.y + t.z + t.w == 1.2345e-33f) k0 = 0.0f;
+  }
+#endif
+  cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
+  const float inf = __builtin_inff();
+  // branch-free pushes: a missed child is written to a slot that the next push (or the next node) overwrites
+  stk[sp] = make_uint2(c3, fbits(k3)); sp += (k3 < inf) ? 1 : 0;
+  stk[sp] = make_uint2(c2, fbits(k2)); sp += (k2 < inf) ? 1 : 0;
+  stk[sp] = make_uint2(c1, fbits(k1)); sp += (k1 < inf) ? 1 : 0;
+  return (k0 < inf) ? c0 : kBvhEmpty;
+}
+
+LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
+
+// ---- the persistent two-level traversal ----
+// A query type Q provides (all per lane):
+//   bool load(sc, idx, origin, dir, tmax)   read item idx; false = nothing to trace
+//   bool on_tris(sc, inst, first, count, o, d, tmax)   test `count` triangles starting at blas_tris[first] against the
+//                                                      object-space ray; may shrink tmax; true = stop this ray
+//   void finish(sc, idx)                    write the result of the finished ray
+// Top-level leaves hold exactly one instance; entering it pushes a marker and maps the ray with the instance's world->object
+// matrix (an affine map preserves distances along the ray, so tmax and the stacked entry distances stay valid across levels).
+template <class Q>
+LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays) {
+  uint2 stk[kStackSize];
+  int sp = 0;
+  TRay r;
+  V3 wo = v3(0.0f, 0.0f, 0.0f), wd = v3(0.0f, 0.0f, 1.0f);
+  float tmax = 0.0f;
+  uint32_t cur = kTraversalDone, inst = kNoInstance, idx = 0;
+  r.set(wo, wd);
+  bool more = true;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const Bvh4Node* __restrict__ nodes = sc.bvh_nodes;
 
   auto pop = [&]() {
     while (true) {
-      if (stk.sp == 0) { cur = kTraversalDone; return; }
-      stk.sp--;
-      cur = stk.node[stk.sp];
-      if (cur == kLeaveInstance) {
-        inst = kNoInstance;
-        nodes = sc.tlas_nodes;
-        o = wo; d = wd;
-        inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-        oi = o * inv;
-        continue;
-      }
-      if (stk.tnear[stk.sp] <= tmax * 1.000004f + 1e-30f) return;
+      if (sp == 0) { cur = kTraversalDone; return; }
+      sp--;
+      const uint2 e = stk[sp];
+      cur = e.x;
+      if (cur == kLeaveInstance) { inst = kNoInstance; r.set(wo, wd); continue; }
+      if (within(bitsf(e.y), tmax)) return;
     }
   };
 
   while (true) {
-    // inner nodes (top or bottom level) until this lane holds a leaf
-    while (!(cur & kBvhLeafBit)) {
-      st.nodes++;
-      if (!descend(nodes[cur], inv, oi, tmax, stk, cur)) pop();
+    const unsigned long long idle = __ballot(cur == kTraversalDone);
+    if (idle != 0ull && more) {  // wave-uniform
+      const uint32_t want = (uint32_t) __popcll(idle);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(cursor, want);
+      base = __builtin_amdgcn_readfirstlane(base);
+      more = base + want < n;
+      if (cur == kTraversalDone) {
+        idx = base + (uint32_t) __popcll(idle & below);
+        if (idx < n && q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; inst = kNoInstance; rays++; }
+      }
     }
-    if (cur == kTraversalDone) return false;
-    if (inst == kNoInstance) {
-      inst = sc.tlas_prims[cur & 0x0FFFFFFFu];
-      mesh = sc.instance_mesh_ids[inst];
-      const float4 r0 = sc.instance_inv[3 * inst], r1 = sc.instance_inv[3 * inst + 1], r2 = sc.instance_inv[3 * inst + 2];
-      const float px = wo.x - r0.w, py = wo.y - r1.w, pz = wo.z - r2.w;
-      o = v3(mat_row_apply(r0.x, r0.y, r0.z, px, py, pz), mat_row_apply(r1.x, r1.y, r1.z, px, py, pz), mat_row_apply(r2.x, r2.y, r2.z, px, py, pz));
-      d = v3(mat_row_apply(r0.x, r0.y, r0.z, wd.x, wd.y, wd.z), mat_row_apply(r1.x, r1.y, r1.z, wd.x, wd.y, wd.z),
-             mat_row_apply(r2.x, r2.y, r2.z, wd.x, wd.y, wd.z));
-      inv = v3(safe_inv(d.x), safe_inv(d.y), safe_inv(d.z));
-      oi = o * inv;
-      nodes = sc.blas_nodes + sc.mesh_node_offset[mesh];
-      tris = sc.blas_tris + sc.mesh_bvhtri_offset[mesh];
-      stk.push(kLeaveInstance, 0.0f);
-      cur = 0;
-    }
-    else {
-      if (on_tris(inst, mesh, tris, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, o, d, tmax)) return true;
-      pop();
+    if (__ballot(cur != kTraversalDone) == 0ull) break;
+
+    while (cur != kTraversalDone) {
+      while (!(cur & kBvhLeafBit)) {
+        st.nodes++;
+        cur = visit_node(nodes, cur, r, tmax, stk, sp);
+        if (cur == kBvhEmpty) pop();
+      }
+      if (cur != kTraversalDone) {
+        if (inst == kNoInstance) {
+          inst = sc.tlas_prims[cur & 0x0FFFFFFFu];
+          const float4 r0 = sc.instance_inv[3 * inst], r1 = sc.instance_inv[3 * inst + 1], r2 = sc.instance_inv[3 * inst + 2];
+          const float px = wo.x - r0.w, py = wo.y - r1.w, pz = wo.z - r2.w;
+          const V3 oo = v3(mat_row_apply(r0.x, r0.y, r0.z, px, py, pz), mat_row_apply(r1.x, r1.y, r1.z, px, py, pz), mat_row_apply(r2.x, r2.y, r2.z, px, py, pz));
+          const V3 od = v3(mat_row_apply(r0.x, r0.y, r0.z, wd.x, wd.y, wd.z), mat_row_apply(r1.x, r1.y, r1.z, wd.x, wd.y, wd.z),
+                           mat_row_apply(r2.x, r2.y, r2.z, wd.x, wd.y, wd.z));
+          r.set(oo, od);
+          stk[sp] = make_uint2(kLeaveInstance, 0u); sp++;
+          cur = sc.mesh_root[sc.instance_mesh_ids[inst]];
+        }
+        else {
+          if (q.on_tris(sc, inst, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
+          else pop();
+        }
+      }
+      if (cur == kTraversalDone) q.finish(sc, idx);
+      if (more && __popcll(__ballot(cur != kTraversalDone)) < LUM_REFILL) break;
     }
   }
 }
@@ -170,50 +201,82 @@ LUM_DEV bool traverse_scene(const DeviceScene& sc, V3 wo, V3 wd, float& tmax, Ra
 struct Hit { uint32_t instance_id, tri_id; float t; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
-LUM_DEV Hit closest_hit(const DeviceScene& sc, V3 origin, V3 dir, bool use_ignore, uint32_t ign_inst, uint32_t ign_tri, RayStats& st) {
-  Hit best{kHitSky, 0u, kFltMax};
-  float tmax = kFltMax;
-  traverse_scene(sc, origin, dir, tmax, st, [&](uint32_t inst, uint32_t, const BvhTri* __restrict__ tris, uint32_t first, uint32_t count, V3 o, V3 d, float& tm) {
+struct ClosestState {
+  bool use_ignore;
+  uint32_t ign_inst, ign_tri;
+  Hit best;
+  LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax}; }
+  LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
     for (uint32_t j = 0; j < count; j++) {
-      const BvhTri tr = tris[first + j];
+      const float4 a = tri_f4(sc.blas_tris, first + j, 0), b = tri_f4(sc.blas_tris, first + j, 1), c = tri_f4(sc.blas_tris, first + j, 2);
+      const uint32_t id = fbits(a.w);
       st.tris++;
-      if (use_ignore && inst == ign_inst && tr.id == ign_tri) continue;
+      if (use_ignore && inst == ign_inst && id == ign_tri) continue;
       F2 uv;
-      const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), o, d, uv);
-      if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && tr.id < best.tri_id)))) {
-        best.instance_id = inst; best.tri_id = tr.id; best.t = t; tm = t;
+      const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
+      if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && id < best.tri_id)))) {
+        best.instance_id = inst; best.tri_id = id; best.t = t; tmax = t;
       }
     }
     return false;
-  });
-  if (best.t == kFltMax) { best.instance_id = kHitSky; best.tri_id = 0; }
-  return best;
-}
+  }
+  LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax} : best; }
+};
 
 // Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light
 // (`target`) and the surface being shaded (`self`).
-LUM_DEV Col shadow_query(const DeviceScene& sc, V3 origin, V3 dir, float dist, uint32_t tgt_inst, uint32_t tgt_tri, uint32_t self_inst,
-                         uint32_t self_tri, RayStats& st) {
-  Col through = splat(1.0f);
-  float tmax = dist;
-  const bool blocked = traverse_scene(sc, origin, dir, tmax, st, [&](uint32_t inst, uint32_t mesh, const BvhTri* __restrict__ tris, uint32_t first, uint32_t count, V3 o, V3 d, float&) {
+struct ShadowState {
+  uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
+  float dist;
+  Col through;
+  bool blocked;
+  LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; through = splat(1.0f); blocked = false; }
+  LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float&, RayStats& st) {
     for (uint32_t j = 0; j < count; j++) {
-      const BvhTri tr = tris[first + j];
+      const float4 a = tri_f4(sc.blas_tris, first + j, 0), b = tri_f4(sc.blas_tris, first + j, 1), c = tri_f4(sc.blas_tris, first + j, 2);
+      const uint32_t id = fbits(a.w);
       st.tris++;
-      if ((inst == tgt_inst && tr.id == tgt_tri) || (inst == self_inst && tr.id == self_tri)) continue;
+      if ((inst == tgt_inst && id == tgt_tri) || (inst == self_inst && id == self_tri)) continue;
       F2 uv;
-      const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), o, d, uv);
+      const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (!(t > kEps && t < dist)) continue;
-      const Material m = load_material(sc, sc.tri_tex[sc.mesh_tri_offset[mesh] + tr.id].w & 0xFFFFu);
+      const Material m = load_material(sc, sc.tri_tex[fbits(b.w)].w & 0xFFFFu);  // b.w = triangle index in the scene arrays
       const bool colored = (m.flags & kDMatColoredTransparency) != 0;
-      if (m.alpha == 1.0f) return true;
+      if (m.alpha == 1.0f) { blocked = true; return true; }
       if (m.alpha == 0.0f && !colored) continue;
       const float tp = 1.0f - m.alpha;
       through = through * (colored ? m.albedo * tp : splat(tp));
     }
     return false;
-  });
-  return blocked ? splat(0.0f) : through;
+  }
+  LUM_DEV Col result() const { return blocked ? splat(0.0f) : through; }
+};
+
+// ---- single-level traversal of the light-only BVH (rare: BSDF-sampled light directions) ----
+template <typename LeafFn>
+LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
+  uint2 stk[kStackSize];
+  int sp = 0;
+  TRay r;
+  r.set(o, d);
+  uint32_t cur = 0;
+  while (true) {
+    if (cur & kBvhLeafBit) {
+      on_leaf(cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, tmax);
+      cur = kBvhEmpty;
+    }
+    else {
+      st.nodes++;
+      cur = visit_node(sc.light_nodes, cur, r, tmax, stk, sp);
+    }
+    if (cur == kBvhEmpty) {
+      do {
+        if (sp == 0) return;
+        sp--;
+        cur = stk[sp].x;
+      } while (!within(bitsf(stk[sp].y), tmax));
+    }
+  }
 }
 
 // Light-BVH query on (eps, FLT_MAX). OptiX leaves the any-hit order unspecified, so the reference's reservoir is restated
@@ -226,14 +289,15 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
   uint32_t best_id = kLightIdInvalid, best_key = 0xFFFFFFFFu, n = 0;
   for (int pass = 0; pass < 2; pass++) {
     float tmax = tstar;
-    traverse_bvh4(sc.light_nodes, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float& tm) {
+    traverse_lights(sc, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float& tm) {
       for (uint32_t j = 0; j < count; j++) {
-        const BvhTri tr = sc.light_tris[first + j];
+        const float4 a = tri_f4(sc.light_tris, first + j, 0), b = tri_f4(sc.light_tris, first + j, 1), c = tri_f4(sc.light_tris, first + j, 2);
+        const uint32_t light = fbits(a.w);
         st.tris++;
-        const uint2 handle = sc.light_tri_handles[tr.id];
+        const uint2 handle = sc.light_tri_handles[light];
         if (handle.x == self_inst && handle.y == self_tri) continue;
         F2 uv;
-        const float t = intersect_triangle(tri_p0(tr), tri_e1(tr), tri_e2(tr), origin, dir, uv);
+        const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), origin, dir, uv);
         if (!(t > kEps && t != kFltMax && t <= tstar)) continue;
         const uint32_t mesh = sc.instance_mesh_ids[handle.x];
         const Material m = load_material(sc, sc.tri_tex[sc.mesh_tri_offset[mesh] + handle.y].w & 0xFFFFu);
@@ -241,11 +305,10 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
         if (pass == 0) { if (m.alpha == 1.0f && t < tstar) { tstar = t; tm = t; } }
         else {
           n++;
-          const uint32_t key = squares32(0xfcbd6e15u, 0x9E3779B9u * tr.id + fbits(random));
-          if (key < best_key || (key == best_key && tr.id < best_id)) { best_key = key; best_id = tr.id; }
+          const uint32_t key = squares32(0xfcbd6e15u, 0x9E3779B9u * light + fbits(random));
+          if (key < best_key || (key == best_key && light < best_id)) { best_key = key; best_id = light; }
         }
       }
-      return false;
     });
   }
   num_hits = n;

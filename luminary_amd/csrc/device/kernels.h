@@ -2,8 +2,12 @@
 //
 // One pass renders `batch` consecutive sample ids of `num_pixels` pixels: path slot = sample_in_batch * num_pixels + pixel.
 // Live paths are kept compacted in a PathQueue (SoA of 16-byte words); every depth runs
-//     trace (closest hit)  ->  shade (context, NEE sampling, bounce, emission, roulette; appends survivors to the other
-//     queue with one wave-aggregated atomic)  ->  shadow (visibility of the NEE work, adds into the path's result slot)
+//     trace (closest hit, persistent waves)
+//     -> shade (context, NEE sampling, bounce, emission, roulette; appends survivors to the other queue and the visibility
+//        rays / light queries it needs to compacted work lists, one wave-aggregated atomic per list)
+//     -> light query (rare: BSDF-sampled directions against the light-only BVH; may append one more visibility ray)
+//     -> shadow rays (any-hit, persistent waves, one ray per lane)
+//     -> resolve (adds the visible light into the path's result slot in the fixed order sampled light, BSDF light, ambient)
 // and the pass ends with an in-order accumulation into the frame moments, which reproduces the reference's
 // one-sample-at-a-time sums bit for bit (cuda/accumulation.cuh:63-84).
 // Reference schedule: device/device_renderer.c:53-134; per-kernel restatements cite their sources below.
@@ -19,6 +23,9 @@ enum PathState : uint32_t {  // cuda/utils.cuh:114-121
 enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 constexpr int kBlock = 256;
+#ifndef LUM_TRACE_WAVES
+#define LUM_TRACE_WAVES 4  // minimum waves per SIMD the ray kernels are compiled for
+#endif
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
 #endif
@@ -96,18 +103,29 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams 
 }
 
 // ---- closest-hit pass (replaces optix/optix_kernel_raytrace.cu:147-183) ----
-__global__ __launch_bounds__(kBlock) void k_trace(DeviceScene sc, PathQueue q, const uint32_t* count, uint64_t* counters) {
-  const uint32_t n = *count;
+struct TraceQuery : ClosestState {
+  PathQueue q;
+  LUM_DEV bool load(const DeviceScene&, uint32_t i, V3& o, V3& d, float& tmax) {
+    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
+    const uint32_t state = q.aux[i].w;
+    const uint2 ign = *reinterpret_cast<const uint2*>(&q.hit_id[i]);
+    begin((state & kStUseIgnoreHandle) != 0, ign.x, ign.y);
+    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = kFltMax;
+    return true;
+  }
+  LUM_DEV void finish(const DeviceScene&, uint32_t i) {
+    const Hit h = result();
+    reinterpret_cast<float*>(&q.origin_t[i])[3] = h.t;
+    *reinterpret_cast<uint2*>(&q.hit_id[i]) = make_uint2(h.instance_id, h.tri_id);
+  }
+};
+
+__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_trace(DeviceScene sc, PathQueue q, uint32_t* ctrl, uint64_t* counters) {
   RayStats st{0, 0};
   uint32_t rays = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
-    const uint4 aux = q.aux[i], hid = q.hit_id[i];
-    const Hit h = closest_hit(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), (aux.w & kStUseIgnoreHandle) != 0, hid.x, hid.y, st);
-    q.origin_t[i] = make_float4(o4.x, o4.y, o4.z, h.t);
-    q.hit_id[i]   = make_uint4(h.instance_id, h.tri_id, hid.z, hid.w);
-    rays++;
-  }
+  TraceQuery tq;
+  tq.q = q;
+  trace_items(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris);
 }
 
@@ -173,17 +191,21 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 }
 
 // ---- shading pass: cuda/geometry.cuh:11-180 (+ miss handling of cuda/sky.cuh:609-633, roulette cuda/directives.cuh:11-32) ----
-__global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, float4* results, const uint32_t* count_in,
-                                                  uint32_t* count_out, uint32_t depth_const, uint64_t* counters) {
-  const uint32_t n = *count_in;
+__global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
+                                                                    uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
+  const uint32_t n = ctrl[kCtlPaths];
+  uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   const Col sky = (sc.sky_mode == kSkyConstantColor) ? col(sc.sky_constant_color[0], sc.sky_constant_color[1], sc.sky_constant_color[2]) : splat(0.0f);
   uint32_t vertices = 0;
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
   for (uint32_t round = 0; round < rounds; round++) {
     const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
-    bool survive = false;
+    bool survive = false, want_geo = false, want_amb = false, want_lq = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
+    float4 s_origin, s_geo_dir, s_amb_dir; uint4 s_geo_ids;
     if (i < n) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
@@ -201,25 +223,38 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);
-        float root_sum = 0.0f;
-        float4 geo_rd = make_float4(0.0f, 0.0f, 0.0f, 0.0f), geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
+        float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
         float4 bs_rp = make_float4(0.0f, 0.0f, 1.0f, 0.0f), bs_ws = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, 0.0f);
+        s_geo_ids = make_uint4(0xFFFFFFFFu, 0u, hid.x, hid.y);
         if (geo_allowed) {
           const LightSample ls = sample_light(sc, g, smp);
-          root_sum = ls.root_sum;
-          geo_rd = make_float4(ls.ray.x, ls.ray.y, ls.ray.z, ls.dist);
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
+          if (ls.light_id != kLightIdInvalid) {
+            want_geo = true;
+            const uint2 target = sc.light_tri_handles[ls.light_id];
+            s_geo_dir = make_float4(ls.ray.x, ls.ray.y, ls.ray.z, ls.dist);
+            s_geo_ids.x = target.x; s_geo_ids.y = target.y;
+          }
           const LightDirSample lb = sample_light_direction(sc, g, smp);
           bs_rp = make_float4(lb.ray.x, lb.ray.y, lb.ray.z, lb.probability);
-          bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, root_sum);
+          if (lb.probability != 0.0f) {
+            want_lq = true;
+            bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, ls.root_sum);
+          }
         }
         const BounceSample bounce = sample_bounce(sc, g, smp, 0);
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
         if (sc.sky_mode != kSkyDefault) {
           const U2 c = record_pack(sky * bounce.weight), r = ray_pack(bounce.ray);
           amb = make_uint4(c.x, c.y, r.x, r.y);
+          if (c.x != 0 || c.y != 0) {
+            want_amb = true;
+            const V3 ar = ray_unpack(r);
+            s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+          }
         }
-        nee.geo_ray_dist[i] = geo_rd; nee.geo_color_light[i] = geo_cl;
+        nee.geo_color_light[i] = geo_cl;
         nee.bsdf_ray_prob[i] = bs_rp; nee.bsdf_weight_sum[i] = bs_ws;
         nee.ambient[i] = amb;
 
@@ -271,19 +306,42 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         }
       }
     }
-    // wave-aggregated append: one atomic per wave
+    // wave-aggregated appends: one atomic per wave and list
     const unsigned long long ballot = __ballot(survive);
     if (ballot) {
-      const uint32_t lane = threadIdx.x & 63;
-      const uint32_t rank = __popcll(ballot & ((1ull << lane) - 1ull));
       uint32_t base = 0;
-      const int leader = __ffsll((long long) ballot) - 1;
-      if ((int) lane == leader) base = atomicAdd(count_out, (uint32_t) __popcll(ballot));
-      base = __shfl(base, leader);
+      if (lane == 0) base = atomicAdd(count_out, (uint32_t) __popcll(ballot));
+      base = __builtin_amdgcn_readfirstlane(base);
       if (survive) {
-        const uint32_t j = base + rank;
+        const uint32_t j = base + (uint32_t) __popcll(ballot & below);
         out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
       }
+    }
+    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb);
+    if (bg | ba) {
+      const uint32_t ng = (uint32_t) __popcll(bg);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, ng + (uint32_t) __popcll(ba));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_geo) {
+        const uint32_t j = base + (uint32_t) __popcll(bg & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w);
+        sq.dir_out[j] = make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i));
+        sq.ids[j] = s_geo_ids;
+      }
+      if (want_amb) {
+        const uint32_t j = base + ng + (uint32_t) __popcll(ba & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w);
+        sq.dir_out[j] = make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+      }
+    }
+    const unsigned long long bl = __ballot(want_lq);
+    if (bl) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlLightItems, (uint32_t) __popcll(bl));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_lq) sq.light_items[base + (uint32_t) __popcll(bl & below)] = i;
     }
   }
 #pragma unroll
@@ -291,43 +349,31 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
   if ((threadIdx.x & 63) == 0 && vertices) atomicAdd((unsigned long long*) &counters[kCntVertices], (unsigned long long) vertices);
 }
 
-// ---- shadow pass: optix/optix_kernel_shadow.cu:15-100, cuda/direct_lighting.cuh:445-669 ----
-__global__ __launch_bounds__(kBlock) void k_shadow(DeviceScene sc, PathQueue in, NeeQueue nee, float4* results, const uint32_t* count_in, uint32_t depth_const,
-                                                   uint64_t* counters) {
-  const uint32_t n = *count_in;
-  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+// ---- light queries: BSDF-sampled direction against the light-only BVH (cuda/direct_lighting.cuh:586-667) ----
+__global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const,
+                                                        uint64_t* counters) {
+  const uint32_t n = ctrl[kCtlLightItems];
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
   RayStats st{0, 0};
-  uint32_t rays = 0, light_queries = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint4 hid = in.hit_id[i];
-    if (hid.x == kHitSky) continue;
-    const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
-    const uint4 aux = in.aux[i];
-    const V3 hit_origin = v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w;
-    const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
-    Col acc = splat(0.0f);
-    {  // sampled light (direct_lighting.cuh:445-464)
-      const float4 rd = nee.geo_ray_dist[i], cl = nee.geo_color_light[i];
-      const uint32_t light_id = fbits(cl.w);
-      Col vis = splat(0.0f);
-      if (light_id != kLightIdInvalid && geo_allowed) {
-        const uint2 target = sc.light_tri_handles[light_id];
-        vis = shadow_query(sc, hit_origin, v3(rd.x, rd.y, rd.z), rd.w, target.x, target.y, hid.x, hid.y, st);
-        rays++;
-      }
-      acc = acc + col(cl.x, cl.y, cl.z) * vis;
-    }
-    {  // BSDF-sampled direction against the light-only BVH (direct_lighting.cuh:586-667)
+  uint32_t light_queries = 0;
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t item = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    bool want = false;
+    float4 s_origin, s_dir; uint4 s_ids; uint32_t i = 0;
+    if (item < n) {
+      i = sq.light_items[item];
+      const uint4 hid = in.hit_id[i];
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const V3 hit_origin = v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w;
       const float4 rp = nee.bsdf_ray_prob[i], ws = nee.bsdf_weight_sum[i];
       const V3 ray = v3(rp.x, rp.y, rp.z);
-      bool valid = geo_allowed && rp.w != 0.0f;
-      uint32_t light_id = kLightIdInvalid, num_hits = 0;
-      if (valid) {
-        const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
-        light_id = light_query(sc, hit_origin, ray, hid.x, hid.y, smp.next1(kRndLightBsdfTrace), num_hits, st);
-        light_queries++;
-      }
-      valid = valid && light_id != kLightIdInvalid;
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      uint32_t num_hits = 0;
+      const uint32_t light_id = light_query(sc, hit_origin, ray, hid.x, hid.y, smp.next1(kRndLightBsdfTrace), num_hits, st);
+      light_queries++;
+      bool valid = light_id != kLightIdInvalid;
       float dist = kFltMax;
       uint2 handle = make_uint2(0xFFFFFFFFu, 0u);
       Col lc = splat(0.0f);
@@ -344,26 +390,89 @@ __global__ __launch_bounds__(kBlock) void k_shadow(DeviceScene sc, PathQueue in,
         }
         else valid = false;
       }
-      Col vis = splat(0.0f);
-      if (valid) { vis = shadow_query(sc, hit_origin, ray, dist, handle.x, handle.y, hid.x, hid.y, st); rays++; }
-      acc = acc + lc * vis;
-    }
-    // sun: disabled in constant-colour mode (direct_lighting.cuh:262); procedural sky is out of scope
-    {  // ambient (direct_lighting.cuh:521-584)
-      const uint4 amb = nee.ambient[i];
-      const bool allowed = sc.sky_mode != kSkyDefault;
-      if (allowed) {
-        Col vis = splat(0.0f);
-        if (amb.x != 0 || amb.y != 0) { vis = shadow_query(sc, hit_origin, ray_unpack(U2{amb.z, amb.w}), kFltMax, 0xFFFFFFFFu, 0u, hid.x, hid.y, st); rays++; }
-        acc = acc + record_unpack(U2{amb.x, amb.y}) * vis;
+      nee.bsdf_weight_sum[i] = make_float4(lc.r, lc.g, lc.b, valid ? 1.0f : 0.0f);
+      if (valid) {
+        want = true;
+        s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, dist);
+        s_dir = make_float4(ray.x, ray.y, ray.z, bitsf(sq.capacity + i));
+        s_ids = make_uint4(handle.x, handle.y, hid.x, hid.y);
       }
     }
-    add_to_result(results, fbits(d4.w), acc * record_unpack(U2{aux.x, aux.y}));
+    const unsigned long long bw = __ballot(want);
+    if (bw) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, (uint32_t) __popcll(bw));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want) {
+        const uint32_t j = base + (uint32_t) __popcll(bw & below);
+        sq.origin_dist[j] = s_origin; sq.dir_out[j] = s_dir; sq.ids[j] = s_ids;
+      }
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) light_queries += __shfl_down(light_queries, off);
   if ((threadIdx.x & 63) == 0 && light_queries) atomicAdd((unsigned long long*) &counters[kCntLightBvh], (unsigned long long) light_queries);
+  flush_stats(counters, st, 0, kCntLightBvh, kCntNodesLight, kCntTrisLight);
+}
+
+// ---- visibility rays (optix/optix_kernel_shadow.cu:15-100, cuda/optix_anyhit.cuh:49-139) ----
+struct ShadowQuery : ShadowState {
+  ShadowQueue sq;
+  uint32_t out;
+  LUM_DEV bool load(const DeviceScene&, uint32_t j, V3& o, V3& d, float& tmax) {
+    const float4 o4 = sq.origin_dist[j], d4 = sq.dir_out[j];
+    begin(sq.ids[j], o4.w);
+    out = fbits(d4.w);
+    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = o4.w;
+    return true;
+  }
+  LUM_DEV void finish(const DeviceScene&, uint32_t) {
+    const Col v = result();
+    sq.vis[out] = make_float4(v.r, v.g, v.b, 0.0f);
+  }
+};
+
+__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, uint32_t* ctrl, uint64_t* counters) {
+  RayStats st{0, 0};
+  uint32_t rays = 0;
+  ShadowQuery q;
+  q.sq = sq;
+  trace_items(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays);
   flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow);
+}
+
+// ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
+__global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, float4* results, const uint32_t* ctrl) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
+    if (hid.x == kHitSky) continue;
+    const uint4 aux = in.aux[i];
+    const uint32_t slot = fbits(in.dir_slot[i].w);
+    const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
+    Col acc = splat(0.0f);
+    {  // sampled light (direct_lighting.cuh:445-464)
+      const float4 cl = nee.geo_color_light[i];
+      Col vis = splat(0.0f);
+      if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = sq.vis[i]; vis = col(v.x, v.y, v.z); }
+      acc = acc + col(cl.x, cl.y, cl.z) * vis;
+    }
+    {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
+      const float4 lc = nee.bsdf_weight_sum[i];
+      Col vis = splat(0.0f);
+      if (lc.w != 0.0f) { const float4 v = sq.vis[sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+      acc = acc + col(lc.x, lc.y, lc.z) * vis;
+    }
+    // sun: disabled in constant-colour mode (direct_lighting.cuh:262); procedural sky is out of scope
+    if (sc.sky_mode != kSkyDefault) {  // ambient (direct_lighting.cuh:521-584)
+      const uint4 amb = nee.ambient[i];
+      Col vis = splat(0.0f);
+      if (amb.x != 0 || amb.y != 0) { const float4 v = sq.vis[2u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+      acc = acc + record_unpack(U2{amb.x, amb.y}) * vis;
+    }
+    add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
+  }
 }
 
 // ---- accumulation (cuda/accumulation.cuh:63-84): samples of a pixel are added in sample order ----
@@ -382,17 +491,27 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* results, ui
 }
 
 // ---- standalone closest-hit entry for traversal tests and the trace micro-benchmark ----
-__global__ __launch_bounds__(kBlock) void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
-                                                       uint32_t* out, uint64_t* counters) {
+struct RaysQuery : ClosestState {
+  const float* origins; const float* dirs; const uint32_t* ignore; uint32_t* out;
+  LUM_DEV bool load(const DeviceScene&, uint32_t i, V3& o, V3& d, float& tmax) {
+    const bool ign = ignore != nullptr && ignore[2 * i] != 0xFFFFFFFFu;
+    begin(ign, ign ? ignore[2 * i] : 0u, ign ? ignore[2 * i + 1] : 0u);
+    o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]); d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]); tmax = kFltMax;
+    return true;
+  }
+  LUM_DEV void finish(const DeviceScene&, uint32_t i) {
+    const Hit h = result();
+    out[3 * i] = h.instance_id; out[3 * i + 1] = h.tri_id; out[3 * i + 2] = fbits(h.t);
+  }
+};
+
+__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
+                                                       uint32_t* out, uint32_t* cursor, uint64_t* counters) {
   RayStats st{0, 0};
   uint32_t rays = 0;
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const bool ign = ignore != nullptr && ignore[2 * i] != 0xFFFFFFFFu;
-    const Hit h = closest_hit(sc, v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), ign,
-                              ign ? ignore[2 * i] : 0u, ign ? ignore[2 * i + 1] : 0u, st);
-    out[3 * i] = h.instance_id; out[3 * i + 1] = h.tri_id; out[3 * i + 2] = fbits(h.t);
-    rays++;
-  }
+  RaysQuery q;
+  q.origins = origins; q.dirs = dirs; q.ignore = ignore; q.out = out;
+  trace_items(sc, n, cursor, q, st, rays);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris);
 }
 

@@ -174,7 +174,7 @@ Bvh4 collapse(const Builder& b) {
 
 }  // namespace
 
-Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf) {
+Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) {
   if (count == 0) {
     Bvh4 out;
     Bvh4Node n;
@@ -201,8 +201,7 @@ Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf) {
     b.nodes.reserve(2 * (size_t) count);
     b.build(0, count, 0);
     Bvh4 out = collapse(b);
-    // the traversal stack holds 64 entries and a level pushes at most 3
-    if (out.max_depth <= 20 || attempt == 1) return out;
+    if (out.max_depth <= max_depth) return out;
   }
   return Bvh4();
 }

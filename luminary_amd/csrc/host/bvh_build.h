@@ -19,7 +19,9 @@ struct Bvh4 {
   uint32_t max_depth = 0;
 };
 
-// Builds a BVH4 over `count` boxes. Leaves hold at most `max_leaf` (<= kBvhLeafMaxTri) primitives.
-Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri);
+// Builds a BVH4 over `count` boxes. Leaves hold at most `max_leaf` (<= kBvhLeafMaxTri) primitives. The tree has at most
+// `max_depth` BVH4 levels (the kernels' traversal stack is sized for that): a SAH tree that is deeper is rebuilt with median
+// splits; if that is still too deep the result is empty (nodes.empty()).
+Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri, uint32_t max_depth = 20);
 
 }  // namespace lum

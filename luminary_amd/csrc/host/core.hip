@@ -37,15 +37,16 @@ struct LumContext {
   void* work_block = nullptr;
   PathQueue queue[2]{};
   NeeQueue nee{};
+  ShadowQueue shadow{};
   float4* d_results = nullptr;
-  uint32_t* d_counts = nullptr;   // one per depth + 1
+  uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
   // profiling
   bool profiling = false;
   struct Stamp { hipEvent_t a, b; int kernel; };
   std::vector<Stamp> stamps;
-  double kernel_ms[LUMC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
-  uint32_t kernel_launches[LUMC_KERNEL_COUNT] = {0, 0, 0, 0, 0};
+  double kernel_ms[LUMC_KERNEL_COUNT] = {};
+  uint32_t kernel_launches[LUMC_KERNEL_COUNT] = {};
 };
 
 namespace {
@@ -87,9 +88,9 @@ void free_work(LumContext* ctx) {
 int ensure_work(LumContext* ctx, uint32_t paths) {
   if (paths <= ctx->capacity) return 0;
   free_work(ctx);
-  // per path: 2 queues x 64 B + NEE 80 B + result 16 B = 224 B
+  // per path: 2 queues x 64 B + NEE 64 B + result 16 B + up to 3 visibility rays x (48 B + 16 B result) + 4 B light-query index
   const size_t n = paths;
-  const size_t bytes = n * (2 * 64 + 80 + 16);
+  const size_t bytes = n * (2 * 64 + 64 + 16 + 3 * 64 + 4);
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += sz; return r; };
@@ -99,19 +100,32 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
     ctx->queue[k].aux      = (uint4*) take(n * 16);
     ctx->queue[k].hit_id   = (uint4*) take(n * 16);
   }
-  ctx->nee.geo_ray_dist    = (float4*) take(n * 16);
   ctx->nee.geo_color_light = (float4*) take(n * 16);
   ctx->nee.bsdf_ray_prob   = (float4*) take(n * 16);
   ctx->nee.bsdf_weight_sum = (float4*) take(n * 16);
   ctx->nee.ambient         = (uint4*) take(n * 16);
   ctx->d_results           = (float4*) take(n * 16);
+  ctx->shadow.origin_dist  = (float4*) take(3 * n * 16);
+  ctx->shadow.dir_out      = (float4*) take(3 * n * 16);
+  ctx->shadow.ids          = (uint4*) take(3 * n * 16);
+  ctx->shadow.vis          = (float4*) take(3 * n * 16);
+  ctx->shadow.light_items  = (uint32_t*) take(n * 4);
+  ctx->shadow.capacity     = paths;
   ctx->capacity = paths;
   return 0;
 }
 
+constexpr uint32_t kCtrlRows = 68;  // depths 0..63, one row past the last depth, spare, lumc_trace_closest
+
 inline uint32_t grid_for(uint32_t n) {
   const uint32_t blocks = (n + kBlock - 1) / kBlock;
   return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);  // 256 CUs x 8 resident blocks, grid-stride beyond that
+}
+
+// Persistent ray kernels: enough blocks to fill every CU at the kernels' occupancy; the waves pull work from a global cursor.
+inline uint32_t grid_persistent(uint32_t n) {
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  return blocks < 1 ? 1 : (blocks > 1280 ? 1280 : blocks);  // 256 CUs x 5 blocks of 4 waves
 }
 
 struct Launch {
@@ -219,7 +233,8 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   HIP_TRY(ctx, hipGetDeviceCount(&count));
   if (device_ordinal < 0 || device_ordinal >= count) { ctx->error = "no such HIP device"; return 1; }
   HIP_TRY(ctx, hipSetDevice(device_ordinal));
-  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_counts, sizeof(uint32_t) * 128));
+  HIP_TRY(ctx, hipMalloc((void**) &ctx->d_ctrl, sizeof(uint32_t) * kCtlStride * kCtrlRows));
+  HIP_TRY(ctx, hipMemset(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * kCtrlRows));
   HIP_TRY(ctx, hipMalloc((void**) &ctx->d_counters, sizeof(uint64_t) * LUMC_CNT_COUNT));
   HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(uint64_t) * LUMC_CNT_COUNT));
   return 0;
@@ -235,7 +250,7 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_pixels) (void) hipFree(ctx->d_pixels);
   if (ctx->d_first_moment) (void) hipFree(ctx->d_first_moment);
   if (ctx->d_second_moment) (void) hipFree(ctx->d_second_moment);
-  if (ctx->d_counts) (void) hipFree(ctx->d_counts);
+  if (ctx->d_ctrl) (void) hipFree(ctx->d_ctrl);
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   delete ctx;
 }
@@ -267,49 +282,29 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   }
   if (upload(ctx, v->bluenoise_2d, 65536, &sc.bluenoise_2d)) return 1;
 
-  // ---- bottom-level BVHs, one per mesh, concatenated ----
-  std::vector<Bvh4Node> blas_nodes;
-  std::vector<BvhTri> blas_tris((size_t) total_tris);
-  std::vector<uint32_t> node_off(v->num_meshes + 1, 0), tri_off(v->num_meshes + 1, 0);
+  // ---- top-level BVH over the instances' world boxes + one bottom-level BVH per mesh, in ONE node array with absolute indices ----
+  // Depth caps keep the traversal stack bounded (dev_trace.h kStackSize): top level <= 16, bottom levels <= 26 BVH4 levels.
   std::vector<Aabb> mesh_box(v->num_meshes);
+  std::vector<std::vector<Aabb>> tri_boxes(v->num_meshes);
   for (uint32_t m = 0; m < v->num_meshes; m++) {
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
-    std::vector<Aabb> boxes(nt);
+    tri_boxes[m].resize(nt);
     Aabb mb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
     for (uint32_t t = 0; t < nt; t++) {
       const float* p = v->vertices + (size_t) (t0 + t) * 12;
-      boxes[t] = tri_box(p, p + 4, p + 8);
-      for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], boxes[t].lo[k]); mb.hi[k] = std::max(mb.hi[k], boxes[t].hi[k]); }
+      tri_boxes[m][t] = tri_box(p, p + 4, p + 8);
+      for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], tri_boxes[m][t].lo[k]); mb.hi[k] = std::max(mb.hi[k], tri_boxes[m][t].hi[k]); }
     }
     mesh_box[m] = mb;
-    Bvh4 bvh = build_bvh4(boxes.data(), nt);
-    node_off[m] = (uint32_t) blas_nodes.size();
-    tri_off[m] = t0;
-    // leaf ranges index the per-mesh triangle array; inner child ids are relative to the mesh's first node
-    blas_nodes.insert(blas_nodes.end(), bvh.nodes.begin(), bvh.nodes.end());
-    for (uint32_t i = 0; i < nt; i++) {
-      const uint32_t t = bvh.prims[i];
-      const float* p = v->vertices + (size_t) (t0 + t) * 12;
-      BvhTri& bt = blas_tris[(size_t) t0 + i];
-      for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
-      bt.id = t; bt.pad0 = 0; bt.pad1 = 0;
-    }
   }
-  node_off[v->num_meshes] = (uint32_t) blas_nodes.size();
-  tri_off[v->num_meshes] = total_tris;
-  if (blas_nodes.empty()) { Bvh4 e = build_bvh4(nullptr, 0); blas_nodes = e.nodes; }
-  if (upload(ctx, blas_nodes.data(), blas_nodes.size(), &sc.blas_nodes)) return 1;
-  if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
-  if (upload(ctx, node_off.data(), node_off.size(), &sc.mesh_node_offset)) return 1;
-  if (upload(ctx, tri_off.data(), tri_off.size(), &sc.mesh_bvhtri_offset)) return 1;
+  std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
+  for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
+  if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_inv)) return 1;
 
-  // ---- top-level BVH over the world boxes of the instances ----
+  std::vector<Bvh4Node> nodes;
   {
     std::vector<Aabb> boxes;
     std::vector<uint32_t> ids;
-    std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
-    for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
-    if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_inv)) return 1;
     for (uint32_t i = 0; i < v->num_instances; i++) {
       const uint32_t m = v->instance_mesh_ids[i];
       if (m >= v->num_meshes || v->mesh_tri_offset[m + 1] == v->mesh_tri_offset[m]) continue;
@@ -318,21 +313,54 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       boxes.push_back(wb);
       ids.push_back(i);
     }
-    Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1);  // one instance per top-level leaf (dev_trace.h)
+    Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1, 16);  // one instance per top-level leaf (dev_trace.h)
+    if (tlas.nodes.empty()) { ctx->error = "top-level BVH exceeds 16 levels"; return 1; }
     std::vector<uint32_t> prims(tlas.prims.size());
     for (size_t i = 0; i < prims.size(); i++) prims[i] = ids[tlas.prims[i]];
     if (prims.empty()) prims.push_back(0);
-    if (upload(ctx, tlas.nodes.data(), tlas.nodes.size(), &sc.tlas_nodes)) return 1;
     if (upload(ctx, prims.data(), prims.size(), &sc.tlas_prims)) return 1;
+    nodes = tlas.nodes;  // root at index 0, child indices already absolute
     sc.tlas_num_nodes = (uint32_t) tlas.nodes.size();
     ctx->bvh_stats[2] = tlas.nodes.size();
   }
+  std::vector<BvhTri> blas_tris((size_t) total_tris + 1);
+  std::memset(blas_tris.data(), 0, sizeof(BvhTri) * blas_tris.size());
+  std::vector<uint32_t> mesh_root(v->num_meshes + 1, 0);
+  for (uint32_t m = 0; m < v->num_meshes; m++) {
+    const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
+    Bvh4 bvh = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+    if (bvh.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
+    const uint32_t base = (uint32_t) nodes.size();
+    mesh_root[m] = base;
+    for (Bvh4Node n : bvh.nodes) {
+      for (int k = 0; k < 4; k++) {
+        if (n.child[k] == kBvhEmpty) continue;
+        if (n.child[k] & kBvhLeafBit) n.child[k] += t0;  // leaf ranges index blas_tris directly (28 bits)
+        else n.child[k] += base;
+      }
+      nodes.push_back(n);
+    }
+    for (uint32_t i = 0; i < nt; i++) {
+      const uint32_t t = bvh.prims[i];
+      const float* p = v->vertices + (size_t) (t0 + t) * 12;
+      BvhTri& bt = blas_tris[(size_t) t0 + i];
+      for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
+      bt.id = t; bt.scene_index = t0 + t; bt.pad1 = 0;
+    }
+    tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit();
+  }
+  if (total_tris >= (1u << 28) || nodes.size() >= (1u << 25)) { ctx->error = "scene too large for 28-bit leaf ranges / 32-bit node offsets"; return 1; }
+  if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
+  if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
+  if (upload(ctx, mesh_root.data(), mesh_root.size(), &sc.mesh_root)) return 1;
+  ctx->bvh_stats[0] = nodes.size() - sc.tlas_num_nodes;
   // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
   {
     const uint32_t nl = (v->light_tree_root && v->light_bvh_tris) ? v->num_lights : 0;
     std::vector<Aabb> boxes(nl);
     for (uint32_t l = 0; l < nl; l++) { const float* p = v->light_bvh_tris + (size_t) l * 12; boxes[l] = tri_box(p, p + 4, p + 8); }
-    Bvh4 lb = build_bvh4(boxes.data(), nl);
+    Bvh4 lb = build_bvh4(boxes.data(), nl, kBvhLeafMaxTri, 40);
+    if (lb.nodes.empty()) { ctx->error = "light BVH exceeds 40 levels"; return 1; }
     std::vector<BvhTri> tris(nl ? nl : 1);
     std::memset(tris.data(), 0, sizeof(BvhTri) * tris.size());
     for (uint32_t i = 0; i < nl; i++) {
@@ -346,7 +374,6 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     sc.light_num_nodes = (uint32_t) lb.nodes.size();
     ctx->bvh_stats[3] = lb.nodes.size();
   }
-  ctx->bvh_stats[0] = blas_nodes.size();
   ctx->bvh_stats[1] = total_tris;
 
   sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights;
@@ -433,29 +460,36 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
     const uint32_t batch = std::min(samples_per_pass, num_samples - done);
     const uint32_t N = P * batch;
     PassParams pp{ctx->d_pixels, P, batch, first_sample + done};
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_counts, 0, sizeof(uint32_t) * (max_depth + 2), stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (max_depth + 2), stream));
     {
       Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
-      hipLaunchKernelGGL(k_generate, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_counts);
+      hipLaunchKernelGGL(k_generate, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
     }
     int cur = 0;
     for (uint32_t depth = 0; depth <= max_depth; depth++) {
       // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
       const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
-      const uint32_t grid = grid_for(N);
+      uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
       {
         Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->d_counts + depth, ctx->d_counters);
+        hipLaunchKernelGGL(k_trace, dim3(grid_persistent(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters);
       }
       {
         Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->d_results,
-                           ctx->d_counts + depth, ctx->d_counts + depth + 1, depth_const, ctx->d_counters);
+        hipLaunchKernelGGL(k_shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
+                           depth_const, ctx->d_counters);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
+        hipLaunchKernelGGL(k_light_query, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
       }
       {
         Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
-        hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->d_results, ctx->d_counts + depth, depth_const,
-                           ctx->d_counters);
+        hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(N)), dim3(kBlock), 0, stream, sc, ctx->shadow, ctrl, ctx->d_counters);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+        hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
       }
       cur ^= 1;
     }
@@ -511,8 +545,10 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_trace_closest: no scene"; return 1; }
   if (n == 0) return 0;
   hipStream_t stream = (hipStream_t) stream_;
+  uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
+  HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  hipLaunchKernelGGL(k_trace_rays, dim3(grid_for(n)), dim3(kBlock), 0, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, ctx->d_counters);
+  hipLaunchKernelGGL(k_trace_rays, dim3(grid_persistent(n)), dim3(kBlock), 0, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
