@@ -227,23 +227,41 @@ LUM_DEV float eval_diffuse_over_vndf(V3 V, float roughness, float NdotL, float N
 }
 
 // ---- lobes (bsdf_utils.cuh:383-587) ----
+// The energy-compensation lookups depend on (NdotV, roughness, material flags) only, i.e. on the vertex and not on the direction
+// being evaluated, so they are fetched once per vertex and reused by every evaluation there (same values as fetching each time).
+struct Energy { float conductor, glossy, dielectric; };
+LUM_DEV Energy energy_terms(const DeviceScene& sc, const MatParams& p, float NdotV) {
+  Energy e{1.0f, 0.0f, 1.0f};
+  const float roughness = p.roughness();
+  if ((p.flags & kMatSubstrateMask) == 0) {
+    e.conductor = lut2d(sc.lut_conductor, NdotV, roughness);
+    if ((p.flags & kMatMetallic) == 0) e.glossy = lut2d(sc.lut_glossy, NdotV, roughness);
+  }
+  else {
+    const float ior = roughness;  // sic: bsdf_utils.cuh:517 reads the roughness parameter
+    const bool use_inv = ior > 1.0f;
+    const float w = use_inv ? (ior - 1.0f) * 0.5f : (1.0f / ior - 1.0f) * 0.5f;
+    e.dielectric = lut3d(use_inv ? sc.lut_dielectric_inv : sc.lut_dielectric, NdotV, roughness, w);
+  }
+  return e;
+}
 LUM_DEV float single_scatter_term(const RayTerms& c, int hint, float roughness, float ior_quirk, float inv_pdf) {
   if (hint == kHintGeneral) return eval_microfacet(roughness, c.NdotH, c.NdotL, c.NdotV) * inv_pdf;
   if (hint == kHintMicrofacet) return eval_microfacet_over_vndf(c.V, roughness, c.NdotL, c.NdotV);
   if (hint == kHintDiffuse) return eval_microfacet_over_diffuse(roughness, c.NdotH, c.NdotL, c.NdotV);
   return eval_microfacet(roughness, c.NdotH, c.NdotL, c.NdotV) / pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior_quirk);
 }
-LUM_DEV Col lobe_conductor(const DeviceScene& sc, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
+LUM_DEV Col lobe_conductor(const Energy& en, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
   if (c.NdotL <= 0.0f || c.NdotV <= 0.0f) return splat(0.0f);
   if ((p.flags & kMatSubstrateMask) != 0 || (p.flags & kMatMetallic) == 0) return splat(0.0f);
   const float roughness = p.roughness();
   const float ss = single_scatter_term(c, hint, roughness, (hint == kHintRefraction) ? roughness : 1.0f, inv_pdf);
   const Col albedo = p.albedo();
-  const float da = lut2d(sc.lut_conductor, c.NdotV, roughness);
+  const float da = en.conductor;
   const Col fres = fresnel_schlick(albedo, shadowed_f90(albedo), c.HdotV);
   return fres * ss + albedo * (fres * (((1.0f / da) - 1.0f) * ss));
 }
-LUM_DEV Col lobe_glossy(const DeviceScene& sc, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
+LUM_DEV Col lobe_glossy(const Energy& en, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
   if (c.NdotL <= 0.0f || c.NdotV <= 0.0f) return splat(0.0f);
   if ((p.flags & kMatSubstrateMask) != 0 || (p.flags & kMatMetallic) != 0) return splat(0.0f);
   const float roughness = p.roughness();
@@ -255,12 +273,12 @@ LUM_DEV Col lobe_glossy(const DeviceScene& sc, const MatParams& p, const RayTerm
   else if (hint == kHintMicrofacet) diff = eval_diffuse_over_vndf(c.V, roughness, c.NdotL, c.NdotH, c.NdotV);
   else diff = pdf_diffuse(c.NdotL) / pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, iorq);
   const Col albedo = p.albedo();
-  const float cda = lut2d(sc.lut_conductor, c.NdotV, roughness), gda = lut2d(sc.lut_glossy, c.NdotV, roughness);
+  const float cda = en.conductor, gda = en.glossy;
   const Col f0 = col(0.04f, 0.04f, 0.04f);
   const Col fres = fresnel_schlick(f0, shadowed_f90(f0), c.HdotV);
   return fres * (ss / cda) + albedo * (diff * (1.0f - gda));
 }
-LUM_DEV Col lobe_dielectric(const DeviceScene& sc, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
+LUM_DEV Col lobe_dielectric(const Energy& en, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
   if (c.NdotL <= 0.0f || c.NdotV <= 0.0f) return splat(0.0f);
   if ((p.flags & kMatSubstrateMask) != kMatTranslucent) return splat(0.0f);
   const float roughness = p.roughness();
@@ -278,16 +296,14 @@ LUM_DEV Col lobe_dielectric(const DeviceScene& sc, const MatParams& p, const Ray
     else term = eval_microfacet(roughness, c.NdotH, c.NdotL, c.NdotV) / pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior);
     term *= c.fresnel_dielectric;
   }
-  const bool use_inv = ior > 1.0f;
-  const float w = use_inv ? (ior - 1.0f) * 0.5f : (1.0f / ior - 1.0f) * 0.5f;
-  term /= lut3d(use_inv ? sc.lut_dielectric_inv : sc.lut_dielectric, c.NdotV, roughness, w);
+  term /= en.dielectric;
   if (ior == 1.0f && c.is_refraction) term = (hint == kHintRefraction) ? 1.0f : 0.0f;
   return p.albedo() * term;
 }
-LUM_DEV Col eval_layers(const DeviceScene& sc, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
+LUM_DEV Col eval_layers(const Energy& en, const MatParams& p, const RayTerms& c, int hint, float inv_pdf) {
   const float opacity = p.opacity();
-  if (c.is_refraction) return lobe_dielectric(sc, p, c, hint, inv_pdf) * opacity;
-  return ((lobe_conductor(sc, p, c, hint, inv_pdf) + lobe_glossy(sc, p, c, hint, inv_pdf)) + lobe_dielectric(sc, p, c, hint, inv_pdf)) * opacity;
+  if (c.is_refraction) return lobe_dielectric(en, p, c, hint, inv_pdf) * opacity;
+  return ((lobe_conductor(en, p, c, hint, inv_pdf) + lobe_glossy(en, p, c, hint, inv_pdf)) + lobe_dielectric(en, p, c, hint, inv_pdf)) * opacity;
 }
 
 // bsdf.cuh:11-50
@@ -311,11 +327,11 @@ LUM_DEV RayTerms analyze_direction(const MatParams& p, V3 normal, V3 V, V3 L) {
   return c;
 }
 // bsdf.cuh:52-64
-LUM_DEV Col eval_with_face_normal(const DeviceScene& sc, const MatParams& p, const RayTerms& c, int hint, V3 L, V3 face_normal, float inv_pdf) {
+LUM_DEV Col eval_with_face_normal(const Energy& en, const MatParams& p, const RayTerms& c, int hint, V3 L, V3 face_normal, float inv_pdf) {
   const float fl = dot(face_normal, L);
   const float flip = c.is_refraction ? -1.0f : 1.0f;
   if (fl * flip < kEps) return splat(0.0f);
-  return eval_layers(sc, p, c, hint, inv_pdf);
+  return eval_layers(en, p, c, hint, inv_pdf);
 }
 // bsdf.cuh:103-133
 LUM_DEV RayTerms sampled_direction_terms(const MatParams& p, V3 normal, V3 V, V3 H, V3 L, bool is_refraction) {
@@ -337,17 +353,29 @@ LUM_DEV RayTerms sampled_direction_terms(const MatParams& p, V3 normal, V3 V, V3
   c.V = V;
   return c;
 }
-// bsdf.cuh:73-83
-LUM_DEV Col eval_bsdf(const DeviceScene& sc, const GeoContext& g, V3 L, int hint, bool& is_refraction, float inv_pdf) {
+// bsdf.cuh:73-83; `en` = energy_terms(sc, g.params, world_ndotv(g))
+LUM_DEV float world_ndotv(const GeoContext& g) { return saturate(dot(g.normal, g.V)); }
+LUM_DEV Col eval_bsdf(const Energy& en, const GeoContext& g, V3 L, int hint, bool& is_refraction, float inv_pdf) {
   const RayTerms c = analyze_direction(g.params, g.normal, g.V, L);
   is_refraction = c.is_refraction;
-  return eval_with_face_normal(sc, g.params, c, hint, L, normal_unpack(g.face_normal_packed), inv_pdf);
+  return eval_with_face_normal(en, g.params, c, hint, L, normal_unpack(g.face_normal_packed), inv_pdf);
+}
+
+// Shading frame with the normal on +z, shared by the bounce and the BSDF-driven light direction (bsdf.cuh:150-156, light_bsdf.cuh:30-36).
+struct LocalFrame { Quat to_z; V3 V, face_normal; Energy energy; };
+LUM_DEV LocalFrame local_frame(const DeviceScene& sc, const GeoContext& g) {
+  LocalFrame f;
+  f.to_z = rotation_to_z(g.normal);
+  f.V = qapply(f.to_z, g.V);
+  f.face_normal = qapply(f.to_z, normal_unpack(g.face_normal_packed));
+  f.energy = energy_terms(sc, g.params, saturate(dot(v3(0.0f, 0.0f, 1.0f), f.V)));
+  return f;
 }
 
 struct BounceSample { V3 ray; Col weight; bool transparent_pass, microfacet_based; };
 
 // Three-technique resampled bounce (bsdf.cuh:138-301). `set` picks RandomSet::BSDF<set> (random.cuh:120-129).
-LUM_DEV BounceSample sample_bounce(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, uint32_t set) {
+LUM_DEV BounceSample sample_bounce(const LocalFrame& lf, const GeoContext& g, const Sampler& smp, uint32_t set) {
   const MatParams& p = g.params;
   BounceSample out;
   const float opacity = p.opacity();
@@ -360,9 +388,8 @@ LUM_DEV BounceSample sample_bounce(const DeviceScene& sc, const GeoContext& g, c
       return out;
     }
   }
-  const Quat to_z = rotation_to_z(g.normal);
-  const V3 Vl = qapply(to_z, g.V);
-  const V3 fnl = qapply(to_z, normal_unpack(g.face_normal_packed));
+  const Quat to_z = lf.to_z;
+  const V3 Vl = lf.V, fnl = lf.face_normal;
   const V3 up = v3(0.0f, 0.0f, 1.0f);
   const uint32_t substrate = p.flags & kMatSubstrateMask;
   const bool with_diffuse = (substrate == 0) && ((p.flags & kMatMetallic) == 0);
@@ -377,7 +404,7 @@ LUM_DEV BounceSample sample_bounce(const DeviceScene& sc, const GeoContext& g, c
     const V3 m = sample_vndf_bounded(Vl, roughness, smp.next2(kRndBsdfReflection + set));
     const V3 ray = reflect(Vl, m);
     const RayTerms c = sampled_direction_terms(p, up, Vl, m, ray, false);
-    const Col eval = eval_with_face_normal(sc, p, c, kHintMicrofacet, ray, fnl, 1.0f);
+    const Col eval = eval_with_face_normal(lf.energy, p, c, kHintMicrofacet, ray, fnl, 1.0f);
     const float pdf = pdf_vndf_bounded(Vl, roughness, c.NdotH, c.NdotV);
     const float dp = with_diffuse ? pdf_diffuse(c.NdotL) : 0.0f;
     const float rp = with_refraction ? pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior) : 0.0f;
@@ -391,7 +418,7 @@ LUM_DEV BounceSample sample_bounce(const DeviceScene& sc, const GeoContext& g, c
     const V3 ray = sample_ray_sphere(r2.x, r2.y);
     const V3 m = normalize(Vl + ray);
     const RayTerms c = sampled_direction_terms(p, up, Vl, m, ray, false);
-    const Col eval = eval_with_face_normal(sc, p, c, kHintDiffuse, ray, fnl, 1.0f);
+    const Col eval = eval_with_face_normal(lf.energy, p, c, kHintDiffuse, ray, fnl, 1.0f);
     const float pdf = pdf_diffuse(c.NdotL);
     const float mp = pdf_vndf_bounded(Vl, roughness, c.NdotH, c.NdotV);
     const float rp = with_refraction ? pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior) : 0.0f;
@@ -411,7 +438,7 @@ LUM_DEV BounceSample sample_bounce(const DeviceScene& sc, const GeoContext& g, c
     const V3 m = sample_vndf_caps(Vl, roughness, smp.next2(kRndBsdfRefraction + set));
     const V3 ray = refract(Vl, m, ior, total_reflection);
     const RayTerms c = sampled_direction_terms(p, up, Vl, m, ray, !total_reflection);
-    const Col eval = eval_with_face_normal(sc, p, c, kHintRefraction, ray, fnl, 1.0f);
+    const Col eval = eval_with_face_normal(lf.energy, p, c, kHintRefraction, ray, fnl, 1.0f);
     float mis = 1.0f;
     if (total_reflection) {
       const float pdf = pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior);

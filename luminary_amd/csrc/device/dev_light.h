@@ -91,12 +91,15 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const 
       const float prob = (target > 0.0f) ? target / total : 0.0f;
       if (prob == 0.0f) continue;
       sum += target;
+      // The eight lanes divide by one of two numbers per child; the reciprocals are formed once (the reference, built with
+      // --use_fast_math, multiplies by a reciprocal here as well: cuda/ris.cuh:138-148).
+      const float inv_accept = 1.0f / prob, inv_reject = 1.0f / (1.0f - prob);
 #pragma unroll
       for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
         const bool accept = lane_random[l] < prob;
         lane_target[l] = accept ? target : lane_target[l];
-        const float shift = accept ? 0.0f : prob, scale = accept ? prob : 1.0f - prob;
-        lane_random[l] = clamp_random((lane_random[l] - shift) / scale);
+        const float shifted = accept ? lane_random[l] : lane_random[l] - prob;
+        lane_random[l] = clamp_random(shifted * (accept ? inv_accept : inv_reject));
         if (accept) lane_pick[l] = s * 8 + c;
       }
     }
@@ -208,13 +211,12 @@ struct LightDirSample { V3 ray; Col weight; float probability; };
 LUM_DEV float light_dir_roughness(float r) { return lerpf(r, 1.0f, 0.04f); }
 LUM_DEV float light_dir_rr(float r) { return remap01(r, 0.5f, 0.1f); }
 
-LUM_DEV LightDirSample sample_light_direction(const DeviceScene& sc, const GeoContext& g, const Sampler& smp) {
+LUM_DEV LightDirSample sample_light_direction(const LocalFrame& lf, const GeoContext& g, const Sampler& smp) {
   LightDirSample out;
   out.ray = v3(0.0f, 0.0f, 1.0f); out.weight = splat(0.0f); out.probability = 0.0f;
   const MatParams& p = g.params;
-  const Quat to_z = rotation_to_z(g.normal);
-  const V3 Vl = qapply(to_z, g.V);
-  const V3 fnl = qapply(to_z, normal_unpack(g.face_normal_packed));
+  const Quat to_z = lf.to_z;
+  const V3 Vl = lf.V, fnl = lf.face_normal;
   const V3 up = v3(0.0f, 0.0f, 1.0f);
   const bool with_refraction = (p.flags & kMatSubstrateMask) == kMatTranslucent;
   const uint32_t num_tech = with_refraction ? 2 : 1;
@@ -230,7 +232,7 @@ LUM_DEV LightDirSample sample_light_direction(const DeviceScene& sc, const GeoCo
     const V3 ray = reflect(Vl, m);
     const RayTerms c = sampled_direction_terms(p, up, Vl, m, ray, false);
     const float pdf = pdf_vndf_bounded(Vl, sr, c.NdotH, c.NdotV);
-    out.weight = eval_with_face_normal(sc, p, c, kHintGeneral, ray, fnl, 1.0f / pdf);
+    out.weight = eval_with_face_normal(lf.energy, p, c, kHintGeneral, ray, fnl, 1.0f / pdf);
     out.ray = ray;
     out.probability = (1.0f - refr_prob) * pdf;
   }
@@ -241,7 +243,7 @@ LUM_DEV LightDirSample sample_light_direction(const DeviceScene& sc, const GeoCo
     const V3 ray = refract(Vl, m, ior, total_reflection);
     const RayTerms c = sampled_direction_terms(p, up, Vl, m, ray, !total_reflection);
     const float pdf = pdf_refraction(sr, c.NdotH, c.NdotV, c.HdotV, c.HdotL, ior);
-    out.weight = eval_with_face_normal(sc, p, c, kHintGeneral, ray, fnl, 1.0f / pdf);
+    out.weight = eval_with_face_normal(lf.energy, p, c, kHintGeneral, ray, fnl, 1.0f / pdf);
     out.ray = ray;
     out.probability = refr_prob * pdf;
   }
@@ -286,13 +288,17 @@ struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum;
 
 LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp) {
   const TreeWork work = tree_prepass(sc, g, smp);
+  const Energy energy = energy_terms(sc, g.params, world_ndotv(g));
   LightSample out;
   out.light_id = kLightIdInvalid; out.ray = v3(0.0f, 0.0f, 0.0f); out.color = splat(0.0f); out.dist = 0.0f;
   Reservoir rv;
   rv.random = smp.next1(kRndLightGeoResampling);
   rv.reset();
+#ifndef LUM_ABLATE_LANES
+#define LUM_ABLATE_LANES kLightTreeOutputs  // measurement only: fewer resampling lanes evaluated (results are wrong)
+#endif
 #pragma nounroll
-  for (uint32_t lane = 0; lane < kLightTreeOutputs; lane++) {
+  for (uint32_t lane = 0; lane < LUM_ABLATE_LANES; lane++) {
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
     const uint2 handle = sc.light_tri_handles[pick.light_id];
@@ -305,7 +311,7 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     if (dist == kFltMax) continue;
     Col lc = tri_light_color(sc, tl);
     bool is_refraction;
-    const Col bw = eval_bsdf(sc, g, ray, kHintGeneral, is_refraction, 1.0f);
+    const Col bw = eval_bsdf(energy, g, ray, kHintGeneral, is_refraction, 1.0f);
     const float mis = mis_for_light_sample(g, ray, tl, lc, dist, sa, work.root_sum);
     lc = (lc * bw) * mis;
     if (rv.add(importance(lc), pick.weight * sa)) { out.light_id = pick.light_id; out.ray = ray; out.color = lc; out.dist = dist; }

@@ -28,7 +28,7 @@ constexpr uint32_t kNoInstance    = 0xFFFFFFFFu;
 // most 3 entries and entering an instance pushes one marker: 3*16 + 1 + 3*26 = 127.
 constexpr int kStackSize = 128;
 #ifndef LUM_REFILL
-#define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
+#define LUM_REFILL 24  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
 #endif
 
 struct RayStats { uint32_t nodes, tris; };

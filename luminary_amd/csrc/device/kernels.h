@@ -223,12 +223,18 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);
+        const LocalFrame lf = local_frame(sc, g);
         float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
         float4 bs_rp = make_float4(0.0f, 0.0f, 1.0f, 0.0f), bs_ws = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, 0.0f);
         s_geo_ids = make_uint4(0xFFFFFFFFu, 0u, hid.x, hid.y);
+#ifndef LUM_ABLATE
+#define LUM_ABLATE 0  // measurement only: 1 skips light sampling, 2 the BSDF light direction, 4 the bounce (results are wrong)
+#endif
         if (geo_allowed) {
-          const LightSample ls = sample_light(sc, g, smp);
+          LightSample ls;
+          if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
+          else ls = sample_light(sc, g, smp);
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
           if (ls.light_id != kLightIdInvalid) {
             want_geo = true;
@@ -236,14 +242,18 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
             s_geo_dir = make_float4(ls.ray.x, ls.ray.y, ls.ray.z, ls.dist);
             s_geo_ids.x = target.x; s_geo_ids.y = target.y;
           }
-          const LightDirSample lb = sample_light_direction(sc, g, smp);
+          LightDirSample lb;
+          if (LUM_ABLATE & 2) { lb.ray = v3(0.0f, 0.0f, 1.0f); lb.weight = splat(0.0f); lb.probability = 0.0f; }
+          else lb = sample_light_direction(lf, g, smp);
           bs_rp = make_float4(lb.ray.x, lb.ray.y, lb.ray.z, lb.probability);
           if (lb.probability != 0.0f) {
             want_lq = true;
             bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, ls.root_sum);
           }
         }
-        const BounceSample bounce = sample_bounce(sc, g, smp, 0);
+        BounceSample bounce;
+        if (LUM_ABLATE & 4) { bounce.ray = g.normal; bounce.weight = splat(0.5f); bounce.transparent_pass = false; bounce.microfacet_based = false; }
+        else bounce = sample_bounce(lf, g, smp, 0);
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
         if (sc.sky_mode != kSkyDefault) {
           const U2 c = record_pack(sky * bounce.weight), r = ray_pack(bounce.ray);

@@ -57,12 +57,14 @@ static inline bool ris_add(RISReservoir* r, float target, float sampling_weight)
 }
 static inline float ris_sampling_weight(const RISReservoir* r) { return (r->selected_target > 0.0f) ? r->sum_weight / r->selected_target : 0.0f; }
 
+/* ris.cuh:138-148. The lanes of one stream divide by one of two numbers per sample; the reciprocals are formed once per sample
+ * and multiplied in (the reference is built with --use_fast_math, where the division is a reciprocal multiply as well). */
 typedef struct { float selected_target, random; } RISLane;
-static inline bool ris_lane_add(RISLane* l, float prob, float target) {
+static inline bool ris_lane_add(RISLane* l, float prob, float target, float inv_accept, float inv_reject) {
   const bool acc = l->random < prob;
   l->selected_target = acc ? target : l->selected_target;
-  const float shift = acc ? 0.0f : prob, scale = acc ? prob : 1.0f - prob;
-  l->random = rng_saturate((l->random - shift) / scale);
+  const float shifted = acc ? l->random : l->random - prob;
+  l->random = rng_saturate(shifted * (acc ? inv_accept : inv_reject));
   return acc;
 }
 
@@ -133,8 +135,9 @@ static inline LTWork light_tree_prepass(const OracleScene* s, const GeoCtx* g, c
       const float prob = (target > 0.0f) ? target / agg_sum : 0.0f;
       if (prob == 0.0f) continue;
       sum += target;
+      const float inv_accept = 1.0f / prob, inv_reject = 1.0f / (1.0f - prob);
       for (uint32_t l = 0; l < LIGHT_TREE_NUM_OUTPUTS; l++)
-        if (ris_lane_add(&lane[l], prob, target)) selected[l] = sec * 8 + c;
+        if (ris_lane_add(&lane[l], prob, target, inv_accept, inv_reject)) selected[l] = sec * 8 + c;
     }
   }
   LTWork w;
