@@ -23,9 +23,24 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-NODE_BYTES, TRI_BYTES = 128, 48  # BVH4 node = 128 B, triangle = 48 B (DESIGN.md "Algorithmic bytes")
+NODE_BYTES, TRI_BYTES = 112, 48  # one node visit fetches 7 x 16 B of a 128-B BVH4 node; triangle = 48 B (DESIGN.md "Algorithmic bytes")
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
-IO_SHADOW_BYTES = 48 + 16  # visibility ray item + its transparency result
+IO_SHADOW_BYTES = 24 + 4 + 12  # origin+dir, tmax, RGB visibility
+TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+
+
+def measured_traffic(workload, kernel, spp_per_step):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc pass of this same command (tools/pmc_traffic.py
+    writes profiles/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE)."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        e = t[workload][kernel]
+        if int(e["spp_per_step"]) != int(spp_per_step):
+            return None
+        return float(e["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402
@@ -166,7 +181,7 @@ def main():
     dom_bytes, dom_ms, dom_n = (bytes_trace, trace_ms, trace_n) if dominant == "trace" else (bytes_shadow, shadow_ms, shadow_n)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
+                "traffic": measured_traffic(args.workload, "k_trace" if dominant == "trace" else "k_shadow_rays", args.samples_per_pass), "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1)}
     cpu = cpu_baseline(view, args.cpu_budget) if args.cpu_budget > 0 else None
     out = {

@@ -51,11 +51,10 @@ struct DeviceScene {
   const uint16_t* lut_dielectric;
   const uint16_t* lut_dielectric_inv;
   // acceleration structures (node indices and leaf ranges are absolute, so one base pointer serves both levels)
-  const Bvh4Node* bvh_nodes;       // [0, tlas_num_nodes): top level over instances (leaves index tlas_prims); then every mesh's BVH
+  const Bvh4Node* bvh_nodes;       // [0, tlas_num_nodes): top level over instances (leaves index tlas_leaves); then every mesh's BVH
   const BvhTri* blas_tris;         // all meshes, traversal order
-  const uint32_t* mesh_root;       // node index of mesh m's root
-  const uint32_t* tlas_prims;      // instance ids in traversal order
-  const float4* instance_inv;      // 3 x float4 per instance: rows of the world->object matrix, .w = translation component
+  const float4* tlas_leaves;       // 4 x float4 per top-level leaf (traversal order): rows of the instance's world->object matrix
+                                   // (.w = translation component), then uint bits {instance id, root node of its mesh, 0, 0}
   const Bvh4Node* light_nodes;     // leaves index light_tris
   const BvhTri* light_tris;        // world space, id = light id
   uint32_t num_meshes, num_instances, num_materials, num_lights;

@@ -27,8 +27,12 @@ constexpr uint32_t kNoInstance    = 0xFFFFFFFFu;
 // Stack bound: the host builder caps the top level at 16 and every bottom level at 26 BVH4 levels (core.hip); a level pushes at
 // most 3 entries and entering an instance pushes one marker: 3*16 + 1 + 3*26 = 127.
 constexpr int kStackSize = 128;
+#ifndef LUM_CHUNK_MAX
+#define LUM_CHUNK_MAX 256u  // most items a wave reserves per atomic
+#endif
+constexpr uint32_t kBlockThreads = 256;
 #ifndef LUM_REFILL
-#define LUM_REFILL 24  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
+#define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
 #endif
 
 struct RayStats { uint32_t nodes, tris; };
@@ -85,7 +89,7 @@ LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tm
 
 // Visits inner node `cur`: returns the nearest child the ray may touch after pushing the others far-to-near, or kBvhEmpty when
 // the ray misses all four (the caller pops).
-LUM_DEV uint32_t visit_node(const Bvh4Node* __restrict__ nodes, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp) {
+LUM_DEV uint32_t visit_node(const Bvh4Node* __restrict__ nodes, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp, uint2& top) {
   const uint32_t b = cur << 7;
   const float4 nx = node_f4(nodes, b + r.nx), ny = node_f4(nodes, b + r.ny), nz = node_f4(nodes, b + r.nz);
   const float4 fx = node_f4(nodes, b + r.fx), fy = node_f4(nodes, b + r.fy), fz = node_f4(nodes, b + r.fz);
@@ -112,14 +116,48 @@ LUM_DEV uint32_t visit_node(const Bvh4Node* __restrict__ nodes, uint32_t cur, co
 #endif
   cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
   const float inf = __builtin_inff();
-  // branch-free pushes: a missed child is written to a slot that the next push (or the next node) overwrites
-  stk[sp] = make_uint2(c3, fbits(k3)); sp += (k3 < inf) ? 1 : 0;
-  stk[sp] = make_uint2(c2, fbits(k2)); sp += (k2 < inf) ? 1 : 0;
-  stk[sp] = make_uint2(c1, fbits(k1)); sp += (k1 < inf) ? 1 : 0;
+  // Branch-free pushes. The newest entry lives in registers (`top`), older ones in scratch: a push spills the old top to a slot
+  // that is only kept if the push is real, so a pop never waits for a scratch load before it can fetch the next node.
+  {
+    const bool v = k3 < inf;
+    stk[sp] = top; sp += v ? 1 : 0;
+    top = v ? make_uint2(c3, fbits(k3)) : top;
+  }
+  {
+    const bool v = k2 < inf;
+    stk[sp] = top; sp += v ? 1 : 0;
+    top = v ? make_uint2(c2, fbits(k2)) : top;
+  }
+  {
+    const bool v = k1 < inf;
+    stk[sp] = top; sp += v ? 1 : 0;
+    top = v ? make_uint2(c1, fbits(k1)) : top;
+  }
   return (k0 < inf) ? c0 : kBvhEmpty;
 }
 
+// Pops the newest entry into (node, tnear) and refills the register top from scratch. The bottom of the stack is a sentinel
+// (kTraversalDone) that is never removed.
+LUM_DEV uint2 stack_pop(uint2* __restrict__ stk, int& sp, uint2& top) {
+  const uint2 e = top;
+  if (sp > 0) { sp--; top = stk[sp]; }
+  else top = make_uint2(kTraversalDone, 0u);
+  return e;
+}
+LUM_DEV void stack_push(uint2* __restrict__ stk, int& sp, uint2& top, uint2 e) { stk[sp] = top; sp++; top = e; }
+
 LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
+
+// All triangles of a leaf are fetched before the first test, so a leaf costs one memory round trip instead of one per triangle.
+struct LeafTris {
+  float4 a[kBvhLeafMaxTri], b[kBvhLeafMaxTri], c[kBvhLeafMaxTri];
+  LUM_DEV void load(const BvhTri* __restrict__ tris, uint32_t first, uint32_t count) {
+#pragma unroll
+    for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
+      if (j < count) { a[j] = tri_f4(tris, first + j, 0); b[j] = tri_f4(tris, first + j, 1); c[j] = tri_f4(tris, first + j, 2); }
+    }
+  }
+};
 
 // ---- the persistent two-level traversal ----
 // A query type Q provides (all per lane):
@@ -143,28 +181,43 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   const unsigned long long below = (1ull << lane) - 1ull;
   const Bvh4Node* __restrict__ nodes = sc.bvh_nodes;
 
+  uint2 top = make_uint2(kTraversalDone, 0u);
   auto pop = [&]() {
     while (true) {
-      if (sp == 0) { cur = kTraversalDone; return; }
-      sp--;
-      const uint2 e = stk[sp];
+      const uint2 e = stack_pop(stk, sp, top);
       cur = e.x;
+      if (cur == kTraversalDone) return;
       if (cur == kLeaveInstance) { inst = kNoInstance; r.set(wo, wd); continue; }
       if (within(bitsf(e.y), tmax)) return;
     }
   };
 
+  // Work distribution: a wave reserves a chunk of consecutive items with one atomic and hands them to its idle lanes; a single
+  // global cursor bumped once per refill would serialise every wave of the GPU on one L2 atomic.
+  const uint32_t waves = gridDim.x * (kBlockThreads / 64u);
+  uint32_t chunk = n / (waves * 2u);
+  chunk = (min(max(chunk, 64u), LUM_CHUNK_MAX) + 63u) & ~63u;
+  uint32_t chunk_next = 0, chunk_end = 0;
+
   while (true) {
     const unsigned long long idle = __ballot(cur == kTraversalDone);
     if (idle != 0ull && more) {  // wave-uniform
-      const uint32_t want = (uint32_t) __popcll(idle);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(cursor, want);
-      base = __builtin_amdgcn_readfirstlane(base);
-      more = base + want < n;
-      if (cur == kTraversalDone) {
-        idx = base + (uint32_t) __popcll(idle & below);
-        if (idx < n && q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; inst = kNoInstance; rays++; }
+      if (chunk_next >= chunk_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, chunk);
+        base = __builtin_amdgcn_readfirstlane(base);
+        chunk_next = base;
+        chunk_end = min(base + chunk, n);
+        more = base < n;
+      }
+      if (more) {
+        const uint32_t avail = chunk_end - chunk_next, want = (uint32_t) __popcll(idle);
+        const uint32_t rank = (uint32_t) __popcll(idle & below);
+        if (cur == kTraversalDone && rank < avail) {
+          idx = chunk_next + rank;
+          if (q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; top = make_uint2(kTraversalDone, 0u); inst = kNoInstance; rays++; }
+        }
+        chunk_next += min(want, avail);
       }
     }
     if (__ballot(cur != kTraversalDone) == 0ull) break;
@@ -172,20 +225,21 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     while (cur != kTraversalDone) {
       while (!(cur & kBvhLeafBit)) {
         st.nodes++;
-        cur = visit_node(nodes, cur, r, tmax, stk, sp);
+        cur = visit_node(nodes, cur, r, tmax, stk, sp, top);
         if (cur == kBvhEmpty) pop();
       }
       if (cur != kTraversalDone) {
         if (inst == kNoInstance) {
-          inst = sc.tlas_prims[cur & 0x0FFFFFFFu];
-          const float4 r0 = sc.instance_inv[3 * inst], r1 = sc.instance_inv[3 * inst + 1], r2 = sc.instance_inv[3 * inst + 2];
+          const float4* __restrict__ leaf = sc.tlas_leaves + 4u * (cur & 0x0FFFFFFFu);
+          const float4 r0 = leaf[0], r1 = leaf[1], r2 = leaf[2], meta = leaf[3];
+          inst = fbits(meta.x);
           const float px = wo.x - r0.w, py = wo.y - r1.w, pz = wo.z - r2.w;
           const V3 oo = v3(mat_row_apply(r0.x, r0.y, r0.z, px, py, pz), mat_row_apply(r1.x, r1.y, r1.z, px, py, pz), mat_row_apply(r2.x, r2.y, r2.z, px, py, pz));
           const V3 od = v3(mat_row_apply(r0.x, r0.y, r0.z, wd.x, wd.y, wd.z), mat_row_apply(r1.x, r1.y, r1.z, wd.x, wd.y, wd.z),
                            mat_row_apply(r2.x, r2.y, r2.z, wd.x, wd.y, wd.z));
           r.set(oo, od);
-          stk[sp] = make_uint2(kLeaveInstance, 0u); sp++;
-          cur = sc.mesh_root[sc.instance_mesh_ids[inst]];
+          stack_push(stk, sp, top, make_uint2(kLeaveInstance, 0u));
+          cur = fbits(meta.y);
         }
         else {
           if (q.on_tris(sc, inst, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
@@ -207,8 +261,12 @@ struct ClosestState {
   Hit best;
   LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax}; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
-    for (uint32_t j = 0; j < count; j++) {
-      const float4 a = tri_f4(sc.blas_tris, first + j, 0), b = tri_f4(sc.blas_tris, first + j, 1), c = tri_f4(sc.blas_tris, first + j, 2);
+    LeafTris lt;
+    lt.load(sc.blas_tris, first, count);
+#pragma unroll
+    for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
+      if (j >= count) break;
+      const float4 a = lt.a[j], b = lt.b[j], c = lt.c[j];
       const uint32_t id = fbits(a.w);
       st.tris++;
       if (use_ignore && inst == ign_inst && id == ign_tri) continue;
@@ -232,8 +290,12 @@ struct ShadowState {
   bool blocked;
   LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; through = splat(1.0f); blocked = false; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float&, RayStats& st) {
-    for (uint32_t j = 0; j < count; j++) {
-      const float4 a = tri_f4(sc.blas_tris, first + j, 0), b = tri_f4(sc.blas_tris, first + j, 1), c = tri_f4(sc.blas_tris, first + j, 2);
+    LeafTris lt;
+    lt.load(sc.blas_tris, first, count);
+#pragma unroll
+    for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
+      if (j >= count) break;
+      const float4 a = lt.a[j], b = lt.b[j], c = lt.c[j];
       const uint32_t id = fbits(a.w);
       st.tris++;
       if ((inst == tgt_inst && id == tgt_tri) || (inst == self_inst && id == self_tri)) continue;
@@ -257,6 +319,7 @@ template <typename LeafFn>
 LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
   uint2 stk[kStackSize];
   int sp = 0;
+  uint2 top = make_uint2(kTraversalDone, 0u);
   TRay r;
   r.set(o, d);
   uint32_t cur = 0;
@@ -267,14 +330,15 @@ LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, Ray
     }
     else {
       st.nodes++;
-      cur = visit_node(sc.light_nodes, cur, r, tmax, stk, sp);
+      cur = visit_node(sc.light_nodes, cur, r, tmax, stk, sp, top);
     }
     if (cur == kBvhEmpty) {
-      do {
-        if (sp == 0) return;
-        sp--;
-        cur = stk[sp].x;
-      } while (!within(bitsf(stk[sp].y), tmax));
+      while (true) {
+        const uint2 e = stack_pop(stk, sp, top);
+        cur = e.x;
+        if (cur == kTraversalDone) return;
+        if (within(bitsf(e.y), tmax)) break;
+      }
     }
   }
 }

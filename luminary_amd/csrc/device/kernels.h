@@ -24,7 +24,7 @@ enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 }
 
 constexpr int kBlock = 256;
 #ifndef LUM_TRACE_WAVES
-#define LUM_TRACE_WAVES 4  // minimum waves per SIMD the ray kernels are compiled for
+#define LUM_TRACE_WAVES 3  // minimum waves per SIMD the ray kernels are compiled for
 #endif
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
@@ -436,9 +436,13 @@ struct ShadowQuery : ShadowState {
     o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = o4.w;
     return true;
   }
-  LUM_DEV void finish(const DeviceScene&, uint32_t) {
+  LUM_DEV void finish(const DeviceScene&, uint32_t j) {
     const Col v = result();
+#ifdef LUM_EXPERIMENT_VIS_IN_ITEM_ORDER
+    sq.vis[j] = make_float4(v.r, v.g, v.b, 0.0f);
+#else
     sq.vis[out] = make_float4(v.r, v.g, v.b, 0.0f);
+#endif
   }
 };
 

@@ -299,9 +299,9 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   }
   std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
   for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
-  if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_inv)) return 1;
 
   std::vector<Bvh4Node> nodes;
+  std::vector<uint32_t> tlas_order;  // instance id of every top-level leaf
   {
     std::vector<Aabb> boxes;
     std::vector<uint32_t> ids;
@@ -315,10 +315,8 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     }
     Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1, 16);  // one instance per top-level leaf (dev_trace.h)
     if (tlas.nodes.empty()) { ctx->error = "top-level BVH exceeds 16 levels"; return 1; }
-    std::vector<uint32_t> prims(tlas.prims.size());
-    for (size_t i = 0; i < prims.size(); i++) prims[i] = ids[tlas.prims[i]];
-    if (prims.empty()) prims.push_back(0);
-    if (upload(ctx, prims.data(), prims.size(), &sc.tlas_prims)) return 1;
+    tlas_order.resize(tlas.prims.size());
+    for (size_t i = 0; i < tlas_order.size(); i++) tlas_order[i] = ids[tlas.prims[i]];
     nodes = tlas.nodes;  // root at index 0, child indices already absolute
     sc.tlas_num_nodes = (uint32_t) tlas.nodes.size();
     ctx->bvh_stats[2] = tlas.nodes.size();
@@ -352,7 +350,16 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   if (total_tris >= (1u << 28) || nodes.size() >= (1u << 25)) { ctx->error = "scene too large for 28-bit leaf ranges / 32-bit node offsets"; return 1; }
   if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
   if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
-  if (upload(ctx, mesh_root.data(), mesh_root.size(), &sc.mesh_root)) return 1;
+  {
+    std::vector<float4> leaves(4 * tlas_order.size() + 4);
+    for (size_t i = 0; i < tlas_order.size(); i++) {
+      const uint32_t inst = tlas_order[i];
+      for (int k = 0; k < 3; k++) leaves[4 * i + k] = inv_rows[3 * (size_t) inst + k];
+      const uint32_t words[4] = {inst, mesh_root[v->instance_mesh_ids[inst]], 0u, 0u};
+      std::memcpy(&leaves[4 * i + 3], words, 16);
+    }
+    if (upload(ctx, leaves.data(), leaves.size(), &sc.tlas_leaves)) return 1;
+  }
   ctx->bvh_stats[0] = nodes.size() - sc.tlas_num_nodes;
   // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
   {
