@@ -75,16 +75,20 @@ def cpu_baseline(view, budget_s):
         _, _, cnt = oracle_lib.render(v, 0, spp, pixels=pixels, use_bvh=True, threads=cores)
         return max(time.time() - t - t_build, 1e-6), float(cnt[0] + cnt[1] + cnt[2])
 
-    calib = np.arange(0, n_total, 97, dtype=np.uint32)
-    dt, rays = run(calib, 1)
-    rate_px = calib.size / dt  # pixel-samples per second
-    want = max(rate_px * budget_s, calib.size)
-    if want <= n_total:
-        stride = max(1, int(n_total / want))
-        pixels, spp = np.arange(0, n_total, stride, dtype=np.uint32), 1
-    else:
-        pixels, spp = None, max(1, min(64, int(want / n_total)))
+    # calibrate on a strided subset, then grow the sample until it takes about `budget_s` (at most 3 rounds)
+    pixels, spp = np.arange(0, n_total, 97, dtype=np.uint32), 1
     dt, rays = run(pixels, spp)
+    for _ in range(3):
+        if dt >= 0.5 * budget_s:
+            break
+        grow = min(max(budget_s / max(dt, 1e-3), 1.5), 64.0)
+        npx = n_total if pixels is None else pixels.size
+        want_px_spp = npx * spp * grow
+        if want_px_spp <= n_total:
+            pixels, spp = np.arange(0, n_total, max(1, int(n_total / want_px_spp)), dtype=np.uint32), 1
+        else:
+            pixels, spp = None, max(1, min(64, int(want_px_spp / n_total)))
+        dt, rays = run(pixels, spp)
     npx = n_total if pixels is None else pixels.size
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
             "sample": "oracle/ (CPU restatement, OpenMP over pixels, %d threads) on %d pixels x %d spp of the same frame, all 9 depth passes: "

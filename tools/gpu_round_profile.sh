@@ -1,0 +1,19 @@
+# Round-end evidence run on the GPU box (through gpurun): parity tests, default bench, rocprofv3 kernel stats of the same bench
+# command, and separate PMC passes for memory-side traffic. Everything lands in gpurun_out/<tag>/ ; copy what is judged to profiles/.
+#   bash tools/gpu_round_profile.sh r01
+tag=${1:-r01}
+out=gpurun_out/$tag
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+timeout 600 python -m pytest tests -m gpu -q > $out/pytest_gpu.log 2>&1; tail -2 $out/pytest_gpu.log
+timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1; tail -1 $out/smoke.log
+timeout 900 python bench.py > $out/bench_example.json 2> $out/bench_example.err; tail -c 600 $out/bench_example.json
+timeout 900 python bench.py --workload hall --steps 4 --warmup 1 > $out/bench_hall.json 2> $out/bench_hall.err; tail -c 300 $out/bench_hall.json
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_example -- python3 bench.py --cpu-budget 0 > $out/stats_example.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats_hall -- python3 bench.py --workload hall --steps 4 --warmup 1 --cpu-budget 0 > $out/stats_hall.log 2>&1
+for w in example hall; do
+  extra=""; [ $w = hall ] && extra="--workload hall"
+  timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$w -- python3 bench.py --steps 2 --warmup 1 --cpu-budget 0 $extra > $out/pmc_fetch_$w.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$w -- python3 bench.py --steps 2 --warmup 1 --cpu-budget 0 $extra > $out/pmc_write_$w.log 2>&1
+done
+find $out -name "*.csv" | head -40
