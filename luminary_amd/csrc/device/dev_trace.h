@@ -282,13 +282,15 @@ struct ClosestState {
 };
 
 // Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light
-// (`target`) and the surface being shaded (`self`).
+// (`target`) and the surface being shaded (`self`). The order in which a traversal meets the surfaces is arbitrary and a float
+// product of three or more factors depends on it, so the product is carried in binary64 (exact for two factors, 29 guard bits
+// beyond that) and rounded to binary32 once at the end; the oracle does the same.
 struct ShadowState {
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
-  Col through;
+  double tr, tg, tb;
   bool blocked;
-  LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; through = splat(1.0f); blocked = false; }
+  LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; tr = tg = tb = 1.0; blocked = false; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float&, RayStats& st) {
     LeafTris lt;
     lt.load(sc.blas_tris, first, count);
@@ -307,11 +309,12 @@ struct ShadowState {
       if (m.alpha == 1.0f) { blocked = true; return true; }
       if (m.alpha == 0.0f && !colored) continue;
       const float tp = 1.0f - m.alpha;
-      through = through * (colored ? m.albedo * tp : splat(tp));
+      const Col f = colored ? m.albedo * tp : splat(tp);
+      tr *= (double) f.r; tg *= (double) f.g; tb *= (double) f.b;
     }
     return false;
   }
-  LUM_DEV Col result() const { return blocked ? splat(0.0f) : through; }
+  LUM_DEV Col result() const { return blocked ? splat(0.0f) : col((float) tr, (float) tg, (float) tb); }
 };
 
 // ---- single-level traversal of the light-only BVH (rare: BSDF-sampled light directions) ----

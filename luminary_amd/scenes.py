@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from . import RGBAF, RGBF, SKY_MODE_CONSTANT_COLOR, Host, Vec3, default_material
+from . import RGBAF, RGBF, SKY_MODE_CONSTANT_COLOR, SUBSTRATE_TRANSLUCENT, Host, Vec3, default_material
 
 
 def apply_benchmark_settings(host, width, height, max_ray_depth, sky=(1.0, 1.0, 1.0)):
@@ -371,4 +371,104 @@ def scan_scene(width=1920, height=1080, bounces=8, seed=3, level=9):
     lid = host.add_mesh(lq, np.full(len(lq), light_mat, dtype=np.uint16))
     host.new_instance(lid)
     set_camera(host, (0.0, 12.0, 38.0), (-0.05, 0.0, 0.0), fov=0.8)
+    return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity scene: every material branch and a light tree deep enough to need node descent
+# ---------------------------------------------------------------------------------------------------------------------
+
+def zoo_scene(width=96, height=64, bounces=8, seed=7, light_triangles=320, sky_mode=SKY_MODE_CONSTANT_COLOR, aperture=0.0, blades=0):
+    """Small scene that exercises what the benchmark scenes do not: translucent (rough and smooth, IOR above and below the medium),
+    coloured and plain transparency, partially opaque surfaces, metals, roughness-as-smoothness, one-sided emitters, rotated and
+    non-uniformly scaled instances, more light triangles than the light-tree root holds (so lanes descend through tree nodes), an
+    optional lens aperture (round or bladed) and either sky mode."""
+    rng = np.random.RandomState(seed)
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.6, 0.7, 0.9))
+    if sky_mode != SKY_MODE_CONSTANT_COLOR:
+        k = host.get_sky()
+        k.mode = sky_mode
+        host.set_sky(k)
+
+    def mat(albedo, roughness, alpha=1.0, **kw):
+        m = _material(albedo, roughness, alpha=alpha, metallic=kw.get("metallic", False), emission=kw.get("emission"),
+                      bidirectional=kw.get("bidirectional", True))
+        if kw.get("translucent"):
+            m.base_substrate = SUBSTRATE_TRANSLUCENT
+            m.refraction_index = kw.get("ior", 1.5)
+        m.colored_transparency = kw.get("colored", False)
+        m.roughness_as_smoothness = kw.get("smoothness", False)
+        if "clamp" in kw:
+            m.roughness_clamp = kw["clamp"]
+        return host.add_material(m)
+
+    mats = [
+        mat((0.7, 0.7, 0.7), 0.8),                                         # 0 diffuse
+        mat((0.9, 0.6, 0.2), 0.1, metallic=True),                          # 1 smooth metal
+        mat((0.8, 0.8, 0.9), 0.5, metallic=True, smoothness=True),         # 2 metal, roughness stored as smoothness
+        mat((0.9, 0.95, 1.0), 0.02, alpha=0.1, translucent=True, ior=1.5),  # 3 clear glass
+        mat((0.6, 0.9, 0.7), 0.35, alpha=0.3, translucent=True, ior=1.33, colored=True),  # 4 rough tinted glass
+        mat((0.9, 0.3, 0.3), 0.6, alpha=0.5, colored=True),                # 5 half-transparent coloured sheet
+        mat((0.5, 0.5, 0.5), 0.6, alpha=0.0),                              # 6 fully transparent, uncoloured (invisible to shadow rays)
+        mat((0.3, 0.4, 0.9), 0.25, alpha=0.75),                            # 7 partially opaque, plain
+        mat((0.95, 0.95, 0.95), 0.04, clamp=0.0),                          # 8 glossy dielectric coat, no clamp
+        mat((0.9, 0.9, 0.9), 0.3, alpha=1.0, translucent=True, ior=1.0),   # 9 translucent with IOR 1 (pass-through branch)
+    ]
+    light_one_sided = mat((0.8, 0.8, 0.8), 0.7, emission=(14.0, 12.0, 9.0), bidirectional=False)
+    light_two_sided = mat((0.8, 0.8, 0.8), 0.7, emission=(3.0, 6.0, 12.0), bidirectional=True)
+
+    ground = _grid(8, 8, -12, 12, -12, 12, lambda X, Z: 0.15 * np.sin(0.9 * X) * np.cos(0.7 * Z))
+    host.new_instance(host.add_mesh(ground, np.full(len(ground), mats[0], dtype=np.uint16)))
+    sp_pos, sp_nrm = _sphere(10)
+    bx_pos, _ = _box()
+    k = 0
+    for mid in mats[1:]:
+        x, z = -9.0 + 2.3 * k, -2.0 + 1.5 * ((k * 7) % 3)
+        if k % 2 == 0:
+            m = host.add_mesh(sp_pos, np.full(len(sp_pos), mid, dtype=np.uint16), normals=sp_nrm)
+            host.new_instance(m, (x, 1.4, z), (0.3 * k, 0.2, 0.1 * k), (1.2, 1.0 + 0.1 * k, 0.9))
+        else:
+            m = host.add_mesh(bx_pos, np.full(len(bx_pos), mid, dtype=np.uint16))
+            host.new_instance(m, (x, 1.2, z), (0.2, 0.5 * k, -0.3), (0.9, 1.3, 0.6 + 0.1 * k))
+        k += 1
+    # a sheet made of two materials hanging in front of the objects
+    sheet = _grid(2, 2, -3, 3, 0, 2.5)
+    sheet = sheet.reshape(-1, 3, 3)[:, :, [0, 2, 1]].reshape(-1, 9).copy()  # stand it up (swap y and z)
+    sheet_m = np.array([mats[5], mats[6], mats[7], mats[5], mats[3], mats[4], mats[6], mats[7]][:len(sheet)], dtype=np.uint16)
+    host.new_instance(host.add_mesh(sheet.astype(np.float32), sheet_m), (0.0, 0.2, 3.5), (0.0, 0.3, 0.0), (1.0, 1.0, 1.0))
+    # many small emitters: a strip of one-sided triangles above, a ring of two-sided ones around
+    tris = []
+    n_strip = light_triangles // 2
+    for i in range(n_strip):
+        x = -10.0 + 20.0 * i / max(n_strip - 1, 1)
+        z = 2.0 * np.sin(0.37 * i)
+        y = 6.5 + 0.3 * np.cos(0.21 * i)
+        s = 0.08 + 0.05 * rng.rand()
+        tris.append((x - s, y, z - s, x + s, y, z - s, x, y, z + s))  # facing down (one-sided emitters emit along -n or +n? both orders used)
+        if i % 3 == 0:
+            tris[-1] = (x - s, y, z - s, x, y, z + s, x + s, y, z - s)
+    strip = np.array(tris, dtype=np.float32)
+    host.new_instance(host.add_mesh(strip, np.full(len(strip), light_one_sided, dtype=np.uint16)))
+    tris = []
+    n_ring = light_triangles - n_strip
+    for i in range(n_ring):
+        a = 2.0 * np.pi * i / n_ring
+        r = 9.0 + 0.5 * np.sin(5 * a)
+        x, z, y = r * np.cos(a), r * np.sin(a), 1.0 + 2.5 * rng.rand()
+        s = 0.1 + 0.1 * rng.rand()
+        tris.append((x, y - s, z, x + s * np.sin(a), y + s, z - s * np.cos(a), x - s * np.sin(a), y + s, z + s * np.cos(a)))
+    ring = np.array(tris, dtype=np.float32)
+    host.new_instance(host.add_mesh(ring, np.full(len(ring), light_two_sided, dtype=np.uint16)), (0.0, 0.0, 0.0), (0.0, 0.4, 0.0), (1.0, 1.2, 1.0))
+
+    c = host.get_camera()
+    c.pos = Vec3(0.5, 3.2, 13.0)
+    c.rotation = Vec3(-0.16, 0.03, 0.0)
+    c.thin_lens.fov = 0.8
+    c.thin_lens.aperture_size = aperture
+    c.aperture_shape = 1 if blades else 0
+    c.aperture_blade_count = blades if blades else 7
+    c.object_distance = 12.0
+    c.russian_roulette_threshold = 0.1
+    host.set_camera(c)
     return host

@@ -215,7 +215,9 @@ static inline OHit trace_closest(const OTracer* tr, vec3 origin, vec3 dir, bool 
  */
 static inline RGBF trace_shadow(const OTracer* tr, vec3 origin, vec3 dir, float dist, uint32_t tgt_inst, uint32_t tgt_tri, uint32_t self_inst, uint32_t self_tri) {
   const OracleScene* s = tr->scene;
-  RGBF thr = c_splat(1.0f);
+  /* The crossing order of a traversal is arbitrary and a float product of three or more factors depends on it: the product is
+   * carried in binary64 (exact for two factors) and rounded to binary32 once; the HIP path does the same. */
+  double thr[3] = {1.0, 1.0, 1.0};
   bool blocked = false;
   for (uint32_t inst = 0; inst < s->num_instances && !blocked; inst++) {
     const uint32_t mesh = s->instance_mesh_ids[inst];
@@ -237,13 +239,13 @@ static inline RGBF trace_shadow(const OTracer* tr, vec3 origin, vec3 dir, float 
           else if (!(m.albedo.a == 0.0f && !colored)) {
             const float tp = 1.0f - m.albedo.a;
             const RGBF f = colored ? c_scale(c3(m.albedo.r, m.albedo.g, m.albedo.b), tp) : c_splat(tp);
-            thr = c_mul(thr, f);
+            thr[0] *= (double) f.r; thr[1] *= (double) f.g; thr[2] *= (double) f.b;
           }
         }
       }
     });
   }
-  return blocked ? c_splat(0.0f) : thr;
+  return blocked ? c_splat(0.0f) : c3((float) thr[0], (float) thr[1], (float) thr[2]);
 }
 
 /*

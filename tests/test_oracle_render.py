@@ -64,3 +64,15 @@ def test_white_furnace_is_bounded(tmp_path):
     fm, _, cnt = oracle_lib.render(v, 0, 4)
     assert np.isfinite(fm).all() and fm.mean() > 0.01
     assert cnt[0] >= 24 * 24 * 4 and cnt[1] > 0 and cnt[3] > 0
+
+
+def test_material_zoo_bvh_equals_brute_force_and_descends_the_light_tree():
+    """The zoo scene covers translucent/transparent/metallic materials, one-sided emitters, transformed instances and a light tree
+    with inner nodes; the oracle's two intersectors must agree on it and every ray class must occur."""
+    v = oracle_lib.with_luts(scenes.zoo_scene(48, 32, 6).device_scene())
+    assert v.num_lights > 128 and v.num_light_tree_nodes > 0
+    a = oracle_lib.render(v, 0, 2, use_bvh=True)
+    b = oracle_lib.render(v, 0, 2, use_bvh=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.isfinite(a[0]).all() and a[0].max() > 0
+    assert a[2][0] > 0 and a[2][1] > 0 and a[2][2] > 0  # closest, shadow and light-BVH rays all present
