@@ -4,8 +4,9 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
 
-Step   = one wavefront pass: --samples-per-pass (default 8) sample ids of every pixel of the 1920x1080 frame through all 9 depth
-         passes (8 bounces). Deep bounces keep few paths alive, so several sample ids share a pass to keep 256 CUs busy.
+Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x1080 frame through all 9 depth passes (8 bounces) for
+         --samples-per-pass (default 8) x N sample ids, i.e. 1920*1080*8 paths per GPU and step whatever N is (weak scaling: the
+         frame gains 8*N samples per step). Deep bounces keep few paths alive, so several sample ids share a pass to keep 256 CUs busy.
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
@@ -137,11 +138,15 @@ def main():
     sm = torch.zeros(P, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
 
+    spp_step = args.samples_per_pass * world  # per-GPU paths per step stay W*H*samples_per_pass
+
     def step(i):
-        core.render(i * args.samples_per_pass, args.samples_per_pass, args.samples_per_pass, fm.data_ptr(), sm.data_ptr(), stream)
+        core.render(i * spp_step, spp_step, spp_step, fm.data_ptr(), sm.data_ptr(), stream)
 
     for i in range(args.warmup):
         step(i)
+    if dist is not None:
+        assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)  # untimed: creates the RCCL communicator and its buffers
     torch.cuda.synchronize()
     core.synchronize()
     core.reset_counters()
@@ -185,7 +190,7 @@ def main():
     dom_bytes, dom_ms, dom_n = (bytes_trace, trace_ms, trace_n) if dominant == "trace" else (bytes_shadow, shadow_ms, shadow_n)
     achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, "k_trace" if dominant == "trace" else "k_shadow_rays", args.samples_per_pass), "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
+                "traffic": measured_traffic(args.workload, "k_trace" if dominant == "trace" else "k_shadow_rays", args.samples_per_pass) if world == 1 else None, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1)}
     cpu = cpu_baseline(view, args.cpu_budget) if args.cpu_budget > 0 else None
     out = {
@@ -193,8 +198,8 @@ def main():
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": workload_name, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth,
-                   "spp_per_step": args.samples_per_pass, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
-                   "samples_per_s": view.width * view.height * args.samples_per_pass * args.steps / elapsed,
+                   "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
+                   "samples_per_s": view.width * view.height * spp_step * args.steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2)},
