@@ -62,7 +62,7 @@ typedef struct LumDeviceSceneView {
 } LumDeviceSceneView;
 
 enum { LUMC_CNT_TRACE = 0, LUMC_CNT_SHADOW = 1, LUMC_CNT_LIGHT_BVH = 2, LUMC_CNT_VERTICES = 3, LUMC_CNT_NODES = 4, LUMC_CNT_TRIS = 5, LUMC_CNT_NODES_SHADOW = 6, LUMC_CNT_TRIS_SHADOW = 7,
-       LUMC_CNT_NODES_LIGHT = 8, LUMC_CNT_TRIS_LIGHT = 9, LUMC_CNT_COUNT = 10 };
+       LUMC_CNT_NODES_LIGHT = 8, LUMC_CNT_TRIS_LIGHT = 9, LUMC_CNT_NODES_LDS = 10, LUMC_CNT_NODES_LDS_SHADOW = 11, LUMC_CNT_COUNT = 12 };
 enum { LUMC_KERNEL_GENERATE = 0, LUMC_KERNEL_TRACE = 1, LUMC_KERNEL_SHADE = 2, LUMC_KERNEL_SHADOW = 3, LUMC_KERNEL_ACCUMULATE = 4, LUMC_KERNEL_LIGHT_QUERY = 5,
        LUMC_KERNEL_RESOLVE = 6, LUMC_KERNEL_COUNT = 7 };
 

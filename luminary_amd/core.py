@@ -5,7 +5,7 @@ import numpy as np
 
 from . import DeviceSceneView, _lib
 
-CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT = range(10)
+CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
 KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve")
 
 
@@ -81,7 +81,7 @@ class Core:
         return fm.reshape(3, -1), sm
 
     def counters(self):
-        out = (C.c_uint64 * 10)()
+        out = (C.c_uint64 * 12)()
         self._call("lumc_counters", out)
         return [int(x) for x in out]
 

@@ -98,6 +98,7 @@ struct ShadowQueue {
 // Per-depth control words (zeroed once per pass).
 enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlStride = 8 };
 
-enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntCount };
+enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
+                         kCntNodesLdsShadow, kCntCount };
 
 }  // namespace lum

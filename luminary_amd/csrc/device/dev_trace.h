@@ -30,12 +30,11 @@ constexpr int kStackSize = 128;
 #ifndef LUM_CHUNK_MAX
 #define LUM_CHUNK_MAX 256u  // most items a wave reserves per atomic
 #endif
-constexpr uint32_t kBlockThreads = 256;
 #ifndef LUM_REFILL
 #define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
 #endif
 
-struct RayStats { uint32_t nodes, tris; };
+struct RayStats { uint32_t nodes, tris, lds_nodes; };  // lds_nodes: node visits served from the LDS-staged top of the tree
 
 LUM_DEV float safe_inv(float d) { return (fabsf(d) < 1e-30f) ? copysignf(1e30f, d) : 1.0f / d; }
 
@@ -89,31 +88,32 @@ LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tm
 
 // Visits inner node `cur`: returns the nearest child the ray may touch after pushing the others far-to-near, or kBvhEmpty when
 // the ray misses all four (the caller pops).
-LUM_DEV uint32_t visit_node(const Bvh4Node* __restrict__ nodes, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp, uint2& top) {
+// The first `lds_count` nodes of the array (the top of the tree in breadth-first order, core.hip) are staged in LDS by every
+// workgroup of the persistent ray kernels: a divergent 16-byte LDS read costs a fraction of a divergent L1 access.
+struct NodeSource { const Bvh4Node* global; const char* lds; uint32_t lds_count; };
+
+LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp, uint2& top, RayStats& st) {
   const uint32_t b = cur << 7;
-  const float4 nx = node_f4(nodes, b + r.nx), ny = node_f4(nodes, b + r.ny), nz = node_f4(nodes, b + r.nz);
-  const float4 fx = node_f4(nodes, b + r.fx), fy = node_f4(nodes, b + r.fy), fz = node_f4(nodes, b + r.fz);
-  const uint4 ch = node_u4(nodes, b + 96u);
+  float4 nx, ny, nz, fx, fy, fz;
+  uint4 ch;
+  if (cur < src.lds_count) {
+    const char* p = src.lds + b;
+    nx = *reinterpret_cast<const float4*>(p + r.nx); ny = *reinterpret_cast<const float4*>(p + r.ny); nz = *reinterpret_cast<const float4*>(p + r.nz);
+    fx = *reinterpret_cast<const float4*>(p + r.fx); fy = *reinterpret_cast<const float4*>(p + r.fy); fz = *reinterpret_cast<const float4*>(p + r.fz);
+    ch = *reinterpret_cast<const uint4*>(p + 96u);
+    st.lds_nodes++;
+  }
+  else {
+    const Bvh4Node* __restrict__ nodes = src.global;
+    nx = node_f4(nodes, b + r.nx); ny = node_f4(nodes, b + r.ny); nz = node_f4(nodes, b + r.nz);
+    fx = node_f4(nodes, b + r.fx); fy = node_f4(nodes, b + r.fy); fz = node_f4(nodes, b + r.fz);
+    ch = node_u4(nodes, b + 96u);
+  }
   float k0 = child_entry(nx.x, ny.x, nz.x, fx.x, fy.x, fz.x, r, tmax);
   float k1 = child_entry(nx.y, ny.y, nz.y, fx.y, fy.y, fz.y, r, tmax);
   float k2 = child_entry(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, r, tmax);
   float k3 = child_entry(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, r, tmax);
   uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-#ifdef LUM_EXPERIMENT_DOUBLE_LOADS  // measurement only: issue the node's seven loads a second time
-  {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 a0, a1, a2, a3, a4, a5, a6;
-    const uint32_t o0 = b + r.nx, o1 = b + r.ny, o2 = b + r.nz, o3 = b + r.fx, o4 = b + r.fy, o5 = b + r.fz, o6 = b + 96u;
-    asm volatile(
-        "global_load_dwordx4 %0, %7, %14\n global_load_dwordx4 %1, %8, %14\n global_load_dwordx4 %2, %9, %14\n global_load_dwordx4 %3, %10, %14\n"
-        "global_load_dwordx4 %4, %11, %14\n global_load_dwordx4 %5, %12, %14\n global_load_dwordx4 %6, %13, %14\n s_waitcnt vmcnt(0)"
-        : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(a4), "=&v"(a5), "=&v"(a6)
-        : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "v"(o4), "v"(o5), "v"(o6), "s"(nodes)
-        : "memory");
-    const f4 t = a0 + a1 + a2 + a3 + a4 + a5 + a6;
-    if (t.x + t.y + t.z + t.w == 1.2345e-33f) k0 = 0.0f;
-  }
-#endif
   cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
   const float inf = __builtin_inff();
   // Branch-free pushes. The newest entry lives in registers (`top`), older ones in scratch: a push spills the old top to a slot
@@ -168,7 +168,7 @@ struct LeafTris {
 // Top-level leaves hold exactly one instance; entering it pushes a marker and maps the ray with the instance's world->object
 // matrix (an affine map preserves distances along the ray, so tmax and the stacked entry distances stay valid across levels).
 template <class Q>
-LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays) {
+LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays, uint32_t lds_count) {
   uint2 stk[kStackSize];
   int sp = 0;
   TRay r;
@@ -179,7 +179,14 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   bool more = true;
   const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const Bvh4Node* __restrict__ nodes = sc.bvh_nodes;
+  // stage the top of the tree
+  extern __shared__ float4 lds_top[];
+  {
+    const float4* __restrict__ g = reinterpret_cast<const float4*>(sc.bvh_nodes);
+    for (uint32_t i = threadIdx.x; i < lds_count * 8u; i += blockDim.x) lds_top[i] = g[i];
+    __syncthreads();
+  }
+  const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
 
   uint2 top = make_uint2(kTraversalDone, 0u);
   auto pop = [&]() {
@@ -194,7 +201,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 
   // Work distribution: a wave reserves a chunk of consecutive items with one atomic and hands them to its idle lanes; a single
   // global cursor bumped once per refill would serialise every wave of the GPU on one L2 atomic.
-  const uint32_t waves = gridDim.x * (kBlockThreads / 64u);
+  const uint32_t waves = gridDim.x * (blockDim.x / 64u);
   uint32_t chunk = n / (waves * 2u);
   chunk = (min(max(chunk, 64u), LUM_CHUNK_MAX) + 63u) & ~63u;
   uint32_t chunk_next = 0, chunk_end = 0;
@@ -225,7 +232,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     while (cur != kTraversalDone) {
       while (!(cur & kBvhLeafBit)) {
         st.nodes++;
-        cur = visit_node(nodes, cur, r, tmax, stk, sp, top);
+        cur = visit_node(nodes, cur, r, tmax, stk, sp, top, st);
         if (cur == kBvhEmpty) pop();
       }
       if (cur != kTraversalDone) {
@@ -333,7 +340,7 @@ LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, Ray
     }
     else {
       st.nodes++;
-      cur = visit_node(sc.light_nodes, cur, r, tmax, stk, sp, top);
+      cur = visit_node(NodeSource{sc.light_nodes, nullptr, 0u}, cur, r, tmax, stk, sp, top, st);
     }
     if (cur == kBvhEmpty) {
       while (true) {

@@ -23,9 +23,10 @@ enum PathState : uint32_t {  // cuda/utils.cuh:114-121
 enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 constexpr int kBlock = 256;
-#ifndef LUM_TRACE_WAVES
-#define LUM_TRACE_WAVES 3  // minimum waves per SIMD the ray kernels are compiled for
+#ifndef LUM_TRACE_BLOCK
+#define LUM_TRACE_BLOCK 256  // threads per workgroup of the persistent ray kernels; every workgroup keeps its own LDS copy of the tree top
 #endif
+constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
 #endif
@@ -35,12 +36,14 @@ struct PassParams {
   uint32_t num_pixels, batch, first_sample;
 };
 
-LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter) {
+LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
+                         uint32_t lds_counter = kCntCount) {
   // one atomic per wave and counter
-  uint32_t n = st.nodes, t = st.tris, r = rays;
+  uint32_t n = st.nodes, t = st.tris, r = rays, l = st.lds_nodes;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off); t += __shfl_down(t, off); r += __shfl_down(r, off); }
+  for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off); t += __shfl_down(t, off); r += __shfl_down(r, off); l += __shfl_down(l, off); }
   if ((threadIdx.x & 63) == 0) {
+    if (l && lds_counter != kCntCount) atomicAdd((unsigned long long*) &counters[lds_counter], (unsigned long long) l);
     if (n) atomicAdd((unsigned long long*) &counters[node_counter], (unsigned long long) n);
     if (t) atomicAdd((unsigned long long*) &counters[tri_counter], (unsigned long long) t);
     if (r) atomicAdd((unsigned long long*) &counters[ray_counter], (unsigned long long) r);
@@ -120,13 +123,13 @@ struct TraceQuery : ClosestState {
   }
 };
 
-__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_trace(DeviceScene sc, PathQueue q, uint32_t* ctrl, uint64_t* counters) {
-  RayStats st{0, 0};
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene sc, PathQueue q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+  RayStats st{0, 0, 0};
   uint32_t rays = 0;
   TraceQuery tq;
   tq.q = q;
-  trace_items(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays);
-  flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris);
+  trace_items(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
+  flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
 // ---- surface context (cuda/geometry_utils.cuh:13-221, untextured) ----
@@ -365,7 +368,7 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
   const uint32_t n = ctrl[kCtlLightItems];
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
-  RayStats st{0, 0};
+  RayStats st{0, 0, 0};
   uint32_t light_queries = 0;
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
   for (uint32_t round = 0; round < rounds; round++) {
@@ -446,13 +449,13 @@ struct ShadowQuery : ShadowState {
   }
 };
 
-__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, uint32_t* ctrl, uint64_t* counters) {
-  RayStats st{0, 0};
+__global__ __launch_bounds__(kTraceBlock) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+  RayStats st{0, 0, 0};
   uint32_t rays = 0;
   ShadowQuery q;
   q.sq = sq;
-  trace_items(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays);
-  flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow);
+  trace_items(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
+  flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow, kCntNodesLdsShadow);
 }
 
 // ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
@@ -519,14 +522,14 @@ struct RaysQuery : ClosestState {
   }
 };
 
-__global__ __launch_bounds__(kBlock, LUM_TRACE_WAVES) void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
-                                                       uint32_t* out, uint32_t* cursor, uint64_t* counters) {
-  RayStats st{0, 0};
+__global__ __launch_bounds__(kTraceBlock) void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
+                                                           uint32_t* out, uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
+  RayStats st{0, 0, 0};
   uint32_t rays = 0;
   RaysQuery q;
   q.origins = origins; q.dirs = dirs; q.ignore = ignore; q.out = out;
-  trace_items(sc, n, cursor, q, st, rays);
-  flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris);
+  trace_items(sc, n, cursor, q, st, rays, lds_nodes);
+  flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
 // ---- BSDF energy LUTs (cuda/bsdf_lut.cuh:20-211): pixel (0,0), depth 0, sample id = iteration ----

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -25,6 +26,8 @@ struct LumContext {
   DeviceScene scene{};
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
+  uint32_t lds_nodes = 0;         // nodes of the tree top every ray-kernel workgroup stages in LDS
+  uint32_t trace_blocks = 256;    // persistent grid of the ray kernels
   // LUTs owned by the context when generated here
   uint16_t* d_luts[4] = {nullptr, nullptr, nullptr, nullptr};
   // pixels and accumulators
@@ -122,10 +125,10 @@ inline uint32_t grid_for(uint32_t n) {
   return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);  // 256 CUs x 8 resident blocks, grid-stride beyond that
 }
 
-// Persistent ray kernels: enough blocks to fill every CU at the kernels' occupancy; the waves pull work from a global cursor.
-inline uint32_t grid_persistent(uint32_t n) {
-  const uint32_t blocks = (n + kBlock - 1) / kBlock;
-  return blocks < 1 ? 1 : (blocks > 1280 ? 1280 : blocks);  // 256 CUs x 5 blocks of 4 waves
+// Persistent ray kernels: one workgroup per CU (kTraceBlock threads, its own LDS copy of the tree top); waves pull work from a cursor.
+inline uint32_t grid_persistent(const LumContext* ctx, uint32_t n) {
+  const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+  return blocks < 1 ? 1 : (blocks > ctx->trace_blocks ? ctx->trace_blocks : blocks);
 }
 
 struct Launch {
@@ -347,6 +350,43 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     }
     tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit();
   }
+  // ---- renumber: the top of the tree first, in breadth-first order across both levels (top-level leaves continue into the root of
+  // their mesh), so that "node index < K" selects the K most visited nodes; the ray kernels stage those in LDS ----
+  {
+    const size_t n = nodes.size();
+    std::vector<uint32_t> order;
+    std::vector<uint8_t> seen(n, 0);
+    order.reserve(n);
+    order.push_back(0); seen[0] = 1;
+    const size_t top_budget = std::min<size_t>(n, 4096);
+    for (size_t head = 0; head < order.size() && order.size() < top_budget; head++) {
+      const uint32_t id = order[head];
+      const bool top_level = id < sc.tlas_num_nodes;
+      for (int k = 0; k < 4; k++) {
+        const uint32_t c = nodes[id].child[k];
+        if (c == kBvhEmpty) continue;
+        uint32_t next;
+        if (c & kBvhLeafBit) {
+          if (!top_level) continue;
+          next = mesh_root[v->instance_mesh_ids[tlas_order[c & 0x0FFFFFFFu]]];
+        }
+        else next = c;
+        if (!seen[next]) { seen[next] = 1; order.push_back(next); }
+      }
+    }
+    for (uint32_t i = 0; i < n; i++) if (!seen[i]) order.push_back(i);
+    std::vector<uint32_t> new_index(n);
+    for (uint32_t i = 0; i < n; i++) new_index[order[i]] = i;
+    std::vector<Bvh4Node> renum(n);
+    for (uint32_t i = 0; i < n; i++) {
+      Bvh4Node node = nodes[order[i]];
+      for (int k = 0; k < 4; k++)
+        if (node.child[k] != kBvhEmpty && !(node.child[k] & kBvhLeafBit)) node.child[k] = new_index[node.child[k]];
+      renum[i] = node;
+    }
+    nodes.swap(renum);
+    for (uint32_t m = 0; m < v->num_meshes; m++) mesh_root[m] = new_index[mesh_root[m]];
+  }
   if (total_tris >= (1u << 28) || nodes.size() >= (1u << 25)) { ctx->error = "scene too large for 28-bit leaf ranges / 32-bit node offsets"; return 1; }
   if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
   if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
@@ -361,6 +401,23 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     if (upload(ctx, leaves.data(), leaves.size(), &sc.tlas_leaves)) return 1;
   }
   ctx->bvh_stats[0] = nodes.size() - sc.tlas_num_nodes;
+  {
+    // resident workgroups per CU share the LDS: what the device offers minus a margin, 128 B per node
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    size_t lds_bytes = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
+    // the ray kernels need ~148 VGPRs: 3 waves per SIMD = 12 waves per CU
+    const int blocks_per_cu = std::max(1, 768 / kTraceBlock);
+    lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
+    lds_bytes = lds_bytes > 4096 ? lds_bytes - 2048 : 0;
+    ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / sizeof(Bvh4Node), nodes.size());
+    if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
+    ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
+    const size_t dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_shadow_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+  }
   // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
   {
     const uint32_t nl = (v->light_tree_root && v->light_bvh_tris) ? v->num_lights : 0;
@@ -462,6 +519,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
   if (ensure_work(ctx, (uint32_t) want)) return 1;
   const DeviceScene& sc = ctx->scene;
   const uint32_t max_depth = sc.max_ray_depth;
+  const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
 
   for (uint32_t done = 0; done < num_samples; done += samples_per_pass) {
     const uint32_t batch = std::min(samples_per_pass, num_samples - done);
@@ -479,7 +537,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
       uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
       {
         Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-        hipLaunchKernelGGL(k_trace, dim3(grid_persistent(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters);
+        hipLaunchKernelGGL(k_trace, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
       }
       {
         Launch l(ctx, stream, LUMC_KERNEL_SHADE);
@@ -492,7 +550,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
       }
       {
         Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
-        hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(N)), dim3(kBlock), 0, stream, sc, ctx->shadow, ctrl, ctx->d_counters);
+        hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
       }
       {
         Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
@@ -555,7 +613,8 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
   HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  hipLaunchKernelGGL(k_trace_rays, dim3(grid_persistent(n)), dim3(kBlock), 0, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters);
+  hipLaunchKernelGGL(k_trace_rays, dim3(grid_persistent(ctx, n)), dim3(kTraceBlock), (size_t) ctx->lds_nodes * sizeof(Bvh4Node), stream, ctx->scene, n, d_origins, d_dirs, d_ignore,
+                     d_out, cursor, ctx->d_counters, ctx->lds_nodes);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
