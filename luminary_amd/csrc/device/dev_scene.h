@@ -75,6 +75,7 @@ struct PathQueue {
   float4* dir_slot;   // direction.xyz, result slot (uint bits)
   uint4* aux;         // throughput record x,y | medium IOR stack | state flags
   uint4* hit_id;      // hit (or ignore) instance, triangle | pixel x | y << 16 | sample id
+  uint32_t* hit_scene_tri;  // index of the hit triangle in the scene arrays (vertices, tri_tex): spares the shade kernel two dependent loads
 };
 
 // Next-event-estimation data of the vertices of one depth, indexed like the path queue they were shaded from.

@@ -259,14 +259,14 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   }
 }
 
-struct Hit { uint32_t instance_id, tri_id; float t; };
+struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
 struct ClosestState {
   bool use_ignore;
   uint32_t ign_inst, ign_tri;
   Hit best;
-  LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax}; }
+  LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax, 0u}; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
     LeafTris lt;
     lt.load(sc.blas_tris, first, count);
@@ -280,12 +280,12 @@ struct ClosestState {
       F2 uv;
       const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && id < best.tri_id)))) {
-        best.instance_id = inst; best.tri_id = id; best.t = t; tmax = t;
+        best.instance_id = inst; best.tri_id = id; best.t = t; best.scene_tri = fbits(b.w); tmax = t;
       }
     }
     return false;
   }
-  LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax} : best; }
+  LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax, 0u} : best; }
 };
 
 // Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light

@@ -120,6 +120,7 @@ struct TraceQuery : ClosestState {
     const Hit h = result();
     reinterpret_cast<float*>(&q.origin_t[i])[3] = h.t;
     *reinterpret_cast<uint2*>(&q.hit_id[i]) = make_uint2(h.instance_id, h.tri_id);
+    q.hit_scene_tri[i] = h.scene_tri;
   }
 };
 
@@ -133,10 +134,8 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene sc, PathQueue
 }
 
 // ---- surface context (cuda/geometry_utils.cuh:13-221, untextured) ----
-LUM_DEV GeoContext build_context(const DeviceScene& sc, V3 hit_origin, V3 ray_world, uint32_t state, uint32_t inst, uint32_t tri, uint32_t medium) {
-  const uint32_t mesh = sc.instance_mesh_ids[inst];
+LUM_DEV GeoContext build_context(const DeviceScene& sc, V3 hit_origin, V3 ray_world, uint32_t state, uint32_t inst, uint32_t tri, uint32_t tbase, uint32_t medium) {
   const Transform tf = load_transform(sc, inst);
-  const uint32_t tbase = sc.mesh_tri_offset[mesh] + tri;
   const float4 a = sc.vertices[3 * tbase], b = sc.vertices[3 * tbase + 1], c = sc.vertices[3 * tbase + 2];
   const uint4 tt = sc.tri_tex[tbase];
   V3 position = xf_point_inv(tf, hit_origin);
@@ -222,7 +221,7 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
         const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
-        const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, aux.z);
+        const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i], aux.z);
 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);

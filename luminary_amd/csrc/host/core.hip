@@ -93,15 +93,16 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   free_work(ctx);
   // per path: 2 queues x 64 B + NEE 64 B + result 16 B + up to 3 visibility rays x (48 B + 16 B result) + 4 B light-query index
   const size_t n = paths;
-  const size_t bytes = n * (2 * 64 + 64 + 16 + 3 * 64 + 4);
+  const size_t bytes = n * (2 * 68 + 64 + 16 + 3 * 64 + 4) + 32 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
-  auto take = [&](size_t sz) { char* r = p; p += sz; return r; };
+  auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
   for (int k = 0; k < 2; k++) {
     ctx->queue[k].origin_t = (float4*) take(n * 16);
     ctx->queue[k].dir_slot = (float4*) take(n * 16);
     ctx->queue[k].aux      = (uint4*) take(n * 16);
     ctx->queue[k].hit_id   = (uint4*) take(n * 16);
+    ctx->queue[k].hit_scene_tri = (uint32_t*) take(n * 4);
   }
   ctx->nee.geo_color_light = (float4*) take(n * 16);
   ctx->nee.bsdf_ray_prob   = (float4*) take(n * 16);
