@@ -267,6 +267,90 @@ LUMINARY_API LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* h
 
 /* ---- additive extension (not in the reference) ---- */
 struct LumDeviceSceneView;
+/* ---- "extra utils" frontends link against: reference include/luminary/{host_memory,array,queue,ringbuffer,thread_status,log,name_strings}.h ---- */
+#define host_malloc(ptr, size) _host_malloc((void**) (ptr), (size), (const char*) #ptr, (const char*) __func__, __LINE__)
+#define host_realloc(ptr, size) _host_realloc((void**) (ptr), (size), (const char*) #ptr, (const char*) __func__, __LINE__)
+#define host_free(ptr) _host_free((void**) (ptr), (const char*) #ptr, (const char*) __func__, __LINE__)
+LUMINARY_API LuminaryResult _host_malloc(void** ptr, size_t size, const char* buf_name, const char* func, uint32_t line);   /* host_memory.h:28 */
+LUMINARY_API LuminaryResult _host_realloc(void** ptr, size_t size, const char* buf_name, const char* func, uint32_t line);  /* host_memory.h:29 */
+LUMINARY_API LuminaryResult _host_free(void** ptr, const char* buf_name, const char* func, uint32_t line);                  /* host_memory.h:30 */
+
+#define array_create(array, size_of_element, num_elements) \
+  _array_create((void**) (array), (size_of_element), (num_elements), (const char*) #array, (const char*) __func__, __LINE__)
+#define array_resize(array, size) _array_resize((void**) (array), (size), (const char*) #array, (const char*) __func__, __LINE__)
+#define array_push(array, object) _array_push((void**) (array), (void*) (object), (const char*) #array, (const char*) __func__, __LINE__)
+#define array_copy(dst, src) _array_copy((void**) (dst), (void**) (src), (const char*) #dst, (const char*) __func__, __LINE__)
+#define array_append(dst, src) _array_append((void**) (dst), (const void*) (src), (const char*) #dst, (const char*) __func__, __LINE__)
+#define array_set_num_elements(array, num_elements) \
+  _array_set_num_elements((void**) (array), (num_elements), (const char*) #array, (const char*) __func__, __LINE__)
+#define array_destroy(array) _array_destroy((void**) (array), (const char*) #array, (const char*) __func__, __LINE__)
+LUMINARY_API LuminaryResult _array_create(void** array, size_t size_of_element, uint32_t num_elements, const char* buf_name, const char* func, uint32_t line); /* array.h:34 */
+LUMINARY_API LuminaryResult _array_resize(void** array, size_t size, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult _array_push(void** array, void* object, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult _array_copy(void** dst, const void* src, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult _array_append(void** dst, const void* src, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult _array_destroy(void** array, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult array_clear(void* array);
+LUMINARY_API LuminaryResult array_get_size(const void* array, size_t* size);
+LUMINARY_API LuminaryResult array_get_num_elements(const void* array, uint32_t* num_elements);
+LUMINARY_API LuminaryResult _array_set_num_elements(void** array, uint32_t num_elements, const char* buf_name, const char* func, uint32_t line);
+
+typedef struct LuminaryQueue LuminaryQueue;          /* queue.h:25-40 */
+typedef bool (*LuminaryEqOp)(void* lhs, void* rhs);
+#define queue_create(queue, size_of_element, num_elements) \
+  _queue_create((queue), (size_of_element), (num_elements), (const char*) #queue, (const char*) __func__, __LINE__)
+#define queue_destroy(queue) _queue_destroy((queue), (const char*) #queue, (const char*) __func__, __LINE__)
+LUMINARY_API LuminaryResult _queue_create(LuminaryQueue** queue, size_t size_of_element, size_t num_elements, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult queue_push(LuminaryQueue* queue, void* object);
+LUMINARY_API LuminaryResult queue_push_unique(LuminaryQueue* queue, void* object, LuminaryEqOp equal_operator, bool* already_queued);
+LUMINARY_API LuminaryResult queue_pop(LuminaryQueue* queue, void* object, bool* success);
+LUMINARY_API LuminaryResult queue_pop_blocking(LuminaryQueue* queue, void* object, bool* success);
+LUMINARY_API LuminaryResult queue_set_is_blocking(LuminaryQueue* queue, bool is_blocking);
+LUMINARY_API LuminaryResult _queue_destroy(LuminaryQueue** queue, const char* buf_name, const char* func, uint32_t line);
+
+typedef struct LuminaryRingBuffer LuminaryRingBuffer;  /* ringbuffer.h:25-34 */
+#define ringbuffer_create(buffer, size) _ringbuffer_create((buffer), (size), (const char*) #buffer, (const char*) __func__, __LINE__)
+#define ringbuffer_destroy(buffer) _ringbuffer_destroy((buffer), (const char*) #buffer, (const char*) __func__, __LINE__)
+LUMINARY_API LuminaryResult _ringbuffer_create(LuminaryRingBuffer** buffer, size_t size, const char* buf_name, const char* func, uint32_t line);
+LUMINARY_API LuminaryResult ringbuffer_allocate_entry(LuminaryRingBuffer* buffer, size_t entry_size, void** entry);
+LUMINARY_API LuminaryResult ringbuffer_release_entry(LuminaryRingBuffer* buffer, size_t entry_size);
+LUMINARY_API LuminaryResult _ringbuffer_destroy(LuminaryRingBuffer** buffer, const char* buf_name, const char* func, uint32_t line);
+
+typedef struct LuminaryThreadStatus LuminaryThreadStatus;  /* thread_status.h:25-34 */
+LUMINARY_API LuminaryResult thread_status_create(LuminaryThreadStatus** thread_status);
+LUMINARY_API LuminaryResult thread_status_set_worker_name(LuminaryThreadStatus* thread_status, const char* name);
+LUMINARY_API LuminaryResult thread_status_get_worker_name(LuminaryThreadStatus* thread_status, const char** name);
+LUMINARY_API LuminaryResult thread_status_start(LuminaryThreadStatus* thread_status, const char* string);
+LUMINARY_API LuminaryResult thread_status_get_time(LuminaryThreadStatus* thread_status, double* time);
+LUMINARY_API LuminaryResult thread_status_get_string(LuminaryThreadStatus* thread_status, const char** string);
+LUMINARY_API LuminaryResult thread_status_stop(LuminaryThreadStatus* thread_status);
+LUMINARY_API LuminaryResult thread_status_destroy(LuminaryThreadStatus** thread_status);
+
+#define log_message(fmt, ...) luminary_print_log("[%s:%d] " fmt, __func__, __LINE__, ##__VA_ARGS__)   /* log.h:23-31 */
+#define warn_message(fmt, ...) luminary_print_warn("[%s:%d] " fmt, __func__, __LINE__, ##__VA_ARGS__)
+#define error_message(fmt, ...) luminary_print_error("[%s:%d] " fmt, __func__, __LINE__, ##__VA_ARGS__)
+#define crash_message(fmt, ...) luminary_print_crash("[%s:%d] " fmt, __func__, __LINE__, ##__VA_ARGS__)
+LUMINARY_API void luminary_print_log(const char* format, ...);
+LUMINARY_API void luminary_print_info(bool log, const char* format, ...);
+LUMINARY_API void luminary_print_info_inline(bool log, const char* format, ...);
+LUMINARY_API void luminary_print_warn(const char* format, ...);
+LUMINARY_API void luminary_print_error(const char* format, ...);
+LUMINARY_API void luminary_print_crash(const char* format, ...);
+LUMINARY_API void luminary_write_log(void);
+
+extern const char* const luminary_strings_shading_mode[LUMINARY_SHADING_MODE_COUNT];   /* name_strings.h:22-29 */
+extern const char* const luminary_strings_adaptive_sampling_output_mode[LUMINARY_ADAPTIVE_SAMPLING_OUTPUT_MODE_COUNT];
+extern const char* const luminary_strings_filter[LUMINARY_FILTER_COUNT];
+extern const char* const luminary_strings_tonemap[LUMINARY_TONEMAP_COUNT];
+extern const char* const luminary_strings_aperture[LUMINARY_APERTURE_COUNT];
+extern const char* const luminary_strings_jerlov_water_type[LUMINARY_JERLOV_WATER_TYPE_COUNT];
+extern const char* const luminary_strings_sky_mode[LUMINARY_SKY_MODE_COUNT];
+extern const char* const luminary_strings_material_base_substrate[LUMINARY_MATERIAL_BASE_SUBSTRATE_COUNT];
+
+/* additive: bytes currently held through _host_malloc, and the text luminary_write_log would write */
+LUMINARY_API LuminaryResult luminary_ext_host_memory_in_use(uint64_t* bytes);
+LUMINARY_API LuminaryResult luminary_ext_get_log(const char** text, size_t* length);
+
 /* Adds a mesh from flat per-triangle arrays (reference Mesh layout, mesh.h:8-14): 9 position floats, 9 normal floats, 6 uv floats and one
  * material id per triangle. Materials are added with luminary_ext_add_material. Returns the new ids. */
 LUMINARY_API LuminaryResult luminary_ext_add_mesh(
