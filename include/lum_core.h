@@ -64,7 +64,7 @@ typedef struct LumDeviceSceneView {
 enum { LUMC_CNT_TRACE = 0, LUMC_CNT_SHADOW = 1, LUMC_CNT_LIGHT_BVH = 2, LUMC_CNT_VERTICES = 3, LUMC_CNT_NODES = 4, LUMC_CNT_TRIS = 5, LUMC_CNT_NODES_SHADOW = 6, LUMC_CNT_TRIS_SHADOW = 7,
        LUMC_CNT_NODES_LIGHT = 8, LUMC_CNT_TRIS_LIGHT = 9, LUMC_CNT_NODES_LDS = 10, LUMC_CNT_NODES_LDS_SHADOW = 11, LUMC_CNT_COUNT = 12 };
 enum { LUMC_KERNEL_GENERATE = 0, LUMC_KERNEL_TRACE = 1, LUMC_KERNEL_SHADE = 2, LUMC_KERNEL_SHADOW = 3, LUMC_KERNEL_ACCUMULATE = 4, LUMC_KERNEL_LIGHT_QUERY = 5,
-       LUMC_KERNEL_RESOLVE = 6, LUMC_KERNEL_COUNT = 7 };
+       LUMC_KERNEL_RESOLVE = 6, LUMC_KERNEL_OUTPUT = 7, LUMC_KERNEL_COUNT = 8 };
 
 int lumc_context_create(int device_ordinal, LumContext** out);
 void lumc_context_destroy(LumContext* ctx);
@@ -94,6 +94,28 @@ int lumc_reset_counters(LumContext* ctx);
 /* With profiling on, every kernel launch of lumc_render is bracketed by HIP events on its own stream. */
 int lumc_set_profiling(LumContext* ctx, int enabled);
 int lumc_kernel_times(LumContext* ctx, double total_ms[LUMC_KERNEL_COUNT], uint32_t launches[LUMC_KERNEL_COUNT]);
+
+/*
+ * Output chain (replaces device/device_output.c:178-343 + cuda/kernels.cuh:503-644 generate_final_image / convert_RGBF_to_ARGB8 and
+ * cuda/tonemap.cuh): planar first moment [3 * src pixels] of a full frame -> ARGB8 words (b | g << 8 | r << 16 | 0xFF << 24) of the
+ * requested size. The values are the reference's device-side camera/output state (device_structs.c:40-88): `exposure` is already
+ * exp(camera.exposure), `passthrough` is set when the shading mode is not DEFAULT.
+ */
+typedef struct LumOutputParams {
+  uint32_t src_width, src_height, dst_width, dst_height;
+  float inv_sample_count, exposure;
+  uint32_t tonemap, filter, dithering, purkinje, use_color_correction, passthrough;
+  float purkinje_kappa1, purkinje_kappa2;
+  float cc_h, cc_s, cc_v;
+  float film_grain;
+  float agx_slope, agx_power, agx_saturation;
+} LumOutputParams;
+/* d_first_moment NULL = the context's own accumulators (needs a full-frame pixel set). d_argb8: DEVICE buffer of dst pixels. */
+int lumc_generate_output(LumContext* ctx, const LumOutputParams* params, const float* d_first_moment, uint32_t* d_argb8, void* stream);
+/* Same, result copied to host memory; optionally also the display-referred float planes [3 * src pixels] (NULL to skip). */
+int lumc_generate_output_host(LumContext* ctx, const LumOutputParams* params, const float* d_first_moment, uint32_t* argb8, float* frame_output);
+/* Same with the first moment in HOST memory (e.g. a frame assembled from several GPUs); it is uploaded to a temporary buffer. */
+int lumc_generate_output_from_host(LumContext* ctx, const LumOutputParams* params, const float* first_moment, uint32_t* argb8, float* frame_output);
 
 /* Closest-hit query on device buffers (float3 origins/dirs, optional uint2 ignore handles, uint3 out: instance, triangle, t bits). */
 int lumc_trace_closest(LumContext* ctx, uint32_t num_rays, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream);

@@ -57,7 +57,8 @@ def build(force=False, verbose=False):
         objs.append(o)
     bn = os.path.join(ROOT, "data", "bluenoise_2D.bin")
     o = os.path.join(OBJ_DIR, "embed.o")
-    _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, os.path.join(CSRC, "host", "embed.S"), "-o", o])
+    bn1 = os.path.join(ROOT, "data", "bluenoise_1D.bin")
+    _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, "-DLUM_BLUENOISE_1D_PATH=\"%s\"" % bn1, os.path.join(CSRC, "host", "embed.S"), "-o", o])
     objs.append(o)
     for s in HIP_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")

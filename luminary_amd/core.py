@@ -6,11 +6,33 @@ import numpy as np
 from . import DeviceSceneView, _lib
 
 CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
-KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve")
+KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output")
 
 
 class CoreError(RuntimeError):
     pass
+
+
+class OutputParams(C.Structure):
+    """include/lum_core.h LumOutputParams == oracle/oracle.h OracleOutputParamsAbi."""
+    _fields_ = [("src_width", C.c_uint32), ("src_height", C.c_uint32), ("dst_width", C.c_uint32), ("dst_height", C.c_uint32),
+                ("inv_sample_count", C.c_float), ("exposure", C.c_float), ("tonemap", C.c_uint32), ("filter", C.c_uint32), ("dithering", C.c_uint32),
+                ("purkinje", C.c_uint32), ("use_color_correction", C.c_uint32), ("passthrough", C.c_uint32), ("purkinje_kappa1", C.c_float),
+                ("purkinje_kappa2", C.c_float), ("cc_h", C.c_float), ("cc_s", C.c_float), ("cc_v", C.c_float), ("film_grain", C.c_float),
+                ("agx_slope", C.c_float), ("agx_power", C.c_float), ("agx_saturation", C.c_float)]
+
+
+def default_output_params(width, height, sample_count, dst=None):
+    """Camera defaults of the reference (camera.c:7-66): AgX, dithering and Purkinje shift on, exposure exp(0)."""
+    p = OutputParams()
+    p.src_width, p.src_height = width, height
+    p.dst_width, p.dst_height = dst if dst else (width, height)
+    p.inv_sample_count = np.float32(1.0) / np.float32(sample_count)
+    p.exposure = 1.0
+    p.tonemap, p.filter, p.dithering, p.purkinje = 4, 0, 1, 1
+    p.purkinje_kappa1, p.purkinje_kappa2 = 0.2, 0.29
+    p.agx_slope = p.agx_power = p.agx_saturation = 1.0
+    return p
 
 
 class Core:
@@ -48,6 +70,21 @@ class Core:
         self._view_keepalive = view
         self._call("lumc_scene_upload", C.byref(view))
         self.width, self.height = view.width, view.height
+
+    def generate_output(self, params, first_moment=None, want_float=False):
+        """ARGB8 image [dst_height, dst_width] (uint32 words b | g<<8 | r<<16 | a<<24). `first_moment`: None = the context's own
+        accumulators, an int = device pointer to a planar [3*P] first moment, a numpy array = host data (uploaded). Optionally also
+        returns the display-referred float planes [3, src_height, src_width]."""
+        out = np.zeros((params.dst_height, params.dst_width), dtype=np.uint32)
+        planes = np.zeros((3, params.src_height, params.src_width), dtype=np.float32) if want_float else None
+        pl = planes.ctypes.data_as(C.c_void_p) if want_float else C.c_void_p(0)
+        if isinstance(first_moment, np.ndarray):
+            fm = np.ascontiguousarray(first_moment, dtype=np.float32)
+            self._call("lumc_generate_output_from_host", C.byref(params), fm.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p), pl)
+        else:
+            ptr = C.c_void_p(0) if first_moment is None else C.c_void_p(int(first_moment))
+            self._call("lumc_generate_output_host", C.byref(params), ptr, out.ctypes.data_as(C.c_void_p), pl)
+        return (out, planes) if want_float else out
 
     def download_luts(self):
         out = {"conductor": np.zeros(1024, np.uint16), "glossy": np.zeros(1024, np.uint16), "dielectric": np.zeros(32768, np.uint16),

@@ -15,6 +15,7 @@
 
 #include "../../../include/lum_core.h"
 #include "../device/kernels.h"
+#include "../device/dev_output.h"
 #include "bvh_build.h"
 
 using namespace lum;
@@ -42,6 +43,11 @@ struct LumContext {
   NeeQueue nee{};
   ShadowQueue shadow{};
   float4* d_results = nullptr;
+  float* d_frame_output = nullptr;  // display-referred planes of the output chain [3 * W * H]
+  uint32_t frame_output_pixels = 0;
+  uint16_t* d_bluenoise_1d = nullptr;
+  uint32_t* d_argb8 = nullptr;
+  uint32_t argb8_pixels = 0;
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
   // profiling
@@ -255,6 +261,9 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_first_moment) (void) hipFree(ctx->d_first_moment);
   if (ctx->d_second_moment) (void) hipFree(ctx->d_second_moment);
   if (ctx->d_ctrl) (void) hipFree(ctx->d_ctrl);
+  if (ctx->d_frame_output) (void) hipFree(ctx->d_frame_output);
+  if (ctx->d_bluenoise_1d) (void) hipFree(ctx->d_bluenoise_1d);
+  if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   delete ctx;
 }
@@ -605,6 +614,75 @@ int lumc_kernel_times(LumContext* ctx, double total_ms[LUMC_KERNEL_COUNT], uint3
   if (lumc_synchronize(ctx)) return 1;
   for (int k = 0; k < LUMC_KERNEL_COUNT; k++) { total_ms[k] = ctx->kernel_ms[k]; launches[k] = ctx->kernel_launches[k]; }
   return 0;
+}
+
+extern "C" const unsigned char lum_embedded_bluenoise_1d[];
+extern "C" const unsigned char lum_embedded_bluenoise_1d_end[];
+
+int lumc_generate_output(LumContext* ctx, const LumOutputParams* params, const float* d_first_moment, uint32_t* d_argb8, void* stream_) {
+  if (!ctx || !params || !d_argb8) { if (ctx) ctx->error = "lumc_generate_output: null argument"; return 1; }
+  static_assert(sizeof(LumOutputParams) == sizeof(OutputParams), "output parameter structs must match");
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t) stream_;
+  OutputParams p;
+  std::memcpy(&p, params, sizeof(p));
+  if (p.src_width == 0 || p.src_height == 0 || p.dst_width < 2 || p.dst_height < 2) { ctx->error = "lumc_generate_output: image sizes must be at least 2x2"; return 1; }
+  const uint32_t ns = p.src_width * p.src_height;
+  if (!d_first_moment) {
+    if (!ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ns) { ctx->error = "lumc_generate_output: the context does not hold a full frame of this size"; return 1; }
+    d_first_moment = ctx->d_first_moment;
+  }
+  if (!ctx->d_bluenoise_1d) {
+    const size_t bytes = (size_t) (lum_embedded_bluenoise_1d_end - lum_embedded_bluenoise_1d);
+    if (bytes != 65536 * sizeof(uint16_t)) { ctx->error = "embedded 1D blue-noise mask has the wrong size"; return 1; }
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_bluenoise_1d, bytes));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_bluenoise_1d, lum_embedded_bluenoise_1d, bytes, hipMemcpyHostToDevice));
+  }
+  if (ctx->frame_output_pixels < ns) {
+    if (ctx->d_frame_output) (void) hipFree(ctx->d_frame_output);
+    ctx->d_frame_output = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_frame_output, sizeof(float) * 3 * (size_t) ns));
+    ctx->frame_output_pixels = ns;
+  }
+  {
+    Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
+    hipLaunchKernelGGL(k_final_image, dim3(grid_for(ns)), dim3(256), 0, stream, p, d_first_moment, ctx->d_frame_output);
+    hipLaunchKernelGGL(k_to_argb8, dim3(grid_for(p.dst_width * p.dst_height)), dim3(256), 0, stream, p, (const float*) ctx->d_frame_output,
+                       (const uint16_t*) ctx->d_bluenoise_1d, d_argb8);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int lumc_generate_output_host(LumContext* ctx, const LumOutputParams* params, const float* d_first_moment, uint32_t* argb8, float* frame_output) {
+  if (!ctx || !params || !argb8) { if (ctx) ctx->error = "lumc_generate_output_host: null argument"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t n = params->dst_width * params->dst_height;
+  if (ctx->argb8_pixels < n) {
+    if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
+    ctx->d_argb8 = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_argb8, sizeof(uint32_t) * (size_t) n));
+    ctx->argb8_pixels = n;
+  }
+  if (lumc_generate_output(ctx, params, d_first_moment, ctx->d_argb8, nullptr)) return 1;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(argb8, ctx->d_argb8, sizeof(uint32_t) * (size_t) n, hipMemcpyDeviceToHost));
+  if (frame_output)
+    HIP_TRY(ctx, hipMemcpy(frame_output, ctx->d_frame_output, sizeof(float) * 3 * (size_t) params->src_width * params->src_height, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_generate_output_from_host(LumContext* ctx, const LumOutputParams* params, const float* first_moment, uint32_t* argb8, float* frame_output) {
+  if (!ctx || !params || !first_moment || !argb8) { if (ctx) ctx->error = "lumc_generate_output_from_host: null argument"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float) * 3 * (size_t) params->src_width * params->src_height;
+  float* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**) &d, bytes));
+  int rc = 1;
+  if (hipMemcpy(d, first_moment, bytes, hipMemcpyHostToDevice) == hipSuccess) rc = lumc_generate_output_host(ctx, params, d, argb8, frame_output);
+  else ctx->error = "lumc_generate_output_from_host: upload failed";
+  (void) hipFree(d);
+  return rc;
 }
 
 int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream_) {

@@ -1,5 +1,5 @@
-/* Embeds the blue-noise mask into the shared library (the reference embeds its data files with its `Ceb` tool,
- * src/luminary/CMakeLists.txt:206-226). LUM_BLUENOISE_PATH is set by luminary_amd/build.py. */
+/* Embeds the blue-noise masks (2D: sampler, 1D: output dither) into the shared library (the reference embeds its data files with its `Ceb` tool,
+ * src/luminary/CMakeLists.txt:206-226). LUM_BLUENOISE_PATH / LUM_BLUENOISE_1D_PATH are set by luminary_amd/build.py. */
     .section .rodata
     .balign 16
     .global lum_embedded_bluenoise_2d
@@ -7,4 +7,10 @@
 lum_embedded_bluenoise_2d:
     .incbin LUM_BLUENOISE_PATH
 lum_embedded_bluenoise_2d_end:
+    .balign 16
+    .global lum_embedded_bluenoise_1d
+    .global lum_embedded_bluenoise_1d_end
+lum_embedded_bluenoise_1d:
+    .incbin LUM_BLUENOISE_1D_PATH
+lum_embedded_bluenoise_1d_end:
     .section .note.GNU-stack,"",@progbits

@@ -19,6 +19,7 @@
 #endif
 
 #include "o_trace.h"
+#include "o_output.h"
 
 enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
@@ -421,4 +422,14 @@ void oracle_camera_ray(const OracleScene* s, uint32_t x, uint32_t y, uint32_t sa
   vec3 o, d; camera_sample(s, &smp, &o, &d);
   out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = d.x; out[4] = d.y; out[5] = d.z;
 }
+_Static_assert(sizeof(OracleOutputParams) == sizeof(OracleOutputParamsAbi), "output parameter structs must match");
 uint32_t oracle_scene_sizeof(void) { return (uint32_t) sizeof(OracleScene); }
+
+void oracle_generate_output(const OracleOutputParamsAbi* params, const float* first_moment, const uint16_t* bluenoise_1d, float* frame_output, uint32_t* argb8) {
+  OracleOutputParams p;
+  memcpy(&p, params, sizeof(p));
+  output_generate(&p, first_moment, bluenoise_1d, frame_output, argb8);
+}
+float oracle_log2(float x) { return o_log2(x); }
+float oracle_exp2(float x) { return o_exp2(x); }
+float oracle_pow(float x, float y) { return o_pow(x, y); }

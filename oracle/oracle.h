@@ -91,6 +91,22 @@ float oracle_atan2(float y, float x);
 void oracle_camera_ray(const OracleScene* scene, uint32_t x, uint32_t y, uint32_t sample_id, float out[6]);
 uint32_t oracle_scene_sizeof(void);
 
+/* Output chain (o_output.h): planar first moment [3 * src pixels] -> display-referred planes `frame_output` [3 * src pixels] and
+ * ARGB8 words [dst pixels]. Field-for-field the same as LumOutputParams (include/lum_core.h). */
+typedef struct {
+  uint32_t src_width, src_height, dst_width, dst_height;
+  float inv_sample_count, exposure;
+  uint32_t tonemap, filter, dithering, purkinje, use_color_correction, passthrough;
+  float purkinje_kappa1, purkinje_kappa2;
+  float cc_h, cc_s, cc_v;
+  float film_grain;
+  float agx_slope, agx_power, agx_saturation;
+} OracleOutputParamsAbi;
+void oracle_generate_output(const OracleOutputParamsAbi* params, const float* first_moment, const uint16_t* bluenoise_1d, float* frame_output, uint32_t* argb8);
+float oracle_log2(float x);
+float oracle_exp2(float x);
+float oracle_pow(float x, float y);
+
 #ifdef __cplusplus
 }
 #endif
