@@ -347,6 +347,8 @@ extern const char* const luminary_strings_jerlov_water_type[LUMINARY_JERLOV_WATE
 extern const char* const luminary_strings_sky_mode[LUMINARY_SKY_MODE_COUNT];
 extern const char* const luminary_strings_material_base_substrate[LUMINARY_MATERIAL_BASE_SUBSTRATE_COUNT];
 
+/* additive: RGBA8 PNG of an ARGB8 image (words b | g << 8 | r << 16 | a << 24; `ld` = words per row), as luminary_host_save_png writes */
+LUMINARY_API LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld);
 /* additive: bytes currently held through _host_malloc, and the text luminary_write_log would write */
 LUMINARY_API LuminaryResult luminary_ext_host_memory_in_use(uint64_t* bytes);
 LUMINARY_API LuminaryResult luminary_ext_get_log(const char** text, size_t* length);

@@ -84,6 +84,21 @@ class Material(C.Structure):
                 ("luminance_tex", C.c_uint16), ("roughness_tex", C.c_uint16), ("metallic_tex", C.c_uint16), ("normal_tex", C.c_uint16)]
 
 
+class OutputProperties(C.Structure):
+    _fields_ = [("enabled", C.c_bool), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class OutputRequestProperties(C.Structure):
+    _fields_ = [("sample_count", C.c_uint32), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+class Image(C.Structure):
+    _fields_ = [("buffer", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("ld", C.c_size_t), ("time", C.c_float), ("sample_count", C.c_uint32)]
+
+
+OUTPUT_HANDLE_INVALID = 0xFFFFFFFF
+
+
 class Instance(C.Structure):
     _fields_ = [("id", C.c_uint32), ("mesh_id", C.c_uint32), ("position", Vec3), ("rotation", Vec3), ("scale", Vec3)]
 
@@ -226,6 +241,43 @@ class Host:
         _call("luminary_host_get_num_materials", self._h, C.byref(b))
         _call("luminary_host_get_num_instances", self._h, C.byref(c))
         return a.value, b.value, c.value
+
+    # ---- output chain ----
+    def set_output_properties(self, width, height, enabled=True):
+        _call("luminary_host_set_output_properties", self._h, OutputProperties(enabled, width, height))
+
+    def request_output(self, sample_count, width, height):
+        h = C.c_uint32()
+        _call("luminary_host_request_output", self._h, OutputRequestProperties(sample_count, width, height), C.byref(h))
+        return h.value
+
+    def try_await_output(self, promise):
+        h = C.c_uint32()
+        _call("luminary_host_try_await_output", self._h, C.c_uint32(promise), C.byref(h))
+        return None if h.value == OUTPUT_HANDLE_INVALID else h.value
+
+    def acquire_output(self):
+        h = C.c_uint32()
+        _call("luminary_host_acquire_output", self._h, C.byref(h))
+        return None if h.value == OUTPUT_HANDLE_INVALID else h.value
+
+    def get_image(self, handle):
+        """(ARGB8 words [height, width] as a copy, sample_count, time) of an acquired output."""
+        import numpy as np
+        img = Image()
+        _call("luminary_host_get_image", self._h, C.c_uint32(handle), C.byref(img))
+        words = np.ctypeslib.as_array(C.cast(img.buffer, C.POINTER(C.c_uint32)), shape=(img.height, img.ld))[:, :img.width].copy()
+        return words, img.sample_count, img.time
+
+    def release_output(self, handle):
+        _call("luminary_host_release_output", self._h, C.c_uint32(handle))
+
+    def save_png(self, handle, path):
+        p = self._path(path)
+        try:
+            _call("luminary_host_save_png", self._h, C.c_uint32(handle), p)
+        finally:
+            _call("luminary_path_destroy", C.byref(p))
 
     def start_new_render(self):
         _call("luminary_host_start_new_render", self._h)

@@ -16,7 +16,7 @@ OBJ_DIR = os.path.join(ROOT, "lib", "obj")
 ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
-HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp", "host/utils_api.cpp"]
+HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp", "host/utils_api.cpp", "host/output.cpp"]
 HIP_SOURCES = ["host/core.hip"]
 EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -68,7 +68,7 @@ def build(force=False, verbose=False):
         if verbose:
             print(out)
         objs.append(o)
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB])
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", LIB])
     return LIB
 
 

@@ -4,6 +4,8 @@
 // thread; this implementation applies scene edits immediately on the caller's thread and renders synchronously inside the
 // luminary_ext_* calls (one process drives one GPU; DESIGN.md "Threading").
 #include <cmath>
+#include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -18,6 +20,8 @@
 extern "C" const unsigned char lum_embedded_bluenoise_2d[];
 extern "C" const unsigned char lum_embedded_bluenoise_2d_end[];
 
+#include "output.h"
+
 struct LuminaryPath { std::string value; };
 
 struct LuminaryHost {
@@ -31,7 +35,8 @@ struct LuminaryHost {
   bool pixels_all = true;
   uint32_t num_pixels = 0;
   uint32_t accumulated_samples = 0;
-  LuminaryOutputProperties output_props{false, 0, 0};
+  lum::OutputStore outputs;
+  double render_seconds = 0.0;
   std::vector<std::string> log;
   std::mutex mutex;
 };
@@ -218,15 +223,37 @@ LuminaryResult luminary_host_get_queue_worker_name(const LuminaryHost* host, uin
 LuminaryResult luminary_host_get_queue_worker_string(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
 LuminaryResult luminary_host_get_queue_worker_time(const LuminaryHost* host, uint32_t id, double* time) { CHECK_NULL(host); CHECK_NULL(time); (void) id; *time = 0.0; return LUMINARY_SUCCESS; }
 
-// Output chain (tone mapping to ARGB8, promises, PNG) is the next component after the radiance path.
-LuminaryResult luminary_host_set_output_properties(LuminaryHost* host, LuminaryOutputProperties p) { CHECK_NULL(host); host->output_props = p; return LUMINARY_SUCCESS; }
-LuminaryResult luminary_host_request_output(LuminaryHost* host, LuminaryOutputRequestProperties p, LuminaryOutputPromiseHandle* handle) { CHECK_NULL(host); CHECK_NULL(handle); (void) p; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
-LuminaryResult luminary_host_try_await_output(LuminaryHost* host, LuminaryOutputPromiseHandle handle, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); (void) handle; *out = LUMINARY_OUTPUT_HANDLE_INVALID; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
-LuminaryResult luminary_host_acquire_output(LuminaryHost* host, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); *out = LUMINARY_OUTPUT_HANDLE_INVALID; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
-LuminaryResult luminary_host_get_image(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryImage* image) { CHECK_NULL(host); CHECK_NULL(image); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
-LuminaryResult luminary_host_release_output(LuminaryHost* host, LuminaryOutputHandle handle) { CHECK_NULL(host); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+// ---- output chain (host.c:930-1075, host_output_handler.c, device_output.c:178-343) ----
+// Rendering is synchronous here (luminary_ext_render_samples), so outputs are produced on the caller's thread right after the pass
+// that reaches the sample count they are due at; the handle/promise semantics are the reference's.
+LuminaryResult luminary_host_set_output_properties(LuminaryHost* host, LuminaryOutputProperties p) { CHECK_NULL(host); host->outputs.set_properties(p); return LUMINARY_SUCCESS; }
+LuminaryResult luminary_host_request_output(LuminaryHost* host, LuminaryOutputRequestProperties p, LuminaryOutputPromiseHandle* handle) {
+  CHECK_NULL(host); CHECK_NULL(handle);
+  if (p.width < 2 || p.height < 2) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  *handle = host->outputs.add_request(p);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_host_try_await_output(LuminaryHost* host, LuminaryOutputPromiseHandle handle, LuminaryOutputHandle* out) {
+  CHECK_NULL(host); CHECK_NULL(out);
+  return host->outputs.acquire_from_promise(handle, out);
+}
+LuminaryResult luminary_host_acquire_output(LuminaryHost* host, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); return host->outputs.acquire_recurring(out); }
+LuminaryResult luminary_host_get_image(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryImage* image) { CHECK_NULL(host); CHECK_NULL(image); return host->outputs.get_image(handle, image); }
+LuminaryResult luminary_host_release_output(LuminaryHost* host, LuminaryOutputHandle handle) { CHECK_NULL(host); return host->outputs.release(handle); }
+// pixel queries need the identification AOV of the first hit, which the hot path does not keep
 LuminaryResult luminary_host_get_pixel_info(LuminaryHost* host, uint16_t x, uint16_t y, LuminaryPixelQueryResult* result) { CHECK_NULL(host); CHECK_NULL(result); (void) x; (void) y; result->pixel_query_is_valid = false; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
-LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryPath* path) { CHECK_NULL(host); CHECK_NULL(path); (void) handle; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryPath* path) {
+  CHECK_NULL(host); CHECK_NULL(path);
+  if (handle == LUMINARY_OUTPUT_HANDLE_INVALID) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  LuminaryResult r = host->outputs.acquire(handle);
+  if (r) return r;
+  LuminaryImage image;
+  r = host->outputs.get_image(handle, &image);
+  if (!r) r = lum::write_png(path->value.c_str(), reinterpret_cast<const uint32_t*>(image.buffer), image.width, image.height, image.ld);
+  host->outputs.release(handle);
+  return r;
+}
+LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld) { return lum::write_png(path, argb8, width, height, ld); }
 LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) { CHECK_NULL(host); return LUMINARY_ERROR_NOT_IMPLEMENTED; }
 
 // ---- entity getters / setters (host.c:705-900) ----
@@ -344,6 +371,54 @@ LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const LumDevi
   *view = &host->device_scene.view;
   return LUMINARY_SUCCESS;
 }
+namespace {
+// camera / settings -> device-side output state (device_structs.c:40-88: exposure is stored as exp(exposure))
+LumOutputParams output_params(const LuminaryHost* h, uint32_t dst_width, uint32_t dst_height) {
+  const LuminaryCamera& c = h->scene.camera;
+  const LumDeviceSceneView& v = h->device_scene.view;
+  LumOutputParams p;
+  std::memset(&p, 0, sizeof(p));
+  p.src_width = v.width; p.src_height = v.height; p.dst_width = dst_width; p.dst_height = dst_height;
+  p.inv_sample_count = 1.0f / (float) h->accumulated_samples;
+  p.exposure = std::exp(c.exposure);
+  p.tonemap = (uint32_t) c.tonemap; p.filter = (uint32_t) c.filter; p.dithering = c.dithering ? 1u : 0u; p.purkinje = c.purkinje ? 1u : 0u;
+  p.use_color_correction = c.use_color_correction ? 1u : 0u;
+  p.passthrough = (h->scene.settings.shading_mode != LUMINARY_SHADING_MODE_DEFAULT) ? 1u : 0u;
+  p.purkinje_kappa1 = c.purkinje_kappa1; p.purkinje_kappa2 = c.purkinje_kappa2;
+  p.cc_h = c.color_correction.r; p.cc_s = c.color_correction.g; p.cc_v = c.color_correction.b;
+  p.film_grain = c.film_grain;
+  p.agx_slope = c.agx_custom_slope; p.agx_power = c.agx_custom_power; p.agx_saturation = c.agx_custom_saturation;
+  return p;
+}
+
+// device_output_generate_output, device_output.c:203-270: the recurring output if enabled, then every request that is due now
+LuminaryResult produce_outputs(LuminaryHost* h) {
+  if (!h->pixels_all || h->accumulated_samples == 0) return LUMINARY_SUCCESS;
+  const LuminaryOutputProperties props = h->outputs.properties();
+  lum::OutputMeta meta;
+  meta.sample_count = h->accumulated_samples;
+  meta.time = (float) h->render_seconds;
+  if (props.enabled && props.width >= 2 && props.height >= 2) {
+    meta.width = props.width; meta.height = props.height;
+    const uint32_t handle = h->outputs.begin_recurring(meta);
+    const LumOutputParams p = output_params(h, meta.width, meta.height);
+    if (lumc_generate_output_host(h->core, &p, nullptr, h->outputs.data(handle), nullptr)) { h->outputs.publish(handle); return LUMINARY_ERROR_CUDA; }
+    h->outputs.publish(handle);
+  }
+  for (const LuminaryOutputRequestProperties& req : h->outputs.pending_requests()) {
+    if (req.sample_count > 0 && req.sample_count != h->accumulated_samples) continue;
+    meta.width = req.width; meta.height = req.height;
+    uint32_t handle;
+    if (h->outputs.begin_for_request(meta, &handle)) continue;
+    const LumOutputParams p = output_params(h, meta.width, meta.height);
+    const int rc = lumc_generate_output_host(h->core, &p, nullptr, h->outputs.data(handle), nullptr);
+    h->outputs.publish(handle);
+    if (rc) return LUMINARY_ERROR_CUDA;
+  }
+  return LUMINARY_SUCCESS;
+}
+}  // namespace
+
 LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
                                            uint32_t samples_per_pass) {
   CHECK_NULL(host);
@@ -359,10 +434,23 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
     if (!all) host->pixels.assign(pixels, pixels + num_pixels);
     host->num_pixels = all ? host->device_scene.view.width * host->device_scene.view.height : num_pixels;
     host->accumulated_samples = 0;
+    host->render_seconds = 0.0;
   }
-  if (lumc_render(host->core, first_sample, num_samples, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
-  if (lumc_synchronize(host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
-  host->accumulated_samples += num_samples;
+  // stop at every sample count a pending request is keyed to (device_output.c:160-168), produce the outputs due there, go on
+  uint32_t done = 0;
+  while (done < num_samples) {
+    uint32_t chunk = num_samples - done;
+    for (const LuminaryOutputRequestProperties& req : host->outputs.pending_requests())
+      if (req.sample_count > host->accumulated_samples && req.sample_count - host->accumulated_samples < chunk) chunk = req.sample_count - host->accumulated_samples;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (lumc_render(host->core, first_sample + done, chunk, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+    if (lumc_synchronize(host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    host->accumulated_samples += chunk;
+    done += chunk;
+    r = produce_outputs(host);
+    if (r) return r;
+  }
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels) {

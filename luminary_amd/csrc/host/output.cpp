@@ -1,0 +1,210 @@
+#include "output.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+
+namespace lum {
+
+void OutputStore::set_properties(LuminaryOutputProperties p) { std::lock_guard<std::mutex> l(mutex_); props_ = p; }
+LuminaryOutputProperties OutputStore::properties() { std::lock_guard<std::mutex> l(mutex_); return props_; }
+
+uint32_t OutputStore::add_request(LuminaryOutputRequestProperties p) {
+  std::lock_guard<std::mutex> l(mutex_);
+  uint32_t id = kInvalid;
+  for (uint32_t i = 0; i < promises_.size(); i++)
+    if (!promises_[i].pending) { id = i; break; }
+  if (id == kInvalid) { promises_.emplace_back(); id = (uint32_t) promises_.size() - 1; }
+  promises_[id].pending = true;
+  promises_[id].props = p;
+  promises_[id].handle = kInvalid;
+  return id;
+}
+
+std::vector<LuminaryOutputRequestProperties> OutputStore::pending_requests() {
+  std::lock_guard<std::mutex> l(mutex_);
+  std::vector<LuminaryOutputRequestProperties> out;
+  for (const Promise& p : promises_)
+    if (p.pending && p.handle == kInvalid) out.push_back(p.props);
+  return out;
+}
+
+// host_output_handler.c:195-236: the oldest unreferenced slot; slots of another size go first; keep four valid recurring images
+uint32_t OutputStore::slot_for_write(const OutputMeta& meta, bool recurring) {
+  uint32_t selected = kInvalid, valid = 0;
+  uint64_t earliest = UINT64_MAX;
+  bool selected_is_valid = true;
+  for (uint32_t i = 0; i < objects_.size(); i++) {
+    const Object& o = objects_[i];
+    if (o.reference_count || o.promise_reference != kInvalid) continue;
+    const bool still_valid = (o.meta.width == meta.width && o.meta.height == meta.height) || !recurring;
+    if (still_valid) {
+      valid++;
+      if (o.time_stamp >= earliest) continue;
+    }
+    selected = i;
+    earliest = o.time_stamp;
+    if (!still_valid) { selected_is_valid = false; break; }
+  }
+  if (valid < 4 && selected_is_valid) selected = kInvalid;
+  if (selected == kInvalid) { objects_.emplace_back(); selected = (uint32_t) objects_.size() - 1; }
+  return selected;
+}
+
+void OutputStore::prepare(uint32_t handle, const OutputMeta& meta, bool recurring, uint32_t promise) {
+  Object& o = objects_[handle];
+  o.pixels.resize((size_t) meta.width * meta.height);
+  o.meta = meta;
+  o.recurring = recurring;
+  o.populated = false;
+  o.allocated = true;
+  o.reference_count = 1;  // held by the producer until publish()
+  o.promise_reference = promise;
+}
+
+uint32_t OutputStore::begin_recurring(const OutputMeta& meta) {
+  std::lock_guard<std::mutex> l(mutex_);
+  const uint32_t h = slot_for_write(meta, true);
+  prepare(h, meta, true, kInvalid);
+  return h;
+}
+
+LuminaryResult OutputStore::begin_for_request(const OutputMeta& meta, uint32_t* handle) {
+  std::lock_guard<std::mutex> l(mutex_);
+  uint32_t promise = kInvalid;
+  for (uint32_t i = 0; i < promises_.size(); i++) {
+    const Promise& p = promises_[i];
+    if (!p.pending || p.handle != kInvalid) continue;
+    if (p.props.width != meta.width || p.props.height != meta.height) continue;
+    if (p.props.sample_count > 0 && p.props.sample_count != meta.sample_count) continue;
+    promise = i;
+    break;
+  }
+  if (promise == kInvalid) return LUMINARY_ERROR_API_EXCEPTION;  // "Tried to create an output for a request that has no promise."
+  const uint32_t h = slot_for_write(meta, false);
+  prepare(h, meta, false, promise);
+  promises_[promise].handle = h;
+  *handle = h;
+  return LUMINARY_SUCCESS;
+}
+
+uint32_t* OutputStore::data(uint32_t handle) { std::lock_guard<std::mutex> l(mutex_); return handle < objects_.size() ? objects_[handle].pixels.data() : nullptr; }
+
+LuminaryResult OutputStore::publish(uint32_t handle) {
+  std::lock_guard<std::mutex> l(mutex_);
+  if (handle >= objects_.size() || objects_[handle].reference_count == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  objects_[handle].populated = true;
+  objects_[handle].reference_count--;
+  objects_[handle].time_stamp = ++clock_;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult OutputStore::acquire_recurring(uint32_t* handle) {
+  std::lock_guard<std::mutex> l(mutex_);
+  uint32_t latest = kInvalid;
+  uint64_t stamp = 0;
+  for (uint32_t i = 0; i < objects_.size(); i++) {
+    const Object& o = objects_[i];
+    if (!o.populated || o.time_stamp <= stamp) continue;
+    if (o.meta.width != props_.width || o.meta.height != props_.height) continue;
+    if (o.promise_reference != kInvalid || !o.recurring) continue;  // outputs made for requests are not handed out here
+    latest = i;
+    stamp = o.time_stamp;
+  }
+  if (latest != kInvalid) objects_[latest].reference_count++;
+  *handle = latest;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult OutputStore::acquire_from_promise(uint32_t promise, uint32_t* handle) {
+  if (promise == kInvalid) { *handle = kInvalid; return LUMINARY_SUCCESS; }
+  std::lock_guard<std::mutex> l(mutex_);
+  if (promise >= promises_.size()) return LUMINARY_ERROR_API_EXCEPTION;
+  Promise& p = promises_[promise];
+  uint32_t h = p.handle;
+  if (h != kInvalid && !objects_[h].populated) h = kInvalid;
+  if (h != kInvalid) {
+    objects_[h].reference_count++;
+    objects_[h].promise_reference = kInvalid;
+    p.pending = false;
+  }
+  *handle = h;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult OutputStore::acquire(uint32_t handle) {
+  if (handle == kInvalid) return LUMINARY_SUCCESS;
+  std::lock_guard<std::mutex> l(mutex_);
+  if (handle >= objects_.size() || objects_[handle].reference_count == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  objects_[handle].reference_count++;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult OutputStore::release(uint32_t handle) {
+  if (handle == kInvalid) return LUMINARY_SUCCESS;
+  std::lock_guard<std::mutex> l(mutex_);
+  if (handle >= objects_.size() || objects_[handle].reference_count == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  objects_[handle].reference_count--;
+  return LUMINARY_SUCCESS;
+}
+
+LuminaryResult OutputStore::get_image(uint32_t handle, LuminaryImage* image) {
+  if (handle == kInvalid) { std::memset(image, 0, sizeof(*image)); return LUMINARY_SUCCESS; }
+  std::lock_guard<std::mutex> l(mutex_);
+  if (handle >= objects_.size() || objects_[handle].reference_count == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  Object& o = objects_[handle];
+  image->buffer = reinterpret_cast<uint8_t*>(o.pixels.data());
+  image->width = o.meta.width;
+  image->height = o.meta.height;
+  image->ld = o.meta.width;
+  image->meta_data.time = o.meta.time;
+  image->meta_data.sample_count = o.meta.sample_count;
+  return LUMINARY_SUCCESS;
+}
+
+// ---- PNG: signature, IHDR, one IDAT (zlib stream of filter-type-0 scanlines), IEND ----
+namespace {
+void put_u32(std::vector<uint8_t>& v, uint32_t x) { v.push_back(x >> 24); v.push_back(x >> 16); v.push_back(x >> 8); v.push_back(x); }
+void put_chunk(std::vector<uint8_t>& file, const char type[4], const uint8_t* payload, size_t n) {
+  put_u32(file, (uint32_t) n);
+  const size_t start = file.size();
+  file.insert(file.end(), type, type + 4);
+  if (n) file.insert(file.end(), payload, payload + n);
+  put_u32(file, (uint32_t) crc32(0L, file.data() + start, (uInt) (n + 4)));
+}
+}  // namespace
+
+LuminaryResult write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld) {
+  if (!path || !argb8) return LUMINARY_ERROR_ARGUMENT_NULL;
+  if (width == 0 || height == 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  std::vector<uint8_t> raw((size_t) height * (1 + 4 * (size_t) width));
+  for (uint32_t y = 0; y < height; y++) {
+    uint8_t* row = raw.data() + (size_t) y * (1 + 4 * (size_t) width);
+    row[0] = 0;  // filter type None
+    for (uint32_t x = 0; x < width; x++) {
+      const uint32_t w = argb8[x + (size_t) y * ld];
+      row[1 + 4 * x + 0] = (w >> 16) & 0xFF;
+      row[1 + 4 * x + 1] = (w >> 8) & 0xFF;
+      row[1 + 4 * x + 2] = w & 0xFF;
+      row[1 + 4 * x + 3] = w >> 24;
+    }
+  }
+  uLongf bound = compressBound((uLong) raw.size());
+  std::vector<uint8_t> z(bound);
+  if (compress2(z.data(), &bound, raw.data(), (uLong) raw.size(), 6) != Z_OK) return LUMINARY_ERROR_C_STD;
+  std::vector<uint8_t> file = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  std::vector<uint8_t> ihdr;
+  put_u32(ihdr, width); put_u32(ihdr, height);
+  ihdr.push_back(8); ihdr.push_back(6); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);  // 8 bit, truecolour + alpha
+  put_chunk(file, "IHDR", ihdr.data(), ihdr.size());
+  put_chunk(file, "IDAT", z.data(), bound);
+  put_chunk(file, "IEND", nullptr, 0);
+  FILE* f = std::fopen(path, "wb");
+  if (!f) return LUMINARY_ERROR_C_STD;
+  const size_t written = std::fwrite(file.data(), 1, file.size(), f);
+  std::fclose(f);
+  return written == file.size() ? LUMINARY_SUCCESS : LUMINARY_ERROR_C_STD;
+}
+
+}  // namespace lum

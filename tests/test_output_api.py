@@ -1,0 +1,114 @@
+"""Output side of the public API: promises and handles (host.h:72-87, :123), PNG files. CPU part: the store's rules and the PNG
+writer; GPU part: images delivered through the API equal the oracle's output chain applied to the oracle's render."""
+import ctypes as C
+import struct
+import zlib
+
+import numpy as np
+import pytest
+
+import luminary_amd
+import oracle_lib
+from luminary_amd import LuminaryError, scenes
+from luminary_amd.core import default_output_params
+
+INVALID_ARG, API_EXCEPTION = 3, 7
+
+
+def _decode_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, chunks = 8, []
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        (crc,) = struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])
+        assert crc == zlib.crc32(typ + body), typ
+        chunks.append((typ, body))
+        pos += 12 + n
+    assert [c[0] for c in chunks] == [b"IHDR", b"IDAT", b"IEND"]
+    w, h, depth, colour, comp, filt, interlace = struct.unpack(">IIBBBBB", chunks[0][1])
+    assert (depth, colour, comp, filt, interlace) == (8, 6, 0, 0, 0)
+    raw = zlib.decompress(chunks[1][1])
+    rows = np.frombuffer(raw, dtype=np.uint8).reshape(h, 1 + 4 * w)
+    assert (rows[:, 0] == 0).all()
+    return rows[:, 1:].reshape(h, w, 4)
+
+
+def test_png_writer_round_trip(tmp_path):
+    lib = luminary_amd._lib()
+    lib.luminary_ext_write_png.restype = C.c_uint64
+    rng = np.random.RandomState(0)
+    w, h, ld = 37, 21, 40
+    img = rng.randint(0, 2 ** 32, size=(h, ld), dtype=np.uint64).astype(np.uint32)
+    path = str(tmp_path / "a.png")
+    assert lib.luminary_ext_write_png(path.encode(), img.ctypes.data_as(C.c_void_p), C.c_uint32(w), C.c_uint32(h), C.c_size_t(ld)) == 0
+    rgba = _decode_png(path)
+    words = img[:, :w]
+    want = np.stack([(words >> 16) & 0xFF, (words >> 8) & 0xFF, words & 0xFF, words >> 24], axis=-1).astype(np.uint8)
+    assert np.array_equal(rgba, want)
+    assert lib.luminary_ext_write_png(path.encode(), img.ctypes.data_as(C.c_void_p), C.c_uint32(0), C.c_uint32(h), C.c_size_t(ld)) == INVALID_ARG
+
+
+def test_output_handles_without_rendering(tmp_path):
+    host = scenes.cornell_host(str(tmp_path), 32, 32, 1)
+    host.set_output_properties(32, 32)
+    p0 = host.request_output(4, 32, 32)
+    p1 = host.request_output(0, 64, 48)
+    assert p0 != p1
+    assert host.try_await_output(p0) is None and host.try_await_output(p1) is None and host.acquire_output() is None
+    with pytest.raises(LuminaryError) as e:
+        host.request_output(1, 1, 32)  # images are at least 2 x 2
+    assert e.value.code == INVALID_ARG
+    with pytest.raises(LuminaryError) as e:
+        host.release_output(5)  # never handed out
+    assert e.value.code == API_EXCEPTION
+    host.release_output(luminary_amd.OUTPUT_HANDLE_INVALID)  # releasing "no output" is allowed (host_output_handler.c:150-152)
+    with pytest.raises(LuminaryError) as e:
+        host.save_png(luminary_amd.OUTPUT_HANDLE_INVALID, str(tmp_path / "x.png"))
+    assert e.value.code == INVALID_ARG
+
+
+@pytest.mark.gpu
+def test_outputs_through_the_api_match_the_oracle(tmp_path):
+    w, h = 64, 48
+    host = scenes.cornell_host(str(tmp_path), w, h, 3)
+    cam = host.get_camera()
+    cam.exposure = 0.5
+    host.set_camera(cam)
+    host.set_output_properties(w, h)
+    at2 = host.request_output(2, w, h)          # exactly at 2 samples
+    scaled = host.request_output(0, 100, 30)    # the next output, other size
+    at3 = host.request_output(3, w, h)          # the render loop stops at every requested count inside a render call
+    host.render_samples(0, 4, samples_per_pass=4)
+
+    view = oracle_lib.with_luts(host.device_scene())
+
+    def oracle_image(spp, dst=None):
+        fm, _, _ = oracle_lib.render(view, 0, spp)
+        p = default_output_params(w, h, spp, dst=dst)
+        p.exposure = float(np.exp(np.float32(0.5)))
+        return oracle_lib.generate_output(p, fm)[0]
+
+    h2 = host.try_await_output(at2)
+    assert h2 is not None
+    img, count, _ = host.get_image(h2)
+    assert count == 2 and np.array_equal(img, oracle_image(2))
+    hs = host.try_await_output(scaled)
+    img_s, count_s, _ = host.get_image(hs)
+    assert img_s.shape == (30, 100) and count_s == 2 and np.array_equal(img_s, oracle_image(2, dst=(100, 30)))
+    h3 = host.try_await_output(at3)
+    assert h3 is not None and host.get_image(h3)[1] == 3 and np.array_equal(host.get_image(h3)[0], oracle_image(3))
+    rec = host.acquire_output()
+    img_r, count_r, t = host.get_image(rec)
+    assert count_r == 4 and t > 0.0 and np.array_equal(img_r, oracle_image(4))
+    assert len({h2, hs, h3, rec}) == 4  # images owed to promises are not recycled before they were awaited
+
+    path = str(tmp_path / "frame.png")
+    host.save_png(rec, path)
+    rgba = _decode_png(path)
+    assert np.array_equal(rgba[..., 0], (img_r >> 16) & 0xFF) and np.array_equal(rgba[..., 2], img_r & 0xFF) and (rgba[..., 3] == 255).all()
+    for handle in (h2, hs, h3, rec):
+        host.release_output(handle)
+    with pytest.raises(LuminaryError):
+        host.release_output(rec)  # already released
