@@ -53,6 +53,8 @@ def build_workload(name, width, height, bounces):
         return scenes.example_scene(width, height, bounces), "C2 Example-class scene (~100k triangles, 72 instances, 16 emissive quads)"
     if name == "hall":
         return scenes.hall_scene(width, height, bounces), "C3 Sponza-class hall (1M triangles, one mesh, 32 emissive panels)"
+    if name == "scan":
+        return scenes.scan_scene(width, height, bounces), "C5 scanned-object class (5.2M-triangle displaced icosphere, 8 area lights)"
     if name == "cornell":
         return scenes.cornell_host("/tmp/lum_bench_cornell", width, height, bounces), "C1 Cornell box (36 triangles)"
     raise SystemExit("unknown workload " + name)
@@ -168,6 +170,18 @@ def main():
 
     cnt = core.counters()
     times = core.kernel_times()
+    # output chain (tone map + ARGB8 of the frame just rendered), outside the timed region: streaming kernels, 40 B/pixel algorithmic
+    output_chain = None
+    if world == 1:
+        from luminary_amd.core import default_output_params
+        op = default_output_params(view.width, view.height, max(spp_step * (args.steps + args.warmup), 1))
+        for _ in range(5):
+            core.generate_output(op, fm.data_ptr())
+        out_ms, out_n = core.kernel_times()["output"]
+        if out_n:
+            per = out_ms / out_n
+            output_chain = {"ms_per_frame": round(per, 4), "GB/s": round(40.0 * view.width * view.height / (per * 1e-3) / 1e9, 1),
+                            "frac_of_hbm_peak": round(40.0 * view.width * view.height / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)}
     rays_local = cnt[CNT_TRACE] + cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]
     stats = torch.tensor([float(rays_local), float(cnt[CNT_TRACE]), float(cnt[CNT_SHADOW]), float(cnt[CNT_LIGHT_BVH]), elapsed], dtype=torch.float64,
                          device="cuda")
@@ -192,7 +206,7 @@ def main():
     roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": measured_traffic(args.workload, "k_trace" if dominant == "trace" else "k_shadow_rays", args.samples_per_pass) if world == 1 else None, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
                 "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1)}
-    cpu = cpu_baseline(view, args.cpu_budget) if args.cpu_budget > 0 else None
+    cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1) else None  # reported at N=1 only
     out = {
         "metric": "Mrays/s at 1920x1080, 8 bounces", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
@@ -204,7 +218,7 @@ def main():
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2),
                                      "lds_hit_rate_closest": round(cnt[10] / max(nodes_trace, 1), 3), "lds_hit_rate_shadow": round(cnt[11] / max(nodes_shadow, 1), 3)},
-                   "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()}, "scene_upload_s": round(upload_s, 2)},
+                   "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()}, "output_chain_rank0": output_chain, "scene_upload_s": round(upload_s, 2)},
         "roofline": roofline, "cpu_baseline": cpu,
     }
     print(json.dumps(out))

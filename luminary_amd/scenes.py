@@ -188,7 +188,10 @@ def example_scene(width=1920, height=1080, bounces=8, seed=1, sphere_segments=20
     for _ in range(12):
         albedo = 0.2 + 0.7 * rng.rand(3)
         rough = [0.05, 0.3, 0.7][rng.randint(3)]
-        palette.append(host.add_material(_material(albedo, rough, metallic=rng.rand() < 0.05)))
+        metallic = rng.rand() < 0.05
+        if os.environ.get("LUM_EXPERIMENT_UNIFORM_MATERIALS"):  # measurement only: one material class everywhere
+            rough, metallic = 0.7, False
+        palette.append(host.add_material(_material(albedo, rough, metallic=metallic)))
     ground_mat = host.add_material(_material((0.6, 0.6, 0.6), 0.7))
     light_mat = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(20.0, 18.0, 15.0)))
 

@@ -173,3 +173,43 @@ def test_trace_parity_material_zoo(core):
     got = core.trace_closest_host(o, d, ign)
     want = oracle_lib.trace_closest(view, o, d, ign, use_bvh=False)
     _assert_same(got, want, "closest hits (rotated, non-uniformly scaled instances) vs brute force")
+
+
+def test_full_size_frame_properties(core):
+    """BASELINE config 1 at its full size (1920x1080, 8 bounces, ~100 k triangles): size-independent properties instead of a full
+    oracle frame - a strided sample of pixels equals the oracle exactly, two sample ids rendered in one pass equal two passes, and a
+    3-way tile partition reproduces the full frame bit for bit (checked through exact equality and a checksum of the bit patterns)."""
+    host = scenes.example_scene(1920, 1080, 8)
+    view = oracle_lib.with_luts(host.device_scene())
+    core.upload(view)
+    core.set_pixels(None)
+    core.reset_counters()
+    core.render(0, 2, samples_per_pass=2)
+    full, full_sm = core.accumulators()
+    cnt = core.counters()
+    assert np.isfinite(full).all() and full.max() > 0.0 and cnt[0] > 2 * 1920 * 1080
+    checksum = int(full.view(np.uint32).astype(np.uint64).sum() + full_sm.view(np.uint32).astype(np.uint64).sum())
+
+    px = np.arange(0, 1920 * 1080, 977, dtype=np.uint32)  # 2123 pixels across the frame
+    ofm, osm, _ = oracle_lib.render(view, 0, 2, pixels=px)
+    _assert_same(full[:, px], ofm, "strided pixels of the full-size frame vs oracle")
+    _assert_same(full_sm[px], osm, "second moment of the strided pixels")
+
+    core.clear()
+    core.render(0, 1, samples_per_pass=1)
+    core.render(1, 1, samples_per_pass=1)
+    two, two_sm = core.accumulators()
+    _assert_same(two, full, "one sample id per pass vs two per pass")
+
+    import bench
+    acc = np.zeros_like(full)
+    acc_sm = np.zeros_like(full_sm)
+    for rank in range(3):
+        tiles = bench.tile_pixels(1920, 1080, rank, 3)
+        core.set_pixels(tiles)
+        core.render(0, 2, samples_per_pass=2)
+        part, part_sm = core.accumulators()
+        acc[:, tiles] = part
+        acc_sm[tiles] = part_sm
+    assert int(acc.view(np.uint32).astype(np.uint64).sum() + acc_sm.view(np.uint32).astype(np.uint64).sum()) == checksum
+    _assert_same(acc, full, "3-rank tile partition at full size")
