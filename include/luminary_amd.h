@@ -347,6 +347,10 @@ extern const char* const luminary_strings_jerlov_water_type[LUMINARY_JERLOV_WATE
 extern const char* const luminary_strings_sky_mode[LUMINARY_SKY_MODE_COUNT];
 extern const char* const luminary_strings_material_base_substrate[LUMINARY_MATERIAL_BASE_SUBSTRATE_COUNT];
 
+/* Embedded data files by name, as the reference's Ceb-generated accessor (device/device_embedded.c:1075-1093): "bluenoise_1D.bin",
+ * "bluenoise_2D.bin"; *info = 0 on success, non-zero for an unknown name (frontend assets such as fonts are not part of this library). */
+LUMINARY_API void ceb_access(const char* name, void** ptr, int64_t* lmem, uint64_t* info);
+
 /* additive: RGBA8 PNG of an ARGB8 image (words b | g << 8 | r << 16 | a << 24; `ld` = words per row), as luminary_host_save_png writes */
 LUMINARY_API LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld);
 /* additive: bytes currently held through _host_malloc, and the text luminary_write_log would write */

@@ -448,6 +448,29 @@ LuminaryResult luminary_ext_get_log(const char** text, size_t* length) {
   return LUMINARY_SUCCESS;
 }
 
+// ---- embedded files: the reference embeds its data with the Ceb tool and frontends fetch them by name
+// (device/device_embedded.c:10-14, :1075-1093; src/mandarin_duck/display.c:219). info = 0 on success, non-zero = unknown name. ----
+extern const unsigned char lum_embedded_bluenoise_2d[];
+extern const unsigned char lum_embedded_bluenoise_2d_end[];
+extern const unsigned char lum_embedded_bluenoise_1d[];
+extern const unsigned char lum_embedded_bluenoise_1d_end[];
+void ceb_access(const char* name, void** ptr, int64_t* lmem, uint64_t* info) {
+  struct Entry { const char* name; const unsigned char* begin; const unsigned char* end; };
+  const Entry files[] = {{"bluenoise_2D.bin", lum_embedded_bluenoise_2d, lum_embedded_bluenoise_2d_end},
+                         {"bluenoise_1D.bin", lum_embedded_bluenoise_1d, lum_embedded_bluenoise_1d_end}};
+  if (info) *info = 1;
+  if (ptr) *ptr = nullptr;
+  if (lmem) *lmem = 0;
+  if (!name) return;
+  for (const Entry& e : files) {
+    if (strcmp(name, e.name) != 0) continue;
+    if (ptr) *ptr = const_cast<unsigned char*>(e.begin);
+    if (lmem) *lmem = (int64_t) (e.end - e.begin);
+    if (info) *info = 0;
+    return;
+  }
+}
+
 // ---- name_strings.h ----
 const char* const luminary_strings_shading_mode[LUMINARY_SHADING_MODE_COUNT] = {"None", "Albedo", "Depth", "Normal", "Identification", "Lights"};
 const char* const luminary_strings_adaptive_sampling_output_mode[LUMINARY_ADAPTIVE_SAMPLING_OUTPUT_MODE_COUNT] = {"Beauty", "Rel Variance", "Rel Error",

@@ -203,3 +203,17 @@ def test_log_and_name_tables(tmp_path, monkeypatch):
     assert table("luminary_strings_material_base_substrate", 2) == ["Opaque", "Translucent"]
     assert table("luminary_strings_aperture", 2) == ["Round", "Bladed"] and len(table("luminary_strings_jerlov_water_type", 10)) == 10
     assert table("luminary_strings_adaptive_sampling_output_mode", 4)[1] == "Rel Variance"
+
+
+def test_embedded_files_by_name():
+    import os
+    l = lib()
+    l.ceb_access.restype = None
+    ptr, n, info = C.c_void_p(), C.c_int64(), C.c_uint64(7)
+    l.ceb_access(b"bluenoise_1D.bin", C.byref(ptr), C.byref(n), C.byref(info))
+    data_dir = os.path.join(os.path.dirname(luminary_amd.__file__), "data")
+    assert info.value == 0 and n.value == 131072 and C.string_at(ptr, n.value) == open(os.path.join(data_dir, "bluenoise_1D.bin"), "rb").read()
+    l.ceb_access(b"bluenoise_2D.bin", C.byref(ptr), C.byref(n), C.byref(info))
+    assert info.value == 0 and n.value == 262144 and C.string_at(ptr, 64) == open(os.path.join(data_dir, "bluenoise_2D.bin"), "rb").read(64)
+    l.ceb_access(b"SplashScreen.bmp", C.byref(ptr), C.byref(n), C.byref(info))
+    assert info.value != 0 and ptr.value is None and n.value == 0
