@@ -314,15 +314,21 @@ LUM_DEV RayTerms analyze_direction(const MatParams& p, V3 normal, V3 V, V3 L) {
   c.is_refraction = c.NdotL < 0.0f;
   c.NdotL = c.is_refraction ? -c.NdotL : c.NdotL;
   const float ior = p.ior();
-  V3 refr, H;
-  bool total_reflection;
-  if (c.is_refraction) { total_reflection = false; H = half_vector(L, V, ior); refr = L; }
-  else { H = half_vector(L, V, 1.0f); refr = refract(V, H, ior, total_reflection); }
+  // the dielectric Fresnel term is read by the dielectric lobe only, which is empty unless the substrate is translucent
+  const bool needs_fresnel = (p.flags & kMatSubstrateMask) == kMatTranslucent;
+  V3 refr = L, H;
+  bool total_reflection = false;
+  if (c.is_refraction) H = half_vector(L, V, ior);
+  else {
+    H = half_vector(L, V, 1.0f);
+    if (needs_fresnel) refr = refract(V, H, ior, total_reflection);
+  }
   c.HdotV = fabsf(dot(H, V));
   c.HdotL = fabsf(dot(H, L));
   c.NdotH = dot(normal, H);
   if (c.NdotH < 0.0f) { H = H * -1.0f; c.NdotH = -c.NdotH; }
-  c.fresnel_dielectric = total_reflection ? 1.0f : fresnel_dielectric(H, V, refr, ior);
+  c.fresnel_dielectric = 1.0f;
+  if (needs_fresnel && !total_reflection) c.fresnel_dielectric = fresnel_dielectric(H, V, refr, ior);
   c.V = V;
   return c;
 }
@@ -341,15 +347,17 @@ LUM_DEV RayTerms sampled_direction_terms(const MatParams& p, V3 normal, V3 V, V3
   c.is_refraction = is_refraction;
   c.NdotL = is_refraction ? -c.NdotL : c.NdotL;
   const float ior = p.ior();
+  const bool needs_fresnel = (p.flags & kMatSubstrateMask) == kMatTranslucent;  // see analyze_direction
   bool total_reflection = false;
-  V3 refr;
-  if (is_refraction) refr = L; else refr = refract(V, H, ior, total_reflection);
+  V3 refr = L;
+  if (!is_refraction && needs_fresnel) refr = refract(V, H, ior, total_reflection);
   c.HdotV = fabsf(dot(H, V));
   c.HdotL = fabsf(dot(H, L));
   c.NdotH = dot(normal, H);
   float flip = 1.0f;
   if (c.NdotH < 0.0f) { flip = -1.0f; c.NdotH = -c.NdotH; }
-  c.fresnel_dielectric = total_reflection ? 1.0f : fresnel_dielectric(H * flip, V, refr, ior);
+  c.fresnel_dielectric = 1.0f;
+  if (needs_fresnel && !total_reflection) c.fresnel_dielectric = fresnel_dielectric(H * flip, V, refr, ior);
   c.V = V;
   return c;
 }

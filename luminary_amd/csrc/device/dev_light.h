@@ -9,6 +9,9 @@
 namespace lum {
 
 constexpr uint32_t kLightTreeOutputs = 8;
+#ifndef LUM_ABLATE_LIGHT
+#define LUM_ABLATE_LIGHT 0  // measurement only: 1 no BSDF evaluation, 2 no MIS weight, 4 one resampling lane in the root pass (results are wrong)
+#endif
 constexpr uint32_t kLightIdInvalid   = 0xFFFFFFFFu;
 
 LUM_DEV Transform load_transform(const DeviceScene& sc, uint32_t inst) {
@@ -95,7 +98,7 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const 
       // --use_fast_math, multiplies by a reciprocal here as well: cuda/ris.cuh:138-148).
       const float inv_accept = 1.0f / prob, inv_reject = 1.0f / (1.0f - prob);
 #pragma unroll
-      for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
+      for (uint32_t l = 0; l < ((LUM_ABLATE_LIGHT & 4) ? 1u : kLightTreeOutputs); l++) {
         const bool accept = lane_random[l] < prob;
         lane_target[l] = accept ? target : lane_target[l];
         const float shifted = accept ? lane_random[l] : lane_random[l] - prob;
@@ -311,8 +314,14 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     if (dist == kFltMax) continue;
     Col lc = tri_light_color(sc, tl);
     bool is_refraction;
-    const Col bw = eval_bsdf(energy, g, ray, kHintGeneral, is_refraction, 1.0f);
-    const float mis = mis_for_light_sample(g, ray, tl, lc, dist, sa, work.root_sum);
+#ifndef LUM_ABLATE_LIGHT_DEFINED_BELOW
+#define LUM_ABLATE_LIGHT_DEFINED_BELOW
+#endif
+#if 0
+#define LUM_ABLATE_LIGHT 0  // measurement only: 1 no BSDF evaluation, 2 no MIS weight, 4 one resampling lane in the root pass (results are wrong)
+#endif
+    const Col bw = (LUM_ABLATE_LIGHT & 1) ? splat(0.5f) : eval_bsdf(energy, g, ray, kHintGeneral, is_refraction, 1.0f);
+    const float mis = (LUM_ABLATE_LIGHT & 2) ? 0.5f : mis_for_light_sample(g, ray, tl, lc, dist, sa, work.root_sum);
     lc = (lc * bw) * mis;
     if (rv.add(importance(lc), pick.weight * sa)) { out.light_id = pick.light_id; out.ray = ray; out.color = lc; out.dist = dist; }
   }

@@ -92,6 +92,7 @@ LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tm
 // workgroup of the persistent ray kernels: a divergent 16-byte LDS read costs a fraction of a divergent L1 access.
 struct NodeSource { const Bvh4Node* global; const char* lds; uint32_t lds_count; };
 
+template <bool kOrdered>
 LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp, uint2& top, RayStats& st) {
   const uint32_t b = cur << 7;
   float4 nx, ny, nz, fx, fy, fz;
@@ -114,7 +115,9 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
   float k2 = child_entry(nx.z, ny.z, nz.z, fx.z, fy.z, fz.z, r, tmax);
   float k3 = child_entry(nx.w, ny.w, nz.w, fx.w, fy.w, fz.w, r, tmax);
   uint32_t c0 = ch.x, c1 = ch.y, c2 = ch.z, c3 = ch.w;
-  cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
+  if (kOrdered) {  // nearest first; visibility rays visit everything on the segment anyway, any order does
+    cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
+  }
   const float inf = __builtin_inff();
   // Branch-free pushes. The newest entry lives in registers (`top`), older ones in scratch: a push spills the old top to a slot
   // that is only kept if the push is real, so a pop never waits for a scratch load before it can fetch the next node.
@@ -232,7 +235,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     while (cur != kTraversalDone) {
       while (!(cur & kBvhLeafBit)) {
         st.nodes++;
-        cur = visit_node(nodes, cur, r, tmax, stk, sp, top, st);
+        cur = visit_node<Q::kOrdered>(nodes, cur, r, tmax, stk, sp, top, st);
         if (cur == kBvhEmpty) pop();
       }
       if (cur != kTraversalDone) {
@@ -263,6 +266,7 @@ struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
 struct ClosestState {
+  static constexpr bool kOrdered = true;
   bool use_ignore;
   uint32_t ign_inst, ign_tri;
   Hit best;
@@ -293,6 +297,7 @@ struct ClosestState {
 // product of three or more factors depends on it, so the product is carried in binary64 (exact for two factors, 29 guard bits
 // beyond that) and rounded to binary32 once at the end; the oracle does the same.
 struct ShadowState {
+  static constexpr bool kOrdered = false;
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
   double tr, tg, tb;
@@ -340,7 +345,7 @@ LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, Ray
     }
     else {
       st.nodes++;
-      cur = visit_node(NodeSource{sc.light_nodes, nullptr, 0u}, cur, r, tmax, stk, sp, top, st);
+      cur = visit_node<true>(NodeSource{sc.light_nodes, nullptr, 0u}, cur, r, tmax, stk, sp, top, st);
     }
     if (cur == kBvhEmpty) {
       while (true) {
