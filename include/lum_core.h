@@ -46,12 +46,14 @@ typedef struct LumDeviceSceneView {
   const uint32_t* light_tri_handles;  /* 2 per light */
   const float* light_bvh_tris;        /* 12 floats per light (device_light.h LightTreeBVHTriangle) */
   uint32_t num_light_tree_nodes;
-  uint32_t pad0;
+  uint32_t num_textures;
   const uint32_t* bluenoise_2d;       /* 65536 texels */
   const uint16_t* lut_conductor;      /* 4 BSDF energy tables; pass NULL to have the library generate them on the GPU */
   const uint16_t* lut_glossy;
   const uint16_t* lut_dielectric;
   const uint16_t* lut_dielectric_inv;
+  const uint32_t* texture_table;      /* 4 words per texture: first texel, width, height, gamma (float bits) */
+  const uint32_t* texels;             /* RGBA8, r in the low byte; all textures back to back */
   uint32_t width, height, max_ray_depth, shading_mode;
   float cam_pos[3];
   float cam_rotation[4];

@@ -347,6 +347,11 @@ extern const char* const luminary_strings_jerlov_water_type[LUMINARY_JERLOV_WATE
 extern const char* const luminary_strings_sky_mode[LUMINARY_SKY_MODE_COUNT];
 extern const char* const luminary_strings_material_base_substrate[LUMINARY_MATERIAL_BASE_SUBSTRATE_COUNT];
 
+/* Adds an RGBA8 texture (byte order r, g, b, a; rows top to bottom as in a PNG) and returns the id materials refer to through
+ * albedo_tex / roughness_tex / normal_tex (luminance and metallic textures are not evaluated, the latter like in the reference). `gamma` is
+ * applied to r, g, b on fetch (1 = none; PNG files carry 100000 / gAMA). */
+LUMINARY_API LuminaryResult luminary_ext_add_texture(LuminaryHost* host, const uint8_t* rgba8, uint32_t width, uint32_t height, float gamma, uint16_t* texture_id);
+
 /* Embedded data files by name, as the reference's Ceb-generated accessor (device/device_embedded.c:1075-1093): "bluenoise_1D.bin",
  * "bluenoise_2D.bin"; *info = 0 on success, non-zero for an unknown name (frontend assets such as fonts are not part of this library). */
 LUMINARY_API void ceb_access(const char* name, void** ptr, int64_t* lmem, uint64_t* info);

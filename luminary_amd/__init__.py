@@ -108,9 +108,9 @@ class DeviceSceneView(C.Structure):
     _fields_ = [("num_meshes", C.c_uint32), ("num_instances", C.c_uint32), ("num_materials", C.c_uint32), ("num_lights", C.c_uint32),
                 ("mesh_tri_offset", C.c_void_p), ("vertices", C.c_void_p), ("tri_tex", C.c_void_p), ("instance_mesh_ids", C.c_void_p),
                 ("instance_transforms", C.c_void_p), ("materials", C.c_void_p), ("light_tree_root", C.c_void_p), ("light_tree_nodes", C.c_void_p),
-                ("light_tri_handles", C.c_void_p), ("light_bvh_tris", C.c_void_p), ("num_light_tree_nodes", C.c_uint32), ("pad0", C.c_uint32),
+                ("light_tri_handles", C.c_void_p), ("light_bvh_tris", C.c_void_p), ("num_light_tree_nodes", C.c_uint32), ("num_textures", C.c_uint32),
                 ("bluenoise_2d", C.c_void_p), ("lut_conductor", C.c_void_p), ("lut_glossy", C.c_void_p), ("lut_dielectric", C.c_void_p),
-                ("lut_dielectric_inv", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("max_ray_depth", C.c_uint32),
+                ("lut_dielectric_inv", C.c_void_p), ("texture_table", C.c_void_p), ("texels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("max_ray_depth", C.c_uint32),
                 ("shading_mode", C.c_uint32), ("cam_pos", C.c_float * 3), ("cam_rotation", C.c_float * 4), ("cam_fov", C.c_float),
                 ("cam_aperture_size", C.c_float), ("cam_object_distance", C.c_float), ("cam_scale", C.c_float), ("cam_rr_threshold", C.c_float),
                 ("cam_aperture_shape", C.c_uint32), ("cam_aperture_blade_count", C.c_uint32), ("sky_mode", C.c_uint32),
@@ -301,6 +301,16 @@ class Host:
         _call("luminary_ext_add_mesh", self._h, positions.ctypes.data_as(C.c_void_p), npt, upt, material_ids.ctypes.data_as(C.c_void_p),
               C.c_uint32(n), C.byref(mid))
         return mid.value
+
+    def add_texture(self, rgba8, gamma=1.0):
+        """rgba8: uint8 array [height, width, 4]; returns the texture id for Material.albedo_tex / roughness_tex / normal_tex."""
+        import numpy as np
+        img = np.ascontiguousarray(rgba8, dtype=np.uint8)
+        assert img.ndim == 3 and img.shape[2] == 4
+        i = C.c_uint16()
+        _call("luminary_ext_add_texture", self._h, img.ctypes.data_as(C.c_void_p), C.c_uint32(img.shape[1]), C.c_uint32(img.shape[0]), C.c_float(gamma),
+              C.byref(i))
+        return i.value
 
     def add_material(self, m):
         i = C.c_uint16()

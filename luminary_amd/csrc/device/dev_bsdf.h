@@ -14,7 +14,7 @@ namespace lum {
 
 enum DevMatFlag : uint32_t {  // device_structs.h:186-200
   kDMatSubstrateMask = 0x01, kDMatEmission = 0x02, kDMatMetallic = 0x08, kDMatColoredTransparency = 0x10,
-  kDMatRoughnessAsSmoothness = 0x20, kDMatBidirectionalEmission = 0x80
+  kDMatRoughnessAsSmoothness = 0x20, kDMatNormalMapCompressed = 0x40, kDMatBidirectionalEmission = 0x80
 };
 enum MatFlag : uint32_t { kMatTranslucent = 1, kMatSubstrateMask = 1, kMatRefractionInside = 2, kMatMetallic = 4, kMatColoredTransparency = 8 };
 constexpr uint32_t kTextureNone = 0xFFFFu;
@@ -24,7 +24,7 @@ struct Material {
   float roughness_clamp, roughness, refraction_index;
   Col albedo; float alpha;
   Col emission;
-  uint32_t metallic_tex;
+  uint32_t metallic_tex, albedo_tex, luminance_tex, roughness_tex, normal_tex;
 };
 
 LUM_DEV Material load_material(const DeviceScene& sc, uint32_t id) {
@@ -39,7 +39,58 @@ LUM_DEV Material load_material(const DeviceScene& sc, uint32_t id) {
   m.alpha            = unorm16(a.w >> 16);
   const float scale  = bitsf((b.y >> 16) << 15);
   m.emission         = col(unorm16(b.x), unorm16(b.x >> 16), unorm16(b.y)) * scale;
+  m.albedo_tex = b.z & 0xFFFFu; m.luminance_tex = b.z >> 16; m.roughness_tex = b.w & 0xFFFFu; m.normal_tex = b.w >> 16;
   return m;
+}
+
+// ---- textures (cuda/texture_utils.cuh:20-45; objects are created normalised, wrap-addressed, linearly filtered, mip level 0:
+// texture.c:77-90, device_texture.c:247-268). The texture unit's 8-bit interpolation weights are replaced by exact float lerps, the
+// gamma powf by pow_det, so that a fetch is reproducible. `def` is returned for an invalid handle. ----
+LUM_DEV float4 unpack_texel(uint32_t t) {
+  return make_float4((t & 0xFFu) * (1.0f / 255.0f), ((t >> 8) & 0xFFu) * (1.0f / 255.0f), ((t >> 16) & 0xFFu) * (1.0f / 255.0f), (t >> 24) * (1.0f / 255.0f));
+}
+LUM_DEV float4 texture_load(const DeviceScene& sc, uint32_t tex, F2 uv, bool apply_gamma, float4 def) {
+  if (tex >= sc.num_textures) return def;
+  const uint4 t = sc.texture_table[tex];
+  const int w = (int) t.y, h = (int) t.z;
+  const float u = uv.x, v = 1.0f - uv.y;  // flip_v
+  const float xb = (u - floorf(u)) * (float) w - 0.5f, yb = (v - floorf(v)) * (float) h - 0.5f;
+  const float xf = floorf(xb), yf = floorf(yb);
+  const float ax = xb - xf, ay = yb - yf;
+  int x0 = (int) xf, y0 = (int) yf, x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += w;
+  if (y0 < 0) y0 += h;
+  if (x1 >= w) x1 -= w;
+  if (y1 >= h) y1 -= h;
+  const uint32_t* __restrict__ base = sc.texels + t.x;
+  const float4 c00 = unpack_texel(base[x0 + y0 * w]), c10 = unpack_texel(base[x1 + y0 * w]);
+  const float4 c01 = unpack_texel(base[x0 + y1 * w]), c11 = unpack_texel(base[x1 + y1 * w]);
+  float4 r;
+  {
+    const float top = c00.x + ax * (c10.x - c00.x), bot = c01.x + ax * (c11.x - c01.x);
+    r.x = top + ay * (bot - top);
+  }
+  {
+    const float top = c00.y + ax * (c10.y - c00.y), bot = c01.y + ax * (c11.y - c01.y);
+    r.y = top + ay * (bot - top);
+  }
+  {
+    const float top = c00.z + ax * (c10.z - c00.z), bot = c01.z + ax * (c11.z - c01.z);
+    r.z = top + ay * (bot - top);
+  }
+  {
+    const float top = c00.w + ax * (c10.w - c00.w), bot = c01.w + ax * (c11.w - c01.w);
+    r.w = top + ay * (bot - top);
+  }
+  const float gamma = bitsf(t.w);
+  if (apply_gamma && gamma != 1.0f) { r.x = pow_det(r.x, gamma); r.y = pow_det(r.y, gamma); r.z = pow_det(r.z, gamma); }  // never the alpha
+  return r;
+}
+// cuda/math.cuh:246-253, :1706-1713 and cuda/memory.cuh:414-425
+LUM_DEV F2 uv_unpack(uint32_t d) { return F2{bitsf(d & 0xFFFF0000u), bitsf(d << 16)}; }
+LUM_DEV F2 triangle_uv(uint4 tri_tex, F2 coords) {
+  const F2 a = uv_unpack(tri_tex.x), b = uv_unpack(tri_tex.y), c = uv_unpack(tri_tex.z);
+  return F2{a.x + coords.x * (b.x - a.x) + coords.y * (c.x - a.x), a.y + coords.x * (b.y - a.y) + coords.y * (c.y - a.y)};
 }
 
 // material.cuh:36-53: EMISSION bits 0..31 | ALBEDO 32..61 | OPACITY 62..69 | ROUGHNESS 70..79 | IOR 80..87

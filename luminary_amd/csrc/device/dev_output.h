@@ -25,40 +25,6 @@ struct OutputParams {
   float agx_slope, agx_power, agx_saturation;
 };
 
-// log2 for positive normal floats: exponent + 2*atanh((m-1)/(m+1)) / ln 2 with m in [sqrt(1/2), sqrt(2)).
-LUM_DEV float log2_det(float x) {
-  const uint32_t bits = fbits(x);
-  int e = (int) ((bits >> 23) & 0xFFu) - 127;
-  float m = bitsf((bits & 0x007FFFFFu) | 0x3F800000u);
-  if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
-  const float s = (m - 1.0f) / (m + 1.0f);
-  const float z = s * s;
-  float p = 0.0909090909f;
-  p = p * z + 0.111111111f;
-  p = p * z + 0.142857143f;
-  p = p * z + 0.2f;
-  p = p * z + 0.333333333f;
-  p = p * z;
-  const float ln_m = 2.0f * s + (2.0f * s) * p;
-  return (float) e + ln_m * 1.44269504f;
-}
-// 2^x for x in [-126, 127]: nearest integer part exactly (ldexp), fraction by the degree-7 Taylor polynomial of exp(f ln 2).
-LUM_DEV float exp2_det(float x) {
-  x = fminf(fmaxf(x, -126.0f), 127.0f);
-  const float n = rintf(x);
-  const float f = x - n;
-  float p = 1.52527338e-5f;
-  p = p * f + 1.54035304e-4f;
-  p = p * f + 1.33335581e-3f;
-  p = p * f + 9.61812911e-3f;
-  p = p * f + 5.55041087e-2f;
-  p = p * f + 2.40226507e-1f;
-  p = p * f + 6.93147181e-1f;
-  p = p * f + 1.0f;
-  return ldexpf(p, (int) n);
-}
-LUM_DEV float pow_det(float x, float y) { return (x > 0.0f) ? exp2_det(y * log2_det(x)) : 0.0f; }
-
 LUM_DEV float linear_to_srgb(float v) { return (v <= 0.0031308f) ? 12.92f * v : 1.055f * pow_det(v, 0.416666666667f) - 0.055f; }  // math.cuh:1044-1051
 LUM_DEV float srgb_to_linear(float v) { return (v <= 0.04045f) ? v / 12.92f : pow_det((v + 0.055f) / 1.055f, 2.4f); }             // math.cuh:1053-1060
 

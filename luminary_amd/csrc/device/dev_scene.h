@@ -29,7 +29,9 @@ constexpr uint32_t kBvhLeafMaxTri = 4;
 // Triangle in traversal order, 48 bytes: v0.xyz + id | e1.xyz + scene index | e2.xyz (edges precomputed with the same float
 // subtraction the reference's intersection code performs, so hit distances are identical). `id` is the triangle id inside its
 // mesh (what hits report), `scene_index` = mesh_tri_offset[mesh] + id indexes vertices/tri_tex directly.
-struct BvhTri { float p0[3]; uint32_t id; float e1[3]; uint32_t scene_index; float e2[3]; uint32_t pad1; };
+struct BvhTri { float p0[3]; uint32_t id; float e1[3]; uint32_t scene_index; float e2[3]; uint32_t albedo_tex; };  // albedo_tex: texture id of the
+// triangle's material or kBvhTriNoTexture: the ray queries consult the texture's alpha without touching the material first
+constexpr uint32_t kBvhTriNoTexture = 0xFFFFFFFFu;
 static_assert(sizeof(BvhTri) == 48, "48 bytes per triangle");
 
 struct DeviceScene {
@@ -50,6 +52,9 @@ struct DeviceScene {
   const uint16_t* lut_glossy;
   const uint16_t* lut_dielectric;
   const uint16_t* lut_dielectric_inv;
+  // textures (reference: device_texture.c, cuda/texture_utils.cuh): RGBA8 texels of all textures back to back + a table
+  const uint4* texture_table;     // first texel, width, height, gamma (float bits)
+  const uint32_t* texels;         // r in the low byte
   // acceleration structures (node indices and leaf ranges are absolute, so one base pointer serves both levels)
   const Bvh4Node* bvh_nodes;       // [0, tlas_num_nodes): top level over instances (leaves index tlas_leaves); then every mesh's BVH
   const BvhTri* blas_tris;         // all meshes, traversal order
@@ -57,7 +62,7 @@ struct DeviceScene {
                                    // (.w = translation component), then uint bits {instance id, root node of its mesh, 0, 0}
   const Bvh4Node* light_nodes;     // leaves index light_tris
   const BvhTri* light_tris;        // world space, id = light id
-  uint32_t num_meshes, num_instances, num_materials, num_lights;
+  uint32_t num_meshes, num_instances, num_materials, num_lights, num_textures;
   uint32_t tlas_num_nodes, light_num_nodes;
   // settings / camera / sky (device_structs.h:8-124)
   uint32_t width, height, max_ray_depth, shading_mode;

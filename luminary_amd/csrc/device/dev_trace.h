@@ -284,6 +284,10 @@ struct ClosestState {
       F2 uv;
       const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && id < best.tri_id)))) {
+        // alpha cut-outs: texels with alpha 0 do not exist for the ray (optix_common.cuh:20-46, optix_anyhit.cuh:26-30)
+        if (fbits(c.w) != kBvhTriNoTexture && fbits(c.w) < sc.num_textures &&
+            texture_load(sc, fbits(c.w), triangle_uv(sc.tri_tex[fbits(b.w)], uv), true, make_float4(0.0f, 0.0f, 0.0f, 1.0f)).w == 0.0f)
+          continue;
         best.instance_id = inst; best.tri_id = id; best.t = t; best.scene_tri = fbits(b.w); tmax = t;
       }
     }
@@ -316,12 +320,21 @@ struct ShadowState {
       F2 uv;
       const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (!(t > kEps && t < dist)) continue;
-      const Material m = load_material(sc, sc.tri_tex[fbits(b.w)].w & 0xFFFFu);  // b.w = triangle index in the scene arrays
+      const uint4 tt = sc.tri_tex[fbits(b.w)];  // b.w = triangle index in the scene arrays
+      const Material m = load_material(sc, tt.w & 0xFFFFu);
+      Col albedo = m.albedo;
+      float alpha = m.alpha;
+      if (m.albedo_tex != kTextureNone) {  // optix_get_albedo_for_shadowing, optix_common.cuh:48-65
+        const float4 af = (m.albedo_tex < sc.num_textures) ? texture_load(sc, m.albedo_tex, triangle_uv(tt, uv), true, make_float4(0.0f, 0.0f, 0.0f, 0.0f))
+                                                           : make_float4(0.9f, 0.9f, 0.9f, 1.0f);
+        albedo = col(af.x, af.y, af.z);
+        alpha = af.w;
+      }
       const bool colored = (m.flags & kDMatColoredTransparency) != 0;
-      if (m.alpha == 1.0f) { blocked = true; return true; }
-      if (m.alpha == 0.0f && !colored) continue;
-      const float tp = 1.0f - m.alpha;
-      const Col f = colored ? m.albedo * tp : splat(tp);
+      if (alpha == 1.0f) { blocked = true; return true; }
+      if (alpha == 0.0f && !colored) continue;
+      const float tp = 1.0f - alpha;
+      const Col f = colored ? albedo * tp : splat(tp);
       tr *= (double) f.r; tg *= (double) f.g; tb *= (double) f.b;
     }
     return false;
@@ -379,9 +392,13 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
         const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), origin, dir, uv);
         if (!(t > kEps && t != kFltMax && t <= tstar)) continue;
         const uint32_t mesh = sc.instance_mesh_ids[handle.x];
-        const Material m = load_material(sc, sc.tri_tex[sc.mesh_tri_offset[mesh] + handle.y].w & 0xFFFFu);
-        if (m.alpha == 0.0f && (m.flags & kDMatColoredTransparency) == 0) continue;
-        if (pass == 0) { if (m.alpha == 1.0f && t < tstar) { tstar = t; tm = t; } }
+        const uint4 tt = sc.tri_tex[sc.mesh_tri_offset[mesh] + handle.y];
+        const Material m = load_material(sc, tt.w & 0xFFFFu);
+        float alpha = m.alpha;
+        if (m.albedo_tex != kTextureNone)  // optix_anyhit.cuh:158 -> optix_get_albedo_for_shadowing
+          alpha = (m.albedo_tex < sc.num_textures) ? texture_load(sc, m.albedo_tex, triangle_uv(tt, uv), true, make_float4(0.0f, 0.0f, 0.0f, 0.0f)).w : 1.0f;
+        if (alpha == 0.0f && (m.flags & kDMatColoredTransparency) == 0) continue;
+        if (pass == 0) { if (alpha == 1.0f && t < tstar) { tstar = t; tm = t; } }
         else {
           n++;
           const uint32_t key = squares32(0xfcbd6e15u, 0x9E3779B9u * light + fbits(random));

@@ -147,17 +147,32 @@ LUM_DEV GeoContext build_context(const DeviceScene& sc, V3 hit_origin, V3 ray_wo
   position = p0 + (e1 * co.x + e2 * co.y);
   position = xf_point(tf, position);
   const Material mat = load_material(sc, tt.w & 0xFFFFu);
+  const F2 tex_coords = triangle_uv(tt, co);
   const V3 n0 = normal_unpack(fbits(a.w)), n1 = normal_unpack(fbits(b.w)), n2 = normal_unpack(fbits(c.w));
   const bool inside = dot(face, ray) > 0.0f;
   if (inside) face = face * -1.0f;
   V3 normal = lerp_normals(n0, n1 - n0, n2 - n0, co, face);
+  if (mat.normal_tex != kTextureNone) {  // geometry_utils.cuh:25-50
+    const bool valid = mat.normal_tex < sc.num_textures;
+    const float4 nf = texture_load(sc, mat.normal_tex, tex_coords, false, make_float4(0.0f, 0.0f, 1.0f, 0.0f));
+    V3 mn = v3(nf.x, nf.y, nf.z);
+    if ((mat.flags & kDMatNormalMapCompressed) && valid) mn = mn * 2.0f - v3(1.0f, 1.0f, 1.0f);
+    mn = normalize(mn);
+    normal = qapply(qinv(rotation_to_z(normal)), mn);
+  }
   normal = adapt_normal(ray * -1.0f, normal, face);
   Col albedo = mat.albedo;
   float alpha = mat.alpha;
+  if (mat.albedo_tex != kTextureNone) {  // geometry_utils.cuh:109-121
+    const float4 af = texture_load(sc, mat.albedo_tex, tex_coords, true, make_float4(0.9f, 0.9f, 0.9f, 1.0f));
+    albedo = col(af.x, af.y, af.z);
+    alpha = af.w;
+  }
   const bool emissive_side = !inside || (mat.flags & kDMatBidirectionalEmission);
   const bool emits = (mat.flags & kDMatEmission) && emissive_side && ((state & kStAllowEmission) != 0);
   const Col emission = emits ? mat.emission : col(0.0f, 0.0f, 0.0f);
   float roughness = mat.roughness;
+  if (mat.roughness_tex != kTextureNone) roughness = texture_load(sc, mat.roughness_tex, tex_coords, true, make_float4(0.5f, 0.0f, 0.0f, 0.0f)).x;  // :140-150
   if (mat.flags & kDMatRoughnessAsSmoothness) roughness = 1.0f - roughness;
   roughness = fmaxf(roughness, 2e-2f);                                          // BSDF_ROUGHNESS_CLAMP, cuda/utils.cuh:46
   if ((state & kStDeltaPath) == 0) roughness = fmaxf(roughness, mat.roughness_clamp);

@@ -253,6 +253,19 @@ LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle h
   host->outputs.release(handle);
   return r;
 }
+LuminaryResult luminary_ext_add_texture(LuminaryHost* host, const uint8_t* rgba8, uint32_t width, uint32_t height, float gamma, uint16_t* texture_id) {
+  CHECK_NULL(host); CHECK_NULL(rgba8); CHECK_NULL(texture_id);
+  if (width == 0 || height == 0 || host->scene.textures.size() >= 0xFFFF) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  std::lock_guard<std::mutex> lock(host->mutex);
+  lum::HostTexture t;
+  t.width = width; t.height = height; t.gamma = gamma;
+  t.texels.resize((size_t) width * height);
+  std::memcpy(t.texels.data(), rgba8, t.texels.size() * 4);
+  host->scene.textures.push_back(std::move(t));
+  *texture_id = (uint16_t) (host->scene.textures.size() - 1);
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
 LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld) { return lum::write_png(path, argb8, width, height, ld); }
 LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) { CHECK_NULL(host); return LUMINARY_ERROR_NOT_IMPLEMENTED; }
 

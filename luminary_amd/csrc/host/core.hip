@@ -294,6 +294,15 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     if (upload(ctx, (const uint2*) v->light_tri_handles, v->num_lights, &sc.light_tri_handles)) return 1;
   }
   if (upload(ctx, v->bluenoise_2d, 65536, &sc.bluenoise_2d)) return 1;
+  sc.num_textures = 0;
+  if (v->num_textures && v->texture_table && v->texels) {
+    size_t texel_count = 0;
+    for (uint32_t t = 0; t < v->num_textures; t++)
+      texel_count = std::max(texel_count, (size_t) v->texture_table[4 * t] + (size_t) v->texture_table[4 * t + 1] * v->texture_table[4 * t + 2]);
+    if (upload(ctx, (const uint4*) v->texture_table, v->num_textures, &sc.texture_table)) return 1;
+    if (upload(ctx, v->texels, texel_count, &sc.texels)) return 1;
+    sc.num_textures = v->num_textures;
+  }
 
   // ---- top-level BVH over the instances' world boxes + one bottom-level BVH per mesh, in ONE node array with absolute indices ----
   // Depth caps keep the traversal stack bounded (dev_trace.h kStackSize): top level <= 16, bottom levels <= 26 BVH4 levels.
@@ -356,7 +365,12 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       const float* p = v->vertices + (size_t) (t0 + t) * 12;
       BvhTri& bt = blas_tris[(size_t) t0 + i];
       for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
-      bt.id = t; bt.scene_index = t0 + t; bt.pad1 = 0;
+      bt.id = t; bt.scene_index = t0 + t;
+      {
+        const uint32_t material = v->tri_tex[(size_t) (t0 + t) * 4 + 3] & 0xFFFFu;
+        const uint16_t albedo_tex = (material < v->num_materials) ? v->materials[(size_t) material * 16 + 12] : (uint16_t) 0xFFFF;
+        bt.albedo_tex = (albedo_tex == 0xFFFF) ? kBvhTriNoTexture : albedo_tex;
+      }
     }
     tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit();
   }
@@ -450,7 +464,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   }
   ctx->bvh_stats[1] = total_tris;
 
-  sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights;
+  { const uint32_t nt = sc.num_textures; sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights; sc.num_textures = nt; }
   sc.width = v->width; sc.height = v->height; sc.max_ray_depth = v->max_ray_depth; sc.shading_mode = v->shading_mode;
   std::memcpy(sc.cam_pos, v->cam_pos, sizeof(sc.cam_pos));
   std::memcpy(sc.cam_rotation, v->cam_rotation, sizeof(sc.cam_rotation));

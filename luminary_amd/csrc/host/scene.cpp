@@ -677,6 +677,17 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   std::memset(&v, 0, sizeof(v));
   v.num_meshes = (uint32_t) scene.meshes.size(); v.num_instances = (uint32_t) scene.instances.size();
   v.num_materials = (uint32_t) scene.materials.size(); v.num_lights = (uint32_t) (lt.tri_handles.size() / 2);
+  b.texture_table.clear(); b.texels.clear();
+  for (const HostTexture& t : scene.textures) {
+    float g = t.gamma;
+    uint32_t gbits;
+    std::memcpy(&gbits, &g, 4);
+    b.texture_table.push_back((uint32_t) b.texels.size()); b.texture_table.push_back(t.width); b.texture_table.push_back(t.height); b.texture_table.push_back(gbits);
+    b.texels.insert(b.texels.end(), t.texels.begin(), t.texels.end());
+  }
+  v.num_textures = (uint32_t) scene.textures.size();
+  v.texture_table = b.texture_table.empty() ? nullptr : b.texture_table.data();
+  v.texels = b.texels.empty() ? nullptr : b.texels.data();
   v.mesh_tri_offset = b.mesh_tri_offset.data(); v.vertices = b.vertices.data(); v.tri_tex = b.tri_tex.data();
   v.instance_mesh_ids = b.instance_mesh_ids.data(); v.instance_transforms = b.instance_transforms.data(); v.materials = b.materials.data();
   v.light_tree_root = lt.root.empty() ? nullptr : b.light_tree_root.data();

@@ -28,6 +28,10 @@ struct HostInstance {  // mesh.h:23-30
   bool active = true;
 };
 
+// RGBA8 texture (r in the low byte of a texel word) sampled normalised, wrapped and linearly filtered; `gamma` is applied to r, g, b
+// (texture.h:20-40: PNG files set it to 100000 / gAMA, everything else keeps 1).
+struct HostTexture { uint32_t width = 0, height = 0; float gamma = 1.0f; std::vector<uint32_t> texels; };
+
 struct HostScene {
   LuminaryRendererSettings settings;
   LuminaryCamera camera;
@@ -39,6 +43,7 @@ struct HostScene {
   std::vector<LuminaryMaterial> materials;
   std::vector<HostMesh> meshes;
   std::vector<HostInstance> instances;
+  std::vector<HostTexture> textures;
   HostScene();
 };
 
@@ -72,6 +77,7 @@ struct DeviceSceneBuffers {
   std::vector<uint32_t> light_tri_handles;
   std::vector<float> light_bvh_tris;
   std::vector<uint32_t> bluenoise;
+  std::vector<uint32_t> texture_table, texels;
 };
 
 // Fills `out` from the scene. `bluenoise` must hold 65536 texels. Returns an empty string or an error message.

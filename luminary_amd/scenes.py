@@ -475,3 +475,86 @@ def zoo_scene(width=96, height=64, bounces=8, seed=7, light_triangles=320, sky_m
     c.russian_roulette_threshold = 0.1
     host.set_camera(c)
     return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Parity scene for textures: albedo + alpha cut-outs, roughness map, normal map, gamma
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _quad_uv(a, b, c, d, rep=1.0):
+    """Two triangles of the quad a-b-c-d with positions (2 x 9) and uvs (2 x 6); uv (0,0) at a, (rep, rep) at c."""
+    pos = np.array([a + b + c, a + c + d], dtype=np.float32)
+    uv = np.array([[0, 0, rep, 0, rep, rep], [0, 0, rep, rep, 0, rep]], dtype=np.float32)
+    return pos, uv
+
+
+def textured_scene(width=96, height=64, bounces=6, seed=11):
+    """Textured ground (checker with gamma 2.2), a fence of alpha cut-outs (alpha 0 / 0.5 / 1 texels) in front of a light, a panel with
+    roughness and normal maps, a tinted window whose alpha comes from a texture (coloured transparency), and emitters."""
+    rng = np.random.RandomState(seed)
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.5, 0.6, 0.8))
+
+    n = 16
+    yy, xx = np.mgrid[0:n, 0:n]
+    checker = np.zeros((n, n, 4), dtype=np.uint8)
+    checker[..., :3] = np.where(((xx // 2 + yy // 2) % 2)[..., None] == 0, (220, 200, 160), (60, 90, 140))
+    checker[..., 3] = 255
+    t_checker = host.add_texture(checker, gamma=2.2)
+
+    fence = np.zeros((8, 8, 4), dtype=np.uint8)
+    fence[..., :3] = (180, 140, 90)
+    fence[..., 3] = 0
+    fence[:, ::3, 3] = 255          # opaque slats
+    fence[4, :, 3] = 128            # one half-transparent rail
+    fence[0, :, 3] = 255
+    t_fence = host.add_texture(fence)
+
+    rough = np.zeros((8, 8, 4), dtype=np.uint8)
+    rough[..., 0] = (np.linspace(10, 230, 64).reshape(8, 8)).astype(np.uint8)
+    rough[..., 3] = 255
+    t_rough = host.add_texture(rough)
+
+    m = 16
+    yy, xx = np.mgrid[0:m, 0:m].astype(np.float32)
+    nx, ny = 0.35 * np.sin(xx * 0.8), 0.35 * np.cos(yy * 0.7)
+    nz = np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))
+    nmap = np.zeros((m, m, 4), dtype=np.uint8)
+    nmap[..., 0], nmap[..., 1], nmap[..., 2], nmap[..., 3] = (nx * 0.5 + 0.5) * 255, (ny * 0.5 + 0.5) * 255, (nz * 0.5 + 0.5) * 255, 255
+    t_normal = host.add_texture(nmap)
+
+    glass = rng.randint(0, 255, size=(4, 4, 4)).astype(np.uint8)
+    glass[..., 3] = (rng.randint(0, 3, size=(4, 4)) * 100).astype(np.uint8)  # alpha 0, 100/255, 200/255
+    t_glass = host.add_texture(glass)
+
+    def mat(albedo, roughness, **kw):
+        mt = _material(albedo, roughness, alpha=kw.get("alpha", 1.0), metallic=kw.get("metallic", False), emission=kw.get("emission"))
+        mt.albedo_tex = kw.get("albedo_tex", 0xFFFF)
+        mt.roughness_tex = kw.get("roughness_tex", 0xFFFF)
+        mt.normal_tex = kw.get("normal_tex", 0xFFFF)
+        mt.colored_transparency = kw.get("colored", False)
+        mt.roughness_as_smoothness = kw.get("smoothness", False)
+        return host.add_material(mt)
+
+    m_ground = mat((0.5, 0.5, 0.5), 0.8, albedo_tex=t_checker)
+    m_fence = mat((0.5, 0.5, 0.5), 0.6, albedo_tex=t_fence)
+    m_panel = mat((0.8, 0.8, 0.85), 0.3, roughness_tex=t_rough, normal_tex=t_normal, metallic=True)
+    m_window = mat((0.5, 0.5, 0.5), 0.2, albedo_tex=t_glass, colored=True)
+    m_missing = mat((0.2, 0.9, 0.2), 0.5, albedo_tex=77)  # dangling handle: the default albedo applies
+    m_light = mat((0.8, 0.8, 0.8), 0.7, emission=(16.0, 14.0, 11.0))
+
+    def add(quads, material, rep=1.0):
+        pos, uv = zip(*[_quad_uv(*q, rep=rep) for q in quads])
+        pos, uv = np.concatenate(pos), np.concatenate(uv)
+        return host.add_mesh(pos, np.full(len(pos), material, dtype=np.uint16), uvs=uv)
+
+    host.new_instance(add([((-10, 0, -10), (10, 0, -10), (10, 0, 10), (-10, 0, 10))], m_ground, rep=5.0))
+    host.new_instance(add([((-4, 0, 2), (4, 0, 2), (4, 3, 2), (-4, 3, 2))], m_fence, rep=2.0))
+    host.new_instance(add([((-6, 0.2, -3), (-1, 0.2, -4), (-1, 3.5, -4), (-6, 3.5, -3))], m_panel, rep=1.5), (0, 0, 0), (0.0, 0.2, 0.0), (1.0, 1.0, 1.0))
+    host.new_instance(add([((1, 0.3, -2), (5, 0.3, -2), (5, 3.0, -2), (1, 3.0, -2))], m_window))
+    host.new_instance(add([((6, 0, -1), (8, 0, -1), (8, 2, -1), (6, 2, -1))], m_missing))
+    host.new_instance(add([((-1.5, 2.0, -1.0), (1.5, 2.0, -1.0), (1.5, 2.0, 1.0), (-1.5, 2.0, 1.0)),     # behind the fence, facing down
+                           ((-8, 5.5, -6), (-5, 5.5, -6), (-5, 5.5, -3), (-8, 5.5, -3)),
+                           ((4, 6.0, -5), (7, 6.0, -5), (7, 6.0, -2), (4, 6.0, -2))], m_light))
+    set_camera(host, (0.5, 2.6, 9.0), (-0.17, 0.02, 0.0), fov=0.75)
+    return host

@@ -35,6 +35,56 @@ static inline OTransform scene_transform(const OracleScene* s, uint32_t inst) {
   return t;
 }
 static inline OMaterial scene_material(const OracleScene* s, uint32_t id) { return material_load((const OMaterialC*) (s->materials + (size_t) id * 16)); }
+/* ---- textures (cuda/texture_utils.cuh:20-45): normalised coordinates, wrap addressing, linear filter, mip level 0
+ * (texture.c:77-90, device_texture.c:247-268). Exact float lerps instead of the texture unit's 8-bit weights, o_pow for the gamma.
+ * `def` is returned for an invalid handle. ---- */
+typedef struct { float x, y, z, w; } float4_t;
+static inline float4_t f4(float x, float y, float z, float w) { float4_t r = {x, y, z, w}; return r; }
+static inline float4_t texel_unpack(uint32_t t) {
+  return f4((t & 0xFFu) * (1.0f / 255.0f), ((t >> 8) & 0xFFu) * (1.0f / 255.0f), ((t >> 16) & 0xFFu) * (1.0f / 255.0f), (t >> 24) * (1.0f / 255.0f));
+}
+static inline float4_t texture_load(const OracleScene* s, uint32_t tex, UV uv, bool apply_gamma, float4_t def) {
+  if (tex >= s->num_textures) return def;
+  const uint32_t* t = s->texture_table + 4 * (size_t) tex;
+  const int w = (int) t[1], h = (int) t[2];
+  const float u = uv.u, v = 1.0f - uv.v; /* flip_v */
+  const float xb = (u - floorf(u)) * (float) w - 0.5f, yb = (v - floorf(v)) * (float) h - 0.5f;
+  const float xf = floorf(xb), yf = floorf(yb);
+  const float ax = xb - xf, ay = yb - yf;
+  int x0 = (int) xf, y0 = (int) yf, x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += w;
+  if (y0 < 0) y0 += h;
+  if (x1 >= w) x1 -= w;
+  if (y1 >= h) y1 -= h;
+  const uint32_t* base = s->texels + t[0];
+  const float4_t c00 = texel_unpack(base[x0 + y0 * w]), c10 = texel_unpack(base[x1 + y0 * w]);
+  const float4_t c01 = texel_unpack(base[x0 + y1 * w]), c11 = texel_unpack(base[x1 + y1 * w]);
+  float4_t r;
+  { const float top = c00.x + ax * (c10.x - c00.x), bot = c01.x + ax * (c11.x - c01.x); r.x = top + ay * (bot - top); }
+  { const float top = c00.y + ax * (c10.y - c00.y), bot = c01.y + ax * (c11.y - c01.y); r.y = top + ay * (bot - top); }
+  { const float top = c00.z + ax * (c10.z - c00.z), bot = c01.z + ax * (c11.z - c01.z); r.z = top + ay * (bot - top); }
+  { const float top = c00.w + ax * (c10.w - c00.w), bot = c01.w + ax * (c11.w - c01.w); r.w = top + ay * (bot - top); }
+  const float gamma = u2f(t[3]);
+  if (apply_gamma && gamma != 1.0f) { r.x = o_pow(r.x, gamma); r.y = o_pow(r.y, gamma); r.z = o_pow(r.z, gamma); } /* never the alpha */
+  return r;
+}
+/* cuda/math.cuh:246-253, cuda/memory.cuh:414-425 */
+static inline UV triangle_uv(const uint32_t* tri_tex, float2_t coords) {
+  const UV a = uv_unpack(tri_tex[0]), b = uv_unpack(tri_tex[1]), c = uv_unpack(tri_tex[2]);
+  UV r = {a.u + coords.x * (b.u - a.u) + coords.y * (c.u - a.u), a.v + coords.x * (b.v - a.v) + coords.y * (c.v - a.v)};
+  return r;
+}
+/* optix_get_albedo_for_shadowing, optix_common.cuh:48-65 */
+static inline RGBAF albedo_for_shadowing(const OracleScene* s, const OMaterial* m, const uint32_t* tri_tex, float2_t coords) {
+  RGBAF albedo = m->albedo;
+  if (m->albedo_tex != TEXTURE_NONE) {
+    if (m->albedo_tex >= s->num_textures) { RGBAF d = {0.9f, 0.9f, 0.9f, 1.0f}; return d; }
+    const float4_t t = texture_load(s, m->albedo_tex, triangle_uv(tri_tex, coords), true, f4(0.0f, 0.0f, 0.0f, 0.0f));
+    albedo.r = t.x; albedo.g = t.y; albedo.b = t.z; albedo.a = t.w;
+  }
+  return albedo;
+}
+
 static inline OLuts scene_luts(const OracleScene* s) {
   OLuts l = {s->lut_conductor, s->lut_glossy, s->lut_dielectric, s->lut_dielectric_inv};
   return l;

@@ -25,37 +25,6 @@ typedef struct {
   float agx_slope, agx_power, agx_saturation;
 } OracleOutputParams;
 
-static inline float o_log2(float x) {
-  const uint32_t bits = f2u(x);
-  int e = (int) ((bits >> 23) & 0xFFu) - 127;
-  float m = u2f((bits & 0x007FFFFFu) | 0x3F800000u);
-  if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
-  const float s = (m - 1.0f) / (m + 1.0f);
-  const float z = s * s;
-  float p = 0.0909090909f;
-  p = p * z + 0.111111111f;
-  p = p * z + 0.142857143f;
-  p = p * z + 0.2f;
-  p = p * z + 0.333333333f;
-  p = p * z;
-  const float ln_m = 2.0f * s + (2.0f * s) * p;
-  return (float) e + ln_m * 1.44269504f;
-}
-static inline float o_exp2(float x) {
-  x = fminf(fmaxf(x, -126.0f), 127.0f);
-  const float n = rintf(x);
-  const float f = x - n;
-  float p = 1.52527338e-5f;
-  p = p * f + 1.54035304e-4f;
-  p = p * f + 1.33335581e-3f;
-  p = p * f + 9.61812911e-3f;
-  p = p * f + 5.55041087e-2f;
-  p = p * f + 2.40226507e-1f;
-  p = p * f + 6.93147181e-1f;
-  p = p * f + 1.0f;
-  return ldexpf(p, (int) n);
-}
-static inline float o_pow(float x, float y) { return (x > 0.0f) ? o_exp2(y * o_log2(x)) : 0.0f; }
 static inline float o_linear_to_srgb(float v) { return (v <= 0.0031308f) ? 12.92f * v : 1.055f * o_pow(v, 0.416666666667f) - 0.055f; }
 static inline float o_srgb_to_linear(float v) { return (v <= 0.04045f) ? v / 12.92f : o_pow((v + 0.055f) / 1.055f, 2.4f); }
 

@@ -91,15 +91,29 @@ static GeoCtx geometry_get_context(const OracleScene* s, vec3 hit_origin, vec3 t
   const bool is_inside = v_dot(face_normal, ray) > 0.0f;
   if (is_inside) face_normal = v_scale(face_normal, -1.0f);
   vec3 normal = lerp_normals(n0, e1n, e2n, co, face_normal);
+  const UV tex_coords = triangle_uv(tt, co);
+  if (mat.normal_tex != TEXTURE_NONE) { /* geometry_utils.cuh:25-50 */
+    const bool valid = mat.normal_tex < s->num_textures;
+    const float4_t nf = texture_load(s, mat.normal_tex, tex_coords, false, f4(0.0f, 0.0f, 1.0f, 0.0f));
+    vec3 mn = v3(nf.x, nf.y, nf.z);
+    if ((mat.flags & DMAT_NORMAL_MAP_COMPRESSED) && valid) mn = v_sub(v_scale(mn, 2.0f), v3(1.0f, 1.0f, 1.0f));
+    mn = v_norm(mn);
+    normal = q_apply(q_inverse(q_rotation_to_z(normal)), mn);
+  }
   normal = normal_adaptation_apply(v_scale(ray, -1.0f), normal, face_normal);
 
   RGBAF albedo = mat.albedo;
+  if (mat.albedo_tex != TEXTURE_NONE) { /* geometry_utils.cuh:109-121 */
+    const float4_t af = texture_load(s, mat.albedo_tex, tex_coords, true, f4(0.9f, 0.9f, 0.9f, 1.0f));
+    albedo.r = af.x; albedo.g = af.y; albedo.b = af.z; albedo.a = af.w;
+  }
   const bool emissive_side = (!is_inside) || (mat.flags & DMAT_BIDIRECTIONAL_EMISSION);
   const bool has_emission = (mat.flags & DMAT_EMISSION) && emissive_side;
   const bool include_emission = has_emission && ((state & ST_ALLOW_EMISSION) != 0);
   RGBF emission = c3(0.0f, 0.0f, 0.0f);
   if (include_emission) emission = mat.emission;
   float roughness = mat.roughness;
+  if (mat.roughness_tex != TEXTURE_NONE) roughness = texture_load(s, mat.roughness_tex, tex_coords, true, f4(0.5f, 0.0f, 0.0f, 0.0f)).x; /* :140-150 */
   if (mat.flags & DMAT_ROUGHNESS_AS_SMOOTHNESS) roughness = 1.0f - roughness;
   roughness = fmaxf(roughness, BSDF_ROUGHNESS_CLAMP);
   if ((state & ST_DELTA_PATH) == 0) roughness = fmaxf(roughness, mat.roughness_clamp);

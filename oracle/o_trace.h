@@ -200,7 +200,12 @@ static inline OHit trace_closest(const OTracer* tr, vec3 origin, vec3 dir, bool 
         float2_t c;
         const float th = tri_intersect(t.p0, t.e1, t.e2, o, d, &c);
         if (th < best.t || (th == best.t && th != FLT_MAX && (inst < best.instance_id || (inst == best.instance_id && tri < best.tri_id)))) {
-          best.instance_id = inst; best.tri_id = tri; best.t = th;
+          /* alpha cut-outs: a texel with alpha 0 does not exist for the ray (optix_common.cuh:20-46, optix_anyhit.cuh:26-30) */
+          const uint32_t* tt = scene_tritex(s, mesh, tri);
+          const uint16_t albedo_tex = scene_material(s, tt[3] & 0xFFFF).albedo_tex;
+          const bool cut = albedo_tex != TEXTURE_NONE && albedo_tex < s->num_textures &&
+                           texture_load(s, albedo_tex, triangle_uv(tt, c), true, f4(0.0f, 0.0f, 0.0f, 1.0f)).w == 0.0f;
+          if (!cut) { best.instance_id = inst; best.tri_id = tri; best.t = th; }
         }
       }
     });
@@ -232,13 +237,14 @@ static inline RGBF trace_shadow(const OTracer* tr, vec3 origin, vec3 dir, float 
         float2_t c;
         const float th = tri_intersect(t.p0, t.e1, t.e2, o, d, &c);
         if (th > O_EPS && th < dist) {
-          const uint32_t mat_id = scene_tritex(s, mesh, tri)[3] & 0xFFFF;
-          const OMaterial m = scene_material(s, mat_id);
+          const uint32_t* tt = scene_tritex(s, mesh, tri);
+          const OMaterial m = scene_material(s, tt[3] & 0xFFFF);
+          const RGBAF albedo = albedo_for_shadowing(s, &m, tt, c);
           const bool colored = (m.flags & DMAT_COLORED_TRANSPARENCY) != 0;
-          if (m.albedo.a == 1.0f) blocked = true;
-          else if (!(m.albedo.a == 0.0f && !colored)) {
-            const float tp = 1.0f - m.albedo.a;
-            const RGBF f = colored ? c_scale(c3(m.albedo.r, m.albedo.g, m.albedo.b), tp) : c_splat(tp);
+          if (albedo.a == 1.0f) blocked = true;
+          else if (!(albedo.a == 0.0f && !colored)) {
+            const float tp = 1.0f - albedo.a;
+            const RGBF f = colored ? c_scale(c3(albedo.r, albedo.g, albedo.b), tp) : c_splat(tp);
             thr[0] *= (double) f.r; thr[1] *= (double) f.g; thr[2] *= (double) f.b;
           }
         }
@@ -270,10 +276,12 @@ static inline uint32_t trace_light_bvh(const OTracer* tr, vec3 origin, vec3 dir,
         const float th = tri_intersect(t.p0, t.e1, t.e2, origin, dir, &c);
         if (th > O_EPS && th != FLT_MAX && th <= tstar) {
           const uint32_t mesh = s->instance_mesh_ids[inst];
-          const OMaterial m = scene_material(s, scene_tritex(s, mesh, tri)[3] & 0xFFFF);
+          const uint32_t* tt = scene_tritex(s, mesh, tri);
+          const OMaterial m = scene_material(s, tt[3] & 0xFFFF);
+          const float alpha = albedo_for_shadowing(s, &m, tt, c).a; /* optix_anyhit.cuh:158 */
           const bool colored = (m.flags & DMAT_COLORED_TRANSPARENCY) != 0;
-          if (!(m.albedo.a == 0.0f && !colored)) {
-            if (pass == 0) { if (m.albedo.a == 1.0f && th < tstar) tstar = th; }
+          if (!(alpha == 0.0f && !colored)) {
+            if (pass == 0) { if (alpha == 1.0f && th < tstar) tstar = th; }
             else {
               n++;
               const uint32_t key = squares32(0xfcbd6e15u, 0x9E3779B9u * light + f2u(random));

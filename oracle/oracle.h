@@ -37,13 +37,15 @@ typedef struct OracleScene {
   const uint32_t* light_tri_handles; /* 2 per light: instance_id, tri_id */
   const float* light_bvh_tris;       /* 12 floats per light: 3 x (x,y,z,pad) world space */
   uint32_t num_light_tree_nodes;
-  uint32_t pad0;
+  uint32_t num_textures;
   /* sampler + LUTs */
   const uint32_t* bluenoise_2d;      /* 65536 */
   const uint16_t* lut_conductor;     /* 1024 */
   const uint16_t* lut_glossy;        /* 1024 */
   const uint16_t* lut_dielectric;    /* 32768 */
   const uint16_t* lut_dielectric_inv;/* 32768 */
+  const uint32_t* texture_table;      /* 4 words per texture: first texel, width, height, gamma (float bits) */
+  const uint32_t* texels;             /* RGBA8, r in the low byte; all textures back to back */
   /* settings (device_structs.h:8-22), internal resolution */
   uint32_t width, height, max_ray_depth, shading_mode;
   /* camera (device_structs.h:38-82), thin lens only */

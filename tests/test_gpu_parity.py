@@ -213,3 +213,25 @@ def test_full_size_frame_properties(core):
         acc_sm[tiles] = part_sm
     assert int(acc.view(np.uint32).astype(np.uint64).sum() + acc_sm.view(np.uint32).astype(np.uint64).sum()) == checksum
     _assert_same(acc, full, "3-rank tile partition at full size")
+
+
+def test_render_parity_textured_scene(core):
+    """Textures: albedo with gamma, alpha cut-outs in closest-hit and visibility rays, texture-driven coloured transparency,
+    roughness and normal maps, a dangling texture handle: moments and ray counters identical to the oracle."""
+    host = scenes.textured_scene(96, 64, 6)
+    view = oracle_lib.with_luts(host.device_scene())
+    assert view.num_textures == 5
+    core.upload(view)
+    core.set_pixels(None)
+    core.reset_counters()
+    core.render(2, 3, samples_per_pass=3)
+    fm, sm = core.accumulators()
+    ofm, osm, ocnt = oracle_lib.render(view, 2, 3)
+    _assert_same(fm, ofm, "first moment (textured scene)")
+    _assert_same(sm, osm, "second moment (textured scene)")
+    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    # closest hits through the cut-outs agree with brute force as well
+    o, d = _random_rays(30000, 21, -9.0, 9.0)
+    o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.1
+    ign = np.full((o.shape[0], 2), 0xFFFFFFFF, dtype=np.uint32)
+    _assert_same(core.trace_closest_host(o, d, ign), oracle_lib.trace_closest(view, o, d, ign, use_bvh=False), "closest hits with alpha cut-outs")

@@ -76,3 +76,26 @@ def test_material_zoo_bvh_equals_brute_force_and_descends_the_light_tree():
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
     assert np.isfinite(a[0]).all() and a[0].max() > 0
     assert a[2][0] > 0 and a[2][1] > 0 and a[2][2] > 0  # closest, shadow and light-BVH rays all present
+
+
+def test_textures_change_the_image_and_cut_outs_let_rays_through():
+    """Oracle self-check for the texture path: BVH == brute force on the textured scene, the alpha-0 texels of the fence are holes for
+    closest-hit rays, and removing the textures changes the image."""
+    host = scenes.textured_scene(48, 32, 4)
+    v = oracle_lib.with_luts(host.device_scene())
+    a = oracle_lib.render(v, 0, 2, use_bvh=True)
+    b = oracle_lib.render(v, 0, 2, use_bvh=False)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and np.isfinite(a[0]).all()
+    # rays straight at the fence (z = 2 plane, x in [-4, 4], y in [0, 3]) from the camera side: some pass through the holes
+    n = 4000
+    rng = np.random.RandomState(0)
+    o = np.stack([rng.uniform(-3.9, 3.9, n), rng.uniform(0.1, 2.9, n), np.full(n, 6.0)], axis=1).astype(np.float32)
+    d = np.tile(np.array([0.0, 0.0, -1.0], dtype=np.float32), (n, 1))
+    hits = oracle_lib.trace_closest(v, o, d, np.full((n, 2), 0xFFFFFFFF, dtype=np.uint32), use_bvh=True)
+    t = hits[:, 2].copy().view(np.float32)
+    on_fence = np.isclose(t, 4.0, atol=1e-4)
+    assert 0.5 < on_fence.mean() < 0.98  # slats and rails are hit; only texels whose filtered alpha is exactly 0 are holes
+    untextured = oracle_lib.with_luts(host.device_scene())
+    untextured.num_textures = 0
+    c = oracle_lib.render(untextured, 0, 2)
+    assert not np.array_equal(a[0], c[0])
