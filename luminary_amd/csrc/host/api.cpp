@@ -171,13 +171,15 @@ LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* pat
   std::vector<LuminaryMaterial> mats;
   std::vector<std::string> warnings;
   std::string err;
-  if (!lum::load_obj(path->value, lum::ObjLoadArgs(), (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err)) {
+  std::vector<lum::HostTexture> textures;
+  if (!lum::load_obj(path->value, lum::ObjLoadArgs(), (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err, &textures, (uint32_t) host->scene.textures.size())) {
     std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
     return LUMINARY_ERROR_API_EXCEPTION;
   }
   for (auto& w : warnings) std::fprintf(stderr, "[luminary_amd] warning: %s\n", w.c_str());
   if (mesh.triangle_count() == 0 && mesh.name.empty()) return LUMINARY_SUCCESS;
   host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
+  for (auto& t : textures) host->scene.textures.push_back(std::move(t));
   host->scene.meshes.push_back(std::move(mesh));
   invalidate(host);
   return LUMINARY_SUCCESS;
@@ -198,12 +200,14 @@ LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* pat
   for (const std::string& obj : content.obj_files) {
     lum::HostMesh mesh;
     std::vector<LuminaryMaterial> mats;
-    if (!lum::load_obj(dir + obj, content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err)) {
+    std::vector<lum::HostTexture> textures;
+    if (!lum::load_obj(dir + obj, content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err, &textures, (uint32_t) host->scene.textures.size())) {
       std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
       return LUMINARY_ERROR_API_EXCEPTION;
     }
     const uint32_t mesh_id = (uint32_t) host->scene.meshes.size();
     host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
+    for (auto& t : textures) host->scene.textures.push_back(std::move(t));
     host->scene.meshes.push_back(std::move(mesh));
     lum::HostInstance inst;
     inst.mesh_id = mesh_id;

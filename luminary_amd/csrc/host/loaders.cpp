@@ -4,6 +4,7 @@
 // an `o` line is required), :758-824 (material mapping), :828-996 (flat per-triangle mesh, degenerate removal, face normals
 // when `vn` is missing); src/luminary/host/lum.c:51-128 (header), lum_v4.c:18-757 (8-character keys per section).
 #include "loaders.h"
+#include "output.h"
 
 #include <cfloat>
 #include <cmath>
@@ -19,7 +20,7 @@ namespace {
 struct ObjMaterial {
   std::string name;
   float kd[3] = {0.9f, 0.9f, 0.9f}, dissolve = 1.0f, ks[3] = {0, 0, 0}, ns = 300.0f, ke[3] = {0, 0, 0}, ni = 1.0f;
-  bool has_map[5] = {false, false, false, false, false};  // albedo, luminance, roughness, metallic, normal
+  std::string map[5];  // albedo (map_Kd), luminance (map_Ke), roughness (map_Ns), metallic (map_refl), normal (map_Bump); paths relative to the .mtl
 };
 struct ObjTri { int32_t v[3], vt[3], vn[3]; uint16_t material; };
 
@@ -107,11 +108,31 @@ bool read_mtl(const std::string& path, float emission_scale, std::vector<ObjMate
       if (read_floats(l + 3, 3, v) == 3) { cur.ke[0] = v[0] * emission_scale; cur.ke[1] = v[1] * emission_scale; cur.ke[2] = v[2] * emission_scale; }
     }
     else if (l[0] == 'N' && l[1] == 'i') { if (read_floats(l + 3, 1, v)) cur.ni = v[0]; }
-    else if (l[0] == 'm' && l[1] == 'a') {
-      // texture maps (map_Kd/Ke/Ns/refl/Bump, wavefront.c:166-190) are outside the current scope; remember that they were requested
-      if (line.compare(0, 6, "map_Kd") == 0) cur.has_map[0] = true;
-      else if (line.compare(0, 6, "map_Ke") == 0) cur.has_map[1] = true;
-      else if (line.compare(0, 6, "map_Ns") == 0) cur.has_map[2] = true;
+    else if (line.compare(0, 4, "map_") == 0 && line.size() >= 8) {
+      // wavefront.c:159-245: the map kind, optional "-option args..." groups, then the path
+      int kind = -1;
+      size_t off = 7;
+      if (line.compare(4, 2, "Kd") == 0) kind = 0;
+      else if (line.compare(4, 2, "Ke") == 0) kind = 1;
+      else if (line.compare(4, 2, "Ns") == 0) kind = 2;
+      else if (line.compare(4, 4, "refl") == 0) { kind = 3; off = 9; }
+      else if (line.compare(4, 4, "Bump") == 0) { kind = 4; off = 9; }
+      if (kind >= 0 && off < line.size()) {
+        std::string rest = trim(line.substr(off));
+        while (!rest.empty() && rest[0] == '-') {
+          const char c0 = rest.size() > 1 ? rest[1] : ' ';
+          uint32_t num_args = 0;
+          if (c0 == 'o' || c0 == 's') num_args = 3;
+          else if (c0 == 't') num_args = (rest.size() > 2 && rest[2] == ' ') ? 3 : 1;
+          else if (c0 == 'm') num_args = 2;
+          else if (c0 == 'c' || c0 == 'b') num_args = 1;
+          for (uint32_t a = 0; a <= num_args && !rest.empty(); a++) {
+            const size_t sp = rest.find(' ');
+            rest = (sp == std::string::npos) ? std::string() : trim(rest.substr(sp + 1));
+          }
+        }
+        if (!rest.empty()) cur.map[kind] = rest;
+      }
     }
   }
   return true;
@@ -120,13 +141,14 @@ bool read_mtl(const std::string& path, float emission_scale, std::vector<ObjMate
 }  // namespace
 
 bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t material_offset, HostMesh* mesh_out, std::vector<LuminaryMaterial>* materials_out,
-              std::vector<std::string>* warnings, std::string* err) {
+              std::vector<std::string>* warnings, std::string* err, std::vector<HostTexture>* textures_out, uint32_t texture_offset) {
   std::ifstream in(path);
   if (!in) { *err = "File " + path + " could not be opened!"; return false; }
   std::vector<float> verts, normals, uvs;
   std::vector<ObjTri> tris;
   std::vector<ObjMaterial> mats(1);  // material 0 of every file is the default one (wavefront.c:64-68)
   std::vector<std::string> loaded_mtls, object_names;
+  std::string mtl_dir = dirname_of(path);
   uint16_t current_material = 0;
   std::string line;
   while (std::getline(in, line)) {
@@ -151,6 +173,7 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
       if (!seen) {
         loaded_mtls.push_back(name);
         if (!read_mtl(dirname_of(path) + name, args.emission_scale, &mats, err)) return false;
+        mtl_dir = dirname_of(dirname_of(path) + name);
       }
     }
     else if (line.compare(0, 6, "usemtl") == 0) {
@@ -165,6 +188,7 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
     return true;
   }
   // materials (wavefront.c:758-824)
+  std::vector<std::string> texture_files;
   for (size_t m = 0; m < mats.size(); m++) {
     const ObjMaterial& w = mats[m];
     LuminaryMaterial mat;
@@ -183,7 +207,25 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
     mat.normal_map_is_compressed = true;
     mat.bidirectional_emission = args.force_bidirectional_emission;
     mat.metallic = w.ks[0] > 0.5f;
-    if (w.has_map[0] || w.has_map[1] || w.has_map[2]) warnings->push_back("texture maps of material '" + w.name + "' are ignored (textures are not supported yet)");
+    // wavefront.c:787-818: one texture per distinct file; albedo, roughness and normal maps are evaluated by the renderer
+    uint16_t* slot[5] = {&mat.albedo_tex, &mat.luminance_tex, &mat.roughness_tex, &mat.metallic_tex, &mat.normal_tex};
+    for (int k = 0; k < 5; k++) {
+      if (w.map[k].empty()) continue;
+      if (k == 1 || k == 3) { warnings->push_back("map of material '" + w.name + "' (" + w.map[k] + ") is not evaluated: emission and metallic textures are outside the current scope"); continue; }
+      if (!textures_out) { warnings->push_back("texture " + w.map[k] + " ignored: no texture store"); continue; }
+      uint32_t id = 0xFFFF;
+      for (size_t t = 0; t < texture_files.size(); t++) if (texture_files[t] == w.map[k]) id = (uint32_t) t;
+      if (id == 0xFFFF) {
+        HostTexture tex;
+        std::string terr;
+        if (!read_png(mtl_dir + w.map[k], &tex.width, &tex.height, &tex.gamma, &tex.texels, &terr)) { warnings->push_back("texture ignored: " + terr); continue; }
+        if (texture_offset + textures_out->size() >= 0xFFFF) { warnings->push_back("Exceeded limit of 65535 textures."); continue; }
+        textures_out->push_back(std::move(tex));
+        texture_files.push_back(w.map[k]);
+        id = (uint32_t) texture_files.size() - 1;
+      }
+      *slot[k] = (uint16_t) (texture_offset + id);
+    }
     materials_out->push_back(mat);
   }
   // mesh (wavefront.c:828-996)

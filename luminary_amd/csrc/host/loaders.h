@@ -18,7 +18,7 @@ struct ObjLoadArgs {  // wavefront.h WavefrontArguments
 // Reads one .obj (+ its .mtl files) into a single mesh and the list of materials it defines (material 0 = default material).
 // `material_offset` is added to the material ids stored in the mesh. An .obj without an `o` line yields an empty mesh and a warning.
 bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t material_offset, HostMesh* mesh, std::vector<LuminaryMaterial>* materials,
-              std::vector<std::string>* warnings, std::string* err);
+              std::vector<std::string>* warnings, std::string* err, std::vector<HostTexture>* textures = nullptr, uint32_t texture_offset = 0);
 
 struct LumFileContent {
   LuminaryRendererSettings settings;

@@ -2,7 +2,9 @@
 
 #include <zlib.h>
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace lum {
@@ -205,6 +207,98 @@ LuminaryResult write_png(const char* path, const uint32_t* argb8, uint32_t width
   const size_t written = std::fwrite(file.data(), 1, file.size(), f);
   std::fclose(f);
   return written == file.size() ? LUMINARY_SUCCESS : LUMINARY_ERROR_C_STD;
+}
+
+namespace {
+uint32_t be32(const uint8_t* p) { return ((uint32_t) p[0] << 24) | ((uint32_t) p[1] << 16) | ((uint32_t) p[2] << 8) | p[3]; }
+uint8_t paeth(int a, int b, int c) {
+  const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+  return (uint8_t) ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c));
+}
+}  // namespace
+
+bool read_png(const std::string& path, uint32_t* width, uint32_t* height, float* gamma, std::vector<uint32_t>* rgba8, std::string* err) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) { *err = "File " + path + " could not be opened!"; return false; }
+  std::vector<uint8_t> file;
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
+  std::fclose(f);
+  static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+  if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) { *err = path + " is not a PNG file"; return false; }
+  uint32_t w = 0, h = 0, depth = 0, colour = 0, interlace = 0;
+  std::vector<uint8_t> idat, palette, trns;
+  *gamma = 1.0f;
+  size_t pos = 8;
+  while (pos + 12 <= file.size()) {
+    const uint32_t len = be32(&file[pos]);
+    const char* type = (const char*) &file[pos + 4];
+    if (pos + 12 + (size_t) len > file.size()) { *err = path + ": truncated chunk"; return false; }
+    const uint8_t* body = &file[pos + 8];
+    if (be32(body + len) != (uint32_t) crc32(0L, &file[pos + 4], (uInt) (len + 4))) { *err = path + ": chunk checksum mismatch"; return false; }
+    if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = be32(body); h = be32(body + 4); depth = body[8]; colour = body[9]; interlace = body[12]; }
+    else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
+    else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+    else if (!std::memcmp(type, "gAMA", 4) && len == 4 && be32(body) != 0) *gamma = 100000.0f / (float) be32(body);
+    else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+    else if (!std::memcmp(type, "IEND", 4)) break;
+    pos += 12 + (size_t) len;
+  }
+  static const int channels_of[7] = {1, 0, 3, 1, 2, 0, 4};
+  if (w == 0 || h == 0 || colour > 6 || channels_of[colour] == 0 || interlace != 0 || (depth != 8 && depth != 16 && !(depth < 8 && (colour == 0 || colour == 3)))) {
+    *err = path + ": unsupported PNG layout (interlaced or unusual bit depth)";
+    return false;
+  }
+  const uint32_t channels = (uint32_t) channels_of[colour];
+  const size_t bits_per_pixel = (size_t) channels * depth, bpp = std::max<size_t>(1, bits_per_pixel / 8), stride = (bits_per_pixel * w + 7) / 8;
+  std::vector<uint8_t> raw((stride + 1) * (size_t) h);
+  uLongf raw_len = (uLongf) raw.size();
+  if (uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size()) != Z_OK || raw_len != raw.size()) { *err = path + ": corrupt image data"; return false; }
+  // undo the scanline filters in place (PNG specification, section 9)
+  std::vector<uint8_t> prev(stride, 0);
+  for (uint32_t y = 0; y < h; y++) {
+    uint8_t* row = &raw[(stride + 1) * (size_t) y];
+    const uint8_t filter = row[0];
+    uint8_t* px = row + 1;
+    for (size_t i = 0; i < stride; i++) {
+      const int a = i >= bpp ? px[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0;
+      switch (filter) {
+        case 1: px[i] = (uint8_t) (px[i] + a); break;
+        case 2: px[i] = (uint8_t) (px[i] + b); break;
+        case 3: px[i] = (uint8_t) (px[i] + ((a + b) >> 1)); break;
+        case 4: px[i] = (uint8_t) (px[i] + paeth(a, b, c)); break;
+        default: break;
+      }
+    }
+    std::memcpy(prev.data(), px, stride);
+  }
+  rgba8->assign((size_t) w * h, 0);
+  for (uint32_t y = 0; y < h; y++) {
+    const uint8_t* px = &raw[(stride + 1) * (size_t) y + 1];
+    for (uint32_t x = 0; x < w; x++) {
+      uint8_t s[4] = {0, 0, 0, 255};
+      if (depth < 8) {  // packed grey or palette index
+        const size_t bit = (size_t) x * depth;
+        const uint32_t v = (px[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+        s[0] = (colour == 3) ? (uint8_t) v : (uint8_t) (v * 255u / ((1u << depth) - 1u));
+      }
+      else for (uint32_t c = 0; c < channels; c++) s[c] = px[((size_t) x * channels + c) * (depth / 8)];  // high byte of 16-bit samples
+      uint8_t r, g, b, a = 255;
+      if (colour == 0) { r = g = b = s[0]; }
+      else if (colour == 4) { r = g = b = s[0]; a = s[1]; }
+      else if (colour == 3) {
+        const size_t idx = s[0];
+        if (3 * idx + 2 >= palette.size()) { *err = path + ": palette index out of range"; return false; }
+        r = palette[3 * idx]; g = palette[3 * idx + 1]; b = palette[3 * idx + 2];
+        if (idx < trns.size()) a = trns[idx];
+      }
+      else { r = s[0]; g = s[1]; b = s[2]; if (colour == 6) a = s[3]; }
+      (*rgba8)[(size_t) y * w + x] = (uint32_t) r | ((uint32_t) g << 8) | ((uint32_t) b << 16) | ((uint32_t) a << 24);
+    }
+  }
+  *width = w; *height = h;
+  return true;
 }
 
 }  // namespace lum

@@ -62,4 +62,9 @@ class OutputStore {
 // RGBA8 truecolour PNG of an ARGB8 image (words b | g << 8 | r << 16 | a << 24), like png_store_image (host/png.c:757-784).
 LuminaryResult write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld);
 
+// PNG reader for material textures (host/png.c:25-720 handles the same subset): non-interlaced, colour types 0, 2, 3, 4, 6 at 8 or 16
+// bits (16-bit samples keep their high byte; 1/2/4-bit grey and palette images are expanded), all five scanline filters, tRNS for
+// palettes, gAMA (gamma = 100000 / gAMA, png.c:541). Result: RGBA8 words (r in the low byte), rows top to bottom.
+bool read_png(const std::string& path, uint32_t* width, uint32_t* height, float* gamma, std::vector<uint32_t>* rgba8, std::string* err);
+
 }  // namespace lum

@@ -112,3 +112,73 @@ def test_defaults_match_reference_defaults():
     assert c.aperture_blade_count == 7 and abs(c.russian_roulette_threshold - 0.1) < 1e-7 and abs(c.thin_lens.fov - 1.0) < 1e-7
     k = host.get_sky()
     assert k.mode == 0 and k.steps == 40 and abs(k.azimuth - 3.141) < 1e-6
+
+
+def test_obj_loader_reads_texture_maps(tmp_path):
+    """map_Kd / map_Ns / map_Bump of an .mtl become textures (wavefront.c:159-281); the PNG reader handles RGBA8, RGB8 with every
+    scanline filter, 16-bit grey and palettes with tRNS, and takes the gamma from gAMA (png.c:541)."""
+    import struct
+    import zlib
+
+    import numpy as np
+
+    import luminary_amd
+    import oracle_lib
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+
+    def png(path, w, h, depth, colour, rows, extra=b""):
+        raw = b"".join(rows)
+        data = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 0)) + extra + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+        open(path, "wb").write(data)
+
+    rng = np.random.RandomState(3)
+    rgba = rng.randint(0, 256, size=(5, 7, 4)).astype(np.uint8)
+    png(str(tmp_path / "albedo.png"), 7, 5, 8, 6, [b"\x00" + rgba[y].tobytes() for y in range(5)], extra=chunk(b"gAMA", struct.pack(">I", 45455)))
+    # RGB8 written with the Sub, Up, Average and Paeth filters (rows 1..4) to exercise the un-filtering
+    rgb = rng.randint(0, 256, size=(5, 6, 3)).astype(np.int32)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+
+    rows = []
+    for y in range(5):
+        cur, prev = rgb[y].reshape(-1), (rgb[y - 1].reshape(-1) if y else np.zeros(18, dtype=np.int32))
+        out = []
+        for i in range(18):
+            a = cur[i - 3] if i >= 3 else 0
+            b = prev[i]
+            c = prev[i - 3] if i >= 3 else 0
+            pred = [0, a, b, (a + b) // 2, paeth(int(a), int(b), int(c))][y]
+            out.append((int(cur[i]) - int(pred)) & 0xFF)
+        rows.append(bytes([y]) + bytes(out))
+    png(str(tmp_path / "rough.png"), 6, 5, 8, 2, rows)
+    grey16 = rng.randint(0, 65536, size=(3, 4)).astype(">u2")
+    png(str(tmp_path / "bump.png"), 4, 3, 16, 0, [b"\x00" + grey16[y].tobytes() for y in range(3)])
+    (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nmap_Kd -s 1 1 1 albedo.png\nmap_Ns rough.png\nmap_Bump -bm 0.3 bump.png\nmap_Ke missing.png\n"
+                                    "newmtl b\nKd 0.1 0.2 0.3\nmap_Kd albedo.png\n")
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\no quad\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\nusemtl b\nf 1/1 3/3 4/4\n")
+    host = luminary_amd.Host()
+    host.load_obj_file(str(tmp_path / "m.obj"))
+    host.new_instance(0)
+    ma, mb = host.get_material(1), host.get_material(2)  # material 0 is the loader's default material
+    assert (ma.albedo_tex, ma.roughness_tex, ma.normal_tex, ma.luminance_tex, ma.metallic_tex) == (0, 1, 2, 0xFFFF, 0xFFFF)
+    assert mb.albedo_tex == 0 and mb.roughness_tex == 0xFFFF  # the same file is one texture
+    v = host.device_scene()
+    assert v.num_textures == 3
+    import ctypes as C
+    table = np.ctypeslib.as_array(C.cast(v.texture_table, C.POINTER(C.c_uint32)), shape=(3, 4)).copy()
+    assert table[:, 1].tolist() == [7, 6, 4] and table[:, 2].tolist() == [5, 5, 3] and table[0, 0] == 0 and table[1, 0] == 35 and table[2, 0] == 65
+    assert abs(table[0, 3:4].view(np.float32)[0] - 100000.0 / 45455.0) < 1e-6 and table[1, 3:4].view(np.float32)[0] == 1.0
+    texels = np.ctypeslib.as_array(C.cast(v.texels, C.POINTER(C.c_uint32)), shape=(77,)).copy()
+    assert np.array_equal(texels[:35].view(np.uint8).reshape(5, 7, 4), rgba)
+    got_rgb = texels[35:65].view(np.uint8).reshape(5, 6, 4)
+    assert np.array_equal(got_rgb[..., :3], rgb.astype(np.uint8)) and (got_rgb[..., 3] == 255).all()
+    got_grey = texels[65:].view(np.uint8).reshape(3, 4, 4)
+    assert np.array_equal(got_grey[..., 0], (grey16.astype(np.uint16) >> 8).astype(np.uint8)) and np.array_equal(got_grey[..., 0], got_grey[..., 2])
+    # the packed uvs reach the device format and the oracle renders the textured quad
+    host2 = oracle_lib.with_luts(v)
+    assert host2.num_textures == 3
