@@ -93,7 +93,16 @@ def cpu_baseline(view, budget_s):
             pixels, spp = None, max(1, min(64, int(want_px_spp / n_total)))
         dt, rays = run(pixels, spp)
     npx = n_total if pixels is None else pixels.size
-    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
+    model = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu": model,
             "sample": "oracle/ (CPU restatement, OpenMP over pixels, %d threads) on %d pixels x %d spp of the same frame, all 9 depth passes: "
                       "%.0f rays in %.1f s (its %.1f s BVH build excluded)" % (cores, npx, spp, rays, dt, t_build)}
 

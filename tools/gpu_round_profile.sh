@@ -16,4 +16,6 @@ for w in example hall; do
   timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/pmc_fetch_$w -- python3 bench.py --steps 2 --warmup 1 --cpu-budget 0 $extra > $out/pmc_fetch_$w.log 2>&1
   timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/pmc_write_$w -- python3 bench.py --steps 2 --warmup 1 --cpu-budget 0 $extra > $out/pmc_write_$w.log 2>&1
 done
+timeout 900 rocprofv3 --kernel-trace --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $out/pmc_lds_example -- python3 bench.py --steps 2 --warmup 1 --cpu-budget 0 > $out/pmc_lds_example.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $out/pmc_tcc_hall -- python3 bench.py --workload hall --steps 2 --warmup 1 --cpu-budget 0 > $out/pmc_tcc_hall.log 2>&1
 find $out -name "*.csv" | head -40
