@@ -121,6 +121,10 @@ int lumc_generate_output_from_host(LumContext* ctx, const LumOutputParams* param
 
 /* Closest-hit query on device buffers (float3 origins/dirs, optional uint2 ignore handles, uint3 out: instance, triangle, t bits). */
 int lumc_trace_closest(LumContext* ctx, uint32_t num_rays, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream);
+/* Closest hit of the camera ray of pixel (x, y) at sample id `sample_id`: out = instance id (0xFFFFFFFE = sky), triangle id, t bits, then the ray
+ * direction x, y, z bits. Serves luminary_host_get_pixel_info (the reference fills a G-buffer during undersampled previews instead,
+ * optix/optix_kernel_raytrace.cu:18-76). */
+int lumc_pixel_query(LumContext* ctx, uint32_t x, uint32_t y, uint32_t sample_id, uint32_t out[6]);
 /* Same with host buffers (copies in and out); used by the parity tests. */
 int lumc_trace_closest_host(LumContext* ctx, uint32_t num_rays, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out);
 

@@ -84,6 +84,10 @@ class Material(C.Structure):
                 ("luminance_tex", C.c_uint16), ("roughness_tex", C.c_uint16), ("metallic_tex", C.c_uint16), ("normal_tex", C.c_uint16)]
 
 
+class PixelQueryResult(C.Structure):
+    _fields_ = [("pixel_query_is_valid", C.c_bool), ("instance_id", C.c_uint32), ("material_id", C.c_uint16), ("depth", C.c_float), ("rel_hit_pos", Vec3)]
+
+
 class OutputProperties(C.Structure):
     _fields_ = [("enabled", C.c_bool), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -241,6 +245,11 @@ class Host:
         _call("luminary_host_get_num_materials", self._h, C.byref(b))
         _call("luminary_host_get_num_instances", self._h, C.byref(c))
         return a.value, b.value, c.value
+
+    def get_pixel_info(self, x, y):
+        r = PixelQueryResult()
+        _call("luminary_host_get_pixel_info", self._h, C.c_uint16(x), C.c_uint16(y), C.byref(r))
+        return r
 
     # ---- output chain ----
     def set_output_properties(self, width, height, enabled=True):

@@ -546,6 +546,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_rays(DeviceScene sc, uint
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
+// ---- camera ray of one pixel (first sample id), for pixel queries ----
+__global__ void k_pixel_ray(DeviceScene sc, uint32_t x, uint32_t y, uint32_t sample_id, float* origin, float* dir) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  const Sampler smp{sc.bluenoise_2d, x, y, sample_id, 0};
+  V3 o, d;
+  camera_ray(sc, smp, o, d);
+  origin[0] = o.x; origin[1] = o.y; origin[2] = o.z;
+  dir[0] = d.x; dir[1] = d.y; dir[2] = d.z;
+}
+
 // ---- BSDF energy LUTs (cuda/bsdf_lut.cuh:20-211): pixel (0,0), depth 0, sample id = iteration ----
 LUM_DEV uint16_t quantise_energy(float sum) { return (uint16_t) (1 + (uint16_t) (ceilf(saturate(sum) * 0xFFFE))); }
 

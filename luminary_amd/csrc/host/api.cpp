@@ -4,6 +4,7 @@
 // thread; this implementation applies scene edits immediately on the caller's thread and renders synchronously inside the
 // luminary_ext_* calls (one process drives one GPU; DESIGN.md "Threading").
 #include <cmath>
+#include <cfloat>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -244,8 +245,34 @@ LuminaryResult luminary_host_try_await_output(LuminaryHost* host, LuminaryOutput
 LuminaryResult luminary_host_acquire_output(LuminaryHost* host, LuminaryOutputHandle* out) { CHECK_NULL(host); CHECK_NULL(out); return host->outputs.acquire_recurring(out); }
 LuminaryResult luminary_host_get_image(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryImage* image) { CHECK_NULL(host); CHECK_NULL(image); return host->outputs.get_image(handle, image); }
 LuminaryResult luminary_host_release_output(LuminaryHost* host, LuminaryOutputHandle handle) { CHECK_NULL(host); return host->outputs.release(handle); }
-// pixel queries need the identification AOV of the first hit, which the hot path does not keep
-LuminaryResult luminary_host_get_pixel_info(LuminaryHost* host, uint16_t x, uint16_t y, LuminaryPixelQueryResult* result) { CHECK_NULL(host); CHECK_NULL(result); (void) x; (void) y; result->pixel_query_is_valid = false; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+// host.c:997-1014. The reference reads a G-buffer that its trace kernel fills during undersampled previews (optix_kernel_raytrace.cu:18-76);
+// here the pixel's first-sample camera ray is traced on demand, which gives the same fields at any time.
+LuminaryResult luminary_host_get_pixel_info(LuminaryHost* host, uint16_t x, uint16_t y, LuminaryPixelQueryResult* result) {
+  CHECK_NULL(host); CHECK_NULL(result);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  std::memset(result, 0, sizeof(*result));
+  result->instance_id = 0xFFFFFFFFu; result->material_id = 0xFFFF; result->depth = -1.0f;  // DEPTH_INVALID / MATERIAL_ID_INVALID, utils.h:30-33
+  if (ensure_core(host)) return LUMINARY_SUCCESS;  // no device: the query has no data, like a G-buffer that is not ready
+  const LumDeviceSceneView& v = host->device_scene.view;
+  if (x >= v.width || y >= v.height) return LUMINARY_SUCCESS;
+  uint32_t q[6];
+  if (lumc_pixel_query(host->core, x, y, 0, q)) return LUMINARY_ERROR_CUDA;
+  float depth, dir[3];
+  std::memcpy(&depth, &q[2], 4); std::memcpy(dir, &q[3], 12);
+  result->depth = depth;
+  if (q[0] < 0x7FFFFFFFu && q[0] < v.num_instances) {  // HIT_TYPE_TRIANGLE_ID_LIMIT
+    const uint32_t mesh = v.instance_mesh_ids[q[0]];
+    result->instance_id = q[0];
+    result->material_id = (uint16_t) (v.tri_tex[(size_t) (v.mesh_tri_offset[mesh] + q[1]) * 4 + 3] & 0xFFFFu);
+  }
+  if (depth < FLT_MAX) {  // rel_hit_pos = ray * depth, kept at bfloat16 precision like the G-buffer
+    float rel[3] = {dir[0] * depth, dir[1] * depth, dir[2] * depth};
+    for (int k = 0; k < 3; k++) { uint32_t b; std::memcpy(&b, &rel[k], 4); b &= 0xFFFF0000u; std::memcpy(&rel[k], &b, 4); }
+    result->rel_hit_pos.x = rel[0]; result->rel_hit_pos.y = rel[1]; result->rel_hit_pos.z = rel[2];
+  }
+  result->pixel_query_is_valid = (result->depth != -1.0f) || (result->instance_id != 0xFFFFFFFFu) || (result->material_id != 0xFFFF);
+  return LUMINARY_SUCCESS;
+}
 LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle handle, LuminaryPath* path) {
   CHECK_NULL(host); CHECK_NULL(path);
   if (handle == LUMINARY_OUTPUT_HANDLE_INVALID) return LUMINARY_ERROR_INVALID_API_ARGUMENT;

@@ -736,6 +736,20 @@ int lumc_trace_closest_host(LumContext* ctx, uint32_t n, const float* origins, c
   return rc;
 }
 
+int lumc_pixel_query(LumContext* ctx, uint32_t x, uint32_t y, uint32_t sample_id, uint32_t out[6]) {
+  if (!ctx || !ctx->has_scene || !out) { if (ctx) ctx->error = "lumc_pixel_query: no scene"; return 1; }
+  if (x >= ctx->scene.width || y >= ctx->scene.height) { ctx->error = "lumc_pixel_query: pixel outside the frame"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  float* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**) &d, sizeof(float) * 9));
+  hipLaunchKernelGGL(k_pixel_ray, dim3(1), dim3(64), 0, 0, ctx->scene, x, y, sample_id, d, d + 3);
+  int rc = lumc_trace_closest(ctx, 1, d, d + 3, nullptr, (uint32_t*) (d + 6), nullptr);
+  if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d + 6, 12, hipMemcpyDeviceToHost) != hipSuccess ||
+              hipMemcpy(out + 3, d + 3, 12, hipMemcpyDeviceToHost) != hipSuccess)) { ctx->error = "lumc_pixel_query: device error"; rc = 1; }
+  (void) hipFree(d);
+  return rc;
+}
+
 int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]) {
   if (!ctx) return 1;
   for (int k = 0; k < 4; k++) out[k] = ctx->bvh_stats[k];

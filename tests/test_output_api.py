@@ -112,3 +112,32 @@ def test_outputs_through_the_api_match_the_oracle(tmp_path):
         host.release_output(handle)
     with pytest.raises(LuminaryError):
         host.release_output(rec)  # already released
+
+
+@pytest.mark.gpu
+def test_pixel_query_reports_the_first_hit(tmp_path):
+    """luminary_host_get_pixel_info (host.h:89): instance, material, depth and the hit offset of the pixel's first-sample camera ray,
+    checked against the oracle's camera ray and closest-hit query."""
+    w, h = 64, 48
+    host = scenes.cornell_host(str(tmp_path), w, h, 1)
+    view = oracle_lib.with_luts(host.device_scene())
+    l = oracle_lib.lib()
+    import ctypes as C
+    hits = 0
+    for (x, y) in [(5, 5), (32, 24), (50, 40), (63, 47), (20, 10)]:
+        r = host.get_pixel_info(x, y)
+        ray = (C.c_float * 6)()
+        l.oracle_camera_ray(C.byref(view), C.c_uint32(x), C.c_uint32(y), C.c_uint32(0), ray)
+        o = np.array([list(ray)[:3]], dtype=np.float32)
+        d = np.array([list(ray)[3:]], dtype=np.float32)
+        want = oracle_lib.trace_closest(view, o, d, np.full((1, 2), 0xFFFFFFFF, dtype=np.uint32), use_bvh=False)[0]
+        depth = want[2:3].copy().view(np.float32)[0]
+        assert r.pixel_query_is_valid and np.float32(r.depth) == depth
+        if want[0] < 0x7FFFFFFF:
+            hits += 1
+            assert r.instance_id == want[0]
+            rel = (d[0] * depth).astype(np.float32).view(np.uint32) & 0xFFFF0000
+            got = np.array([r.rel_hit_pos.x, r.rel_hit_pos.y, r.rel_hit_pos.z], dtype=np.float32).view(np.uint32)
+            assert np.array_equal(got, rel) and r.material_id != 0xFFFF
+    assert hits >= 3
+    assert not host.get_pixel_info(w, h).pixel_query_is_valid  # outside the frame
