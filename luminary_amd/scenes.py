@@ -558,3 +558,46 @@ def textured_scene(width=96, height=64, bounces=6, seed=11):
                            ((4, 6.0, -5), (7, 6.0, -5), (7, 6.0, -2), (4, 6.0, -2))], m_light))
     set_camera(host, (0.5, 2.6, 9.0), (-0.17, 0.02, 0.0), fov=0.75)
     return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Edge cases for the parity tests
+# ---------------------------------------------------------------------------------------------------------------------
+
+def edge_scene(kind, width=48, height=32, bounces=4):
+    """Small scenes at the borders of the input domain:
+    "empty"        no geometry at all (every path leaves to the sky on its first ray)
+    "no_lights"    geometry without any emissive triangle (no light tree: next-event estimation is skipped)
+    "degenerate"   zero-area and duplicated coplanar triangles, a zero-scale instance, an instance of an empty mesh
+    "one_triangle" a single emissive triangle seen from both sides
+    """
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.4, 0.5, 0.7))
+    grey = host.add_material(_material((0.6, 0.6, 0.6), 0.6))
+    glow = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(9.0, 8.0, 7.0)))
+    if kind == "empty":
+        pass
+    elif kind == "no_lights":
+        g = _grid(4, 4, -8, 8, -8, 8)
+        host.new_instance(host.add_mesh(g, np.full(len(g), grey, dtype=np.uint16)))
+        bx, _ = _box()
+        host.new_instance(host.add_mesh(bx, np.full(len(bx), grey, dtype=np.uint16)), (0.0, 1.0, -1.0), (0.3, 0.4, 0.0), (1.5, 1.0, 1.0))
+    elif kind == "degenerate":
+        tris = np.array([
+            [-6, 0, -6, 6, 0, -6, 6, 0, 6], [-6, 0, -6, 6, 0, 6, -6, 0, 6],        # floor
+            [-6, 0, -6, 6, 0, -6, 6, 0, 6], [-6, 0, -6, 6, 0, 6, -6, 0, 6],        # the same floor again (exact ties)
+            [1, 1, 1, 1, 1, 1, 1, 1, 1], [0, 2, 0, 1, 2, 0, 2, 2, 0],              # a point and a line: zero area
+            [-2, 0.5, -2, 2, 0.5, -2, 0, 3.0, -2],                                  # a regular triangle
+        ], dtype=np.float32)
+        m = host.add_mesh(tris, np.full(len(tris), grey, dtype=np.uint16))
+        host.new_instance(m)
+        host.new_instance(m, (0.0, 0.0, 0.0), (0.0, 0.0, 0.0), (0.0, 1.0, 1.0))   # collapsed along x
+        lq = np.array([[-1, 4, -1, 1, 4, 1, 1, 4, -1], [-1, 4, -1, -1, 4, 1, 1, 4, 1]], dtype=np.float32)
+        host.new_instance(host.add_mesh(lq, np.full(2, glow, dtype=np.uint16)))
+    elif kind == "one_triangle":
+        t = np.array([[-3, 0.5, -2, 3, 0.5, -2, 0, 4.0, -2]], dtype=np.float32)
+        host.new_instance(host.add_mesh(t, np.full(1, glow, dtype=np.uint16)))
+    else:
+        raise ValueError(kind)
+    set_camera(host, (0.0, 2.0, 9.0), (-0.1, 0.0, 0.0), fov=0.8)
+    return host

@@ -235,3 +235,49 @@ def test_render_parity_textured_scene(core):
     o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.1
     ign = np.full((o.shape[0], 2), 0xFFFFFFFF, dtype=np.uint32)
     _assert_same(core.trace_closest_host(o, d, ign), oracle_lib.trace_closest(view, o, d, ign, use_bvh=False), "closest hits with alpha cut-outs")
+
+
+@pytest.mark.parametrize("kind", ["empty", "no_lights", "degenerate", "one_triangle"])
+def test_render_parity_edge_scenes(core, kind):
+    """Borders of the input domain: no geometry, no lights, zero-area / duplicated triangles with a collapsed instance, a single
+    triangle. Moments and ray counters identical to the oracle."""
+    host = scenes.edge_scene(kind, 48, 32, 4)
+    view = oracle_lib.with_luts(host.device_scene())
+    core.upload(view)
+    core.set_pixels(None)
+    core.reset_counters()
+    core.render(0, 3, samples_per_pass=2)  # 2 + 1: a ragged last pass
+    fm, sm = core.accumulators()
+    ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
+    _assert_same(fm, ofm, "first moment (%s)" % kind)
+    _assert_same(sm, osm, "second moment (%s)" % kind)
+    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    if kind == "empty":
+        assert np.allclose(fm / 3.0, np.array([[0.4], [0.5], [0.7]], dtype=np.float32), rtol=1e-6)  # the constant sky, nothing else
+
+
+@pytest.mark.parametrize("bounces", [0, 63])
+def test_render_parity_depth_limits(core, tmp_path_factory, bounces):
+    """max_ray_depth 0 (camera rays and their direct light only) and 63 (the largest value the 6-bit depth field holds)."""
+    host = _cornell(tmp_path_factory, 40, 30, bounces)
+    view = oracle_lib.with_luts(host.device_scene())
+    core.upload(view)
+    core.set_pixels(None)
+    core.render(1, 2, samples_per_pass=2)
+    fm, sm = core.accumulators()
+    ofm, osm, _ = oracle_lib.render(view, 1, 2)
+    _assert_same(fm, ofm, "first moment (max depth %d)" % bounces)
+    _assert_same(sm, osm, "second moment (max depth %d)" % bounces)
+
+
+def test_empty_pixel_set_and_single_pixel(core, tmp_path_factory):
+    host = _cornell(tmp_path_factory, 40, 30, 2)
+    view = oracle_lib.with_luts(host.device_scene())
+    core.upload(view)
+    one = np.array([40 * 15 + 20], dtype=np.uint32)
+    core.set_pixels(one)
+    core.render(0, 5, samples_per_pass=3)
+    fm, sm = core.accumulators()
+    ofm, osm, _ = oracle_lib.render(view, 0, 5, pixels=one)
+    _assert_same(fm, ofm, "single pixel")
+    _assert_same(sm, osm, "single pixel (second moment)")
