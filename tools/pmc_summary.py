@@ -6,7 +6,8 @@ from collections import defaultdict
 acc = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(int)
 for d in sys.argv[1:]:
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    import os
+    for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1:]:  # newest pass only
         seen = set()
         for row in csv.DictReader(open(f)):
             k = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("lum::", "").replace("void ", "")[:28]

@@ -15,7 +15,8 @@ workload, spp, fetch_dir, write_dir = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 
 def per_kernel(d, counter):
     tot, n = defaultdict(float), defaultdict(set)
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+    files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # gpurun merges successive runs into the same directory: only the newest pass counts
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] != counter:
                 continue
