@@ -218,20 +218,47 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
   const Col sky = (sc.sky_mode == kSkyConstantColor) ? col(sc.sky_constant_color[0], sc.sky_constant_color[1], sc.sky_constant_color[2]) : splat(0.0f);
   uint32_t vertices = 0;
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-  for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+  // Paths that left the scene only add the sky term; the surface vertices are two orders of magnitude more work. A wave therefore
+  // collects the indices of its surface hits in LDS and shades them 64 at a time, so that misses do not leave lanes idle during the
+  // expensive part (the reference sorts tasks by hit type for the same reason, cuda/kernels.cuh:391-484).
+  __shared__ uint32_t pending_hits[kBlock / 64][128];
+  uint32_t* pending = pending_hits[threadIdx.x >> 6];
+  uint32_t num_pending = 0;  // wave-uniform
+  for (uint32_t round = 0;; round++) {
+    const bool input_done = round >= rounds;
+    if (!input_done) {
+      const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      bool is_hit = false;
+      if (i < n) {
+        if (in.hit_id[i].x == kHitSky) {
+          const uint4 aux = in.aux[i];
+          if (aux.w & kStAllowAmbient) add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
+        }
+        else is_hit = true;
+      }
+      const unsigned long long bh = __ballot(is_hit);
+      if (is_hit) pending[num_pending + (uint32_t) __popcll(bh & below)] = i;
+      num_pending += (uint32_t) __popcll(bh);
+    }
+    if (num_pending < 64u && !(input_done && num_pending > 0u)) {
+      if (input_done) break;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t take = min(num_pending, 64u);
+    num_pending -= take;
+    const bool valid = lane < take;
+    const uint32_t i = valid ? pending[num_pending + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
     bool survive = false, want_geo = false, want_amb = false, want_lq = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_geo_dir, s_amb_dir; uint4 s_geo_ids;
-    if (i < n) {
+    if (valid) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
       const uint32_t slot = fbits(d4.w), state = aux.w;
       const Col record_in = record_unpack(U2{aux.x, aux.y});
-      if (hid.x == kHitSky) {
-        if (state & kStAllowAmbient) add_to_result(results, slot, sky * record_in);
-      }
-      else {
+      {
         vertices++;
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
