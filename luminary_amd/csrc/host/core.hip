@@ -750,6 +750,14 @@ int lumc_pixel_query(LumContext* ctx, uint32_t x, uint32_t y, uint32_t sample_id
   return rc;
 }
 
+#ifdef LUM_PHASE_STATS
+extern "C" int lumc_debug_phase_stats(uint64_t out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lum::g_phase), sizeof(uint64_t) * 8) != hipSuccess) return 1;
+  if (reset) { const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lum::g_phase), zero, sizeof(zero)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]) {
   if (!ctx) return 1;
   for (int k = 0; k < 4; k++) out[k] = ctx->bvh_stats[k];

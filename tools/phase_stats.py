@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Where do the lanes of the persistent ray kernels idle? Needs a diagnostic build:
+  LUM_CXXFLAGS=-DLUM_PHASE_STATS python -m luminary_amd.build --force && python tools/phase_stats.py [example|hall|scan]
+Prints wave-level iteration counts per traversal phase and the lane occupancy of each (both ray kernels together)."""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import luminary_amd  # noqa: E402
+from luminary_amd.core import Core  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "example"
+host, label = bench.build_workload(name, 1920, 1080, 8)
+core = Core(0)
+core.upload(host.device_scene())
+core.set_pixels(None)
+lib = luminary_amd._lib()
+out = (C.c_uint64 * 8)()
+core.render(0, 8, samples_per_pass=8)
+lib.lumc_debug_phase_stats(out, 1)
+core.reset_counters()
+core.render(8, 8, samples_per_pass=8)
+lib.lumc_debug_phase_stats(out, 1)
+cnt = core.counters()
+node_it, inst_it, inst_l, tri_it, tri_l, outer, pop_it, pop_l = [int(x) for x in out]
+nodes = int(cnt[4] + cnt[6]); tris = int(cnt[5] + cnt[7]); rays = int(cnt[0] + cnt[1])
+print(label)
+print("rays %d  node visits %d  triangle tests %d" % (rays, nodes, tris))
+print("node phase:     %10d wave iterations, lane occupancy %.3f" % (node_it, nodes / (64.0 * max(node_it, 1))))
+print("pop:            %10d wave iterations, lane occupancy %.3f" % (pop_it, pop_l / (64.0 * max(pop_it, 1))))
+print("instance entry: %10d wave iterations, lane occupancy %.3f" % (inst_it, inst_l / (64.0 * max(inst_it, 1))))
+print("triangle phase: %10d wave iterations, lane occupancy %.3f, triangle slots used %.3f of 4" % (tri_it, tri_l / (64.0 * max(tri_it, 1)), tris / max(tri_l, 1)))
+print("outer iterations (refill checks): %d" % outer)
+print("per ray: %.2f node, %.2f instance, %.2f leaf visits" % (nodes / rays, inst_l / rays, tri_l / rays))
