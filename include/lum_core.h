@@ -119,6 +119,49 @@ int lumc_generate_output_host(LumContext* ctx, const LumOutputParams* params, co
 /* Same with the first moment in HOST memory (e.g. a frame assembled from several GPUs); it is uploaded to a temporary buffer. */
 int lumc_generate_output_from_host(LumContext* ctx, const LumOutputParams* params, const float* first_moment, uint32_t* argb8, float* frame_output);
 
+/*
+ * Adaptive sampling (replaces device/device_adaptive_sampler.c, cuda/adaptive_sampling.cuh, cuda/kernels.cuh:195-355 and the stage
+ * schedule of device/device_renderer.c:350-375). Works on the whole frame with the context's own accumulators.
+ * An *execution* is one sample allocation step of the reference: at stage 0 one sample of every pixel, at stage s >= 1
+ * rate_s(block) samples of every pixel of a 4x4 block. Stage s lasts exactly `update_interval << s` executions; then the rates of
+ * stage s+1 are computed from the measured variance (at most four such builds).
+ */
+typedef struct LumAdaptiveParams {
+  uint32_t max_sampling_rate, avg_sampling_rate, update_interval; /* LuminaryRendererSettings::adaptive_sampling_* */
+  float exposure;        /* exp(camera.exposure) when exposure aware, 0 otherwise (device_adaptive_sampler.c:57) */
+  LumOutputParams tone;  /* tone curve of the compression factor: only tonemap and agx_* are read */
+} LumAdaptiveParams;
+typedef struct LumAdaptiveInfo {
+  uint32_t stage_id, executions[5], num_blocks, blocks_x, blocks_y;
+  uint32_t tasks_per_execution; /* paths one execution of the current stage generates (pixels of partial edge blocks included) */
+  float variance_total;         /* sum of the block variances of the last stage build */
+} LumAdaptiveInfo;
+/* Starts (or restarts) adaptive rendering: needs a full-frame pixel set; clears the accumulators and the stage state. */
+int lumc_adaptive_begin(LumContext* ctx, const LumAdaptiveParams* params);
+/* Runs `executions` executions, building stages when they are due. Asynchronous like lumc_render except for one small download per
+ * stage build (the task prefix, used to cut an execution into passes). */
+int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream);
+int lumc_adaptive_info(LumContext* ctx, LumAdaptiveInfo* out);
+/* Per-block packed rates (byte s-1 = rate of stage s, minus one) and optionally the block variances of the last build. */
+int lumc_adaptive_download(LumContext* ctx, uint32_t* stage_counts, float* block_variance);
+/* Leaves adaptive mode (lumc_set_pixels does so too). */
+int lumc_adaptive_end(LumContext* ctx);
+
+/*
+ * Result image (replaces accumulation_generate_result, cuda/accumulation.cuh:86-200): planar mean radiance [3 * W * H] from the
+ * context's accumulators. mode: 0 beauty (with optional local error minimisation), 1 variance, 2 error, 3 sample distribution
+ * (LuminaryAdaptiveSamplingOutputMode). While adaptive mode is active every pixel is normalised by its own sample count, otherwise by
+ * `uniform_samples`. `exposure` = exp(camera.exposure) and `tone` feed the error image. d_result: DEVICE buffer or NULL for the
+ * context's own (what lumc_generate_output reads when params->inv_sample_count == 1 and d_first_moment is that buffer).
+ */
+int lumc_generate_result(LumContext* ctx, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure,
+                         const LumOutputParams* tone, float* d_result, void* stream);
+/* Same, copied to host memory [3 * W * H]. */
+int lumc_generate_result_host(LumContext* ctx, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure,
+                              const LumOutputParams* tone, float* result);
+/* Device address of the context's result image (valid after lumc_generate_result with d_result == NULL). */
+const float* lumc_result_image(LumContext* ctx);
+
 /* Closest-hit query on device buffers (float3 origins/dirs, optional uint2 ignore handles, uint3 out: instance, triangle, t bits). */
 int lumc_trace_closest(LumContext* ctx, uint32_t num_rays, const float* d_origins, const float* d_dirs, const uint32_t* d_ignore, uint32_t* d_out, void* stream);
 /* Closest hit of the camera ray of pixel (x, y) at sample id `sample_id`: out = instance id (0xFFFFFFFE = sky), triangle id, t bits, then the ray

@@ -35,6 +35,18 @@ def default_output_params(width, height, sample_count, dst=None):
     return p
 
 
+class AdaptiveParams(C.Structure):
+    """include/lum_core.h LumAdaptiveParams."""
+    _fields_ = [("max_sampling_rate", C.c_uint32), ("avg_sampling_rate", C.c_uint32), ("update_interval", C.c_uint32), ("exposure", C.c_float),
+                ("tone", OutputParams)]
+
+
+class AdaptiveInfo(C.Structure):
+    """include/lum_core.h LumAdaptiveInfo."""
+    _fields_ = [("stage_id", C.c_uint32), ("executions", C.c_uint32 * 5), ("num_blocks", C.c_uint32), ("blocks_x", C.c_uint32), ("blocks_y", C.c_uint32),
+                ("tasks_per_execution", C.c_uint32), ("variance_total", C.c_float)]
+
+
 class Core:
     def __init__(self, device=0):
         self._lib = _lib()
@@ -133,6 +145,42 @@ class Core:
         n = (C.c_uint32 * len(KERNELS))()
         self._call("lumc_kernel_times", ms, n)
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(KERNELS)}
+
+    # ---- adaptive sampling (lumc_adaptive_*) ----
+    def adaptive_begin(self, max_rate, avg_rate, update_interval, exposure=0.0, tone=None):
+        p = AdaptiveParams()
+        p.max_sampling_rate, p.avg_sampling_rate, p.update_interval, p.exposure = max_rate, avg_rate, update_interval, exposure
+        if tone is not None:
+            p.tone = tone
+        self._call("lumc_adaptive_begin", C.byref(p))
+
+    def adaptive_render(self, executions, stream=0):
+        self._call("lumc_adaptive_render", C.c_uint32(executions), C.c_void_p(stream))
+
+    def adaptive_info(self):
+        info = AdaptiveInfo()
+        self._call("lumc_adaptive_info", C.byref(info))
+        return {"stage_id": int(info.stage_id), "executions": [int(x) for x in info.executions], "num_blocks": int(info.num_blocks),
+                "blocks": (int(info.blocks_x), int(info.blocks_y)), "tasks_per_execution": int(info.tasks_per_execution),
+                "variance_total": float(info.variance_total)}
+
+    def adaptive_download(self):
+        n = self.adaptive_info()["num_blocks"]
+        counts = np.zeros(n, dtype=np.uint32)
+        variance = np.zeros(n, dtype=np.float32)
+        self._call("lumc_adaptive_download", counts.ctypes.data_as(C.c_void_p), variance.ctypes.data_as(C.c_void_p))
+        return counts, variance
+
+    def adaptive_end(self):
+        self._call("lumc_adaptive_end")
+
+    def generate_result(self, mode=0, local_error_minimization=False, uniform_samples=0, exposure=1.0, tone=None):
+        """Mean-radiance / diagnostic image [3, H, W] of the context's full-frame accumulators (lumc_generate_result_host)."""
+        out = np.zeros((3, self.height, self.width), dtype=np.float32)
+        tp = C.byref(tone) if tone is not None else C.c_void_p(0)
+        self._call("lumc_generate_result_host", C.c_uint32(mode), C.c_uint32(1 if local_error_minimization else 0), C.c_uint32(uniform_samples),
+                   C.c_float(exposure), tp, out.ctypes.data_as(C.c_void_p))
+        return out
 
     def bvh_stats(self):
         out = (C.c_uint64 * 4)()

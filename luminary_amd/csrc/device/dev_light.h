@@ -138,6 +138,7 @@ LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const GeoContext& g, const
   rv.random = smp.next1(kRndLightTreePostpass + lane);
   rv.reset();
   while (r.light_id == kLightIdInvalid) {
+    LUM_STAT(12, 13);
     const uint4 n0 = sc.light_tree_nodes[4 * node_id], n1 = sc.light_tree_nodes[4 * node_id + 1], n2 = sc.light_tree_nodes[4 * node_id + 2],
                 n3 = sc.light_tree_nodes[4 * node_id + 3];
     const V3 base = v3(bfloat_unpack(n0.x), bfloat_unpack(n0.x >> 16), bfloat_unpack(n0.y));
@@ -290,6 +291,7 @@ LUM_DEV float mis_for_light_sample(const GeoContext& g, V3 L, const TriLight& t,
 struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum; };
 
 LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp) {
+  LUM_STAT(14, 15);
   const TreeWork work = tree_prepass(sc, g, smp);
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));
   LightSample out;
@@ -302,6 +304,7 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
 #endif
 #pragma nounroll
   for (uint32_t lane = 0; lane < LUM_ABLATE_LANES; lane++) {
+    LUM_STAT(8, 9);
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
     const uint2 handle = sc.light_tri_handles[pick.light_id];
@@ -312,6 +315,7 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     F2 uv;
     const float dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, g.position, ray, uv);
     if (dist == kFltMax) continue;
+    LUM_STAT(10, 11);
     Col lc = tri_light_color(sc, tl);
     bool is_refraction;
 #ifndef LUM_ABLATE_LIGHT_DEFINED_BELOW

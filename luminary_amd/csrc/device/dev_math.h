@@ -13,6 +13,16 @@
 
 #define LUM_DEV __device__ __forceinline__
 
+// Diagnostic build (-DLUM_PHASE_STATS, tools/phase_stats.py): how many lanes are active where. LUM_STAT(i, l) adds one to
+// g_phase[i] per wave-level execution and the number of active lanes to g_phase[l].
+#ifdef LUM_PHASE_STATS
+__device__ unsigned long long g_phase[16];
+#define LUM_STAT(k_iter, k_lanes) do { const unsigned long long act_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(act_)) { \
+  atomicAdd(&g_phase[k_iter], 1ull); atomicAdd(&g_phase[k_lanes], (unsigned long long) __popcll(act_)); } } while (0)
+#else
+#define LUM_STAT(k_iter, k_lanes) do {} while (0)
+#endif
+
 namespace lum {
 
 struct V3 { float x, y, z; };

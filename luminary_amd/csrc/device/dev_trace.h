@@ -44,7 +44,6 @@ struct RayStats { uint32_t nodes, tris, lds_nodes; };
 //   0 node-phase iterations   1 instance-entry iterations   2 lanes entering   3 triangle-phase iterations   4 lanes in them
 //   5 outer iterations (refill checks)   6 pop iterations   7 lanes popping
 #ifdef LUM_PHASE_STATS
-__device__ unsigned long long g_phase[8];
 #define LUM_PHASE(k) do { const unsigned long long act_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(act_)) phase_[k]++; } while (0)
 #define LUM_PHASE_LANES(k) do { phase_[k]++; } while (0)
 #else

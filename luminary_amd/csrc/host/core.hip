@@ -16,6 +16,8 @@
 #include "../../../include/lum_core.h"
 #include "../device/kernels.h"
 #include "../device/dev_output.h"
+#include "../device/dev_adaptive.h"
+#include <hipcub/hipcub.hpp>
 #include "bvh_build.h"
 
 using namespace lum;
@@ -48,6 +50,25 @@ struct LumContext {
   uint16_t* d_bluenoise_1d = nullptr;
   uint32_t* d_argb8 = nullptr;
   uint32_t argb8_pixels = 0;
+  // adaptive sampling (dev_adaptive.h)
+  struct Adaptive {
+    bool active = false;
+    LumAdaptiveParams params{};
+    uint32_t blocks_x = 0, blocks_y = 0, num_blocks = 0;
+    uint32_t stage_id = 0;
+    uint32_t executions[kAdaptiveStages + 1] = {0, 0, 0, 0, 0};
+    uint32_t* d_stage_counts = nullptr;
+    uint32_t* d_block_tasks = nullptr;
+    uint32_t* d_block_task_end = nullptr;
+    float* d_block_variance = nullptr;
+    float* d_partial = nullptr;   // chunk sums, then the total in the last element
+    void* d_scan_temp = nullptr;
+    size_t scan_temp_bytes = 0;
+    std::vector<uint32_t> task_end;  // host copy of d_block_task_end: passes are cut at block boundaries
+    float variance_total = 0.0f;
+  } adaptive;
+  float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
+  uint32_t frame_result_pixels = 0;
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
   // profiling
@@ -86,6 +107,13 @@ void free_scene(LumContext* ctx) {
   ctx->scene_allocs.clear();
   for (int i = 0; i < 4; i++) { if (ctx->d_luts[i]) (void) hipFree(ctx->d_luts[i]); ctx->d_luts[i] = nullptr; }
   ctx->has_scene = false;
+}
+
+void free_adaptive(LumContext* ctx) {
+  LumContext::Adaptive& a = ctx->adaptive;
+  void* bufs[] = {a.d_stage_counts, a.d_block_tasks, a.d_block_task_end, a.d_block_variance, a.d_partial, a.d_scan_temp};
+  for (void* b : bufs) if (b) (void) hipFree(b);
+  a = LumContext::Adaptive();
 }
 
 void free_work(LumContext* ctx) {
@@ -265,6 +293,8 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_bluenoise_1d) (void) hipFree(ctx->d_bluenoise_1d);
   if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
+  if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
+  free_adaptive(ctx);
   delete ctx;
 }
 
@@ -506,6 +536,7 @@ int lumc_set_pixels(LumContext* ctx, const uint32_t* pixels, uint32_t num_pixels
   if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_set_pixels: no scene"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   if (!pixels) num_pixels = ctx->scene.width * ctx->scene.height;
+  free_adaptive(ctx);
   if (ctx->d_pixels) { (void) hipFree(ctx->d_pixels); ctx->d_pixels = nullptr; }
   if (ctx->d_first_moment) { (void) hipFree(ctx->d_first_moment); ctx->d_first_moment = nullptr; }
   if (ctx->d_second_moment) { (void) hipFree(ctx->d_second_moment); ctx->d_second_moment = nullptr; }
@@ -527,6 +558,42 @@ int lumc_clear_accumulators(LumContext* ctx) {
   return 0;
 }
 
+// The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
+static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
+  const DeviceScene& sc = ctx->scene;
+  const uint32_t max_depth = sc.max_ray_depth;
+  const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
+  int cur = 0;
+  for (uint32_t depth = 0; depth <= max_depth; depth++) {
+    // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
+    const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
+    uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+      hipLaunchKernelGGL(k_trace, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
+    }
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+      hipLaunchKernelGGL(k_shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
+                         depth_const, ctx->d_counters);
+    }
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
+      hipLaunchKernelGGL(k_light_query, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
+    }
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
+      hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
+    }
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+      hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
+    }
+    cur ^= 1;
+  }
+  return 0;
+}
+
 int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, uint32_t samples_per_pass, float* d_fm, float* d_sm, void* stream_) {
   if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_render: no scene"; return 1; }
   if (ctx->num_pixels == 0) return 0;
@@ -543,7 +610,6 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
   if (ensure_work(ctx, (uint32_t) want)) return 1;
   const DeviceScene& sc = ctx->scene;
   const uint32_t max_depth = sc.max_ray_depth;
-  const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
 
   for (uint32_t done = 0; done < num_samples; done += samples_per_pass) {
     const uint32_t batch = std::min(samples_per_pass, num_samples - done);
@@ -554,34 +620,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
       Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
       hipLaunchKernelGGL(k_generate, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
     }
-    int cur = 0;
-    for (uint32_t depth = 0; depth <= max_depth; depth++) {
-      // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
-      const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
-      uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
-      {
-        Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-        hipLaunchKernelGGL(k_trace, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
-      }
-      {
-        Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-        hipLaunchKernelGGL(k_shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
-                           depth_const, ctx->d_counters);
-      }
-      {
-        Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
-        hipLaunchKernelGGL(k_light_query, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
-      }
-      {
-        Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
-        hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
-      }
-      {
-        Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
-        hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
-      }
-      cur ^= 1;
-    }
+    if (wavefront_depths(ctx, stream, N)) return 1;
     {
       Launch l(ctx, stream, LUMC_KERNEL_ACCUMULATE);
       hipLaunchKernelGGL(k_accumulate, dim3(grid_for(P)), dim3(kBlock), 0, stream, (const float4*) ctx->d_results, P, batch, d_fm, d_sm);
@@ -590,6 +629,224 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
   }
   return 0;
 }
+
+
+// ---- adaptive sampling ----
+namespace {
+
+AdaptiveView adaptive_view(const LumContext* ctx) {
+  const LumContext::Adaptive& a = ctx->adaptive;
+  AdaptiveView v;
+  v.stage_counts = a.d_stage_counts; v.block_task_end = a.d_block_task_end;
+  v.blocks_x = a.blocks_x; v.blocks_y = a.blocks_y; v.num_blocks = a.num_blocks;
+  for (uint32_t s = 0; s <= kAdaptiveStages; s++) v.executions[s] = a.executions[s];
+  v.stage_id = a.stage_id;
+  return v;
+}
+
+OutputParams tone_params(const LumOutputParams* p) {
+  OutputParams op;
+  std::memset(&op, 0, sizeof(op));
+  if (p) std::memcpy(&op, p, sizeof(op));
+  return op;
+}
+
+// adaptive_sampler_compute_next_stage (device_adaptive_sampler.c:105-215): rates of stage `stage_id + 1` from the variance measured so far
+int adaptive_build_stage(LumContext* ctx, hipStream_t stream) {
+  LumContext::Adaptive& a = ctx->adaptive;
+  const DeviceScene& sc = ctx->scene;
+  const uint32_t nb = a.num_blocks, chunks = (nb + kAdaptiveSumChunk - 1) / kAdaptiveSumChunk;
+  const AdaptiveView view = adaptive_view(ctx);
+  const OutputParams op = tone_params(&a.params.tone);
+  hipLaunchKernelGGL(k_adaptive_block_variance, dim3((nb * 16 + 255) / 256), dim3(256), 0, stream, view, op, sc.width, sc.height, a.params.exposure,
+                     (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment, a.d_block_variance);
+  hipLaunchKernelGGL(k_adaptive_sum_chunks, dim3((chunks + 63) / 64), dim3(64), 0, stream, (const float*) a.d_block_variance, nb, a.d_partial);
+  hipLaunchKernelGGL(k_adaptive_sum_total, dim3(1), dim3(1), 0, stream, (const float*) a.d_partial, chunks, a.d_partial + chunks);
+  hipLaunchKernelGGL(k_adaptive_stage_counts, dim3((nb + 255) / 256), dim3(256), 0, stream, (const float*) a.d_block_variance, (const float*) (a.d_partial + chunks), nb,
+                     a.stage_id, a.params.max_sampling_rate, a.params.avg_sampling_rate, a.d_stage_counts, a.d_block_tasks);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(a.d_scan_temp, a.scan_temp_bytes, a.d_block_tasks, a.d_block_task_end, (int) nb, stream));
+  a.task_end.resize(nb);
+  HIP_TRY(ctx, hipMemcpyAsync(a.task_end.data(), a.d_block_task_end, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipMemcpyAsync(&a.variance_total, a.d_partial + chunks, sizeof(float), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));
+  a.stage_id++;
+  return 0;
+}
+
+// One execution of stage >= 1, cut into passes of whole blocks (tasks_create_adaptive_sampling + the usual depth loop + accumulation).
+int adaptive_execute(LumContext* ctx, hipStream_t stream) {
+  LumContext::Adaptive& a = ctx->adaptive;
+  const DeviceScene& sc = ctx->scene;
+  const uint32_t nb = a.num_blocks;
+  const uint32_t kMaxTasksPerPass = 24u << 20;
+  const AdaptiveView view = adaptive_view(ctx);
+  uint32_t block = 0;
+  while (block < nb) {
+    AdaptivePass pass;
+    pass.block_begin = block;
+    pass.task_begin = block ? a.task_end[block - 1] : 0u;
+    // as many whole blocks as fit the pass (a single block has at most 16 * 256 tasks)
+    const uint32_t limit = pass.task_begin + kMaxTasksPerPass;
+    uint32_t end = (uint32_t) (std::upper_bound(a.task_end.begin() + block, a.task_end.end(), limit) - a.task_end.begin());
+    if (end == block) end = block + 1;
+    pass.block_end = end;
+    pass.task_end = a.task_end[end - 1];
+    const uint32_t N = pass.task_end - pass.task_begin;
+    if (ensure_work(ctx, N)) return 1;
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (sc.max_ray_depth + 2), stream));
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
+      hipLaunchKernelGGL(k_generate_adaptive, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, view, pass, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
+    }
+    if (wavefront_depths(ctx, stream, N)) return 1;
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_ACCUMULATE);
+      hipLaunchKernelGGL(k_accumulate_adaptive, dim3(grid_for((end - block) * 16)), dim3(kBlock), 0, stream, view, pass, sc.width, sc.height, (const float4*) ctx->d_results,
+                         ctx->d_first_moment, ctx->d_second_moment);
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    block = end;
+  }
+  a.executions[a.stage_id]++;
+  return 0;
+}
+
+}  // namespace
+
+int lumc_adaptive_begin(LumContext* ctx, const LumAdaptiveParams* params) {
+  if (!ctx || !params) { if (ctx) ctx->error = "lumc_adaptive_begin: null argument"; return 1; }
+  if (!ctx->has_scene || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height || ctx->num_pixels == 0) {
+    ctx->error = "lumc_adaptive_begin: needs a scene and the full-frame pixel set (lumc_set_pixels(ctx, NULL, 0))";
+    return 1;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  free_adaptive(ctx);
+  LumContext::Adaptive& a = ctx->adaptive;
+  a.params = *params;
+  // adaptive_sampler_setup, device_adaptive_sampler.c:40-58
+  a.params.max_sampling_rate = std::min(std::max(params->max_sampling_rate, 1u), kAdaptiveMaxRate);
+  a.params.avg_sampling_rate = std::min(std::max(params->avg_sampling_rate, 1u), a.params.max_sampling_rate);
+  a.params.update_interval = std::max(params->update_interval, 1u);
+  a.blocks_x = (ctx->scene.width + 3u) >> kAdaptiveBlockLog;
+  a.blocks_y = (ctx->scene.height + 3u) >> kAdaptiveBlockLog;
+  a.num_blocks = a.blocks_x * a.blocks_y;
+  const uint32_t nb = a.num_blocks, chunks = (nb + kAdaptiveSumChunk - 1) / kAdaptiveSumChunk;
+  HIP_TRY(ctx, hipMalloc((void**) &a.d_stage_counts, sizeof(uint32_t) * nb));
+  HIP_TRY(ctx, hipMalloc((void**) &a.d_block_tasks, sizeof(uint32_t) * nb));
+  HIP_TRY(ctx, hipMalloc((void**) &a.d_block_task_end, sizeof(uint32_t) * nb));
+  HIP_TRY(ctx, hipMalloc((void**) &a.d_block_variance, sizeof(float) * nb));
+  HIP_TRY(ctx, hipMalloc((void**) &a.d_partial, sizeof(float) * (chunks + 1)));
+  HIP_TRY(ctx, hipMemset(a.d_stage_counts, 0, sizeof(uint32_t) * nb));
+  HIP_TRY(ctx, hipMemset(a.d_block_variance, 0, sizeof(float) * nb));
+  HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(nullptr, a.scan_temp_bytes, a.d_block_tasks, a.d_block_task_end, (int) nb, (hipStream_t) 0));
+  HIP_TRY(ctx, hipMalloc(&a.d_scan_temp, std::max<size_t>(a.scan_temp_bytes, 16)));
+  a.active = true;
+  return lumc_clear_accumulators(ctx);
+}
+
+int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
+  if (!ctx || !ctx->adaptive.active) { if (ctx) ctx->error = "lumc_adaptive_render: call lumc_adaptive_begin first"; return 1; }
+  hipStream_t stream = (hipStream_t) stream_;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  LumContext::Adaptive& a = ctx->adaptive;
+  while (executions > 0) {
+    const uint32_t s = a.stage_id;
+    // stage s lasts update_interval << s executions (device_renderer.c:364-371); the last stage never ends
+    uint32_t run = executions;
+    if (s < kAdaptiveStages) {
+      const uint64_t due = (uint64_t) a.params.update_interval << s;
+      run = (uint32_t) std::min<uint64_t>(run, due > a.executions[s] ? due - a.executions[s] : 0);
+    }
+    if (s == 0) {
+      // one sample id for every pixel per execution: the uniform wavefront pass, several executions per pass
+      if (run && lumc_render(ctx, a.executions[0], run, std::min(run, 8u), nullptr, nullptr, stream_)) return 1;
+      a.executions[0] += run;
+    }
+    else {
+      for (uint32_t e = 0; e < run; e++)
+        if (adaptive_execute(ctx, stream)) return 1;
+    }
+    executions -= run;
+    if (s < kAdaptiveStages && a.executions[s] >= ((uint64_t) a.params.update_interval << s)) {
+      if (adaptive_build_stage(ctx, stream)) return 1;
+    }
+  }
+  return 0;
+}
+
+int lumc_adaptive_info(LumContext* ctx, LumAdaptiveInfo* out) {
+  if (!ctx || !out || !ctx->adaptive.active) { if (ctx) ctx->error = "lumc_adaptive_info: adaptive mode is not active"; return 1; }
+  const LumContext::Adaptive& a = ctx->adaptive;
+  out->stage_id = a.stage_id;
+  for (uint32_t s = 0; s <= kAdaptiveStages; s++) out->executions[s] = a.executions[s];
+  out->num_blocks = a.num_blocks; out->blocks_x = a.blocks_x; out->blocks_y = a.blocks_y;
+  out->tasks_per_execution = (a.stage_id == 0 || a.task_end.empty()) ? a.num_blocks * 16u : a.task_end.back();
+  out->variance_total = a.variance_total;
+  return 0;
+}
+
+int lumc_adaptive_download(LumContext* ctx, uint32_t* stage_counts, float* block_variance) {
+  if (!ctx || !ctx->adaptive.active) { if (ctx) ctx->error = "lumc_adaptive_download: adaptive mode is not active"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const LumContext::Adaptive& a = ctx->adaptive;
+  if (stage_counts) HIP_TRY(ctx, hipMemcpy(stage_counts, a.d_stage_counts, sizeof(uint32_t) * a.num_blocks, hipMemcpyDeviceToHost));
+  if (block_variance) HIP_TRY(ctx, hipMemcpy(block_variance, a.d_block_variance, sizeof(float) * a.num_blocks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_adaptive_end(LumContext* ctx) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  free_adaptive(ctx);
+  return 0;
+}
+
+int lumc_generate_result(LumContext* ctx, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const LumOutputParams* tone,
+                         float* d_result, void* stream_) {
+  if (!ctx || !ctx->has_scene || !ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height) {
+    if (ctx) ctx->error = "lumc_generate_result: needs the full-frame accumulators";
+    return 1;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t) stream_;
+  const uint32_t n = ctx->num_pixels;
+  if (!d_result) {
+    if (ctx->frame_result_pixels != n) {
+      if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
+      ctx->d_frame_result = nullptr; ctx->frame_result_pixels = 0;
+      HIP_TRY(ctx, hipMalloc((void**) &ctx->d_frame_result, sizeof(float) * 3 * (size_t) n));
+      ctx->frame_result_pixels = n;
+    }
+    d_result = ctx->d_frame_result;
+  }
+  AdaptiveView view;
+  std::memset(&view, 0, sizeof(view));
+  if (ctx->adaptive.active) view = adaptive_view(ctx);
+  else { view.blocks_x = (ctx->scene.width + 3u) >> kAdaptiveBlockLog; view.blocks_y = (ctx->scene.height + 3u) >> kAdaptiveBlockLog; view.num_blocks = view.blocks_x * view.blocks_y; }
+  if (!ctx->adaptive.active && uniform_samples == 0) { ctx->error = "lumc_generate_result: no samples"; return 1; }
+  ResultParams rp{ctx->scene.width, ctx->scene.height, mode, local_error_minimization, uniform_samples, exposure};
+  const OutputParams op = tone_params(tone);
+  {
+    Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
+    hipLaunchKernelGGL(k_generate_result, dim3(grid_for(n)), dim3(256), 0, stream, view, rp, op, (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment, d_result);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int lumc_generate_result_host(LumContext* ctx, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const LumOutputParams* tone,
+                              float* result) {
+  if (!ctx || !result) { if (ctx) ctx->error = "lumc_generate_result_host: null argument"; return 1; }
+  if (lumc_generate_result(ctx, mode, local_error_minimization, uniform_samples, exposure, tone, nullptr, nullptr)) return 1;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  HIP_TRY(ctx, hipMemcpy(result, ctx->d_frame_result, sizeof(float) * 3 * (size_t) ctx->num_pixels, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+const float* lumc_result_image(LumContext* ctx) { return ctx ? ctx->d_frame_result : nullptr; }
 
 int lumc_synchronize(LumContext* ctx) {
   if (!ctx) return 1;
@@ -751,9 +1008,9 @@ int lumc_pixel_query(LumContext* ctx, uint32_t x, uint32_t y, uint32_t sample_id
 }
 
 #ifdef LUM_PHASE_STATS
-extern "C" int lumc_debug_phase_stats(uint64_t out[8], int reset) {
-  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(lum::g_phase), sizeof(uint64_t) * 8) != hipSuccess) return 1;
-  if (reset) { const uint64_t zero[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(lum::g_phase), zero, sizeof(zero)) != hipSuccess) return 1; }
+extern "C" int lumc_debug_phase_stats(uint64_t out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(uint64_t) * 16) != hipSuccess) return 1;
+  if (reset) { const uint64_t zero[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero)) != hipSuccess) return 1; }
   return 0;
 }
 #endif

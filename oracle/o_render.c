@@ -20,6 +20,7 @@
 
 #include "o_trace.h"
 #include "o_output.h"
+#include "o_adaptive.h"
 
 enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
@@ -447,3 +448,75 @@ void oracle_generate_output(const OracleOutputParamsAbi* params, const float* fi
 float oracle_log2(float x) { return o_log2(x); }
 float oracle_exp2(float x) { return o_exp2(x); }
 float oracle_pow(float x, float y) { return o_pow(x, y); }
+
+/* ---- adaptive sampling (o_adaptive.h) ---- */
+int oracle_render_counts(
+  const OracleScene* s, const uint32_t* first_sample, const uint32_t* num_samples, int use_bvh, int threads, float* first_moment, float* second_moment,
+  uint64_t* counters) {
+  if (!s || !first_moment || !first_sample || !num_samples) return 1;
+  OTracer tr;
+  tracer_init(&tr, s, use_bvh);
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#endif
+  const uint32_t num_pixels = s->width * s->height;
+  uint64_t total[ORACLE_CNT_COUNT] = {0, 0, 0, 0};
+#pragma omp parallel
+  {
+    uint64_t cnt[ORACLE_CNT_COUNT] = {0, 0, 0, 0};
+#pragma omp for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t) num_pixels; i++) {
+      const uint32_t y = (uint32_t) i / s->width, x = (uint32_t) i - y * s->width;
+      for (uint32_t k = 0; k < num_samples[i]; k++) {
+        const uint32_t sample_id = first_sample[i] + k;
+        if (sample_id >= MAX_GLOBAL_SAMPLES) break;
+        const RGBF r = render_path(s, &tr, x, y, sample_id, cnt);
+        first_moment[i] += r.r;
+        first_moment[(size_t) num_pixels + i] += r.g;
+        first_moment[2 * (size_t) num_pixels + i] += r.b;
+        if (second_moment) second_moment[i] += c_luminance(c_mul(r, r));
+      }
+    }
+#pragma omp critical
+    for (int k = 0; k < ORACLE_CNT_COUNT; k++) total[k] += cnt[k];
+  }
+  if (counters) for (int k = 0; k < ORACLE_CNT_COUNT; k++) counters[k] += total[k];
+  tracer_free(&tr);
+  return 0;
+}
+
+static OAdaptive adaptive_view(uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t stage_id, const uint32_t* stage_counts) {
+  OAdaptive a;
+  a.stage_counts = stage_counts;
+  a.blocks_x = (width + 3u) >> 2; a.blocks_y = (height + 3u) >> 2;
+  for (int k = 0; k < 5; k++) a.executions[k] = executions ? executions[k] : 0u;
+  a.stage_id = stage_id;
+  return a;
+}
+
+void oracle_adaptive_build_stage(
+  uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, float exposure,
+  const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, uint32_t* stage_counts, float* block_variance, float* total) {
+  const OAdaptive a = adaptive_view(width, height, executions, current_stage, stage_counts);
+  const uint32_t nb = a.blocks_x * a.blocks_y;
+  float* bv = block_variance ? block_variance : (float*) malloc(sizeof(float) * nb);
+  oa_block_variance(&a, (const OracleOutputParams*) op, width, height, exposure, first_moment, second_moment, bv);
+  const float t = oa_variance_total(bv, nb);
+  if (total) *total = t;
+  oa_stage_counts(bv, t, nb, current_stage, max_rate, avg_rate, stage_counts);
+  if (!block_variance) free(bv);
+}
+
+void oracle_pixel_samples(uint32_t width, uint32_t height, const uint32_t executions[5], const uint32_t* stage_counts, uint32_t* out) {
+  const OAdaptive a = adaptive_view(width, height, executions, 0, stage_counts);
+  for (uint32_t y = 0; y < height; y++)
+    for (uint32_t x = 0; x < width; x++) out[x + y * width] = oa_pixel_samples(&a, stage_counts[oa_block_of(&a, x, y)]);
+}
+
+void oracle_generate_result(
+  uint32_t width, uint32_t height, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const uint32_t executions[5],
+  uint32_t stage_id, const uint32_t* stage_counts, const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, float* frame_result) {
+  const OAdaptive a = adaptive_view(width, height, executions, stage_id, stage_counts);
+  const OResultParams rp = {width, height, mode, local_error_minimization, uniform_samples, exposure};
+  oa_generate_result(&a, &rp, (const OracleOutputParams*) op, first_moment, second_moment, frame_result);
+}

@@ -105,6 +105,18 @@ typedef struct {
   float agx_slope, agx_power, agx_saturation;
 } OracleOutputParamsAbi;
 void oracle_generate_output(const OracleOutputParamsAbi* params, const float* first_moment, const uint16_t* bluenoise_1d, float* frame_output, uint32_t* argb8);
+/* Adaptive sampling (o_adaptive.h). Blocks are 4x4 pixels, row-major over ceil(width/4) x ceil(height/4); executions[s] = completed
+ * executions of stage s; stage_counts[block] holds count-1 of stages 1..4 in its four bytes. */
+int oracle_render_counts(
+  const OracleScene* scene, const uint32_t* first_sample, const uint32_t* num_samples, int use_bvh, int threads, float* first_moment,
+  float* second_moment, uint64_t* counters); /* per-pixel sample ranges over the whole frame, added like oracle_render */
+void oracle_adaptive_build_stage(
+  uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, float exposure,
+  const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, uint32_t* stage_counts, float* block_variance, float* total);
+void oracle_pixel_samples(uint32_t width, uint32_t height, const uint32_t executions[5], const uint32_t* stage_counts, uint32_t* out);
+void oracle_generate_result(
+  uint32_t width, uint32_t height, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const uint32_t executions[5],
+  uint32_t stage_id, const uint32_t* stage_counts, const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, float* frame_result);
 float oracle_log2(float x);
 float oracle_exp2(float x);
 float oracle_pow(float x, float y);

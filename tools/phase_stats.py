@@ -17,14 +17,15 @@ core = Core(0)
 core.upload(host.device_scene())
 core.set_pixels(None)
 lib = luminary_amd._lib()
-out = (C.c_uint64 * 8)()
+out = (C.c_uint64 * 16)()
 core.render(0, 8, samples_per_pass=8)
 lib.lumc_debug_phase_stats(out, 1)
 core.reset_counters()
 core.render(8, 8, samples_per_pass=8)
 lib.lumc_debug_phase_stats(out, 1)
 cnt = core.counters()
-node_it, inst_it, inst_l, tri_it, tri_l, outer, pop_it, pop_l = [int(x) for x in out]
+node_it, inst_it, inst_l, tri_it, tri_l, outer, pop_it, pop_l = [int(x) for x in out][:8]
+sh = [int(x) for x in out][8:]
 nodes = int(cnt[4] + cnt[6]); tris = int(cnt[5] + cnt[7]); rays = int(cnt[0] + cnt[1])
 print(label)
 print("rays %d  node visits %d  triangle tests %d" % (rays, nodes, tris))
@@ -34,3 +35,7 @@ print("instance entry: %10d wave iterations, lane occupancy %.3f" % (inst_it, in
 print("triangle phase: %10d wave iterations, lane occupancy %.3f, triangle slots used %.3f of 4" % (tri_it, tri_l / (64.0 * max(tri_it, 1)), tris / max(tri_l, 1)))
 print("outer iterations (refill checks): %d" % outer)
 print("per ray: %.2f node, %.2f instance, %.2f leaf visits" % (nodes / rays, inst_l / rays, tri_l / rays))
+print("shade: light sampling entered by %d waves, lane occupancy %.3f" % (sh[6], sh[7] / (64.0 * max(sh[6], 1))))
+print("shade: candidate loop %d wave iterations, occupancy %.3f; BSDF+MIS part %d wave iterations, occupancy %.3f (%.2f of 8 candidates per vertex)"
+      % (sh[0], sh[1] / (64.0 * max(sh[0], 1)), sh[2], sh[3] / (64.0 * max(sh[2], 1)), sh[3] / max(sh[7], 1)))
+print("shade: light-tree descent %d wave iterations, occupancy %.3f" % (sh[4], sh[5] / (64.0 * max(sh[4], 1))))
