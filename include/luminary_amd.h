@@ -373,6 +373,11 @@ LUMINARY_API LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, 
 /* Synchronous batch rendering of sample ids [first_sample, first_sample + num_samples) of `pixels` (NULL = all) on this process' GPU. */
 LUMINARY_API LuminaryResult luminary_ext_render_samples(
   LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples, uint32_t samples_per_pass);
+/* The reference's render loop, synchronous: `num_samples` more sample allocations of the whole frame. With
+ * settings.enable_adaptive_sampling an allocation is one execution of the adaptive sampler's current stage (rates per 4x4 block, stages
+ * built after adaptive_sampling_update_interval << stage allocations); otherwise one sample id per pixel. Outputs (recurring and
+ * requested) are produced through the result image: local error minimisation and adaptive_sampling_output_mode apply. */
+LUMINARY_API LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples);
 /* Planar float accumulators of the pixels given to luminary_ext_render_samples: first moment [R|G|B] and luminance second moment. */
 LUMINARY_API LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels);
 /* Radiance = first moment / sample_count for the full frame (rgb interleaved, width*height*3 floats). */

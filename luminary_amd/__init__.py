@@ -344,6 +344,10 @@ class Host:
             _call("luminary_ext_render_samples", self._h, px.ctypes.data_as(C.c_void_p), C.c_uint32(px.size), C.c_uint32(first_sample),
                   C.c_uint32(num_samples), C.c_uint32(samples_per_pass))
 
+    def render(self, num_samples):
+        """The reference's render loop for `num_samples` more sample allocations (adaptive sampling per the renderer settings)."""
+        _call("luminary_ext_render", self._h, C.c_uint32(num_samples))
+
     def accumulators(self):
         import numpy as np
         n = C.c_uint32()

@@ -35,7 +35,8 @@ struct LuminaryHost {
   std::vector<uint32_t> pixels;  // pixel set of the current accumulation
   bool pixels_all = true;
   uint32_t num_pixels = 0;
-  uint32_t accumulated_samples = 0;
+  uint32_t accumulated_samples = 0;  // uniform rendering: samples per pixel; adaptive rendering: executions (the reference's sample count)
+  bool adaptive_active = false;      // the accumulation is driven by lumc_adaptive_* (luminary_ext_render with adaptive sampling enabled)
   lum::OutputStore outputs;
   double render_seconds = 0.0;
   std::vector<std::string> log;
@@ -51,7 +52,7 @@ std::vector<uint32_t> embedded_bluenoise() {
   return v;
 }
 
-void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; }
+void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false; }
 
 #define CHECK_NULL(p) do { if (!(p)) return LUMINARY_ERROR_ARGUMENT_NULL; } while (0)
 
@@ -427,12 +428,24 @@ LumOutputParams output_params(const LuminaryHost* h, uint32_t dst_width, uint32_
   p.exposure = std::exp(c.exposure);
   p.tonemap = (uint32_t) c.tonemap; p.filter = (uint32_t) c.filter; p.dithering = c.dithering ? 1u : 0u; p.purkinje = c.purkinje ? 1u : 0u;
   p.use_color_correction = c.use_color_correction ? 1u : 0u;
-  p.passthrough = (h->scene.settings.shading_mode != LUMINARY_SHADING_MODE_DEFAULT) ? 1u : 0u;
+  // tonemap_apply leaves the pixel alone for debug shading modes and for the adaptive-sampling diagnostic images (tonemap.cuh:206-211)
+  p.passthrough = (h->scene.settings.shading_mode != LUMINARY_SHADING_MODE_DEFAULT ||
+                   h->scene.settings.adaptive_sampling_output_mode != LUMINARY_ADAPTIVE_SAMPLING_OUTPUT_MODE_BEAUTY) ? 1u : 0u;
   p.purkinje_kappa1 = c.purkinje_kappa1; p.purkinje_kappa2 = c.purkinje_kappa2;
   p.cc_h = c.color_correction.r; p.cc_s = c.color_correction.g; p.cc_v = c.color_correction.b;
   p.film_grain = c.film_grain;
   p.agx_slope = c.agx_custom_slope; p.agx_power = c.agx_custom_power; p.agx_saturation = c.agx_custom_saturation;
   return p;
+}
+
+// accumulation_generate_result (accumulation.cuh:86-200) into the core's result image; the output chain then reads that image with a
+// sample count of one. Returns the parameters to hand to lumc_generate_output*.
+int result_image(LuminaryHost* h, LumOutputParams* p) {
+  const uint32_t mode = (uint32_t) h->scene.settings.adaptive_sampling_output_mode;
+  const uint32_t lem = h->scene.camera.use_local_error_minimization ? 1u : 0u;
+  if (lumc_generate_result(h->core, mode, lem, h->adaptive_active ? 0u : h->accumulated_samples, p->exposure, p, nullptr, nullptr)) return 1;
+  p->inv_sample_count = 1.0f;
+  return 0;
 }
 
 // device_output_generate_output, device_output.c:203-270: the recurring output if enabled, then every request that is due now
@@ -445,8 +458,11 @@ LuminaryResult produce_outputs(LuminaryHost* h) {
   if (props.enabled && props.width >= 2 && props.height >= 2) {
     meta.width = props.width; meta.height = props.height;
     const uint32_t handle = h->outputs.begin_recurring(meta);
-    const LumOutputParams p = output_params(h, meta.width, meta.height);
-    if (lumc_generate_output_host(h->core, &p, nullptr, h->outputs.data(handle), nullptr)) { h->outputs.publish(handle); return LUMINARY_ERROR_CUDA; }
+    LumOutputParams p = output_params(h, meta.width, meta.height);
+    if (result_image(h, &p) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr)) {
+      h->outputs.publish(handle);
+      return LUMINARY_ERROR_CUDA;
+    }
     h->outputs.publish(handle);
   }
   for (const LuminaryOutputRequestProperties& req : h->outputs.pending_requests()) {
@@ -454,8 +470,8 @@ LuminaryResult produce_outputs(LuminaryHost* h) {
     meta.width = req.width; meta.height = req.height;
     uint32_t handle;
     if (h->outputs.begin_for_request(meta, &handle)) continue;
-    const LumOutputParams p = output_params(h, meta.width, meta.height);
-    const int rc = lumc_generate_output_host(h->core, &p, nullptr, h->outputs.data(handle), nullptr);
+    LumOutputParams p = output_params(h, meta.width, meta.height);
+    const int rc = result_image(h, &p) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr);
     h->outputs.publish(handle);
     if (rc) return LUMINARY_ERROR_CUDA;
   }
@@ -472,8 +488,10 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
   const bool all = pixels == nullptr;
   bool same = (host->num_pixels != 0) && (all == host->pixels_all);
   if (same && !all) same = (host->pixels.size() == num_pixels) && std::memcmp(host->pixels.data(), pixels, sizeof(uint32_t) * num_pixels) == 0;
+  if (host->adaptive_active) same = false;  // leaving adaptive mode restarts the accumulation
   if (!same) {
     if (lumc_set_pixels(host->core, pixels, num_pixels)) return LUMINARY_ERROR_CUDA;
+    host->adaptive_active = false;
     host->pixels_all = all;
     if (!all) host->pixels.assign(pixels, pixels + num_pixels);
     host->num_pixels = all ? host->device_scene.view.width * host->device_scene.view.height : num_pixels;
@@ -497,6 +515,49 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
   }
   return LUMINARY_SUCCESS;
 }
+// The reference's render loop for `num_samples` more sample allocations of the whole frame (device_renderer.c:488-575): with
+// settings.enable_adaptive_sampling the stage schedule of the adaptive sampler, otherwise one sample id per pixel and allocation.
+LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
+  CHECK_NULL(host);
+  const LuminaryRendererSettings settings = host->scene.settings;
+  if (!settings.enable_adaptive_sampling) return luminary_ext_render_samples(host, nullptr, 0, host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0, num_samples, 8);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  LuminaryResult r = ensure_core(host);
+  if (r) return r;
+  if (!host->adaptive_active) {
+    if (lumc_set_pixels(host->core, nullptr, 0)) return LUMINARY_ERROR_CUDA;
+    host->pixels_all = true;
+    host->num_pixels = host->device_scene.view.width * host->device_scene.view.height;
+    host->accumulated_samples = 0;
+    host->render_seconds = 0.0;
+    LumAdaptiveParams ap;
+    std::memset(&ap, 0, sizeof(ap));
+    ap.max_sampling_rate = settings.adaptive_sampling_max_sampling_rate;
+    ap.avg_sampling_rate = settings.adaptive_sampling_avg_sampling_rate;
+    ap.update_interval = settings.adaptive_sampling_update_interval;
+    ap.tone = output_params(host, host->device_scene.view.width, host->device_scene.view.height);
+    ap.exposure = settings.adaptive_sampling_exposure_aware ? ap.tone.exposure : 0.0f;
+    if (lumc_adaptive_begin(host->core, &ap)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+    host->adaptive_active = true;
+  }
+  uint32_t done = 0;
+  while (done < num_samples) {
+    uint32_t chunk = num_samples - done;
+    for (const LuminaryOutputRequestProperties& req : host->outputs.pending_requests())
+      if (req.sample_count > host->accumulated_samples && req.sample_count - host->accumulated_samples < chunk) chunk = req.sample_count - host->accumulated_samples;
+    const auto t0 = std::chrono::steady_clock::now();
+    if (lumc_adaptive_render(host->core, chunk, nullptr) || lumc_synchronize(host->core)) {
+      std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core));
+      return LUMINARY_ERROR_CUDA;
+    }
+    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    host->accumulated_samples += chunk;
+    done += chunk;
+    r = produce_outputs(host);
+    if (r) return r;
+  }
+  return LUMINARY_SUCCESS;
+}
 LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels) {
   CHECK_NULL(host);
   std::lock_guard<std::mutex> lock(host->mutex);
@@ -511,6 +572,14 @@ LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_
   if (!host->core || !host->pixels_all || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
   const LumDeviceSceneView& v = host->device_scene.view;
   if (width != v.width || height != v.height) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  if (host->adaptive_active) {  // every pixel has its own sample count: the beauty result image is the radiance
+    std::vector<float> planes(3 * (size_t) host->num_pixels);
+    if (lumc_generate_result_host(host->core, 0, 0, 0, 1.0f, nullptr, planes.data())) return LUMINARY_ERROR_CUDA;
+    for (size_t p = 0; p < host->num_pixels; p++)
+      for (int c = 0; c < 3; c++) rgb[3 * p + c] = planes[(size_t) c * host->num_pixels + p];
+    if (sample_count) *sample_count = host->accumulated_samples;
+    return LUMINARY_SUCCESS;
+  }
   std::vector<float> fm(3 * (size_t) host->num_pixels);
   if (lumc_download_accumulators(host->core, fm.data(), nullptr)) return LUMINARY_ERROR_CUDA;
   const float norm = host->accumulated_samples ? 1.0f / host->accumulated_samples : 0.0f;  // accumulation.cuh:149-153

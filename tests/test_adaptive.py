@@ -118,3 +118,38 @@ def test_result_image_without_adaptive_sampling(tmp_path_factory):
             assert np.array_equal(got, want), mode
     finally:
         core.close()
+
+
+@pytest.mark.gpu
+def test_adaptive_rendering_through_the_api(tmp_path):
+    """luminary_ext_render with the renderer settings' adaptive sampling: the requested output equals the oracle's adaptive run pushed
+    through the oracle's result image and output chain; the settings' diagnostic output mode is honoured."""
+    host = scenes.cornell_host(str(tmp_path), W, H, BOUNCES)
+    s = host.get_settings()
+    s.enable_adaptive_sampling = True
+    s.adaptive_sampling_max_sampling_rate, s.adaptive_sampling_avg_sampling_rate, s.adaptive_sampling_update_interval = MAX_RATE, AVG_RATE, INTERVAL
+    s.adaptive_sampling_exposure_aware = True
+    host.set_settings(s)
+    cam = host.get_camera()
+    cam.exposure = 0.25
+    cam.use_local_error_minimization = True
+    host.set_camera(cam)
+    view = oracle_lib.with_luts(host.device_scene())
+    promise = host.request_output(7, W, H)   # 2 + 4 + 1 executions: one execution into stage 2
+    host.render(9)
+    handle = host.try_await_output(promise)
+    assert handle is not None
+    img, count, _ = host.get_image(handle)
+    assert count == 7
+
+    exposure = float(np.exp(np.float32(0.25)))
+    tone = default_output_params(W, H, 1)
+    tone.exposure = exposure
+    o = oracle_lib.AdaptiveOracle(view, MAX_RATE, AVG_RATE, INTERVAL, exposure=exposure, tone=tone)
+    o.render(7)
+    want, _ = oracle_lib.generate_output(tone, o.result(mode=0, local_error_minimization=True, exposure=exposure, tone=tone).reshape(3, -1))
+    assert np.array_equal(img, want)
+    fm, sm = host.accumulators()
+    o.render(2)
+    assert np.array_equal(fm, o.fm.reshape(3, -1)) and np.array_equal(sm, o.sm)
+    host.release_output(handle)
