@@ -125,7 +125,10 @@ __global__ __launch_bounds__(256) void k_adaptive_stage_counts(const float* __re
 // tasks_create_adaptive_sampling (cuda/kernels.cuh:195-355): task -> (block, pixel of the block, sample of this execution).
 // Result slot = task id; paths are appended compacted (tasks outside the frame or beyond the last sample id create nothing).
 // One pass covers the tasks [task_begin, task_end) = all tasks of the blocks [block_begin, block_end); slots are relative to task_begin.
-struct AdaptivePass { uint32_t task_begin, task_end, block_begin, block_end; };
+// `executions` consecutive executions of the stage share the pass: a pixel then takes executions * rate consecutive sample ids, which
+// are added in the same order as one execution after the other would add them. Task numbers are in units of the merged pass
+// (block_task_end * executions).
+struct AdaptivePass { uint32_t task_begin, task_end, block_begin, block_end, executions; };
 
 __global__ __launch_bounds__(256) void k_generate_adaptive(DeviceScene sc, AdaptiveView a, AdaptivePass pass, PathQueue q, float4* results, uint32_t* count) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -142,12 +145,12 @@ __global__ __launch_bounds__(256) void k_generate_adaptive(DeviceScene sc, Adapt
       uint32_t lo = pass.block_begin, hi = pass.block_end - 1u;
       while (lo < hi) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (t < a.block_task_end[mid]) hi = mid; else lo = mid + 1u;
+        if (t < a.block_task_end[mid] * pass.executions) hi = mid; else lo = mid + 1u;
       }
       const uint32_t block = lo;
-      const uint32_t base = block ? a.block_task_end[block - 1u] : 0u;
+      const uint32_t base = block ? a.block_task_end[block - 1u] * pass.executions : 0u;
       const uint32_t packed = a.stage_counts[block];
-      const uint32_t per_pixel = adaptive_stage_count(packed, a.stage_id);
+      const uint32_t per_pixel = adaptive_stage_count(packed, a.stage_id) * pass.executions;
       const uint32_t local = t - base;
       const uint32_t local_pixel = local / per_pixel, local_sample = local - local_pixel * per_pixel;
       const uint32_t by = block / a.blocks_x, bx = block - by * a.blocks_x;
@@ -189,9 +192,9 @@ __global__ __launch_bounds__(256) void k_accumulate_adaptive(AdaptiveView a, Ada
     if (x >= width || y >= height) continue;
     const uint32_t p = x + y * width;
     const uint32_t packed = a.stage_counts[block];
-    const uint32_t per_pixel = adaptive_stage_count(packed, a.stage_id);
+    const uint32_t per_pixel = adaptive_stage_count(packed, a.stage_id) * pass.executions;
     const uint32_t first_id = adaptive_pixel_samples(a, packed);
-    const uint32_t base = (block ? a.block_task_end[block - 1u] : 0u) - pass.task_begin + local * per_pixel;
+    const uint32_t base = (block ? a.block_task_end[block - 1u] * pass.executions : 0u) - pass.task_begin + local * per_pixel;
     float r = first_moment[p], g = first_moment[num_pixels + p], b = first_moment[2 * num_pixels + p];
     float s = second_moment[p];
     for (uint32_t k = 0; k < per_pixel; k++) {

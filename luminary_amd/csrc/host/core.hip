@@ -674,24 +674,27 @@ int adaptive_build_stage(LumContext* ctx, hipStream_t stream) {
   return 0;
 }
 
-// One execution of stage >= 1, cut into passes of whole blocks (tasks_create_adaptive_sampling + the usual depth loop + accumulation).
-int adaptive_execute(LumContext* ctx, hipStream_t stream) {
+// `merged` consecutive executions of stage >= 1 as one set of passes of whole blocks (tasks_create_adaptive_sampling + the usual depth
+// loop + accumulation). Merging keeps the passes large enough to fill the GPU when the rates are low.
+constexpr uint32_t kAdaptiveTasksPerPass = 16u << 20;
+
+int adaptive_execute(LumContext* ctx, hipStream_t stream, uint32_t merged) {
   LumContext::Adaptive& a = ctx->adaptive;
   const DeviceScene& sc = ctx->scene;
   const uint32_t nb = a.num_blocks;
-  const uint32_t kMaxTasksPerPass = 24u << 20;
   const AdaptiveView view = adaptive_view(ctx);
   uint32_t block = 0;
   while (block < nb) {
     AdaptivePass pass;
+    pass.executions = merged;
     pass.block_begin = block;
-    pass.task_begin = block ? a.task_end[block - 1] : 0u;
-    // as many whole blocks as fit the pass (a single block has at most 16 * 256 tasks)
-    const uint32_t limit = pass.task_begin + kMaxTasksPerPass;
+    pass.task_begin = (block ? a.task_end[block - 1] : 0u) * merged;
+    // as many whole blocks as fit the pass (a single block has at most 16 * 256 tasks per execution)
+    const uint32_t limit = (pass.task_begin + kAdaptiveTasksPerPass) / merged;
     uint32_t end = (uint32_t) (std::upper_bound(a.task_end.begin() + block, a.task_end.end(), limit) - a.task_end.begin());
     if (end == block) end = block + 1;
     pass.block_end = end;
-    pass.task_end = a.task_end[end - 1];
+    pass.task_end = a.task_end[end - 1] * merged;
     const uint32_t N = pass.task_end - pass.task_begin;
     if (ensure_work(ctx, N)) return 1;
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (sc.max_ray_depth + 2), stream));
@@ -708,7 +711,7 @@ int adaptive_execute(LumContext* ctx, hipStream_t stream) {
     HIP_TRY(ctx, hipGetLastError());
     block = end;
   }
-  a.executions[a.stage_id]++;
+  a.executions[a.stage_id] += merged;
   return 0;
 }
 
@@ -764,8 +767,14 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
       a.executions[0] += run;
     }
     else {
-      for (uint32_t e = 0; e < run; e++)
-        if (adaptive_execute(ctx, stream)) return 1;
+      // merge executions while a merged pass stays within the usual pass size
+      const uint32_t per_execution = std::max(a.task_end.empty() ? 1u : a.task_end.back(), 1u);
+      const uint32_t merge_max = std::max(1u, std::min(kAdaptiveTasksPerPass / per_execution, 64u));
+      for (uint32_t e = 0; e < run;) {
+        const uint32_t merged = std::min(merge_max, run - e);
+        if (adaptive_execute(ctx, stream, merged)) return 1;
+        e += merged;
+      }
     }
     executions -= run;
     if (s < kAdaptiveStages && a.executions[s] >= ((uint64_t) a.params.update_interval << s)) {
