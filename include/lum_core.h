@@ -171,6 +171,14 @@ int lumc_pixel_query(LumContext* ctx, uint32_t x, uint32_t y, uint32_t sample_id
 /* Same with host buffers (copies in and out); used by the parity tests. */
 int lumc_trace_closest_host(LumContext* ctx, uint32_t num_rays, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out);
 
+/* Builder of the per-mesh BVHs at the next lumc_scene_upload: 0 = binned SAH on the host (default: best trees), 1 = LBVH on the GPU
+ * (Morton order + Karras hierarchy, lbvh.hip: fastest build, for scene edits and very large meshes). Images do not depend on it.
+ * An environment variable LUM_BVH_BUILDER=lbvh selects 1 for new contexts. */
+int lumc_set_bvh_builder(LumContext* ctx, int builder);
+/* Seconds the per-mesh builds of the last lumc_scene_upload took (host wall clock, transfers included). */
+double lumc_bvh_build_seconds(const LumContext* ctx);
+/* Meshes of the last upload built by the SAH builder (out[0]; includes LBVH trees that came out too deep) and by LBVH (out[1]). */
+int lumc_bvh_meshes_by_builder(const LumContext* ctx, uint32_t out[2]);
 /* Sizes of the acceleration structures built by lumc_scene_upload: out[0] BLAS nodes, [1] BLAS triangles, [2] TLAS nodes, [3] light nodes. */
 int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]);
 uint32_t lumc_scene_view_sizeof(void);

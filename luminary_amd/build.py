@@ -17,7 +17,7 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp", "host/utils_api.cpp", "host/output.cpp"]
-HIP_SOURCES = ["host/core.hip"]
+HIP_SOURCES = ["host/core.hip", "host/lbvh.hip"]
 EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 
@@ -63,7 +63,7 @@ def build(force=False, verbose=False):
     for s in HIP_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
         out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
-        with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w") as f:
+        with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w" if s == HIP_SOURCES[0] else "a") as f:
             f.write(out)
         if verbose:
             print(out)

@@ -182,6 +182,20 @@ class Core:
                    C.c_float(exposure), tp, out.ctypes.data_as(C.c_void_p))
         return out
 
+    def set_bvh_builder(self, name):
+        """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
+        self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1}[name]))
+
+    def bvh_build_seconds(self):
+        fn = self._lib.lumc_bvh_build_seconds
+        fn.restype = C.c_double
+        return float(fn(self._ctx))
+
+    def bvh_meshes_by_builder(self):
+        out = (C.c_uint32 * 2)()
+        self._call("lumc_bvh_meshes_by_builder", out)
+        return {"sah": int(out[0]), "lbvh": int(out[1])}
+
     def bvh_stats(self):
         out = (C.c_uint64 * 4)()
         self._call("lumc_bvh_stats", out)

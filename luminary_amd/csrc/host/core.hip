@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -29,6 +30,9 @@ struct LumContext {
   DeviceScene scene{};
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
+  int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU (lumc_set_bvh_builder)
+  double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
+  uint32_t bvh_meshes_by_builder[2] = {0, 0};  // meshes of the last upload built by SAH / by LBVH
   uint32_t lds_nodes = 0;         // nodes of the tree top every ray-kernel workgroup stages in LDS
   uint32_t trace_blocks = 256;    // persistent grid of the ray kernels
   // LUTs owned by the context when generated here
@@ -266,6 +270,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   *out = nullptr;
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
+  if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : 0;
   *out = ctx;
   int count = 0;
   HIP_TRY(ctx, hipGetDeviceCount(&count));
@@ -373,12 +378,19 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     sc.tlas_num_nodes = (uint32_t) tlas.nodes.size();
     ctx->bvh_stats[2] = tlas.nodes.size();
   }
+  ctx->bvh_build_seconds = 0.0;
+  ctx->bvh_meshes_by_builder[0] = ctx->bvh_meshes_by_builder[1] = 0;
   std::vector<BvhTri> blas_tris((size_t) total_tris + 1);
   std::memset(blas_tris.data(), 0, sizeof(BvhTri) * blas_tris.size());
   std::vector<uint32_t> mesh_root(v->num_meshes + 1, 0);
   for (uint32_t m = 0; m < v->num_meshes; m++) {
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
-    Bvh4 bvh = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+    const auto t_build = std::chrono::steady_clock::now();
+    Bvh4 bvh;
+    if (ctx->bvh_builder == 1) bvh = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+    if (!bvh.nodes.empty()) ctx->bvh_meshes_by_builder[1]++;
+    else { bvh = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26); ctx->bvh_meshes_by_builder[0]++; }  // default, and fallback for too deep LBVH trees
+    ctx->bvh_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
     if (bvh.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
     const uint32_t base = (uint32_t) nodes.size();
     mesh_root[m] = base;
@@ -1023,6 +1035,18 @@ extern "C" int lumc_debug_phase_stats(uint64_t out[16], int reset) {
   return 0;
 }
 #endif
+
+int lumc_set_bvh_builder(LumContext* ctx, int builder) {
+  if (!ctx || builder < 0 || builder > 1) { if (ctx) ctx->error = "lumc_set_bvh_builder: 0 (SAH, host) or 1 (LBVH, GPU)"; return 1; }
+  ctx->bvh_builder = builder;
+  return 0;
+}
+double lumc_bvh_build_seconds(const LumContext* ctx) { return ctx ? ctx->bvh_build_seconds : 0.0; }
+int lumc_bvh_meshes_by_builder(const LumContext* ctx, uint32_t out[2]) {
+  if (!ctx || !out) return 1;
+  out[0] = ctx->bvh_meshes_by_builder[0]; out[1] = ctx->bvh_meshes_by_builder[1];
+  return 0;
+}
 
 int lumc_bvh_stats(LumContext* ctx, uint64_t out[4]) {
   if (!ctx) return 1;

@@ -1,0 +1,265 @@
+// GPU LBVH builder: Morton-ordered binary radix tree (Karras, "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d
+// Trees", HPG 2012) collapsed into the 128-byte 4-wide nodes the ray kernels walk.
+// It replaces what the reference gets from optixAccelBuild (src/luminary/device/optix_bvh.c:150-684) when build time matters more than
+// tree quality (scene edits, very large meshes): the binned-SAH host builder (bvh_build.cpp) stays the default because its trees trace
+// faster. Any valid tree gives the same image: hits are resolved by (t, instance, triangle), never by traversal order.
+//
+//   1. k_lbvh_codes       63-bit Morton code of every primitive's box centre inside the mesh bounds
+//   2. hipcub radix sort  (code, primitive) pairs
+//   3. k_lbvh_hierarchy   one thread per internal node: its key range and split from longest common prefixes (ties: index bits)
+//   4. k_lbvh_fit         leaves walk up, the second arrival at a node merges the child boxes
+//   5. k_lbvh_collapse    breadth-first, one thread per 4-wide node: expands the binary children by surface area until four, subtrees
+//                         of at most `max_leaf` primitives become leaves (their primitives are consecutive in Morton order)
+// The result comes back to the host in the same form as the SAH builder's (nodes in breadth-first order, primitive order), so the
+// scene assembly in core.hip does not care which builder ran.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cfloat>
+#include <cstring>
+
+#include "bvh_build.h"
+
+namespace lum {
+namespace {
+
+struct BinBox { float lo[3], hi[3]; };
+
+__device__ __forceinline__ uint64_t expand21(uint32_t v) {  // 21 bits -> every third bit of 63
+  uint64_t x = v & 0x1FFFFFull;
+  x = (x | (x << 32)) & 0x1F00000000FFFFull;
+  x = (x | (x << 16)) & 0x1F0000FF0000FFull;
+  x = (x | (x << 8)) & 0x100F00F00F00F00Full;
+  x = (x | (x << 4)) & 0x10C30C30C30C30C3ull;
+  x = (x | (x << 2)) & 0x1249249249249249ull;
+  return x;
+}
+
+__global__ void k_lbvh_codes(const BinBox* __restrict__ boxes, uint32_t n, BinBox bounds, uint64_t* __restrict__ codes, uint32_t* __restrict__ ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t q[3];
+  for (int a = 0; a < 3; a++) {
+    const float ext = bounds.hi[a] - bounds.lo[a];
+    const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+    float u = (ext > 0.0f) ? (c - bounds.lo[a]) / ext : 0.0f;
+    u = fminf(fmaxf(u, 0.0f), 1.0f);
+    q[a] = min((uint32_t) (u * 2097152.0f), 2097151u);
+  }
+  codes[i] = (expand21(q[0]) << 2) | (expand21(q[1]) << 1) | expand21(q[2]);
+  ids[i] = i;
+}
+
+// Length of the common prefix of keys i and j; equal codes fall back to the index bits, out-of-range j gives -1.
+__device__ __forceinline__ int lcp(const uint64_t* __restrict__ codes, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint64_t a = codes[i], b = codes[j];
+  if (a != b) return __clzll((long long) (a ^ b));
+  return 64 + __clz(i ^ j);
+}
+
+// Binary nodes: internal node i in [0, n-1), leaf k is node (n - 1) + k. Node 0 is the root.
+__global__ void k_lbvh_hierarchy(const uint64_t* __restrict__ codes, int n, int2* __restrict__ children, int2* __restrict__ ranges, int* __restrict__ parent) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (lcp(codes, n, i, i + 1) - lcp(codes, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int delta_min = lcp(codes, n, i, i - d);
+  int lmax = 2;
+  while (lcp(codes, n, i, i + lmax * d) > delta_min) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (lcp(codes, n, i, i + (l + t) * d) > delta_min) l += t;
+  const int j = i + l * d;
+  const int delta_node = lcp(codes, n, i, j);
+  int s = 0, t = l;
+  do {
+    t = (t + 1) >> 1;
+    if (lcp(codes, n, i, i + (s + t) * d) > delta_node) s += t;
+  } while (t > 1);
+  const int gamma = i + s * d + min(d, 0);
+  const int first = min(i, j), last = max(i, j);
+  const int left = (first == gamma) ? (n - 1) + gamma : gamma;
+  const int right = (last == gamma + 1) ? (n - 1) + gamma + 1 : gamma + 1;
+  children[i] = make_int2(left, right);
+  ranges[i] = make_int2(first, last);
+  parent[left] = i;
+  parent[right] = i;
+  if (i == 0) parent[0] = -1;
+}
+
+__global__ void k_lbvh_fit(const BinBox* __restrict__ boxes, const uint32_t* __restrict__ ids, int n, const int2* __restrict__ children, const int* __restrict__ parent,
+                           BinBox* __restrict__ node_box, uint32_t* __restrict__ arrivals) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  node_box[(n - 1) + k] = boxes[ids[k]];
+  __threadfence();
+  int node = parent[(n - 1) + k];
+  while (node >= 0) {
+    if (atomicAdd(&arrivals[node], 1u) == 0u) return;  // the sibling subtree is not finished yet: its last thread continues
+    __threadfence();
+    const int2 c = children[node];
+    // the other child's box was written by another thread: read it past the caches of this CU
+    BinBox a, b;
+    for (int x = 0; x < 3; x++) {
+      a.lo[x] = __builtin_nontemporal_load(&node_box[c.x].lo[x]); a.hi[x] = __builtin_nontemporal_load(&node_box[c.x].hi[x]);
+      b.lo[x] = __builtin_nontemporal_load(&node_box[c.y].lo[x]); b.hi[x] = __builtin_nontemporal_load(&node_box[c.y].hi[x]);
+    }
+    BinBox m;
+    for (int x = 0; x < 3; x++) { m.lo[x] = fminf(a.lo[x], b.lo[x]); m.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    node_box[node] = m;
+    __threadfence();
+    node = parent[node];
+  }
+}
+
+__device__ __forceinline__ float half_area(const BinBox& b) {
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+struct CollapseItem { int bin; uint32_t node4; };
+
+// One 4-wide node per queue entry. Children that stay inner nodes get consecutive new indices and go to the next level's queue.
+__global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const int2* __restrict__ ranges, const BinBox* __restrict__ node_box, uint32_t max_leaf,
+                                const CollapseItem* __restrict__ in, uint32_t in_count, CollapseItem* __restrict__ out, uint32_t* __restrict__ out_count,
+                                uint32_t* __restrict__ node_count, Bvh4Node* __restrict__ nodes) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= in_count) return;
+  const CollapseItem item = in[q];
+  auto prim_count = [&](int b) -> uint32_t { return (b >= n - 1) ? 1u : (uint32_t) (ranges[b].y - ranges[b].x + 1); };
+  auto is_leaf = [&](int b) -> bool { return prim_count(b) <= max_leaf; };
+  int kids[4];
+  int nk = 0;
+  if (is_leaf(item.bin)) kids[nk++] = item.bin;  // whole mesh fits one leaf: root with a single leaf child
+  else { const int2 c = children[item.bin]; kids[nk++] = c.x; kids[nk++] = c.y; }
+  while (nk < 4) {
+    int pick = -1;
+    float best = -1.0f;
+    for (int k = 0; k < nk; k++) {
+      if (is_leaf(kids[k])) continue;
+      const float a = half_area(node_box[kids[k]]);
+      if (a > best) { best = a; pick = k; }
+    }
+    if (pick < 0) break;
+    const int2 c = children[kids[pick]];
+    kids[pick] = c.x;
+    kids[nk++] = c.y;
+  }
+  uint32_t inner = 0;
+  for (int k = 0; k < nk; k++) inner += is_leaf(kids[k]) ? 0u : 1u;
+  uint32_t first_new = 0, first_slot = 0;
+  if (inner) { first_new = atomicAdd(node_count, inner); first_slot = atomicAdd(out_count, inner); }
+  Bvh4Node node;
+  for (int k = 0; k < 4; k++) {
+    node.child[k] = kBvhEmpty; node.pad[k] = 0;
+    node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = FLT_MAX;
+    node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -FLT_MAX;
+  }
+  uint32_t used = 0;
+  for (int k = 0; k < nk; k++) {
+    const BinBox b = node_box[kids[k]];
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) {  // same conservative padding as the host builder (bvh_build.cpp set_child_box)
+      const float pad = 1e-5f * fmaxf(fmaxf(fabsf(b.lo[a]), fabsf(b.hi[a])), 1e-20f) + 1e-30f;
+      lo[a] = b.lo[a] - pad; hi[a] = b.hi[a] + pad;
+    }
+    node.lo_x[k] = lo[0]; node.lo_y[k] = lo[1]; node.lo_z[k] = lo[2];
+    node.hi_x[k] = hi[0]; node.hi_y[k] = hi[1]; node.hi_z[k] = hi[2];
+    if (is_leaf(kids[k])) {
+      const uint32_t first = (kids[k] >= n - 1) ? (uint32_t) (kids[k] - (n - 1)) : (uint32_t) ranges[kids[k]].x;
+      node.child[k] = kBvhLeafBit | ((prim_count(kids[k]) - 1u) << 28) | first;
+    }
+    else {
+      node.child[k] = first_new + used;
+      out[first_slot + used] = CollapseItem{kids[k], first_new + used};
+      used++;
+    }
+  }
+  nodes[item.node4] = node;
+}
+
+#define LBVH_TRY(expr) do { if ((expr) != hipSuccess) { ok = false; goto done; } } while (0)
+
+}  // namespace
+
+Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) {
+  static_assert(sizeof(Aabb) == sizeof(BinBox), "box layouts must match");
+  Bvh4 result;
+  if (count < 2) return build_bvh4(boxes, count, max_leaf, max_depth);  // nothing to sort
+  max_leaf = max_leaf < 1 ? 1 : (max_leaf > kBvhLeafMaxTri ? kBvhLeafMaxTri : max_leaf);
+  const int n = (int) count;
+  BinBox bounds{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+  for (uint32_t i = 0; i < count; i++)
+    for (int a = 0; a < 3; a++) {
+      const float c = 0.5f * (boxes[i].lo[a] + boxes[i].hi[a]);
+      bounds.lo[a] = std::min(bounds.lo[a], c); bounds.hi[a] = std::max(bounds.hi[a], c);
+    }
+  BinBox* d_boxes = nullptr; BinBox* d_node_box = nullptr;
+  uint64_t* d_codes = nullptr; uint64_t* d_codes_sorted = nullptr;
+  uint32_t* d_ids = nullptr; uint32_t* d_ids_sorted = nullptr; uint32_t* d_arrivals = nullptr; uint32_t* d_counters = nullptr;
+  int2* d_children = nullptr; int2* d_ranges = nullptr; int* d_parent = nullptr;
+  CollapseItem* d_queue[2] = {nullptr, nullptr};
+  Bvh4Node* d_nodes = nullptr;
+  void* d_temp = nullptr;
+  size_t temp_bytes = 0;
+  bool ok = true;
+  uint32_t node_count = 1, level_count = 1, depth = 0;
+  const uint32_t max_nodes = count;  // a 4-wide node has at least two children, so fewer nodes than primitives
+  const int threads = 256;
+  LBVH_TRY(hipMalloc((void**) &d_boxes, sizeof(BinBox) * count));
+  LBVH_TRY(hipMalloc((void**) &d_node_box, sizeof(BinBox) * (2 * (size_t) count - 1)));
+  LBVH_TRY(hipMalloc((void**) &d_codes, sizeof(uint64_t) * count));
+  LBVH_TRY(hipMalloc((void**) &d_codes_sorted, sizeof(uint64_t) * count));
+  LBVH_TRY(hipMalloc((void**) &d_ids, sizeof(uint32_t) * count));
+  LBVH_TRY(hipMalloc((void**) &d_ids_sorted, sizeof(uint32_t) * count));
+  LBVH_TRY(hipMalloc((void**) &d_arrivals, sizeof(uint32_t) * count));
+  LBVH_TRY(hipMalloc((void**) &d_counters, sizeof(uint32_t) * 4));
+  LBVH_TRY(hipMalloc((void**) &d_children, sizeof(int2) * count));
+  LBVH_TRY(hipMalloc((void**) &d_ranges, sizeof(int2) * count));
+  LBVH_TRY(hipMalloc((void**) &d_parent, sizeof(int) * (2 * (size_t) count - 1)));
+  LBVH_TRY(hipMalloc((void**) &d_queue[0], sizeof(CollapseItem) * count));
+  LBVH_TRY(hipMalloc((void**) &d_queue[1], sizeof(CollapseItem) * count));
+  LBVH_TRY(hipMalloc((void**) &d_nodes, sizeof(Bvh4Node) * max_nodes));
+  LBVH_TRY(hipMemcpy(d_boxes, boxes, sizeof(BinBox) * count, hipMemcpyHostToDevice));
+  LBVH_TRY(hipMemset(d_arrivals, 0, sizeof(uint32_t) * count));
+  hipLaunchKernelGGL(k_lbvh_codes, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const BinBox*) d_boxes, count, bounds, d_codes, d_ids);
+  LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_codes, d_codes_sorted, d_ids, d_ids_sorted, n, 0, 63));
+  LBVH_TRY(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16));
+  LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_codes, d_codes_sorted, d_ids, d_ids_sorted, n, 0, 63));
+  hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const uint64_t*) d_codes_sorted, n, d_children, d_ranges, d_parent);
+  hipLaunchKernelGGL(k_lbvh_fit, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const BinBox*) d_boxes, (const uint32_t*) d_ids_sorted, n,
+                     (const int2*) d_children, (const int*) d_parent, d_node_box, d_arrivals);
+  LBVH_TRY(hipGetLastError());
+  {
+    const CollapseItem root{0, 0u};
+    LBVH_TRY(hipMemcpy(d_queue[0], &root, sizeof(root), hipMemcpyHostToDevice));
+    const uint32_t init[4] = {0u, 1u, 0u, 0u};  // [0] next level's queue length, [1] nodes allocated
+    LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  for (int cur = 0; level_count > 0; cur ^= 1) {
+    depth++;
+    if (depth > max_depth) { ok = false; goto done; }  // deeper than the traversal stack allows: the caller falls back to the host builder
+    hipLaunchKernelGGL(k_lbvh_collapse, dim3((level_count + threads - 1) / threads), dim3(threads), 0, 0, n, (const int2*) d_children, (const int2*) d_ranges,
+                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[cur], level_count, d_queue[cur ^ 1], d_counters, d_counters + 1, d_nodes);
+    uint32_t host_counters[2];
+    LBVH_TRY(hipMemcpy(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost));
+    level_count = host_counters[0];
+    node_count = host_counters[1];
+    if (node_count > max_nodes) { ok = false; goto done; }
+    LBVH_TRY(hipMemset(d_counters, 0, sizeof(uint32_t)));
+  }
+  result.nodes.resize(node_count);
+  result.prims.resize(count);
+  LBVH_TRY(hipMemcpy(result.nodes.data(), d_nodes, sizeof(Bvh4Node) * node_count, hipMemcpyDeviceToHost));
+  LBVH_TRY(hipMemcpy(result.prims.data(), d_ids_sorted, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+  result.max_depth = depth;
+done:
+  {
+    void* bufs[] = {d_boxes, d_node_box, d_codes, d_codes_sorted, d_ids, d_ids_sorted, d_arrivals, d_counters, d_children, d_ranges, d_parent, d_queue[0], d_queue[1], d_nodes, d_temp};
+    for (void* b : bufs) if (b) (void) hipFree(b);
+  }
+  if (!ok) return Bvh4();
+  return result;
+}
+
+}  // namespace lum
