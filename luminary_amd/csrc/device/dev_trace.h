@@ -8,12 +8,15 @@
 // Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
 // the candidate set only (see light_query).
 //
-// Execution model (gfx950): the ray kernels are instruction-issue bound (rocprofv3 PMC: <25% VALU lane utilisation with the
-// naive loop), so the traversal is written for few instructions per node and full lanes:
+// Execution model (gfx950): the ray kernels are chains of dependent memory round trips at 3 waves per SIMD; no unit is saturated
+// (VALU issue ~60 %, L1 address path 30-60 %, L2 ~40 %, HBM < 30 %), so both the instructions and the round trips per wave iteration
+// count:
 //   * one node visit = 7 x 16-byte loads (near/far planes picked by the ray's direction signs, so no per-axis min/max),
 //     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and branch-free pushes;
-//   * "while-while" loop: all lanes walk inner nodes, then all lanes handle leaves;
-//   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing.
+//   * every wave iteration runs ONE phase - node visit, instance entry or triangle tests - chosen by a vote over its lanes, so a
+//     lane that holds a leaf does not wait for the slowest lane of the wave to find one (plain while-while: 0.33-0.41 lane occupancy);
+//   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing;
+//   * the first nodes of the array (breadth-first across both levels) are staged in LDS by every workgroup.
 #pragma once
 
 #include "dev_light.h"
