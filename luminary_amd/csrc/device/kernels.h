@@ -24,7 +24,8 @@ enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 }
 
 constexpr int kBlock = 256;
 #ifndef LUM_TRACE_BLOCK
-#define LUM_TRACE_BLOCK 256  // threads per workgroup of the persistent ray kernels; every workgroup keeps its own LDS copy of the tree top
+#define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
+                             // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)
 #endif
 constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_SHADE_WAVES

@@ -472,7 +472,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     size_t lds_bytes = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
-    // the ray kernels need ~148 VGPRs: 3 waves per SIMD = 12 waves per CU
+    // the ray kernels need ~160 VGPRs: 3 waves per SIMD = 12 waves per CU = one workgroup of kTraceBlock = 768 threads
     const int blocks_per_cu = std::max(1, 768 / kTraceBlock);
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
     lds_bytes = lds_bytes > 4096 ? lds_bytes - 2048 : 0;
