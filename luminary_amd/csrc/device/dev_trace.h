@@ -218,13 +218,22 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 #endif
   auto pop = [&]() {
     LUM_PHASE(6); LUM_PHASE_LANES(7);
-    while (true) {
-      const uint2 e = stack_pop(stk, sp, top);
-      cur = e.x;
-      if (cur == kTraversalDone) return;
-      if (cur == kLeaveInstance) { inst = kNoInstance; r.set(wo, wd); continue; }
-      if (within(bitsf(e.y), tmax)) return;
-    }
+    // One exit condition and a predicated load per iteration; the loop carries only (sp, top): restoring the world-space ray inside it
+    // made every ray register loop-carried (two dozen v_mov per iteration). The bottom of the stack is the kTraversalDone sentinel, so
+    // any other entry has something below it.
+    bool left_instance = false, again;
+    uint2 e;
+    do {
+      e = top;
+      const bool done = e.x == kTraversalDone, leave = e.x == kLeaveInstance;
+      // (an unconditional load, with the sentinel kept in memory or selected afterwards, was measured 2-16 % slower: the loaded entry
+      // must flow into `top` untouched so that nothing waits for it before the next node's loads are in flight)
+      if (!done) { sp--; top = stk[sp]; }
+      left_instance |= leave;
+      again = !done && (leave || !within(bitsf(e.y), tmax));
+    } while (again);
+    cur = e.x;
+    if (left_instance) { inst = kNoInstance; r.set(wo, wd); }
   };
 
   // Work distribution: a wave reserves a chunk of consecutive items with one atomic and hands them to its idle lanes; a single
