@@ -280,16 +280,20 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       const uint32_t n_nodes = n_live - n_tris - n_enter;
       const bool run_tris = n_tris * LUM_VOTE_TRIS >= max(n_nodes, n_enter) * LUM_VOTE_NODES;
       const bool run_enter = !run_tris && n_enter >= n_nodes;
-      if (run_tris) {
-        if (want_tris) {
+      // Three per-lane conditions of which the vote leaves at most one non-empty. Written as independent divergent ifs on purpose: with
+      // wave-uniform if/else-if branches the compiler routed every ray register through a temporary and back at the merge point
+      // (about forty v_mov per iteration).
+      const bool do_tris = run_tris && want_tris, do_enter = run_enter && want_enter, do_node = !run_tris && !run_enter && live && !at_leaf;
+      {
+        if (do_tris) {
           LUM_PHASE(3); LUM_PHASE_LANES(4);
           if (q.on_tris(sc, inst, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
           else pop();
           if (cur == kTraversalDone) q.finish(sc, idx);
         }
       }
-      else if (run_enter) {
-        if (want_enter) {
+      {
+        if (do_enter) {
           LUM_PHASE(1); LUM_PHASE_LANES(2);
           const float4* __restrict__ leaf = sc.tlas_leaves + 4u * (cur & 0x0FFFFFFFu);
           const float4 r0 = leaf[0], r1 = leaf[1], r2 = leaf[2], meta = leaf[3];
@@ -303,8 +307,8 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           cur = fbits(meta.y);
         }
       }
-      else {
-        if (live && !at_leaf) {
+      {
+        if (do_node) {
           LUM_PHASE(0);
           st.nodes++;
           cur = visit_node<Q::kOrdered>(nodes, cur, r, tmax, stk, sp, top, st);
