@@ -118,7 +118,12 @@ class DeviceSceneView(C.Structure):
                 ("shading_mode", C.c_uint32), ("cam_pos", C.c_float * 3), ("cam_rotation", C.c_float * 4), ("cam_fov", C.c_float),
                 ("cam_aperture_size", C.c_float), ("cam_object_distance", C.c_float), ("cam_scale", C.c_float), ("cam_rr_threshold", C.c_float),
                 ("cam_aperture_shape", C.c_uint32), ("cam_aperture_blade_count", C.c_uint32), ("sky_mode", C.c_uint32),
-                ("sky_constant_color", C.c_float * 3)]
+                ("sky_constant_color", C.c_float * 3),
+                ("sky_steps", C.c_uint32), ("sky_ozone_absorption", C.c_uint32), ("sky_geometry_offset", C.c_float * 3), ("sky_sun_strength", C.c_float),
+                ("sky_base_density", C.c_float), ("sky_rayleigh_density", C.c_float), ("sky_mie_density", C.c_float), ("sky_ozone_density", C.c_float),
+                ("sky_rayleigh_falloff", C.c_float), ("sky_mie_falloff", C.c_float), ("sky_ground_visibility", C.c_float),
+                ("sky_ozone_layer_thickness", C.c_float), ("sky_multiscattering_factor", C.c_float), ("sky_sun_pos", C.c_float * 3),
+                ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2

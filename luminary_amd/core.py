@@ -104,6 +104,13 @@ class Core:
         self._call("lumc_download_luts", *[out[k].ctypes.data_as(C.c_void_p) for k in ("conductor", "glossy", "dielectric", "dielectric_inv")])
         return out
 
+    def download_sky_luts(self):
+        """The procedural sky's transmittance and multiscattering tables as flat float32 arrays (2*64*256*4 and 2*32*32*4)."""
+        tm = np.zeros(2 * 64 * 256 * 4, dtype=np.float32)
+        ms = np.zeros(2 * 32 * 32 * 4, dtype=np.float32)
+        self._call("lumc_download_sky_luts", tm.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
+        return tm, ms
+
     def set_pixels(self, pixels=None):
         if pixels is None:
             self._call("lumc_set_pixels", C.c_void_p(0), C.c_uint32(0))

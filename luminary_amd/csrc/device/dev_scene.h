@@ -72,6 +72,15 @@ struct DeviceScene {
   uint32_t cam_aperture_shape, cam_aperture_blade_count;
   uint32_t sky_mode;
   float sky_constant_color[3];
+  // procedural sky (dev_sky.h), read when sky_mode == DEFAULT
+  uint32_t sky_steps, sky_ozone_absorption;
+  float sky_geometry_offset[3];
+  float sky_sun_strength, sky_base_density, sky_rayleigh_density, sky_mie_density, sky_ozone_density, sky_rayleigh_falloff, sky_mie_falloff,
+    sky_ground_visibility, sky_ozone_layer_thickness, sky_multiscattering_factor;
+  float sky_sun_pos[3];
+  float sky_mie_phase[4];
+  const float4* sky_lut_transmittance;    // low plane [64][256], high plane
+  const float4* sky_lut_multiscattering;  // low plane [32][32], high plane
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).
@@ -102,7 +111,7 @@ struct ShadowQueue {
 };
 
 // Per-depth control words (zeroed once per pass).
-enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlStride = 8 };
+enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlSkyItems = 5, kCtlStride = 8 };
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow, kCntCount };

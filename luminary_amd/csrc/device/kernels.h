@@ -14,6 +14,7 @@
 #pragma once
 
 #include "dev_trace.h"
+#include "dev_sky.h"
 
 namespace lum {
 
@@ -229,13 +230,23 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
     const bool input_done = round >= rounds;
     if (!input_done) {
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
-      bool is_hit = false;
+      bool is_hit = false, is_sky = false;
       if (i < n) {
         if (in.hit_id[i].x == kHitSky) {
           const uint4 aux = in.aux[i];
-          if (aux.w & kStAllowAmbient) add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
+          if (aux.w & kStAllowAmbient) {
+            if (sc.sky_mode == kSkyDefault) is_sky = true;  // the atmosphere is ray-marched by k_sky
+            else add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
+          }
         }
         else is_hit = true;
+      }
+      const unsigned long long bs = __ballot(is_sky);
+      if (bs) {  // the list grows downwards from the end of the light-query list: a path is in at most one of the two
+        uint32_t base = 0;
+        if (lane == (uint32_t) __builtin_ctzll(bs)) base = atomicAdd(ctrl + kCtlSkyItems, (uint32_t) __popcll(bs));
+        base = __shfl(base, __builtin_ctzll(bs));
+        if (is_sky) sq.light_items[sq.capacity - 1u - (base + (uint32_t) __popcll(bs & below))] = i;
       }
       const unsigned long long bh = __ballot(is_hit);
       if (is_hit) pending[num_pending + (uint32_t) __popcll(bh & below)] = i;
@@ -402,6 +413,22 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) vertices += __shfl_down(vertices, off);
   if ((threadIdx.x & 63) == 0 && vertices) atomicAdd((unsigned long long*) &counters[kCntVertices], (unsigned long long) vertices);
+}
+
+// ---- paths that left the scene, procedural sky: sky_process_tasks (cuda/sky.cuh:609-633) with sky_color_main's DEFAULT branch ----
+__global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, ShadowQueue sq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlSkyItems];
+  const SkyView sky = sky_view(sc);
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock) {
+    const uint32_t i = sq.light_items[sq.capacity - 1u - k];
+    const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+    const uint4 aux = in.aux[i], hid = in.hit_id[i];
+    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+    const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z));
+    const bool include_sun = (aux.w & (kStCameraDirection | kStAllowEmission)) != 0;
+    const Col c = sky_get_color(sky, sky_origin, v3(d4.x, d4.y, d4.z), kFltMax, include_sun, (int) sky.steps, smp.next1(kRndSkyStepOffset));
+    add_to_result(results, fbits(d4.w), c * record_unpack(U2{aux.x, aux.y}));
+  }
 }
 
 // ---- light queries: BSDF-sampled direction against the light-only BVH (cuda/direct_lighting.cuh:586-667) ----

@@ -515,6 +515,34 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   sc.cam_aperture_shape = v->cam_aperture_shape; sc.cam_aperture_blade_count = v->cam_aperture_blade_count;
   sc.sky_mode = v->sky_mode;
   std::memcpy(sc.sky_constant_color, v->sky_constant_color, sizeof(sc.sky_constant_color));
+  sc.sky_steps = v->sky_steps; sc.sky_ozone_absorption = v->sky_ozone_absorption;
+  std::memcpy(sc.sky_geometry_offset, v->sky_geometry_offset, sizeof(sc.sky_geometry_offset));
+  sc.sky_sun_strength = v->sky_sun_strength; sc.sky_base_density = v->sky_base_density; sc.sky_rayleigh_density = v->sky_rayleigh_density;
+  sc.sky_mie_density = v->sky_mie_density; sc.sky_ozone_density = v->sky_ozone_density; sc.sky_rayleigh_falloff = v->sky_rayleigh_falloff;
+  sc.sky_mie_falloff = v->sky_mie_falloff; sc.sky_ground_visibility = v->sky_ground_visibility; sc.sky_ozone_layer_thickness = v->sky_ozone_layer_thickness;
+  sc.sky_multiscattering_factor = v->sky_multiscattering_factor;
+  std::memcpy(sc.sky_sun_pos, v->sky_sun_pos, sizeof(sc.sky_sun_pos));
+  std::memcpy(sc.sky_mie_phase, v->sky_mie_phase, sizeof(sc.sky_mie_phase));
+  // ---- sky look-up tables: taken from the caller or generated here (device/device_sky.c:64-200), only for the procedural sky ----
+  sc.sky_lut_transmittance = nullptr; sc.sky_lut_multiscattering = nullptr;
+  if (sc.sky_mode == kSkyDefault) {
+    const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
+    if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
+      if (upload(ctx, (const float4*) v->sky_lut_transmittance, tm_texels, &sc.sky_lut_transmittance)) return 1;
+      if (upload(ctx, (const float4*) v->sky_lut_multiscattering, ms_texels, &sc.sky_lut_multiscattering)) return 1;
+    }
+    else {
+      float4* tm = nullptr; float4* ms = nullptr;
+      HIP_TRY(ctx, hipMalloc((void**) &tm, sizeof(float4) * tm_texels)); ctx->scene_allocs.push_back(tm);
+      HIP_TRY(ctx, hipMalloc((void**) &ms, sizeof(float4) * ms_texels)); ctx->scene_allocs.push_back(ms);
+      hipLaunchKernelGGL(k_sky_transmittance_lut, dim3((kSkyTmWidth * kSkyTmHeight + 63) / 64), dim3(64), 0, 0, sc, tm);
+      sc.sky_lut_transmittance = tm;  // the multiscattering integration reads the finished transmittance table
+      hipLaunchKernelGGL(k_sky_multiscattering_lut, dim3(kSkyMsSize, kSkyMsSize), dim3(kSkyMsIter), 0, 0, sc, ms);
+      sc.sky_lut_multiscattering = ms;
+      HIP_TRY(ctx, hipGetLastError());
+      HIP_TRY(ctx, hipDeviceSynchronize());
+    }
+  }
 
   // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
   const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
@@ -541,6 +569,13 @@ int lumc_download_luts(LumContext* ctx, uint16_t* conductor, uint16_t* glossy, u
   const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
   for (int t = 0; t < 4; t++)
     if (dst[t]) HIP_TRY(ctx, hipMemcpy(dst[t], ctx->d_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_download_sky_luts(LumContext* ctx, float* transmittance, float* multiscattering) {
+  if (!ctx || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_download_sky_luts: the scene has no procedural sky"; return 1; }
+  if (transmittance) HIP_TRY(ctx, hipMemcpy(transmittance, ctx->scene.sky_lut_transmittance, sizeof(float4) * 2 * kSkyTmWidth * kSkyTmHeight, hipMemcpyDeviceToHost));
+  if (multiscattering) HIP_TRY(ctx, hipMemcpy(multiscattering, ctx->scene.sky_lut_multiscattering, sizeof(float4) * 2 * kSkyMsSize * kSkyMsSize, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -588,6 +623,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
       hipLaunchKernelGGL(k_shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
                          depth_const, ctx->d_counters);
+    }
+    if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
+      Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+      hipLaunchKernelGGL(k_sky, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);

@@ -46,6 +46,40 @@ void default_camera(LuminaryCamera* c) {  // camera.c:7-66
   c->physical.sensor_width = 20.0f;
 }
 
+// jendersie_eon_phase_parameters, cuda/math.cuh:1189-1232: the four parameters depend on the droplet diameter only, so they are
+// evaluated once here (the reference evaluates them per ray on the device) and travel with the scene.
+void jendersie_eon_parameters(float d, float out[4]) {
+  float g_hg, g_d, alpha, w_d;
+  if (d >= 5.0f && d <= 50.0f) {
+    g_hg = std::exp(-0.0990567f / (d - 1.67154f));
+    g_d = std::exp(-(2.20679f / (d + 3.91029f)) - 0.428934f);
+    alpha = std::exp(3.62489f - (8.29288f / (d + 5.52825f)));
+    w_d = std::exp(-(0.599085f / (d - 0.641583f)) - 0.665888f);
+  }
+  else if (d >= 1.5f && d < 5.0f) {
+    const float l = std::log(d), ll = std::log(l);
+    g_hg = 0.0604931f * ll + 0.940256f;
+    g_d = 0.500411f - (0.081287f / (-2.0f * l + std::tan(l) + 1.27551f));
+    alpha = 7.30354f * l + 6.31675f;
+    w_d = 0.026914f * (l - std::cos(5.68947f * (ll - 0.0292149f))) + 0.376475f;
+  }
+  else if (d >= 0.1f && d < 1.5f) {
+    const float l = std::log(d);
+    g_hg = 0.862f - 0.143f * l * l;
+    g_d = 0.379685f * std::cos(1.19692f * std::cos(((l - 0.238604f) * (l + 1.00667f)) / (0.507522f - 0.15677f * l)) + 1.37932f * l + 0.0625835f) + 0.344213f;
+    alpha = 250.0f;
+    w_d = 0.146209f * std::cos(3.38707f * l + 2.11193f) + 0.316072f + 0.0778917f * l;
+  }
+  else if (d < 0.1f) {
+    g_hg = 13.8f * d * d;
+    g_d = 1.1456f * d * std::sin(9.29044f * d);
+    alpha = 250.0f;
+    w_d = 0.252977f - 312.983f * std::pow(d, 4.3f);
+  }
+  else { g_hg = 0.0f; g_d = 0.0f; alpha = 0.0f; w_d = 0.0f; }  // beyond 50 um the reference leaves the values unset
+  out[0] = g_hg; out[1] = g_d; out[2] = alpha; out[3] = w_d;
+}
+
 void default_sky(LuminarySky* s) {  // sky.c:6-41
   std::memset(s, 0, sizeof(*s));
   s->geometry_offset.y = 0.1f; s->altitude = 0.5f; s->azimuth = 3.141f; s->moon_altitude = -0.5f;
@@ -706,6 +740,24 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   v.cam_aperture_shape = scene.camera.aperture_shape & 1u; v.cam_aperture_blade_count = scene.camera.aperture_blade_count & 7u;
   v.sky_mode = scene.sky.mode & 3u;
   v.sky_constant_color[0] = scene.sky.constant_color.r; v.sky_constant_color[1] = scene.sky.constant_color.g; v.sky_constant_color[2] = scene.sky.constant_color.b;
+  // procedural sky: device_struct_sky_convert, device_structs.c:106-150 (sun position in double, as there)
+  const LuminarySky& sky = scene.sky;
+  v.sky_steps = sky.steps & 1023u; v.sky_ozone_absorption = sky.ozone_absorption ? 1u : 0u;
+  v.sky_geometry_offset[0] = sky.geometry_offset.x; v.sky_geometry_offset[1] = sky.geometry_offset.y; v.sky_geometry_offset[2] = sky.geometry_offset.z;
+  v.sky_sun_strength = sky.sun_strength; v.sky_base_density = sky.base_density; v.sky_rayleigh_density = sky.rayleigh_density; v.sky_mie_density = sky.mie_density;
+  v.sky_ozone_density = sky.ozone_density; v.sky_rayleigh_falloff = sky.rayleigh_falloff; v.sky_mie_falloff = sky.mie_falloff;
+  v.sky_ground_visibility = sky.ground_visibility; v.sky_ozone_layer_thickness = sky.ozone_layer_thickness; v.sky_multiscattering_factor = sky.multiscattering_factor;
+  {
+    double sx = std::cos((double) sky.azimuth) * std::cos((double) sky.altitude), sy = std::sin((double) sky.altitude), sz = std::sin((double) sky.azimuth) * std::cos((double) sky.altitude);
+    const double scale = 1.0 / std::sqrt(sx * sx + sy * sy + sz * sz);
+    const double sun_distance = 149597870.0f, earth_radius = 6371.0f;  // sky_defines.h:4-6
+    sx *= scale * sun_distance; sy *= scale * sun_distance; sz *= scale * sun_distance;
+    sy -= earth_radius;
+    sx -= sky.geometry_offset.x; sy -= sky.geometry_offset.y; sz -= sky.geometry_offset.z;
+    v.sky_sun_pos[0] = (float) sx; v.sky_sun_pos[1] = (float) sy; v.sky_sun_pos[2] = (float) sz;
+  }
+  jendersie_eon_parameters(sky.mie_diameter, v.sky_mie_phase);
+  v.sky_lut_transmittance = nullptr; v.sky_lut_multiscattering = nullptr;  // generated on the GPU at upload
   return std::string();
 }
 

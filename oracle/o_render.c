@@ -21,6 +21,7 @@
 #include "o_trace.h"
 #include "o_output.h"
 #include "o_adaptive.h"
+#include "o_sky.h"
 
 enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
@@ -185,7 +186,15 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     const OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
     cnt[ORACLE_CNT_TRACE]++;
     if (hit.instance_id == HIT_TYPE_SKY) {
-      if (state & ST_ALLOW_AMBIENT) beauty_add(&result, c_mul(sky_color, record_unpack(record_p)));
+      if (state & ST_ALLOW_AMBIENT) {
+        RGBF sky = sky_color;
+        if (s->sky_mode == SKY_MODE_DEFAULT && s->sky_lut_transmittance && s->sky_lut_multiscattering) { /* sky_color_main, sky.cuh:567-577 */
+          const OSky view = osky_view(s);
+          const bool include_sun = (state & (ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION)) != 0;
+          sky = sky_get_color(&view, world_to_sky(&view, origin), ray, FLT_MAX, include_sun, (int) view.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET));
+        }
+        beauty_add(&result, c_mul(sky, record_unpack(record_p)));
+      }
       break;
     }
     cnt[ORACLE_CNT_VERTICES]++;
@@ -519,4 +528,18 @@ void oracle_generate_result(
   const OAdaptive a = adaptive_view(width, height, executions, stage_id, stage_counts);
   const OResultParams rp = {width, height, mode, local_error_minimization, uniform_samples, exposure};
   oa_generate_result(&a, &rp, (const OracleOutputParams*) op, first_moment, second_moment, frame_result);
+}
+
+/* ---- procedural sky (o_sky.h) ---- */
+void oracle_sky_generate_luts(const OracleScene* scene, float* transmittance, float* multiscattering) {
+  OSky s = osky_view(scene);
+  sky_transmittance_lut(&s, transmittance);
+  s.tm = transmittance;
+  sky_multiscattering_lut(&s, multiscattering);
+}
+void oracle_sky_color(const OracleScene* scene, const float origin_world[3], const float ray[3], int include_sun, float random_offset, float out[3]) {
+  const OSky s = osky_view(scene);
+  const RGBF c = sky_get_color(&s, world_to_sky(&s, v3(origin_world[0], origin_world[1], origin_world[2])), v3(ray[0], ray[1], ray[2]), FLT_MAX, include_sun != 0,
+                               (int) s.steps, random_offset);
+  out[0] = c.r; out[1] = c.g; out[2] = c.b;
 }

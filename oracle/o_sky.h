@@ -1,0 +1,371 @@
+/*
+ * ORACLE (test infrastructure, not product): procedural sky, first part of SURVEY §8 f4.
+ *
+ * Restated from cuda/sky.cuh:47-108 (densities, path through the atmosphere), :110-176 (transmittance LUT), :186-332 (multiscattering
+ * LUT), :338-446 (sky_compute_atmosphere), :508-515, :567-577 (sky_get_color / sky_color_main, DEFAULT branch), cuda/sky_utils.cuh
+ * (8-wavelength spectrum, LUT parametrisation, spectrum -> RGB), cuda/math.cuh:620-779 (sphere tests), :1162-1239 (phase functions),
+ * :1429-1439 (solid angle of the sun). Out: moon, stars, cloud shadows, aerial perspective, HDRI mode.
+ * expf := o_exp2(x * log2 e); asinf(x) := o_atan2(x, sqrt(1 - x^2)); the LUTs are filtered in software (clamp addressing, exact lerps)
+ * where the reference uses the texture unit. The Jendersie-Eon parameters of the droplet diameter arrive with the scene.
+ * Parity unpinned, like the rest of the oracle.
+ */
+#ifndef ORACLE_O_SKY_H
+#define ORACLE_O_SKY_H
+
+#include "o_rng.h"
+#include "oracle.h"
+
+#define SKY_EARTH_RADIUS 6371.0f
+#define SKY_SUN_RADIUS 696340.0f
+#define SKY_SUN_DISTANCE 149597870.0f
+#define SKY_ATMO_HEIGHT 100.0f
+#define SKY_ATMO_RADIUS (SKY_ATMO_HEIGHT + SKY_EARTH_RADIUS)
+#define SKY_HEIGHT_OFFSET 0.0005f
+#define SKY_TM_W 256
+#define SKY_TM_H 64
+#define SKY_MS_SIZE 32
+#define SKY_MS_BASE 16
+#define SKY_MS_ITER 256
+#define RANDOM_TARGET_SKY_STEP_OFFSET 77u /* allocation rule of random.cuh:24-66 */
+#define SKY_MIE_SCATTERING (3.996f * 0.001f)
+#define SKY_MIE_EXTINCTION (4.440f * 0.001f)
+
+typedef struct { float v[8]; } Spectrum;
+static inline Spectrum sp_set1(float x) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = x; return r; }
+static inline Spectrum sp_add(Spectrum a, Spectrum b) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i] + b.v[i]; return r; }
+static inline Spectrum sp_sub(Spectrum a, Spectrum b) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i] - b.v[i]; return r; }
+static inline Spectrum sp_mul(Spectrum a, Spectrum b) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i] * b.v[i]; return r; }
+static inline Spectrum sp_scale(Spectrum a, float b) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = a.v[i] * b; return r; }
+static inline Spectrum sp_inv(Spectrum a) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = 1.0f / a.v[i]; return r; }
+static inline float o_exp(float x) { return o_exp2(x * 1.44269504f); }
+static inline Spectrum sp_exp(Spectrum a) { Spectrum r; for (int i = 0; i < 8; i++) r.v[i] = o_exp(a.v[i]); return r; }
+static const Spectrum SP_IDENT = {{8.4205e-03f, 2.6449e-01f, 4.0273e-01f, 1.6624e-01f, 2.4324e-01f, 3.5849e-01f, 3.6342e-01f, 2.4177e-01f}};
+static const Spectrum SKY_SUN_RADIANCE = {{2.463170e+04f, 2.888721e+04f, 2.795153e+04f, 2.629836e+04f, 2.667237e+04f, 2.638737e+04f, 2.490630e+04f, 2.338930e+04f}};
+static const Spectrum SKY_RAYLEIGH_SCATTERING = {{3.945800e-02f, 2.939289e-02f, 2.235060e-02f, 1.730112e-02f, 1.360286e-02f, 1.084340e-02f, 8.750306e-03f, 7.139216e-03f}};
+static const Spectrum SKY_OZONE_EXTINCTION = {{1.484836e-05f, 8.501668e-05f, 2.646158e-04f, 7.953520e-04f, 1.661103e-03f, 2.510733e-03f, 2.697211e-03f, 1.727741e-03f}};
+
+/* sky_utils.cuh:289-316 */
+static inline RGBF sky_color_from_spectrum(Spectrum s) {
+  const float r = 0.00640271f * s.v[0] + 0.179441f * s.v[1] + 0.04852f * s.v[2] - 0.43822f * s.v[3] - 0.920721f * s.v[4] - 0.0226871f * s.v[5] + 1.83443f * s.v[6] + 2.36265f * s.v[7];
+  const float g = -0.00550232f * s.v[0] - 0.164f * s.v[1] - 0.119836f * s.v[2] + 0.365423f * s.v[3] + 1.28952f * s.v[4] + 1.41809f * s.v[5] + 0.629138f * s.v[6] - 0.0816028f * s.v[7];
+  const float b = 0.0386558f * s.v[0] + 1.21426f * s.v[1] + 1.80395f * s.v[2] + 0.475181f * s.v[3] - 0.0638328f * s.v[4] - 0.169502f * s.v[5] - 0.114583f * s.v[6] - 0.0374822f * s.v[7];
+  return c3(fmaxf(r, 0.0f), fmaxf(g, 0.0f), fmaxf(b, 0.0f));
+}
+
+/* math.cuh:620-779 */
+static inline float sph_int_p0(vec3 ray, vec3 origin, float r) {
+  const float d0 = v_dot(origin, ray), r2 = r * r;
+  const vec3 k = v_sub(origin, v_scale(ray, d0));
+  const float d = r2 - v_dot(k, k);
+  if (d < 0.0f) return FLT_MAX;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  const float c = v_dot(origin, origin) - r2;
+  const float t0 = c / q;
+  if (t0 >= 0.0f) return t0;
+  return (q >= 0.0f) ? q : FLT_MAX;
+}
+static inline float sph_int_back_p0(vec3 ray, vec3 origin, float r) {
+  const float d0 = v_dot(origin, ray), r2 = r * r;
+  const vec3 k = v_sub(origin, v_scale(ray, d0));
+  const float d = r2 - v_dot(k, k);
+  if (d < 0.0f) return FLT_MAX;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  const float c = v_dot(origin, origin) - r2;
+  if (q >= 0.0f) return q;
+  const float t0 = c / q;
+  return (t0 >= 0.0f) ? t0 : FLT_MAX;
+}
+static inline bool sph_hit_p0(vec3 ray, vec3 origin, float r) {
+  const float d0 = v_dot(origin, ray), r2 = r * r;
+  const vec3 k = v_sub(origin, v_scale(ray, d0));
+  const float d = r2 - v_dot(k, k);
+  if (d < 0.0f) return false;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  const float c = v_dot(origin, origin) - r2;
+  return (c / q) >= 0.0f;
+}
+static inline float sphere_int(vec3 ray, vec3 origin, vec3 p, float r) {
+  const vec3 diff = v_sub(origin, p);
+  const float d0 = v_dot(diff, ray), r2 = r * r;
+  const float c = v_dot(diff, diff) - r2;
+  const vec3 k = v_sub(diff, v_scale(ray, d0));
+  const float d = r2 - v_dot(k, k);
+  if (d < 0.0f) return FLT_MAX;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  const float t0 = c / q;
+  if (t0 >= 0.0f) return t0;
+  return (q >= 0.0f) ? q : FLT_MAX;
+}
+static inline float o_asin(float x) { return o_atan2(x, sqrtf(fmaxf(1.0f - x * x, 0.0f))); }
+static inline float sphere_solid_angle(vec3 p, float r, vec3 origin) { /* math.cuh:1429-1439 */
+  const float d = v_len(v_sub(p, origin));
+  if (d < r) return 2.0f * O_PI;
+  const float a = o_asin(r / d);
+  return 2.0f * O_PI * a * a;
+}
+
+typedef struct {
+  uint32_t steps, ozone_absorption;
+  vec3 geometry_offset, sun_pos;
+  float sun_strength, base_density, rayleigh_density, mie_density, ozone_density, rayleigh_falloff, mie_falloff, ground_visibility, ozone_layer_thickness,
+    multiscattering_factor;
+  float g_hg, g_d, alpha, w_d;
+  const float* tm; /* low plane [64][256][4], high plane */
+  const float* ms; /* low plane [32][32][4], high plane */
+} OSky;
+
+static inline OSky osky_view(const OracleScene* sc) {
+  OSky s;
+  s.steps = sc->sky_steps; s.ozone_absorption = sc->sky_ozone_absorption;
+  s.geometry_offset = v3(sc->sky_geometry_offset[0], sc->sky_geometry_offset[1], sc->sky_geometry_offset[2]);
+  s.sun_pos = v3(sc->sky_sun_pos[0], sc->sky_sun_pos[1], sc->sky_sun_pos[2]);
+  s.sun_strength = sc->sky_sun_strength; s.base_density = sc->sky_base_density; s.rayleigh_density = sc->sky_rayleigh_density; s.mie_density = sc->sky_mie_density;
+  s.ozone_density = sc->sky_ozone_density; s.rayleigh_falloff = sc->sky_rayleigh_falloff; s.mie_falloff = sc->sky_mie_falloff;
+  s.ground_visibility = sc->sky_ground_visibility; s.ozone_layer_thickness = sc->sky_ozone_layer_thickness; s.multiscattering_factor = sc->sky_multiscattering_factor;
+  s.g_hg = sc->sky_mie_phase[0]; s.g_d = sc->sky_mie_phase[1]; s.alpha = sc->sky_mie_phase[2]; s.w_d = sc->sky_mie_phase[3];
+  s.tm = sc->sky_lut_transmittance; s.ms = sc->sky_lut_multiscattering;
+  return s;
+}
+
+static inline float sky_height(vec3 p) { return v_len(p) - SKY_EARTH_RADIUS; }
+static inline vec3 world_to_sky(const OSky* s, vec3 p) { return v_add(v3(p.x * 0.001f, p.y * 0.001f + SKY_EARTH_RADIUS, p.z * 0.001f), s->geometry_offset); }
+static inline float sky_sub_to_unit_uv(float u, float res) { return (u - 0.5f / res) * (res / (res - 1.0f)); }
+static inline float sky_rayleigh_phase(float c) { return 3.0f * (1.0f + c * c) / (16.0f * 3.1415926535f); }
+static inline float sky_rayleigh_density(const OSky* s, float h) { return 2.5f * s->base_density * o_exp(-h * (1.0f / s->rayleigh_falloff)); }
+static inline float sky_mie_density(const OSky* s, float h) {
+  const float inso = o_exp(-h * (1.0f / s->mie_falloff));
+  float waso = 0.0f;
+  if (h < 2.0f) waso = 1.0f + 0.125f * (2.0f - h);
+  else if (h < 3.0f) waso = 3.0f - h;
+  waso *= 60.0f / s->ground_visibility;
+  return s->base_density * (inso + waso);
+}
+static inline float sky_ozone_density(const OSky* s, float h) {
+  if (!s->ozone_absorption) return 0.0f;
+  const float min_val = (h > 25.0f) ? 0.0f : 0.1f;
+  return s->base_density * fmaxf(min_val, 1.0f - fabsf(h - 25.0f) / s->ozone_layer_thickness);
+}
+static inline float hg_phase(float c, float g) {
+  const float g2 = g * g;
+  const float den = 1.0f + g2 - 2.0f * g * c;
+  return (1.0f - g * g) / (4.0f * O_PI * (den * sqrtf(den)));
+}
+static inline float sky_mie_phase(const OSky* s, float c) {
+  const float hg = hg_phase(c, s->g_hg);
+  const float dr = hg_phase(c, s->g_d) * ((1.0f + s->alpha * c * c) / (1.0f + (s->alpha / 3.0f) * (1.0f + 2.0f * s->g_d * s->g_d)));
+  return (1.0f - s->w_d) * hg + s->w_d * dr;
+}
+typedef struct { Spectrum scattering_rayleigh, scattering, extinction; float scattering_mie; } SkyMedium;
+static inline SkyMedium sky_medium(const OSky* s, float height) {
+  const float dr = sky_rayleigh_density(s, height) * s->rayleigh_density, dm = sky_mie_density(s, height) * s->mie_density, doz = sky_ozone_density(s, height) * s->ozone_density;
+  SkyMedium m;
+  m.scattering_rayleigh = sp_scale(SKY_RAYLEIGH_SCATTERING, dr);
+  m.scattering_mie = SKY_MIE_SCATTERING * dm;
+  const Spectrum ext_r = sp_scale(SKY_RAYLEIGH_SCATTERING, dr);
+  const float ext_m = SKY_MIE_EXTINCTION * dm;
+  const Spectrum ext_o = sp_scale(SKY_OZONE_EXTINCTION, doz);
+  m.scattering = sp_add(m.scattering_rayleigh, sp_set1(m.scattering_mie));
+  m.extinction = sp_add(sp_add(ext_r, sp_set1(ext_m)), ext_o);
+  return m;
+}
+
+/* sky.cuh:78-108 */
+static inline float2_t sky_compute_path(vec3 origin, vec3 ray, float min_height, float max_height) {
+  const float height = v_len(origin);
+  float2_t r;
+  if (height <= min_height) { r.x = 0.0f; r.y = -FLT_MAX; return r; }
+  float distance, start = 0.0f;
+  if (height > max_height) {
+    const float earth = sph_int_p0(ray, origin, min_height), atmo = sph_int_p0(ray, origin, max_height), atmo2 = sph_int_back_p0(ray, origin, max_height);
+    distance = fminf(earth - atmo, atmo2 - atmo);
+    start = atmo;
+  }
+  else {
+    const float earth = sph_int_p0(ray, origin, min_height), atmo = sph_int_p0(ray, origin, max_height);
+    distance = fminf(earth, atmo);
+  }
+  r.x = start; r.y = distance;
+  return r;
+}
+
+static inline Spectrum sky_lut_fetch(const float* lut, int w, int h, float u, float v) {
+  const float x = u * (float) w - 0.5f, y = v * (float) h - 0.5f;
+  const float fx = floorf(x), fy = floorf(y);
+  const float tx = x - fx, ty = y - fy;
+  int x0 = (int) fx, x1 = (int) fx + 1, y0 = (int) fy, y1 = (int) fy + 1;
+  x0 = x0 < 0 ? 0 : (x0 > w - 1 ? w - 1 : x0); x1 = x1 < 0 ? 0 : (x1 > w - 1 ? w - 1 : x1);
+  y0 = y0 < 0 ? 0 : (y0 > h - 1 ? h - 1 : y0); y1 = y1 < 0 ? 0 : (y1 > h - 1 ? h - 1 : y1);
+  Spectrum r;
+  for (int plane = 0; plane < 2; plane++) {
+    const float* p = lut + (size_t) plane * w * h * 4;
+    const float* a = p + 4 * (y0 * w + x0); const float* b = p + 4 * (y0 * w + x1);
+    const float* c = p + 4 * (y1 * w + x0); const float* d = p + 4 * (y1 * w + x1);
+    for (int k = 0; k < 4; k++) {
+      const float top = a[k] + tx * (b[k] - a[k]), bot = c[k] + tx * (d[k] - c[k]);
+      r.v[plane * 4 + k] = top + ty * (bot - top);
+    }
+  }
+  return r;
+}
+static inline float2_t sky_transmittance_uv(float height, float zenith_cos) { /* sky_utils.cuh:273-287 */
+  height += SKY_EARTH_RADIUS;
+  const float H = sqrtf(fmaxf(0.0f, SKY_ATMO_RADIUS * SKY_ATMO_RADIUS - SKY_EARTH_RADIUS * SKY_EARTH_RADIUS));
+  const float rho = sqrtf(fmaxf(0.0f, height * height - SKY_EARTH_RADIUS * SKY_EARTH_RADIUS));
+  const float disc = height * height * (zenith_cos * zenith_cos - 1.0f) + SKY_ATMO_RADIUS * SKY_ATMO_RADIUS;
+  const float d = fmaxf(0.0f, (-height * zenith_cos + sqrtf(disc)));
+  const float d_min = SKY_ATMO_RADIUS - height, d_max = rho + H;
+  float2_t r;
+  r.x = (d - d_min) / (d_max - d_min); r.y = rho / H;
+  return r;
+}
+
+/* sky.cuh:110-176 */
+static Spectrum sky_optical_depth(const OSky* s, float r, float mu) {
+  const int steps = 2500;
+  const float disc = r * r * (mu * mu - 1.0f) + SKY_ATMO_RADIUS * SKY_ATMO_RADIUS;
+  const float dist = fmaxf(-r * mu + sqrtf(fmaxf(0.0f, disc)), 0.0f);
+  const float step_size = dist / steps;
+  Spectrum depth = sp_set1(0.0f);
+  for (int i = 0; i <= steps; i++) {
+    const float reach = i * step_size;
+    const float height = sqrtf(reach * reach + 2.0f * r * mu * reach + r * r) - SKY_EARTH_RADIUS;
+    const SkyMedium m = sky_medium(s, height);
+    const float w = (i == 0 || i == steps) ? 0.5f : 1.0f;
+    depth = sp_add(depth, sp_scale(m.extinction, w * step_size));
+  }
+  return depth;
+}
+static void sky_transmittance_lut(const OSky* s, float* dst) {
+#pragma omp parallel for schedule(dynamic, 16)
+  for (int id = 0; id < SKY_TM_W * SKY_TM_H; id++) {
+    const int y = id / SKY_TM_W, x = id - y * SKY_TM_W;
+    float fx = ((float) x + 0.5f) / SKY_TM_W, fy = ((float) y + 0.5f) / SKY_TM_H;
+    fx = sky_sub_to_unit_uv(fx, SKY_TM_W); fy = sky_sub_to_unit_uv(fy, SKY_TM_H);
+    const float H = sqrtf(SKY_ATMO_RADIUS * SKY_ATMO_RADIUS - SKY_EARTH_RADIUS * SKY_EARTH_RADIUS);
+    const float rho = H * fy;
+    const float r = sqrtf(rho * rho + SKY_EARTH_RADIUS * SKY_EARTH_RADIUS);
+    const float d_min = SKY_ATMO_RADIUS - r, d_max = rho + H;
+    const float d = d_min + fx * (d_max - d_min);
+    float mu = (d == 0.0f) ? 1.0f : (H * H - rho * rho - d * d) / (2.0f * r * d);
+    mu = fminf(1.0f, fmaxf(-1.0f, mu));
+    const Spectrum t = sp_exp(sp_scale(sky_optical_depth(s, r, mu), -1.0f));
+    for (int k = 0; k < 4; k++) { dst[4 * id + k] = t.v[k]; dst[4 * (SKY_TM_W * SKY_TM_H + id) + k] = t.v[4 + k]; }
+  }
+}
+
+typedef struct { Spectrum L, ms_as_1; } SkyMsResult;
+/* sky.cuh:186-273 */
+static SkyMsResult sky_multiscattering_integration(const OSky* s, vec3 origin, vec3 ray, vec3 sun_pos) {
+  SkyMsResult res;
+  res.L = sp_set1(0.0f); res.ms_as_1 = sp_set1(0.0f);
+  const float2_t path = sky_compute_path(origin, ray, SKY_EARTH_RADIUS, SKY_ATMO_RADIUS);
+  if (path.y == -FLT_MAX) return res;
+  const float start = path.x, distance = path.y;
+  if (distance > 0.0f) {
+    const int steps = 500;
+    float reach = start;
+    const float light_angle = sphere_solid_angle(sun_pos, SKY_SUN_RADIUS, origin);
+    Spectrum transmittance = sp_set1(1.0f);
+    for (int i = 0; i < steps; i++) {
+      const float new_reach = start + distance * (i + 0.3f) / steps;
+      const float step_size = new_reach - reach;
+      reach = new_reach;
+      const vec3 pos = v_add(origin, v_scale(ray, reach));
+      const float height = sky_height(pos);
+      const vec3 ray_scatter = v_norm(v_sub(sun_pos, pos));
+      const float cos_angle = v_dot(ray, ray_scatter);
+      const float phase_r = sky_rayleigh_phase(cos_angle), phase_m = sky_mie_phase(s, cos_angle);
+      const float zenith_cos = v_dot(v_norm(pos), ray_scatter);
+      const float2_t uv = sky_transmittance_uv(height, zenith_cos);
+      const Spectrum extinction_sun = sky_lut_fetch(s->tm, SKY_TM_W, SKY_TM_H, uv.x, uv.y);
+      const SkyMedium m = sky_medium(s, height);
+      const Spectrum phase_times_scattering = sp_add(sp_scale(m.scattering_rayleigh, phase_r), sp_set1(m.scattering_mie * phase_m));
+      const float shadow = sph_hit_p0(ray_scatter, pos, SKY_EARTH_RADIUS) ? 0.0f : 1.0f;
+      const Spectrum S = sp_scale(sp_mul(extinction_sun, phase_times_scattering), shadow * light_angle);
+      const Spectrum step_t = sp_exp(sp_scale(m.extinction, -step_size));
+      const Spectrum inv_ext = sp_inv(m.extinction);
+      const Spectrum ss_int = sp_mul(sp_sub(S, sp_mul(S, step_t)), inv_ext);
+      const Spectrum ms_int = sp_mul(sp_sub(m.scattering, sp_mul(m.scattering, step_t)), inv_ext);
+      res.L = sp_add(res.L, sp_mul(ss_int, transmittance));
+      res.ms_as_1 = sp_add(res.ms_as_1, sp_mul(ms_int, transmittance));
+      transmittance = sp_mul(transmittance, step_t);
+    }
+  }
+  return res;
+}
+/* sky.cuh:276-332: 256 directions per texel, added by the kernel's shared-memory tree (i = 128, 64, ... 1: s[t] += s[t + i]) */
+static void sky_multiscattering_lut(const OSky* s, float* dst) {
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int id = 0; id < SKY_MS_SIZE * SKY_MS_SIZE; id++) {
+    const int y = id / SKY_MS_SIZE, x = id - y * SKY_MS_SIZE;
+    float fx = ((float) x + 0.5f) / SKY_MS_SIZE, fy = ((float) y + 0.5f) / SKY_MS_SIZE;
+    fx = sky_sub_to_unit_uv(fx, SKY_MS_SIZE); fy = sky_sub_to_unit_uv(fy, SKY_MS_SIZE);
+    const float cos_angle = fx * 2.0f - 1.0f;
+    const vec3 sun_dir = v3(0.0f, cos_angle, sqrtf(o_saturate(1.0f - cos_angle * cos_angle)));
+    const float height = SKY_EARTH_RADIUS + o_saturate(fy + SKY_HEIGHT_OFFSET) * (SKY_ATMO_HEIGHT - SKY_HEIGHT_OFFSET);
+    const vec3 pos = v3(0.0f, height, 0.0f), sun_pos = v_scale(sun_dir, SKY_SUN_DISTANCE);
+    const float sqrt_sample = (float) SKY_MS_BASE;
+    Spectrum lum[SKY_MS_ITER], ms[SKY_MS_ITER];
+    for (int t = 0; t < SKY_MS_ITER; t++) {
+      const float a = (float) (t / SKY_MS_BASE), b = (float) (t - (t / SKY_MS_BASE) * SKY_MS_BASE);
+      const vec3 ray = sample_ray_sphere(2.0f * (a / sqrt_sample) - 1.0f, b / sqrt_sample);
+      const SkyMsResult r = sky_multiscattering_integration(s, pos, ray, sun_pos);
+      lum[t] = r.L; ms[t] = r.ms_as_1;
+    }
+    for (int i = SKY_MS_ITER >> 1; i > 0; i >>= 1)
+      for (int t = 0; t < i; t++) { lum[t] = sp_add(lum[t], lum[t + i]); ms[t] = sp_add(ms[t], ms[t + i]); }
+    const Spectrum luminance = sp_scale(lum[0], 1.0f / (sqrt_sample * sqrt_sample));
+    const Spectrum multiscattering = sp_scale(ms[0], 1.0f / (sqrt_sample * sqrt_sample));
+    const Spectrum contribution = sp_inv(sp_sub(sp_set1(1.0f), multiscattering));
+    const Spectrum L = sp_scale(sp_mul(luminance, contribution), s->multiscattering_factor);
+    for (int k = 0; k < 4; k++) { dst[4 * id + k] = L.v[k]; dst[4 * (SKY_MS_SIZE * SKY_MS_SIZE + id) + k] = L.v[4 + k]; }
+  }
+}
+
+/* sky_compute_atmosphere (sky.cuh:338-446) with the sun disk as the only celestial body; sky_get_color (:508-515) */
+static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
+  Spectrum result = sp_set1(0.0f);
+  const float2_t path = sky_compute_path(origin, ray, SKY_EARTH_RADIUS, SKY_ATMO_RADIUS);
+  const float start = path.x, distance = fminf(path.y, limit - start);
+  Spectrum transmittance = SP_IDENT;
+  if (distance > 0.0f) {
+    float reach = start;
+    const float light_angle = sphere_solid_angle(s->sun_pos, SKY_SUN_RADIUS, origin);
+    for (int i = 0; i < steps; i++) {
+      const float new_reach = start + distance * (i + random_offset) / steps;
+      const float step_size = new_reach - reach;
+      reach = new_reach;
+      const vec3 pos = v_add(origin, v_scale(ray, reach));
+      const float height = sky_height(pos);
+      const vec3 ray_scatter = v_norm(v_sub(s->sun_pos, pos));
+      const float cos_angle = v_dot(ray, ray_scatter);
+      const float zenith_cos = v_dot(v_norm(pos), ray_scatter);
+      const float phase_r = sky_rayleigh_phase(cos_angle), phase_m = sky_mie_phase(s, cos_angle);
+      const float shadow = sph_hit_p0(ray_scatter, pos, SKY_EARTH_RADIUS) ? 0.0f : 1.0f;
+      const float2_t uv = sky_transmittance_uv(height, zenith_cos);
+      const Spectrum extinction_sun = sky_lut_fetch(s->tm, SKY_TM_W, SKY_TM_H, uv.x, uv.y);
+      const SkyMedium m = sky_medium(s, height);
+      const Spectrum phase_times_scattering = sp_add(sp_scale(m.scattering_rayleigh, phase_r), sp_set1(m.scattering_mie * phase_m));
+      const Spectrum ss_radiance = sp_scale(sp_mul(extinction_sun, phase_times_scattering), shadow * light_angle);
+      const Spectrum ms_tex = sky_lut_fetch(s->ms, SKY_MS_SIZE, SKY_MS_SIZE, zenith_cos * 0.5f + 0.5f, height / SKY_ATMO_HEIGHT);
+      const Spectrum S = sp_add(ss_radiance, sp_mul(ms_tex, m.scattering));
+      const Spectrum step_t = sp_exp(sp_scale(m.extinction, -step_size));
+      const Spectrum s_int = sp_mul(sp_sub(S, sp_mul(S, step_t)), sp_inv(m.extinction));
+      result = sp_add(result, sp_mul(s_int, transmittance));
+      transmittance = sp_mul(transmittance, step_t);
+    }
+    result = sp_mul(result, sp_scale(SKY_SUN_RADIANCE, s->sun_strength));
+  }
+  if (celestials) {
+    const float sun_hit = sphere_int(ray, origin, s->sun_pos, SKY_SUN_RADIUS);
+    const float earth_hit = sph_int_p0(ray, origin, SKY_EARTH_RADIUS);
+    if (earth_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+  }
+  return sky_color_from_spectrum(result);
+}
+
+#endif

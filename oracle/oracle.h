@@ -56,6 +56,15 @@ typedef struct OracleScene {
   /* sky (device_structs.h:100-124) */
   uint32_t sky_mode;
   float sky_constant_color[3];
+  /* procedural sky (device_structs.h:101-124), read when sky_mode == DEFAULT */
+  uint32_t sky_steps, sky_ozone_absorption;
+  float sky_geometry_offset[3];
+  float sky_sun_strength, sky_base_density, sky_rayleigh_density, sky_mie_density, sky_ozone_density, sky_rayleigh_falloff, sky_mie_falloff,
+    sky_ground_visibility, sky_ozone_layer_thickness, sky_multiscattering_factor;
+  float sky_sun_pos[3];   /* sky space, kilometres (device_structs.c:135-150) */
+  float sky_mie_phase[4]; /* Jendersie-Eon g_hg, g_d, alpha, w_d of sky.mie_diameter (math.cuh:1189-1232) */
+  const float* sky_lut_transmittance;   /* 2 x 64 x 256 float4 (low wavelengths plane, high plane); inputs: oracle_sky_generate_luts makes them */
+  const float* sky_lut_multiscattering; /* 2 x 32 x 32 float4 */
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -117,6 +126,10 @@ void oracle_pixel_samples(uint32_t width, uint32_t height, const uint32_t execut
 void oracle_generate_result(
   uint32_t width, uint32_t height, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const uint32_t executions[5],
   uint32_t stage_id, const uint32_t* stage_counts, const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, float* frame_result);
+/* Procedural sky (o_sky.h): the two look-up tables of the scene's atmosphere (2 x 64 x 256 x 4 and 2 x 32 x 32 x 4 floats), and the colour
+ * of the sky seen from a world-space point along `ray` with the given ray-march offset in [0, 1). */
+void oracle_sky_generate_luts(const OracleScene* scene, float* transmittance, float* multiscattering);
+void oracle_sky_color(const OracleScene* scene, const float origin_world[3], const float ray[3], int include_sun, float random_offset, float out[3]);
 float oracle_log2(float x);
 float oracle_exp2(float x);
 float oracle_pow(float x, float y);

@@ -1,0 +1,115 @@
+"""Procedural sky (first part): look-up tables, the colour of rays that leave the scene, the sun disk.
+CPU part: properties of the oracle restatement. GPU part: tables and images against the oracle, bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from luminary_amd import SKY_MODE_DEFAULT, scenes
+from luminary_amd.core import Core
+
+W, H = 72, 40
+
+
+def _scene(bounces=3, altitude=0.5, azimuth=3.141):
+    host = scenes.example_scene(W, H, bounces, sphere_segments=8, ground_res=16, num_objects=24, num_lights=4)
+    sky = host.get_sky()
+    sky.mode = SKY_MODE_DEFAULT
+    sky.altitude, sky.azimuth = altitude, azimuth
+    host.set_sky(sky)
+    return host
+
+
+_LUT_CACHE = {}
+
+
+def _oracle_luts(view):
+    key = (tuple(view.sky_sun_pos), tuple(view.sky_mie_phase), view.sky_base_density)
+    if key not in _LUT_CACHE:
+        tm = np.zeros(2 * 64 * 256 * 4, np.float32)
+        ms = np.zeros(2 * 32 * 32 * 4, np.float32)
+        oracle_lib.lib().oracle_sky_generate_luts(C.byref(view), tm.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
+        _LUT_CACHE[key] = (tm, ms)
+    return _LUT_CACHE[key]
+
+
+def _with_sky_luts(view):
+    v = oracle_lib.with_luts(view)
+    tm, ms = _oracle_luts(view)
+    v.sky_lut_transmittance, v.sky_lut_multiscattering = tm.ctypes.data, ms.ctypes.data
+    v._sky_keep = (tm, ms)
+    return v
+
+
+def _sky_color(v, origin, ray, include_sun, offset=0.5):
+    out = (C.c_float * 3)()
+    oracle_lib.lib().oracle_sky_color(C.byref(v), (C.c_float * 3)(*origin), (C.c_float * 3)(*[float(x) for x in ray]), C.c_int(1 if include_sun else 0),
+                                      C.c_float(offset), out)
+    return np.array(list(out), dtype=np.float32)
+
+
+def test_oracle_sky_tables_and_colours():
+    host = _scene()
+    v = _with_sky_luts(host.device_scene())
+    tm, ms = v._sky_keep
+    tm4 = tm.reshape(2, 64, 256, 4)
+    assert np.isfinite(tm).all() and tm.min() >= 0.0 and tm.max() <= 1.0
+    assert np.isfinite(ms).all() and ms.min() >= 0.0 and ms.max() > 0.0
+    # looking straight up from higher in the atmosphere there is less air above: transmittance grows with height (u = 0 is "up")
+    assert (np.diff(tm4[0, :, 0, 1]) >= -1e-6).all() and tm4[0, -1, 0, 1] > tm4[0, 0, 0, 1]
+    # the host layer's sun position: distance to the earth's centre is the sun's distance, direction from azimuth / altitude
+    sun = np.array(list(v.sky_sun_pos), dtype=np.float64) + np.array([0.0, 6371.0 + 0.1, 0.0])
+    assert abs(np.linalg.norm(sun) - 149597870.0) < 1e3
+    assert abs(sun[1] / np.linalg.norm(sun) - np.sin(0.5)) < 1e-5
+    zenith = _sky_color(v, (0, 1, 0), (0, 1, 0), False)
+    horizon = _sky_color(v, (0, 1, 0), (0.9998, 0.02, 0), False)
+    assert zenith[2] > zenith[0] * 2 and zenith.min() > 0.0, "blue sky overhead"
+    assert horizon.sum() > zenith.sum(), "brighter towards the horizon"
+    sun_dir = np.array(list(v.sky_sun_pos)) / np.linalg.norm(list(v.sky_sun_pos))
+    with_disk, without = _sky_color(v, (0, 1, 0), sun_dir, True), _sky_color(v, (0, 1, 0), sun_dir, False)
+    assert with_disk.min() > 1000.0 * without.max(), "the sun disk is only added for camera / emission-allowed rays"
+    down = _sky_color(v, (0, 1, 0), (0, -1, 0), True)
+    assert down.sum() < 0.05 * horizon.sum(), "below the camera is the planet: only the hundred metres of air above the ground scatter"
+    # sunset: the sky near the sun turns red
+    low = _with_sky_luts(_scene(altitude=0.02).device_scene())
+    sd = np.array(list(low.sky_sun_pos)) / np.linalg.norm(list(low.sky_sun_pos))
+    glow = _sky_color(low, (0, 1, 0), (sd[0], sd[1] + 0.05, sd[2]) / np.linalg.norm((sd[0], sd[1] + 0.05, sd[2])), False)
+    assert glow[0] > glow[2]
+
+
+@pytest.mark.gpu
+def test_sky_tables_match_the_oracle():
+    host = _scene()
+    view = host.device_scene()
+    tm, ms = _oracle_luts(view)
+    core = Core(0)
+    try:
+        core.upload(oracle_lib.with_luts(view))  # sky LUT pointers NULL -> generated on the GPU
+        got_tm, got_ms = core.download_sky_luts()
+        assert np.array_equal(got_tm, tm), "transmittance table: %d of %d differ" % ((got_tm != tm).sum(), tm.size)
+        assert np.array_equal(got_ms, ms), "multiscattering table: %d of %d differ" % ((got_ms != ms).sum(), ms.size)
+    finally:
+        core.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("altitude", [0.5, 0.03])
+def test_render_parity_with_the_procedural_sky(altitude):
+    """Open scene under the atmosphere: camera rays see the sky and the sun disk, bounce rays gather sky light."""
+    host = _scene(altitude=altitude)
+    view = _with_sky_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.reset_counters()
+        core.render(0, 3, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
+        assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
+        assert np.array_equal(sm, osm)
+        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert fm.reshape(3, H, W)[:, :4].mean() > 0.0, "the top rows see the sky"
+    finally:
+        core.close()
