@@ -9,6 +9,7 @@
 // the LUTs are float4 pairs filtered in software (clamp addressing, exact lerps) instead of by the texture unit.
 #pragma once
 
+#include "dev_light.h"
 #include "dev_sampler.h"
 #include "dev_scene.h"
 
@@ -18,7 +19,8 @@ constexpr float kSkyEarthRadius = 6371.0f, kSkySunRadius = 696340.0f, kSkySunDis
 constexpr float kSkyAtmoRadius = kSkyAtmoHeight + kSkyEarthRadius;
 constexpr float kSkyHeightOffset = 0.0005f;
 constexpr int kSkyTmWidth = 256, kSkyTmHeight = 64, kSkyMsSize = 32, kSkyMsBase = 16, kSkyMsIter = 256;
-constexpr uint32_t kRndSkyStepOffset = 77;  // RANDOM_TARGET_SKY_STEP_OFFSET by the allocation rule of random.cuh:24-66
+// RANDOM_TARGET_SKY_STEP_OFFSET and RandomSet::LIGHT_SUN<0> (geometry, material.cuh:61) by the allocation rule of random.cuh:24-66
+constexpr uint32_t kRndSkyStepOffset = 77, kRndSunBsdf = 346, kRndSunBsdfMethod = 349, kRndSunRay = 352, kRndSunResampling = 355;
 constexpr float kSkyMieScattering = 3.996f * 0.001f, kSkyMieExtinction = 4.440f * 0.001f;
 
 struct Spectrum { float v[8]; };
@@ -369,6 +371,101 @@ LUM_DEV Col sky_get_color(const SkyView& s, V3 origin, V3 ray, float limit, bool
     if (earth_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(sky_sun_radiance(), s.sun_strength)));
   }
   return sky_color_from_spectrum(result);
+}
+
+// ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ----
+LUM_DEV bool sphere_hit(V3 ray, V3 origin, V3 p, float r) {  // math.cuh:679-696
+  const V3 diff = origin - p;
+  const float d0 = dot(diff, ray), r2 = r * r;
+  const float c = dot(diff, diff) - r2;
+  const V3 k = diff - ray * d0;
+  const float d = r2 - dot(k, k);
+  if (d < 0.0f) return false;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  return (c / q) >= 0.0f;
+}
+// math.cuh:277-299
+LUM_DEV V3 sample_hemisphere_basis(float altitude, float azimuth, V3 basis) {
+  const float sign = copysignf(1.0f, basis.z);
+  const float a = -1.0f / (sign + basis.z);
+  const float b = basis.x * basis.y * a;
+  const V3 u1 = v3(1.0f + sign * basis.x * basis.x * a, sign * b, -sign * basis.x);
+  const V3 u2 = v3(b, sign + basis.y * basis.y * a, -basis.y);
+  float sa, ca, sz, cz;
+  sincos_det(altitude, sa, ca); sincos_det(azimuth, sz, cz);
+  const float c1 = sa * cz, c2 = sa * sz, c3 = ca;
+  return normalize(v3(c1 * u1.x + c2 * u2.x + c3 * basis.x, c1 * u1.y + c2 * u2.y + c3 * basis.y, c1 * u1.z + c2 * u2.z + c3 * basis.z));
+}
+// math.cuh:1393-1419
+LUM_DEV V3 sample_sphere(V3 p, float r, V3 origin, F2 random, float& area) {
+  float r1 = random.x, r2 = random.y;
+  V3 dir = p - origin;
+  const float d = length(dir);
+  if (d < r) { area = 4.0f * kPi; return normalize(sample_ray_sphere(2.0f * r1 - 1.0f, r2)); }
+  r1 = 0.999f * r1; r2 = 0.999f * r2;
+  dir = dir * (1.0f / d);
+  const float angle = asin_det(saturate(r / d));
+  area = 2.0f * kPi * angle * angle;
+  const float u = sqrtf(r1) * angle, v = 2.0f * kPi * r2;
+  return normalize(sample_hemisphere_basis(u, v, dir));
+}
+// sky_utils.cuh:318-347 (no clouds, no HDRI)
+LUM_DEV Col sky_sun_color(const SkyView& s, V3 origin, V3 ray) {
+  const float height = sky_height(origin);
+  const float zenith_cos = dot(normalize(origin), ray);
+  const F2 uv = sky_transmittance_uv(height, zenith_cos);
+  const Spectrum extinction_sun = sp_mul(sp_ident(), sky_lut_fetch(s.tm, kSkyTmWidth, kSkyTmHeight, uv.x, uv.y));
+  return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(sky_sun_radiance(), s.sun_strength)));
+}
+// bsdf_sample_for_sun_pdf<GEOMETRY>, bsdf.cuh:438-458. The reference hands the WORLD-space view vector to the bounded-VNDF density,
+// which reads it as a local one; kept as it is.
+LUM_DEV float sun_bsdf_pdf(const GeoContext& g, V3 L, float reflection_prob, float refraction_prob) {
+  const RayTerms c = analyze_direction(g.params, g.normal, g.V, L);
+  const float roughness = g.params.roughness();
+  if (c.is_refraction) return refraction_prob * pdf_refraction(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, g.params.ior());
+  return reflection_prob * pdf_vndf_bounded(g.V, roughness, c.NdotH, c.NdotV);
+}
+// direct_lighting_sun_create_task + direct_lighting_sun_direct: two candidate directions (BSDF sample, sun solid angle), one kept by
+// resampling. Returns false when there is nothing to trace.
+LUM_DEV bool sample_sun(const DeviceScene& sc, const SkyView& sky, const LocalFrame& lf, const GeoContext& g, const Sampler& smp, Col& light_out, V3& dir_out) {
+  const Energy energy = energy_terms(sc, g.params, world_ndotv(g));  // bsdf_evaluate analyses the direction in world space, like sample_light
+  const V3 sky_pos = world_to_sky(sky, g.position);
+  const bool sun_below_horizon = sph_hit_p0(normalize(sky.sun_pos - sky_pos), sky_pos, kSkyEarthRadius);
+  const bool inside_earth = length(sky_pos) < kSkyEarthRadius;
+  if (sun_below_horizon || inside_earth) return false;
+  const MatParams& p = g.params;
+  // bsdf_sample_for_light_probabilities, bsdf.cuh:355-374
+  const bool translucent = (p.flags & kMatSubstrateMask) == kMatTranslucent;
+  const float w_refl = 1.0f, w_refr = translucent ? 1.0f : 0.0f;
+  const float reflection_prob = w_refl / (w_refl + w_refr), refraction_prob = w_refr / (w_refl + w_refr);
+  // bsdf_sample_for_sun<GEOMETRY>, bsdf.cuh:380-403
+  const float roughness = p.roughness();
+  V3 ray_local;
+  if (smp.next1(kRndSunBsdfMethod) < reflection_prob) ray_local = reflect(lf.V, sample_vndf_bounded(lf.V, roughness, smp.next2(kRndSunBsdf)));
+  else { bool total_reflection; ray_local = refract(lf.V, sample_vndf_caps(lf.V, roughness, smp.next2(kRndSunBsdf)), p.ior(), total_reflection); }
+  const V3 dir_bsdf = normalize(qapply(qinv(lf.to_z), ray_local));
+  Col light_bsdf = splat(0.0f);
+  bool is_refraction;
+  if (sphere_hit(dir_bsdf, sky_pos, sky.sun_pos, kSkySunRadius)) light_bsdf = sky_sun_color(sky, sky_pos, dir_bsdf) * eval_bsdf(energy, g, dir_bsdf, kHintGeneral, is_refraction, 1.0f);
+  float solid_angle;
+  const V3 dir_sa = sample_sphere(sky.sun_pos, kSkySunRadius, sky_pos, smp.next2(kRndSunRay), solid_angle);
+  const Col light_sa = sky_sun_color(sky, sky_pos, dir_sa) * eval_bsdf(energy, g, dir_sa, kHintGeneral, is_refraction, 1.0f);
+  const float target_bsdf = importance(light_bsdf), target_sa = importance(light_sa);
+  const float mis_bsdf = solid_angle / (sun_bsdf_pdf(g, dir_bsdf, reflection_prob, refraction_prob) * solid_angle + 1.0f);
+  const float mis_sa = solid_angle / (sun_bsdf_pdf(g, dir_sa, reflection_prob, refraction_prob) * solid_angle + 1.0f);
+  const float weight_bsdf = target_bsdf * mis_bsdf, weight_sa = target_sa * mis_sa;
+  const float sum_weights = weight_bsdf + weight_sa;
+  if (sum_weights == 0.0f) return false;
+  float target;
+  Col light;
+  if (smp.next1(kRndSunResampling) * sum_weights < weight_bsdf) { dir_out = dir_bsdf; target = target_bsdf; light = light_bsdf; }
+  else { dir_out = dir_sa; target = target_sa; light = light_sa; }
+  light = light * (sum_weights / target);
+  if (target == 0.0f) return false;
+  if (importance(light) == 0.0f) return false;
+  light_out = light;
+  return true;
 }
 
 }  // namespace lum

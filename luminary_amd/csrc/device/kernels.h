@@ -320,6 +320,20 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
             s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
           }
         }
+        else {
+          // procedural sky: the sun is sampled instead (direct_lighting.cuh:262, :279 make the two exclusive outside HDRI mode), so its
+          // packed colour and ray travel in the ambient slots and its visibility ray is the third kind of item
+          Col sun_light; V3 sun_dir;
+          if (sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir)) {
+            const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
+            amb = make_uint4(c.x, c.y, r.x, r.y);
+            if (c.x != 0 || c.y != 0) {
+              want_amb = true;
+              const V3 ar = ray_unpack(r);
+              s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+            }
+          }
+        }
         nee.geo_color_light[i] = geo_cl;
         nee.bsdf_ray_prob[i] = bs_rp; nee.bsdf_weight_sum[i] = bs_ws;
         nee.ambient[i] = amb;
@@ -550,8 +564,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       if (lc.w != 0.0f) { const float4 v = sq.vis[sq.capacity + i]; vis = col(v.x, v.y, v.z); }
       acc = acc + col(lc.x, lc.y, lc.z) * vis;
     }
-    // sun: disabled in constant-colour mode (direct_lighting.cuh:262); procedural sky is out of scope
-    if (sc.sky_mode != kSkyDefault) {  // ambient (direct_lighting.cuh:521-584)
+    {  // sun (procedural sky, direct_lighting.cuh:466-519) or ambient (constant colour, :521-584): exclusive, same slots
       const uint4 amb = nee.ambient[i];
       Col vis = splat(0.0f);
       if (amb.x != 0 || amb.y != 0) { const float4 v = sq.vis[2u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }

@@ -211,6 +211,14 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     if (bsdf_allowed) lb = light_bsdf_get_sample(&luts, &g, &smp);
     const BSDFSample bounce = bsdf_sample(&luts, &g, &smp, 0);
     const bool ambient_allowed = s->sky_mode != SKY_MODE_DEFAULT;
+    /* sun (direct_lighting.cuh:352-383): allowed outside constant-colour mode (:257-263); needs the procedural sky's tables */
+    const bool sun_allowed = s->sky_mode == SKY_MODE_DEFAULT && s->sky_lut_transmittance && s->sky_lut_multiscattering;
+    uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
+    if (sun_allowed) {
+      const OSky sky_v = osky_view(s);
+      RGBF lc; vec3 dir;
+      if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+    }
     uint2_t amb_color = {0, 0}, amb_ray = {0, 0};
     if (ambient_allowed) { /* direct_lighting.cuh:385-403 */
       amb_color = record_pack(c_mul(sky_color, bounce.weight));
@@ -274,7 +282,15 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
         if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, lb.ray, dist, lh_inst, lh_tri, hit.instance_id, hit.tri_id); }
         acc = c_add(acc, c_mul(lc, vis));
       }
-      /* sun: not allowed in constant-colour mode (direct_lighting.cuh:262) and out of scope otherwise -> contributes 0 */
+      { /* direct_lighting.cuh:466-519 without ocean caustics */
+        const bool valid = (sun_color.x != 0 || sun_color.y != 0) && sun_allowed;
+        const vec3 sr = ray_unpack(sun_ray);
+        RGBF vis = c_splat(0.0f);
+        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, sr, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, hit.tri_id); }
+        RGBF lc = c_mul(record_unpack(sun_color), vis);
+        if (!sun_allowed) lc = c_splat(0.0f);
+        acc = c_add(acc, lc);
+      }
       { /* direct_lighting.cuh:521-584 */
         const bool valid = (amb_color.x != 0 || amb_color.y != 0) && ambient_allowed;
         const vec3 ar = ray_unpack(amb_ray);

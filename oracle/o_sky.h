@@ -12,6 +12,7 @@
 #ifndef ORACLE_O_SKY_H
 #define ORACLE_O_SKY_H
 
+#include "o_light.h"
 #include "o_rng.h"
 #include "oracle.h"
 
@@ -26,7 +27,11 @@
 #define SKY_MS_SIZE 32
 #define SKY_MS_BASE 16
 #define SKY_MS_ITER 256
-#define RANDOM_TARGET_SKY_STEP_OFFSET 77u /* allocation rule of random.cuh:24-66 */
+#define RANDOM_TARGET_SKY_STEP_OFFSET 77u /* allocation rule of random.cuh:24-66; the sun targets are RandomSet::LIGHT_SUN<0> (material.cuh:61) */
+#define RT_SUN_BSDF 346u
+#define RT_SUN_BSDF_METHOD 349u
+#define RT_SUN_RAY 352u
+#define RT_SUN_RESAMPLING 355u
 #define SKY_MIE_SCATTERING (3.996f * 0.001f)
 #define SKY_MIE_EXTINCTION (4.440f * 0.001f)
 
@@ -366,6 +371,95 @@ static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, boo
     if (earth_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
   }
   return sky_color_from_spectrum(result);
+}
+
+/* ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ---- */
+static inline bool sphere_hit(vec3 ray, vec3 origin, vec3 p, float r) { /* math.cuh:679-696 */
+  const vec3 diff = v_sub(origin, p);
+  const float d0 = v_dot(diff, ray), r2 = r * r;
+  const float c = v_dot(diff, diff) - r2;
+  const vec3 k = v_sub(diff, v_scale(ray, d0));
+  const float d = r2 - v_dot(k, k);
+  if (d < 0.0f) return false;
+  const float sd = sqrtf(d);
+  const float q = -d0 - copysignf(sd, d0);
+  return (c / q) >= 0.0f;
+}
+static inline vec3 sample_hemisphere_basis(float altitude, float azimuth, vec3 basis) { /* math.cuh:277-299 */
+  const float sign = copysignf(1.0f, basis.z);
+  const float a = -1.0f / (sign + basis.z);
+  const float b = basis.x * basis.y * a;
+  const vec3 u1 = v3(1.0f + sign * basis.x * basis.x * a, sign * b, -sign * basis.x);
+  const vec3 u2 = v3(b, sign + basis.y * basis.y * a, -basis.y);
+  float sa, ca, sz, cz;
+  o_sincos(altitude, &sa, &ca); o_sincos(azimuth, &sz, &cz);
+  const float c1 = sa * cz, c2 = sa * sz, c3 = ca;
+  return v_norm(v3(c1 * u1.x + c2 * u2.x + c3 * basis.x, c1 * u1.y + c2 * u2.y + c3 * basis.y, c1 * u1.z + c2 * u2.z + c3 * basis.z));
+}
+static inline vec3 sample_sphere(vec3 p, float r, vec3 origin, float2_t random, float* area) { /* math.cuh:1393-1419 */
+  float r1 = random.x, r2 = random.y;
+  vec3 dir = v_sub(p, origin);
+  const float d = v_len(dir);
+  if (d < r) { *area = 4.0f * O_PI; return v_norm(sample_ray_sphere(2.0f * r1 - 1.0f, r2)); }
+  r1 = 0.999f * r1; r2 = 0.999f * r2;
+  dir = v_scale(dir, 1.0f / d);
+  const float angle = o_asin(o_saturate(r / d));
+  *area = 2.0f * O_PI * angle * angle;
+  const float u = sqrtf(r1) * angle, v = 2.0f * O_PI * r2;
+  return v_norm(sample_hemisphere_basis(u, v, dir));
+}
+static inline RGBF sky_sun_color(const OSky* s, vec3 origin, vec3 ray) { /* sky_utils.cuh:318-347 */
+  const float height = sky_height(origin);
+  const float zenith_cos = v_dot(v_norm(origin), ray);
+  const float2_t uv = sky_transmittance_uv(height, zenith_cos);
+  const Spectrum extinction_sun = sp_mul(SP_IDENT, sky_lut_fetch(s->tm, SKY_TM_W, SKY_TM_H, uv.x, uv.y));
+  return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+}
+/* bsdf_sample_for_sun_pdf<GEOMETRY>, bsdf.cuh:438-458: the world-space V goes into the bounded-VNDF density as it does there */
+static inline float sun_bsdf_pdf(const GeoCtx* g, vec3 L, float reflection_prob, float refraction_prob) {
+  const BSDFRayCtx c = bsdf_evaluate_analyze(&g->params, g->normal, g->V, L);
+  const float roughness = mp_roughness(&g->params);
+  if (c.is_refraction) return refraction_prob * microfacet_refraction_pdf(roughness, c.NdotH, c.NdotV, c.HdotV, c.HdotL, mp_ior(&g->params));
+  return reflection_prob * microfacet_pdf(g->V, roughness, c.NdotH, c.NdotV);
+}
+/* direct_lighting_sun_create_task + direct_lighting_sun_direct */
+static bool sun_sample(const OSky* sky, const OLuts* l, const GeoCtx* g, const Sampler* smp, RGBF* light_out, vec3* dir_out) {
+  const vec3 sky_pos = world_to_sky(sky, g->position);
+  const bool sun_below_horizon = sph_hit_p0(v_norm(v_sub(sky->sun_pos, sky_pos)), sky_pos, SKY_EARTH_RADIUS);
+  const bool inside_earth = v_len(sky_pos) < SKY_EARTH_RADIUS;
+  if (sun_below_horizon || inside_earth) return false;
+  const MatParams* p = &g->params;
+  const bool translucent = (p->flags & MAT_SUBSTRATE_MASK) == MAT_TRANSLUCENT;
+  const float w_refl = 1.0f, w_refr = translucent ? 1.0f : 0.0f;
+  const float reflection_prob = w_refl / (w_refl + w_refr), refraction_prob = w_refr / (w_refl + w_refr);
+  const Quat rot = q_rotation_to_z(g->normal);
+  const vec3 Vl = q_apply(rot, g->V);
+  const float roughness = mp_roughness(p);
+  vec3 ray_local;
+  if (rnd1(smp, RT_SUN_BSDF_METHOD) < reflection_prob) ray_local = v_reflect(Vl, microfacet_sample_normal(Vl, roughness, rnd2(smp, RT_SUN_BSDF)));
+  else { bool tot; ray_local = refract_vector(Vl, microfacet_refraction_sample_normal(Vl, roughness, rnd2(smp, RT_SUN_BSDF)), mp_ior(p), &tot); }
+  const vec3 dir_bsdf = v_norm(q_apply(q_inverse(rot), ray_local));
+  RGBF light_bsdf = c_splat(0.0f);
+  bool is_refraction;
+  if (sphere_hit(dir_bsdf, sky_pos, sky->sun_pos, SKY_SUN_RADIUS)) light_bsdf = c_mul(sky_sun_color(sky, sky_pos, dir_bsdf), bsdf_evaluate(l, g, dir_bsdf, HINT_GENERAL, &is_refraction, 1.0f));
+  float solid_angle;
+  const vec3 dir_sa = sample_sphere(sky->sun_pos, SKY_SUN_RADIUS, sky_pos, rnd2(smp, RT_SUN_RAY), &solid_angle);
+  const RGBF light_sa = c_mul(sky_sun_color(sky, sky_pos, dir_sa), bsdf_evaluate(l, g, dir_sa, HINT_GENERAL, &is_refraction, 1.0f));
+  const float target_bsdf = c_importance(light_bsdf), target_sa = c_importance(light_sa);
+  const float mis_bsdf = solid_angle / (sun_bsdf_pdf(g, dir_bsdf, reflection_prob, refraction_prob) * solid_angle + 1.0f);
+  const float mis_sa = solid_angle / (sun_bsdf_pdf(g, dir_sa, reflection_prob, refraction_prob) * solid_angle + 1.0f);
+  const float weight_bsdf = target_bsdf * mis_bsdf, weight_sa = target_sa * mis_sa;
+  const float sum_weights = weight_bsdf + weight_sa;
+  if (sum_weights == 0.0f) return false;
+  float target;
+  RGBF light;
+  if (rnd1(smp, RT_SUN_RESAMPLING) * sum_weights < weight_bsdf) { *dir_out = dir_bsdf; target = target_bsdf; light = light_bsdf; }
+  else { *dir_out = dir_sa; target = target_sa; light = light_sa; }
+  light = c_scale(light, sum_weights / target);
+  if (target == 0.0f) return false;
+  if (c_importance(light) == 0.0f) return false;
+  *light_out = light;
+  return true;
 }
 
 #endif

@@ -113,3 +113,16 @@ def test_render_parity_with_the_procedural_sky(altitude):
         assert fm.reshape(3, H, W)[:, :4].mean() > 0.0, "the top rows see the sky"
     finally:
         core.close()
+
+
+def test_oracle_sun_lights_the_ground():
+    """Sun next-event estimation: with the sun up the ground is lit by it through extra visibility rays; below the horizon no sun ray is
+    traced and only the faint sky remains."""
+    day = _with_sky_luts(_scene(altitude=0.5).device_scene())
+    night = _with_sky_luts(_scene(altitude=-0.2).device_scene())
+    fm_d, _, cnt_d = oracle_lib.render(day, 0, 1)
+    fm_n, _, cnt_n = oracle_lib.render(night, 0, 1)
+    assert cnt_d[0] == cnt_n[0] and cnt_d[3] == cnt_n[3], "same paths (the sun does not change the bounce directions)"
+    assert cnt_d[1] > cnt_n[1] + 1000, "sun rays are counted with the shadow rays"
+    ground_d, ground_n = fm_d.reshape(3, H, W)[:, -10:].mean(), fm_n.reshape(3, H, W)[:, -10:].mean()
+    assert ground_d > 20.0 * ground_n
