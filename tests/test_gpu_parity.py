@@ -148,7 +148,8 @@ def test_render_parity_material_zoo(core, sky_mode, aperture, blades):
     non-uniformly scaled instances, a light tree with node descent (320 light triangles), both sky modes and the lens aperture:
     moments and ray counters identical to the oracle."""
     host = scenes.zoo_scene(96, 64, 8, sky_mode=sky_mode, aperture=aperture, blades=blades)
-    view = oracle_lib.with_luts(host.device_scene())
+    # sky mode DEFAULT is the procedural atmosphere with sun sampling: the oracle needs its two tables (the GPU is handed the same ones)
+    view = oracle_lib.with_sky_luts(host.device_scene()) if sky_mode == 0 else oracle_lib.with_luts(host.device_scene())
     assert view.num_light_tree_nodes > 0, "the scene must force light-tree descent"
     core.upload(view)
     core.set_pixels(None)

@@ -21,25 +21,8 @@ def _scene(bounces=3, altitude=0.5, azimuth=3.141):
     return host
 
 
-_LUT_CACHE = {}
-
-
-def _oracle_luts(view):
-    key = (tuple(view.sky_sun_pos), tuple(view.sky_mie_phase), view.sky_base_density)
-    if key not in _LUT_CACHE:
-        tm = np.zeros(2 * 64 * 256 * 4, np.float32)
-        ms = np.zeros(2 * 32 * 32 * 4, np.float32)
-        oracle_lib.lib().oracle_sky_generate_luts(C.byref(view), tm.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
-        _LUT_CACHE[key] = (tm, ms)
-    return _LUT_CACHE[key]
-
-
-def _with_sky_luts(view):
-    v = oracle_lib.with_luts(view)
-    tm, ms = _oracle_luts(view)
-    v.sky_lut_transmittance, v.sky_lut_multiscattering = tm.ctypes.data, ms.ctypes.data
-    v._sky_keep = (tm, ms)
-    return v
+_oracle_luts = oracle_lib.sky_luts
+_with_sky_luts = oracle_lib.with_sky_luts
 
 
 def _sky_color(v, origin, ray, include_sun, offset=0.5):
