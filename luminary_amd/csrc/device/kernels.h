@@ -210,6 +210,9 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 }
 
 // ---- shading pass: cuda/geometry.cuh:11-180 (+ miss handling of cuda/sky.cuh:609-633, roulette cuda/directives.cuh:11-32) ----
+// Two instantiations: the procedural sky adds sun sampling (a third of the kernel's code again) that a constant-colour scene never runs
+// but would pay for in registers and instruction cache; kProceduralSky == (sc.sky_mode == kSkyDefault), chosen at launch.
+template <bool kProceduralSky>
 __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
   const uint32_t n = ctrl[kCtlPaths];
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         if (in.hit_id[i].x == kHitSky) {
           const uint4 aux = in.aux[i];
           if (aux.w & kStAllowAmbient) {
-            if (sc.sky_mode == kSkyDefault) is_sky = true;  // the atmosphere is ray-marched by k_sky
+            if (kProceduralSky) is_sky = true;  // the atmosphere is ray-marched by k_sky
             else add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
           }
         }
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         if (LUM_ABLATE & 4) { bounce.ray = g.normal; bounce.weight = splat(0.5f); bounce.transparent_pass = false; bounce.microfacet_based = false; }
         else bounce = sample_bounce(lf, g, smp, 0);
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
-        if (sc.sky_mode != kSkyDefault) {
+        if (!kProceduralSky) {
           const U2 c = record_pack(sky * bounce.weight), r = ray_pack(bounce.ray);
           amb = make_uint4(c.x, c.y, r.x, r.y);
           if (c.x != 0 || c.y != 0) {
@@ -356,7 +359,7 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         record = record * bounce.weight;
 
         uint32_t new_state = state | kStUseIgnoreHandle;
-        if (sc.sky_mode != kSkyDefault && !pass_through) new_state &= ~kStAllowAmbient; else new_state |= kStAllowAmbient;
+        if (!kProceduralSky && !pass_through) new_state &= ~kStAllowAmbient; else new_state |= kStAllowAmbient;
         if (!is_delta) new_state &= ~kStDeltaPath;
         if (!pass_through) new_state &= ~(kStCameraDirection | kStAllowEmission);
 

@@ -621,8 +621,12 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      hipLaunchKernelGGL(k_shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
-                         depth_const, ctx->d_counters);
+      if (sc.sky_mode == kSkyDefault)
+        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
+                           depth_const, ctx->d_counters);
+      else
+        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
+                           depth_const, ctx->d_counters);
     }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
