@@ -153,3 +153,29 @@ def test_adaptive_rendering_through_the_api(tmp_path):
     o.render(2)
     assert np.array_equal(fm, o.fm.reshape(3, -1)) and np.array_equal(sm, o.sm)
     host.release_output(handle)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tonemap,max_rate,avg_rate", [(0, 256, 8), (1, 3, 9), (6, 2, 1)])
+def test_adaptive_parity_other_settings(tmp_path_factory, tonemap, max_rate, avg_rate):
+    """Tone curves of the compression factor (none, ACES, custom AgX), a rate cap of 256 with a high mean rate (large executions),
+    a mean rate above the cap (clamped like adaptive_sampler_setup does)."""
+    view = _scene(tmp_path_factory)
+    tone = default_output_params(W, H, 1)
+    tone.tonemap = tonemap
+    tone.agx_slope, tone.agx_power, tone.agx_saturation = 1.1, 1.2, 0.9
+    o = oracle_lib.AdaptiveOracle(view, max_rate, avg_rate, 1, exposure=2.0, tone=tone)
+    o.render(1 + 2 + 2)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.adaptive_begin(max_rate, avg_rate, 1, exposure=2.0, tone=tone)
+        core.adaptive_render(5)
+        counts, variance = core.adaptive_download()
+        assert np.array_equal(counts, o.stage_counts) and np.array_equal(variance, o.block_variance)
+        fm, sm = core.accumulators()
+        assert np.array_equal(fm, o.fm.reshape(3, -1)) and np.array_equal(sm, o.sm)
+        assert np.array_equal(core.generate_result(mode=2, exposure=2.0, tone=tone), o.result(mode=2, exposure=2.0, tone=tone))
+    finally:
+        core.close()

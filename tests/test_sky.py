@@ -109,3 +109,45 @@ def test_oracle_sun_lights_the_ground():
     assert cnt_d[1] > cnt_n[1] + 1000, "sun rays are counted with the shadow rays"
     ground_d, ground_n = fm_d.reshape(3, H, W)[:, -10:].mean(), fm_n.reshape(3, H, W)[:, -10:].mean()
     assert ground_d > 20.0 * ground_n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["no_ozone", "dense_high_camera", "few_steps_translucent"])
+def test_sky_variants_match_the_oracle(variant):
+    """Other corners of the atmosphere's parameter space: ozone off, a denser atmosphere seen from 3 km up with a shifted planet centre,
+    very few ray-march steps; the zoo scene adds translucent and transparent surfaces to the sun sampling."""
+    if variant == "few_steps_translucent":
+        host = scenes.zoo_scene(64, 40, 5, sky_mode=SKY_MODE_DEFAULT)
+    else:
+        host = _scene(bounces=2)
+    sky = host.get_sky()
+    sky.mode = SKY_MODE_DEFAULT
+    if variant == "no_ozone":
+        sky.ozone_absorption = False
+        sky.mie_diameter = 20.0            # the first branch of the phase-function fit
+    elif variant == "dense_high_camera":
+        sky.base_density, sky.rayleigh_density, sky.mie_density, sky.ground_visibility = 1.5, 1.2, 2.0, 20.0
+        sky.geometry_offset.x, sky.geometry_offset.y, sky.geometry_offset.z = 5.0, 3.0, -2.0
+        sky.sun_strength, sky.multiscattering_factor, sky.mie_diameter = 2.0, 0.5, 0.5
+        sky.altitude, sky.azimuth = 0.15, 1.0
+    else:
+        sky.steps = 3
+        sky.altitude = 1.2
+    host.set_sky(sky)
+    view = oracle_lib.with_sky_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(oracle_lib.with_luts(host.device_scene()))  # tables generated on the GPU
+        got_tm, got_ms = core.download_sky_luts()
+        tm, ms = oracle_lib.sky_luts(host.device_scene())
+        assert np.array_equal(got_tm, tm) and np.array_equal(got_ms, ms), "tables"
+        core.set_pixels(None)
+        core.reset_counters()
+        core.render(1, 2, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        ofm, osm, ocnt = oracle_lib.render(view, 1, 2)
+        assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
+        assert np.array_equal(sm, osm)
+        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    finally:
+        core.close()
