@@ -629,7 +629,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
                            depth_const, ctx->d_counters);
     }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
-      Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+      Launch l(ctx, stream, LUMC_KERNEL_SKY);
       hipLaunchKernelGGL(k_sky, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     {
