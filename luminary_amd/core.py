@@ -44,7 +44,7 @@ class AdaptiveParams(C.Structure):
 class AdaptiveInfo(C.Structure):
     """include/lum_core.h LumAdaptiveInfo."""
     _fields_ = [("stage_id", C.c_uint32), ("executions", C.c_uint32 * 5), ("num_blocks", C.c_uint32), ("blocks_x", C.c_uint32), ("blocks_y", C.c_uint32),
-                ("tasks_per_execution", C.c_uint32), ("variance_total", C.c_float)]
+                ("tasks_per_execution", C.c_uint32), ("variance_total", C.c_float), ("build_pending", C.c_uint32)]
 
 
 class Core:
@@ -169,7 +169,7 @@ class Core:
         self._call("lumc_adaptive_info", C.byref(info))
         return {"stage_id": int(info.stage_id), "executions": [int(x) for x in info.executions], "num_blocks": int(info.num_blocks),
                 "blocks": (int(info.blocks_x), int(info.blocks_y)), "tasks_per_execution": int(info.tasks_per_execution),
-                "variance_total": float(info.variance_total)}
+                "variance_total": float(info.variance_total), "build_pending": bool(info.build_pending)}
 
     def adaptive_download(self):
         n = self.adaptive_info()["num_blocks"]
@@ -177,6 +177,21 @@ class Core:
         variance = np.zeros(n, dtype=np.float32)
         self._call("lumc_adaptive_download", counts.ctypes.data_as(C.c_void_p), variance.ctypes.data_as(C.c_void_p))
         return counts, variance
+
+    def adaptive_set_partition(self, block_mask):
+        """Blocks (4x4 pixels, row-major) this context renders: uint8 array of num_blocks entries."""
+        m = np.ascontiguousarray(block_mask, dtype=np.uint8)
+        assert m.size == self.adaptive_info()["num_blocks"]
+        self._call("lumc_adaptive_set_partition", m.ctypes.data_as(C.c_void_p))
+
+    def adaptive_variance(self):
+        v = np.zeros(self.adaptive_info()["num_blocks"], dtype=np.float32)
+        self._call("lumc_adaptive_variance", v.ctypes.data_as(C.c_void_p))
+        return v
+
+    def adaptive_build_from(self, block_variance):
+        v = np.ascontiguousarray(block_variance, dtype=np.float32)
+        self._call("lumc_adaptive_build_from", v.ctypes.data_as(C.c_void_p))
 
     def adaptive_end(self):
         self._call("lumc_adaptive_end")

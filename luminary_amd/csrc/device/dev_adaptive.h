@@ -33,12 +33,13 @@ struct AdaptiveView {
   uint32_t stage_id;
 };
 
-LUM_DEV uint32_t adaptive_stage_count(uint32_t packed, uint32_t stage) { return ((packed >> ((stage - 1u) * 8u)) & 0xFFu) + 1u; }  // stage in 1..4
+// samples per pixel and execution of `stage`: one in stage 0, the block's rate in stages 1..4
+LUM_DEV uint32_t adaptive_stage_count(uint32_t packed, uint32_t stage) { return stage ? ((packed >> ((stage - 1u) * 8u)) & 0xFFu) + 1u : 1u; }
 // adaptive_sampling.cuh:57-76 / :78-105: samples a pixel of this block has received = id of its next sample
 LUM_DEV uint32_t adaptive_pixel_samples(const AdaptiveView& a, uint32_t packed) {
   uint32_t n = a.executions[0];
 #pragma unroll
-  for (uint32_t s = 1; s <= kAdaptiveStages; s++) n += a.executions[s] * adaptive_stage_count(packed, s);
+  for (uint32_t s = 1; s <= kAdaptiveStages; s++) n += a.executions[s] * (((packed >> ((s - 1u) * 8u)) & 0xFFu) + 1u);
   return n;
 }
 LUM_DEV uint32_t adaptive_block_of(const AdaptiveView& a, uint32_t x, uint32_t y) { return (x >> kAdaptiveBlockLog) + (y >> kAdaptiveBlockLog) * a.blocks_x; }
@@ -105,7 +106,7 @@ __global__ void k_adaptive_sum_total(const float* __restrict__ partial, uint32_t
 // Also writes the tasks of that stage per block (16 pixels x rate) for the prefix sum.
 __global__ __launch_bounds__(256) void k_adaptive_stage_counts(const float* __restrict__ block_variance, const float* __restrict__ total, uint32_t num_blocks,
                                                               uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, uint32_t* __restrict__ stage_counts,
-                                                              uint32_t* __restrict__ block_tasks) {
+                                                              uint32_t* __restrict__ block_tasks, const uint8_t* __restrict__ block_mask) {
   const uint32_t block = blockIdx.x * 256u + threadIdx.x;
   if (block >= num_blocks) return;
   const float avg_variance = *total / (float) num_blocks;
@@ -119,7 +120,13 @@ __global__ __launch_bounds__(256) void k_adaptive_stage_counts(const float* __re
   rate = min(rate, max_rate);
   packed |= (rate - 1u) << (current_stage * 8u);
   stage_counts[block] = packed;
-  block_tasks[block] = rate << (2u * kAdaptiveBlockLog);
+  // image-tile partition over GPUs: every rank knows every block's rate, but only creates tasks for the blocks it owns
+  block_tasks[block] = (!block_mask || block_mask[block]) ? rate << (2u * kAdaptiveBlockLog) : 0u;
+}
+// Tasks per block of a stage-0 execution under a partition (one sample per pixel of the owned blocks).
+__global__ __launch_bounds__(256) void k_adaptive_uniform_tasks(const uint8_t* __restrict__ block_mask, uint32_t num_blocks, uint32_t* __restrict__ block_tasks) {
+  const uint32_t block = blockIdx.x * 256u + threadIdx.x;
+  if (block < num_blocks) block_tasks[block] = block_mask[block] ? 1u << (2u * kAdaptiveBlockLog) : 0u;
 }
 
 // tasks_create_adaptive_sampling (cuda/kernels.cuh:195-355): task -> (block, pixel of the block, sample of this execution).
@@ -194,7 +201,9 @@ __global__ __launch_bounds__(256) void k_accumulate_adaptive(AdaptiveView a, Ada
     const uint32_t packed = a.stage_counts[block];
     const uint32_t per_pixel = adaptive_stage_count(packed, a.stage_id) * pass.executions;
     const uint32_t first_id = adaptive_pixel_samples(a, packed);
-    const uint32_t base = (block ? a.block_task_end[block - 1u] * pass.executions : 0u) - pass.task_begin + local * per_pixel;
+    const uint32_t block_begin = block ? a.block_task_end[block - 1u] : 0u;
+    if (a.block_task_end[block] == block_begin) continue;  // a block of another GPU's tiles: no tasks here
+    const uint32_t base = block_begin * pass.executions - pass.task_begin + local * per_pixel;
     float r = first_moment[p], g = first_moment[num_pixels + p], b = first_moment[2 * num_pixels + p];
     float s = second_moment[p];
     for (uint32_t k = 0; k < per_pixel; k++) {

@@ -70,6 +70,8 @@ struct LumContext {
     size_t scan_temp_bytes = 0;
     std::vector<uint32_t> task_end;  // host copy of d_block_task_end: passes are cut at block boundaries
     float variance_total = 0.0f;
+    uint8_t* d_block_mask = nullptr; // image-tile partition over GPUs: blocks this context renders (nullptr = all)
+    bool build_pending = false;      // partitioned: a stage is due and waits for the block variances of all ranks
   } adaptive;
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
@@ -115,7 +117,7 @@ void free_scene(LumContext* ctx) {
 
 void free_adaptive(LumContext* ctx) {
   LumContext::Adaptive& a = ctx->adaptive;
-  void* bufs[] = {a.d_stage_counts, a.d_block_tasks, a.d_block_task_end, a.d_block_variance, a.d_partial, a.d_scan_temp};
+  void* bufs[] = {a.d_stage_counts, a.d_block_tasks, a.d_block_task_end, a.d_block_variance, a.d_partial, a.d_scan_temp, a.d_block_mask};
   for (void* b : bufs) if (b) (void) hipFree(b);
   a = LumContext::Adaptive();
 }
@@ -706,27 +708,48 @@ OutputParams tone_params(const LumOutputParams* p) {
   return op;
 }
 
-// adaptive_sampler_compute_next_stage (device_adaptive_sampler.c:105-215): rates of stage `stage_id + 1` from the variance measured so far
-int adaptive_build_stage(LumContext* ctx, hipStream_t stream) {
+// adaptive_sampler_compute_next_stage (device_adaptive_sampler.c:105-215) in two halves: the block variances measured so far, then the
+// rates of stage `stage_id + 1` from them. Between the halves a partitioned render exchanges the variances of the ranks' blocks.
+int adaptive_compute_variance(LumContext* ctx, hipStream_t stream) {
   LumContext::Adaptive& a = ctx->adaptive;
   const DeviceScene& sc = ctx->scene;
-  const uint32_t nb = a.num_blocks, chunks = (nb + kAdaptiveSumChunk - 1) / kAdaptiveSumChunk;
   const AdaptiveView view = adaptive_view(ctx);
   const OutputParams op = tone_params(&a.params.tone);
-  hipLaunchKernelGGL(k_adaptive_block_variance, dim3((nb * 16 + 255) / 256), dim3(256), 0, stream, view, op, sc.width, sc.height, a.params.exposure,
+  hipLaunchKernelGGL(k_adaptive_block_variance, dim3((a.num_blocks * 16 + 255) / 256), dim3(256), 0, stream, view, op, sc.width, sc.height, a.params.exposure,
                      (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment, a.d_block_variance);
-  hipLaunchKernelGGL(k_adaptive_sum_chunks, dim3((chunks + 63) / 64), dim3(64), 0, stream, (const float*) a.d_block_variance, nb, a.d_partial);
-  hipLaunchKernelGGL(k_adaptive_sum_total, dim3(1), dim3(1), 0, stream, (const float*) a.d_partial, chunks, a.d_partial + chunks);
-  hipLaunchKernelGGL(k_adaptive_stage_counts, dim3((nb + 255) / 256), dim3(256), 0, stream, (const float*) a.d_block_variance, (const float*) (a.d_partial + chunks), nb,
-                     a.stage_id, a.params.max_sampling_rate, a.params.avg_sampling_rate, a.d_stage_counts, a.d_block_tasks);
   HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+// Inclusive prefix over d_block_tasks and its host copy (passes are cut at block boundaries).
+int adaptive_task_prefix(LumContext* ctx, hipStream_t stream) {
+  LumContext::Adaptive& a = ctx->adaptive;
+  const uint32_t nb = a.num_blocks;
   HIP_TRY(ctx, hipcub::DeviceScan::InclusiveSum(a.d_scan_temp, a.scan_temp_bytes, a.d_block_tasks, a.d_block_task_end, (int) nb, stream));
   a.task_end.resize(nb);
   HIP_TRY(ctx, hipMemcpyAsync(a.task_end.data(), a.d_block_task_end, sizeof(uint32_t) * nb, hipMemcpyDeviceToHost, stream));
-  HIP_TRY(ctx, hipMemcpyAsync(&a.variance_total, a.d_partial + chunks, sizeof(float), hipMemcpyDeviceToHost, stream));
   HIP_TRY(ctx, hipStreamSynchronize(stream));
-  a.stage_id++;
   return 0;
+}
+
+int adaptive_finish_build(LumContext* ctx, hipStream_t stream) {
+  LumContext::Adaptive& a = ctx->adaptive;
+  const uint32_t nb = a.num_blocks, chunks = (nb + kAdaptiveSumChunk - 1) / kAdaptiveSumChunk;
+  hipLaunchKernelGGL(k_adaptive_sum_chunks, dim3((chunks + 63) / 64), dim3(64), 0, stream, (const float*) a.d_block_variance, nb, a.d_partial);
+  hipLaunchKernelGGL(k_adaptive_sum_total, dim3(1), dim3(1), 0, stream, (const float*) a.d_partial, chunks, a.d_partial + chunks);
+  hipLaunchKernelGGL(k_adaptive_stage_counts, dim3((nb + 255) / 256), dim3(256), 0, stream, (const float*) a.d_block_variance, (const float*) (a.d_partial + chunks), nb,
+                     a.stage_id, a.params.max_sampling_rate, a.params.avg_sampling_rate, a.d_stage_counts, a.d_block_tasks, (const uint8_t*) a.d_block_mask);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipMemcpyAsync(&a.variance_total, a.d_partial + chunks, sizeof(float), hipMemcpyDeviceToHost, stream));
+  if (adaptive_task_prefix(ctx, stream)) return 1;
+  a.stage_id++;
+  a.build_pending = false;
+  return 0;
+}
+
+int adaptive_build_stage(LumContext* ctx, hipStream_t stream) {
+  if (adaptive_compute_variance(ctx, stream)) return 1;
+  return adaptive_finish_build(ctx, stream);
 }
 
 // `merged` consecutive executions of stage >= 1 as one set of passes of whole blocks (tasks_create_adaptive_sampling + the usual depth
@@ -808,6 +831,7 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
   hipStream_t stream = (hipStream_t) stream_;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   LumContext::Adaptive& a = ctx->adaptive;
+  if (a.build_pending) { ctx->error = "lumc_adaptive_render: a stage build is pending (lumc_adaptive_variance / lumc_adaptive_build_from)"; return 1; }
   while (executions > 0) {
     const uint32_t s = a.stage_id;
     // stage s lasts update_interval << s executions (device_renderer.c:364-371); the last stage never ends
@@ -816,7 +840,7 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
       const uint64_t due = (uint64_t) a.params.update_interval << s;
       run = (uint32_t) std::min<uint64_t>(run, due > a.executions[s] ? due - a.executions[s] : 0);
     }
-    if (s == 0) {
+    if (s == 0 && !a.d_block_mask) {
       // one sample id for every pixel per execution: the uniform wavefront pass, several executions per pass
       if (run && lumc_render(ctx, a.executions[0], run, std::min(run, 8u), nullptr, nullptr, stream_)) return 1;
       a.executions[0] += run;
@@ -833,10 +857,42 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
     }
     executions -= run;
     if (s < kAdaptiveStages && a.executions[s] >= ((uint64_t) a.params.update_interval << s)) {
+      // partitioned: the rates need the block variances of every rank; stop here and let the caller exchange them
+      if (a.d_block_mask) { a.build_pending = true; return 0; }
       if (adaptive_build_stage(ctx, stream)) return 1;
     }
   }
   return 0;
+}
+
+int lumc_adaptive_set_partition(LumContext* ctx, const uint8_t* block_mask) {
+  if (!ctx || !ctx->adaptive.active || !block_mask) { if (ctx) ctx->error = "lumc_adaptive_set_partition: adaptive mode is not active or null mask"; return 1; }
+  LumContext::Adaptive& a = ctx->adaptive;
+  for (uint32_t s = 0; s <= kAdaptiveStages; s++)
+    if (a.executions[s]) { ctx->error = "lumc_adaptive_set_partition: call it before the first execution"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (!a.d_block_mask) HIP_TRY(ctx, hipMalloc((void**) &a.d_block_mask, a.num_blocks));
+  HIP_TRY(ctx, hipMemcpy(a.d_block_mask, block_mask, a.num_blocks, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_adaptive_uniform_tasks, dim3((a.num_blocks + 255) / 256), dim3(256), 0, 0, (const uint8_t*) a.d_block_mask, a.num_blocks, a.d_block_tasks);
+  HIP_TRY(ctx, hipGetLastError());
+  return adaptive_task_prefix(ctx, (hipStream_t) 0);
+}
+
+int lumc_adaptive_variance(LumContext* ctx, float* block_variance) {
+  if (!ctx || !ctx->adaptive.active || !block_variance) { if (ctx) ctx->error = "lumc_adaptive_variance: adaptive mode is not active or null buffer"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (adaptive_compute_variance(ctx, (hipStream_t) 0)) return 1;
+  HIP_TRY(ctx, hipMemcpy(block_variance, ctx->adaptive.d_block_variance, sizeof(float) * ctx->adaptive.num_blocks, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_adaptive_build_from(LumContext* ctx, const float* block_variance) {
+  if (!ctx || !ctx->adaptive.active || !block_variance) { if (ctx) ctx->error = "lumc_adaptive_build_from: adaptive mode is not active or null buffer"; return 1; }
+  LumContext::Adaptive& a = ctx->adaptive;
+  if (a.stage_id >= kAdaptiveStages) { ctx->error = "lumc_adaptive_build_from: the last stage is already running"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(a.d_block_variance, block_variance, sizeof(float) * a.num_blocks, hipMemcpyHostToDevice));
+  return adaptive_finish_build(ctx, (hipStream_t) 0);
 }
 
 int lumc_adaptive_info(LumContext* ctx, LumAdaptiveInfo* out) {
@@ -845,8 +901,9 @@ int lumc_adaptive_info(LumContext* ctx, LumAdaptiveInfo* out) {
   out->stage_id = a.stage_id;
   for (uint32_t s = 0; s <= kAdaptiveStages; s++) out->executions[s] = a.executions[s];
   out->num_blocks = a.num_blocks; out->blocks_x = a.blocks_x; out->blocks_y = a.blocks_y;
-  out->tasks_per_execution = (a.stage_id == 0 || a.task_end.empty()) ? a.num_blocks * 16u : a.task_end.back();
+  out->tasks_per_execution = a.task_end.empty() ? a.num_blocks * 16u : a.task_end.back();
   out->variance_total = a.variance_total;
+  out->build_pending = a.build_pending ? 1u : 0u;
   return 0;
 }
 

@@ -32,3 +32,37 @@ def assemble_frame(first_moment, second_moment, pixels, num_frame_pixels, dist=N
     if dist is not None:
         dist.reduce(full, dst=dst, op=dist.ReduceOp.SUM)
     return full
+
+
+def block_mask(width, height, rank, world, tile=32):
+    """Adaptive-sampling blocks (4x4 pixels, row-major over ceil(w/4) x ceil(h/4)) owned by `rank` under the same tile deal as
+    tile_pixels: a block belongs to the rank of the tile it lies in (tiles are whole blocks: tile % 4 == 0)."""
+    assert tile % 4 == 0
+    bx, by = (width + 3) // 4, (height + 3) // 4
+    tx = (width + tile - 1) // tile
+    ys, xs = np.meshgrid(np.arange(by), np.arange(bx), indexing="ij")
+    tile_id = (xs * 4) // tile + ((ys * 4) // tile) * tx
+    return (tile_id % world == rank).astype(np.uint8).ravel()
+
+
+def adaptive_render(core, executions, dist=None, device=None):
+    """Runs `executions` executions of adaptive rendering on a partitioned context (Core.adaptive_set_partition). When a stage is due,
+    the ranks' block variances are summed with ONE all-reduce (every block has one owner, so the sum is a gather; 4 bytes per block)
+    and every rank builds the same rates from the complete array. `dist` None = a single rank (the exchange is the identity)."""
+    import torch
+    remaining = executions
+    while remaining > 0:
+        before = sum(core.adaptive_info()["executions"])
+        core.adaptive_render(remaining)
+        info = core.adaptive_info()
+        remaining -= sum(info["executions"]) - before
+        if info["build_pending"]:
+            var = torch.from_numpy(core.adaptive_variance())
+            if dist is not None:
+                if device is not None:
+                    var = var.to(device)
+                dist.all_reduce(var, op=dist.ReduceOp.SUM)
+                var = var.cpu()
+            core.adaptive_build_from(var.numpy())
+        elif remaining > 0 and sum(info["executions"]) == before:
+            raise RuntimeError("adaptive_render made no progress")

@@ -532,6 +532,22 @@ void oracle_adaptive_build_stage(
   if (!block_variance) free(bv);
 }
 
+/* The two halves of the stage build, for a render partitioned over ranks: block variances of this rank's accumulators, then the rates
+ * from the complete variance array. */
+void oracle_adaptive_block_variance(
+  uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t current_stage, float exposure, const OracleOutputParamsAbi* op,
+  const float* first_moment, const float* second_moment, const uint32_t* stage_counts, float* block_variance) {
+  const OAdaptive a = adaptive_view(width, height, executions, current_stage, stage_counts);
+  oa_block_variance(&a, (const OracleOutputParams*) op, width, height, exposure, first_moment, second_moment, block_variance);
+}
+float oracle_adaptive_counts_from(
+  uint32_t width, uint32_t height, uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, const float* block_variance, uint32_t* stage_counts) {
+  const uint32_t nb = ((width + 3u) >> 2) * ((height + 3u) >> 2);
+  const float t = oa_variance_total(block_variance, nb);
+  oa_stage_counts(block_variance, t, nb, current_stage, max_rate, avg_rate, stage_counts);
+  return t;
+}
+
 void oracle_pixel_samples(uint32_t width, uint32_t height, const uint32_t executions[5], const uint32_t* stage_counts, uint32_t* out) {
   const OAdaptive a = adaptive_view(width, height, executions, 0, stage_counts);
   for (uint32_t y = 0; y < height; y++)

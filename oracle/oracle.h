@@ -122,6 +122,11 @@ int oracle_render_counts(
 void oracle_adaptive_build_stage(
   uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, float exposure,
   const OracleOutputParamsAbi* op, const float* first_moment, const float* second_moment, uint32_t* stage_counts, float* block_variance, float* total);
+void oracle_adaptive_block_variance(
+  uint32_t width, uint32_t height, const uint32_t executions[5], uint32_t current_stage, float exposure, const OracleOutputParamsAbi* op,
+  const float* first_moment, const float* second_moment, const uint32_t* stage_counts, float* block_variance);
+float oracle_adaptive_counts_from(
+  uint32_t width, uint32_t height, uint32_t current_stage, uint32_t max_rate, uint32_t avg_rate, const float* block_variance, uint32_t* stage_counts);
 void oracle_pixel_samples(uint32_t width, uint32_t height, const uint32_t executions[5], const uint32_t* stage_counts, uint32_t* out);
 void oracle_generate_result(
   uint32_t width, uint32_t height, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const uint32_t executions[5],

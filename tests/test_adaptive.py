@@ -179,3 +179,57 @@ def test_adaptive_parity_other_settings(tmp_path_factory, tonemap, max_rate, avg
         assert np.array_equal(core.generate_result(mode=2, exposure=2.0, tone=tone), o.result(mode=2, exposure=2.0, tone=tone))
     finally:
         core.close()
+
+
+def test_block_mask_partitions_the_blocks():
+    from luminary_amd.distributed import block_mask, tile_pixels
+    w, h, world = 100, 70, 3
+    masks = [block_mask(w, h, r, world, tile=16) for r in range(world)]
+    assert np.array_equal(sum(m.astype(int) for m in masks), np.ones(25 * 18, dtype=int)), "every block has exactly one owner"
+    for r in range(world):  # a rank's blocks cover exactly its pixels
+        px = tile_pixels(w, h, r, world, tile=16)
+        owned = masks[r].reshape(18, 25)[(px // w) // 4, (px % w) // 4]
+        assert owned.all() and int(masks[r].sum()) * 16 >= px.size
+
+
+@pytest.mark.gpu
+def test_partitioned_adaptive_rendering_equals_one_gpu(tmp_path_factory):
+    """Two ranks emulated by two contexts on one GPU: own blocks only, block variances exchanged at every stage build (here: added in
+    numpy, in the real thing one all-reduce). The summed frame, the rates and the variances equal the single-context run."""
+    from luminary_amd.distributed import block_mask
+    view = _scene(tmp_path_factory)
+    tone = default_output_params(W, H, 1)
+    executions = 2 + 4 + 5
+    o, _ = _oracle_run(view, executions, 1.5)
+    world = 2
+    cores = [Core(0) for _ in range(world)]
+    try:
+        for r, c in enumerate(cores):
+            c.upload(view)
+            c.set_pixels(None)
+            c.adaptive_begin(MAX_RATE, AVG_RATE, INTERVAL, exposure=1.5, tone=tone)
+            c.adaptive_set_partition(block_mask(W, H, r, world, tile=8))
+        remaining = executions
+        while remaining > 0:
+            before = sum(cores[0].adaptive_info()["executions"])
+            for c in cores:
+                c.adaptive_render(remaining)
+            infos = [c.adaptive_info() for c in cores]
+            assert infos[0]["executions"] == infos[1]["executions"] and infos[0]["build_pending"] == infos[1]["build_pending"]
+            remaining -= sum(infos[0]["executions"]) - before
+            if infos[0]["build_pending"]:
+                parts = [c.adaptive_variance() for c in cores]
+                assert not np.any((parts[0] != 0) & (parts[1] != 0)), "a block's variance comes from its owner only"
+                full = parts[0] + parts[1]
+                for c in cores:
+                    c.adaptive_build_from(full)
+        assert cores[0].adaptive_info()["stage_id"] == o.stage_id == 2
+        for c in cores:
+            counts, variance = c.adaptive_download()
+            assert np.array_equal(counts, o.stage_counts) and np.array_equal(variance, o.block_variance)
+        fm = sum(c.accumulators()[0] for c in cores)
+        sm = sum(c.accumulators()[1] for c in cores)
+        assert np.array_equal(fm, o.fm.reshape(3, -1)) and np.array_equal(sm, o.sm)
+    finally:
+        for c in cores:
+            c.close()

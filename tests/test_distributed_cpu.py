@@ -37,3 +37,43 @@ def test_two_rank_tile_partition_and_reduce(tmp_path):
     result = os.path.join(str(tmp_path), "result.txt")
     mp.spawn(_worker, args=(2, port, str(tmp_path), result), nprocs=2, join=True)
     assert open(result).read() == "ok"
+
+
+def _adaptive_worker(rank, world, port, tmp, result_file):
+    """Adaptive rendering partitioned over two ranks: luminary_amd.distributed.adaptive_render drives a per-rank renderer (the oracle
+    standing in for the GPU core, same interface) and exchanges the block variances with one all-reduce per stage build."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle_lib
+    from luminary_amd import scenes
+    from luminary_amd.core import default_output_params
+    from luminary_amd.distributed import adaptive_render, block_mask
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w, h = 40, 24
+    view = oracle_lib.with_luts(scenes.cornell_host(os.path.join(tmp, "a%d" % rank), w, h, 2).device_scene())
+    tone = default_output_params(w, h, 1)
+    core = oracle_lib.AdaptiveOracle(view, 5, 2, 1, exposure=1.0, tone=tone, threads=2)
+    core.adaptive_set_partition(block_mask(w, h, rank, world, tile=8))
+    adaptive_render(core, 1 + 2 + 3, dist)
+    frame = torch.from_numpy(np.concatenate([core.fm, core.sm]))
+    dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # every pixel has one owner: the sum assembles the frame
+    if rank == 0:
+        ref = oracle_lib.AdaptiveOracle(view, 5, 2, 1, exposure=1.0, tone=tone, threads=2)
+        ref.render(1 + 2 + 3)
+        ok = (core.stage_id == ref.stage_id == 2 and np.array_equal(core.stage_counts, ref.stage_counts) and np.array_equal(core.block_variance, ref.block_variance)
+              and np.array_equal(frame.numpy(), np.concatenate([ref.fm, ref.sm])))
+        open(result_file, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_adaptive_rendering(tmp_path):
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    result = os.path.join(str(tmp_path), "result_adaptive.txt")
+    mp.spawn(_adaptive_worker, args=(2, port, str(tmp_path), result), nprocs=2, join=True)
+    assert open(result).read() == "ok"
