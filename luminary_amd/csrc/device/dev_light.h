@@ -96,7 +96,10 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const 
       sum += target;
       // The eight lanes divide by one of two numbers per child; the reciprocals are formed once (the reference, built with
       // --use_fast_math, multiplies by a reciprocal here as well: cuda/ris.cuh:138-148).
-      const float inv_accept = 1.0f / prob, inv_reject = 1.0f / (1.0f - prob);
+      float inv_accept = 1.0f / prob, inv_reject = 1.0f / (1.0f - prob);
+      // keep them two divisions: without the barrier the compiler rewrites `accept ? 1/p : 1/(1-p)` as `1 / (accept ? p : 1-p)` in
+      // each of the eight lanes (same bits, eight correctly rounded divisions of 11 instructions instead of two)
+      asm volatile("" : "+v"(inv_accept), "+v"(inv_reject));
 #pragma unroll
       for (uint32_t l = 0; l < ((LUM_ABLATE_LIGHT & 4) ? 1u : kLightTreeOutputs); l++) {
         const bool accept = lane_random[l] < prob;
