@@ -123,7 +123,9 @@ class DeviceSceneView(C.Structure):
                 ("sky_base_density", C.c_float), ("sky_rayleigh_density", C.c_float), ("sky_mie_density", C.c_float), ("sky_ozone_density", C.c_float),
                 ("sky_rayleigh_falloff", C.c_float), ("sky_mie_falloff", C.c_float), ("sky_ground_visibility", C.c_float),
                 ("sky_ozone_layer_thickness", C.c_float), ("sky_multiscattering_factor", C.c_float), ("sky_sun_pos", C.c_float * 3),
-                ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p)]
+                ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p),
+                ("sky_moon_pos", C.c_float * 3), ("sky_moon_tex_offset", C.c_float), ("sky_moon_albedo_tex", C.c_uint32), ("sky_moon_normal_tex", C.c_uint32),
+                ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2

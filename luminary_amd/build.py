@@ -58,7 +58,9 @@ def build(force=False, verbose=False):
     bn = os.path.join(ROOT, "data", "bluenoise_2D.bin")
     o = os.path.join(OBJ_DIR, "embed.o")
     bn1 = os.path.join(ROOT, "data", "bluenoise_1D.bin")
-    _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, "-DLUM_BLUENOISE_1D_PATH=\"%s\"" % bn1, os.path.join(CSRC, "host", "embed.S"), "-o", o])
+    moon = [os.path.join(ROOT, "data", n) for n in ("moon_albedo.png", "moon_normal.png")]
+    _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, "-DLUM_BLUENOISE_1D_PATH=\"%s\"" % bn1, "-DLUM_MOON_ALBEDO_PATH=\"%s\"" % moon[0],
+          "-DLUM_MOON_NORMAL_PATH=\"%s\"" % moon[1], os.path.join(CSRC, "host", "embed.S"), "-o", o])
     objs.append(o)
     for s in HIP_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")

@@ -81,6 +81,13 @@ struct DeviceScene {
   float sky_mie_phase[4];
   const float4* sky_lut_transmittance;    // low plane [64][256], high plane
   const float4* sky_lut_multiscattering;  // low plane [32][32], high plane
+  float sky_moon_pos[3];
+  float sky_moon_tex_offset;
+  uint32_t sky_moon_albedo_tex, sky_moon_normal_tex;
+  float sky_stars_intensity;
+  uint32_t sky_stars_count;
+  const float4* sky_stars;            // altitude, azimuth, radius, intensity
+  const uint32_t* sky_stars_offsets;  // 64 x 32 + 1
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).

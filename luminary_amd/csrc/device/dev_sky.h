@@ -4,7 +4,7 @@
 // (multiscattering LUT, [Hil20]), :338-446 (ray-marched single scattering + multiscattering), :508-515, :567-577 (sky_color_main),
 // cuda/sky_utils.cuh (spectrum of 8 wavelengths, LUT parametrisation, spectrum -> RGB), cuda/math.cuh:620-779 (sphere tests),
 // :1162-1239 (Henyey-Greenstein / Draine / Jendersie-Eon phase functions), :1429-1439 (solid angle of the sun).
-// Kept out: moon, stars (celestials other than the sun disk), cloud shadows, aerial perspective (off by default), HDRI mode.
+// Kept out: cloud shadows, aerial perspective (off by default), HDRI mode.
 // Numerics contract as everywhere: IEEE + - x / sqrt only; expf := exp2_det(x * log2 e); asinf(x) := atan2_det(x, sqrt(1 - x^2));
 // the LUTs are float4 pairs filtered in software (clamp addressing, exact lerps) instead of by the texture unit.
 #pragma once
@@ -16,6 +16,8 @@
 namespace lum {
 
 constexpr float kSkyEarthRadius = 6371.0f, kSkySunRadius = 696340.0f, kSkySunDistance = 149597870.0f, kSkyAtmoHeight = 100.0f;  // sky_defines.h
+constexpr float kSkyMoonRadius = 1737.4f;
+constexpr float kRefPi = 3.141592653589f;  // the reference's PI (utils.h:14), where it enters texture coordinates and grid cells
 constexpr float kSkyAtmoRadius = kSkyAtmoHeight + kSkyEarthRadius;
 constexpr float kSkyHeightOffset = 0.0005f;
 constexpr int kSkyTmWidth = 256, kSkyTmHeight = 64, kSkyMsSize = 32, kSkyMsBase = 16, kSkyMsIter = 256;
@@ -96,6 +98,7 @@ LUM_DEV float sphere_int(V3 ray, V3 origin, V3 p, float r) {
   if (t0 >= 0.0f) return t0;
   return (q >= 0.0f) ? q : kFltMax;
 }
+LUM_DEV bool sphere_hit(V3 ray, V3 origin, V3 p, float r);
 LUM_DEV float asin_det(float x) { return atan2_det(x, sqrtf(fmaxf(1.0f - x * x, 0.0f))); }
 // math.cuh:1429-1439
 LUM_DEV float sphere_solid_angle(V3 p, float r, V3 origin) {
@@ -114,6 +117,11 @@ struct SkyView {
   float g_hg, g_d, alpha, w_d;  // Jendersie-Eon parameters of mie_diameter (math.cuh:1189-1232), evaluated once by the host layer
   const float4* tm;             // transmittance LUT: low plane [64][256], then high plane
   const float4* ms;             // multiscattering LUT: low plane [32][32], then high plane
+  V3 moon_pos;
+  float moon_tex_offset, stars_intensity;
+  uint32_t moon_albedo_tex, moon_normal_tex, stars_count;
+  const float4* stars;
+  const uint32_t* stars_offsets;
 };
 
 LUM_DEV SkyView sky_view(const DeviceScene& sc) {
@@ -126,6 +134,10 @@ LUM_DEV SkyView sky_view(const DeviceScene& sc) {
   s.ground_visibility = sc.sky_ground_visibility; s.ozone_layer_thickness = sc.sky_ozone_layer_thickness; s.multiscattering_factor = sc.sky_multiscattering_factor;
   s.g_hg = sc.sky_mie_phase[0]; s.g_d = sc.sky_mie_phase[1]; s.alpha = sc.sky_mie_phase[2]; s.w_d = sc.sky_mie_phase[3];
   s.tm = sc.sky_lut_transmittance; s.ms = sc.sky_lut_multiscattering;
+  s.moon_pos = v3(sc.sky_moon_pos[0], sc.sky_moon_pos[1], sc.sky_moon_pos[2]);
+  s.moon_tex_offset = sc.sky_moon_tex_offset; s.stars_intensity = sc.sky_stars_intensity;
+  s.moon_albedo_tex = sc.sky_moon_albedo_tex; s.moon_normal_tex = sc.sky_moon_normal_tex; s.stars_count = sc.sky_stars_count;
+  s.stars = sc.sky_stars; s.stars_offsets = sc.sky_stars_offsets;
   return s;
 }
 
@@ -331,8 +343,16 @@ __global__ __launch_bounds__(256) void k_sky_multiscattering_lut(DeviceScene sc,
   dst[kSkyMsSize * kSkyMsSize + id] = make_float4(L.v[4], L.v[5], L.v[6], L.v[7]);
 }
 
-// ---- sky_compute_atmosphere (sky.cuh:338-446) with the sun disk as the only celestial body; sky_get_color (:508-515) ----
-LUM_DEV Col sky_get_color(const SkyView& s, V3 origin, V3 ray, float limit, bool celestials, int steps, float random_offset) {
+LUM_DEV Spectrum sky_moon_solar_flux() { return Spectrum{{1.7f, 1.8f, 2.0f, 1.9f, 1.87f, 1.7f, 1.65f, 1.55f}}; }  // sky_utils.cuh:272
+// math.cuh:781-789
+LUM_DEV V3 angles_to_direction(float altitude, float azimuth) {
+  float sa, ca, sz, cz;
+  sincos_det(altitude, sa, ca); sincos_det(azimuth, sz, cz);
+  return v3(cz * ca, sa, sz * ca);
+}
+
+// ---- sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars; sky_get_color (:508-515) ----
+LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3 ray, float limit, bool celestials, int steps, float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const F2 path = sky_compute_path(origin, ray, kSkyEarthRadius, kSkyAtmoRadius);
   const float start = path.x, distance = fminf(path.y, limit - start);
@@ -368,7 +388,47 @@ LUM_DEV Col sky_get_color(const SkyView& s, V3 origin, V3 ray, float limit, bool
   if (celestials) {
     const float sun_hit = sphere_int(ray, origin, s.sun_pos, kSkySunRadius);
     const float earth_hit = sph_int_p0(ray, origin, kSkyEarthRadius);
-    if (earth_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(sky_sun_radiance(), s.sun_strength)));
+    const bool has_moon = s.moon_albedo_tex != 0xFFFFFFFFu;
+    const float moon_hit = has_moon ? sphere_int(ray, origin, s.moon_pos, kSkyMoonRadius) : kFltMax;
+    if (earth_hit > sun_hit && moon_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(sky_sun_radiance(), s.sun_strength)));
+    else if (earth_hit > moon_hit) {
+      const V3 moon_point = origin + ray * moon_hit;
+      const V3 bounce_ray = normalize(s.sun_pos - moon_point);
+      if (!sphere_hit(bounce_ray, moon_point, v3(0.0f, 0.0f, 0.0f), kSkyEarthRadius)) {
+        V3 normal = normalize(moon_point - s.moon_pos);
+        const float tex_u = 0.5f + s.moon_tex_offset + atan2_det(normal.z, normal.x) * (1.0f / (2.0f * kRefPi));
+        const float tex_v = 0.5f + asin_det(normal.y) * (1.0f / kRefPi);
+        const F2 uv = F2{tex_u, tex_v};
+        // create_basis + transform_vec3, math.cuh:301-321, :445-453
+        const float sign = copysignf(1.0f, normal.z);
+        const float a = -1.0f / (sign + normal.z);
+        const float b = normal.x * normal.y * a;
+        const V3 u1 = v3(1.0f + sign * normal.x * normal.x * a, sign * b, -sign * normal.x);
+        const V3 u2 = v3(b, sign + normal.y * normal.y * a, -normal.y);
+        const float4 nv = texture_load(sc, s.moon_normal_tex, uv, true, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        const V3 mn = v3(nv.x * 2.0f - 1.0f, nv.y * 2.0f - 1.0f, nv.z * 2.0f - 1.0f);
+        normal = normalize(v3(u1.x * mn.x + u2.x * mn.y + normal.x * mn.z, u1.y * mn.x + u2.y * mn.y + normal.y * mn.z, u1.z * mn.x + u2.z * mn.y + normal.z * mn.z));
+        const float NdotL = dot(normal, bounce_ray);
+        if (NdotL > 0.0f) {
+          const float albedo = texture_load(sc, s.moon_albedo_tex, uv, true, make_float4(0.0f, 0.0f, 0.0f, 0.0f)).x;
+          const float light_angle = sphere_solid_angle(s.sun_pos, kSkySunRadius, moon_point);
+          const float weight = albedo * s.sun_strength * NdotL * light_angle / (2.0f * kRefPi);
+          result = sp_add(result, sp_mul(transmittance, sp_mul(sky_moon_solar_flux(), sp_scale(sky_sun_radiance(), weight))));
+        }
+      }
+    }
+    if (s.stars != nullptr && sun_hit == kFltMax && earth_hit == kFltMax && moon_hit == kFltMax) {
+      const float ray_altitude = asin_det(ray.y);
+      const float ray_azimuth = atan2_det(-ray.z, -ray.x) + kRefPi;
+      const uint32_t x = f2u_sat(ray_azimuth * 10.0f), y = f2u_sat((ray_altitude + kRefPi * 0.5f) * 10.0f);
+      const uint32_t grid = min(x, 63u) + min(y, 31u) * 64u;  // the reference does not clamp; x = 63 and y = 31 are the last cells the generator fills
+      const uint32_t first = s.stars_offsets[grid], last = s.stars_offsets[grid + 1u];
+      for (uint32_t i = first; i < last; i++) {
+        const float4 star = s.stars[i];
+        const V3 star_pos = angles_to_direction(star.x, star.y);
+        if (sphere_hit(ray, v3(0.0f, 0.0f, 0.0f), star_pos, star.z)) result = sp_add(result, sp_scale(transmittance, star.w * s.stars_intensity));
+      }
+    }
   }
   return sky_color_from_spectrum(result);
 }

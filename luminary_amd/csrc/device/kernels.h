@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, Sh
     const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
     const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z));
     const bool include_sun = (aux.w & (kStCameraDirection | kStAllowEmission)) != 0;
-    const Col c = sky_get_color(sky, sky_origin, v3(d4.x, d4.y, d4.z), kFltMax, include_sun, (int) sky.steps, smp.next1(kRndSkyStepOffset));
+    const Col c = sky_get_color(sc, sky, sky_origin, v3(d4.x, d4.y, d4.z), kFltMax, include_sun, (int) sky.steps, smp.next1(kRndSkyStepOffset));
     add_to_result(results, fbits(d4.w), c * record_unpack(U2{aux.x, aux.y}));
   }
 }

@@ -525,6 +525,15 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   sc.sky_multiscattering_factor = v->sky_multiscattering_factor;
   std::memcpy(sc.sky_sun_pos, v->sky_sun_pos, sizeof(sc.sky_sun_pos));
   std::memcpy(sc.sky_mie_phase, v->sky_mie_phase, sizeof(sc.sky_mie_phase));
+  std::memcpy(sc.sky_moon_pos, v->sky_moon_pos, sizeof(sc.sky_moon_pos));
+  sc.sky_moon_tex_offset = v->sky_moon_tex_offset; sc.sky_stars_intensity = v->sky_stars_intensity;
+  sc.sky_moon_albedo_tex = v->sky_moon_albedo_tex; sc.sky_moon_normal_tex = v->sky_moon_normal_tex;
+  sc.sky_stars_count = 0; sc.sky_stars = nullptr; sc.sky_stars_offsets = nullptr;
+  if (v->sky_stars && v->sky_stars_offsets && v->sky_stars_count) {
+    if (upload(ctx, (const float4*) v->sky_stars, (size_t) v->sky_stars_count, &sc.sky_stars)) return 1;
+    if (upload(ctx, v->sky_stars_offsets, (size_t) 64 * 32 + 1, &sc.sky_stars_offsets)) return 1;
+    sc.sky_stars_count = v->sky_stars_count;
+  }
   // ---- sky look-up tables: taken from the caller or generated here (device/device_sky.c:64-200), only for the procedural sky ----
   sc.sky_lut_transmittance = nullptr; sc.sky_lut_multiscattering = nullptr;
   if (sc.sky_mode == kSkyDefault) {

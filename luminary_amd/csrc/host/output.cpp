@@ -225,6 +225,12 @@ bool read_png(const std::string& path, uint32_t* width, uint32_t* height, float*
   size_t n;
   while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
   std::fclose(f);
+  return read_png_memory(file.data(), file.size(), path, width, height, gamma, rgba8, err);
+}
+
+bool read_png_memory(const uint8_t* data, size_t size, const std::string& path, uint32_t* width, uint32_t* height, float* gamma, std::vector<uint32_t>* rgba8,
+                     std::string* err) {
+  const std::vector<uint8_t> file(data, data + size);
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) { *err = path + " is not a PNG file"; return false; }
   uint32_t w = 0, h = 0, depth = 0, colour = 0, interlace = 0;

@@ -66,5 +66,8 @@ LuminaryResult write_png(const char* path, const uint32_t* argb8, uint32_t width
 // bits (16-bit samples keep their high byte; 1/2/4-bit grey and palette images are expanded), all five scanline filters, tRNS for
 // palettes, gAMA (gamma = 100000 / gAMA, png.c:541). Result: RGBA8 words (r in the low byte), rows top to bottom.
 bool read_png(const std::string& path, uint32_t* width, uint32_t* height, float* gamma, std::vector<uint32_t>* rgba8, std::string* err);
+// Same from memory (`name` only labels error messages): the embedded moon textures (device/device_embedded_data.c:62-92).
+bool read_png_memory(const uint8_t* data, size_t size, const std::string& name, uint32_t* width, uint32_t* height, float* gamma, std::vector<uint32_t>* rgba8,
+                     std::string* err);
 
 }  // namespace lum

@@ -1,5 +1,10 @@
 #include "scene.h"
 
+#include <mutex>
+#include <stdlib.h>
+
+#include "output.h"
+
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
@@ -78,6 +83,68 @@ void jendersie_eon_parameters(float d, float out[4]) {
   }
   else { g_hg = 0.0f; g_d = 0.0f; alpha = 0.0f; w_d = 0.0f; }  // beyond 50 um the reference leaves the values unset
   out[0] = g_hg; out[1] = g_d; out[2] = alpha; out[3] = w_d;
+}
+
+// _sky_stars_generate, device/device_sky.c:484-547: `count` stars from the C library's generator seeded with `seed`, bucketed into a
+// 64 x 32 grid over (azimuth, altitude) in steps of 0.1 rad. srand()/rand() are glibc's random(); random_r with a private state
+// yields the same sequence without touching the process-wide generator.
+bool generate_stars(uint32_t seed, uint32_t count, std::vector<float>* stars, std::vector<uint32_t>* offsets) {
+  constexpr uint32_t kGridX = 64, kGridY = 32;
+  constexpr float kRefPi = 3.141592653589f;  // utils.h:14
+  struct random_data state;
+  char state_buf[128];
+  std::memset(&state, 0, sizeof(state));
+  std::memset(state_buf, 0, sizeof(state_buf));
+  if (initstate_r(seed, state_buf, sizeof(state_buf), &state) != 0) return false;
+  auto rnd = [&]() { int32_t r = 0; random_r(&state, &r); return (float) (((double) r) / RAND_MAX); };
+  struct Star { float altitude, azimuth, radius, intensity; };
+  std::vector<Star> buffer(count);
+  std::vector<uint32_t> counts(kGridX * kGridY, 0);
+  auto cell = [&](const Star& s) { return (uint32_t) (s.azimuth * 10.0f) + (uint32_t) ((s.altitude + kRefPi * 0.5f) * 10.0f) * kGridX; };
+  for (uint32_t i = 0; i < count; i++) {
+    Star s;
+    s.altitude = -kRefPi * 0.5f + kRefPi * (1.0f - std::sqrt(rnd()));
+    s.azimuth = 2.0f * kRefPi * rnd();
+    s.radius = 0.0001f + 0.0004f * (1.0f - std::sqrt(rnd()));
+    s.intensity = 0.0001f + 0.0015f * (0.1f + 0.9f * (1.0f - std::sqrt(rnd())));
+    const uint32_t x = (uint32_t) (s.azimuth * 10.0f), y = (uint32_t) ((s.altitude + kRefPi * 0.5f) * 10.0f);
+    if (x >= kGridX || y >= kGridY) return false;  // "Star generation exception." in the reference
+    counts[cell(s)]++;
+    buffer[i] = s;
+  }
+  offsets->assign(kGridX * kGridY + 1, 0);
+  uint32_t offset = 0;
+  for (uint32_t i = 0; i < kGridX * kGridY; i++) { (*offsets)[i] = offset; offset += counts[i]; counts[i] = 0; }
+  (*offsets)[kGridX * kGridY] = offset;
+  stars->assign(4 * (size_t) count + 4, 0.0f);
+  for (uint32_t i = 0; i < count; i++) {
+    const uint32_t p = cell(buffer[i]);
+    const uint32_t o = (*offsets)[p] + counts[p]++;
+    std::memcpy(&(*stars)[4 * (size_t) o], &buffer[i], sizeof(Star));
+  }
+  return true;
+}
+
+extern "C" const unsigned char lum_embedded_moon_albedo[];
+extern "C" const unsigned char lum_embedded_moon_albedo_end[];
+extern "C" const unsigned char lum_embedded_moon_normal[];
+extern "C" const unsigned char lum_embedded_moon_normal_end[];
+// The embedded moon textures, decoded once.
+bool moon_textures(const HostTexture* out[2]) {
+  static HostTexture tex[2];
+  static int state = 0;  // 0 untried, 1 ok, -1 failed
+  static std::mutex mutex;
+  std::lock_guard<std::mutex> lock(mutex);
+  if (state == 0) {
+    std::string err;
+    const bool a = read_png_memory(lum_embedded_moon_albedo, (size_t) (lum_embedded_moon_albedo_end - lum_embedded_moon_albedo), "moon_albedo.png", &tex[0].width,
+                                   &tex[0].height, &tex[0].gamma, &tex[0].texels, &err);
+    const bool n = read_png_memory(lum_embedded_moon_normal, (size_t) (lum_embedded_moon_normal_end - lum_embedded_moon_normal), "moon_normal.png", &tex[1].width,
+                                   &tex[1].height, &tex[1].gamma, &tex[1].texels, &err);
+    state = (a && n) ? 1 : -1;
+  }
+  out[0] = &tex[0]; out[1] = &tex[1];
+  return state == 1;
 }
 
 void default_sky(LuminarySky* s) {  // sky.c:6-41
@@ -720,6 +787,23 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
     b.texels.insert(b.texels.end(), t.texels.begin(), t.texels.end());
   }
   v.num_textures = (uint32_t) scene.textures.size();
+  v.sky_moon_albedo_tex = v.sky_moon_normal_tex = 0xFFFFFFFFu;
+  if ((scene.sky.mode & 3u) == LUMINARY_SKY_MODE_DEFAULT) {
+    // the embedded moon textures join the pool behind the scene's own (device_embedded_data.c:62-92)
+    const HostTexture* moon[2];
+    if (moon_textures(moon)) {
+      for (int k = 0; k < 2; k++) {
+        float g = moon[k]->gamma;
+        uint32_t gbits;
+        std::memcpy(&gbits, &g, 4);
+        b.texture_table.push_back((uint32_t) b.texels.size()); b.texture_table.push_back(moon[k]->width); b.texture_table.push_back(moon[k]->height);
+        b.texture_table.push_back(gbits);
+        b.texels.insert(b.texels.end(), moon[k]->texels.begin(), moon[k]->texels.end());
+      }
+      v.sky_moon_albedo_tex = v.num_textures; v.sky_moon_normal_tex = v.num_textures + 1;
+      v.num_textures += 2;
+    }
+  }
   v.texture_table = b.texture_table.empty() ? nullptr : b.texture_table.data();
   v.texels = b.texels.empty() ? nullptr : b.texels.data();
   v.mesh_tri_offset = b.mesh_tri_offset.data(); v.vertices = b.vertices.data(); v.tri_tex = b.tri_tex.data();
@@ -757,6 +841,22 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
     v.sky_sun_pos[0] = (float) sx; v.sky_sun_pos[1] = (float) sy; v.sky_sun_pos[2] = (float) sz;
   }
   jendersie_eon_parameters(sky.mie_diameter, v.sky_mie_phase);
+  {
+    double mx = std::cos((double) sky.moon_azimuth) * std::cos((double) sky.moon_altitude), my = std::sin((double) sky.moon_altitude),
+           mz = std::sin((double) sky.moon_azimuth) * std::cos((double) sky.moon_altitude);
+    const double scale = 1.0 / std::sqrt(mx * mx + my * my + mz * mz);
+    const double moon_distance = 384399.0f, earth_radius = 6371.0f;  // sky_defines.h:4, :8
+    mx *= scale * moon_distance; my *= scale * moon_distance; mz *= scale * moon_distance;
+    my -= earth_radius;
+    mx -= sky.geometry_offset.x; my -= sky.geometry_offset.y; mz -= sky.geometry_offset.z;
+    v.sky_moon_pos[0] = (float) mx; v.sky_moon_pos[1] = (float) my; v.sky_moon_pos[2] = (float) mz;
+  }
+  v.sky_moon_tex_offset = sky.moon_tex_offset;
+  v.sky_stars_intensity = sky.stars_intensity;
+  v.sky_stars_count = 0; v.sky_stars = nullptr; v.sky_stars_offsets = nullptr;
+  if ((sky.mode & 3u) == LUMINARY_SKY_MODE_DEFAULT && generate_stars(sky.stars_seed, sky.stars_count, &b.sky_stars, &b.sky_stars_offsets)) {
+    v.sky_stars_count = sky.stars_count; v.sky_stars = b.sky_stars.data(); v.sky_stars_offsets = b.sky_stars_offsets.data();
+  }
   v.sky_lut_transmittance = nullptr; v.sky_lut_multiscattering = nullptr;  // generated on the GPU at upload
   return std::string();
 }

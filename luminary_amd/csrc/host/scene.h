@@ -78,6 +78,8 @@ struct DeviceSceneBuffers {
   std::vector<float> light_bvh_tris;
   std::vector<uint32_t> bluenoise;
   std::vector<uint32_t> texture_table, texels;
+  std::vector<float> sky_stars;            // 4 floats per star, grid order
+  std::vector<uint32_t> sky_stars_offsets; // 64 x 32 + 1
 };
 
 // Fills `out` from the scene. `bluenoise` must hold 65536 texels. Returns an empty string or an error message.

@@ -4,7 +4,7 @@
  * Restated from cuda/sky.cuh:47-108 (densities, path through the atmosphere), :110-176 (transmittance LUT), :186-332 (multiscattering
  * LUT), :338-446 (sky_compute_atmosphere), :508-515, :567-577 (sky_get_color / sky_color_main, DEFAULT branch), cuda/sky_utils.cuh
  * (8-wavelength spectrum, LUT parametrisation, spectrum -> RGB), cuda/math.cuh:620-779 (sphere tests), :1162-1239 (phase functions),
- * :1429-1439 (solid angle of the sun). Out: moon, stars, cloud shadows, aerial perspective, HDRI mode.
+ * :1429-1439 (solid angle of the sun). Out: cloud shadows, aerial perspective, HDRI mode.
  * expf := o_exp2(x * log2 e); asinf(x) := o_atan2(x, sqrt(1 - x^2)); the LUTs are filtered in software (clamp addressing, exact lerps)
  * where the reference uses the texture unit. The Jendersie-Eon parameters of the droplet diameter arrive with the scene.
  * Parity unpinned, like the rest of the oracle.
@@ -19,6 +19,8 @@
 #define SKY_EARTH_RADIUS 6371.0f
 #define SKY_SUN_RADIUS 696340.0f
 #define SKY_SUN_DISTANCE 149597870.0f
+#define SKY_MOON_RADIUS 1737.4f
+#define REF_PI 3.141592653589f /* utils.h:14: the reference's PI where it enters texture coordinates and grid cells */
 #define SKY_ATMO_HEIGHT 100.0f
 #define SKY_ATMO_RADIUS (SKY_ATMO_HEIGHT + SKY_EARTH_RADIUS)
 #define SKY_HEIGHT_OFFSET 0.0005f
@@ -121,6 +123,12 @@ typedef struct {
   float g_hg, g_d, alpha, w_d;
   const float* tm; /* low plane [64][256][4], high plane */
   const float* ms; /* low plane [32][32][4], high plane */
+  vec3 moon_pos;
+  float moon_tex_offset, stars_intensity;
+  uint32_t moon_albedo_tex, moon_normal_tex, stars_count;
+  const float* stars;
+  const uint32_t* stars_offsets;
+  const OracleScene* scene; /* for the moon's textures */
 } OSky;
 
 static inline OSky osky_view(const OracleScene* sc) {
@@ -133,6 +141,11 @@ static inline OSky osky_view(const OracleScene* sc) {
   s.ground_visibility = sc->sky_ground_visibility; s.ozone_layer_thickness = sc->sky_ozone_layer_thickness; s.multiscattering_factor = sc->sky_multiscattering_factor;
   s.g_hg = sc->sky_mie_phase[0]; s.g_d = sc->sky_mie_phase[1]; s.alpha = sc->sky_mie_phase[2]; s.w_d = sc->sky_mie_phase[3];
   s.tm = sc->sky_lut_transmittance; s.ms = sc->sky_lut_multiscattering;
+  s.moon_pos = v3(sc->sky_moon_pos[0], sc->sky_moon_pos[1], sc->sky_moon_pos[2]);
+  s.moon_tex_offset = sc->sky_moon_tex_offset; s.stars_intensity = sc->sky_stars_intensity;
+  s.moon_albedo_tex = sc->sky_moon_albedo_tex; s.moon_normal_tex = sc->sky_moon_normal_tex; s.stars_count = sc->sky_stars_count;
+  s.stars = sc->sky_stars; s.stars_offsets = sc->sky_stars_offsets;
+  s.scene = sc;
   return s;
 }
 
@@ -331,7 +344,15 @@ static void sky_multiscattering_lut(const OSky* s, float* dst) {
   }
 }
 
-/* sky_compute_atmosphere (sky.cuh:338-446) with the sun disk as the only celestial body; sky_get_color (:508-515) */
+static const Spectrum SKY_MOON_SOLAR_FLUX = {{1.7f, 1.8f, 2.0f, 1.9f, 1.87f, 1.7f, 1.65f, 1.55f}}; /* sky_utils.cuh:272 */
+static inline bool sphere_hit(vec3 ray, vec3 origin, vec3 p, float r);
+static inline vec3 angles_to_direction(float altitude, float azimuth) { /* math.cuh:781-789 */
+  float sa, ca, sz, cz;
+  o_sincos(altitude, &sa, &ca); o_sincos(azimuth, &sz, &cz);
+  return v3(cz * ca, sa, sz * ca);
+}
+
+/* sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars; sky_get_color (:508-515) */
 static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const float2_t path = sky_compute_path(origin, ray, SKY_EARTH_RADIUS, SKY_ATMO_RADIUS);
@@ -368,7 +389,48 @@ static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, boo
   if (celestials) {
     const float sun_hit = sphere_int(ray, origin, s->sun_pos, SKY_SUN_RADIUS);
     const float earth_hit = sph_int_p0(ray, origin, SKY_EARTH_RADIUS);
-    if (earth_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+    const bool has_moon = s->moon_albedo_tex != 0xFFFFFFFFu;
+    const float moon_hit = has_moon ? sphere_int(ray, origin, s->moon_pos, SKY_MOON_RADIUS) : FLT_MAX;
+    if (earth_hit > sun_hit && moon_hit > sun_hit) result = sp_add(result, sp_mul(transmittance, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+    else if (earth_hit > moon_hit) {
+      const vec3 moon_point = v_add(origin, v_scale(ray, moon_hit));
+      const vec3 bounce_ray = v_norm(v_sub(s->sun_pos, moon_point));
+      if (!sphere_hit(bounce_ray, moon_point, v3(0.0f, 0.0f, 0.0f), SKY_EARTH_RADIUS)) {
+        vec3 normal = v_norm(v_sub(moon_point, s->moon_pos));
+        UV uv;
+        uv.u = 0.5f + s->moon_tex_offset + o_atan2(normal.z, normal.x) * (1.0f / (2.0f * REF_PI));
+        uv.v = 0.5f + o_asin(normal.y) * (1.0f / REF_PI);
+        const float sign = copysignf(1.0f, normal.z);
+        const float a = -1.0f / (sign + normal.z);
+        const float b = normal.x * normal.y * a;
+        const vec3 u1 = v3(1.0f + sign * normal.x * normal.x * a, sign * b, -sign * normal.x);
+        const vec3 u2 = v3(b, sign + normal.y * normal.y * a, -normal.y);
+        const float4_t nv = texture_load(s->scene, s->moon_normal_tex, uv, true, f4(0.0f, 0.0f, 0.0f, 0.0f));
+        const vec3 mn = v3(nv.x * 2.0f - 1.0f, nv.y * 2.0f - 1.0f, nv.z * 2.0f - 1.0f);
+        normal = v_norm(v3(u1.x * mn.x + u2.x * mn.y + normal.x * mn.z, u1.y * mn.x + u2.y * mn.y + normal.y * mn.z, u1.z * mn.x + u2.z * mn.y + normal.z * mn.z));
+        const float NdotL = v_dot(normal, bounce_ray);
+        if (NdotL > 0.0f) {
+          const float albedo = texture_load(s->scene, s->moon_albedo_tex, uv, true, f4(0.0f, 0.0f, 0.0f, 0.0f)).x;
+          const float light_angle = sphere_solid_angle(s->sun_pos, SKY_SUN_RADIUS, moon_point);
+          const float weight = albedo * s->sun_strength * NdotL * light_angle / (2.0f * REF_PI);
+          result = sp_add(result, sp_mul(transmittance, sp_mul(SKY_MOON_SOLAR_FLUX, sp_scale(SKY_SUN_RADIANCE, weight))));
+        }
+      }
+    }
+    if (s->stars != NULL && sun_hit == FLT_MAX && earth_hit == FLT_MAX && moon_hit == FLT_MAX) {
+      const float ray_altitude = o_asin(ray.y);
+      const float ray_azimuth = o_atan2(-ray.z, -ray.x) + REF_PI;
+      uint32_t x = f2u_sat(ray_azimuth * 10.0f), y = f2u_sat((ray_altitude + REF_PI * 0.5f) * 10.0f);
+      if (x > 63u) x = 63u;
+      if (y > 31u) y = 31u;
+      const uint32_t grid = x + y * 64u;
+      const uint32_t first = s->stars_offsets[grid], last = s->stars_offsets[grid + 1u];
+      for (uint32_t i = first; i < last; i++) {
+        const float* star = s->stars + 4 * (size_t) i;
+        const vec3 star_pos = angles_to_direction(star[0], star[1]);
+        if (sphere_hit(ray, v3(0.0f, 0.0f, 0.0f), star_pos, star[2])) result = sp_add(result, sp_scale(transmittance, star[3] * s->stars_intensity));
+      }
+    }
   }
   return sky_color_from_spectrum(result);
 }

@@ -65,6 +65,14 @@ typedef struct OracleScene {
   float sky_mie_phase[4]; /* Jendersie-Eon g_hg, g_d, alpha, w_d of sky.mie_diameter (math.cuh:1189-1232) */
   const float* sky_lut_transmittance;   /* 2 x 64 x 256 float4 (low wavelengths plane, high plane); inputs: oracle_sky_generate_luts makes them */
   const float* sky_lut_multiscattering; /* 2 x 32 x 32 float4 */
+  /* the other celestial bodies of the procedural sky (sky.cuh:447-505) */
+  float sky_moon_pos[3];
+  float sky_moon_tex_offset;
+  uint32_t sky_moon_albedo_tex, sky_moon_normal_tex; /* texture ids in texture_table (appended by the host layer); 0xFFFFFFFF = no moon */
+  float sky_stars_intensity;
+  uint32_t sky_stars_count;
+  const float* sky_stars;            /* 4 floats per star in grid order: altitude, azimuth, radius, intensity (utils.h:115-121) */
+  const uint32_t* sky_stars_offsets; /* 64 x 32 + 1 cell offsets (device_sky.c:469-547) */
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */

@@ -151,3 +151,69 @@ def test_sky_variants_match_the_oracle(variant):
         assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
     finally:
         core.close()
+
+
+def _night_scene(fov=0.03):
+    """The example scene at night through a long lens: sun below the horizon, the moon placed on the optical axis, stars around it."""
+    host = _scene(bounces=2, altitude=-0.4, azimuth=1.0)
+    scenes.set_camera(host, (0.0, 6.0, 28.0), (0.25, 0.3, 0.0), fov=fov)
+    view = host.device_scene()
+    ray = (C.c_float * 6)()
+    oracle_lib.lib().oracle_camera_ray(C.byref(view), C.c_uint32(W // 2), C.c_uint32(H // 2), C.c_uint32(0), ray)
+    d = np.array(list(ray)[3:], dtype=np.float64)
+    sky = host.get_sky()
+    # the moon's position is direction * 384399 km - (0, R, 0) - offset in sky space (device_structs.c:152-165) while the camera sits at
+    # (0, R, 0) + offset + position / 1000: solve for the direction whose moon lies on the optical axis as seen from the camera
+    off = np.array([sky.geometry_offset.x, sky.geometry_offset.y, sky.geometry_offset.z], dtype=np.float64)
+    base = np.array([0.0, 6.0, 28.0]) * 0.001 + np.array([0.0, 6371.0, 0.0]) + off + np.array([0.0, 6371.0, 0.0]) + off
+    b, c = 2.0 * np.dot(base, d), np.dot(base, base) - 384399.0 ** 2
+    t = (-b + np.sqrt(b * b - 4.0 * c)) / 2.0
+    q = (base + t * d) / 384399.0
+    sky.moon_altitude, sky.moon_azimuth = float(np.arcsin(q[1])), float(np.arctan2(q[2], q[0]))
+    sky.stars_intensity = 50.0
+    host.set_sky(sky)
+    return host, d
+
+
+def test_oracle_moon_and_stars():
+    host, d = _night_scene()
+    view = host.device_scene()
+    assert view.sky_moon_albedo_tex == view.num_textures - 2 and view.sky_moon_normal_tex == view.num_textures - 1
+    assert view.sky_stars_count == 10000
+    offsets = np.ctypeslib.as_array(C.cast(view.sky_stars_offsets, C.POINTER(C.c_uint32)), shape=(64 * 32 + 1,))
+    stars = np.ctypeslib.as_array(C.cast(view.sky_stars, C.POINTER(C.c_float)), shape=(10000, 4))
+    assert offsets[0] == 0 and offsets[-1] == 10000 and (np.diff(offsets.astype(np.int64)) >= 0).all()
+    cell = (stars[:, 1] * np.float32(10.0)).astype(np.uint32) + ((stars[:, 0] + np.float32(3.141592653589) * np.float32(0.5)) * np.float32(10.0)).astype(np.uint32) * 64
+    assert (np.diff(cell.astype(np.int64)) >= 0).all(), "stars are stored cell by cell"
+    v = _with_sky_luts(view)
+    moon = _sky_color(v, (0.0, 6.0, 28.0), d, True)
+    off = _sky_color(v, (0.0, 6.0, 28.0), (d + np.array([0.0, 0.02, 0.0])) / np.linalg.norm(d + np.array([0.0, 0.02, 0.0])), True)
+    assert moon.min() > 0.0 and moon.sum() > 50.0 * off.sum(), "the moon's lit face against the night sky"
+    assert np.array_equal(_sky_color(v, (0.0, 6.0, 28.0), d, False), _sky_color(v, (0.0, 6.0, 28.0), d, False)) and _sky_color(v, (0.0, 6.0, 28.0), d, False).sum() < moon.sum() / 50.0
+    # a ray straight at a star picks it up
+    k = int(np.argmax(stars[:, 3] * (stars[:, 0] > 0.3)))
+    alt, az = float(stars[k, 0]), float(stars[k, 1])
+    sd = np.array([np.cos(az) * np.cos(alt), np.sin(alt), np.sin(az) * np.cos(alt)])
+    lit = _sky_color(v, (0.0, 6.0, 28.0), sd, True)
+    dark = _sky_color(v, (0.0, 6.0, 28.0), sd, False)
+    assert lit.sum() > dark.sum() + 1e-4
+
+
+@pytest.mark.gpu
+def test_night_sky_matches_the_oracle():
+    """Moon (textured, lit by the sun from below the horizon) and stars through a long lens, bit for bit."""
+    host, _ = _night_scene()
+    view = _with_sky_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.render(0, 2, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        ofm, osm, _ = oracle_lib.render(view, 0, 2)
+        assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
+        assert np.array_equal(sm, osm)
+        img = fm.reshape(3, H, W).sum(axis=0)
+        assert img[H // 2 - 3:H // 2 + 3, W // 2 - 3:W // 2 + 3].mean() > 20.0 * np.median(img), "the moon is in the middle of the frame"
+    finally:
+        core.close()
