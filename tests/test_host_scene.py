@@ -168,7 +168,7 @@ def test_obj_loader_reads_texture_maps(tmp_path):
     assert (ma.albedo_tex, ma.roughness_tex, ma.normal_tex, ma.luminance_tex, ma.metallic_tex) == (0, 1, 2, 0xFFFF, 0xFFFF)
     assert mb.albedo_tex == 0 and mb.roughness_tex == 0xFFFF  # the same file is one texture
     v = host.device_scene()
-    assert v.num_textures == 3
+    assert v.num_textures == 3 + 2 and (v.sky_moon_albedo_tex, v.sky_moon_normal_tex) == (3, 4)  # the default sky mode brings the moon's two textures along
     import ctypes as C
     table = np.ctypeslib.as_array(C.cast(v.texture_table, C.POINTER(C.c_uint32)), shape=(3, 4)).copy()
     assert table[:, 1].tolist() == [7, 6, 4] and table[:, 2].tolist() == [5, 5, 3] and table[0, 0] == 0 and table[1, 0] == 35 and table[2, 0] == 65
