@@ -181,4 +181,4 @@ def test_obj_loader_reads_texture_maps(tmp_path):
     assert np.array_equal(got_grey[..., 0], (grey16.astype(np.uint16) >> 8).astype(np.uint8)) and np.array_equal(got_grey[..., 0], got_grey[..., 2])
     # the packed uvs reach the device format and the oracle renders the textured quad
     host2 = oracle_lib.with_luts(v)
-    assert host2.num_textures == 3
+    assert host2.num_textures == 5
