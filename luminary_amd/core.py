@@ -111,6 +111,14 @@ class Core:
         self._call("lumc_download_sky_luts", tm.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
         return tm, ms
 
+    def sky_hdri_build(self, origin, dim, samples):
+        """Bakes the procedural sky seen from `origin` (world space) and returns it as [dim, dim, 4] float32."""
+        o = (C.c_float * 3)(*[float(x) for x in origin])
+        self._call("lumc_sky_hdri_build", o, C.c_uint32(dim), C.c_uint32(samples))
+        out = np.zeros((dim, dim, 4), dtype=np.float32)
+        self._call("lumc_sky_hdri_download", out.ctypes.data_as(C.c_void_p), C.c_void_p(0))
+        return out
+
     def set_pixels(self, pixels=None):
         if pixels is None:
             self._call("lumc_set_pixels", C.c_void_p(0), C.c_uint32(0))

@@ -433,6 +433,60 @@ LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3
   return sky_color_from_spectrum(result);
 }
 
+// ---- HDRI bake (cuda/sky_hdri.cuh:13-160, device/device_sky.c:283-316): the sky without celestial bodies seen from `origin`, as an
+// equirectangular dim x dim image. 32 lanes per texel share its samples; their means go through the reference's trimmed mean. ----
+LUM_DEV float sky_hdri_median_of_means(float* buckets, uint32_t num_buckets) {  // sky_hdri.cuh:13-56, on this group's 32 LDS slots
+  for (uint32_t i = 1; i < num_buckets; i++) {
+    const float x = buckets[i];
+    uint32_t j = i;
+    while (j > 0 && buckets[j - 1] > x) { buckets[j] = buckets[j - 1]; j--; }
+    buckets[j] = x;
+  }
+  float num = 0.0f, denom = 0.0f;
+  for (uint32_t b = 0; b < num_buckets; b++) { num += (float) b * buckets[b]; denom += buckets[b]; }
+  num *= 2.0f;
+  denom *= (float) num_buckets;
+  const float G = saturate((num / denom) - ((float) num_buckets + 1.0f) / (float) num_buckets);
+  const uint32_t k = num_buckets >> 1;
+  const uint32_t c = f2u_sat((float) k - (1.0f - G) * (float) k);
+  float output = 0.0f;
+  for (uint32_t b = c; b < num_buckets - c; b++) output += buckets[b];
+  return output / (float) (num_buckets - 2u * c);
+}
+__global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, float oy, float oz, uint32_t dim, uint32_t sample_count, float4* __restrict__ dst) {
+  __shared__ float values[256];
+  const uint32_t pixel = (blockIdx.x * 256u + threadIdx.x) >> 5, lane = threadIdx.x & 31u;
+  const bool in_range = pixel < dim * dim;
+  const uint32_t y = in_range ? pixel / dim : 0u, x = in_range ? pixel - y * dim : 0u;
+  const SkyView sky = sky_view(sc);
+  const float step_size = 1.0f / (float) (dim - 1u);
+  Col color = splat(0.0f);
+  uint32_t num_samples = 0;
+  if (in_range) {
+    for (uint32_t sample_id = lane; sample_id < sample_count; sample_id += 32u) {
+      const Sampler smp{sc.bluenoise_2d, x, y, sample_id, 0};
+      const F2 jitter = smp.next2(kRndCameraJitter);
+      const float u = ((float) x + jitter.x) * step_size, v = 1.0f - ((float) y + jitter.y) * step_size;
+      const float altitude = kPi * v - 0.5f * kPi, azimuth = 2.0f * kPi * u - kPi;
+      const V3 ray = angles_to_direction(altitude, azimuth);
+      color = color + sky_get_color(sc, sky, world_to_sky(sky, v3(ox, oy, oz)), ray, kFltMax, false, (int) sky.steps, smp.next1(kRndSkyStepOffset));
+      num_samples++;
+    }
+  }
+  const uint32_t buckets = min(32u, sample_count);
+  float* group = values + (threadIdx.x & ~31u);
+  float out[3];
+  const float mean[3] = {num_samples ? color.r / (float) num_samples : 0.0f, num_samples ? color.g / (float) num_samples : 0.0f, num_samples ? color.b / (float) num_samples : 0.0f};
+#pragma unroll
+  for (int ch = 0; ch < 3; ch++) {
+    __syncthreads();
+    values[threadIdx.x] = mean[ch];
+    __syncthreads();
+    out[ch] = (lane == 0u && in_range) ? sky_hdri_median_of_means(group, buckets) : 0.0f;
+  }
+  if (lane == 0u && in_range) dst[x + y * dim] = make_float4(out[0], out[1], out[2], 0.0f);
+}
+
 // ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ----
 LUM_DEV bool sphere_hit(V3 ray, V3 origin, V3 p, float r) {  // math.cuh:679-696
   const V3 diff = origin - p;

@@ -73,6 +73,8 @@ struct LumContext {
     uint8_t* d_block_mask = nullptr; // image-tile partition over GPUs: blocks this context renders (nullptr = all)
     bool build_pending = false;      // partitioned: a stage is due and waits for the block variances of all ranks
   } adaptive;
+  float4* d_sky_hdri = nullptr;     // baked sky (lumc_sky_hdri_build): dim x dim equirectangular, rgb + 0
+  uint32_t sky_hdri_dim = 0;
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
@@ -301,6 +303,7 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
+  if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
   free_adaptive(ctx);
   delete ctx;
 }
@@ -587,6 +590,30 @@ int lumc_download_sky_luts(LumContext* ctx, float* transmittance, float* multisc
   if (!ctx || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_download_sky_luts: the scene has no procedural sky"; return 1; }
   if (transmittance) HIP_TRY(ctx, hipMemcpy(transmittance, ctx->scene.sky_lut_transmittance, sizeof(float4) * 2 * kSkyTmWidth * kSkyTmHeight, hipMemcpyDeviceToHost));
   if (multiscattering) HIP_TRY(ctx, hipMemcpy(multiscattering, ctx->scene.sky_lut_multiscattering, sizeof(float4) * 2 * kSkyMsSize * kSkyMsSize, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, uint32_t samples) {
+  if (!ctx || !origin || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_sky_hdri_build: the scene has no procedural sky"; return 1; }
+  if (dim < 2 || dim > 16384 || samples == 0) { ctx->error = "lumc_sky_hdri_build: dim must be in [2, 16384] and samples positive"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->sky_hdri_dim != dim) {
+    if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
+    ctx->d_sky_hdri = nullptr; ctx->sky_hdri_dim = 0;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sky_hdri, sizeof(float4) * (size_t) dim * dim));
+    ctx->sky_hdri_dim = dim;
+  }
+  const uint64_t threads = (uint64_t) dim * dim * 32u;
+  hipLaunchKernelGGL(k_sky_hdri, dim3((uint32_t) ((threads + 255) / 256)), dim3(256), 0, 0, ctx->scene, origin[0], origin[1], origin[2], dim, samples, ctx->d_sky_hdri);
+  HIP_TRY(ctx, hipGetLastError());
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  return 0;
+}
+
+int lumc_sky_hdri_download(LumContext* ctx, float* rgba, uint32_t* dim) {
+  if (!ctx || !ctx->d_sky_hdri) { if (ctx) ctx->error = "lumc_sky_hdri_download: no baked sky"; return 1; }
+  if (dim) *dim = ctx->sky_hdri_dim;
+  if (rgba) HIP_TRY(ctx, hipMemcpy(rgba, ctx->d_sky_hdri, sizeof(float4) * (size_t) ctx->sky_hdri_dim * ctx->sky_hdri_dim, hipMemcpyDeviceToHost));
   return 0;
 }
 

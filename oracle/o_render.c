@@ -575,3 +575,6 @@ void oracle_sky_color(const OracleScene* scene, const float origin_world[3], con
                                (int) s.steps, random_offset);
   out[0] = c.r; out[1] = c.g; out[2] = c.b;
 }
+void oracle_sky_hdri(const OracleScene* scene, const float origin_world[3], uint32_t dim, uint32_t samples, float* rgba) {
+  sky_hdri_bake(scene, v3(origin_world[0], origin_world[1], origin_world[2]), dim, samples, rgba);
+}

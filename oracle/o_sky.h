@@ -435,6 +435,54 @@ static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, boo
   return sky_color_from_spectrum(result);
 }
 
+/* ---- HDRI bake (cuda/sky_hdri.cuh:13-160) ---- */
+static float sky_hdri_median_of_means(float* buckets, uint32_t num_buckets) {
+  for (uint32_t i = 1; i < num_buckets; i++) {
+    const float x = buckets[i];
+    uint32_t j = i;
+    while (j > 0 && buckets[j - 1] > x) { buckets[j] = buckets[j - 1]; j--; }
+    buckets[j] = x;
+  }
+  float num = 0.0f, denom = 0.0f;
+  for (uint32_t b = 0; b < num_buckets; b++) { num += (float) b * buckets[b]; denom += buckets[b]; }
+  num *= 2.0f;
+  denom *= (float) num_buckets;
+  const float G = o_saturate((num / denom) - ((float) num_buckets + 1.0f) / (float) num_buckets);
+  const uint32_t k = num_buckets >> 1;
+  const uint32_t c = f2u_sat((float) k - (1.0f - G) * (float) k);
+  float output = 0.0f;
+  for (uint32_t b = c; b < num_buckets - c; b++) output += buckets[b];
+  return output / (float) (num_buckets - 2u * c);
+}
+static void sky_hdri_bake(const OracleScene* sc, vec3 origin_world, uint32_t dim, uint32_t sample_count, float* dst /* dim*dim*4 */) {
+  const OSky sky = osky_view(sc);
+  const float step_size = 1.0f / (float) (dim - 1u);
+  const uint32_t buckets = sample_count < 32u ? sample_count : 32u;
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int64_t pixel = 0; pixel < (int64_t) dim * dim; pixel++) {
+    const uint32_t y = (uint32_t) pixel / dim, x = (uint32_t) pixel - y * dim;
+    float mean[3][32];
+    for (uint32_t lane = 0; lane < 32; lane++) {
+      RGBF color = c_splat(0.0f);
+      uint32_t num_samples = 0;
+      for (uint32_t sample_id = lane; sample_id < sample_count; sample_id += 32u) {
+        const Sampler smp = {sc->bluenoise_2d, x, y, sample_id, 0};
+        const float2_t jitter = rnd2(&smp, RT_CAMERA_JITTER);
+        const float u = ((float) x + jitter.x) * step_size, v = 1.0f - ((float) y + jitter.y) * step_size;
+        const float altitude = O_PI * v - 0.5f * O_PI, azimuth = 2.0f * O_PI * u - O_PI;
+        const vec3 ray = angles_to_direction(altitude, azimuth);
+        color = c_add(color, sky_get_color(&sky, world_to_sky(&sky, origin_world), ray, FLT_MAX, false, (int) sky.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET)));
+        num_samples++;
+      }
+      mean[0][lane] = num_samples ? color.r / (float) num_samples : 0.0f;
+      mean[1][lane] = num_samples ? color.g / (float) num_samples : 0.0f;
+      mean[2][lane] = num_samples ? color.b / (float) num_samples : 0.0f;
+    }
+    for (int ch = 0; ch < 3; ch++) dst[4 * pixel + ch] = sky_hdri_median_of_means(mean[ch], buckets);
+    dst[4 * pixel + 3] = 0.0f;
+  }
+}
+
 /* ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ---- */
 static inline bool sphere_hit(vec3 ray, vec3 origin, vec3 p, float r) { /* math.cuh:679-696 */
   const vec3 diff = v_sub(origin, p);

@@ -143,6 +143,7 @@ void oracle_generate_result(
  * of the sky seen from a world-space point along `ray` with the given ray-march offset in [0, 1). */
 void oracle_sky_generate_luts(const OracleScene* scene, float* transmittance, float* multiscattering);
 void oracle_sky_color(const OracleScene* scene, const float origin_world[3], const float ray[3], int include_sun, float random_offset, float out[3]);
+void oracle_sky_hdri(const OracleScene* scene, const float origin_world[3], uint32_t dim, uint32_t samples, float* rgba); /* sky_hdri.cuh:58-160 */
 float oracle_log2(float x);
 float oracle_exp2(float x);
 float oracle_pow(float x, float y);

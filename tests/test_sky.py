@@ -217,3 +217,34 @@ def test_night_sky_matches_the_oracle():
         assert img[H // 2 - 3:H // 2 + 3, W // 2 - 3:W // 2 + 3].mean() > 20.0 * np.median(img), "the moon is in the middle of the frame"
     finally:
         core.close()
+
+
+def _oracle_hdri(view, origin, dim, samples):
+    out = np.zeros((dim, dim, 4), dtype=np.float32)
+    oracle_lib.lib().oracle_sky_hdri(C.byref(view), (C.c_float * 3)(*origin), C.c_uint32(dim), C.c_uint32(samples), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def test_oracle_hdri_bake_is_a_sky_panorama():
+    v = _with_sky_luts(_scene().device_scene())
+    img = _oracle_hdri(v, (0.0, 6.0, 28.0), 16, 3)
+    assert np.isfinite(img).all() and (img[..., 3] == 0.0).all()
+    assert img[:8, :, :3].mean() > 20.0 * img[9:, :, :3].mean(), "rows above the horizon hold the sky, rows below it the thin air above the ground"
+    assert img[1:7, :, 2].mean() > img[1:7, :, 0].mean(), "blue overhead"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,samples", [(24, 40), (9, 5)])
+def test_hdri_bake_matches_the_oracle(dim, samples):
+    """lumc_sky_hdri_build: jittered samples per texel shared by 32 lanes, their means through the trimmed mean (more samples than
+    lanes, and fewer buckets than lanes)."""
+    host = _scene(altitude=0.3)
+    view = _with_sky_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(view)
+        got = core.sky_hdri_build((1.0, 6.0, 28.0), dim, samples)
+        want = _oracle_hdri(view, (1.0, 6.0, 28.0), dim, samples)
+        assert np.array_equal(got, want), "%d of %d values differ, max %g" % ((got != want).sum(), got.size, np.abs(got - want).max())
+    finally:
+        core.close()
