@@ -125,7 +125,8 @@ class DeviceSceneView(C.Structure):
                 ("sky_ozone_layer_thickness", C.c_float), ("sky_multiscattering_factor", C.c_float), ("sky_sun_pos", C.c_float * 3),
                 ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p),
                 ("sky_moon_pos", C.c_float * 3), ("sky_moon_tex_offset", C.c_float), ("sky_moon_albedo_tex", C.c_uint32), ("sky_moon_normal_tex", C.c_uint32),
-                ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p)]
+                ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p),
+                ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -368,6 +369,23 @@ class Host:
         out = (C.c_uint64 * 8)()
         _call("luminary_ext_get_ray_counters", self._h, out)
         return list(out)
+
+    def request_sky_hdri_build(self):
+        """luminary_host_request_sky_hdri_build: the sky panorama of HDRI mode is baked again, from the camera's current position."""
+        _call("luminary_host_request_sky_hdri_build", self._h)
+
+    def core_sky_hdri(self):
+        """The panorama the GPU core last baked for this host, [dim, dim, 4] float32."""
+        import numpy as np
+        lib, ctx = _lib(), C.c_void_p(self.core_context())
+        dim = C.c_uint32()
+        lib.lumc_sky_hdri_download.restype = C.c_int
+        if lib.lumc_sky_hdri_download(ctx, C.c_void_p(0), C.byref(dim)):
+            raise RuntimeError("no baked sky")
+        out = np.zeros((dim.value, dim.value, 4), dtype=np.float32)
+        if lib.lumc_sky_hdri_download(ctx, out.ctypes.data_as(C.c_void_p), C.byref(dim)):
+            raise RuntimeError("lumc_sky_hdri_download failed")
+        return out
 
     def core_context(self):
         ctx = _lib().luminary_ext_get_core_context(self._h)

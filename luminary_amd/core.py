@@ -119,6 +119,14 @@ class Core:
         self._call("lumc_sky_hdri_download", out.ctypes.data_as(C.c_void_p), C.c_void_p(0))
         return out
 
+    def sky_hdri_download(self):
+        """The panorama the context holds (baked at upload in sky mode HDRI, or by sky_hdri_build), [dim, dim, 4] float32."""
+        dim = C.c_uint32()
+        self._call("lumc_sky_hdri_download", C.c_void_p(0), C.byref(dim))
+        out = np.zeros((dim.value, dim.value, 4), dtype=np.float32)
+        self._call("lumc_sky_hdri_download", out.ctypes.data_as(C.c_void_p), C.byref(dim))
+        return out
+
     def set_pixels(self, pixels=None):
         if pixels is None:
             self._call("lumc_set_pixels", C.c_void_p(0), C.c_uint32(0))

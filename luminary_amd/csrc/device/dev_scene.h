@@ -88,6 +88,8 @@ struct DeviceScene {
   uint32_t sky_stars_count;
   const float4* sky_stars;            // altitude, azimuth, radius, intensity
   const uint32_t* sky_stars_offsets;  // 64 x 32 + 1
+  const float4* sky_hdri;             // [dim][dim] baked panorama (k_sky_hdri), read when sky_mode == HDRI; alpha unused
+  uint32_t sky_hdri_dim;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).
@@ -105,6 +107,7 @@ struct NeeQueue {
   float4* bsdf_ray_prob;    // BSDF-sampled light direction xyz | its probability (0 = none)
   float4* bsdf_weight_sum;  // shade: bsdf weight rgb | light-tree root sum; after the light query: light colour rgb | valid flag
   uint4* ambient;           // packed colour (record format) xy | packed ray zw
+  uint4* sun;               // same for the sun sample (written and read unless the sky is a constant colour)
 };
 
 // Visibility rays, compacted: every entry is one any-hit ray whose transparency goes to vis[out].
@@ -112,10 +115,15 @@ struct ShadowQueue {
   float4* origin_dist;  // origin.xyz | distance
   float4* dir_out;      // direction.xyz | output index (uint bits) = kind * capacity + path index
   uint4* ids;           // target instance, target triangle (the sampled light) | self instance, self triangle
-  float4* vis;          // [3 * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient
+  float4* vis;          // [4 * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun
   uint32_t* light_items;  // path indices that need a light-BVH query
   uint32_t capacity;
 };
+
+enum PathState : uint32_t {  // cuda/utils.cuh:114-121
+  kStDeltaPath = 1, kStCameraDirection = 2, kStVolumeScattered = 4, kStAllowEmission = 8, kStAllowAmbient = 16, kStUseIgnoreHandle = 32
+};
+enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 // Per-depth control words (zeroed once per pass).
 enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlSkyItems = 5, kCtlStride = 8 };

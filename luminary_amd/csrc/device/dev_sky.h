@@ -532,6 +532,30 @@ LUM_DEV Col sky_sun_color(const SkyView& s, V3 origin, V3 ray) {
   const Spectrum extinction_sun = sp_mul(sp_ident(), sky_lut_fetch(s.tm, kSkyTmWidth, kSkyTmHeight, uv.x, uv.y));
   return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(sky_sun_radiance(), s.sun_strength)));
 }
+// ---- baked panorama as the sky (sky mode HDRI) ----
+// sky_hdri_sample, sky_utils.cuh:49-63: equirectangular lookup, nearest texel (device_sky.c:352), wrap addressing (texture_create's
+// default), no gamma. The texel of a normalised coordinate u is floor(frac(u) * dim), as the texture unit's point filter picks it.
+LUM_DEV Col sky_hdri_sample(const DeviceScene& sc, V3 ray) {
+  if (sc.sky_hdri == nullptr) return splat(0.0f);
+  const float theta = atan2_det(ray.z, ray.x), phi = asin_det(ray.y);
+  const float u = (theta + kRefPi) / (2.0f * kRefPi);
+  const float v = 1.0f - ((phi + 0.5f * kRefPi) / kRefPi);
+  const float dim = (float) sc.sky_hdri_dim;
+  const uint32_t x = (uint32_t) ((u - floorf(u)) * dim) % sc.sky_hdri_dim, y = (uint32_t) ((v - floorf(v)) * dim) % sc.sky_hdri_dim;
+  const float4 t = sc.sky_hdri[x + (size_t) y * sc.sky_hdri_dim];
+  return col(t.x, t.y, t.z);
+}
+// sky_color_main / sky_color_no_compute in HDRI mode (sky.cuh:534-606): the panorama holds no sun disk, so rays that may still see
+// emitters add it when they hit the disk above the horizon.
+LUM_DEV Col sky_hdri_color(const DeviceScene& sc, V3 origin, V3 ray, uint32_t state) {
+  Col c = sky_hdri_sample(sc, ray);
+  if (state & (kStCameraDirection | kStAllowEmission)) {
+    const SkyView s = sky_view(sc);
+    const V3 sky_origin = world_to_sky(s, origin);
+    if (sphere_hit(ray, sky_origin, s.sun_pos, kSkySunRadius) && !sph_hit_p0(ray, sky_origin, kSkyEarthRadius)) c = c + sky_sun_color(s, sky_origin, ray);
+  }
+  return c;
+}
 // bsdf_sample_for_sun_pdf<GEOMETRY>, bsdf.cuh:438-458. The reference hands the WORLD-space view vector to the bounded-VNDF density,
 // which reads it as a local one; kept as it is.
 LUM_DEV float sun_bsdf_pdf(const GeoContext& g, V3 L, float reflection_prob, float refraction_prob) {

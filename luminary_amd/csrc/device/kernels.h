@@ -18,11 +18,6 @@
 
 namespace lum {
 
-enum PathState : uint32_t {  // cuda/utils.cuh:114-121
-  kStDeltaPath = 1, kStCameraDirection = 2, kStVolumeScattered = 4, kStAllowEmission = 8, kStAllowAmbient = 16, kStUseIgnoreHandle = 32
-};
-enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
-
 constexpr int kBlock = 256;
 #ifndef LUM_TRACE_BLOCK
 #define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
@@ -210,9 +205,12 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 }
 
 // ---- shading pass: cuda/geometry.cuh:11-180 (+ miss handling of cuda/sky.cuh:609-633, roulette cuda/directives.cuh:11-32) ----
-// Two instantiations: the procedural sky adds sun sampling (a third of the kernel's code again) that a constant-colour scene never runs
-// but would pay for in registers and instruction cache; kProceduralSky == (sc.sky_mode == kSkyDefault), chosen at launch.
-template <bool kProceduralSky>
+// One instantiation per sky mode (kSkyMode == sc.sky_mode, chosen at launch): sun sampling is a third of the kernel's code again, which a
+// constant-colour scene never runs but would pay for in registers and instruction cache. The modes differ in three places
+// (direct_lighting.cuh:257-283, sky.cuh:534-606): what a path that left the scene adds (DEFAULT: ray-marched by k_sky; HDRI: panorama
+// texel + sun disk; CONSTANT: the colour), whether the bounce direction is an ambient sample (not DEFAULT), and whether the sun is
+// sampled (not CONSTANT).
+template <uint32_t kSkyMode>
 __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
   const uint32_t n = ctrl[kCtlPaths];
@@ -238,7 +236,11 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         if (in.hit_id[i].x == kHitSky) {
           const uint4 aux = in.aux[i];
           if (aux.w & kStAllowAmbient) {
-            if (kProceduralSky) is_sky = true;  // the atmosphere is ray-marched by k_sky
+            if (kSkyMode == kSkyDefault) is_sky = true;  // the atmosphere is ray-marched by k_sky
+            else if (kSkyMode == kSkyHdri) {
+              const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+              add_to_result(results, fbits(d4.w), sky_hdri_color(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), aux.w) * record_unpack(U2{aux.x, aux.y}));
+            }
             else add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
           }
         }
@@ -265,9 +267,9 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
     const bool valid = lane < take;
     const uint32_t i = valid ? pending[num_pending + lane] : 0u;
     __builtin_amdgcn_wave_barrier();
-    bool survive = false, want_geo = false, want_amb = false, want_lq = false;
+    bool survive = false, want_geo = false, want_amb = false, want_sun = false, want_lq = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
-    float4 s_origin, s_geo_dir, s_amb_dir; uint4 s_geo_ids;
+    float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
     if (valid) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
@@ -314,8 +316,9 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         if (LUM_ABLATE & 4) { bounce.ray = g.normal; bounce.weight = splat(0.5f); bounce.transparent_pass = false; bounce.microfacet_based = false; }
         else bounce = sample_bounce(lf, g, smp, 0);
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
-        if (!kProceduralSky) {
-          const U2 c = record_pack(sky * bounce.weight), r = ray_pack(bounce.ray);
+        if (kSkyMode != kSkyDefault) {  // ambient: the bounce direction doubles as the sample (direct_lighting.cuh:388-405)
+          const Col ambient = (kSkyMode == kSkyHdri) ? sky_hdri_color(sc, g.position, bounce.ray, 0u) : sky;
+          const U2 c = record_pack(ambient * bounce.weight), r = ray_pack(bounce.ray);
           amb = make_uint4(c.x, c.y, r.x, r.y);
           if (c.x != 0 || c.y != 0) {
             want_amb = true;
@@ -323,19 +326,19 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
             s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
           }
         }
-        else {
-          // procedural sky: the sun is sampled instead (direct_lighting.cuh:262, :279 make the two exclusive outside HDRI mode), so its
-          // packed colour and ray travel in the ambient slots and its visibility ray is the third kind of item
+        if (kSkyMode != kSkyConstantColor) {  // the sun: its own record and the fourth kind of visibility ray
+          uint4 sun = make_uint4(0u, 0u, 0u, 0u);
           Col sun_light; V3 sun_dir;
           if (sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir)) {
             const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
-            amb = make_uint4(c.x, c.y, r.x, r.y);
+            sun = make_uint4(c.x, c.y, r.x, r.y);
             if (c.x != 0 || c.y != 0) {
-              want_amb = true;
+              want_sun = true;
               const V3 ar = ray_unpack(r);
-              s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+              s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
             }
           }
+          nee.sun[i] = sun;
         }
         nee.geo_color_light[i] = geo_cl;
         nee.bsdf_ray_prob[i] = bs_rp; nee.bsdf_weight_sum[i] = bs_ws;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         record = record * bounce.weight;
 
         uint32_t new_state = state | kStUseIgnoreHandle;
-        if (!kProceduralSky && !pass_through) new_state &= ~kStAllowAmbient; else new_state |= kStAllowAmbient;
+        if (kSkyMode != kSkyDefault && !pass_through) new_state &= ~kStAllowAmbient; else new_state |= kStAllowAmbient;
         if (!is_delta) new_state &= ~kStDeltaPath;
         if (!pass_through) new_state &= ~(kStCameraDirection | kStAllowEmission);
 
@@ -400,11 +403,11 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
       }
     }
-    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb);
-    if (bg | ba) {
-      const uint32_t ng = (uint32_t) __popcll(bg);
+    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun);
+    if (bg | ba | bn) {
+      const uint32_t ng = (uint32_t) __popcll(bg), na = (uint32_t) __popcll(ba);
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, ng + (uint32_t) __popcll(ba));
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, ng + na + (uint32_t) __popcll(bn));
       base = __builtin_amdgcn_readfirstlane(base);
       if (want_geo) {
         const uint32_t j = base + (uint32_t) __popcll(bg & below);
@@ -416,6 +419,12 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
         const uint32_t j = base + ng + (uint32_t) __popcll(ba & below);
         sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w);
         sq.dir_out[j] = make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+      }
+      if (want_sun) {
+        const uint32_t j = base + ng + na + (uint32_t) __popcll(bn & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w);
+        sq.dir_out[j] = make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i));
         sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
       }
     }
@@ -567,7 +576,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       if (lc.w != 0.0f) { const float4 v = sq.vis[sq.capacity + i]; vis = col(v.x, v.y, v.z); }
       acc = acc + col(lc.x, lc.y, lc.z) * vis;
     }
-    {  // sun (procedural sky, direct_lighting.cuh:466-519) or ambient (constant colour, :521-584): exclusive, same slots
+    if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
+      const uint4 sun = nee.sun[i];
+      Col vis = splat(0.0f);
+      if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+      acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
+    }
+    {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
       const uint4 amb = nee.ambient[i];
       Col vis = splat(0.0f);
       if (amb.x != 0 || amb.y != 0) { const float4 v = sq.vis[2u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }

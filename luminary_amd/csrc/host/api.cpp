@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -37,6 +38,7 @@ struct LuminaryHost {
   uint32_t num_pixels = 0;
   uint32_t accumulated_samples = 0;  // uniform rendering: samples per pixel; adaptive rendering: executions (the reference's sample count)
   bool adaptive_active = false;      // the accumulation is driven by lumc_adaptive_* (luminary_ext_render with adaptive sampling enabled)
+  bool hdri_origin_pending = true;   // the next scene build re-bakes the sky panorama from the camera's position (SCENE_DIRTY_FLAG_HDRI)
   lum::OutputStore outputs;
   double render_seconds = 0.0;
   std::vector<std::string> log;
@@ -58,6 +60,11 @@ void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_
 
 LuminaryResult ensure_device_scene(LuminaryHost* h) {
   if (h->device_scene_valid) return LUMINARY_SUCCESS;
+  if (h->hdri_origin_pending) {  // sky_hdri_update (device/device_sky.c:249-266): the panorama follows the camera only when the sky is dirty
+    const LuminaryVec3 p = h->scene.camera.pos;
+    h->scene.hdri_origin[0] = p.x; h->scene.hdri_origin[1] = p.y; h->scene.hdri_origin[2] = p.z;
+    h->hdri_origin_pending = false;
+  }
   const std::string err = lum::build_device_scene(h->scene, embedded_bluenoise(), &h->device_scene);
   if (!err.empty()) { h->log.push_back(err); std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
   h->device_scene_valid = true;
@@ -218,6 +225,7 @@ LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* pat
   for (auto& w : warnings) std::fprintf(stderr, "[luminary_amd] warning: %s\n", w.c_str());
   host->scene.settings = content.settings; host->scene.camera = content.camera; host->scene.ocean = content.ocean; host->scene.sky = content.sky;
   host->scene.cloud = content.cloud; host->scene.fog = content.fog; host->scene.particles = content.particles;
+  host->hdri_origin_pending = true;
   invalidate(host);
   return LUMINARY_SUCCESS;
 }
@@ -299,7 +307,14 @@ LuminaryResult luminary_ext_add_texture(LuminaryHost* host, const uint8_t* rgba8
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld) { return lum::write_png(path, argb8, width, height, ld); }
-LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) { CHECK_NULL(host); return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+// host.c:1077-1084 -> scene_set_hdri_dirty (scene.c:712-722): the panorama is baked again, seen from the camera's current position
+LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
+  CHECK_NULL(host);
+  std::lock_guard<std::mutex> lock(host->mutex);
+  host->hdri_origin_pending = true;
+  invalidate(host);
+  return LUMINARY_SUCCESS;
+}
 
 // ---- entity getters / setters (host.c:705-900) ----
 #define ENTITY_ACCESSORS(NAME, TYPE, FIELD)                                                             \
@@ -312,7 +327,11 @@ LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) { CHECK_
   LuminaryResult luminary_host_set_##NAME(LuminaryHost* host, const TYPE* in) {                         \
     CHECK_NULL(host); CHECK_NULL(in);                                                                   \
     std::lock_guard<std::mutex> lock(host->mutex);                                                      \
-    if (std::memcmp(&host->scene.FIELD, in, sizeof(TYPE)) != 0) { host->scene.FIELD = *in; invalidate(host); } \
+    if (std::memcmp(&host->scene.FIELD, in, sizeof(TYPE)) != 0) {                                       \
+      host->scene.FIELD = *in;                                                                          \
+      if (std::is_same<TYPE, LuminarySky>::value) host->hdri_origin_pending = true; /* sky.c:45: every sky change dirties the panorama */ \
+      invalidate(host);                                                                                 \
+    }                                                                                                   \
     return LUMINARY_SUCCESS;                                                                            \
   }
 ENTITY_ACCESSORS(settings, LuminaryRendererSettings, settings)

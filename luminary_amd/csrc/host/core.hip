@@ -75,6 +75,7 @@ struct LumContext {
   } adaptive;
   float4* d_sky_hdri = nullptr;     // baked sky (lumc_sky_hdri_build): dim x dim equirectangular, rgb + 0
   uint32_t sky_hdri_dim = 0;
+  std::vector<uint32_t> sky_hdri_key;  // what the bake was made from (sky parameters, origin, dim, samples): an unchanged key reuses it
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
@@ -133,9 +134,9 @@ void free_work(LumContext* ctx) {
 int ensure_work(LumContext* ctx, uint32_t paths) {
   if (paths <= ctx->capacity) return 0;
   free_work(ctx);
-  // per path: 2 queues x 64 B + NEE 64 B + result 16 B + up to 3 visibility rays x (48 B + 16 B result) + 4 B light-query index
+  // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to 4 visibility rays x (48 B + 16 B result) + 4 B light-query index
   const size_t n = paths;
-  const size_t bytes = n * (2 * 68 + 64 + 16 + 3 * 64 + 4) + 32 * 256;
+  const size_t bytes = n * (2 * 68 + 80 + 16 + 4 * 64 + 4) + 32 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
@@ -150,11 +151,12 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   ctx->nee.bsdf_ray_prob   = (float4*) take(n * 16);
   ctx->nee.bsdf_weight_sum = (float4*) take(n * 16);
   ctx->nee.ambient         = (uint4*) take(n * 16);
+  ctx->nee.sun             = (uint4*) take(n * 16);
   ctx->d_results           = (float4*) take(n * 16);
-  ctx->shadow.origin_dist  = (float4*) take(3 * n * 16);
-  ctx->shadow.dir_out      = (float4*) take(3 * n * 16);
-  ctx->shadow.ids          = (uint4*) take(3 * n * 16);
-  ctx->shadow.vis          = (float4*) take(3 * n * 16);
+  ctx->shadow.origin_dist  = (float4*) take(4 * n * 16);
+  ctx->shadow.dir_out      = (float4*) take(4 * n * 16);
+  ctx->shadow.ids          = (uint4*) take(4 * n * 16);
+  ctx->shadow.vis          = (float4*) take(4 * n * 16);
   ctx->shadow.light_items  = (uint32_t*) take(n * 4);
   ctx->shadow.capacity     = paths;
   ctx->capacity = paths;
@@ -539,7 +541,8 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   }
   // ---- sky look-up tables: taken from the caller or generated here (device/device_sky.c:64-200), only for the procedural sky ----
   sc.sky_lut_transmittance = nullptr; sc.sky_lut_multiscattering = nullptr;
-  if (sc.sky_mode == kSkyDefault) {
+  sc.sky_hdri = nullptr; sc.sky_hdri_dim = 0;
+  if (sc.sky_mode != kSkyConstantColor) {  // HDRI mode bakes from them and samples the sun through them
     const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
     if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
       if (upload(ctx, (const float4*) v->sky_lut_transmittance, tm_texels, &sc.sky_lut_transmittance)) return 1;
@@ -557,7 +560,6 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       HIP_TRY(ctx, hipDeviceSynchronize());
     }
   }
-
   // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
   const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
   const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
@@ -573,6 +575,18 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     HIP_TRY(ctx, hipDeviceSynchronize());
   }
   sc.lut_conductor = ctx->d_luts[0]; sc.lut_glossy = ctx->d_luts[1]; sc.lut_dielectric = ctx->d_luts[2]; sc.lut_dielectric_inv = ctx->d_luts[3];
+  // ---- sky panorama (HDRI mode): the caller's, or baked here from the procedural sky as the reference's device manager does when the
+  // sky changes (device_manager.c:351-366, device_sky.c:249-366); lumc_sky_hdri_build re-bakes on request ----
+  if (sc.sky_mode == kSkyHdri) {
+    if (v->sky_hdri && v->sky_hdri_dim) {
+      if (upload(ctx, (const float4*) v->sky_hdri, (size_t) v->sky_hdri_dim * v->sky_hdri_dim, &sc.sky_hdri)) return 1;
+      sc.sky_hdri_dim = v->sky_hdri_dim;
+    }
+    else {
+      ctx->has_scene = true;  // the bake renders this scene's sky
+      if (lumc_sky_hdri_build(ctx, v->sky_hdri_origin, v->sky_hdri_dim, v->sky_hdri_samples ? v->sky_hdri_samples : 1u)) { ctx->has_scene = false; return 1; }
+    }
+  }
   ctx->has_scene = true;
   return 0;
 }
@@ -593,10 +607,31 @@ int lumc_download_sky_luts(LumContext* ctx, float* transmittance, float* multisc
   return 0;
 }
 
+// Everything the bake reads: the sky's parameters (not its tables: they are functions of the parameters), the star field's size, the moon.
+static std::vector<uint32_t> sky_hdri_key(const DeviceScene& sc, const float origin[3], uint32_t dim, uint32_t samples) {
+  std::vector<uint32_t> key;
+  auto put = [&](const void* p, size_t bytes) { const size_t at = key.size(); key.resize(at + (bytes + 3) / 4, 0u); std::memcpy(key.data() + at, p, bytes); };
+  put(&sc.sky_steps, sizeof(sc.sky_steps)); put(&sc.sky_ozone_absorption, sizeof(sc.sky_ozone_absorption));
+  put(sc.sky_geometry_offset, sizeof(sc.sky_geometry_offset));
+  const float params[] = {sc.sky_sun_strength, sc.sky_base_density, sc.sky_rayleigh_density, sc.sky_mie_density, sc.sky_ozone_density, sc.sky_rayleigh_falloff, sc.sky_mie_falloff,
+                          sc.sky_ground_visibility, sc.sky_ozone_layer_thickness, sc.sky_multiscattering_factor, sc.sky_moon_tex_offset, sc.sky_stars_intensity};
+  put(params, sizeof(params));
+  put(sc.sky_sun_pos, sizeof(sc.sky_sun_pos)); put(sc.sky_mie_phase, sizeof(sc.sky_mie_phase)); put(sc.sky_moon_pos, sizeof(sc.sky_moon_pos));
+  put(&sc.sky_stars_count, sizeof(sc.sky_stars_count));
+  put(origin, 3 * sizeof(float)); put(&dim, sizeof(dim)); put(&samples, sizeof(samples));
+  return key;
+}
+
 int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, uint32_t samples) {
-  if (!ctx || !origin || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_sky_hdri_build: the scene has no procedural sky"; return 1; }
+  if (!ctx || !origin || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_sky_hdri_build: the scene has no atmosphere (constant-colour sky)"; return 1; }
   if (dim < 2 || dim > 16384 || samples == 0) { ctx->error = "lumc_sky_hdri_build: dim must be in [2, 16384] and samples positive"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
+  std::vector<uint32_t> key = sky_hdri_key(ctx->scene, origin, dim, samples);
+  if (ctx->d_sky_hdri && key == ctx->sky_hdri_key) {
+    if (ctx->scene.sky_mode == kSkyHdri) { ctx->scene.sky_hdri = ctx->d_sky_hdri; ctx->scene.sky_hdri_dim = dim; }
+    return 0;
+  }
+  ctx->sky_hdri_key.clear();
   if (ctx->sky_hdri_dim != dim) {
     if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
     ctx->d_sky_hdri = nullptr; ctx->sky_hdri_dim = 0;
@@ -607,6 +642,8 @@ int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, ui
   hipLaunchKernelGGL(k_sky_hdri, dim3((uint32_t) ((threads + 255) / 256)), dim3(256), 0, 0, ctx->scene, origin[0], origin[1], origin[2], dim, samples, ctx->d_sky_hdri);
   HIP_TRY(ctx, hipGetLastError());
   HIP_TRY(ctx, hipDeviceSynchronize());
+  ctx->sky_hdri_key = std::move(key);
+  if (ctx->scene.sky_mode == kSkyHdri) { ctx->scene.sky_hdri = ctx->d_sky_hdri; ctx->scene.sky_hdri_dim = dim; }
   return 0;
 }
 
@@ -659,12 +696,9 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      if (sc.sky_mode == kSkyDefault)
-        hipLaunchKernelGGL(k_shade<true>, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
-                           depth_const, ctx->d_counters);
-      else
-        hipLaunchKernelGGL(k_shade<false>, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl,
-                           depth_const, ctx->d_counters);
+      auto* shade = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri> : k_shade<kSkyConstantColor>;
+      hipLaunchKernelGGL(shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const,
+                         ctx->d_counters);
     }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
       Launch l(ctx, stream, LUMC_KERNEL_SKY);

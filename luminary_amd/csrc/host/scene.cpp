@@ -858,6 +858,10 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
     v.sky_stars_count = sky.stars_count; v.sky_stars = b.sky_stars.data(); v.sky_stars_offsets = b.sky_stars_offsets.data();
   }
   v.sky_lut_transmittance = nullptr; v.sky_lut_multiscattering = nullptr;  // generated on the GPU at upload
+  // HDRI mode: baked on the GPU at upload (sky_hdri_update, device/device_sky.c:249-281: dim and samples at least 1, origin = camera)
+  v.sky_hdri = nullptr;
+  v.sky_hdri_dim = sky.hdri_dim ? sky.hdri_dim : 1u; v.sky_hdri_samples = sky.hdri_samples ? sky.hdri_samples : 1u;
+  std::memcpy(v.sky_hdri_origin, scene.hdri_origin, sizeof(v.sky_hdri_origin));
   return std::string();
 }
 

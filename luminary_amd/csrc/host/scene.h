@@ -44,6 +44,7 @@ struct HostScene {
   std::vector<HostMesh> meshes;
   std::vector<HostInstance> instances;
   std::vector<HostTexture> textures;
+  float hdri_origin[3] = {0.0f, 0.0f, 0.0f};  // where the sky panorama of HDRI mode is baked from: the camera position when the sky last changed
   HostScene();
 };
 

@@ -21,9 +21,9 @@
 #include "o_trace.h"
 #include "o_output.h"
 #include "o_adaptive.h"
+enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 #include "o_sky.h"
 
-enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
 #define GEOMETRY_DELTA_PATH_CUTOFF 0.05f
 #define BSDF_ROUGHNESS_CLAMP 2e-2f
@@ -193,6 +193,7 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
           const bool include_sun = (state & (ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION)) != 0;
           sky = sky_get_color(&view, world_to_sky(&view, origin), ray, FLT_MAX, include_sun, (int) view.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET));
         }
+        else if (s->sky_mode == SKY_MODE_HDRI) sky = sky_hdri_color(s, origin, ray, state); /* sky.cuh:579-595 */
         beauty_add(&result, c_mul(sky, record_unpack(record_p)));
       }
       break;
@@ -212,7 +213,7 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     const BSDFSample bounce = bsdf_sample(&luts, &g, &smp, 0);
     const bool ambient_allowed = s->sky_mode != SKY_MODE_DEFAULT;
     /* sun (direct_lighting.cuh:352-383): allowed outside constant-colour mode (:257-263); needs the procedural sky's tables */
-    const bool sun_allowed = s->sky_mode == SKY_MODE_DEFAULT && s->sky_lut_transmittance && s->sky_lut_multiscattering;
+    const bool sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
     uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
     if (sun_allowed) {
       const OSky sky_v = osky_view(s);
@@ -221,7 +222,8 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     }
     uint2_t amb_color = {0, 0}, amb_ray = {0, 0};
     if (ambient_allowed) { /* direct_lighting.cuh:385-403 */
-      amb_color = record_pack(c_mul(sky_color, bounce.weight));
+      const RGBF ambient = (s->sky_mode == SKY_MODE_HDRI) ? sky_hdri_color(s, g.position, bounce.ray, 0) : sky_color; /* sky_color_no_compute(.., 0) */
+      amb_color = record_pack(c_mul(ambient, bounce.weight));
       amb_ray = ray_pack(bounce.ray);
     }
 
@@ -573,6 +575,10 @@ void oracle_sky_color(const OracleScene* scene, const float origin_world[3], con
   const OSky s = osky_view(scene);
   const RGBF c = sky_get_color(&s, world_to_sky(&s, v3(origin_world[0], origin_world[1], origin_world[2])), v3(ray[0], ray[1], ray[2]), FLT_MAX, include_sun != 0,
                                (int) s.steps, random_offset);
+  out[0] = c.r; out[1] = c.g; out[2] = c.b;
+}
+void oracle_sky_hdri_color(const OracleScene* scene, const float origin_world[3], const float ray[3], uint32_t state, float out[3]) {
+  const RGBF c = sky_hdri_color(scene, v3(origin_world[0], origin_world[1], origin_world[2]), v3(ray[0], ray[1], ray[2]), state);
   out[0] = c.r; out[1] = c.g; out[2] = c.b;
 }
 void oracle_sky_hdri(const OracleScene* scene, const float origin_world[3], uint32_t dim, uint32_t samples, float* rgba) {

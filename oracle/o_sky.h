@@ -526,6 +526,29 @@ static inline RGBF sky_sun_color(const OSky* s, vec3 origin, vec3 ray) { /* sky_
   return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
 }
 /* bsdf_sample_for_sun_pdf<GEOMETRY>, bsdf.cuh:438-458: the world-space V goes into the bounded-VNDF density as it does there */
+/* ---- baked panorama as the sky (sky mode HDRI) ----
+ * sky_hdri_sample, sky_utils.cuh:49-63: equirectangular lookup, point filter (device_sky.c:352), wrap addressing (texture_create's default),
+ * no gamma; the texel of a normalised coordinate u is floor(frac(u) * dim). */
+static inline RGBF sky_hdri_sample(const OracleScene* sc, vec3 ray) {
+  if (!sc->sky_hdri || !sc->sky_hdri_dim) return c_splat(0.0f);
+  const float theta = o_atan2(ray.z, ray.x), phi = o_asin(ray.y);
+  const float u = (theta + REF_PI) / (2.0f * REF_PI);
+  const float v = 1.0f - ((phi + 0.5f * REF_PI) / REF_PI);
+  const float dim = (float) sc->sky_hdri_dim;
+  const uint32_t x = (uint32_t) ((u - floorf(u)) * dim) % sc->sky_hdri_dim, y = (uint32_t) ((v - floorf(v)) * dim) % sc->sky_hdri_dim;
+  const float* t = sc->sky_hdri + 4 * ((size_t) x + (size_t) y * sc->sky_hdri_dim);
+  return c3(t[0], t[1], t[2]);
+}
+/* sky_color_main / sky_color_no_compute, HDRI branch (sky.cuh:534-606): the sun disk is not part of the panorama */
+static inline RGBF sky_hdri_color(const OracleScene* sc, vec3 origin, vec3 ray, uint32_t state) {
+  RGBF c = sky_hdri_sample(sc, ray);
+  if (state & (ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION)) {
+    const OSky s = osky_view(sc);
+    const vec3 sky_origin = world_to_sky(&s, origin);
+    if (sphere_hit(ray, sky_origin, s.sun_pos, SKY_SUN_RADIUS) && !sph_hit_p0(ray, sky_origin, SKY_EARTH_RADIUS)) c = c_add(c, sky_sun_color(&s, sky_origin, ray));
+  }
+  return c;
+}
 static inline float sun_bsdf_pdf(const GeoCtx* g, vec3 L, float reflection_prob, float refraction_prob) {
   const BSDFRayCtx c = bsdf_evaluate_analyze(&g->params, g->normal, g->V, L);
   const float roughness = mp_roughness(&g->params);

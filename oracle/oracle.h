@@ -73,6 +73,11 @@ typedef struct OracleScene {
   uint32_t sky_stars_count;
   const float* sky_stars;            /* 4 floats per star in grid order: altitude, azimuth, radius, intensity (utils.h:115-121) */
   const uint32_t* sky_stars_offsets; /* 64 x 32 + 1 cell offsets (device_sky.c:469-547) */
+  /* sky mode HDRI: a dim x dim equirectangular panorama, 4 floats per texel (device_sky.c:344-366). NULL = baked from the procedural sky
+     * at upload, seen from sky_hdri_origin with sky_hdri_samples samples per texel (sky.hdri_dim / hdri_samples, the camera position) */
+  const float* sky_hdri;
+  uint32_t sky_hdri_dim, sky_hdri_samples;
+  float sky_hdri_origin[3];
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -143,6 +148,9 @@ void oracle_generate_result(
  * of the sky seen from a world-space point along `ray` with the given ray-march offset in [0, 1). */
 void oracle_sky_generate_luts(const OracleScene* scene, float* transmittance, float* multiscattering);
 void oracle_sky_color(const OracleScene* scene, const float origin_world[3], const float ray[3], int include_sun, float random_offset, float out[3]);
+/* what a ray that leaves the scene sees in sky mode HDRI: the panorama's texel, plus the sun disk when `state` holds ST_CAMERA_DIRECTION (2) or
+ * ST_ALLOW_EMISSION (8) (sky_color_main's HDRI branch, cuda/sky.cuh:579-595) */
+void oracle_sky_hdri_color(const OracleScene* scene, const float origin_world[3], const float ray[3], uint32_t state, float out[3]);
 void oracle_sky_hdri(const OracleScene* scene, const float origin_world[3], uint32_t dim, uint32_t samples, float* rgba); /* sky_hdri.cuh:58-160 */
 float oracle_log2(float x);
 float oracle_exp2(float x);
