@@ -19,14 +19,22 @@ class OutputParams(C.Structure):
                 ("inv_sample_count", C.c_float), ("exposure", C.c_float), ("tonemap", C.c_uint32), ("filter", C.c_uint32), ("dithering", C.c_uint32),
                 ("purkinje", C.c_uint32), ("use_color_correction", C.c_uint32), ("passthrough", C.c_uint32), ("purkinje_kappa1", C.c_float),
                 ("purkinje_kappa2", C.c_float), ("cc_h", C.c_float), ("cc_s", C.c_float), ("cc_v", C.c_float), ("film_grain", C.c_float),
-                ("agx_slope", C.c_float), ("agx_power", C.c_float), ("agx_saturation", C.c_float)]
+                ("agx_slope", C.c_float), ("agx_power", C.c_float), ("agx_saturation", C.c_float), ("supersampling", C.c_uint32),
+                ("undersampling_stage", C.c_uint32)]
+
+    def output_planes_shape(self):
+        """Shape of the display-referred planes the chain keeps: the frame >> max(undersampling stage, supersampling)."""
+        uo = max(self.undersampling_stage, self.supersampling)
+        return (3, self.src_height >> uo, self.src_width >> uo)
 
 
-def default_output_params(width, height, sample_count, dst=None):
-    """Camera defaults of the reference (camera.c:7-66): AgX, dithering and Purkinje shift on, exposure exp(0)."""
+def default_output_params(width, height, sample_count, dst=None, supersampling=0, undersampling_stage=0):
+    """Camera defaults of the reference (camera.c:7-66): AgX, dithering and Purkinje shift on, exposure exp(0). `width`, `height`: the
+    rendered frame (output size << supersampling); `dst` defaults to the nominal output size."""
     p = OutputParams()
     p.src_width, p.src_height = width, height
-    p.dst_width, p.dst_height = dst if dst else (width, height)
+    p.supersampling, p.undersampling_stage = supersampling, undersampling_stage
+    p.dst_width, p.dst_height = dst if dst else (width >> supersampling, height >> supersampling)
     p.inv_sample_count = np.float32(1.0) / np.float32(sample_count)
     p.exposure = 1.0
     p.tonemap, p.filter, p.dithering, p.purkinje = 4, 0, 1, 1
@@ -88,7 +96,7 @@ class Core:
         accumulators, an int = device pointer to a planar [3*P] first moment, a numpy array = host data (uploaded). Optionally also
         returns the display-referred float planes [3, src_height, src_width]."""
         out = np.zeros((params.dst_height, params.dst_width), dtype=np.uint32)
-        planes = np.zeros((3, params.src_height, params.src_width), dtype=np.float32) if want_float else None
+        planes = np.zeros(params.output_planes_shape(), dtype=np.float32) if want_float else None
         pl = planes.ctypes.data_as(C.c_void_p) if want_float else C.c_void_p(0)
         if isinstance(first_moment, np.ndarray):
             fm = np.ascontiguousarray(first_moment, dtype=np.float32)
@@ -187,6 +195,14 @@ class Core:
                 "blocks": (int(info.blocks_x), int(info.blocks_y)), "tasks_per_execution": int(info.tasks_per_execution),
                 "variance_total": float(info.variance_total), "build_pending": bool(info.build_pending)}
 
+    @staticmethod
+    def adaptive_info_of(ctx):
+        """adaptive_info of a context owned by somebody else (Host.core_context())."""
+        info = AdaptiveInfo()
+        if _lib().lumc_adaptive_info(C.c_void_p(ctx), C.byref(info)):
+            raise CoreError("lumc_adaptive_info failed")
+        return {"stage_id": int(info.stage_id), "executions": [int(x) for x in info.executions]}
+
     def adaptive_download(self):
         n = self.adaptive_info()["num_blocks"]
         counts = np.zeros(n, dtype=np.uint32)
@@ -219,6 +235,19 @@ class Core:
         self._call("lumc_generate_result_host", C.c_uint32(mode), C.c_uint32(1 if local_error_minimization else 0), C.c_uint32(uniform_samples),
                    C.c_float(exposure), tp, out.ctypes.data_as(C.c_void_p))
         return out
+
+    def render_undersampled(self, stage, iteration, stream=0):
+        """Adds sample 0 of the pixels of one undersampling iteration to the full-frame accumulators (lumc_render_undersampled)."""
+        self._call("lumc_render_undersampled", C.c_uint32(stage), C.c_uint32(iteration), C.c_void_p(stream))
+
+    def generate_result_undersampled(self, stage, iteration):
+        """The compact preview image [3, H >> stage, W >> stage] of the pixels rendered so far."""
+        out = np.zeros((3, self.height >> stage, self.width >> stage), dtype=np.float32)
+        self._call("lumc_generate_result_undersampled_host", C.c_uint32(stage), C.c_uint32(iteration), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def adaptive_note_first_sample(self):
+        self._call("lumc_adaptive_note_first_sample", C.c_void_p(0))
 
     def set_bvh_builder(self, name):
         """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
@@ -261,3 +290,12 @@ def scene_view_sizeof():
     fn = _lib().lumc_scene_view_sizeof
     fn.restype = C.c_uint32
     return fn()
+
+
+def undersampling_schedule(undersampling):
+    """(stage, iteration) of every render iteration of the first sample, in order (device.c:392-420, :1298-1307): stage N four
+    times (iterations 3, 2, 1, 0), every finer stage three times (2, 1, 0). Empty for undersampling 0."""
+    out = []
+    for stage in range(undersampling, 0, -1):
+        out += [(stage, it) for it in ((3, 2, 1, 0) if stage == undersampling else (2, 1, 0))]
+    return out

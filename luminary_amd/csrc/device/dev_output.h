@@ -3,8 +3,7 @@
 // cuda/tonemap.cuh (exposure, colour correction, film grain, Purkinje shift, tone curves), cuda/kernels.cuh:558-644
 // (convert_RGBF_to_ARGB8: optional bilinear resize, filters, dither, sRGB), cuda/math.cuh:1040-1170, :1483-1543, cuda/purkinje.cuh,
 // cuda/post_common.cuh:6-50, cuda/random.cuh:144-154, :197-212, :370-379.
-// Scope of this implementation: undersampling/supersampling 0 (what the benchmark driver sets), no bloom, no local error
-// minimisation, beauty output mode.
+// Scope of this implementation: any supersampling and undersampling stage; no bloom.
 // Numerics: the reference uses fast-math log2f/powf/rsqrtf whose bits are unspecified; here log2, exp2 and pow are the fixed
 // sequences below (relative error < 3e-7), mirrored operation by operation in oracle/o_output.h, so the bytes of an image are a
 // pure function of the moments on any device.
@@ -23,6 +22,9 @@ struct OutputParams {
   float cc_h, cc_s, cc_v;
   float film_grain;
   float agx_slope, agx_power, agx_saturation;
+  // settings.supersampling (the rendered frame is the nominal output size << supersampling) and the stage of the undersampling preview
+  // the input image belongs to (0 = a full result image; s > 0 = the compact (src >> s) image of k_result_undersampled)
+  uint32_t supersampling, undersampling_stage;
 };
 
 LUM_DEV float linear_to_srgb(float v) { return (v <= 0.0031308f) ? 12.92f * v : 1.055f * pow_det(v, 0.416666666667f) - 0.055f; }  // math.cuh:1044-1051
@@ -180,25 +182,66 @@ LUM_DEV Col display_transform(const OutputParams& p, Col px, uint32_t x, uint32_
   return tonemap_curve(p, px);
 }
 
-// accumulation_generate_result + generate_final_image at output scale 1: planar moments -> planar display-referred RGB
-__global__ __launch_bounds__(256) void k_final_image(OutputParams p, const float* __restrict__ first_moment, float* __restrict__ frame_output) {
-  const uint32_t n = p.src_width * p.src_height;
+// generate_final_image, kernels.cuh:503-556 (with accumulation_generate_result's division by the sample count folded in): planar input
+// image of (src >> stage) pixels -> planar display-referred RGB of (src >> max(stage, supersampling)) pixels; every output pixel is the
+// mean of the output_scale^2 tone-mapped input pixels below it, summed row by row.
+__global__ __launch_bounds__(256) void k_final_image(OutputParams p, const float* __restrict__ input, float* __restrict__ frame_output) {
+  const uint32_t ui = p.undersampling_stage, uo = max(ui, p.supersampling);
+  const uint32_t output_scale = 1u << (uo - ui);
+  const uint32_t out_w = p.src_width >> uo, out_h = p.src_height >> uo, in_w = p.src_width >> ui, in_h = p.src_height >> ui;
+  const uint32_t n = out_w * out_h, n_in = in_w * in_h;
+  const float norm = 1.0f / (output_scale * output_scale);
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const uint32_t y = i / p.src_width, x = i - y * p.src_width;
-    Col px = col(first_moment[i] * p.inv_sample_count, first_moment[n + i] * p.inv_sample_count, first_moment[2 * n + i] * p.inv_sample_count);
-    px = display_transform(p, px, x, y);
-    frame_output[i] = px.r; frame_output[n + i] = px.g; frame_output[2 * n + i] = px.b;
+    const uint32_t y = i / out_w, x = i - y * out_w;
+    const uint32_t source_x = x * output_scale, source_y = y * output_scale;
+    Col color = splat(0.0f);
+    for (uint32_t yi = 0; yi < output_scale; yi++) {
+      for (uint32_t xi = 0; xi < output_scale; xi++) {
+        const uint32_t px_x = min(source_x + xi, in_w - 1), px_y = min(source_y + yi, in_h - 1);
+        const uint32_t index = px_x + px_y * in_w;
+        Col px = col(input[index] * p.inv_sample_count, input[n_in + index] * p.inv_sample_count, input[2 * n_in + index] * p.inv_sample_count);
+        color = color + display_transform(p, px, px_x, px_y);
+      }
+    }
+    color = color * norm;
+    frame_output[i] = color.r; frame_output[n + i] = color.g; frame_output[2 * n + i] = color.b;
   }
 }
 
-// post_sample_buffer_clamp, post_common.cuh:6-44 (mem_scale 1)
-LUM_DEV float sample_plane(const float* __restrict__ plane, float x, float y, uint32_t width, uint32_t height) {
+// accumulation_generate_result_undersampling, accumulation.cuh:192-254: while the first sample is rendered coarse to fine, block (x, y) of
+// 2^stage pixels shows the mean of the 4 - iteration pixels of it that exist so far (pattern of kernels.cuh:20-45). Output: compact
+// planar image of (width >> stage) x (height >> stage).
+__global__ __launch_bounds__(256) void k_result_undersampled(const float* __restrict__ first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration,
+                                                             float* __restrict__ result) {
+  const uint32_t scale = 1u << stage, w = width >> stage, h = height >> stage, n = w * h, frame = width * height;
+  const float color_scale = 1.0f / (4 - iteration);
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t dst_y = i / w, dst_x = i - dst_y * w;
+    const uint32_t base_x = dst_x << stage, base_y = dst_y << stage;
+    Col sum = splat(0.0f);
+    for (uint32_t id = iteration; id < 4; id++) {
+      const uint32_t px = min(base_x + ((id & 1u) ? 0u : scale >> 1), width - 1), py = min(base_y + ((id & 2u) ? 0u : scale >> 1), height - 1);
+      const uint32_t index = px + py * width;
+      sum = sum + col(first_moment[index], first_moment[frame + index], first_moment[2 * frame + index]);
+    }
+    sum = sum * color_scale;
+    result[i] = sum.r; result[n + i] = sum.g; result[2 * n + i] = sum.b;
+  }
+}
+
+// post_sample_buffer_clamp, post_common.cuh:6-59. `width`/`height` are the nominal output size; a coarser image in memory is addressed
+// through mem_scale = 2^-k, whose index arithmetic the reference carries out in float (kept: it decides the rounding of the row offset).
+// `last`: index of the plane's last element. A frame that is not a multiple of the coarse block makes the reference read past the coarse
+// image (stale memory); such indices are clamped here so that the bytes stay a function of the input.
+LUM_DEV float sample_plane(const float* __restrict__ plane, float x, float y, uint32_t width, uint32_t height, float mem_scale, uint32_t last) {
   x = fminf(fmaxf(x, 0.0f), bitsf(0x3F7FFFFFu));
   y = fminf(fmaxf(y, 0.0f), bitsf(0x3F7FFFFFu));
-  const float sx = fmaxf(0.0f, x * (width - 1)), sy = fmaxf(0.0f, y * (height - 1));
+  const float sx = fmaxf(0.0f, x * (width - 1)) * mem_scale, sy = fmaxf(0.0f, y * (height - 1)) * mem_scale;
   const uint32_t x0 = (uint32_t) sx, y0 = (uint32_t) sy;
-  const uint32_t x1 = min((uint32_t) (sx + 1.0f), width - 1), y1 = min((uint32_t) (sy + 1.0f), height - 1);
-  const float p00 = plane[x0 + y0 * width], p01 = plane[x0 + y1 * width], p10 = plane[x1 + y0 * width], p11 = plane[x1 + y1 * width];
+  const uint32_t x1 = min((uint32_t) (sx + mem_scale), width - 1), y1 = min((uint32_t) (sy + mem_scale), height - 1);
+  const uint32_t i00 = (uint32_t) ((float) x0 + (float) (y0 * width) * mem_scale), i01 = (uint32_t) ((float) x0 + (float) (y1 * width) * mem_scale);
+  const uint32_t i10 = (uint32_t) ((float) x1 + (float) (y0 * width) * mem_scale), i11 = (uint32_t) ((float) x1 + (float) (y1 * width) * mem_scale);
+  const float p00 = plane[min(i00, last)], p01 = plane[min(i01, last)], p10 = plane[min(i10, last)], p11 = plane[min(i11, last)];
   const float fx = sx - x0, ifx = 1.0f - fx, fy = sy - y0, ify = 1.0f - fy;
   float r = p00 * (ifx * ify);
   r += p01 * (ifx * fy);
@@ -247,18 +290,25 @@ LUM_DEV Col apply_filter(const OutputParams& p, const uint16_t* __restrict__ bn,
 // convert_RGBF_to_ARGB8, kernels.cuh:558-644 (bytes b, g, r, a)
 __global__ __launch_bounds__(256) void k_to_argb8(OutputParams p, const float* __restrict__ frame_output, const uint16_t* __restrict__ bluenoise_1d,
                                                   uint32_t* __restrict__ dst) {
-  const uint32_t n = p.dst_width * p.dst_height, ns = p.src_width * p.src_height;
+  const uint32_t uo = max(p.undersampling_stage, p.supersampling), um = uo - p.supersampling;
+  const uint32_t nominal_w = p.src_width >> p.supersampling, nominal_h = p.src_height >> p.supersampling;  // the size the frame is rendered for
+  const uint32_t mem_w = p.src_width >> uo, mem_h = p.src_height >> uo, ns = mem_w * mem_h;                // the image in memory
+  const uint32_t n = p.dst_width * p.dst_height;
   const float scale_x = 1.0f / (p.dst_width - 1), scale_y = 1.0f / (p.dst_height - 1);
-  const bool scaled = p.dst_width != p.src_width || p.dst_height != p.src_height;
+  const float mem_scale = 1.0f / (1u << um);
+  const bool scaled = p.dst_width != nominal_w || p.dst_height != nominal_h;
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const uint32_t y = i / p.dst_width, x = i - y * p.dst_width;
     Col px;
     if (scaled) {
       const float sx = x * scale_x, sy = y * scale_y;
-      px = col(sample_plane(frame_output, sx, sy, p.src_width, p.src_height), sample_plane(frame_output + ns, sx, sy, p.src_width, p.src_height),
-               sample_plane(frame_output + 2 * ns, sx, sy, p.src_width, p.src_height));
+      px = col(sample_plane(frame_output, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1), sample_plane(frame_output + ns, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1),
+               sample_plane(frame_output + 2 * ns, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1));
     }
-    else px = col(frame_output[i], frame_output[ns + i], frame_output[2 * ns + i]);
+    else {
+      const uint32_t src = min(x >> um, mem_w - 1) + min(y >> um, mem_h - 1) * mem_w;  // the edge repeats where the reference reads past the coarse image
+      px = col(frame_output[src], frame_output[ns + src], frame_output[2 * ns + src]);
+    }
     px = apply_filter(p, bluenoise_1d, px, x, y);
     const float dither = p.dithering ? dither_mask(bluenoise_1d, x, y) : 0.5f;
     const float r = fmaxf(0.0f, fminf(255.9999f, dither + 255.0f * linear_to_srgb(px.r)));

@@ -607,6 +607,18 @@ __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* results, ui
   }
 }
 
+// One sample of a subset of the frame's pixels (an iteration of the undersampling preview, kernels.cuh:47-95): result p belongs to frame
+// pixel pixels[p]. accumulation_collect_results, accumulation.cuh:36-61, with one result per pixel.
+__global__ __launch_bounds__(kBlock) void k_accumulate_scatter(const float4* results, const uint32_t* pixels, uint32_t count, uint32_t frame_pixels, float* first_moment,
+                                                               float* second_moment) {
+  for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < count; p += gridDim.x * kBlock) {
+    const uint32_t index = pixels[p];
+    const float4 v = results[p];
+    first_moment[index] += v.x; first_moment[frame_pixels + index] += v.y; first_moment[2 * frame_pixels + index] += v.z;
+    if (second_moment) second_moment[index] += luminance(col(v.x * v.x, v.y * v.y, v.z * v.z));
+  }
+}
+
 // ---- standalone closest-hit entry for traversal tests and the trace micro-benchmark ----
 struct RaysQuery : ClosestState {
   const float* origins; const float* dirs; const uint32_t* ignore; uint32_t* out;

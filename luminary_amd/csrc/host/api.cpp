@@ -454,12 +454,33 @@ LumOutputParams output_params(const LuminaryHost* h, uint32_t dst_width, uint32_
   p.cc_h = c.color_correction.r; p.cc_s = c.color_correction.g; p.cc_v = c.color_correction.b;
   p.film_grain = c.film_grain;
   p.agx_slope = c.agx_custom_slope; p.agx_power = c.agx_custom_power; p.agx_saturation = c.agx_custom_saturation;
+  p.supersampling = h->scene.settings.supersampling;  // the frame is rendered at output size << supersampling (device_structs.c:20-21)
   return p;
+}
+
+// One render iteration of the undersampling preview (device.c:392-420): stage > 0 while the frame's first sample is rendered coarse to fine.
+struct PreviewState { uint32_t stage = 0, iteration = 0; };
+
+// device_setup_undersampling, device.c:1281-1310: the preview runs only when somebody watches (recurring outputs), never for render regions.
+// Schedule: stage N with iterations 3..0, stages N-1..1 with iterations 2..0.
+std::vector<PreviewState> preview_schedule(LuminaryHost* h) {
+  std::vector<PreviewState> out;
+  const LuminaryRendererSettings& st = h->scene.settings;
+  if (!h->outputs.properties().enabled || !(st.region_width >= 1.0f && st.region_height >= 1.0f)) return out;
+  for (uint32_t stage = st.undersampling & 31u; stage > 0; stage--)
+    for (uint32_t it = (stage == (st.undersampling & 31u)) ? 4u : 3u; it-- > 0;) { PreviewState ps; ps.stage = stage; ps.iteration = it; out.push_back(ps); }
+  return out;
 }
 
 // accumulation_generate_result (accumulation.cuh:86-200) into the core's result image; the output chain then reads that image with a
 // sample count of one. Returns the parameters to hand to lumc_generate_output*.
-int result_image(LuminaryHost* h, LumOutputParams* p) {
+int result_image(LuminaryHost* h, LumOutputParams* p, PreviewState preview) {
+  if (preview.stage) {  // accumulation_generate_result_undersampling (device_renderer.c:410-420): the coarse image of the pixels that exist so far
+    if (lumc_generate_result_undersampled(h->core, preview.stage, preview.iteration, nullptr, nullptr)) return 1;
+    p->inv_sample_count = 1.0f;
+    p->undersampling_stage = preview.stage;
+    return 0;
+  }
   const uint32_t mode = (uint32_t) h->scene.settings.adaptive_sampling_output_mode;
   const uint32_t lem = h->scene.camera.use_local_error_minimization ? 1u : 0u;
   if (lumc_generate_result(h->core, mode, lem, h->adaptive_active ? 0u : h->accumulated_samples, p->exposure, p, nullptr, nullptr)) return 1;
@@ -468,8 +489,9 @@ int result_image(LuminaryHost* h, LumOutputParams* p) {
 }
 
 // device_output_generate_output, device_output.c:203-270: the recurring output if enabled, then every request that is due now
-LuminaryResult produce_outputs(LuminaryHost* h) {
-  if (!h->pixels_all || h->accumulated_samples == 0) return LUMINARY_SUCCESS;
+// `preview`: the state of the iteration just rendered (device.c:1509-1536 generates the output before the state advances).
+LuminaryResult produce_outputs(LuminaryHost* h, PreviewState preview = PreviewState()) {
+  if (!h->pixels_all || (h->accumulated_samples == 0 && preview.stage == 0)) return LUMINARY_SUCCESS;
   const LuminaryOutputProperties props = h->outputs.properties();
   lum::OutputMeta meta;
   meta.sample_count = h->accumulated_samples;
@@ -478,7 +500,7 @@ LuminaryResult produce_outputs(LuminaryHost* h) {
     meta.width = props.width; meta.height = props.height;
     const uint32_t handle = h->outputs.begin_recurring(meta);
     LumOutputParams p = output_params(h, meta.width, meta.height);
-    if (result_image(h, &p) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr)) {
+    if (result_image(h, &p, preview) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr)) {
       h->outputs.publish(handle);
       return LUMINARY_ERROR_CUDA;
     }
@@ -490,7 +512,7 @@ LuminaryResult produce_outputs(LuminaryHost* h) {
     uint32_t handle;
     if (h->outputs.begin_for_request(meta, &handle)) continue;
     LumOutputParams p = output_params(h, meta.width, meta.height);
-    const int rc = result_image(h, &p) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr);
+    const int rc = result_image(h, &p, preview) || lumc_generate_output_host(h->core, &p, lumc_result_image(h->core), h->outputs.data(handle), nullptr);
     h->outputs.publish(handle);
     if (rc) return LUMINARY_ERROR_CUDA;
   }
@@ -534,12 +556,53 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
   }
   return LUMINARY_SUCCESS;
 }
+// The frame's first sample as the undersampling preview: every iteration renders one pixel per block, then the outputs are produced
+// from the coarse image; the last iteration completes sample 0 of every pixel. Returns through *ran whether the preview applied.
+static LuminaryResult render_first_sample_as_preview(LuminaryHost* host, bool* ran) {
+  *ran = false;
+  const std::vector<PreviewState> schedule = preview_schedule(host);
+  if (schedule.empty() || host->accumulated_samples != 0 || !host->pixels_all) return LUMINARY_SUCCESS;
+  for (size_t k = 0; k < schedule.size(); k++) {
+    const auto t0 = std::chrono::steady_clock::now();
+    if (lumc_render_undersampled(host->core, schedule[k].stage, schedule[k].iteration, nullptr) || lumc_synchronize(host->core)) {
+      std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core));
+      return LUMINARY_ERROR_CUDA;
+    }
+    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (k + 1 == schedule.size()) host->accumulated_samples = 1;  // device_renderer_finish_iteration counts the sample with the last iteration
+    const LuminaryResult r = produce_outputs(host, schedule[k]);
+    if (r) return r;
+  }
+  *ran = true;
+  return LUMINARY_SUCCESS;
+}
+
 // The reference's render loop for `num_samples` more sample allocations of the whole frame (device_renderer.c:488-575): with
 // settings.enable_adaptive_sampling the stage schedule of the adaptive sampler, otherwise one sample id per pixel and allocation.
 LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
   CHECK_NULL(host);
   const LuminaryRendererSettings settings = host->scene.settings;
-  if (!settings.enable_adaptive_sampling) return luminary_ext_render_samples(host, nullptr, 0, host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0, num_samples, 8);
+  if (!settings.enable_adaptive_sampling) {
+    uint32_t first = host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0;
+    if (first == 0 && num_samples > 0) {  // a new accumulation: its first sample may be due as the undersampling preview
+      std::lock_guard<std::mutex> lock(host->mutex);
+      const LuminaryResult r = ensure_core(host);
+      if (r) return r;
+      if (!preview_schedule(host).empty()) {
+        if (lumc_set_pixels(host->core, nullptr, 0)) return LUMINARY_ERROR_CUDA;
+        host->adaptive_active = false;
+        host->pixels_all = true;
+        host->num_pixels = host->device_scene.view.width * host->device_scene.view.height;
+        host->accumulated_samples = 0;
+        host->render_seconds = 0.0;
+        bool ran = false;
+        const LuminaryResult rp = render_first_sample_as_preview(host, &ran);
+        if (rp) return rp;
+        if (ran) { first = 1; num_samples--; }
+      }
+    }
+    return luminary_ext_render_samples(host, nullptr, 0, first, num_samples, 8);
+  }
   std::lock_guard<std::mutex> lock(host->mutex);
   LuminaryResult r = ensure_core(host);
   if (r) return r;
@@ -560,6 +623,15 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
     host->adaptive_active = true;
   }
   uint32_t done = 0;
+  if (host->accumulated_samples == 0 && num_samples > 0) {  // execution 0 of stage 0 as the undersampling preview, when one is due
+    bool ran = false;
+    r = render_first_sample_as_preview(host, &ran);
+    if (r) return r;
+    if (ran) {
+      if (lumc_adaptive_note_first_sample(host->core, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+      done = 1;
+    }
+  }
   while (done < num_samples) {
     uint32_t chunk = num_samples - done;
     for (const LuminaryOutputRequestProperties& req : host->outputs.pending_requests())

@@ -75,6 +75,8 @@ struct LumContext {
   } adaptive;
   float4* d_sky_hdri = nullptr;     // baked sky (lumc_sky_hdri_build): dim x dim equirectangular, rgb + 0
   uint32_t sky_hdri_dim = 0;
+  uint32_t* d_undersampling_pixels = nullptr;  // pixel list of the current undersampling iteration (lumc_render_undersampled)
+  uint32_t undersampling_capacity = 0;
   std::vector<uint32_t> sky_hdri_key;  // what the bake was made from (sky parameters, origin, dim, samples): an unchanged key reuses it
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
@@ -306,6 +308,7 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
   if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
+  if (ctx->d_undersampling_pixels) (void) hipFree(ctx->d_undersampling_pixels);
   free_adaptive(ctx);
   delete ctx;
 }
@@ -757,6 +760,61 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
   return 0;
 }
 
+// The pixels of one iteration of the undersampling preview (tasks_create, cuda/kernels.cuh:47-95, whole-frame window): one per block of
+// 2^stage pixels, at the block's corner or half a block in, by the iteration's two bits.
+static std::vector<uint32_t> undersampling_pixels(uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration) {
+  const uint32_t scale = 1u << stage;
+  const uint32_t uw = (width + scale - 1) >> stage, uh = (height + scale - 1) >> stage;
+  std::vector<uint32_t> px;
+  px.reserve((size_t) uw * uh);
+  for (uint32_t id = 0; id < uw * uh; id++) {
+    uint32_t y = id / uw, x = id - y * uw;
+    if (scale > 1) {
+      x = x * scale + ((iteration & 1u) ? 0u : scale >> 1);
+      y = y * scale + ((iteration & 2u) ? 0u : scale >> 1);
+    }
+    if (x >= width || y >= height) continue;
+    px.push_back(x + y * width);
+  }
+  return px;
+}
+
+int lumc_render_undersampled(LumContext* ctx, uint32_t stage, uint32_t iteration, void* stream_) {
+  if (!ctx || !ctx->has_scene || !ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height) {
+    if (ctx) ctx->error = "lumc_render_undersampled: needs the full-frame accumulators";
+    return 1;
+  }
+  if (stage == 0 || stage > 15 || iteration > 3) { ctx->error = "lumc_render_undersampled: stage in [1, 15], iteration in [0, 3]"; return 1; }
+  hipStream_t stream = (hipStream_t) stream_;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const DeviceScene& sc = ctx->scene;
+  const std::vector<uint32_t> px = undersampling_pixels(sc.width, sc.height, stage, iteration);
+  const uint32_t n = (uint32_t) px.size();
+  if (n == 0) return 0;
+  if (ctx->undersampling_capacity < n) {
+    if (ctx->d_undersampling_pixels) (void) hipFree(ctx->d_undersampling_pixels);
+    ctx->d_undersampling_pixels = nullptr; ctx->undersampling_capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_undersampling_pixels, sizeof(uint32_t) * (size_t) n));
+    ctx->undersampling_capacity = n;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(ctx->d_undersampling_pixels, px.data(), sizeof(uint32_t) * (size_t) n, hipMemcpyHostToDevice, stream));
+  HIP_TRY(ctx, hipStreamSynchronize(stream));  // the list leaves scope
+  if (ensure_work(ctx, n)) return 1;
+  PassParams pp{ctx->d_undersampling_pixels, n, 1u, 0u};  // every pixel's first sample
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (sc.max_ray_depth + 2), stream));
+  {
+    Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
+    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
+  }
+  if (wavefront_depths(ctx, stream, n)) return 1;
+  {
+    Launch l(ctx, stream, LUMC_KERNEL_ACCUMULATE);
+    hipLaunchKernelGGL(k_accumulate_scatter, dim3(grid_for(n)), dim3(kBlock), 0, stream, (const float4*) ctx->d_results, (const uint32_t*) ctx->d_undersampling_pixels, n,
+                       ctx->num_pixels, ctx->d_first_moment, ctx->d_second_moment);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
 
 // ---- adaptive sampling ----
 namespace {
@@ -935,6 +993,19 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
   return 0;
 }
 
+int lumc_adaptive_note_first_sample(LumContext* ctx, void* stream_) {
+  if (!ctx || !ctx->adaptive.active) { if (ctx) ctx->error = "lumc_adaptive_note_first_sample: call lumc_adaptive_begin first"; return 1; }
+  LumContext::Adaptive& a = ctx->adaptive;
+  if (a.stage_id != 0 || a.executions[0] != 0) { ctx->error = "lumc_adaptive_note_first_sample: the first execution is already done"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  a.executions[0] = 1;
+  if (a.executions[0] >= (uint64_t) a.params.update_interval) {
+    if (a.d_block_mask) { a.build_pending = true; return 0; }
+    if (adaptive_build_stage(ctx, (hipStream_t) stream_)) return 1;
+  }
+  return 0;
+}
+
 int lumc_adaptive_set_partition(LumContext* ctx, const uint8_t* block_mask) {
   if (!ctx || !ctx->adaptive.active || !block_mask) { if (ctx) ctx->error = "lumc_adaptive_set_partition: adaptive mode is not active or null mask"; return 1; }
   LumContext::Adaptive& a = ctx->adaptive;
@@ -1037,6 +1108,44 @@ int lumc_generate_result_host(LumContext* ctx, uint32_t mode, uint32_t local_err
   return 0;
 }
 
+int lumc_generate_result_undersampled(LumContext* ctx, uint32_t stage, uint32_t iteration, float* d_result, void* stream_) {
+  if (!ctx || !ctx->has_scene || !ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height) {
+    if (ctx) ctx->error = "lumc_generate_result_undersampled: needs the full-frame accumulators";
+    return 1;
+  }
+  if (stage == 0 || stage > 15 || iteration > 3) { ctx->error = "lumc_generate_result_undersampled: stage in [1, 15], iteration in [0, 3]"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t) stream_;
+  const uint32_t n = ctx->num_pixels;
+  if (!d_result) {
+    if (ctx->frame_result_pixels != n) {
+      if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
+      ctx->d_frame_result = nullptr; ctx->frame_result_pixels = 0;
+      HIP_TRY(ctx, hipMalloc((void**) &ctx->d_frame_result, sizeof(float) * 3 * (size_t) n));
+      ctx->frame_result_pixels = n;
+    }
+    d_result = ctx->d_frame_result;
+  }
+  const uint32_t compact = (ctx->scene.width >> stage) * (ctx->scene.height >> stage);
+  if (compact == 0) return 0;
+  {
+    Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
+    hipLaunchKernelGGL(k_result_undersampled, dim3(grid_for(compact)), dim3(256), 0, stream, (const float*) ctx->d_first_moment, ctx->scene.width, ctx->scene.height, stage, iteration,
+                       d_result);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int lumc_generate_result_undersampled_host(LumContext* ctx, uint32_t stage, uint32_t iteration, float* result) {
+  if (!ctx || !result) { if (ctx) ctx->error = "lumc_generate_result_undersampled_host: null argument"; return 1; }
+  if (lumc_generate_result_undersampled(ctx, stage, iteration, nullptr, nullptr)) return 1;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const size_t compact = (size_t) (ctx->scene.width >> stage) * (ctx->scene.height >> stage);
+  HIP_TRY(ctx, hipMemcpy(result, ctx->d_frame_result, sizeof(float) * 3 * compact, hipMemcpyDeviceToHost));
+  return 0;
+}
+
 const float* lumc_result_image(LumContext* ctx) { return ctx ? ctx->d_frame_result : nullptr; }
 
 int lumc_synchronize(LumContext* ctx) {
@@ -1089,8 +1198,13 @@ int lumc_generate_output(LumContext* ctx, const LumOutputParams* params, const f
   OutputParams p;
   std::memcpy(&p, params, sizeof(p));
   if (p.src_width == 0 || p.src_height == 0 || p.dst_width < 2 || p.dst_height < 2) { ctx->error = "lumc_generate_output: image sizes must be at least 2x2"; return 1; }
+  if (p.supersampling > 3 || p.undersampling_stage > 15) { ctx->error = "lumc_generate_output: supersampling at most 3, undersampling stage at most 15"; return 1; }
   const uint32_t ns = p.src_width * p.src_height;
+  const uint32_t uo = std::max(p.undersampling_stage, p.supersampling);
+  const uint32_t n_out = (p.src_width >> uo) * (p.src_height >> uo);
+  if (n_out == 0) { ctx->error = "lumc_generate_output: the frame is smaller than one output pixel"; return 1; }
   if (!d_first_moment) {
+    if (p.undersampling_stage) { ctx->error = "lumc_generate_output: an undersampled image must be passed explicitly (lumc_result_image)"; return 1; }
     if (!ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ns) { ctx->error = "lumc_generate_output: the context does not hold a full frame of this size"; return 1; }
     d_first_moment = ctx->d_first_moment;
   }
@@ -1108,7 +1222,7 @@ int lumc_generate_output(LumContext* ctx, const LumOutputParams* params, const f
   }
   {
     Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
-    hipLaunchKernelGGL(k_final_image, dim3(grid_for(ns)), dim3(256), 0, stream, p, d_first_moment, ctx->d_frame_output);
+    hipLaunchKernelGGL(k_final_image, dim3(grid_for(n_out)), dim3(256), 0, stream, p, d_first_moment, ctx->d_frame_output);
     hipLaunchKernelGGL(k_to_argb8, dim3(grid_for(p.dst_width * p.dst_height)), dim3(256), 0, stream, p, (const float*) ctx->d_frame_output,
                        (const uint16_t*) ctx->d_bluenoise_1d, d_argb8);
   }
@@ -1129,15 +1243,17 @@ int lumc_generate_output_host(LumContext* ctx, const LumOutputParams* params, co
   if (lumc_generate_output(ctx, params, d_first_moment, ctx->d_argb8, nullptr)) return 1;
   HIP_TRY(ctx, hipDeviceSynchronize());
   HIP_TRY(ctx, hipMemcpy(argb8, ctx->d_argb8, sizeof(uint32_t) * (size_t) n, hipMemcpyDeviceToHost));
-  if (frame_output)
-    HIP_TRY(ctx, hipMemcpy(frame_output, ctx->d_frame_output, sizeof(float) * 3 * (size_t) params->src_width * params->src_height, hipMemcpyDeviceToHost));
+  if (frame_output) {
+    const uint32_t uo = std::max(params->undersampling_stage, params->supersampling);
+    HIP_TRY(ctx, hipMemcpy(frame_output, ctx->d_frame_output, sizeof(float) * 3 * (size_t) (params->src_width >> uo) * (params->src_height >> uo), hipMemcpyDeviceToHost));
+  }
   return 0;
 }
 
 int lumc_generate_output_from_host(LumContext* ctx, const LumOutputParams* params, const float* first_moment, uint32_t* argb8, float* frame_output) {
   if (!ctx || !params || !first_moment || !argb8) { if (ctx) ctx->error = "lumc_generate_output_from_host: null argument"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  const size_t bytes = sizeof(float) * 3 * (size_t) params->src_width * params->src_height;
+  const size_t bytes = sizeof(float) * 3 * (size_t) (params->src_width >> params->undersampling_stage) * (params->src_height >> params->undersampling_stage);
   float* d = nullptr;
   HIP_TRY(ctx, hipMalloc((void**) &d, bytes));
   int rc = 1;

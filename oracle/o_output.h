@@ -5,7 +5,7 @@
  * (generate_final_image), cuda/tonemap.cuh:7-246, cuda/purkinje.cuh:19-90, cuda/math.cuh:1044-1060 (sRGB), :1081-1168 (filters),
  * :1483-1543 (HSV), cuda/post_common.cuh:6-44 (bilinear fetch), cuda/kernels.cuh:558-644 (convert_RGBF_to_ARGB8),
  * cuda/random.cuh:150-154, :197-212, :305-307, :370-379 (dither / grain masks).
- * Scope: undersampling = supersampling = 0, beauty output, no bloom, no local error minimisation.
+ * Scope: any supersampling and undersampling stage (incl. accumulation_generate_result_undersampling, accumulation.cuh:192-254); no bloom.
  * The reference's log2f/powf/rsqrtf are fast-math approximations with unspecified bits; log2/exp2/pow are fixed polynomial
  * sequences here (the HIP path uses the same sequences), which keeps the image bytes reproducible. Parity unpinned, like the
  * rest of the oracle: no golden image exists in the reference.
@@ -23,6 +23,7 @@ typedef struct {
   float cc_h, cc_s, cc_v;
   float film_grain;
   float agx_slope, agx_power, agx_saturation;
+  uint32_t supersampling, undersampling_stage; /* src = nominal output size << supersampling; stage s > 0: the input is the compact (src >> s) image */
 } OracleOutputParams;
 
 static inline float o_linear_to_srgb(float v) { return (v <= 0.0031308f) ? 12.92f * v : 1.055f * o_pow(v, 0.416666666667f) - 0.055f; }
@@ -181,16 +182,22 @@ static inline RGBF o_display_transform(const OracleOutputParams* p, RGBF px, uin
   return o_tonemap_curve(p, px);
 }
 
-/* post_common.cuh:6-44 */
-static inline float o_sample_plane(const float* plane, float x, float y, uint32_t width, uint32_t height) {
+/* post_common.cuh:6-59: width/height are the nominal output size, mem_scale = 2^-k addresses a coarser image in memory; the index
+ * arithmetic is the reference's (uint * uint, then float) */
+/* `last`: index of the plane's last element; the reference reads past the coarse image when the frame is not a multiple of the coarse block
+ * (stale memory) - such indices are clamped so that the bytes stay a function of the input */
+static inline uint32_t o_min_u32(uint32_t a, uint32_t b) { return a < b ? a : b; }
+static inline float o_sample_plane(const float* plane, float x, float y, uint32_t width, uint32_t height, float mem_scale, uint32_t last) {
   x = fminf(fmaxf(x, 0.0f), u2f(0x3F7FFFFFu));
   y = fminf(fmaxf(y, 0.0f), u2f(0x3F7FFFFFu));
-  const float sx = fmaxf(0.0f, x * (width - 1)), sy = fmaxf(0.0f, y * (height - 1));
+  const float sx = fmaxf(0.0f, x * (width - 1)) * mem_scale, sy = fmaxf(0.0f, y * (height - 1)) * mem_scale;
   const uint32_t x0 = (uint32_t) sx, y0 = (uint32_t) sy;
-  uint32_t x1 = (uint32_t) (sx + 1.0f), y1 = (uint32_t) (sy + 1.0f);
+  uint32_t x1 = (uint32_t) (sx + mem_scale), y1 = (uint32_t) (sy + mem_scale);
   if (x1 > width - 1) x1 = width - 1;
   if (y1 > height - 1) y1 = height - 1;
-  const float p00 = plane[x0 + y0 * width], p01 = plane[x0 + y1 * width], p10 = plane[x1 + y0 * width], p11 = plane[x1 + y1 * width];
+  const uint32_t i00 = (uint32_t) ((float) x0 + (float) (y0 * width) * mem_scale), i01 = (uint32_t) ((float) x0 + (float) (y1 * width) * mem_scale);
+  const uint32_t i10 = (uint32_t) ((float) x1 + (float) (y0 * width) * mem_scale), i11 = (uint32_t) ((float) x1 + (float) (y1 * width) * mem_scale);
+  const float p00 = plane[o_min_u32(i00, last)], p01 = plane[o_min_u32(i01, last)], p10 = plane[o_min_u32(i10, last)], p11 = plane[o_min_u32(i11, last)];
   const float fx = sx - x0, ifx = 1.0f - fx, fy = sy - y0, ify = 1.0f - fy;
   float r = p00 * (ifx * ify);
   r += p01 * (ifx * fy);
@@ -235,29 +242,75 @@ static inline RGBF o_apply_filter(const OracleOutputParams* p, const uint16_t* b
   }
 }
 
-/* frame_output: 3 planes of the rendered size (display-referred RGB); argb8: dst_width*dst_height words (b | g<<8 | r<<16 | a<<24) */
-static void output_generate(const OracleOutputParams* p, const float* first_moment, const uint16_t* bn, float* frame_output, uint32_t* argb8) {
-  const uint32_t ns = p->src_width * p->src_height;
+/* accumulation_generate_result_undersampling, accumulation.cuh:192-254: compact (width >> stage) x (height >> stage) planar image; block
+ * (x, y) of 2^stage pixels shows the mean of the 4 - iteration pixels of it rendered so far */
+static void output_result_undersampled(const float* first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration, float* result) {
+  const uint32_t scale = 1u << stage, w = width >> stage, h = height >> stage, n = w * h;
+  const size_t frame = (size_t) width * height;
+  const float color_scale = 1.0f / (4 - iteration);
+  for (uint32_t i = 0; i < n; i++) {
+    const uint32_t dst_y = i / w, dst_x = i - dst_y * w;
+    const uint32_t base_x = dst_x << stage, base_y = dst_y << stage;
+    RGBF sum = c_splat(0.0f);
+    for (uint32_t id = iteration; id < 4; id++) {
+      uint32_t px = base_x + ((id & 1u) ? 0u : scale >> 1), py = base_y + ((id & 2u) ? 0u : scale >> 1);
+      if (px > width - 1) px = width - 1;
+      if (py > height - 1) py = height - 1;
+      const size_t index = px + (size_t) py * width;
+      sum = c_add(sum, c3(first_moment[index], first_moment[frame + index], first_moment[2 * frame + index]));
+    }
+    sum = c_scale(sum, color_scale);
+    result[i] = sum.r; result[n + i] = sum.g; result[2 * (size_t) n + i] = sum.b;
+  }
+}
+
+/* generate_final_image (kernels.cuh:503-556) + convert_RGBF_to_ARGB8 (:558-644).
+ * input: 3 planes of (src >> stage) pixels; frame_output: 3 planes of (src >> max(stage, supersampling)) pixels (display-referred RGB);
+ * argb8: dst_width*dst_height words (b | g<<8 | r<<16 | a<<24) */
+static void output_generate(const OracleOutputParams* p, const float* input, const uint16_t* bn, float* frame_output, uint32_t* argb8) {
+  const uint32_t ui = p->undersampling_stage, uo = ui > p->supersampling ? ui : p->supersampling;
+  const uint32_t output_scale = 1u << (uo - ui);
+  const uint32_t out_w = p->src_width >> uo, out_h = p->src_height >> uo, in_w = p->src_width >> ui, in_h = p->src_height >> ui;
+  const uint32_t ns = out_w * out_h;
+  const size_t n_in = (size_t) in_w * in_h;
+  const float norm = 1.0f / (output_scale * output_scale);
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t) ns; i++) {
-    const uint32_t y = (uint32_t) i / p->src_width, x = (uint32_t) i - y * p->src_width;
-    RGBF px = c3(first_moment[i] * p->inv_sample_count, first_moment[ns + i] * p->inv_sample_count, first_moment[2 * (size_t) ns + i] * p->inv_sample_count);
-    px = o_display_transform(p, px, x, y);
-    frame_output[i] = px.r; frame_output[ns + i] = px.g; frame_output[2 * (size_t) ns + i] = px.b;
+    const uint32_t y = (uint32_t) i / out_w, x = (uint32_t) i - y * out_w;
+    const uint32_t source_x = x * output_scale, source_y = y * output_scale;
+    RGBF color = c_splat(0.0f);
+    for (uint32_t yi = 0; yi < output_scale; yi++) {
+      for (uint32_t xi = 0; xi < output_scale; xi++) {
+        uint32_t px_x = source_x + xi, px_y = source_y + yi;
+        if (px_x > in_w - 1) px_x = in_w - 1;
+        if (px_y > in_h - 1) px_y = in_h - 1;
+        const size_t index = px_x + (size_t) px_y * in_w;
+        const RGBF px = c3(input[index] * p->inv_sample_count, input[n_in + index] * p->inv_sample_count, input[2 * n_in + index] * p->inv_sample_count);
+        color = c_add(color, o_display_transform(p, px, px_x, px_y));
+      }
+    }
+    color = c_scale(color, norm);
+    frame_output[i] = color.r; frame_output[ns + i] = color.g; frame_output[2 * (size_t) ns + i] = color.b;
   }
+  const uint32_t um = uo - p->supersampling;
+  const uint32_t nominal_w = p->src_width >> p->supersampling, nominal_h = p->src_height >> p->supersampling;
   const uint32_t n = p->dst_width * p->dst_height;
   const float scale_x = 1.0f / (p->dst_width - 1), scale_y = 1.0f / (p->dst_height - 1);
-  const bool scaled = p->dst_width != p->src_width || p->dst_height != p->src_height;
+  const float mem_scale = 1.0f / (1u << um);
+  const bool scaled = p->dst_width != nominal_w || p->dst_height != nominal_h;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < (int64_t) n; i++) {
     const uint32_t y = (uint32_t) i / p->dst_width, x = (uint32_t) i - y * p->dst_width;
     RGBF px;
     if (scaled) {
       const float sx = x * scale_x, sy = y * scale_y;
-      px = c3(o_sample_plane(frame_output, sx, sy, p->src_width, p->src_height), o_sample_plane(frame_output + ns, sx, sy, p->src_width, p->src_height),
-              o_sample_plane(frame_output + 2 * (size_t) ns, sx, sy, p->src_width, p->src_height));
+      px = c3(o_sample_plane(frame_output, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1), o_sample_plane(frame_output + ns, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1),
+              o_sample_plane(frame_output + 2 * (size_t) ns, sx, sy, nominal_w, nominal_h, mem_scale, ns - 1));
     }
-    else px = c3(frame_output[i], frame_output[ns + i], frame_output[2 * (size_t) ns + i]);
+    else {
+      const size_t src = o_min_u32(x >> um, out_w - 1) + (size_t) o_min_u32(y >> um, out_h - 1) * out_w; /* the edge repeats where the reference reads past the image */
+      px = c3(frame_output[src], frame_output[ns + src], frame_output[2 * (size_t) ns + src]);
+    }
     px = o_apply_filter(p, bn, px, x, y);
     const float dither = p->dithering ? o_dither_mask(bn, x, y) : 0.5f;
     const float r = fmaxf(0.0f, fminf(255.9999f, dither + 255.0f * o_linear_to_srgb(px.r)));

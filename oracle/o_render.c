@@ -472,6 +472,9 @@ void oracle_generate_output(const OracleOutputParamsAbi* params, const float* fi
   memcpy(&p, params, sizeof(p));
   output_generate(&p, first_moment, bluenoise_1d, frame_output, argb8);
 }
+void oracle_result_undersampled(const float* first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration, float* result) {
+  output_result_undersampled(first_moment, width, height, stage, iteration, result);
+}
 float oracle_log2(float x) { return o_log2(x); }
 float oracle_exp2(float x) { return o_exp2(x); }
 float oracle_pow(float x, float y) { return o_pow(x, y); }

@@ -115,7 +115,7 @@ float oracle_atan2(float y, float x);
 void oracle_camera_ray(const OracleScene* scene, uint32_t x, uint32_t y, uint32_t sample_id, float out[6]);
 uint32_t oracle_scene_sizeof(void);
 
-/* Output chain (o_output.h): planar first moment [3 * src pixels] -> display-referred planes `frame_output` [3 * src pixels] and
+/* Output chain (o_output.h): planar first moment [3 * src pixels] -> display-referred planes `frame_output` and
  * ARGB8 words [dst pixels]. Field-for-field the same as LumOutputParams (include/lum_core.h). */
 typedef struct {
   uint32_t src_width, src_height, dst_width, dst_height;
@@ -125,8 +125,12 @@ typedef struct {
   float cc_h, cc_s, cc_v;
   float film_grain;
   float agx_slope, agx_power, agx_saturation;
+  uint32_t supersampling, undersampling_stage;
 } OracleOutputParamsAbi;
+/* input: planes of (src >> undersampling_stage) pixels; frame_output: planes of (src >> max(stage, supersampling)) pixels */
 void oracle_generate_output(const OracleOutputParamsAbi* params, const float* first_moment, const uint16_t* bluenoise_1d, float* frame_output, uint32_t* argb8);
+/* compact preview image of the undersampling iteration (stage, iteration): 3 planes of (width >> stage) x (height >> stage) */
+void oracle_result_undersampled(const float* first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration, float* result);
 /* Adaptive sampling (o_adaptive.h). Blocks are 4x4 pixels, row-major over ceil(width/4) x ceil(height/4); executions[s] = completed
  * executions of stage s; stage_counts[block] holds count-1 of stages 1..4 in its four bytes. */
 int oracle_render_counts(

@@ -116,3 +116,92 @@ def test_output_chain_matches_oracle(tonemap, filt, dither, dst, extras):
     assert np.array_equal(got_planes.view(np.uint32), want_planes.view(np.uint32)), "display-referred planes differ"
     assert np.array_equal(got, want), "%d of %d ARGB8 words differ" % ((got != want).sum(), got.size)
     assert got.max() > 0xFF000000
+
+
+# ---- supersampling and the undersampling preview (generate_final_image / convert_RGBF_to_ARGB8 with their scales) ----
+def test_oracle_supersampling_is_a_box_filter_of_tone_mapped_pixels():
+    w, h, spp = 48, 20, 3
+    fm = _synthetic_moment(w, h, spp, seed=2)
+    mean = (fm / np.float32(spp)).reshape(3, h, w)
+    for ss in (1, 2):
+        p = default_output_params(w, h, spp, supersampling=ss)
+        p.dithering = p.tonemap = p.purkinje = 0
+        assert (p.dst_width, p.dst_height) == (w >> ss, h >> ss)
+        argb, planes = oracle_lib.generate_output(p, fm)
+        assert planes.shape == (3, h >> ss, w >> ss) and argb.shape == (h >> ss, w >> ss)
+        k = 1 << ss
+        box = mean.reshape(3, h >> ss, k, w >> ss, k).astype(np.float64).mean(axis=(2, 4))
+        assert np.allclose(planes, box, rtol=2e-6)
+        # the full chain: identical to tone-mapping every rendered pixel, then averaging (not the other way round)
+        q = default_output_params(w, h, spp, supersampling=ss)
+        q0 = default_output_params(w, h, spp)
+        _, fine = oracle_lib.generate_output(q0, fm)
+        _, coarse = oracle_lib.generate_output(q, fm)
+        want = fine.reshape(3, h >> ss, k, w >> ss, k).astype(np.float64).mean(axis=(2, 4))
+        assert np.allclose(coarse, want, rtol=2e-6, atol=1e-7)
+    # a request of another size resamples the box-filtered image bilinearly: a constant frame stays constant
+    p = default_output_params(w, h, 1, dst=(31, 17), supersampling=1)
+    p.dithering = p.tonemap = p.purkinje = 0
+    flat = np.full((3, w * h), 0.25, np.float32)
+    img = _unpack(oracle_lib.generate_output(p, flat)[0])
+    assert img.shape[:2] == (17, 31) and len(np.unique(img[..., 0])) == 1
+
+
+def test_oracle_undersampling_preview_images():
+    from luminary_amd.core import undersampling_schedule
+    w, h = 37, 22   # not multiples of the block size
+    assert undersampling_schedule(0) == [] and undersampling_schedule(1) == [(1, 3), (1, 2), (1, 1), (1, 0)]
+    sched = undersampling_schedule(3)
+    assert sched == [(3, 3), (3, 2), (3, 1), (3, 0), (2, 2), (2, 1), (2, 0), (1, 2), (1, 1), (1, 0)]
+    seen = np.zeros(w * h, np.int32)
+    frame = np.zeros((3, w * h), np.float32)
+    value = np.random.default_rng(3).random((3, w * h), dtype=np.float32)
+    for stage, it in sched:
+        px = oracle_lib.undersampling_pixels(w, h, stage, it)
+        seen[px] += 1
+        frame[:, px] += value[:, px]
+        img = oracle_lib.result_undersampled(frame, w, h, stage, it)
+        assert img.shape == (3, h >> stage, w >> stage)
+        # every block shows the mean of its 4 - it rendered pixels
+        scale = 1 << stage
+        for (bx, by) in [(0, 0), ((w >> stage) - 1, (h >> stage) - 1)]:
+            pts = [(min(bx * scale + (0 if i & 1 else scale >> 1), w - 1), min(by * scale + (0 if i & 2 else scale >> 1), h - 1)) for i in range(it, 4)]
+            want = np.float32(0.0)
+            for (x, y) in pts:
+                assert seen[x + y * w] == 1, "the preview only reads pixels that exist"
+                want = want + value[0, x + y * w]
+            assert img[0, by, bx] == np.float32(want * np.float32(1.0 / (4 - it)))
+    assert (seen == 1).all(), "after the schedule every pixel holds exactly its first sample"
+    # the display chain of a coarse image: every stored pixel covers 2^(stage - supersampling) output pixels
+    stage = 2
+    compact = np.arange(3 * (h >> stage) * (w >> stage), dtype=np.float32).reshape(3, -1) / 100.0
+    p = default_output_params(w, h, 1, undersampling_stage=stage)
+    p.dithering = p.tonemap = p.purkinje = 0
+    argb, planes = oracle_lib.generate_output(p, compact)
+    assert planes.shape == (3, h >> stage, w >> stage) and argb.shape == (h, w)
+    assert (argb[:4, :4] == argb[0, 0]).all() and argb[0, 4] != argb[0, 0]
+    # with supersampling 1 a stage-1 image is shown as it is, a stage-2 image doubled
+    p1 = default_output_params(w * 2, h * 2, 1, supersampling=1, undersampling_stage=1)
+    p1.dithering = p1.tonemap = p1.purkinje = 0
+    src = np.random.default_rng(1).random((3, w * h), dtype=np.float32)
+    argb1, planes1 = oracle_lib.generate_output(p1, src)
+    assert planes1.shape == (3, h, w) and argb1.shape == (h, w) and np.array_equal(planes1.reshape(3, -1), src)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ss,stage,dst", [(1, 0, None), (2, 0, None), (1, 0, (100, 37)), (3, 0, (16, 9)), (1, 2, None), (0, 2, None), (1, 3, (64, 64)), (0, 1, (50, 30)),
+                                          (2, 1, None), (1, 1, None)])
+def test_output_chain_scales_match_oracle(ss, stage, dst):
+    """Supersampled frames and the coarse images of the undersampling preview through the display chain: bytes and planes identical."""
+    from luminary_amd.core import Core
+    core = Core(0)
+    w, h, spp = 168, 88, 5
+    fm = _synthetic_moment(w >> stage, h >> stage, spp, seed=7)
+    p = default_output_params(w, h, spp, dst=dst, supersampling=ss, undersampling_stage=stage)
+    p.film_grain = 0.2
+    got, got_planes = core.generate_output(p, fm, want_float=True)
+    want, want_planes = oracle_lib.generate_output(p, fm)
+    assert got_planes.shape == want_planes.shape
+    assert np.array_equal(got_planes.view(np.uint32), want_planes.view(np.uint32)), "display-referred planes differ"
+    assert np.array_equal(got, want), "%d of %d ARGB8 words differ" % ((got != want).sum(), got.size)
+    core.close()
