@@ -24,6 +24,7 @@ struct Material {
   float roughness_clamp, roughness, refraction_index;
   Col albedo; float alpha;
   Col emission;
+  float emission_scale;  // as stored: the material's scale over the emission normalisation (device_structs.c:289-303); scales textured emission
   uint32_t metallic_tex, albedo_tex, luminance_tex, roughness_tex, normal_tex;
 };
 
@@ -39,6 +40,7 @@ LUM_DEV Material load_material(const DeviceScene& sc, uint32_t id) {
   m.alpha            = unorm16(a.w >> 16);
   const float scale  = bitsf((b.y >> 16) << 15);
   m.emission         = col(unorm16(b.x), unorm16(b.x >> 16), unorm16(b.y)) * scale;
+  m.emission_scale   = scale;
   m.albedo_tex = b.z & 0xFFFFu; m.luminance_tex = b.z >> 16; m.roughness_tex = b.w & 0xFFFFu; m.normal_tex = b.w >> 16;
   return m;
 }

@@ -165,7 +165,7 @@ LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const GeoContext& g, const
 }
 
 // ---- triangle lights ----
-struct TriLight { V3 vertex, edge1, edge2; uint32_t material_id; bool bidirectional; };
+struct TriLight { V3 vertex, edge1, edge2; uint32_t material_id, scene_tri; bool bidirectional; };
 
 LUM_DEV TriLight load_tri_light(const DeviceScene& sc, uint32_t inst, uint32_t tri) {  // light_triangle.cuh:37-72
   const uint32_t mesh = sc.instance_mesh_ids[inst];
@@ -177,7 +177,8 @@ LUM_DEV TriLight load_tri_light(const DeviceScene& sc, uint32_t inst, uint32_t t
   t.vertex = xf_point(tf, p0);
   t.edge1 = xf_rel(tf, v3(b.x, b.y, b.z) - p0);
   t.edge2 = xf_rel(tf, v3(c.x, c.y, c.z) - p0);
-  t.material_id = sc.tri_tex[sc.mesh_tri_offset[mesh] + tri].w & 0xFFFFu;
+  t.scene_tri = sc.mesh_tri_offset[mesh] + tri;
+  t.material_id = sc.tri_tex[t.scene_tri].w & 0xFFFFu;
   t.bidirectional = (sc.materials[2 * t.material_id].x & kDMatBidirectionalEmission) != 0;
   return t;
 }
@@ -206,10 +207,21 @@ LUM_DEV bool sample_tri_solid_angle(V3 origin, const TriLight& t, F2 rnd, V3& ra
   ray = normalize(b * (sv - tt * s2) + ct * tt);
   return !(not_finite(ray.x) || not_finite(ray.y) || not_finite(ray.z));
 }
-LUM_DEV Col tri_light_color(const DeviceScene& sc, const TriLight& t) {  // light_triangle.cuh:245-280, untextured
+// light_get_color, light_triangle.cuh:245-280. `coords`: barycentrics of the point on the light (light_triangle_sample_finalize_dist_and_uvs,
+// :74-92); the texture coordinates are only formed for materials that have an emission or albedo texture.
+LUM_DEV Col tri_light_color(const DeviceScene& sc, const TriLight& t, F2 coords) {
   const Material m = load_material(sc, t.material_id);
   Col c = m.emission;
-  if (any_positive(c)) c = c * m.alpha;
+  float alpha = m.alpha;
+  if (m.luminance_tex != kTextureNone || m.albedo_tex != kTextureNone) {
+    const F2 tex = triangle_uv(sc.tri_tex[t.scene_tri], coords);
+    if (m.luminance_tex != kTextureNone) {
+      const float4 e = texture_load(sc, m.luminance_tex, tex, true, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+      c = col(e.x, e.y, e.z) * m.emission_scale;
+    }
+    if (any_positive(c) && m.albedo_tex != kTextureNone) alpha = texture_load(sc, m.albedo_tex, tex, true, make_float4(0.0f, 0.0f, 0.0f, 1.0f)).w;
+  }
+  if (any_positive(c)) c = c * alpha;
   return c;
 }
 
@@ -319,7 +331,7 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     const float dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, g.position, ray, uv);
     if (dist == kFltMax) continue;
     LUM_STAT(10, 11);
-    Col lc = tri_light_color(sc, tl);
+    Col lc = tri_light_color(sc, tl, uv);
     bool is_refraction;
 #ifndef LUM_ABLATE_LIGHT_DEFINED_BELOW
 #define LUM_ABLATE_LIGHT_DEFINED_BELOW

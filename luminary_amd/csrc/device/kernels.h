@@ -167,7 +167,11 @@ LUM_DEV GeoContext build_context(const DeviceScene& sc, V3 hit_origin, V3 ray_wo
   }
   const bool emissive_side = !inside || (mat.flags & kDMatBidirectionalEmission);
   const bool emits = (mat.flags & kDMatEmission) && emissive_side && ((state & kStAllowEmission) != 0);
-  const Col emission = emits ? mat.emission : col(0.0f, 0.0f, 0.0f);
+  Col emission = emits ? mat.emission : col(0.0f, 0.0f, 0.0f);
+  if (emits && mat.luminance_tex != kTextureNone) {  // geometry_utils.cuh:130-137
+    const float4 lf = texture_load(sc, mat.luminance_tex, tex_coords, true, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    emission = col(lf.x, lf.y, lf.z) * (alpha * mat.emission_scale);
+  }
   float roughness = mat.roughness;
   if (mat.roughness_tex != kTextureNone) roughness = texture_load(sc, mat.roughness_tex, tex_coords, true, make_float4(0.5f, 0.0f, 0.0f, 0.0f)).x;  // :140-150
   if (mat.flags & kDMatRoughnessAsSmoothness) roughness = 1.0f - roughness;
@@ -491,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
         F2 uv;
         dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, hit_origin, ray, uv);
         if (dist != kFltMax) {
-          lc = tri_light_color(sc, tl);
+          lc = tri_light_color(sc, tl, uv);
           const float mis = mis_for_bsdf_ray(hit_origin, tl, lc, dist, rp.w, ws.w);
           lc = lc * (mis * num_hits);
           lc = lc * col(ws.x, ws.y, ws.z);

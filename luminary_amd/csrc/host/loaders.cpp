@@ -207,11 +207,11 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
     mat.normal_map_is_compressed = true;
     mat.bidirectional_emission = args.force_bidirectional_emission;
     mat.metallic = w.ks[0] > 0.5f;
-    // wavefront.c:787-818: one texture per distinct file; albedo, roughness and normal maps are evaluated by the renderer
+    // wavefront.c:787-818: one texture per distinct file. A metallic map is stored but, as in the reference (geometry_utils.cuh:152-160), not
+    // evaluated: its presence alone makes the material non-metallic.
     uint16_t* slot[5] = {&mat.albedo_tex, &mat.luminance_tex, &mat.roughness_tex, &mat.metallic_tex, &mat.normal_tex};
     for (int k = 0; k < 5; k++) {
       if (w.map[k].empty()) continue;
-      if (k == 1 || k == 3) { warnings->push_back("map of material '" + w.name + "' (" + w.map[k] + ") is not evaluated: emission and metallic textures are outside the current scope"); continue; }
       if (!textures_out) { warnings->push_back("texture " + w.map[k] + " ignored: no texture store"); continue; }
       uint32_t id = 0xFFFF;
       for (size_t t = 0; t < texture_files.size(); t++) if (texture_files[t] == w.map[k]) id = (uint32_t) t;
@@ -226,6 +226,7 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
       }
       *slot[k] = (uint16_t) (texture_offset + id);
     }
+    if (mat.luminance_tex != 0xFFFF) mat.emission_active = true;  // wavefront.c:809
     materials_out->push_back(mat);
   }
   // mesh (wavefront.c:828-996)

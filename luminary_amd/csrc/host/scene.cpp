@@ -9,6 +9,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstring>
+#include <map>
 
 namespace lum {
 
@@ -553,6 +554,121 @@ uint16_t pack_float_mode(float v, int mode) {  // device_packing.c:46-70; mode 0
 }
 float unpack_float16(uint16_t v) { return bits_float(((uint32_t) v) << 16); }
 
+// ---- emission textures: the per-triangle intensity the light tree weighs a textured emitter with (device_light.c:1902-2018 runs
+// light_compute_intensity, cuda/light.cuh:191-270, on the GPU; here it runs where the tree is built). A texture fetch must return the
+// bits the kernels' fetch returns, so log2/exp2/pow are the sequences of csrc/device/dev_math.h and the filter is the one of
+// texture_load in csrc/device/dev_bsdf.h (this file is compiled with -ffp-contract=off like the kernels). ----
+float host_log2_det(float x) {
+  const uint32_t bits = float_bits(x);
+  int e = (int) ((bits >> 23) & 0xFFu) - 127;
+  float m = bits_float((bits & 0x007FFFFFu) | 0x3F800000u);
+  if (m > 1.41421356f) { m = m * 0.5f; e = e + 1; }
+  const float q = (m - 1.0f) / (m + 1.0f);
+  const float z = q * q;
+  float p = 0.0909090909f;
+  p = p * z + 0.111111111f;
+  p = p * z + 0.142857143f;
+  p = p * z + 0.2f;
+  p = p * z + 0.333333333f;
+  p = p * z;
+  const float ln_m = 2.0f * q + (2.0f * q) * p;
+  return (float) e + ln_m * 1.44269504f;
+}
+float host_exp2_det(float x) {
+  x = std::fmin(std::fmax(x, -126.0f), 127.0f);
+  const float n = std::rint(x);
+  const float f = x - n;
+  float p = 1.52527338e-5f;
+  p = p * f + 1.54035304e-4f;
+  p = p * f + 1.33335581e-3f;
+  p = p * f + 9.61812911e-3f;
+  p = p * f + 5.55041087e-2f;
+  p = p * f + 2.40226507e-1f;
+  p = p * f + 6.93147181e-1f;
+  p = p * f + 1.0f;
+  return std::ldexp(p, (int) n);
+}
+float host_pow_det(float x, float y) { return (x > 0.0f) ? host_exp2_det(y * host_log2_det(x)) : 0.0f; }
+
+// rgb of a fetch with the default arguments (flip_v, gamma; cuda/texture_utils.cuh:12-45)
+void host_texture_rgb(const HostTexture& t, float u_in, float v_in, float rgb[3]) {
+  const int w = (int) t.width, h = (int) t.height;
+  const float u = u_in, v = 1.0f - v_in;
+  const float xb = (u - std::floor(u)) * (float) w - 0.5f, yb = (v - std::floor(v)) * (float) h - 0.5f;
+  const float xf = std::floor(xb), yf = std::floor(yb);
+  const float ax = xb - xf, ay = yb - yf;
+  int x0 = (int) xf, y0 = (int) yf, x1 = x0 + 1, y1 = y0 + 1;
+  if (x0 < 0) x0 += w;
+  if (y0 < 0) y0 += h;
+  if (x1 >= w) x1 -= w;
+  if (y1 >= h) y1 -= h;
+  const uint32_t t00 = t.texels[x0 + (size_t) y0 * w], t10 = t.texels[x1 + (size_t) y0 * w], t01 = t.texels[x0 + (size_t) y1 * w], t11 = t.texels[x1 + (size_t) y1 * w];
+  for (int c = 0; c < 3; c++) {
+    const float c00 = ((t00 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), c10 = ((t10 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+    const float c01 = ((t01 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f), c11 = ((t11 >> (8 * c)) & 0xFFu) * (1.0f / 255.0f);
+    const float top = c00 + ax * (c10 - c00), bot = c01 + ax * (c11 - c01);
+    float r = top + ay * (bot - top);
+    if (t.gamma != 1.0f) r = host_pow_det(r, t.gamma);
+    rgb[c] = r;
+  }
+}
+
+// light_microtriangle_id_to_bary, cuda/light_microtriangle.cuh:8-61: 64 micro-triangles in 8 rows of 15, 13, ... 1
+void microtriangle_bary(uint32_t id, float b0[2], float b1[2], float b2[2]) {
+  uint32_t row;
+  // the reference's chain of comparisons, kept literally (its row bounds are inclusive: ids 15, 28, ... belong to the earlier row)
+  uint32_t col;
+  if (id <= 15) { row = 0; col = id >> 1; }
+  else if (id <= 15 + 13) { row = 1; col = (id - 15) >> 1; }
+  else if (id <= 15 + 13 + 11) { row = 2; col = (id - 15 - 13) >> 1; }
+  else if (id <= 15 + 13 + 11 + 9) { row = 3; col = (id - 15 - 13 - 11) >> 1; }
+  else if (id <= 15 + 13 + 11 + 9 + 7) { row = 4; col = (id - 15 - 13 - 11 - 9) >> 1; }
+  else if (id <= 15 + 13 + 11 + 9 + 7 + 5) { row = 5; col = (id - 15 - 13 - 11 - 9 - 7) >> 1; }
+  else if (id <= 15 + 13 + 11 + 9 + 7 + 5 + 3) { row = 6; col = (id - 15 - 13 - 11 - 9 - 7 - 5) >> 1; }
+  else { row = 7; col = 0; }
+  const bool is_top = (id & 1u) == (row & 1u);
+  b0[0] = (float) row; b0[1] = (float) (col + 1);
+  b1[0] = (float) (row + 1); b1[1] = (float) col;
+  b2[0] = is_top ? (float) row : (float) (row + 1); b2[1] = is_top ? (float) col : (float) (col + 1);
+  for (int k = 0; k < 2; k++) { b0[k] *= 1.0f / 8.0f; b1[k] *= 1.0f / 8.0f; b2[k] *= 1.0f / 8.0f; }
+}
+
+// lights_get_max_emission, cuda/light.cuh:191-237: the brightest texel found on a grid over the micro-triangle, one step per texel
+float microtriangle_max_emission(const HostTexture& tex, const float vertex[2], const float edge1[2], const float edge2[2], uint32_t id) {
+  float b0[2], b1[2], b2[2];
+  microtriangle_bary(id, b0, b1, b2);
+  const float uv0[2] = {vertex[0] + b0[0] * edge1[0] + b0[1] * edge2[0], vertex[1] + b0[0] * edge1[1] + b0[1] * edge2[1]};
+  const float uv1[2] = {vertex[0] + b1[0] * edge1[0] + b1[1] * edge2[0], vertex[1] + b1[0] * edge1[1] + b1[1] * edge2[1]};
+  const float uv2[2] = {vertex[0] + b2[0] * edge1[0] + b2[1] * edge2[0], vertex[1] + b2[0] * edge1[1] + b2[1] * edge2[1]};
+  const float me1[2] = {uv1[0] - uv0[0], uv1[1] - uv0[1]}, me2[2] = {uv2[0] - uv0[0], uv2[1] - uv0[1]};
+  const float steps_u = std::fmax(std::fabs(me1[0]), std::fabs(me2[0])) * (float) tex.width;
+  const float steps_v = std::fmax(std::fabs(me1[1]), std::fabs(me2[1])) * (float) tex.height;
+  const float steps = std::ceil(std::fmax(steps_u, steps_v));
+  const float step_size = 1.0f / steps;
+  float best[3] = {0.0f, 0.0f, 0.0f};
+  for (float a = 0.0f; a < 1.0f; a += step_size) {
+    for (float b = 0.0f; a + b < 1.0f; b += step_size) {
+      float rgb[3];
+      host_texture_rgb(tex, uv0[0] + a * me1[0] + b * me2[0], uv0[1] + a * me1[1] + b * me2[1], rgb);
+      for (int c = 0; c < 3; c++) best[c] = std::fmax(best[c], rgb[c]);
+    }
+  }
+  return std::fmax(best[0], std::fmax(best[1], best[2]));  // color_importance, cuda/math.cuh:1066-1068
+}
+
+// light_compute_intensity, cuda/light.cuh:239-270: the maximum over the 64 micro-triangles, from the bf16 texture coordinates the device holds
+float triangle_emission_intensity(const HostTexture& tex, const float* uvs /* 6 */) {
+  float c[3][2];
+  for (int k = 0; k < 3; k++) {
+    const uint32_t packed = pack_uv(uvs[2 * k], uvs[2 * k + 1]);
+    c[k][0] = bits_float(packed & 0xFFFF0000u); c[k][1] = bits_float(packed << 16);
+  }
+  const float e1[2] = {c[1][0] - c[0][0], c[1][1] - c[0][1]}, e2[2] = {c[2][0] - c[0][0], c[2][1] - c[0][1]};
+  float best = 0.0f;
+  for (uint32_t id = 0; id < 64; id++) best = std::fmax(best, microtriangle_max_emission(tex, c[0], e1, e2, id));
+  return best;
+}
+
 struct Quantiser { F3 min_mean; int8_t ex, ey, ez, es; float cx, cy, cz, cv; uint16_t bx, by, bz; };
 
 int8_t exponent_for(float range) { return (int8_t) std::ceil(std::log2(range * 1.0f / 255.0f)); }
@@ -600,6 +716,15 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
   out->root.clear(); out->nodes.clear(); out->tri_handles.clear(); out->bvh_tris.clear();
   // ---- fragments (device_light.c:2020-2113): world-space emissive triangles, grouped per instance by material slot ----
   std::vector<Fragment> frags;
+  std::map<std::pair<uint64_t, uint32_t>, float> intensity_cache;  // (mesh, triangle), texture -> integrated maximum; instances share it
+  auto textured_intensity = [&](uint32_t mesh_id, uint32_t tri, uint32_t tex) {
+    const auto key = std::make_pair(((uint64_t) mesh_id << 32) | tri, tex);
+    auto it = intensity_cache.find(key);
+    if (it != intensity_cache.end()) return it->second;
+    const float v = triangle_emission_intensity(scene.textures[tex], scene.meshes[mesh_id].uvs.data() + 6 * (size_t) tri);
+    intensity_cache.emplace(key, v);
+    return v;
+  };
   for (uint32_t inst_id = 0; inst_id < scene.instances.size(); inst_id++) {
     const HostInstance& inst = scene.instances[inst_id];
     if (!inst.active || inst.mesh_id >= scene.meshes.size()) continue;
@@ -618,8 +743,13 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
       float intensity = 0.0f;  // device_light.c:1828-1846
       if (mat.emission_active) intensity = (mat.luminance_tex != 0xFFFF) ? mat.emission_scale : std::fmax(mat.emission.r, std::fmax(mat.emission.g, mat.emission.b));
       if (!(intensity > 0.0f)) continue;
+      const bool textured = mat.emission_active && mat.luminance_tex != 0xFFFF;
       for (uint32_t t = 0; t < mesh.triangle_count(); t++) {
         if (mesh.material_ids[t] != mat_id) continue;
+        // device_light.c:1686, :2014: 1 for constant emission, the integrated texture maximum otherwise (0 for a missing texture: light.cuh:195-196)
+        float average_intensity = 1.0f;
+        if (textured) average_intensity = mat.luminance_tex < scene.textures.size() ? textured_intensity(inst.mesh_id, t, mat.luminance_tex) : 0.0f;
+        if (average_intensity == 0.0f) continue;
         const float* p = mesh.positions.data() + 9 * (size_t) t;
         const F3 a = rotate_q(f3(p[0], p[1], p[2]), q) * scale + offset, b = rotate_q(f3(p[3], p[4], p[5]), q) * scale + offset,
                  c = rotate_q(f3(p[6], p[7], p[8]), q) * scale + offset;
@@ -630,7 +760,7 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
         f.low = fmin3(a, fmin3(b, c)); f.high = fmax3(a, fmax3(b, c));
         f.middle = (a + (b + c)) * (1.0f / 3.0f);
         f.v0 = a; f.v1 = b; f.v2 = c;
-        f.power = intensity * area * 1.0f;
+        f.power = intensity * area * average_intensity;
         f.instance_id = inst_id; f.tri_id = t;
         frags.push_back(f);
       }

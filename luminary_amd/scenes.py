@@ -561,6 +561,61 @@ def textured_scene(width=96, height=64, bounces=6, seed=11):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+# Parity scene for emission textures (map_Ke): textured emitters in the surface context, in light sampling and in the light tree
+# ---------------------------------------------------------------------------------------------------------------------
+
+def emissive_texture_scene(width=72, height=48, bounces=4):
+    """Floor and back wall lit only by textured emitters (black sky):
+    * a screen whose texture is black over one of its two triangles (that triangle is no light: its integrated intensity is 0),
+    * a coloured screen whose material also has an albedo texture with alpha 0.5 (the light's colour is scaled by the texture's alpha)
+      and a non-zero constant emission colour (which enters the stored emission scale, device_structs.c:289-303),
+    * a screen whose emission texture handle dangles (no light at all), and a small constant emitter."""
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.0, 0.0, 0.0))
+    n = 16
+    yy, xx = np.mgrid[0:n, 0:n]
+    u, v = (xx + 0.5) / n, 1.0 - (yy + 0.5) / n       # texture_load flips v: image row 0 is v = 1
+    half = np.zeros((n, n, 4), dtype=np.uint8)
+    half[..., 3] = 255
+    lit = ((u - v) > 0.3) & (u < 0.9) & (v > 0.1)       # well inside the triangle (0,0)-(1,0)-(1,1) of _quad_uv; a black border, because
+                                                        # wrap addressing would carry the lit corner over to the other triangle's corner
+    half[lit] = (255, 230, 180, 255)
+    t_half = host.add_texture(half)
+    bars = np.zeros((8, 8, 4), dtype=np.uint8)
+    bars[..., 3] = 255
+    bars[:, 0::2, :3] = (250, 60, 40)
+    bars[:, 1::2, :3] = (40, 90, 250)
+    t_bars = host.add_texture(bars, gamma=2.2)
+    veil = np.full((4, 4, 4), 255, dtype=np.uint8)
+    veil[..., 3] = 128
+    t_veil = host.add_texture(veil)
+
+    def emitter(tex, scale, constant=(0.0, 0.0, 0.0), albedo_tex=0xFFFF):
+        mt = _material((0.8, 0.8, 0.8), 0.7, emission=constant)
+        mt.luminance_tex, mt.emission_scale, mt.albedo_tex = tex, scale, albedo_tex
+        return host.add_material(mt)
+
+    m_grey = host.add_material(_material((0.7, 0.7, 0.7), 0.6))
+    m_half = emitter(t_half, 30.0)
+    m_bars = emitter(t_bars, 12.0, constant=(0.5, 0.25, 0.0), albedo_tex=t_veil)
+    m_dangling = emitter(99, 50.0)
+    m_const = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(4.0, 4.0, 4.0)))
+
+    def add(quads, material):
+        pos, uv = zip(*[_quad_uv(*q) for q in quads])
+        pos, uv = np.concatenate(pos), np.concatenate(uv)
+        return host.add_mesh(pos, np.full(len(pos), material, dtype=np.uint16), uvs=uv)
+
+    host.new_instance(add([((-8, 0, -8), (8, 0, -8), (8, 0, 8), (-8, 0, 8)), ((-8, 0, -4), (8, 0, -4), (8, 6, -4), (-8, 6, -4))], m_grey))
+    host.new_instance(add([((-5, 0.5, -3.5), (-1, 0.5, -3.5), (-1, 3.5, -3.5), (-5, 3.5, -3.5))], m_half))
+    host.new_instance(add([((1, 0.5, -3.5), (5, 0.5, -3.5), (5, 3.5, -3.5), (1, 3.5, -3.5))], m_bars))
+    host.new_instance(add([((-1, 4.0, -3.5), (1, 4.0, -3.5), (1, 5.0, -3.5), (-1, 5.0, -3.5))], m_dangling))
+    host.new_instance(add([((-0.5, 0.05, 1.0), (0.5, 0.05, 1.0), (0.5, 0.05, 2.0), (-0.5, 0.05, 2.0))], m_const))
+    set_camera(host, (0.0, 2.2, 7.0), (-0.05, 0.0, 0.0), fov=0.9)
+    return host
+
+
+# ---------------------------------------------------------------------------------------------------------------------
 # Edge cases for the parity tests
 # ---------------------------------------------------------------------------------------------------------------------
 

@@ -302,11 +302,18 @@ static inline bool light_triangle_finalize(TriLight* t, const uint32_t uv_packed
   ok &= light_triangle_finalize_dist(t, uv_packed, origin, *ray, dist);
   return ok;
 }
-/* light_triangle.cuh:245-280 (untextured branch) */
+/* light_triangle.cuh:245-280 */
 static inline RGBF light_get_color(const OracleScene* s, const TriLight* t) {
   const OMaterial m = scene_material(s, t->material_id);
   RGBF c = m.emission;
-  if (c_any(c)) c = c_scale(c, m.albedo.a);
+  if (m.luminance_tex != TEXTURE_NONE) {
+    const float4_t e = texture_load(s, m.luminance_tex, t->tex, true, f4(0.0f, 0.0f, 0.0f, 0.0f));
+    c = c_scale(c3(e.x, e.y, e.z), m.emission_scale);
+  }
+  if (c_any(c)) {
+    const float alpha = (m.albedo_tex != TEXTURE_NONE) ? texture_load(s, m.albedo_tex, t->tex, true, f4(0.0f, 0.0f, 0.0f, 1.0f)).w : m.albedo.a;
+    c = c_scale(c, alpha);
+  }
   return c;
 }
 

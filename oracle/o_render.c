@@ -114,6 +114,10 @@ static GeoCtx geometry_get_context(const OracleScene* s, vec3 hit_origin, vec3 t
   const bool include_emission = has_emission && ((state & ST_ALLOW_EMISSION) != 0);
   RGBF emission = c3(0.0f, 0.0f, 0.0f);
   if (include_emission) emission = mat.emission;
+  if (include_emission && mat.luminance_tex != TEXTURE_NONE) { /* geometry_utils.cuh:130-137 */
+    const float4_t lf = texture_load(s, mat.luminance_tex, tex_coords, true, f4(0.0f, 0.0f, 0.0f, 0.0f));
+    emission = c_scale(c3(lf.x, lf.y, lf.z), albedo.a * mat.emission_scale);
+  }
   float roughness = mat.roughness;
   if (mat.roughness_tex != TEXTURE_NONE) roughness = texture_load(s, mat.roughness_tex, tex_coords, true, f4(0.5f, 0.0f, 0.0f, 0.0f)).x; /* :140-150 */
   if (mat.flags & DMAT_ROUGHNESS_AS_SMOOTHNESS) roughness = 1.0f - roughness;

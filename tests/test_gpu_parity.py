@@ -216,6 +216,23 @@ def test_full_size_frame_properties(core):
     _assert_same(acc, full, "3-rank tile partition at full size")
 
 
+def test_render_parity_emission_textures(core):
+    """Emission textures: textured emitters seen directly, sampled as lights (colour from the texel at the sampled point, alpha from the
+    albedo texture), weighed in the light tree by their integrated texture maximum."""
+    host = scenes.emissive_texture_scene(72, 48, 4)
+    view = oracle_lib.with_luts(host.device_scene())
+    assert view.num_lights == 5 and view.num_textures == 3
+    core.upload(view)
+    core.set_pixels(None)
+    core.reset_counters()
+    core.render(0, 6, samples_per_pass=3)
+    fm, sm = core.accumulators()
+    ofm, osm, ocnt = oracle_lib.render(view, 0, 6)
+    _assert_same(fm, ofm, "first moment (emission textures)")
+    _assert_same(sm, osm, "second moment (emission textures)")
+    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+
+
 def test_render_parity_textured_scene(core):
     """Textures: albedo with gamma, alpha cut-outs in closest-hit and visibility rays, texture-driven coloured transparency,
     roughness and normal maps, a dangling texture handle: moments and ray counters identical to the oracle."""

@@ -159,7 +159,8 @@ def test_obj_loader_reads_texture_maps(tmp_path):
     grey16 = rng.randint(0, 65536, size=(3, 4)).astype(">u2")
     png(str(tmp_path / "bump.png"), 4, 3, 16, 0, [b"\x00" + grey16[y].tobytes() for y in range(3)])
     (tmp_path / "m.mtl").write_text("newmtl a\nKd 0.5 0.5 0.5\nmap_Kd -s 1 1 1 albedo.png\nmap_Ns rough.png\nmap_Bump -bm 0.3 bump.png\nmap_Ke missing.png\n"
-                                    "newmtl b\nKd 0.1 0.2 0.3\nmap_Kd albedo.png\n")
+                                    "newmtl b\nKd 0.1 0.2 0.3\nmap_Kd albedo.png\n"
+                                    "newmtl c\nKd 0 0 0\nmap_Ke albedo.png\nmap_refl rough.png\n")
     (tmp_path / "m.obj").write_text("mtllib m.mtl\no quad\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nusemtl a\nf 1/1 2/2 3/3\nusemtl b\nf 1/1 3/3 4/4\n")
     host = luminary_amd.Host()
     host.load_obj_file(str(tmp_path / "m.obj"))
@@ -167,6 +168,8 @@ def test_obj_loader_reads_texture_maps(tmp_path):
     ma, mb = host.get_material(1), host.get_material(2)  # material 0 is the loader's default material
     assert (ma.albedo_tex, ma.roughness_tex, ma.normal_tex, ma.luminance_tex, ma.metallic_tex) == (0, 1, 2, 0xFFFF, 0xFFFF)
     assert mb.albedo_tex == 0 and mb.roughness_tex == 0xFFFF  # the same file is one texture
+    mc = host.get_material(3)  # an emission map makes the material an emitter (wavefront.c:809); a metallic map is stored (and never evaluated)
+    assert (mc.luminance_tex, mc.metallic_tex, bool(mc.emission_active)) == (0, 1, True) and not bool(ma.emission_active)
     v = host.device_scene()
     assert v.num_textures == 3 + 2 and (v.sky_moon_albedo_tex, v.sky_moon_normal_tex) == (3, 4)  # the default sky mode brings the moon's two textures along
     import ctypes as C

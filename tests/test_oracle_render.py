@@ -99,3 +99,22 @@ def test_textures_change_the_image_and_cut_outs_let_rays_through():
     untextured.num_textures = 0
     c = oracle_lib.render(untextured, 0, 2)
     assert not np.array_equal(a[0], c[0])
+
+
+def test_emission_textures_light_the_scene_and_shape_the_light_tree():
+    """Emission textures (map_Ke): a triangle whose part of the texture is black is no light, a dangling texture handle emits nothing,
+    the screens are visible (surface context) and light the floor (light sampling)."""
+    host = scenes.emissive_texture_scene(48, 32, 3)
+    v = oracle_lib.with_luts(host.device_scene())
+    # lit half of the first screen (1 triangle), both triangles of the second screen, the constant emitter (2): the dark half and the
+    # dangling screen are left out of the light tree (device_light.c:2082)
+    assert v.num_lights == 5
+    a = oracle_lib.render(v, 0, 4, use_bvh=True)
+    b = oracle_lib.render(v, 0, 4, use_bvh=False)
+    assert np.array_equal(a[0], b[0]) and np.isfinite(a[0]).all()
+    img = a[0].reshape(3, 32, 48)
+    assert img[:, 24:, :].mean() > 0.0, "the floor receives light although the sky is black"
+    dark = oracle_lib.with_luts(host.device_scene())
+    dark.num_textures = 0   # without the textures the screens are black: only the small constant emitter is left
+    c = oracle_lib.render(dark, 0, 4)
+    assert c[0].sum() < 0.5 * a[0].sum()
