@@ -236,6 +236,12 @@ class Core:
                    C.c_float(exposure), tp, out.ctypes.data_as(C.c_void_p))
         return out
 
+    def post_bloom(self, image, full_width, full_height, blend, stage=0):
+        """Bloom of a planar result image [3, H >> stage, W >> stage] (host array); returns the processed copy."""
+        img = np.ascontiguousarray(image, dtype=np.float32).copy()
+        self._call("lumc_post_bloom_host", img.ctypes.data_as(C.c_void_p), C.c_uint32(full_width), C.c_uint32(full_height), C.c_uint32(stage), C.c_float(blend))
+        return img
+
     def render_undersampled(self, stage, iteration, stream=0):
         """Adds sample 0 of the pixels of one undersampling iteration to the full-frame accumulators (lumc_render_undersampled)."""
         self._call("lumc_render_undersampled", C.c_uint32(stage), C.c_uint32(iteration), C.c_void_p(stream))

@@ -3,7 +3,7 @@
 // cuda/tonemap.cuh (exposure, colour correction, film grain, Purkinje shift, tone curves), cuda/kernels.cuh:558-644
 // (convert_RGBF_to_ARGB8: optional bilinear resize, filters, dither, sRGB), cuda/math.cuh:1040-1170, :1483-1543, cuda/purkinje.cuh,
 // cuda/post_common.cuh:6-50, cuda/random.cuh:144-154, :197-212, :370-379.
-// Scope of this implementation: any supersampling and undersampling stage; no bloom.
+// Scope of this implementation: any supersampling and undersampling stage, bloom.
 // Numerics: the reference uses fast-math log2f/powf/rsqrtf whose bits are unspecified; here log2, exp2 and pow are the fixed
 // sequences below (relative error < 3e-7), mirrored operation by operation in oracle/o_output.h, so the bytes of an image are a
 // pure function of the moments on any device.
@@ -248,6 +248,74 @@ LUM_DEV float sample_plane(const float* __restrict__ plane, float x, float y, ui
   r += p10 * (fx * ify);
   r += p11 * (fx * fy);
   return r;
+}
+
+// ---- bloom (device/device_post.c:10-170, cuda/post_common.cuh:6-149): a mip chain of the result image, 13-tap downsampling, 9-tap tent
+// upsampling, blended back into the image. Planes are processed one at a time. ----
+// post_sample_buffer_border: zero outside [0, 1); no clamp inside. A NaN coordinate (a 1-pixel-wide level: 1 / (1 - 1) * 0) passes both
+// comparisons and fmaxf(0, NaN) = 0 sends it to texel 0, as on the reference's hardware.
+LUM_DEV float sample_plane_border(const float* __restrict__ plane, float x, float y, uint32_t width, uint32_t height, float weight) {
+  if (x > bitsf(0x3F7FFFFFu) || x < 0.0f) return 0.0f;
+  if (y > bitsf(0x3F7FFFFFu) || y < 0.0f) return 0.0f;
+  const float sx = fmaxf(0.0f, x * (width - 1)), sy = fmaxf(0.0f, y * (height - 1));
+  const uint32_t x0 = (uint32_t) sx, y0 = (uint32_t) sy;
+  const uint32_t x1 = min((uint32_t) (sx + 1.0f), width - 1), y1 = min((uint32_t) (sy + 1.0f), height - 1);
+  const uint32_t i00 = (uint32_t) ((float) x0 + (float) (y0 * width)), i01 = (uint32_t) ((float) x0 + (float) (y1 * width));
+  const uint32_t i10 = (uint32_t) ((float) x1 + (float) (y0 * width)), i11 = (uint32_t) ((float) x1 + (float) (y1 * width));
+  const float p00 = plane[i00], p01 = plane[i01], p10 = plane[i10], p11 = plane[i11];
+  const float fx = sx - x0, ifx = 1.0f - fx, fy = sy - y0, ify = 1.0f - fy;
+  float r = p00 * (ifx * ify);
+  r += p01 * (ifx * fy);
+  r += p10 * (fx * ify);
+  r += p11 * (fx * fy);
+  return r * weight;
+}
+__global__ __launch_bounds__(256) void k_post_downsample(const float* __restrict__ src, uint32_t sw, uint32_t sh, float* __restrict__ dst, uint32_t tw, uint32_t th) {
+  const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
+  const uint32_t n = tw * th;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t y = i / tw, x = i - y * tw;
+    const float sx = scale_x * x, sy = scale_y * y;
+    float p = 0.0f;
+    p += sample_plane_border(src, sx - 0.5f * step_x, sy - 0.5f * step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx + 0.5f * step_x, sy - 0.5f * step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx - 0.5f * step_x, sy + 0.5f * step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx + 0.5f * step_x, sy + 0.5f * step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx, sy, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx, sy - step_y, sw, sh, 0.5f);
+    p += sample_plane_border(src, sx - step_x, sy, sw, sh, 0.5f);
+    p += sample_plane_border(src, sx + step_x, sy, sw, sh, 0.5f);
+    p += sample_plane_border(src, sx, sy + step_y, sw, sh, 0.5f);
+    p += sample_plane_border(src, sx - step_x, sy - step_y, sw, sh, 0.25f);
+    p += sample_plane_border(src, sx + step_x, sy - step_y, sw, sh, 0.25f);
+    p += sample_plane_border(src, sx - step_x, sy + step_y, sw, sh, 0.25f);
+    p += sample_plane_border(src, sx + step_x, sy + step_y, sw, sh, 0.25f);
+    p *= 1.0f / 8.0f;
+    dst[i] = fmaxf(p, 0.0f);  // threshold 0 (device_post.c:82)
+  }
+}
+// dst may be the base image (every thread reads only its own base pixel)
+__global__ __launch_bounds__(256) void k_post_upsample(const float* __restrict__ src, uint32_t sw, uint32_t sh, float* dst, uint32_t tw, uint32_t th, float sa, float sb) {
+  const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
+  const uint32_t n = tw * th;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+    const uint32_t y = i / tw, x = i - y * tw;
+    const float sx = scale_x * x, sy = scale_y * y;
+    float p = sample_plane_border(src, sx - step_x, sy - step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx, sy - step_y, sw, sh, 2.0f);
+    p += sample_plane_border(src, sx + step_x, sy - step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx - step_x, sy, sw, sh, 2.0f);
+    p += sample_plane_border(src, sx, sy, sw, sh, 4.0f);
+    p += sample_plane_border(src, sx + step_x, sy, sw, sh, 2.0f);
+    p += sample_plane_border(src, sx - step_x, sy + step_y, sw, sh, 1.0f);
+    p += sample_plane_border(src, sx, sy + step_y, sw, sh, 2.0f);
+    p += sample_plane_border(src, sx + step_x, sy + step_y, sw, sh, 1.0f);
+    p *= 1.0f / 20.0f;
+    p *= sa;
+    float base = dst[i];
+    base *= sb;
+    dst[i] = p + base;
+  }
 }
 
 LUM_DEV float dither_mask(const uint16_t* __restrict__ bluenoise_1d, uint32_t x, uint32_t y) { return unit_float16(bluenoise_1d[(x & 255u) + (y & 255u) * 256u]); }

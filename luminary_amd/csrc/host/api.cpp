@@ -474,18 +474,30 @@ std::vector<PreviewState> preview_schedule(LuminaryHost* h) {
 
 // accumulation_generate_result (accumulation.cuh:86-200) into the core's result image; the output chain then reads that image with a
 // sample count of one. Returns the parameters to hand to lumc_generate_output*.
+// device_post_apply (device/device_post.c:204-226), run between the result image and the display chain: bloom, for beauty images of
+// the whole frame in the default shading mode
+int post_process(LuminaryHost* h, PreviewState preview) {
+  const LuminaryRendererSettings& st = h->scene.settings;
+  if (st.shading_mode != LUMINARY_SHADING_MODE_DEFAULT || st.adaptive_sampling_output_mode != LUMINARY_ADAPTIVE_SAMPLING_OUTPUT_MODE_BEAUTY) return 0;
+  if (!(st.region_width >= 1.0f && st.region_height >= 1.0f)) return 0;
+  const float blend = h->scene.camera.bloom_blend;
+  if (!(blend > 0.0f)) return 0;  // device_post_update, device_post.c:186-202
+  const LumDeviceSceneView& v = h->device_scene.view;
+  return lumc_post_bloom(h->core, nullptr, v.width, v.height, preview.stage, blend, nullptr);
+}
+
 int result_image(LuminaryHost* h, LumOutputParams* p, PreviewState preview) {
   if (preview.stage) {  // accumulation_generate_result_undersampling (device_renderer.c:410-420): the coarse image of the pixels that exist so far
     if (lumc_generate_result_undersampled(h->core, preview.stage, preview.iteration, nullptr, nullptr)) return 1;
     p->inv_sample_count = 1.0f;
     p->undersampling_stage = preview.stage;
-    return 0;
+    return post_process(h, preview);
   }
   const uint32_t mode = (uint32_t) h->scene.settings.adaptive_sampling_output_mode;
   const uint32_t lem = h->scene.camera.use_local_error_minimization ? 1u : 0u;
   if (lumc_generate_result(h->core, mode, lem, h->adaptive_active ? 0u : h->accumulated_samples, p->exposure, p, nullptr, nullptr)) return 1;
   p->inv_sample_count = 1.0f;
-  return 0;
+  return post_process(h, preview);
 }
 
 // device_output_generate_output, device_output.c:203-270: the recurring output if enabled, then every request that is due now

@@ -75,6 +75,8 @@ struct LumContext {
   } adaptive;
   float4* d_sky_hdri = nullptr;     // baked sky (lumc_sky_hdri_build): dim x dim equirectangular, rgb + 0
   uint32_t sky_hdri_dim = 0;
+  std::vector<float*> bloom_mips;  // mip chain of lumc_post_bloom, level i of (width >> (i + 1)) x (height >> (i + 1))
+  uint32_t bloom_width = 0, bloom_height = 0;
   uint32_t* d_undersampling_pixels = nullptr;  // pixel list of the current undersampling iteration (lumc_render_undersampled)
   uint32_t undersampling_capacity = 0;
   std::vector<uint32_t> sky_hdri_key;  // what the bake was made from (sky parameters, origin, dim, samples): an unchanged key reuses it
@@ -309,6 +311,7 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
   if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
   if (ctx->d_undersampling_pixels) (void) hipFree(ctx->d_undersampling_pixels);
+  for (float* m : ctx->bloom_mips) (void) hipFree(m);
   free_adaptive(ctx);
   delete ctx;
 }
@@ -1147,6 +1150,61 @@ int lumc_generate_result_undersampled_host(LumContext* ctx, uint32_t stage, uint
 }
 
 const float* lumc_result_image(LumContext* ctx) { return ctx ? ctx->d_frame_result : nullptr; }
+
+// _device_post_bloom_apply, device/device_post.c:56-139
+int lumc_post_bloom(LumContext* ctx, float* d_image, uint32_t full_width, uint32_t full_height, uint32_t undersampling_stage, float blend, void* stream_) {
+  if (!ctx) return 1;
+  if (!d_image) d_image = ctx->d_frame_result;
+  if (!d_image || full_width == 0 || full_height == 0) { ctx->error = "lumc_post_bloom: no image"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t stream = (hipStream_t) stream_;
+  uint32_t chain = 0;  // _device_post_bloom_mip_count: floor(log2(min dimension))
+  for (uint32_t m = std::min(full_width, full_height); m > 1; m >>= 1) chain++;
+  if (undersampling_stage + 1 >= chain) return 0;  // too coarse for a mip chain (device_post.c:62-64)
+  if (ctx->bloom_width != full_width || ctx->bloom_height != full_height) {
+    for (float* m : ctx->bloom_mips) (void) hipFree(m);
+    ctx->bloom_mips.clear(); ctx->bloom_width = ctx->bloom_height = 0;
+    for (uint32_t i = 0; i < chain; i++) {
+      float* m = nullptr;
+      HIP_TRY(ctx, hipMalloc((void**) &m, sizeof(float) * (size_t) (full_width >> (i + 1)) * (full_height >> (i + 1))));
+      ctx->bloom_mips.push_back(m);
+    }
+    ctx->bloom_width = full_width; ctx->bloom_height = full_height;
+  }
+  const uint32_t width = full_width >> undersampling_stage, height = full_height >> undersampling_stage, mips = chain - undersampling_stage;
+  const size_t plane = (size_t) width * height;
+  Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
+  for (uint32_t c = 0; c < 3; c++) {
+    float* image = d_image + c * plane;
+    std::vector<float*>& mip = ctx->bloom_mips;
+    hipLaunchKernelGGL(k_post_downsample, dim3(grid_for((width >> 1) * (height >> 1))), dim3(256), 0, stream, (const float*) image, width, height, mip[0], width >> 1, height >> 1);
+    for (uint32_t i = 0; i + 1 < mips; i++)
+      hipLaunchKernelGGL(k_post_downsample, dim3(grid_for((width >> (i + 2)) * (height >> (i + 2)))), dim3(256), 0, stream, (const float*) mip[i], width >> (i + 1), height >> (i + 1),
+                         mip[i + 1], width >> (i + 2), height >> (i + 2));
+    for (uint32_t i = mips - 1; i > 0; i--)
+      hipLaunchKernelGGL(k_post_upsample, dim3(grid_for((width >> i) * (height >> i))), dim3(256), 0, stream, (const float*) mip[i], width >> (i + 1), height >> (i + 1), mip[i - 1],
+                         width >> i, height >> i, 1.0f, 1.0f);
+    hipLaunchKernelGGL(k_post_upsample, dim3(grid_for(width * height)), dim3(256), 0, stream, (const float*) mip[0], width >> 1, height >> 1, image, width, height, blend / mips,
+                       1.0f - blend);
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+
+int lumc_post_bloom_host(LumContext* ctx, float* image, uint32_t full_width, uint32_t full_height, uint32_t undersampling_stage, float blend) {
+  if (!ctx || !image) { if (ctx) ctx->error = "lumc_post_bloom_host: null argument"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t bytes = sizeof(float) * 3 * (size_t) (full_width >> undersampling_stage) * (full_height >> undersampling_stage);
+  float* d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void**) &d, bytes));
+  int rc = 1;
+  if (hipMemcpy(d, image, bytes, hipMemcpyHostToDevice) == hipSuccess && lumc_post_bloom(ctx, d, full_width, full_height, undersampling_stage, blend, nullptr) == 0 &&
+      hipDeviceSynchronize() == hipSuccess && hipMemcpy(image, d, bytes, hipMemcpyDeviceToHost) == hipSuccess)
+    rc = 0;
+  else if (ctx->error.empty()) ctx->error = "lumc_post_bloom_host: transfer failed";
+  (void) hipFree(d);
+  return rc;
+}
 
 int lumc_synchronize(LumContext* ctx) {
   if (!ctx) return 1;

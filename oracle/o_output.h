@@ -5,7 +5,7 @@
  * (generate_final_image), cuda/tonemap.cuh:7-246, cuda/purkinje.cuh:19-90, cuda/math.cuh:1044-1060 (sRGB), :1081-1168 (filters),
  * :1483-1543 (HSV), cuda/post_common.cuh:6-44 (bilinear fetch), cuda/kernels.cuh:558-644 (convert_RGBF_to_ARGB8),
  * cuda/random.cuh:150-154, :197-212, :305-307, :370-379 (dither / grain masks).
- * Scope: any supersampling and undersampling stage (incl. accumulation_generate_result_undersampling, accumulation.cuh:192-254); no bloom.
+ * Scope: any supersampling and undersampling stage (incl. accumulation_generate_result_undersampling, accumulation.cuh:192-254) and bloom (device/device_post.c).
  * The reference's log2f/powf/rsqrtf are fast-math approximations with unspecified bits; log2/exp2/pow are fixed polynomial
  * sequences here (the HIP path uses the same sequences), which keeps the image bytes reproducible. Parity unpinned, like the
  * rest of the oracle: no golden image exists in the reference.
@@ -205,6 +205,88 @@ static inline float o_sample_plane(const float* plane, float x, float y, uint32_
   r += p11 * (fx * fy);
   return r;
 }
+/* ---- bloom: device/device_post.c:10-170, cuda/post_common.cuh:46-149 ---- */
+static inline float o_sample_plane_border(const float* plane, float x, float y, uint32_t width, uint32_t height, float weight) {
+  if (x > u2f(0x3F7FFFFFu) || x < 0.0f) return 0.0f;
+  if (y > u2f(0x3F7FFFFFu) || y < 0.0f) return 0.0f;
+  const float sx = fmaxf(0.0f, x * (width - 1)), sy = fmaxf(0.0f, y * (height - 1)); /* fmaxf(0, NaN) = 0: 1-pixel levels */
+  const uint32_t x0 = (uint32_t) sx, y0 = (uint32_t) sy;
+  uint32_t x1 = (uint32_t) (sx + 1.0f), y1 = (uint32_t) (sy + 1.0f);
+  if (x1 > width - 1) x1 = width - 1;
+  if (y1 > height - 1) y1 = height - 1;
+  const uint32_t i00 = (uint32_t) ((float) x0 + (float) (y0 * width)), i01 = (uint32_t) ((float) x0 + (float) (y1 * width));
+  const uint32_t i10 = (uint32_t) ((float) x1 + (float) (y0 * width)), i11 = (uint32_t) ((float) x1 + (float) (y1 * width));
+  const float p00 = plane[i00], p01 = plane[i01], p10 = plane[i10], p11 = plane[i11];
+  const float fx = sx - x0, ifx = 1.0f - fx, fy = sy - y0, ify = 1.0f - fy;
+  float r = p00 * (ifx * ify);
+  r += p01 * (ifx * fy);
+  r += p10 * (fx * ify);
+  r += p11 * (fx * fy);
+  return r * weight;
+}
+static void o_post_downsample(const float* src, uint32_t sw, uint32_t sh, float* dst, uint32_t tw, uint32_t th) {
+  const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
+  for (uint32_t i = 0; i < tw * th; i++) {
+    const uint32_t y = i / tw, x = i - y * tw;
+    const float sx = scale_x * x, sy = scale_y * y;
+    float p = 0.0f;
+    p += o_sample_plane_border(src, sx - 0.5f * step_x, sy - 0.5f * step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx + 0.5f * step_x, sy - 0.5f * step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx - 0.5f * step_x, sy + 0.5f * step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx + 0.5f * step_x, sy + 0.5f * step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx, sy, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx, sy - step_y, sw, sh, 0.5f);
+    p += o_sample_plane_border(src, sx - step_x, sy, sw, sh, 0.5f);
+    p += o_sample_plane_border(src, sx + step_x, sy, sw, sh, 0.5f);
+    p += o_sample_plane_border(src, sx, sy + step_y, sw, sh, 0.5f);
+    p += o_sample_plane_border(src, sx - step_x, sy - step_y, sw, sh, 0.25f);
+    p += o_sample_plane_border(src, sx + step_x, sy - step_y, sw, sh, 0.25f);
+    p += o_sample_plane_border(src, sx - step_x, sy + step_y, sw, sh, 0.25f);
+    p += o_sample_plane_border(src, sx + step_x, sy + step_y, sw, sh, 0.25f);
+    p *= 1.0f / 8.0f;
+    dst[i] = fmaxf(p, 0.0f);
+  }
+}
+static void o_post_upsample(const float* src, uint32_t sw, uint32_t sh, float* dst, uint32_t tw, uint32_t th, float sa, float sb) {
+  const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
+  for (uint32_t i = 0; i < tw * th; i++) {
+    const uint32_t y = i / tw, x = i - y * tw;
+    const float sx = scale_x * x, sy = scale_y * y;
+    float p = o_sample_plane_border(src, sx - step_x, sy - step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx, sy - step_y, sw, sh, 2.0f);
+    p += o_sample_plane_border(src, sx + step_x, sy - step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx - step_x, sy, sw, sh, 2.0f);
+    p += o_sample_plane_border(src, sx, sy, sw, sh, 4.0f);
+    p += o_sample_plane_border(src, sx + step_x, sy, sw, sh, 2.0f);
+    p += o_sample_plane_border(src, sx - step_x, sy + step_y, sw, sh, 1.0f);
+    p += o_sample_plane_border(src, sx, sy + step_y, sw, sh, 2.0f);
+    p += o_sample_plane_border(src, sx + step_x, sy + step_y, sw, sh, 1.0f);
+    p *= 1.0f / 20.0f;
+    p *= sa;
+    float base = dst[i];
+    base *= sb;
+    dst[i] = p + base;
+  }
+}
+/* _device_post_bloom_apply: in place on the planar image of (full_width >> stage) x (full_height >> stage) */
+static void output_bloom(float* image, uint32_t full_width, uint32_t full_height, uint32_t stage, float blend) {
+  uint32_t chain = 0;
+  for (uint32_t m = full_width < full_height ? full_width : full_height; m > 1; m >>= 1) chain++;
+  if (stage + 1 >= chain) return;
+  const uint32_t width = full_width >> stage, height = full_height >> stage, mips = chain - stage;
+  float** mip = (float**) malloc(sizeof(float*) * mips);
+  for (uint32_t i = 0; i < mips; i++) mip[i] = (float*) malloc(sizeof(float) * ((size_t) (width >> (i + 1)) * (height >> (i + 1)) + 1));
+  for (uint32_t c = 0; c < 3; c++) {
+    float* plane = image + (size_t) c * width * height;
+    o_post_downsample(plane, width, height, mip[0], width >> 1, height >> 1);
+    for (uint32_t i = 0; i + 1 < mips; i++) o_post_downsample(mip[i], width >> (i + 1), height >> (i + 1), mip[i + 1], width >> (i + 2), height >> (i + 2));
+    for (uint32_t i = mips - 1; i > 0; i--) o_post_upsample(mip[i], width >> (i + 1), height >> (i + 1), mip[i - 1], width >> i, height >> i, 1.0f, 1.0f);
+    o_post_upsample(mip[0], width >> 1, height >> 1, plane, width, height, blend / mips, 1.0f - blend);
+  }
+  for (uint32_t i = 0; i < mips; i++) free(mip[i]);
+  free(mip);
+}
+
 static inline float o_dither_mask(const uint16_t* bn, uint32_t x, uint32_t y) { return o_unit16(bn[(x & 255u) + (y & 255u) * 256u]); }
 
 /* math.cuh:1081-1168 */

@@ -476,6 +476,7 @@ void oracle_generate_output(const OracleOutputParamsAbi* params, const float* fi
   memcpy(&p, params, sizeof(p));
   output_generate(&p, first_moment, bluenoise_1d, frame_output, argb8);
 }
+void oracle_post_bloom(float* image, uint32_t full_width, uint32_t full_height, uint32_t stage, float blend) { output_bloom(image, full_width, full_height, stage, blend); }
 void oracle_result_undersampled(const float* first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration, float* result) {
   output_result_undersampled(first_moment, width, height, stage, iteration, result);
 }

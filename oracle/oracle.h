@@ -129,6 +129,8 @@ typedef struct {
 } OracleOutputParamsAbi;
 /* input: planes of (src >> undersampling_stage) pixels; frame_output: planes of (src >> max(stage, supersampling)) pixels */
 void oracle_generate_output(const OracleOutputParamsAbi* params, const float* first_moment, const uint16_t* bluenoise_1d, float* frame_output, uint32_t* argb8);
+/* bloom (device/device_post.c:56-139), in place on the planar image [3][(full_width >> stage) * (full_height >> stage)] */
+void oracle_post_bloom(float* image, uint32_t full_width, uint32_t full_height, uint32_t stage, float blend);
 /* compact preview image of the undersampling iteration (stage, iteration): 3 planes of (width >> stage) x (height >> stage) */
 void oracle_result_undersampled(const float* first_moment, uint32_t width, uint32_t height, uint32_t stage, uint32_t iteration, float* result);
 /* Adaptive sampling (o_adaptive.h). Blocks are 4x4 pixels, row-major over ceil(width/4) x ceil(height/4); executions[s] = completed

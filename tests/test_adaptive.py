@@ -147,7 +147,7 @@ def test_adaptive_rendering_through_the_api(tmp_path):
     tone.exposure = exposure
     o = oracle_lib.AdaptiveOracle(view, MAX_RATE, AVG_RATE, INTERVAL, exposure=exposure, tone=tone)
     o.render(7)
-    want, _ = oracle_lib.generate_output(tone, o.result(mode=0, local_error_minimization=True, exposure=exposure, tone=tone).reshape(3, -1))
+    want = oracle_lib.api_output(tone, o.result(mode=0, local_error_minimization=True, exposure=exposure, tone=tone))
     assert np.array_equal(img, want)
     fm, sm = host.accumulators()
     o.render(2)

@@ -88,7 +88,7 @@ def test_outputs_through_the_api_match_the_oracle(tmp_path):
         fm, _, _ = oracle_lib.render(view, 0, spp)
         p = default_output_params(w, h, spp, dst=dst)
         p.exposure = float(np.exp(np.float32(0.5)))
-        return oracle_lib.generate_output(p, fm)[0]
+        return oracle_lib.api_output(p, fm * (np.float32(1.0) / np.float32(spp)))  # result image, bloom, display chain
 
     h2 = host.try_await_output(at2)
     assert h2 is not None

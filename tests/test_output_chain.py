@@ -205,3 +205,36 @@ def test_output_chain_scales_match_oracle(ss, stage, dst):
     assert np.array_equal(got_planes.view(np.uint32), want_planes.view(np.uint32)), "display-referred planes differ"
     assert np.array_equal(got, want), "%d of %d ARGB8 words differ" % ((got != want).sum(), got.size)
     core.close()
+
+
+# ---- bloom (device_post.c): mip chain of the result image blended back into it ----
+def test_oracle_bloom_properties():
+    w, h = 40, 24
+    flat = np.full((3, h, w), 0.5, np.float32)
+    out = oracle_lib.post_bloom(flat, w, h, 0.25)
+    # the tent filter sums to 16/20 and every level adds to the one above, so a constant image does not keep its level exactly: with four
+    # levels the glow is 0.25 / 4 * 0.8 * (1 + 0.8 + 0.64) of it, the base 0.75 of it; the border reads zeros and is dimmer
+    assert 0.40 < out[0, h // 2, w // 2] < 0.45 and out[0, 0, 0] < out[0, h // 2, w // 2]
+    spot = np.zeros((3, h, w), np.float32)
+    spot[:, 12, 20] = 100.0
+    glow = oracle_lib.post_bloom(spot, w, h, 0.1)
+    assert glow[0, 12, 20] < 100.0 and glow[0, 12, 23] > 0.0 and glow[0, 3, 3] > 0.0, "light spreads over the frame"
+    assert glow[0, 12, 23] > glow[0, 12, 30] > 0.0
+    assert np.array_equal(oracle_lib.post_bloom(spot, w, h, 0.0)[0, 12, 20:21], spot[0, 12, 20:21]), "blend 0: base * 1 + nothing"
+    # too coarse for a chain: floor(log2(24)) = 4 levels, stage 3 leaves one -> untouched
+    small = np.random.default_rng(0).random((3, h >> 3, w >> 3), dtype=np.float32)
+    assert np.array_equal(oracle_lib.post_bloom(small, w, h, 0.3, stage=3), small)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w,h,stage,blend", [(160, 90, 0, 0.01), (97, 61, 0, 0.3), (64, 64, 0, 1.0), (168, 88, 1, 0.05), (168, 88, 2, 0.2), (33, 17, 0, 0.1), (16, 9, 0, 0.5)])
+def test_bloom_matches_oracle(w, h, stage, blend):
+    """Every level of the chain down to 1 x 1 (whose coordinates are NaN by construction), odd sizes, undersampled images."""
+    from luminary_amd.core import Core
+    core = Core(0)
+    img = _synthetic_moment(w >> stage, h >> stage, 1, seed=9).reshape(3, h >> stage, w >> stage)
+    got = core.post_bloom(img, w, h, blend, stage)
+    want = oracle_lib.post_bloom(img, w, h, blend, stage)
+    assert np.isfinite(want).all()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), "%d of %d values differ, max %g" % ((got != want).sum(), got.size, np.abs(got - want).max())
+    core.close()

@@ -73,7 +73,7 @@ def test_preview_through_the_host_api(tmp_path, adaptive):
     assert np.array_equal(got_fm, ofm) and np.array_equal(got_sm, osm)
     coarse = oracle_lib.result_undersampled(ofm, wi, hi, 1, 0)
     p = default_output_params(wi, hi, 1, supersampling=ss, undersampling_stage=1)
-    want_preview = oracle_lib.generate_output(p, coarse.reshape(3, -1))[0]
+    want_preview = oracle_lib.api_output(p, coarse)
     rec = host.acquire_output()
     img, count, _ = host.get_image(rec)
     assert count == 1 and np.array_equal(img, want_preview)
@@ -89,7 +89,7 @@ def test_preview_through_the_host_api(tmp_path, adaptive):
     q = default_output_params(wi, hi, 2, supersampling=ss)
     rec = host.acquire_output()
     img2, count2, _ = host.get_image(rec)
-    assert count2 == 2 and np.array_equal(img2, oracle_lib.generate_output(q, fm2)[0])
+    assert count2 == 2 and np.array_equal(img2, oracle_lib.api_output(q, fm2 * (np.float32(1.0) / np.float32(2.0))))
     if adaptive:  # interval 2: stage 1 was built after these two executions, from the same moments as without a preview
         info = Core.adaptive_info_of(host.core_context())
         assert info["stage_id"] == 1 and info["executions"][0] == 2
@@ -106,4 +106,4 @@ def test_no_preview_without_recurring_outputs(tmp_path):
     fm, _, _ = oracle_lib.render(view, 0, 1)
     q = default_output_params(view.width, view.height, 1, supersampling=1)
     h1 = host.try_await_output(at1)
-    assert h1 is not None and np.array_equal(host.get_image(h1)[0], oracle_lib.generate_output(q, fm)[0])
+    assert h1 is not None and np.array_equal(host.get_image(h1)[0], oracle_lib.api_output(q, fm))
