@@ -369,6 +369,8 @@ LUMINARY_API LuminaryResult luminary_ext_add_mesh(
 LUMINARY_API LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id);
 /* Converts the current scene to the device format (device_structs.c conversions + light tree build). The view and everything it points
  * to stay valid until the next call or host destruction. Needs no GPU. */
+/* rotation_euler_angles_to_quaternion (src/luminary/host_math.c:6-21), x y z w */
+LUMINARY_API LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float quaternion[4]);
 LUMINARY_API LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const struct LumDeviceSceneView** view);
 /* Synchronous batch rendering of sample ids [first_sample, first_sample + num_samples) of `pixels` (NULL = all) on this process' GPU. */
 LUMINARY_API LuminaryResult luminary_ext_render_samples(

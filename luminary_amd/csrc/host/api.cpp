@@ -696,6 +696,13 @@ LuminaryResult luminary_ext_get_ray_counters(LuminaryHost* host, uint64_t out[8]
   if (!host->core) return LUMINARY_ERROR_API_EXCEPTION;
   return lumc_counters(host->core, out) ? LUMINARY_ERROR_CUDA : LUMINARY_SUCCESS;
 }
+// host_math.c:6-21 as the instance transforms use it (exposed so that it can be checked against the reference's own function)
+LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float quaternion[4]) {
+  CHECK_NULL(rotation); CHECK_NULL(quaternion);
+  LuminaryVec3 r; r.x = rotation[0]; r.y = rotation[1]; r.z = rotation[2];
+  lum::euler_to_quaternion(r, quaternion);
+  return LUMINARY_SUCCESS;
+}
 void* luminary_ext_get_core_context(LuminaryHost* host) {
   if (!host) return nullptr;
   std::lock_guard<std::mutex> lock(host->mutex);

@@ -5,10 +5,35 @@ import ctypes as C
 import threading
 import time
 
+import os
+
+import pytest
+
 import luminary_amd
 
 OK, ARG_NULL, INVALID_ARG, MEMORY_LEAK, OOM, API_EXCEPTION = 0, 1, 3, 4, 5, 7
 PROPAGATED = 1 << 63
+
+
+REF_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "libluminary_ref_host.so")
+
+
+@pytest.fixture(params=["ours", "reference"])
+def any_lib(request):
+    """The same expectations are run against this library and against the reference's own array.c / host_memory.c / queue.c / ringbuffer.c
+    (oracle/_ref, built from /root/reference by oracle/build_ref.sh): what the tests expect IS the reference's behaviour."""
+    if request.param == "ours":
+        return lib()
+    if not os.path.exists(REF_PATH):
+        pytest.skip("oracle/_ref not built (no reference sources in this checkout)")
+    l = C.CDLL(REF_PATH, mode=os.RTLD_LAZY | os.RTLD_LOCAL)
+    for name in ("_host_malloc", "_host_realloc", "_host_free", "_array_create", "_array_resize", "_array_push", "_array_copy", "_array_append", "_array_destroy",
+                 "array_clear", "array_get_size", "array_get_num_elements", "_array_set_num_elements", "_queue_create", "queue_push", "queue_push_unique", "queue_pop",
+                 "queue_pop_blocking", "queue_set_is_blocking", "_queue_destroy", "_ringbuffer_create", "ringbuffer_allocate_entry", "ringbuffer_release_entry",
+                 "_ringbuffer_destroy"):
+        getattr(l, name).restype = C.c_uint64
+    l.is_reference = True
+    return l
 
 
 def lib():
@@ -27,20 +52,23 @@ TAG = (b"buf", b"test", C.c_uint32(1))
 
 
 def in_use(l):
+    if getattr(l, "is_reference", False):
+        return 0  # the reference keeps its allocation total private (host_memory.c); the byte counts are checked on ours only
     v = C.c_uint64()
     assert l.luminary_ext_host_memory_in_use(C.byref(v)) == OK
     return v.value
 
 
-def test_counted_allocations():
-    l = lib()
+def test_counted_allocations(any_lib):
+    l = any_lib
     base = in_use(l)
+    grow = 0 if getattr(l, "is_reference", False) else 1
     p = C.c_void_p()
     assert l._host_malloc(C.byref(p), C.c_size_t(1000), *TAG) == OK and p.value and p.value % 16 == 0
-    assert in_use(l) == base + 1000
+    assert in_use(l) == base + 1000 * grow
     C.memset(p, 0xAB, 1000)
     assert l._host_realloc(C.byref(p), C.c_size_t(4000), *TAG) == OK
-    assert in_use(l) == base + 4000 and C.string_at(p, 1000) == b"\xab" * 1000
+    assert in_use(l) == base + 4000 * grow and C.string_at(p, 1000) == b"\xab" * 1000
     assert l._host_free(C.byref(p), *TAG) == OK and p.value is None and in_use(l) == base
     assert l._host_free(C.byref(p), *TAG) == ARG_NULL
     assert l._host_malloc(None, C.c_size_t(8), *TAG) == ARG_NULL
@@ -49,8 +77,8 @@ def test_counted_allocations():
     assert l._host_free(C.byref(not_ours), *TAG) == API_EXCEPTION
 
 
-def test_array_growth_append_and_errors():
-    l = lib()
+def test_array_growth_append_and_errors(any_lib):
+    l = any_lib
     base = in_use(l)
     a = C.c_void_p()
     assert l._array_create(C.byref(a), C.c_size_t(4), C.c_uint32(2), *TAG) == OK
@@ -87,8 +115,8 @@ def test_array_growth_append_and_errors():
     assert in_use(l) == base
 
 
-def test_queue_fifo_unique_and_blocking():
-    l = lib()
+def test_queue_fifo_unique_and_blocking(any_lib):
+    l = any_lib
     q = C.c_void_p()
     assert l._queue_create(C.byref(q), C.c_size_t(0), C.c_size_t(4), *TAG) == INVALID_ARG
     assert l._queue_create(C.byref(q), C.c_size_t(4), C.c_size_t(3), *TAG) == OK
@@ -134,8 +162,8 @@ def test_queue_fifo_unique_and_blocking():
     assert l._queue_destroy(C.byref(q), *TAG) == OK and q.value is None
 
 
-def test_ringbuffer_wraps_without_splitting_entries():
-    l = lib()
+def test_ringbuffer_wraps_without_splitting_entries(any_lib):
+    l = any_lib
     r = C.c_void_p()
     assert l._ringbuffer_create(C.byref(r), C.c_size_t(0), *TAG) == INVALID_ARG
     assert l._ringbuffer_create(C.byref(r), C.c_size_t(100), *TAG) == OK
