@@ -95,23 +95,24 @@ LuminaryResult ensure_core(LuminaryHost* h) {
 
 extern "C" {
 
-// ---- error.c ----
+// ---- error.c ---- (the reference's texts, checked against its own error.c in tests/test_reference_host.py; codes 8 and 9 keep their
+// wording for frontends that print or match them, although the errors come from HIP and the BVH builders here)
 const char* luminary_result_to_string(LuminaryResult result) {
   switch (result & ~LUMINARY_ERROR_PROPAGATED) {
     case LUMINARY_SUCCESS: return "Success";
-    case LUMINARY_ERROR_ARGUMENT_NULL: return "Argument was NULL";
-    case LUMINARY_ERROR_NOT_IMPLEMENTED: return "Not implemented";
-    case LUMINARY_ERROR_INVALID_API_ARGUMENT: return "Invalid API argument";
-    case LUMINARY_ERROR_MEMORY_LEAK: return "Memory leak";
-    case LUMINARY_ERROR_OUT_OF_MEMORY: return "Out of memory";
-    case LUMINARY_ERROR_C_STD: return "C standard library error";
-    case LUMINARY_ERROR_API_EXCEPTION: return "API exception";
-    case LUMINARY_ERROR_CUDA: return "GPU runtime error";
-    case LUMINARY_ERROR_OPTIX: return "Acceleration structure error";
-    case LUMINARY_ERROR_PREVIOUS_ERROR: return "Previous error";
-    case LUMINARY_ERROR_DEBUG_ASSERT: return "Debug assert";
-    case LUMINARY_ERROR_MISSING_DATA: return "Missing data";
-    case LUMINARY_ERROR_INVALID_DEVICE: return "Invalid device";
+    case LUMINARY_ERROR_ARGUMENT_NULL: return "Encountered NULL argument";
+    case LUMINARY_ERROR_NOT_IMPLEMENTED: return "Encountered a section that is not implemented";
+    case LUMINARY_ERROR_INVALID_API_ARGUMENT: return "Encountered an invalid argument";
+    case LUMINARY_ERROR_MEMORY_LEAK: return "Identified a memory leak";
+    case LUMINARY_ERROR_OUT_OF_MEMORY: return "Ran out of memory";
+    case LUMINARY_ERROR_C_STD: return "Encountered an error in a call to a C stdlib function";
+    case LUMINARY_ERROR_API_EXCEPTION: return "Encountered an internal error";
+    case LUMINARY_ERROR_CUDA: return "Encountered an error reported by CUDA";
+    case LUMINARY_ERROR_OPTIX: return "Encountered an error reported by OptiX";
+    case LUMINARY_ERROR_PREVIOUS_ERROR: return "Encountered an unstable state due to a previous error";
+    case LUMINARY_ERROR_DEBUG_ASSERT: return "Encountered an invalid state during debugging";
+    case LUMINARY_ERROR_MISSING_DATA: return "Missing necessary embedded data";
+    case LUMINARY_ERROR_INVALID_DEVICE: return "Specified invalid device";
     default: return "Unknown";
   }
 }

@@ -30,7 +30,8 @@ def any_lib(request):
     for name in ("_host_malloc", "_host_realloc", "_host_free", "_array_create", "_array_resize", "_array_push", "_array_copy", "_array_append", "_array_destroy",
                  "array_clear", "array_get_size", "array_get_num_elements", "_array_set_num_elements", "_queue_create", "queue_push", "queue_push_unique", "queue_pop",
                  "queue_pop_blocking", "queue_set_is_blocking", "_queue_destroy", "_ringbuffer_create", "ringbuffer_allocate_entry", "ringbuffer_release_entry",
-                 "_ringbuffer_destroy"):
+                 "_ringbuffer_destroy", "thread_status_create", "thread_status_set_worker_name", "thread_status_get_worker_name", "thread_status_start",
+                 "thread_status_get_time", "thread_status_get_string", "thread_status_stop", "thread_status_destroy"):
         getattr(l, name).restype = C.c_uint64
     l.is_reference = True
     return l
@@ -185,8 +186,8 @@ def test_ringbuffer_wraps_without_splitting_entries(any_lib):
     assert l._ringbuffer_destroy(C.byref(r), *TAG) == OK and r.value is None
 
 
-def test_thread_status_reports_activity():
-    l = lib()
+def test_thread_status_reports_activity(any_lib):
+    l = any_lib
     s = C.c_void_p()
     assert l.thread_status_create(C.byref(s)) == OK
     name, text, t = C.c_char_p(), C.c_char_p(), C.c_double()

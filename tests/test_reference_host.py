@@ -352,3 +352,18 @@ def test_wavefront_files_load_like_the_reference(tmp_path):
                 x, y = (1 - abs(y)) * np.sign(x), (1 - abs(x)) * np.sign(y)
             d = np.array([x, y, z]) / np.linalg.norm([x, y, z])
             assert np.dot(d, n) > 0.9999, (t, k, d, n)
+
+
+def test_name_tables_and_result_strings_are_the_references():
+    """name_strings.c and error.c: every entry of every table, every result code."""
+    mine_lib, r = luminary_amd._lib(), ref()
+    tables = {"luminary_strings_shading_mode": 6, "luminary_strings_adaptive_sampling_output_mode": 4, "luminary_strings_filter": 7, "luminary_strings_tonemap": 7,
+              "luminary_strings_aperture": 2, "luminary_strings_jerlov_water_type": 10, "luminary_strings_sky_mode": 3, "luminary_strings_material_base_substrate": 2}
+    for name, count in tables.items():
+        a = [x for x in (C.c_char_p * count).in_dll(mine_lib, name)]
+        b = [x for x in (C.c_char_p * count).in_dll(r, name)]
+        assert a == b and all(a), name
+    mine_lib.luminary_result_to_string.restype = C.c_char_p
+    r.luminary_result_to_string.restype = C.c_char_p
+    for code in list(range(0, 24)) + [1 << 63, (1 << 63) | 7]:
+        assert mine_lib.luminary_result_to_string(C.c_uint64(code)) == r.luminary_result_to_string(C.c_uint64(code)), code
