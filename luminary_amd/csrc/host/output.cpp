@@ -110,7 +110,7 @@ LuminaryResult OutputStore::acquire_recurring(uint32_t* handle) {
     const Object& o = objects_[i];
     if (!o.populated || o.time_stamp <= stamp) continue;
     if (o.meta.width != props_.width || o.meta.height != props_.height) continue;
-    if (o.promise_reference != kInvalid || !o.recurring) continue;  // outputs made for requests are not handed out here
+    if (o.promise_reference != kInvalid) continue;  // an output made for a request is not handed out here until its promise was awaited (host_output_handler.c:104-106)
     latest = i;
     stamp = o.time_stamp;
   }

@@ -2,8 +2,10 @@
 // Behaviour follows the reference's output handler (src/luminary/host/host_output_handler.c): images are produced either for the
 // recurring output (size set by luminary_host_set_output_properties) or for a request (promise) keyed by an exact sample count (0 =
 // the next output); a handle stays valid while its reference count is non-zero; at least four recurring images of the current size
-// are kept before the oldest unreferenced one is overwritten; an image produced for a request is not handed out by
-// luminary_host_acquire_output and not overwritten until its promise was awaited.
+// are kept before the oldest unreferenced one is overwritten; an image produced for a request is neither handed out by
+// luminary_host_acquire_output nor overwritten until its promise was awaited. Checked operation by operation against the reference's
+// own handler (tests/test_reference_host.py); two deliberate differences: an image still being written is not handed to an awaiting
+// promise, and a promise that already holds an image is not given a second one.
 #pragma once
 
 #include <cstdint>
