@@ -126,7 +126,7 @@ class DeviceSceneView(C.Structure):
                 ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p),
                 ("sky_moon_pos", C.c_float * 3), ("sky_moon_tex_offset", C.c_float), ("sky_moon_albedo_tex", C.c_uint32), ("sky_moon_normal_tex", C.c_uint32),
                 ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p),
-                ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3)]
+                ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3), ("sky_aerial_perspective", C.c_uint32)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -246,6 +246,14 @@ class Host:
         inst.scale = Vec3(*scale)
         _call("luminary_host_set_instance", self._h, C.byref(inst))
         return inst.id
+
+    def get_instance(self, i):
+        inst = Instance()
+        _call("luminary_host_get_instance", self._h, C.c_uint32(i), C.byref(inst))
+        return inst
+
+    def set_instance(self, inst):
+        _call("luminary_host_set_instance", self._h, C.byref(inst))
 
     def counts(self):
         a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -90,6 +90,7 @@ struct DeviceScene {
   const uint32_t* sky_stars_offsets;  // 64 x 32 + 1
   const float4* sky_hdri;             // [dim][dim] baked panorama (k_sky_hdri), read when sky_mode == HDRI; alpha unused
   uint32_t sky_hdri_dim;
+  uint32_t sky_aerial_perspective;    // the air between a ray's origin and its hit is marched too (k_sky_inscattering)
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).

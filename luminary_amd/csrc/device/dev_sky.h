@@ -22,7 +22,7 @@ constexpr float kSkyAtmoRadius = kSkyAtmoHeight + kSkyEarthRadius;
 constexpr float kSkyHeightOffset = 0.0005f;
 constexpr int kSkyTmWidth = 256, kSkyTmHeight = 64, kSkyMsSize = 32, kSkyMsBase = 16, kSkyMsIter = 256;
 // RANDOM_TARGET_SKY_STEP_OFFSET and RandomSet::LIGHT_SUN<0> (geometry, material.cuh:61) by the allocation rule of random.cuh:24-66
-constexpr uint32_t kRndSkyStepOffset = 77, kRndSunBsdf = 346, kRndSunBsdfMethod = 349, kRndSunRay = 352, kRndSunResampling = 355;
+constexpr uint32_t kRndSkyStepOffset = 77, kRndSkyInscatteringStep = 78, kRndSunBsdf = 346, kRndSunBsdfMethod = 349, kRndSunRay = 352, kRndSunResampling = 355;
 constexpr float kSkyMieScattering = 3.996f * 0.001f, kSkyMieExtinction = 4.440f * 0.001f;
 
 struct Spectrum { float v[8]; };
@@ -351,8 +351,10 @@ LUM_DEV V3 angles_to_direction(float altitude, float azimuth) {
   return v3(cz * ca, sa, sz * ca);
 }
 
-// ---- sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars; sky_get_color (:508-515) ----
-LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3 ray, float limit, bool celestials, int steps, float random_offset) {
+// ---- sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars (no clouds: their shadow term is 1).
+// `transmittance_out` is multiplied by the transmittance of the marched segment. ----
+LUM_DEV Spectrum sky_compute_atmosphere(const DeviceScene& sc, const SkyView& s, Spectrum& transmittance_out, V3 origin, V3 ray, float limit, bool celestials, int steps,
+                                        float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const F2 path = sky_compute_path(origin, ray, kSkyEarthRadius, kSkyAtmoRadius);
   const float start = path.x, distance = fminf(path.y, limit - start);
@@ -430,7 +432,24 @@ LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3
       }
     }
   }
-  return sky_color_from_spectrum(result);
+  transmittance_out = sp_mul(transmittance_out, transmittance);
+  return result;
+}
+// sky_get_color, sky.cuh:508-515
+LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3 ray, float limit, bool celestials, int steps, float random_offset) {
+  Spectrum unused = sp_set1(0.0f);
+  return sky_color_from_spectrum(sky_compute_atmosphere(sc, s, unused, origin, ray, limit, celestials, steps, random_offset));
+}
+// Aerial perspective, sky_trace_inscattering (sky.cuh:517-532): the air between a ray's origin and its hit scatters sun light towards the
+// viewer and dims what lies behind. `limit` in sky units (km); returns the in-scattered colour times `record`, and dims `record`.
+LUM_DEV Col sky_trace_inscattering(const DeviceScene& sc, const SkyView& s, V3 origin, V3 ray, float limit, Col& record, bool primary_ray, float step_random, float random_offset) {
+  Spectrum transmittance = sp_set1(1.0f);
+  const float base_range = primary_ray ? 40.0f : 80.0f;
+  const int steps = (int) (fminf(fmaxf(0.5f, limit / base_range), 2.0f) * (float) (s.steps / 6u) + step_random - 0.5f);
+  const Spectrum radiance = sky_compute_atmosphere(sc, s, transmittance, origin, ray, limit, false, steps, random_offset);
+  const Col inscattering = sky_color_from_spectrum(radiance) * record;
+  record = record * sky_color_from_spectrum(transmittance);
+  return inscattering;
 }
 
 // ---- HDRI bake (cuda/sky_hdri.cuh:13-160, device/device_sky.c:283-316): the sky without celestial bodies seen from `origin`, as an

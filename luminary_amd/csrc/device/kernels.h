@@ -461,6 +461,26 @@ __global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, Sh
   }
 }
 
+// ---- aerial perspective: sky_process_inscattering_events (cuda/kernels.cuh:357-388), between the closest-hit pass and shading ----
+__global__ __launch_bounds__(kBlock) void k_sky_inscattering(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const SkyView sky = sky_view(sc);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint4 hid = in.hit_id[i];
+    if (hid.x == kHitSky) continue;
+    const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+    uint4 aux = in.aux[i];
+    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+    Col record = record_unpack(U2{aux.x, aux.y});
+    const Col c = sky_trace_inscattering(sc, sky, world_to_sky(sky, v3(o4.x, o4.y, o4.z)), v3(d4.x, d4.y, d4.z), o4.w * 0.001f, record, depth_const == 0u,
+                                         smp.next1(kRndSkyInscatteringStep), smp.next1(kRndSkyStepOffset));
+    add_to_result(results, fbits(d4.w), c);
+    const U2 rp = record_pack(record);
+    aux.x = rp.x; aux.y = rp.y;
+    in.aux[i] = aux;
+  }
+}
+
 // ---- light queries: BSDF-sampled direction against the light-only BVH (cuda/direct_lighting.cuh:586-667) ----
 __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const,
                                                         uint64_t* counters) {

@@ -548,6 +548,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   // ---- sky look-up tables: taken from the caller or generated here (device/device_sky.c:64-200), only for the procedural sky ----
   sc.sky_lut_transmittance = nullptr; sc.sky_lut_multiscattering = nullptr;
   sc.sky_hdri = nullptr; sc.sky_hdri_dim = 0;
+  sc.sky_aerial_perspective = v->sky_aerial_perspective;
   if (sc.sky_mode != kSkyConstantColor) {  // HDRI mode bakes from them and samples the sun through them
     const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
     if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
@@ -699,6 +700,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       hipLaunchKernelGGL(k_trace, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
+    }
+    if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
+      Launch l(ctx, stream, LUMC_KERNEL_SKY);
+      hipLaunchKernelGGL(k_sky_inscattering, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);

@@ -992,6 +992,7 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   v.sky_hdri = nullptr;
   v.sky_hdri_dim = sky.hdri_dim ? sky.hdri_dim : 1u; v.sky_hdri_samples = sky.hdri_samples ? sky.hdri_samples : 1u;
   std::memcpy(v.sky_hdri_origin, scene.hdri_origin, sizeof(v.sky_hdri_origin));
+  v.sky_aerial_perspective = sky.aerial_perspective ? 1u : 0u;
   return std::string();
 }
 

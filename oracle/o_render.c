@@ -202,6 +202,15 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       }
       break;
     }
+    if (s->sky_aerial_perspective && s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering) {
+      /* sky_process_inscattering_events, cuda/kernels.cuh:357-388 (device_manager.c:475): before the hit is shaded */
+      const OSky view = osky_view(s);
+      RGBF record = record_unpack(record_p);
+      const RGBF c = sky_trace_inscattering(&view, world_to_sky(&view, origin), ray, hit.t * 0.001f, &record, smp.depth == 0, rnd1(&smp, RANDOM_TARGET_SKY_INSCATTERING_STEP),
+                                            rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET));
+      beauty_add(&result, c);
+      record_p = record_pack(record);
+    }
     cnt[ORACLE_CNT_VERTICES]++;
     const vec3 hit_origin = v_add(origin, v_scale(ray, hit.t));
     const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);

@@ -29,6 +29,7 @@
 #define SKY_MS_SIZE 32
 #define SKY_MS_BASE 16
 #define SKY_MS_ITER 256
+#define RANDOM_TARGET_SKY_INSCATTERING_STEP 78u
 #define RANDOM_TARGET_SKY_STEP_OFFSET 77u /* allocation rule of random.cuh:24-66; the sun targets are RandomSet::LIGHT_SUN<0> (material.cuh:61) */
 #define RT_SUN_BSDF 346u
 #define RT_SUN_BSDF_METHOD 349u
@@ -352,8 +353,9 @@ static inline vec3 angles_to_direction(float altitude, float azimuth) { /* math.
   return v3(cz * ca, sa, sz * ca);
 }
 
-/* sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars; sky_get_color (:508-515) */
-static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
+/* sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars (no clouds: their shadow term is 1);
+ * *transmittance_out is multiplied by the transmittance of the marched segment */
+static Spectrum sky_compute_atmosphere(const OSky* s, Spectrum* transmittance_out, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const float2_t path = sky_compute_path(origin, ray, SKY_EARTH_RADIUS, SKY_ATMO_RADIUS);
   const float start = path.x, distance = fminf(path.y, limit - start);
@@ -432,7 +434,23 @@ static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, boo
       }
     }
   }
-  return sky_color_from_spectrum(result);
+  *transmittance_out = sp_mul(*transmittance_out, transmittance);
+  return result;
+}
+/* sky_get_color, sky.cuh:508-515 */
+static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
+  Spectrum unused = sp_set1(0.0f);
+  return sky_color_from_spectrum(sky_compute_atmosphere(s, &unused, origin, ray, limit, celestials, steps, random_offset));
+}
+/* aerial perspective: sky_trace_inscattering, sky.cuh:517-532 (limit in sky units; IS_PRIMARY_RAY = the depth constant is 0) */
+static RGBF sky_trace_inscattering(const OSky* s, vec3 origin, vec3 ray, float limit, RGBF* record, bool primary_ray, float step_random, float random_offset) {
+  Spectrum transmittance = sp_set1(1.0f);
+  const float base_range = primary_ray ? 40.0f : 80.0f;
+  const int steps = (int) (fminf(fmaxf(0.5f, limit / base_range), 2.0f) * (float) (s->steps / 6u) + step_random - 0.5f);
+  const Spectrum radiance = sky_compute_atmosphere(s, &transmittance, origin, ray, limit, false, steps, random_offset);
+  const RGBF inscattering = c_mul(sky_color_from_spectrum(radiance), *record);
+  *record = c_mul(*record, sky_color_from_spectrum(transmittance));
+  return inscattering;
 }
 
 /* ---- HDRI bake (cuda/sky_hdri.cuh:13-160) ---- */

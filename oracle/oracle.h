@@ -78,6 +78,7 @@ typedef struct OracleScene {
   const float* sky_hdri;
   uint32_t sky_hdri_dim, sky_hdri_samples;
   float sky_hdri_origin[3];
+  uint32_t sky_aerial_perspective; /* sky.aerial_perspective: in-scattering and extinction along rays that hit geometry (not in constant-colour mode) */
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */

@@ -351,3 +351,64 @@ def test_hdri_rebuild_on_request_through_the_host_api():
     assert not np.array_equal(a, b)
     want = oracle_lib.sky_hdri(oracle_lib.with_sky_luts(host.device_scene()))
     assert np.array_equal(b, want)
+
+
+# ---- aerial perspective: the air between a ray's origin and its hit (sky.aerial_perspective) ----
+def _distant_scene(aerial, mode=SKY_MODE_DEFAULT, scale=400.0):
+    """The example scene blown up to kilometres, so that there is enough air in front of the geometry to see."""
+    host = scenes.example_scene(W, H, 3, sphere_segments=8, ground_res=16, num_objects=24, num_lights=4)
+    sky = host.get_sky()
+    sky.mode = mode
+    sky.altitude, sky.azimuth = 0.6, 2.0
+    sky.aerial_perspective = aerial
+    sky.hdri_dim, sky.hdri_samples = 16, 2
+    host.set_sky(sky)
+    n = host.counts()[2]
+    for i in range(n):
+        inst = host.get_instance(i)
+        inst.position.x, inst.position.y, inst.position.z = inst.position.x * scale, inst.position.y * scale, inst.position.z * scale
+        inst.scale.x, inst.scale.y, inst.scale.z = inst.scale.x * scale, inst.scale.y * scale, inst.scale.z * scale
+        host.set_instance(inst)
+    cam = host.get_camera()
+    cam.pos.x, cam.pos.y, cam.pos.z = cam.pos.x * scale, cam.pos.y * scale, cam.pos.z * scale
+    host.set_camera(cam)
+    return host
+
+
+def test_oracle_aerial_perspective_adds_haze():
+    plain = _with_sky_luts(_distant_scene(False).device_scene())
+    hazy = _with_sky_luts(_distant_scene(True).device_scene())
+    assert plain.sky_aerial_perspective == 0 and hazy.sky_aerial_perspective == 1
+    a, _, _ = oracle_lib.render(plain, 0, 2)
+    b, _, _ = oracle_lib.render(hazy, 0, 2)
+    assert np.isfinite(b).all() and not np.array_equal(a, b)
+    # the ground in the lower half of the frame is kilometres away: the air in front of it adds light, blue more than red
+    lower_a, lower_b = a.reshape(3, H, W)[:, H // 2 + 4:], b.reshape(3, H, W)[:, H // 2 + 4:]
+    gain = lower_b.mean(axis=(1, 2)) - lower_a.mean(axis=(1, 2))
+    assert gain[2] > 0.0 and gain[2] > gain[0]
+    # a constant-colour sky has no atmosphere: the switch does nothing there (device_manager.c:475)
+    from luminary_amd import SKY_MODE_CONSTANT_COLOR
+    c1 = oracle_lib.with_luts(_distant_scene(False, mode=SKY_MODE_CONSTANT_COLOR).device_scene())
+    c2 = oracle_lib.with_luts(_distant_scene(True, mode=SKY_MODE_CONSTANT_COLOR).device_scene())
+    assert np.array_equal(oracle_lib.render(c1, 0, 1)[0], oracle_lib.render(c2, 0, 1)[0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [SKY_MODE_DEFAULT, SKY_MODE_HDRI])
+def test_aerial_perspective_matches_the_oracle(mode):
+    host = _distant_scene(True, mode=mode)
+    plain = host.device_scene()
+    view = oracle_lib.with_sky_hdri(plain) if mode == SKY_MODE_HDRI else _with_sky_luts(plain)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.reset_counters()
+        core.render(0, 3, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
+        assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
+        assert np.array_equal(sm, osm)
+        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    finally:
+        core.close()
