@@ -2,8 +2,11 @@
 reference's own device-independent C (entity defaults, .lum v4 parser, Wavefront reader, host math, arrays / queues / ring buffers),
 compiled from /root/reference by oracle/build_ref.sh (nothing copied; the device layer is not buildable here). Each test runs the
 same input through that library and through libluminary_amd.so and compares the results byte for byte.
-Skipped when the library is absent (a checkout without the reference)."""
+When the library is absent (a checkout without the reference, the GPU box) the reference's answers come from
+tests/golden/reference_host.json, which this module records from the live library:
+    LUM_RECORD_GOLDEN=1 python -m pytest tests/test_reference_host.py -q"""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -16,7 +19,24 @@ import luminary_amd
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_PATH = os.path.join(ROOT, "oracle", "_ref", "libluminary_ref_host.so")
-pytestmark = pytest.mark.skipif(not os.path.exists(REF_PATH), reason="oracle/_ref not built (no reference sources in this checkout)")
+GOLDEN_PATH = os.path.join(ROOT, "tests", "golden", "reference_host.json")
+LIVE = os.path.exists(REF_PATH)
+RECORD = LIVE and os.environ.get("LUM_RECORD_GOLDEN") == "1"
+_GOLDEN = json.load(open(GOLDEN_PATH)) if os.path.exists(GOLDEN_PATH) else {}
+
+
+def reference_value(key, compute):
+    """The reference's answer for `key`: computed by the live library (and recorded on request), else read from the committed fixture."""
+    if LIVE:
+        v = compute()
+        if RECORD:
+            _GOLDEN[key] = v
+            json.dump(_GOLDEN, open(GOLDEN_PATH, "w"), indent=0, sort_keys=True)
+        return json.loads(json.dumps(v))  # the same types in both modes
+    if key not in _GOLDEN:
+        pytest.skip("neither oracle/_ref nor a recorded answer for " + key)
+    return _GOLDEN[key]
+
 
 ENTITIES = ["settings", "camera", "ocean", "sky", "cloud", "fog", "particles"]
 C_TYPES = ["LuminaryRendererSettings", "LuminaryCamera", "LuminaryOcean", "LuminarySky", "LuminaryCloud", "LuminaryFog", "LuminaryParticles"]
@@ -48,11 +68,13 @@ def sizes():
 
 
 def ref_default(name, fill=0):
-    buf = (C.c_uint8 * 4096)(*([fill] * 4096))
-    fn = getattr(ref(), name + "_get_default")
-    fn.restype = C.c_uint64
-    assert fn(buf) == 0
-    return bytes(buf)[:sizes()[name]]
+    def live():
+        buf = (C.c_uint8 * 4096)(*([fill] * 4096))
+        fn = getattr(ref(), name + "_get_default")
+        fn.restype = C.c_uint64
+        assert fn(buf) == 0
+        return bytes(buf)[:sizes()[name]].hex()
+    return bytes.fromhex(reference_value("default/%s/%d" % (name, fill), live))
 
 
 def field_mask(name):
@@ -84,10 +106,13 @@ def test_entity_defaults_are_the_references():
 def test_default_material_is_the_references():
     """material.c:5-29 against luminary_amd.default_material(), the starting point of every material the scene generators add."""
     m = luminary_amd.default_material()
-    buf = (C.c_uint8 * 4096)()
-    ref().material_get_default.restype = C.c_uint64
-    assert ref().material_get_default(buf) == 0
-    r = luminary_amd.Material.from_buffer_copy(bytes(buf)[:C.sizeof(luminary_amd.Material)])
+
+    def live():
+        buf = (C.c_uint8 * 4096)()
+        ref().material_get_default.restype = C.c_uint64
+        assert ref().material_get_default(buf) == 0
+        return bytes(buf)[:C.sizeof(luminary_amd.Material)].hex()
+    r = luminary_amd.Material.from_buffer_copy(bytes.fromhex(reference_value("default/material", live)))
     for f, _ in luminary_amd.Material._fields_:
         a, b = getattr(m, f), getattr(r, f)
         if hasattr(a, "_fields_"):
@@ -144,7 +169,7 @@ def _ref_lum(path):
     assert r.luminary_path_create(C.byref(p)) == 0 and r.luminary_path_set_from_string(p, path.encode()) == 0
     assert r.lum_read_file(p, content) == 0
     c = content.contents
-    return {n: bytes(getattr(c, n)) for n in ENTITIES}, c.wavefront_args
+    return {n: bytes(getattr(c, n)).hex() for n in ENTITIES}
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3])
@@ -154,7 +179,7 @@ def test_lum_v4_files_parse_like_the_reference(tmp_path, seed):
     extra = "MATERIAL LIGHTSON 1\nMATERIAL SMOOTHNE 1\nMATERIAL EMISSION 2.5\nCAMERA BLOOM___ %d\n# tail\n" % (seed % 2)
     path = tmp_path / "scene.lum"
     path.write_text(_lum_text(seed, extra))
-    want, wf = _ref_lum(str(path))
+    want = {n: bytes.fromhex(h) for n, h in reference_value("lum_v4/%d" % seed, lambda: _ref_lum(str(path))).items()}
     host = luminary_amd.Host()
     host.load_lum_file(str(path))
     for name in ENTITIES:
@@ -165,24 +190,29 @@ def test_lum_v4_files_parse_like_the_reference(tmp_path, seed):
 
 def test_euler_angles_to_quaternion_matches_host_math():
     """rotation_euler_angles_to_quaternion (host_math.c:6-21) against the rotation our instance transforms are encoded from."""
-    r = ref()
-
     class V(C.Structure):
         _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float)]
 
     class Q(C.Structure):
         _fields_ = [("x", C.c_float), ("y", C.c_float), ("z", C.c_float), ("w", C.c_float)]
-    r.rotation_euler_angles_to_quaternion.restype = Q
-    r.rotation_euler_angles_to_quaternion.argtypes = [V]
     lib = luminary_amd._lib()
     lib.luminary_ext_euler_to_quaternion.restype = C.c_uint64
     rng = np.random.default_rng(0)
     angles = np.concatenate([rng.uniform(-7.0, 7.0, (200, 3)), np.zeros((1, 3)), np.array([[np.pi, 0, 0], [0, np.pi / 2, 0], [0, 0, -np.pi]])]).astype(np.float32)
-    for a in angles:
-        q = r.rotation_euler_angles_to_quaternion(V(*[float(x) for x in a]))
+    def live():
+        r = ref()
+        r.rotation_euler_angles_to_quaternion.restype = Q
+        r.rotation_euler_angles_to_quaternion.argtypes = [V]
+        out = []
+        for a in angles:
+            q = r.rotation_euler_angles_to_quaternion(V(*[float(x) for x in a]))
+            out.append([int(x) for x in np.array([q.x, q.y, q.z, q.w], np.float32).view(np.uint32)])
+        return out
+    want = reference_value("quaternions", live)
+    for a, w in zip(angles, want):
         out = (C.c_float * 4)()
         assert lib.luminary_ext_euler_to_quaternion((C.c_float * 3)(*[float(x) for x in a]), out) == 0
-        assert np.array_equal(np.array(list(out), np.float32).view(np.uint32), np.array([q.x, q.y, q.z, q.w], np.float32).view(np.uint32)), a
+        assert [int(x) for x in np.array(list(out), np.float32).view(np.uint32)] == w, a
 
 
 # ---- Wavefront reader: the reference's parse (wavefront_read_file) against what our loader hands to the renderer ----
@@ -219,12 +249,27 @@ def _ref_wavefront(path, args):
     assert r._queue_create(C.byref(q), C.c_size_t(48), C.c_uint32(64), b"q", b"test", C.c_uint32(1)) == 0
     assert r.wavefront_read_file(content, p, q) == 0
     c = content.contents
-    verts = np.array(_ref_array(c.vertices, C.c_float * 3), dtype=np.float32).reshape(-1, 3)
-    normals = np.array(_ref_array(c.normals, C.c_float * 3), dtype=np.float32).reshape(-1, 3)
-    uvs = np.array(_ref_array(c.uvs, C.c_float * 2), dtype=np.float32).reshape(-1, 2)
-    tris = list(_ref_array(c.triangles, _WfTriangle))
-    mats = list(_ref_array(c.materials, _WfMaterial))
-    return verts, normals, uvs, tris, mats
+    bits = lambda arr, n: np.array(arr, dtype=np.float32).reshape(-1, n).view(np.uint32).tolist()  # floats travel as their bit patterns
+    tri_fields = [f for f, _ in _WfTriangle._fields_]
+    return {"verts": bits(_ref_array(c.vertices, C.c_float * 3), 3), "normals": bits(_ref_array(c.normals, C.c_float * 3), 3),
+            "uvs": bits(_ref_array(c.uvs, C.c_float * 2), 2), "tris": [[int(getattr(t, f)) for f in tri_fields] for t in _ref_array(c.triangles, _WfTriangle)],
+            "mats": [{"kd": bits(m.kd, 3)[0], "dissolve": bits([m.dissolve], 1)[0][0], "ks": bits(m.ks, 3)[0], "ns": bits([m.ns], 1)[0][0], "ke": bits(m.ke, 3)[0],
+                      "ni": bits([m.ni], 1)[0][0], "texture": [int(t) for t in m.texture]} for m in _ref_array(c.materials, _WfMaterial)]}
+
+
+class _Rec:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+
+def _unpack_wavefront(d):
+    f = lambda rows, n: np.array(rows, dtype=np.uint32).reshape(-1, n).view(np.float32)
+    one = lambda b: float(np.array([b], np.uint32).view(np.float32)[0])
+    tri_fields = [f_ for f_, _ in _WfTriangle._fields_]
+    tris = [_Rec(**dict(zip(tri_fields, row))) for row in d["tris"]]
+    mats = [_Rec(kd=f([m["kd"]], 3)[0].tolist(), dissolve=one(m["dissolve"]), ks=f([m["ks"]], 3)[0].tolist(), ns=one(m["ns"]), ke=f([m["ke"]], 3)[0].tolist(), ni=one(m["ni"]),
+                 texture=m["texture"]) for m in d["mats"]]
+    return f(d["verts"], 3), f(d["normals"], 3), f(d["uvs"], 2), tris, mats
 
 
 def _expected_mesh(verts, normals, uvs, tris):
@@ -308,10 +353,12 @@ Tf 1 1 1
 def test_wavefront_files_load_like_the_reference(tmp_path):
     (tmp_path / "scene.obj").write_text(OBJ)
     (tmp_path / "scene.mtl").write_text(MTL)
-    args = _WavefrontArguments(False, False, 1.0, False)
-    ref().wavefront_arguments_get_default.restype = C.c_uint64
-    assert ref().wavefront_arguments_get_default(C.byref(args)) == 0
-    verts, normals, uvs, tris, mats = _ref_wavefront(str(tmp_path / "scene.obj"), args)
+    def live():
+        args = _WavefrontArguments(False, False, 1.0, False)
+        ref().wavefront_arguments_get_default.restype = C.c_uint64
+        assert ref().wavefront_arguments_get_default(C.byref(args)) == 0
+        return _ref_wavefront(str(tmp_path / "scene.obj"), args)
+    verts, normals, uvs, tris, mats = _unpack_wavefront(reference_value("wavefront", live))
     want_pos, want_uv, want_mat, want_nrm = _expected_mesh(verts, normals, uvs, tris)
     assert len(want_pos) >= 8
 
@@ -334,6 +381,7 @@ def test_wavefront_files_load_like_the_reference(tmp_path):
         m = host.get_material(i + offset)
         assert (m.albedo.r, m.albedo.g, m.albedo.b, m.albedo.a) == (wm.kd[0], wm.kd[1], wm.kd[2], wm.dissolve), i
         assert (m.emission.r, m.emission.g, m.emission.b) == tuple(wm.ke), i
+        wm.ks, wm.ke, wm.texture = list(wm.ks), list(wm.ke), list(wm.texture)
         assert m.refraction_index == wm.ni and m.roughness == np.float32(1.0) - np.float32(wm.ns) / np.float32(1000.0), i
         assert bool(m.metallic) == (wm.ks[0] > 0.5) and bool(m.emission_active) == any(x > 0.0 for x in wm.ke), i
         assert [m.albedo_tex, m.luminance_tex, m.roughness_tex, m.metallic_tex, m.normal_tex] == [0xFFFF if t == 0xFFFF else t for t in wm.texture], i
@@ -356,17 +404,23 @@ def test_wavefront_files_load_like_the_reference(tmp_path):
 
 def test_name_tables_and_result_strings_are_the_references():
     """name_strings.c and error.c: every entry of every table, every result code."""
-    mine_lib, r = luminary_amd._lib(), ref()
+    mine_lib = luminary_amd._lib()
     tables = {"luminary_strings_shading_mode": 6, "luminary_strings_adaptive_sampling_output_mode": 4, "luminary_strings_filter": 7, "luminary_strings_tonemap": 7,
               "luminary_strings_aperture": 2, "luminary_strings_jerlov_water_type": 10, "luminary_strings_sky_mode": 3, "luminary_strings_material_base_substrate": 2}
+    codes = list(range(0, 24)) + [1 << 63, (1 << 63) | 7]
+
+    def live():
+        r = ref()
+        r.luminary_result_to_string.restype = C.c_char_p
+        return {"tables": {name: [x.decode() for x in (C.c_char_p * count).in_dll(r, name)] for name, count in tables.items()},
+                "results": [r.luminary_result_to_string(C.c_uint64(code)).decode() for code in codes]}
+    want = reference_value("strings", live)
     for name, count in tables.items():
-        a = [x for x in (C.c_char_p * count).in_dll(mine_lib, name)]
-        b = [x for x in (C.c_char_p * count).in_dll(r, name)]
-        assert a == b and all(a), name
+        a = [x.decode() for x in (C.c_char_p * count).in_dll(mine_lib, name)]
+        assert a == want["tables"][name] and all(a), name
     mine_lib.luminary_result_to_string.restype = C.c_char_p
-    r.luminary_result_to_string.restype = C.c_char_p
-    for code in list(range(0, 24)) + [1 << 63, (1 << 63) | 7]:
-        assert mine_lib.luminary_result_to_string(C.c_uint64(code)) == r.luminary_result_to_string(C.c_uint64(code)), code
+    for code, text in zip(codes, want["results"]):
+        assert mine_lib.luminary_result_to_string(C.c_uint64(code)).decode() == text, code
 
 
 # ---- output handles and promises: lum::OutputStore against the reference's host_output_handler.c, operation by operation ----
@@ -405,14 +459,27 @@ def test_output_store_behaves_like_the_reference_handler(tmp_path, seed):
     handles): result codes, handles, promise ids and image meta data agree after every step."""
     PROP = 1 << 63
     mine = _output_store_lib(tmp_path)
-    r = ref()
-    for f in ("output_handler_create", "output_handler_set_properties", "output_handler_add_request", "output_handler_acquire_recurring", "output_handler_acquire",
-              "output_handler_release", "output_handler_acquire_from_promise", "output_handler_acquire_new", "output_handler_acquire_from_request_new",
-              "output_handler_release_new", "output_handler_get_image"):
-        getattr(r, f).restype = C.c_uint64
-    s = C.c_void_p(mine.os_create())
+    key = "output_trace/%d" % seed
+    recorded = None if LIVE else _GOLDEN.get(key)
+    if not LIVE and recorded is None:
+        pytest.skip("neither oracle/_ref nor a recorded trace")
+    trace = []
     h = C.c_void_p()
-    assert r.output_handler_create(C.byref(h)) == 0
+    if LIVE:
+        r = ref()
+        for f in ("output_handler_create", "output_handler_set_properties", "output_handler_add_request", "output_handler_acquire_recurring", "output_handler_acquire",
+                  "output_handler_release", "output_handler_acquire_from_promise", "output_handler_acquire_new", "output_handler_acquire_from_request_new",
+                  "output_handler_release_new", "output_handler_get_image"):
+            getattr(r, f).restype = C.c_uint64
+        assert r.output_handler_create(C.byref(h)) == 0
+
+    def R(fn):
+        """The reference's answer for this step: from the live handler (and into the trace), or the recorded one."""
+        v = json.loads(json.dumps(fn())) if LIVE else recorded[len(trace)]
+        trace.append(v)
+        return v
+
+    s = C.c_void_p(mine.os_create())
     rng = np.random.default_rng(seed)
     sizes_ = [(8, 6), (5, 4)]
     open_writes, promises = [], []
@@ -420,6 +487,11 @@ def test_output_store_behaves_like_the_reference_handler(tmp_path, seed):
 
     def desc(w, hh, sc, recurring):
         return _OutDesc(recurring, _OutMeta(w, hh, sc, False, 1.0), None)
+
+    def with_handle(fn):
+        out = C.c_uint32(0xFFFFFFFF)
+        code = fn(C.byref(out)) & ~PROP
+        return [code, out.value if code == 0 else None]
 
     log = []
     for step in range(400):
@@ -430,20 +502,16 @@ def test_output_store_behaves_like_the_reference_handler(tmp_path, seed):
         a = b = None
         if op == 0:
             mine.os_set_properties(s, 1, w, hh)
-            assert r.output_handler_set_properties(h, _OutProps(True, w, hh)) == 0
+            a, b = 0, R(lambda: r.output_handler_set_properties(h, _OutProps(True, w, hh)))
         elif op == 1:
             want = int(rng.integers(0, 4))  # 0 = the next output
             pa = mine.os_add_request(s, want, w, hh)
-            pb = C.c_uint32()
-            assert r.output_handler_add_request(h, _OutReq(want, w, hh), C.byref(pb)) == 0
-            a, b = pa, pb.value
+            a, b = [0, pa], R(lambda: with_handle(lambda out: r.output_handler_add_request(h, _OutReq(want, w, hh), out)))
             promises.append(pa)
             model[pa] = [want, w, hh, False, True]
         elif op == 2:
             ha = mine.os_begin_recurring(s, w, hh, sc)
-            hb = C.c_uint32()
-            assert r.output_handler_acquire_new(h, desc(w, hh, sc, True), C.byref(hb)) == 0
-            a, b = ha, hb.value
+            a, b = [0, ha], R(lambda: with_handle(lambda out: r.output_handler_acquire_new(h, desc(w, hh, sc, True), out)))
             open_writes.append(ha)
         elif op == 3:
             match = [p for p in sorted(model) if model[p][4] and (model[p][1], model[p][2]) == (w, hh) and model[p][0] in (0, sc)]
@@ -451,37 +519,39 @@ def test_output_store_behaves_like_the_reference_handler(tmp_path, seed):
                 # the first matching promise already holds an image nobody awaited yet: the reference's handler would hand it a second one (its
                 # device side never asks twice, device_output.c:215-219); ours gives the image to the next promise instead. Not exercised.
                 continue
-            ha, hb = C.c_uint32(0xFFFFFFFF), C.c_uint32(0xFFFFFFFF)
-            ca = mine.os_begin_for_request(s, w, hh, sc, C.byref(ha))
-            cb = r.output_handler_acquire_from_request_new(h, desc(w, hh, sc, False), C.byref(hb)) & ~PROP
-            a, b = (ca, ha.value if ca == 0 else None), (cb, hb.value if cb == 0 else None)
-            if ca == 0:
-                open_writes.append(ha.value)
+            a = with_handle(lambda out: mine.os_begin_for_request(s, w, hh, sc, out))
+            b = R(lambda: with_handle(lambda out: r.output_handler_acquire_from_request_new(h, desc(w, hh, sc, False), out)))
+            if a[0] == 0:
+                open_writes.append(a[1])
                 model[match[0]][3] = True
         elif op == 4 and open_writes:
             x = open_writes.pop(int(rng.integers(0, len(open_writes))))
-            a, b = mine.os_publish(s, x), r.output_handler_release_new(h, C.c_uint32(x)) & ~PROP
+            a, b = mine.os_publish(s, x), R(lambda: r.output_handler_release_new(h, C.c_uint32(x)) & ~PROP)
         elif op == 5:
-            ha, hb = C.c_uint32(), C.c_uint32()
-            a = (mine.os_acquire_recurring(s, C.byref(ha)), ha.value)
-            b = (r.output_handler_acquire_recurring(h, C.byref(hb)) & ~PROP, hb.value)
+            a = with_handle(lambda out: mine.os_acquire_recurring(s, out))
+            b = R(lambda: with_handle(lambda out: r.output_handler_acquire_recurring(h, out)))
         elif op == 6 and promises and not open_writes:  # (ours refuses to hand out an image that is still being written: the one deliberate difference)
             p = promises[int(rng.integers(0, len(promises)))]
-            ha, hb = C.c_uint32(), C.c_uint32()
-            a = (mine.os_acquire_from_promise(s, p, C.byref(ha)), ha.value)
-            b = (r.output_handler_acquire_from_promise(h, C.c_uint32(p), C.byref(hb)) & ~PROP, hb.value)
-            if ha.value != 0xFFFFFFFF:
+            a = with_handle(lambda out: mine.os_acquire_from_promise(s, p, out))
+            b = R(lambda: with_handle(lambda out: r.output_handler_acquire_from_promise(h, C.c_uint32(p), out)))
+            if a[1] != 0xFFFFFFFF:
                 model[p][4] = False
         elif op == 7:
-            a, b = mine.os_acquire(s, hnd), r.output_handler_acquire(h, C.c_uint32(hnd)) & ~PROP
+            a, b = mine.os_acquire(s, hnd), R(lambda: r.output_handler_acquire(h, C.c_uint32(hnd)) & ~PROP)
         elif op == 8:
-            a, b = mine.os_release(s, hnd), r.output_handler_release(h, C.c_uint32(hnd)) & ~PROP
+            a, b = mine.os_release(s, hnd), R(lambda: r.output_handler_release(h, C.c_uint32(hnd)) & ~PROP)
         elif op == 9:
             out = (C.c_uint32 * 3)()
-            img = luminary_amd.Image()
             ca = mine.os_get_image(s, hnd, out)
-            cb = r.output_handler_get_image(h, C.c_uint32(hnd), C.byref(img)) & ~PROP
-            a = (ca, tuple(out) if ca == 0 else None)
-            b = (cb, (img.width, img.height, img.sample_count) if cb == 0 else None)
+            a = [ca, list(out) if ca == 0 else None]
+
+            def ref_image():
+                img = luminary_amd.Image()
+                cb = r.output_handler_get_image(h, C.c_uint32(hnd), C.byref(img)) & ~PROP
+                return [cb, [img.width, img.height, img.sample_count] if cb == 0 else None]
+            b = R(ref_image)
         log.append((step, op, a, b))
         assert a == b, "step %d op %d: ours %s, reference %s; history %s" % (step, op, a, b, log[-8:])
+    if RECORD:
+        _GOLDEN[key] = trace
+        json.dump(_GOLDEN, open(GOLDEN_PATH, "w"), indent=0, sort_keys=True)
