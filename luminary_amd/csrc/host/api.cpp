@@ -41,6 +41,7 @@ struct LuminaryHost {
   bool hdri_origin_pending = true;   // the next scene build re-bakes the sky panorama from the camera's position (SCENE_DIRTY_FLAG_HDRI)
   lum::OutputStore outputs;
   double render_seconds = 0.0;
+  double last_sample_ms = 0.0;  // wall time of the most recent render chunk per sample allocation, in milliseconds (device_sampletime.c)
   std::vector<std::string> log;
   std::mutex mutex;
 };
@@ -231,7 +232,8 @@ LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* pat
   return LUMINARY_SUCCESS;
 }
 
-LuminaryResult luminary_host_get_current_sample_time(LuminaryHost* host, double* time) { CHECK_NULL(host); CHECK_NULL(time); *time = 0.0; return LUMINARY_SUCCESS; }
+// host.c:607-613 -> sample_time_get_time (device_sampletime.c:32-45): with one device, the time its latest sample took (milliseconds; 0 before the first)
+LuminaryResult luminary_host_get_current_sample_time(LuminaryHost* host, double* time) { CHECK_NULL(host); CHECK_NULL(time); *time = host->last_sample_ms; return LUMINARY_SUCCESS; }
 // host.c:615-703: no queue-worker threads exist in this implementation
 LuminaryResult luminary_host_get_num_queue_workers(const LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = 0; return LUMINARY_SUCCESS; }
 LuminaryResult luminary_host_get_queue_worker_name(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
@@ -561,7 +563,7 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
     const auto t0 = std::chrono::steady_clock::now();
     if (lumc_render(host->core, first_sample + done, chunk, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
     if (lumc_synchronize(host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
-    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); host->render_seconds += dt; host->last_sample_ms = 1e3 * dt / (chunk ? chunk : 1u); }
     host->accumulated_samples += chunk;
     done += chunk;
     r = produce_outputs(host);
@@ -581,7 +583,7 @@ static LuminaryResult render_first_sample_as_preview(LuminaryHost* host, bool* r
       std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core));
       return LUMINARY_ERROR_CUDA;
     }
-    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); host->render_seconds += dt; host->last_sample_ms = 1e3 * dt; }
     if (k + 1 == schedule.size()) host->accumulated_samples = 1;  // device_renderer_finish_iteration counts the sample with the last iteration
     const LuminaryResult r = produce_outputs(host, schedule[k]);
     if (r) return r;
@@ -654,7 +656,7 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
       std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core));
       return LUMINARY_ERROR_CUDA;
     }
-    host->render_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); host->render_seconds += dt; host->last_sample_ms = 1e3 * dt / (chunk ? chunk : 1u); }
     host->accumulated_samples += chunk;
     done += chunk;
     r = produce_outputs(host);

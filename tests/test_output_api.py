@@ -101,6 +101,9 @@ def test_outputs_through_the_api_match_the_oracle(tmp_path):
     assert h3 is not None and host.get_image(h3)[1] == 3 and np.array_equal(host.get_image(h3)[0], oracle_image(3))
     rec = host.acquire_output()
     img_r, count_r, t = host.get_image(rec)
+    ms = C.c_double()
+    luminary_amd._call("luminary_host_get_current_sample_time", host._h, C.byref(ms))
+    assert 0.0 < ms.value < 1e4, "milliseconds the latest sample took (device_sampletime.c)"
     assert count_r == 4 and t > 0.0 and np.array_equal(img_r, oracle_image(4))
     assert len({h2, hs, h3, rec}) == 4  # images owed to promises are not recycled before they were awaited
 
