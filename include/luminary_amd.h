@@ -369,6 +369,9 @@ LUMINARY_API LuminaryResult luminary_ext_add_mesh(
 LUMINARY_API LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id);
 /* Converts the current scene to the device format (device_structs.c conversions + light tree build). The view and everything it points
  * to stay valid until the next call or host destruction. Needs no GPU. */
+/* Whether replacing `old` by `input` restarts the integration (camera.c:80-147, settings.c:45-72) or only changes the outputs.
+ * entity 0: LuminaryRendererSettings, 1: LuminaryCamera. luminary_host_set_camera / set_settings apply this rule. */
+LUMINARY_API LuminaryResult luminary_ext_change_restarts_integration(int entity, const void* input, const void* old, bool* restarts);
 /* rotation_euler_angles_to_quaternion (src/luminary/host_math.c:6-21), x y z w */
 LUMINARY_API LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float quaternion[4]);
 LUMINARY_API LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const struct LumDeviceSceneView** view);

@@ -59,6 +59,39 @@ void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_
 
 #define CHECK_NULL(p) do { if (!(p)) return LUMINARY_ERROR_ARGUMENT_NULL; } while (0)
 
+// Does a change of the camera / the renderer settings restart the integration (SCENE_DIRTY_FLAG_INTEGRATION), or does it only change how
+// the accumulated frame is shown (SCENE_DIRTY_FLAG_OUTPUT)? camera_check_for_dirty (camera.c:80-147), settings_check_for_dirty
+// (settings.c:45-72); checked against both in tests/test_reference_host.py.
+bool camera_change_restarts(const LuminaryCamera& in, const LuminaryCamera& old) {
+  bool d = in.pos.x != old.pos.x || in.pos.y != old.pos.y || in.pos.z != old.pos.z || in.rotation.x != old.rotation.x || in.rotation.y != old.rotation.y ||
+           in.rotation.z != old.rotation.z || in.russian_roulette_threshold != old.russian_roulette_threshold || in.camera_scale != old.camera_scale ||
+           in.object_distance != old.object_distance || in.use_physical_camera != old.use_physical_camera || in.aperture_shape != old.aperture_shape;
+  if (in.aperture_shape != LUMINARY_APERTURE_ROUND) d = d || in.aperture_blade_count != old.aperture_blade_count;
+  if (in.use_physical_camera) {
+    const auto& a = in.physical; const auto& b = old.physical;
+    d = d || a.allow_reflections != b.allow_reflections || a.use_spectral_rendering != b.use_spectral_rendering || a.focal_length != b.focal_length ||
+        a.front_focal_point != b.front_focal_point || a.back_focal_point != b.back_focal_point || a.front_principal_point != b.front_principal_point ||
+        a.back_principal_point != b.back_principal_point || a.aperture_point != b.aperture_point || a.aperture_diameter != b.aperture_diameter ||
+        a.exit_pupil_point != b.exit_pupil_point || a.exit_pupil_diameter != b.exit_pupil_diameter || a.image_plane_distance != b.image_plane_distance ||
+        a.sensor_width != b.sensor_width;
+  }
+  else d = d || in.thin_lens.fov != old.thin_lens.fov || in.thin_lens.aperture_size != old.thin_lens.aperture_size;
+  return d;
+}
+bool settings_change_restarts(const LuminaryRendererSettings& in, const LuminaryRendererSettings& old) {
+  bool d = in.width != old.width || in.height != old.height || in.supersampling != old.supersampling || in.bridge_max_num_vertices != old.bridge_max_num_vertices ||
+           in.undersampling != old.undersampling || in.shading_mode != old.shading_mode || in.enable_adaptive_sampling != old.enable_adaptive_sampling ||
+           in.region_x != old.region_x || in.region_y != old.region_y || in.region_width != old.region_width || in.region_height != old.region_height;
+  if (in.enable_adaptive_sampling)
+    d = d || in.adaptive_sampling_max_sampling_rate != old.adaptive_sampling_max_sampling_rate || in.adaptive_sampling_avg_sampling_rate != old.adaptive_sampling_avg_sampling_rate ||
+        in.adaptive_sampling_update_interval != old.adaptive_sampling_update_interval || in.adaptive_sampling_exposure_aware != old.adaptive_sampling_exposure_aware;
+  if (in.shading_mode == LUMINARY_SHADING_MODE_DEFAULT) d = d || in.max_ray_depth != old.max_ray_depth;
+  return d;
+}
+template <typename T> bool change_restarts(const T&, const T&) { return true; }  // sky, ocean, cloud, fog, particles: every field feeds the integration
+inline bool change_restarts(const LuminaryCamera& in, const LuminaryCamera& old) { return camera_change_restarts(in, old); }
+inline bool change_restarts(const LuminaryRendererSettings& in, const LuminaryRendererSettings& old) { return settings_change_restarts(in, old); }
+
 LuminaryResult ensure_device_scene(LuminaryHost* h) {
   if (h->device_scene_valid) return LUMINARY_SUCCESS;
   if (h->hdri_origin_pending) {  // sky_hdri_update (device/device_sky.c:249-266): the panorama follows the camera only when the sky is dirty
@@ -331,9 +364,10 @@ LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
     CHECK_NULL(host); CHECK_NULL(in);                                                                   \
     std::lock_guard<std::mutex> lock(host->mutex);                                                      \
     if (std::memcmp(&host->scene.FIELD, in, sizeof(TYPE)) != 0) {                                       \
+      const bool restarts = change_restarts(*in, host->scene.FIELD);                                    \
       host->scene.FIELD = *in;                                                                          \
       if (std::is_same<TYPE, LuminarySky>::value) host->hdri_origin_pending = true; /* sky.c:45: every sky change dirties the panorama */ \
-      invalidate(host);                                                                                 \
+      if (restarts) invalidate(host); /* else: only the outputs change; the accumulated frame stays (SCENE_DIRTY_FLAG_OUTPUT) */ \
     }                                                                                                   \
     return LUMINARY_SUCCESS;                                                                            \
   }
@@ -704,6 +738,14 @@ LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float q
   CHECK_NULL(rotation); CHECK_NULL(quaternion);
   LuminaryVec3 r; r.x = rotation[0]; r.y = rotation[1]; r.z = rotation[2];
   lum::euler_to_quaternion(r, quaternion);
+  return LUMINARY_SUCCESS;
+}
+// 0: renderer settings, 1: camera. Exposed so that the rule can be checked against the reference's *_check_for_dirty.
+LuminaryResult luminary_ext_change_restarts_integration(int entity, const void* input, const void* old, bool* restarts) {
+  CHECK_NULL(input); CHECK_NULL(old); CHECK_NULL(restarts);
+  if (entity == 0) *restarts = settings_change_restarts(*(const LuminaryRendererSettings*) input, *(const LuminaryRendererSettings*) old);
+  else if (entity == 1) *restarts = camera_change_restarts(*(const LuminaryCamera*) input, *(const LuminaryCamera*) old);
+  else return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   return LUMINARY_SUCCESS;
 }
 void* luminary_ext_get_core_context(LuminaryHost* host) {

@@ -193,3 +193,30 @@ def test_c_frontend_renders_the_same_png_as_the_python_binding(tmp_path):
     host.save_png(handle, str(tmp_path / "py.png"))
     assert open(str(tmp_path / "c.png"), "rb").read() == open(str(tmp_path / "py.png"), "rb").read()
     assert _decode_png(str(tmp_path / "c.png")).shape == (s.height, s.width, 4)
+
+
+@pytest.mark.gpu
+def test_output_only_changes_keep_the_accumulated_frame(tmp_path):
+    """camera.c:80-147: exposure, tone curve, filter, bloom ... only change how the frame is shown (SCENE_DIRTY_FLAG_OUTPUT); moving the
+    camera restarts the integration."""
+    w, h = 48, 32
+    host = scenes.cornell_host(str(tmp_path), w, h, 2)
+    host.set_output_properties(w, h)
+    view = oracle_lib.with_luts(host.device_scene())
+    host.render(2)
+    cam = host.get_camera()
+    cam.exposure, cam.tonemap, cam.bloom_blend = 1.0, 1, 0.0
+    host.set_camera(cam)
+    host.render(1)
+    fm, _ = host.accumulators()
+    ofm, _, _ = oracle_lib.render(view, 0, 3)
+    assert np.array_equal(fm, ofm), "three samples accumulated across the change"
+    img, count, _ = host.get_image(host.acquire_output())
+    p = default_output_params(w, h, 3)
+    p.exposure, p.tonemap = float(np.exp(np.float32(1.0))), 1
+    assert count == 3 and np.array_equal(img, oracle_lib.api_output(p, ofm * (np.float32(1.0) / np.float32(3.0)), blend=0.0)), "shown with the new exposure and curve"
+    cam.pos.x += 0.1
+    host.set_camera(cam)
+    host.render(1)
+    img, count, _ = host.get_image(host.acquire_output())
+    assert count == 1, "a camera move starts over"

@@ -555,3 +555,64 @@ def test_output_store_behaves_like_the_reference_handler(tmp_path, seed):
     if RECORD:
         _GOLDEN[key] = trace
         json.dump(_GOLDEN, open(GOLDEN_PATH, "w"), indent=0, sort_keys=True)
+
+
+# ---- which changes restart the integration: camera_check_for_dirty / settings_check_for_dirty ----
+def _leaf_fields(struct_type, prefix=()):
+    for name, typ in struct_type._fields_:
+        if hasattr(typ, "_fields_"):
+            yield from _leaf_fields(typ, prefix + (name,))
+        else:
+            yield prefix + (name,), typ
+
+
+def _poke(obj, path, typ):
+    for p in path[:-1]:
+        obj = getattr(obj, p)
+    old = getattr(obj, path[-1])
+    if typ is C.c_bool:
+        new = not old
+    elif typ in (C.c_float, C.c_double):
+        new = old + 0.25
+    else:
+        new = old + 1
+    setattr(obj, path[-1], new)
+
+
+def test_only_integration_changes_restart_the_accumulation():
+    """Every field of the camera and of the renderer settings is changed on its own, under every condition the reference's rules look at
+    (bladed aperture, physical camera, custom AgX curve, colour correction, adaptive sampling on, a debug shading mode): the change
+    restarts the accumulation exactly when the reference raises SCENE_DIRTY_FLAG_INTEGRATION (camera.c:80-147, settings.c:45-72)."""
+    INTEGRATION = 0x40000000
+    lib = luminary_amd._lib()
+    lib.luminary_ext_change_restarts_integration.restype = C.c_uint64
+    host = luminary_amd.Host()
+    cases = []
+    for entity, typ, getter, conditions in [
+            (1, luminary_amd.Camera, host.get_camera, [{}, {"aperture_shape": 1}, {"use_physical_camera": True}, {"tonemap": 6}, {"use_color_correction": True}]),
+            (0, luminary_amd.RendererSettings, host.get_settings, [{}, {"enable_adaptive_sampling": False}, {"enable_adaptive_sampling": True}, {"shading_mode": 2}])]:
+        for cond in conditions:
+            for path, ftyp in _leaf_fields(typ):
+                old, new = getter(), getter()
+                for k, v in cond.items():
+                    setattr(old, k, v)
+                    setattr(new, k, v)
+                _poke(new, path, ftyp)
+                cases.append((entity, typ, cond, path, old, new))
+
+    def live():
+        r = ref()
+        out = []
+        for entity, typ, cond, path, old, new in cases:
+            fn = r.camera_check_for_dirty if entity == 1 else r.settings_check_for_dirty
+            fn.restype = C.c_uint64
+            flags = C.c_uint32(0)
+            assert fn(C.byref(new), C.byref(old), C.byref(flags)) == 0
+            out.append(bool(flags.value & INTEGRATION))
+        return out
+    want = reference_value("restarts_integration", live)
+    assert len(want) == len(cases) > 250 and any(want) and not all(want)
+    for (entity, typ, cond, path, old, new), w in zip(cases, want):
+        got = C.c_bool()
+        assert lib.luminary_ext_change_restarts_integration(entity, C.byref(new), C.byref(old), C.byref(got)) == 0
+        assert got.value == w, (typ.__name__, cond, ".".join(path), "reference:", w)
