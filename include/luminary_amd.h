@@ -372,6 +372,9 @@ LUMINARY_API LuminaryResult luminary_ext_add_material(LuminaryHost* host, const 
 /* Whether replacing `old` by `input` restarts the integration (camera.c:80-147, settings.c:45-72) or only changes the outputs.
  * entity 0: LuminaryRendererSettings, 1: LuminaryCamera. luminary_host_set_camera / set_settings apply this rule. */
 LUMINARY_API LuminaryResult luminary_ext_change_restarts_integration(int entity, const void* input, const void* old, bool* restarts);
+/* The path of a file named inside `base_file` (mesh files of a .lum, material libraries of an .obj, maps of an .mtl): path_extend +
+ * path_apply of src/luminary/path.c */
+LUMINARY_API LuminaryResult luminary_ext_path_extend(const char* base_file, const char* name, char* out, size_t out_size);
 /* rotation_euler_angles_to_quaternion (src/luminary/host_math.c:6-21), x y z w */
 LUMINARY_API LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float quaternion[4]);
 LUMINARY_API LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const struct LumDeviceSceneView** view);

@@ -239,13 +239,11 @@ LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* pat
   std::vector<std::string> warnings;
   std::string err;
   if (!lum::load_lum_v4(path->value, &content, &warnings, &err)) { std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
-  const size_t slash = path->value.find_last_of("/\\");
-  const std::string dir = slash == std::string::npos ? std::string() : path->value.substr(0, slash + 1);
   for (const std::string& obj : content.obj_files) {
     lum::HostMesh mesh;
     std::vector<LuminaryMaterial> mats;
     std::vector<lum::HostTexture> textures;
-    if (!lum::load_obj(dir + obj, content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err, &textures, (uint32_t) host->scene.textures.size())) {
+    if (!lum::load_obj(lum::extend_path(path->value, obj), content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err, &textures, (uint32_t) host->scene.textures.size())) {
       std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
       return LUMINARY_ERROR_API_EXCEPTION;
     }
@@ -738,6 +736,14 @@ LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float q
   CHECK_NULL(rotation); CHECK_NULL(quaternion);
   LuminaryVec3 r; r.x = rotation[0]; r.y = rotation[1]; r.z = rotation[2];
   lum::euler_to_quaternion(r, quaternion);
+  return LUMINARY_SUCCESS;
+}
+// path_extend + path_apply (path.c) as the loaders use it; exposed for the check against the reference
+LuminaryResult luminary_ext_path_extend(const char* base_file, const char* name, char* out, size_t out_size) {
+  CHECK_NULL(base_file); CHECK_NULL(name); CHECK_NULL(out);
+  const std::string r = lum::extend_path(base_file, name);
+  if (r.size() + 1 > out_size) return LUMINARY_ERROR_OUT_OF_MEMORY;
+  std::memcpy(out, r.c_str(), r.size() + 1);
   return LUMINARY_SUCCESS;
 }
 // 0: renderer settings, 1: camera. Exposed so that the rule can be checked against the reference's *_check_for_dirty.

@@ -28,6 +28,23 @@ std::string dirname_of(const std::string& p) {
   const size_t s = p.find_last_of("/\\");
   return s == std::string::npos ? std::string() : p.substr(0, s + 1);
 }
+}  // namespace
+
+// path_extend + path_apply (path.c:8-17, :60-115): a file named inside another file. An absolute name (leading '/', or a drive designator)
+// stands for itself; a relative one is looked up next to the file that names it, its directory part read with either separator.
+std::string extend_path(const std::string& base_file, const std::string& name) {
+  if (!name.empty() && (name[0] == '/' || name.find(':') != std::string::npos)) return name;
+  std::string rel = name;
+  const size_t last = rel.find_last_of("/\\");
+  if (last != std::string::npos)
+    for (size_t i = 0; i < last; i++)
+      if (rel[i] == '\\') rel[i] = '/';
+  if (last != std::string::npos && rel[last] == '\\') rel[last] = '/';
+  const size_t s = base_file.find_last_of("/\\");
+  return (s == std::string::npos ? std::string() : base_file.substr(0, s + 1)) + rel;
+}
+
+namespace {
 std::string trim(const std::string& s) {
   size_t a = 0, b = s.size();
   while (a < b && (s[a] == ' ' || s[a] == '\t')) a++;
@@ -172,8 +189,8 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
       for (auto& s : loaded_mtls) seen |= (s == name);
       if (!seen) {
         loaded_mtls.push_back(name);
-        if (!read_mtl(dirname_of(path) + name, args.emission_scale, &mats, err)) return false;
-        mtl_dir = dirname_of(dirname_of(path) + name);
+        if (!read_mtl(extend_path(path, name), args.emission_scale, &mats, err)) return false;
+        mtl_dir = dirname_of(extend_path(path, name));
       }
     }
     else if (line.compare(0, 6, "usemtl") == 0) {
@@ -218,7 +235,7 @@ bool load_obj(const std::string& path, const ObjLoadArgs& args, uint32_t materia
       if (id == 0xFFFF) {
         HostTexture tex;
         std::string terr;
-        if (!read_png(mtl_dir + w.map[k], &tex.width, &tex.height, &tex.gamma, &tex.texels, &terr)) { warnings->push_back("texture ignored: " + terr); continue; }
+        if (!read_png(extend_path(mtl_dir + "x", w.map[k]), &tex.width, &tex.height, &tex.gamma, &tex.texels, &terr)) { warnings->push_back("texture ignored: " + terr); continue; }
         if (texture_offset + textures_out->size() >= 0xFFFF) { warnings->push_back("Exceeded limit of 65535 textures."); continue; }
         textures_out->push_back(std::move(tex));
         texture_files.push_back(w.map[k]);

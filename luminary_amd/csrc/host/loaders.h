@@ -33,5 +33,8 @@ struct LumFileContent {
 };
 
 bool load_lum_v4(const std::string& path, LumFileContent* content, std::vector<std::string>* warnings, std::string* err);
+// A file named inside another file (path_extend + path_apply, path.c): absolute names stand for themselves, relative ones are looked up
+// next to the naming file, with either separator in their directory part.
+std::string extend_path(const std::string& base_file, const std::string& name);
 
 }  // namespace lum

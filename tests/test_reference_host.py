@@ -616,3 +616,28 @@ def test_only_integration_changes_restart_the_accumulation():
         got = C.c_bool()
         assert lib.luminary_ext_change_restarts_integration(entity, C.byref(new), C.byref(old), C.byref(got)) == 0
         assert got.value == w, (typ.__name__, cond, ".".join(path), "reference:", w)
+
+
+def test_files_named_inside_files_resolve_like_the_reference():
+    """path_extend + path_apply (path.c): where a .lum's mesh file, an .obj's material library, an .mtl's map is looked up."""
+    cases = [("/a/b/scene.lum", "mesh.obj"), ("/a/b/scene.lum", "sub/mesh.obj"), ("/a/b/scene.lum", "/x/y.obj"), ("scenes/s.lum", "m.obj"), ("s.lum", "m.obj"),
+             ("/a/b/scene.lum", "../up.obj"), ("/a/b/scene.lum", "sub\\\\win.obj".replace("\\\\", "\\")), ("/a/b/scene.lum", "one\\two/three.png"), ("rel/dir/o.obj", "tex/a.png")]
+
+    def live():
+        r = ref()
+        for f in ("luminary_path_create", "luminary_path_set_from_string", "path_extend", "path_apply"):
+            getattr(r, f).restype = C.c_uint64
+        out = []
+        for base, name in cases:
+            p, q, s = C.c_void_p(), C.c_void_p(), C.c_char_p()
+            assert r.luminary_path_create(C.byref(p)) == 0 and r.luminary_path_set_from_string(p, base.encode()) == 0
+            assert r.path_extend(C.byref(q), p, name.encode()) == 0 and r.path_apply(q, None, C.byref(s)) == 0
+            out.append(s.value.decode())
+        return out
+    want = reference_value("path_extend", live)
+    lib = luminary_amd._lib()
+    lib.luminary_ext_path_extend.restype = C.c_uint64
+    for (base, name), w in zip(cases, want):
+        buf = C.create_string_buffer(512)
+        assert lib.luminary_ext_path_extend(base.encode(), name.encode(), buf, C.c_size_t(512)) == 0
+        assert os.path.normpath(buf.value.decode()) == os.path.normpath(w), (base, name, buf.value, w)
