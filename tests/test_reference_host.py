@@ -350,17 +350,40 @@ Tf 1 1 1
 """
 
 
-def test_wavefront_files_load_like_the_reference(tmp_path):
-    (tmp_path / "scene.obj").write_text(OBJ)
-    (tmp_path / "scene.mtl").write_text(MTL)
+OBJ2 = ("# n-gons, four-component vertices, three-component texture coordinates, unnormalised normals, negative indices\n"
+        "mtllib scene.mtl\n"
+        "o six\n"
+        "v 0 0 0 1\nv 2 0 0\nv 3 1.5 0\nv 2 3 0\nv 0 3 0\nv -1 1.5 1e-1\n"
+        "vt 0 0 0\nvt 1 0 0\nvt 1 1 0\n"
+        "vn 0 0 2\n"
+        "usemtl glass\n"
+        "f 1/1/1 2/2/1 3/3/1 4/1/1 5/2/1 6/3/1\n"
+        "usemtl red\n"
+        "f 1 2 3\n"
+        "f 3/3 2/2 1/1\n"
+        "\n"
+        "f -6//-1 -4//-1 -2//-1\n"
+        "usemtl glow\n"
+        "f 1/4/2 2/5/3 3/6/4\n")
+# (the reference's reader wants exactly one space between tokens and no tabs or trailing blanks: "v\t2 0 0" is no vertex for it, "f  1  2  3" no
+# face, "f 3/3 2/2 1/1   " a quad with a vertex 0. Ours is more forgiving there; such lines are not part of the comparison.)
+MTL2 = ("newmtl red\nKd 0.8 0.1 0.1\nKs 0.6 0.6 0.6\nNs 10\n"
+        "newmtl glow\nKd 0.5 0.5 0.5\nKe 1 0 0\nd 0.5\nNi 1.33\n"
+        "newmtl glass\nKd 1 1 1\nNs 1000\nd 0\n")
+
+
+@pytest.mark.parametrize("variant", ["syntax", "ngons"])
+def test_wavefront_files_load_like_the_reference(tmp_path, variant):
+    (tmp_path / "scene.obj").write_bytes((OBJ if variant == "syntax" else OBJ2).encode())
+    (tmp_path / "scene.mtl").write_bytes((MTL if variant == "syntax" else MTL2).encode())
     def live():
         args = _WavefrontArguments(False, False, 1.0, False)
         ref().wavefront_arguments_get_default.restype = C.c_uint64
         assert ref().wavefront_arguments_get_default(C.byref(args)) == 0
         return _ref_wavefront(str(tmp_path / "scene.obj"), args)
-    verts, normals, uvs, tris, mats = _unpack_wavefront(reference_value("wavefront", live))
+    verts, normals, uvs, tris, mats = _unpack_wavefront(reference_value("wavefront" if variant == "syntax" else "wavefront/" + variant, live))
     want_pos, want_uv, want_mat, want_nrm = _expected_mesh(verts, normals, uvs, tris)
-    assert len(want_pos) >= 8
+    assert len(want_pos) >= 4
 
     host = luminary_amd.Host()
     host.load_obj_file(str(tmp_path / "scene.obj"))
