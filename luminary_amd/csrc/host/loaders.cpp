@@ -419,7 +419,8 @@ bool load_lum_v4(const std::string& path, LumFileContent* content, std::vector<s
       if (std::strncmp(key, "EMISSION", 8) == 0) std::sscanf(value, "%f", &content->obj_args.emission_scale);
       else if (std::strncmp(key, "COLORTRA", 8) == 0) { std::sscanf(value, "%u", &u); content->obj_args.force_transparency_cutout = u != 0; }
       else if (std::strncmp(key, "IORSHADO", 8) == 0) {}
-      else if (std::strncmp(key, "INTERTRO", 8) == 0) { std::sscanf(value, "%u", &u); content->obj_args.legacy_smoothness = u != 0; }
+      // the constant the reference compares with spells INVERTRO (its comment says INTERTRO, lum_v4.c:125-129); found by the pin against lum_v4.c
+      else if (std::strncmp(key, "INVERTRO", 8) == 0) { std::sscanf(value, "%u", &u); content->obj_args.legacy_smoothness = u != 0; }
       else ok = false;
     }
     else if (c0 == 'C' && c1 == 'A') {

@@ -664,3 +664,35 @@ def test_files_named_inside_files_resolve_like_the_reference():
         buf = C.create_string_buffer(512)
         assert lib.luminary_ext_path_extend(base.encode(), name.encode(), buf, C.c_size_t(512)) == 0
         assert os.path.normpath(buf.value.decode()) == os.path.normpath(w), (base, name, buf.value, w)
+
+
+@pytest.mark.parametrize("lines", [["MATERIAL EMISSION 2.5", "MATERIAL INVERTRO 1", "MATERIAL COLORTRA 1"], ["MATERIAL EMISSION 0.125", "MATERIAL INVERTRO 0"],
+                                   ["MATERIAL INTERTRO 1"], []])
+def test_legacy_material_lines_reach_the_mesh_files_like_in_the_reference(tmp_path, lines):
+    """MATERIAL lines of a .lum v4 (lum_v4.c:76-140) become the arguments its mesh files are converted with (wavefront.c:783-821). The
+    reference parses the file without its MESHFILE line here (that line calls into mesh.c, which is not buildable)."""
+    head = "Luminary\nVERSION 4\n" + "".join(l + "\n" for l in lines)
+    (tmp_path / "args.lum").write_text(head)
+    (tmp_path / "scene.lum").write_text(head + "GENERAL MESHFILE scene.obj\n")
+    (tmp_path / "scene.obj").write_text("mtllib scene.mtl\no tri\nv 0 0 0\nv 1 0 0\nv 0 1 0\nusemtl glow\nf 1 2 3\n")
+    (tmp_path / "scene.mtl").write_text("newmtl glow\nKd 0.5 0.5 0.5\nKe 1 2 3\nNs 400\n")
+
+    def live():
+        r = ref()
+        s = sizes()
+
+        class Content(C.Structure):
+            _fields_ = [("obj_paths", C.c_void_p), ("wavefront_args", _WavefrontArguments)] + [(n, C.c_uint8 * s[n]) for n in ENTITIES] + [("instances", C.c_void_p)]
+        for f in ("lum_content_create", "lum_read_file", "luminary_path_create", "luminary_path_set_from_string"):
+            getattr(r, f).restype = C.c_uint64
+        content, p = C.POINTER(Content)(), C.c_void_p()
+        assert r.lum_content_create(C.byref(content)) == 0 and r.luminary_path_create(C.byref(p)) == 0
+        assert r.luminary_path_set_from_string(p, str(tmp_path / "args.lum").encode()) == 0 and r.lum_read_file(p, content) == 0
+        a = content.contents.wavefront_args
+        return [bool(a.legacy_smoothness), bool(a.force_transparency_cutout), float(a.emission_scale), bool(a.force_bidirectional_emission)]
+    smooth, cutout, scale, bidirectional = reference_value("lum_v4_material_args/" + "|".join(lines), live)
+    host = luminary_amd.Host()
+    host.load_lum_file(str(tmp_path / "scene.lum"))
+    m = host.get_material(1)
+    assert (bool(m.roughness_as_smoothness), m.emission_scale, bool(m.bidirectional_emission)) == (smooth, scale, bidirectional)
+    assert (m.emission.r, m.emission.g, m.emission.b) == (np.float32(1 * scale), np.float32(2 * scale), np.float32(3 * scale)), "Ke is scaled while reading (wavefront.c:385-396)"
