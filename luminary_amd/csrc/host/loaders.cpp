@@ -324,7 +324,7 @@ const KeyDesc kSkyKeys[] = {
   {"S", "MIEFALLO", kF32, OFF(LuminarySky, mie_falloff), 0, 0}, {"S", "GROUNDVI", kF32, OFF(LuminarySky, ground_visibility), 0, 0},
   {"S", "DIAMETER", kF32, OFF(LuminarySky, mie_diameter), 0, 0}, {"S", "OZONETHI", kF32, OFF(LuminarySky, ozone_layer_thickness), 0, 0},
   {"S", "MSFACTOR", kF32, OFF(LuminarySky, multiscattering_factor), 0, 0}, {"S", "AERIALPE", kBool, OFF(LuminarySky, aerial_perspective), 0, 0},
-  {"S", "HDRISAMP", kU32, OFF(LuminarySky, hdri_samples), 0, 0}, {"S", "HDRIORIG", kIgnore, 0, 0, 0},
+  {"S", "HDRISAMP", kU32, OFF(LuminarySky, hdri_samples), 0, 0}, {"S", "HDRIORIG", kIgnore, 0, 0, 0}, {"S", "HDRIMIPB", kIgnore, 0, 0, 0},
   {"S", "COLORCON", kF32x3, OFF(LuminarySky, constant_color.r), OFF(LuminarySky, constant_color.g), OFF(LuminarySky, constant_color.b)}};
 #define CLOUD_LAYER(P, L)                                                                                                            \
   {"CL", P "ACTIV", kBool, OFF(LuminaryCloud, L.active), 0, 0},                                                                       \
