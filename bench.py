@@ -2,7 +2,12 @@
 """Benchmark of the MI355X path-tracing core on BASELINE.json's metric (Mrays/s at 1920x1080, 8 bounces).
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...)
+  N > 1 without a torchrun environment: bench.py starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+  127.0.0.1 --master-port P bench.py ...` as a CHILD (before anything touches the GPU) and exits with its code.
+
+Headline workload = the scene the north-star target is quoted on: the 1 M-triangle Sponza-class hall (BASELINE config 3). At N = 1 the
+Example-class scene (config 2) and the 10 M-triangle scan (config 5's scene) are timed after it and reported under "secondary" in the
+same JSON line (`--secondary none` skips them).
 
 Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x1080 frame through all 9 depth passes (8 bounces) for
          --samples-per-pass (default 8) x N sample ids, i.e. 1920*1080*8 paths per GPU and step whatever N is (weak scaling: the
@@ -11,10 +16,23 @@ Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md 
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
 Prints ONE JSON line on rank 0.
+
+roofline: for the dominant ray kernel
+  achieved_algorithmic = (nodes*112 + triangles*48 + rays*40) / kernel time   SURVEY §8d's formula, counted in the kernel. Most of these
+                         bytes are served by LDS/L1/L2, so this is NOT an HBM rate and no fraction of the HBM peak is derived from it.
+  traffic              = memory-side bytes per launch of that kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+                         same command and workload (profiles/pmc_counters.json, written by tools/pmc_collect.py; the factor applied to
+                         FETCH_SIZE for this access pattern is calibrated by tools/microbench/fetch_calib.hip and stored in the file)
+  achieved, frac       = traffic / average launch time, and that over the 8 TB/s HBM peak: the HBM-side figure. null without a PMC
+                         record for the workload.
+  l2                   = L2 request bytes per launch (TCP_TCC_READ_REQ x 64 B... see the file) over the aggregate L2 bandwidth
+and "valu" for k_shade (the longest kernel): wave-level VALU instructions per launch / time against the chip's VALU issue peak.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,41 +41,54 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave instruction = 1228.8 G/s
 NODE_BYTES, TRI_BYTES = 112, 48  # one node visit fetches 7 x 16 B of a 128-B BVH4 node; triangle = 48 B (DESIGN.md "Algorithmic bytes")
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
 IO_SHADOW_BYTES = 24 + 4 + 12  # origin+dir, tmax, RGB visibility
-TRAFFIC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
+from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402  (numpy only at import time)
 
-def measured_traffic(workload, kernel, spp_per_step):
-    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 --pmc pass of this same command (tools/pmc_traffic.py
-    writes profiles/pmc_traffic.json; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE)."""
-    try:
-        with open(TRAFFIC_FILE) as f:
-            t = json.load(f)
-        e = t[workload][kernel]
-        if int(e["spp_per_step"]) != int(spp_per_step):
-            return None
-        return float(e["bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
-
-
-from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402
+WORKLOADS = {
+    "example": "C2 Example-class scene (~100k triangles, 72 instances, 16 emissive quads)",
+    "hall": "C3 Sponza-class hall (1.43M triangles, one mesh, 32 emissive panels)",
+    "scan": "C5 scanned-object class (10.03M-triangle displaced icosphere, ground, 8 area lights)",
+    "scan5m": "scanned-object class at 5.2M triangles (round-1 size)",
+    "cornell": "C1 Cornell box (36 triangles)",
+}
 
 
 def build_workload(name, width, height, bounces):
     from luminary_amd import scenes
     if name == "example":
-        return scenes.example_scene(width, height, bounces), "C2 Example-class scene (~100k triangles, 72 instances, 16 emissive quads)"
+        return scenes.example_scene(width, height, bounces)
     if name == "hall":
-        return scenes.hall_scene(width, height, bounces), "C3 Sponza-class hall (1M triangles, one mesh, 32 emissive panels)"
+        return scenes.hall_scene(width, height, bounces)
     if name == "scan":
-        return scenes.scan_scene(width, height, bounces), "C5 scanned-object class (5.2M-triangle displaced icosphere, 8 area lights)"
+        return scenes.scan_scene(width, height, bounces, triangles=10_000_000)
+    if name == "scan5m":
+        return scenes.scan_scene(width, height, bounces)
     if name == "cornell":
-        return scenes.cornell_host("/tmp/lum_bench_cornell", width, height, bounces), "C1 Cornell box (36 triangles)"
+        return scenes.cornell_host("/tmp/lum_bench_cornell", width, height, bounces)
     raise SystemExit("unknown workload " + name)
+
+
+def pmc_record(workload, spp_per_step, flavour):
+    """Per-kernel counter record of this workload from the committed PMC passes (None when there is none for this configuration)."""
+    try:
+        with open(PMC_FILE) as f:
+            t = json.load(f)
+        e = t["workloads"][workload]
+        if int(e["spp_per_step"]) != int(spp_per_step) or e.get("flavour", "exact") != flavour:
+            return None
+        e = dict(e)
+        e["_source"] = "profiles/pmc_counters.json (%s)" % t.get("collected", "rocprofv3 --pmc passes of this command")
+        e["_fetch_factor"] = t.get("fetch_size_factor")
+        return e
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(view, budget_s):
@@ -103,49 +134,39 @@ def cpu_baseline(view, budget_s):
     except OSError:
         pass
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu": model,
+            "note": "unoptimised test oracle (scalar C restatement written for bit-exact checking, not for speed): a reported baseline, not a target",
             "sample": "oracle/ (CPU restatement, OpenMP over pixels, %d threads) on %d pixels x %d spp of the same frame, all 9 depth passes: "
                       "%.0f rays in %.1f s (its %.1f s BVH build excluded)" % (cores, npx, spp, rays, dt, t_build)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="example")
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
-    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
-    ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
-                    help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")
-    args = ap.parse_args()
+def spawn_distributed(n):
+    """`bench.py --gpus N` outside a torchrun environment: run the N-rank job as a child process and return its exit code. Nothing in
+    this process has touched the GPU yet (no torch.cuda call, no HIP library loaded)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
+
+def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output_chain):
+    """Uploads workload `name`, times `steps` passes after `warmup` untimed ones (barrier + synchronize on both sides, max over ranks) and
+    returns (json dict, device scene view)."""
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-
-    from luminary_amd.core import Core, CNT_LIGHT_BVH, CNT_NODES, CNT_SHADOW, CNT_TRACE, CNT_TRIS
-    host, workload_name = build_workload(args.workload, args.width, args.height, args.bounces)
+    from luminary_amd.core import CNT_LIGHT_BVH, CNT_NODES, CNT_SHADOW, CNT_TRACE, CNT_TRIS, CNT_VERTICES
+    t_build = time.time()
+    host = build_workload(name, args.width, args.height, args.bounces)
+    label = WORKLOADS[name]
     if args.sky == "procedural":
         sky = host.get_sky()
         sky.mode = 0
         host.set_sky(sky)
-        workload_name += " under the procedural sky (mode DEFAULT)"
+        label += " under the procedural sky (mode DEFAULT)"
     view = host.device_scene()
-    core = Core(local_rank)
+    build_s = time.time() - t_build
     t_up = time.time()
     core.upload(view)  # builds the BVHs, generates the BSDF tables on the GPU
     upload_s = time.time() - t_up
@@ -155,13 +176,12 @@ def main():
     fm = torch.zeros(3 * P, dtype=torch.float32, device="cuda")
     sm = torch.zeros(P, dtype=torch.float32, device="cuda")
     stream = torch.cuda.current_stream().cuda_stream
-
     spp_step = args.samples_per_pass * world  # per-GPU paths per step stay W*H*samples_per_pass
 
     def step(i):
         core.render(i * spp_step, spp_step, spp_step, fm.data_ptr(), sm.data_ptr(), stream)
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         step(i)
     if dist is not None:
         assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)  # untimed: creates the RCCL communicator and its buffers
@@ -173,8 +193,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.time()
-    for i in range(args.steps):
-        step(args.warmup + i)
+    for i in range(steps):
+        step(warmup + i)
     if dist is not None:
         # assemble the frame on rank 0: every rank scatters its pixels into a zero frame, one reduce over xGMI
         assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)
@@ -186,14 +206,17 @@ def main():
 
     cnt = core.counters()
     times = core.kernel_times()
+    core.set_profiling(False)
     # output chain (tone map + ARGB8 of the frame just rendered), outside the timed region: streaming kernels, 40 B/pixel algorithmic
     output_chain = None
-    if world == 1:
+    if want_output_chain and world == 1:
         from luminary_amd.core import default_output_params
-        op = default_output_params(view.width, view.height, max(spp_step * (args.steps + args.warmup), 1))
+        core.set_profiling(True)
+        op = default_output_params(view.width, view.height, max(spp_step * (steps + warmup), 1))
         for _ in range(5):
             core.generate_output(op, fm.data_ptr())
         out_ms, out_n = core.kernel_times()["output"]
+        core.set_profiling(False)
         if out_n:
             per = out_ms / out_n
             output_chain = {"ms_per_frame": round(per, 4), "GB/s": round(40.0 * view.width * view.height / (per * 1e-3) / 1e9, 1),
@@ -207,37 +230,128 @@ def main():
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         elapsed = float(mx[4])
     rays_total = float(stats[0])
-    if rank != 0:
-        return
+    del fm, sm
 
-    # roofline of the dominant traversal kernel on rank 0: algorithmic bytes = nodes*128 + triangles*48 + per-ray I/O
-    trace_ms, trace_n = times["trace"]
-    shadow_ms, shadow_n = times["shadow"]
+    # ---- rooflines (rank 0's kernels) ----
+    pmc = pmc_record(name, args.samples_per_pass, core.flavour) if world == 1 else None
     nodes_trace, tris_trace, nodes_shadow, tris_shadow = cnt[CNT_NODES], cnt[CNT_TRIS], cnt[6], cnt[7]
-    bytes_trace = nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES
-    bytes_shadow = nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES
-    dominant = "trace" if trace_ms >= shadow_ms else "shadow"
-    dom_bytes, dom_ms, dom_n = (bytes_trace, trace_ms, trace_n) if dominant == "trace" else (bytes_shadow, shadow_ms, shadow_n)
-    achieved = dom_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_" + dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": measured_traffic(args.workload, "k_trace" if dominant == "trace" else "k_shadow_rays", args.samples_per_pass) if world == 1 else None, "avg_launch_ms": dom_ms / max(dom_n, 1), "launches": dom_n,
-                "algorithmic_bytes_per_launch": dom_bytes / max(dom_n, 1)}
-    # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
-    cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1 and args.sky == "constant") else None
+    alg = {"trace": nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES,
+           "shadow": nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES}
+    pmc_name = {"trace": "k_trace", "shadow": "k_shadow_rays", "shade": "k_shade"}
+
+    def ray_roofline(k):
+        ms, n = times[k]
+        avg_ms = ms / max(n, 1)
+        r = {"bound": "hbm", "kernel": pmc_name[k], "launches": n, "avg_launch_ms": avg_ms, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+             "achieved_algorithmic": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "algorithmic_bytes_per_launch": alg[k] / max(n, 1),
+             "achieved": None, "frac": None, "traffic": None, "l2": None}
+        e = pmc.get(pmc_name[k]) if pmc else None
+        if e and avg_ms > 0:
+            r["traffic"] = e["bytes_per_launch"]
+            r["traffic_fetch"], r["traffic_write"] = e["fetch_bytes_per_launch"], e["write_bytes_per_launch"]
+            # the PMC passes ran the same passes (same sample ids) as this run's steps: bytes per launch carry over, time is this run's
+            r["achieved"] = e["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            r["frac"] = r["achieved"] / HBM_PEAK_GBPS
+            if e.get("l2_read_bytes_per_launch"):
+                l2 = e["l2_read_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+                r["l2"] = {"achieved": l2, "peak": L2_PEAK_GBPS, "frac": l2 / L2_PEAK_GBPS, "hit_rate": e.get("l2_hit_rate"), "unit": "GB/s"}
+            r["traffic_source"], r["fetch_size_factor"] = pmc["_source"], pmc["_fetch_factor"]
+        return r
+
+    def valu_roofline(k):
+        ms, n = times[k]
+        avg_ms = ms / max(n, 1)
+        r = {"bound": "valu", "kernel": pmc_name[k], "launches": n, "avg_launch_ms": avg_ms, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+             "achieved": None, "frac": None, "vertices_per_launch": cnt[CNT_VERTICES] / max(n, 1)}
+        e = pmc.get(pmc_name[k]) if pmc else None
+        if e and e.get("valu_insts_per_launch") and avg_ms > 0:
+            r["achieved"] = e["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
+            r["frac"] = r["achieved"] / VALU_PEAK_GINST
+            r["valu_insts_per_launch"] = e["valu_insts_per_launch"]
+            r["lane_utilisation"] = e.get("valu_lane_utilisation")
+            r["valu_insts_per_vertex_lane"] = e["valu_insts_per_launch"] * 64.0 * (e.get("valu_lane_utilisation") or 0.0) / max(r["vertices_per_launch"], 1.0)
+            r["traffic_source"] = pmc["_source"]
+        return r
+
+    dominant_ray = "trace" if times["trace"][0] >= times["shadow"][0] else "shadow"
+    roofline = ray_roofline(dominant_ray)
+    other = ray_roofline("shadow" if dominant_ray == "trace" else "trace")
+    shade = valu_roofline("shade")
+    total_ms = sum(v[0] for v in times.values()) or 1.0
     out = {
-        "metric": "Mrays/s at 1920x1080, 8 bounces", "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic",
-        "config": {"workload": workload_name, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth,
+        "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
+        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
-                   "samples_per_s": view.width * view.height * spp_step * args.steps / elapsed,
+                   "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2),
                                      "lds_hit_rate_closest": round(cnt[10] / max(nodes_trace, 1), 3), "lds_hit_rate_shadow": round(cnt[11] / max(nodes_shadow, 1), 3)},
-                   "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()}, "output_chain_rank0": output_chain, "scene_upload_s": round(upload_s, 2)},
-        "roofline": roofline, "cpu_baseline": cpu,
+                   "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()},
+                   "kernel_share_rank0": {k: round(v[0] / total_ms, 3) for k, v in times.items() if v[0] > 0},
+                   "output_chain_rank0": output_chain, "scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2)},
+        "roofline": roofline, "roofline_other_ray_kernel": other, "roofline_shade": shade,
     }
+    return out, view
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="hall", choices=sorted(WORKLOADS))
+    ap.add_argument("--secondary", default="example,scan", help="workloads timed after the headline at N = 1 and reported under 'secondary' ('none' skips them)")
+    ap.add_argument("--secondary-steps", type=int, default=4)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--bounces", type=int, default=8)
+    ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
+    ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
+    ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
+                    help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_distributed(args.gpus))
+    if args.gpus != world:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from luminary_amd.core import Core
+    core = Core(local_rank)
+    if args.flavour:
+        core.set_flavour(args.flavour)
+    head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True)
+    # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
+    cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1 and args.sky == "constant" and rank == 0) else None
+    secondary = {}
+    if world == 1 and args.secondary != "none":
+        for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
+            sec, _ = run_workload(core, name, args, rank, world, None, args.secondary_steps, 1, False)
+            secondary[name] = sec
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
+    out = {"metric": "Mrays/s at 1920x1080, 8 bounces", "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": head["config"], "roofline": head["roofline"], "roofline_other_ray_kernel": head["roofline_other_ray_kernel"], "roofline_shade": head["roofline_shade"],
+           "cpu_baseline": cpu, "secondary": secondary or None}
     print(json.dumps(out))
 
 

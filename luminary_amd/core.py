@@ -69,6 +69,18 @@ class Core:
             raise CoreError("lumc_context_create failed (no CPU fallback exists): " + msg)
         self.num_pixels = 0
 
+    @property
+    def flavour(self):
+        """'fast' or 'exact': the arithmetic flavour of the wavefront kernels this context launches (lumc_get_flavour)."""
+        fn = getattr(self._lib, "lumc_get_flavour", None)
+        if fn is None:
+            return "exact"
+        fn.restype = C.c_int
+        return "fast" if fn(self._ctx) == 1 else "exact"
+
+    def set_flavour(self, name):
+        self._call("lumc_set_flavour", C.c_int({"exact": 0, "fast": 1}[name]))
+
     def _call(self, name, *args):
         fn = getattr(self._lib, name)
         fn.restype = C.c_int

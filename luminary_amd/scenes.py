@@ -336,16 +336,48 @@ def _icosphere(level):
     return tri
 
 
-def scan_scene(width=1920, height=1080, bounces=8, seed=3, level=9):
-    """Displaced icosphere: 20 * 4**level triangles (level 9 = 5.2 M, level 10 = 21 M) plus ground and 8 area lights."""
+def _icosphere_frequency(n, indexed=False):
+    """Icosphere by frequency subdivision: every face of the icosahedron becomes n*n triangles (20*n*n in all), vertices pushed to the
+    unit sphere. Unlike the recursive 4-way split this reaches any size, e.g. n = 708 -> 10.03 M triangles.
+    indexed=True returns (points [20*G, 3], triangles [20*n*n, 3] indices) with G = (n+1)(n+2)/2 grid points per face."""
+    base = _icosphere(0)  # [20, 3, 3]
+    i, j = np.meshgrid(np.arange(n + 1), np.arange(n + 1), indexing="ij")
+    inside = (i + j) <= n
+    gid = np.full((n + 1, n + 1), -1, dtype=np.int64)
+    gid[inside] = np.arange(int(inside.sum()))
+    gi, gj = i[inside].astype(np.float64), j[inside].astype(np.float64)
+    wb, wc = gi / n, gj / n
+    wa = 1.0 - wb - wc
+    G = gi.size
+    pts = np.empty((20, G, 3), dtype=np.float64)
+    for f in range(20):
+        a, b, c = base[f]
+        pts[f] = wa[:, None] * a + wb[:, None] * b + wc[:, None] * c
+    pts /= np.sqrt((pts * pts).sum(axis=2, keepdims=True))
+    up = (i + j) <= n - 1          # (i,j) (i+1,j) (i,j+1)
+    down = (i + j) <= n - 2        # (i+1,j) (i+1,j+1) (i,j+1)
+    iu, ju, idn, jdn = i[up], j[up], i[down], j[down]
+    tri = np.concatenate([np.stack([gid[iu, ju], gid[iu + 1, ju], gid[iu, ju + 1]], 1),
+                          np.stack([gid[idn + 1, jdn], gid[idn + 1, jdn + 1], gid[idn, jdn + 1]], 1)], 0)  # [n*n, 3]
+    tris = (tri[None, :, :] + (np.arange(20) * G)[:, None, None]).reshape(-1, 3)
+    pts = pts.reshape(-1, 3)
+    return (pts, tris) if indexed else pts[tris]
+
+
+def scan_scene(width=1920, height=1080, bounces=8, seed=3, level=9, triangles=None):
+    """Displaced icosphere plus ground and 8 area lights. `level`: 20 * 4**level triangles by recursive splitting (level 9 = 5.2 M);
+    `triangles`: at least that many by frequency subdivision (10_000_000 -> 20 * 708**2 = 10.03 M, BASELINE config 5's size)."""
     rng = np.random.RandomState(seed)
     host = Host()
     apply_benchmark_settings(host, width, height, bounces, sky=(0.8, 0.85, 1.0))
     clay = host.add_material(_material((0.75, 0.6, 0.5), 0.3))
     ground_mat = host.add_material(_material((0.5, 0.5, 0.5), 0.7))
     light_mat = host.add_material(_material((0.8, 0.8, 0.8), 0.7, emission=(40.0, 36.0, 30.0)))
-    tri = _icosphere(level)
-    p = tri.reshape(-1, 3)
+    index = None
+    if triangles:
+        p, index = _icosphere_frequency(int(math.ceil(math.sqrt(triangles / 20.0))), indexed=True)  # displace the grid points once, not per corner
+    else:
+        p = _icosphere(level).reshape(-1, 3)
     disp = np.zeros(len(p))
     freq, amp = 1.5, 0.25
     for _ in range(6):
@@ -357,6 +389,8 @@ def scan_scene(width=1920, height=1080, bounces=8, seed=3, level=9):
         amp *= 0.5
     p = p * (10.0 * (1.0 + 0.15 * disp))[:, None]
     p[:, 1] += 11.0
+    if index is not None:
+        p = p.astype(np.float32)[index]
     pos = p.reshape(-1, 9).astype(np.float32)
     mid = host.add_mesh(pos, np.full(len(pos), clay, dtype=np.uint16))
     host.new_instance(mid)

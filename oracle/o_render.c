@@ -12,6 +12,7 @@
  * Quirk kept: the depth constant the sampler sees is not advanced before the last pass (device_renderer.c:126-130).
  * Out of scope: textures, volumes, ocean, particles, procedural sky/sun, physical camera.
  */
+#define _GNU_SOURCE /* qsort_r (o_trace.h) */
 #include <stdio.h>
 #include <stdlib.h>
 #ifdef _OPENMP

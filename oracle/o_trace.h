@@ -63,16 +63,23 @@ static inline OTri light_tri(const OracleScene* s, uint32_t light) {
 
 /* ---- BVH build (oracle's own: median split over the longest centroid axis, leaves <= 4) ---- */
 typedef struct { float c[3]; float lo[3], hi[3]; uint32_t id; } OBuildPrim;
-static int g_sort_axis;
-static int cmp_prim(const void* a, const void* b) {
-  const float x = ((const OBuildPrim*) a)->c[g_sort_axis], y = ((const OBuildPrim*) b)->c[g_sort_axis];
+static int cmp_prim(const void* a, const void* b, void* axis_) {
+  const int axis = *(const int*) axis_;
+  const float x = ((const OBuildPrim*) a)->c[axis], y = ((const OBuildPrim*) b)->c[axis];
   if (x < y) return -1;
   if (x > y) return 1;
   const uint32_t ia = ((const OBuildPrim*) a)->id, ib = ((const OBuildPrim*) b)->id;
   return (ia < ib) ? -1 : (ia > ib);
 }
-static uint32_t bvh_build_rec(OBvh* b, OBuildPrim* prims, uint32_t first, uint32_t count) {
-  const uint32_t idx = b->num_nodes++;
+/* nodes of the subtree over `count` primitives: the split is always count / 2, so the layout (node, left subtree, right subtree) is known
+   before anything is sorted and the two halves can be built by different threads */
+static uint32_t bvh_subtree_nodes(uint32_t count) {
+  if (count <= 4) return 1;
+  const uint32_t half = count / 2;
+  if (half == count - half) return 1 + 2 * bvh_subtree_nodes(half);
+  return 1 + bvh_subtree_nodes(half) + bvh_subtree_nodes(count - half);
+}
+static void bvh_build_rec(OBvh* b, OBuildPrim* prims, uint32_t first, uint32_t count, uint32_t idx) {
   OBvhNode n;
   float clo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, chi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
   for (int k = 0; k < 3; k++) { n.lo[k] = FLT_MAX; n.hi[k] = -FLT_MAX; }
@@ -87,18 +94,19 @@ static uint32_t bvh_build_rec(OBvh* b, OBuildPrim* prims, uint32_t first, uint32
     n.lo[k] -= pad; n.hi[k] += pad;
   }
   n.left = n.right = 0; n.first = first; n.count = 0;
-  if (count <= 4) { n.count = count; b->nodes[idx] = n; return idx; }
+  if (count <= 4) { n.count = count; b->nodes[idx] = n; return; }
   int axis = 0;
   if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
   if (chi[2] - clo[2] > chi[axis] - clo[axis]) axis = 2;
-  g_sort_axis = axis;
-  qsort(prims + first, count, sizeof(OBuildPrim), cmp_prim);
+  qsort_r(prims + first, count, sizeof(OBuildPrim), cmp_prim, &axis);
   const uint32_t half = count / 2;
+  n.left = idx + 1; n.right = idx + 1 + bvh_subtree_nodes(half);
   b->nodes[idx] = n;
-  const uint32_t l = bvh_build_rec(b, prims, first, half);
-  const uint32_t r = bvh_build_rec(b, prims, first + half, count - half);
-  b->nodes[idx].left = l; b->nodes[idx].right = r;
-  return idx;
+#pragma omp task default(shared) if (count > 65536)
+  bvh_build_rec(b, prims, first, half, n.left);
+#pragma omp task default(shared) if (count > 65536)
+  bvh_build_rec(b, prims, first + half, count - half, n.right);
+#pragma omp taskwait
 }
 static void bvh_build(OBvh* b, uint32_t count, OTri (*get)(const OracleScene*, uint32_t, uint32_t), const OracleScene* s, uint32_t mesh) {
   b->nodes = NULL; b->tri_ids = NULL; b->num_nodes = 0;
@@ -116,7 +124,10 @@ static void bvh_build(OBvh* b, uint32_t count, OTri (*get)(const OracleScene*, u
     prims[i].id = i;
   }
   b->nodes = (OBvhNode*) malloc(sizeof(OBvhNode) * (2 * (size_t) count));
-  bvh_build_rec(b, prims, 0, count);
+  b->num_nodes = bvh_subtree_nodes(count);
+#pragma omp parallel
+#pragma omp single
+  bvh_build_rec(b, prims, 0, count, 0);
   b->tri_ids = (uint32_t*) malloc(sizeof(uint32_t) * count);
   for (uint32_t i = 0; i < count; i++) b->tri_ids[i] = prims[i].id;
   free(prims);
