@@ -17,9 +17,19 @@ ROCM = os.environ.get("ROCM_PATH", "/opt/rocm")
 HIPCC = os.path.join(ROCM, "bin", "hipcc")
 
 HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp", "host/utils_api.cpp", "host/output.cpp"]
-HIP_SOURCES = ["host/core.hip", "host/lbvh.hip"]
 EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
-COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+EXACT = ["-ffp-contract=off", "-fno-fast-math"]  # the numerics contract of the exact flavour and of all host code
+# the fast flavour of the wavefront kernels (csrc/device/flavour.h): contraction, hardware reciprocal / sqrt, reciprocal-multiply for x / y
+FAST = ["-DLUM_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-math-errno"]
+# -fno-slp-vectorize: the SLP vectoriser packs neighbouring f32 multiplies/adds into v_pk_* and pays for it with register
+# moves (19 of the 61 instructions of a triangle test); same arithmetic, measured 2 % faster without it
+HIP_SOURCES = [("host/core.hip", EXACT), ("host/lbvh.hip", EXACT), ("device/wavefront_fast.hip", FAST)]
+STAMP = os.path.join(LIB_DIR, "build_flags.txt")
+
+
+def _flags_identity():
+    return "\n".join(["common " + " ".join(COMMON), "exact " + " ".join(EXACT), "fast " + " ".join(FAST), "extra " + " ".join(EXTRA)]) + "\n"
 
 
 def _newer(target, sources):
@@ -47,13 +57,18 @@ def _run(cmd):
 
 
 def build(force=False, verbose=False):
-    if not force and not _newer(LIB, _all_sources()):
+    # the effective flag list is part of the build's identity: a library left behind by a diagnostic build (LUM_CXXFLAGS=-DLUM_PHASE_STATS,
+    # an ablation ...) is rebuilt instead of being silently reused
+    stamp_ok = os.path.exists(STAMP) and open(STAMP).read() == _flags_identity()
+    if not force and stamp_ok and not _newer(LIB, _all_sources()):
         return LIB
     os.makedirs(OBJ_DIR, exist_ok=True)
+    if os.path.exists(STAMP):
+        os.remove(STAMP)
     objs = []
     for s in HOST_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
-        _run(["g++", *COMMON, "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, s), "-o", o])
+        _run(["g++", *COMMON, *EXACT, "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     bn = os.path.join(ROOT, "data", "bluenoise_2D.bin")
     o = os.path.join(OBJ_DIR, "embed.o")
@@ -62,17 +77,25 @@ def build(force=False, verbose=False):
     _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, "-DLUM_BLUENOISE_1D_PATH=\"%s\"" % bn1, "-DLUM_MOON_ALBEDO_PATH=\"%s\"" % moon[0],
           "-DLUM_MOON_NORMAL_PATH=\"%s\"" % moon[1], os.path.join(CSRC, "host", "embed.S"), "-o", o])
     objs.append(o)
-    for s in HIP_SOURCES:
-        o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
-        # -fno-slp-vectorize: the SLP vectoriser packs neighbouring f32 multiplies/adds into v_pk_* and pays for it with register
-        # moves (19 of the 61 instructions of a triangle test); same arithmetic, measured 2 % faster without it
-        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, "-fno-slp-vectorize", *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, s), "-o", o])
-        with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w" if s == HIP_SOURCES[0] else "a") as f:
-            f.write(out)
-        if verbose:
-            print(out)
-        objs.append(o)
+    from concurrent.futures import ThreadPoolExecutor
+
+    def compile_hip(item):
+        src, flags = item
+        o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, *flags, "-fno-slp-vectorize", *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", o])
+        return o, out
+
+    with ThreadPoolExecutor(max_workers=len(HIP_SOURCES)) as pool:
+        results = list(pool.map(compile_hip, HIP_SOURCES))
+    with open(os.path.join(OBJ_DIR, "kernel_resource_usage.txt"), "w") as f:
+        for (src, _), (o, out) in zip(HIP_SOURCES, results):
+            f.write("#### %s\n%s" % (src, out))
+            if verbose:
+                print(out)
+            objs.append(o)
     _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", LIB])
+    with open(STAMP, "w") as f:
+        f.write(_flags_identity())
     return LIB
 
 

@@ -18,20 +18,11 @@
 #include "dev_output.h"
 #include "kernels.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 constexpr uint32_t kAdaptiveBlockLog = 2;        // ADAPTIVE_SAMPLING_BLOCK_SIZE_LOG, device_utils.h:32
-constexpr uint32_t kAdaptiveStages = 4;          // ADAPTIVE_SAMPLER_NUM_STAGES, device_utils.h:331
 constexpr uint32_t kAdaptiveMaxRate = 256;       // ADAPTIVE_SAMPLING_MAX_SAMPLING_RATE, device_utils.h:35
 constexpr uint32_t kAdaptiveSumChunk = 256;      // blocks per partial sum of the variance total
-
-struct AdaptiveView {
-  const uint32_t* stage_counts;    // per block
-  const uint32_t* block_task_end;  // inclusive prefix sum over blocks of 16 * count(current stage); tasks of block b: [end[b-1], end[b])
-  uint32_t blocks_x, blocks_y, num_blocks;
-  uint32_t executions[kAdaptiveStages + 1];  // completed executions per stage (stage_sample_offsets)
-  uint32_t stage_id;
-};
 
 // samples per pixel and execution of `stage`: one in stage 0, the block's rate in stages 1..4
 LUM_DEV uint32_t adaptive_stage_count(uint32_t packed, uint32_t stage) { return stage ? ((packed >> ((stage - 1u) * 8u)) & 0xFFu) + 1u : 1u; }
@@ -60,6 +51,7 @@ LUM_DEV float adaptive_tonemap_compression(const OutputParams& op, Col color, fl
   return (ev > 0.0f) ? tv / ev : 1.0f;
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // adaptive_sampling_block_reduce_variance (adaptive_sampling.cuh:168-199): 16 lanes per block, four blocks per wave.
 __global__ __launch_bounds__(256) void k_adaptive_block_variance(AdaptiveView a, OutputParams op, uint32_t width, uint32_t height, float exposure,
                                                                 const float* __restrict__ fm, const float* __restrict__ sm, float* __restrict__ block_variance) {
@@ -84,7 +76,9 @@ __global__ __launch_bounds__(256) void k_adaptive_block_variance(AdaptiveView a,
   for (int off = 8; off > 0; off >>= 1) variance = fmaxf(variance, __shfl_xor(variance, off, 16));
   if ((t & 15u) == 0u && block < a.num_blocks) block_variance[block] = fabsf(variance);
 }
+#endif
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // Total of the block variances in a fixed order (see the header): one thread per chunk, then one thread over the chunk sums.
 __global__ __launch_bounds__(64) void k_adaptive_sum_chunks(const float* __restrict__ block_variance, uint32_t num_blocks, float* __restrict__ partial) {
   const uint32_t c = blockIdx.x * 64u + threadIdx.x;
@@ -95,13 +89,17 @@ __global__ __launch_bounds__(64) void k_adaptive_sum_chunks(const float* __restr
   for (uint32_t i = first; i < last; i++) s += block_variance[i];
   partial[c] = s;
 }
+#endif
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ void k_adaptive_sum_total(const float* __restrict__ partial, uint32_t num_chunks, float* __restrict__ total) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
   float s = 0.0f;
   for (uint32_t i = 0; i < num_chunks; i++) s += partial[i];
   *total = s;
 }
+#endif
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // adaptive_sampling_compute_stage_sample_counts (adaptive_sampling.cuh:201-221): the rate of the stage after `current_stage`.
 // Also writes the tasks of that stage per block (16 pixels x rate) for the prefix sum.
 __global__ __launch_bounds__(256) void k_adaptive_stage_counts(const float* __restrict__ block_variance, const float* __restrict__ total, uint32_t num_blocks,
@@ -123,11 +121,14 @@ __global__ __launch_bounds__(256) void k_adaptive_stage_counts(const float* __re
   // image-tile partition over GPUs: every rank knows every block's rate, but only creates tasks for the blocks it owns
   block_tasks[block] = (!block_mask || block_mask[block]) ? rate << (2u * kAdaptiveBlockLog) : 0u;
 }
+#endif
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // Tasks per block of a stage-0 execution under a partition (one sample per pixel of the owned blocks).
 __global__ __launch_bounds__(256) void k_adaptive_uniform_tasks(const uint8_t* __restrict__ block_mask, uint32_t num_blocks, uint32_t* __restrict__ block_tasks) {
   const uint32_t block = blockIdx.x * 256u + threadIdx.x;
   if (block < num_blocks) block_tasks[block] = block_mask[block] ? 1u << (2u * kAdaptiveBlockLog) : 0u;
 }
+#endif
 
 // tasks_create_adaptive_sampling (cuda/kernels.cuh:195-355): task -> (block, pixel of the block, sample of this execution).
 // Result slot = task id; paths are appended compacted (tasks outside the frame or beyond the last sample id create nothing).
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void k_adaptive_uniform_tasks(const uint8_t* _
 // `executions` consecutive executions of the stage share the pass: a pixel then takes executions * rate consecutive sample ids, which
 // are added in the same order as one execution after the other would add them. Task numbers are in units of the merged pass
 // (block_task_end * executions).
-struct AdaptivePass { uint32_t task_begin, task_end, block_begin, block_end, executions; };
+// (struct AdaptivePass: dev_scene.h)
 
 __global__ __launch_bounds__(256) void k_generate_adaptive(DeviceScene sc, AdaptiveView a, AdaptivePass pass, PathQueue q, float4* results, uint32_t* count) {
   const uint32_t lane = threadIdx.x & 63u;
@@ -187,6 +188,7 @@ __global__ __launch_bounds__(256) void k_generate_adaptive(DeviceScene sc, Adapt
   }
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // accumulation_collect_results for one adaptive execution: a pixel's samples of this execution are added in sample order.
 __global__ __launch_bounds__(256) void k_accumulate_adaptive(AdaptiveView a, AdaptivePass pass, uint32_t width, uint32_t height, const float4* __restrict__ results,
                                                             float* first_moment, float* second_moment) {
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(256) void k_accumulate_adaptive(AdaptiveView a, Ada
     second_moment[p] = s;
   }
 }
+#endif
 
 // accumulation_generate_result (cuda/accumulation.cuh:86-200): mean radiance (optionally with local error minimisation) or one of
 // the diagnostic images. With a null stage_counts every pixel has `uniform_samples` samples (adaptive sampling off).
@@ -231,6 +234,7 @@ LUM_DEV uint32_t result_pixel_samples(const AdaptiveView& a, const ResultParams&
   return a.stage_counts ? adaptive_pixel_samples(a, a.stage_counts[adaptive_block_of(a, x, y)]) : rp.uniform_samples;
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ __launch_bounds__(256) void k_generate_result(AdaptiveView a, ResultParams rp, OutputParams op, const float* __restrict__ fm, const float* __restrict__ sm,
                                                         float* __restrict__ frame_result) {
   const uint32_t n = rp.width * rp.height;
@@ -295,5 +299,6 @@ __global__ __launch_bounds__(256) void k_generate_result(AdaptiveView a, ResultP
     frame_result[index] = result.r; frame_result[n + index] = result.g; frame_result[2 * n + index] = result.b;
   }
 }
+#endif
 
-}  // namespace lum
+LUM_NS_END

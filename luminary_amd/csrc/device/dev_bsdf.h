@@ -10,7 +10,7 @@
 #include "dev_sampler.h"
 #include "dev_scene.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 enum DevMatFlag : uint32_t {  // device_structs.h:186-200
   kDMatSubstrateMask = 0x01, kDMatEmission = 0x02, kDMatMetallic = 0x08, kDMatColoredTransparency = 0x10,
@@ -526,4 +526,4 @@ LUM_DEV bool is_pass_through(const GeoContext& g, const BounceSample& s) {  // b
   return s.transparent_pass && ((g.params.ior() == 1.0f) || !s.microfacet_based);
 }
 
-}  // namespace lum
+LUM_NS_END

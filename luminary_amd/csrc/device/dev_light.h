@@ -6,7 +6,7 @@
 
 #include "dev_bsdf.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 constexpr uint32_t kLightTreeOutputs = 8;
 #ifndef LUM_ABLATE_LIGHT
@@ -349,4 +349,4 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
   return out;
 }
 
-}  // namespace lum
+LUM_NS_END

@@ -11,11 +11,16 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "flavour.h"
+
 #define LUM_DEV __device__ __forceinline__
 
 // Diagnostic build (-DLUM_PHASE_STATS, tools/phase_stats.py): how many lanes are active where. LUM_STAT(i, l) adds one to
 // g_phase[i] per wave-level execution and the number of active lanes to g_phase[l].
 #ifdef LUM_PHASE_STATS
+#if LUM_FAST
+#define g_phase g_phase_fast  // one counter block per flavour (two translation units in one library)
+#endif
 __device__ unsigned long long g_phase[16];
 #define LUM_STAT(k_iter, k_lanes) do { const unsigned long long act_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(act_)) { \
   atomicAdd(&g_phase[k_iter], 1ull); atomicAdd(&g_phase[k_lanes], (unsigned long long) __popcll(act_)); } } while (0)
@@ -23,7 +28,7 @@ __device__ unsigned long long g_phase[16];
 #define LUM_STAT(k_iter, k_lanes) do {} while (0)
 #endif
 
-namespace lum {
+LUM_NS_BEGIN
 
 struct V3 { float x, y, z; };
 struct Col { float r, g, b; };
@@ -45,10 +50,22 @@ LUM_DEV uint32_t f2u_sat(float v) {
   return (uint32_t) v;
 }
 LUM_DEV float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+#if LUM_FAST
+LUM_DEV float rsqrt_ieee(float x) { return __builtin_amdgcn_rsqf(x); }  // v_rsq_f32, 1 ulp (the reference: rsqrtf under --use_fast_math)
+#else
 LUM_DEV float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }
+#endif
 LUM_DEV float exp2i(int e) { return ldexpf(1.0f, e); }
 
 // sin/cos: Cody-Waite reduction by pi/2, minimax polynomials on [-pi/4, pi/4].
+#if LUM_FAST
+// fast flavour: the hardware's v_sin_f32 / v_cos_f32 on x / 2pi (what __sinf / __cosf are under --use_fast_math in the reference)
+LUM_DEV void sincos_det(float x, float& s_out, float& c_out) {
+  const float r = x * 0.15915494309189532f;
+  s_out = __builtin_amdgcn_sinf(r);
+  c_out = __builtin_amdgcn_cosf(r);
+}
+#else
 LUM_DEV void sincos_det(float x, float& s_out, float& c_out) {
   const float fj = rintf(x * 0.636619772367581343f);
   const int j    = (int) fj;
@@ -68,6 +85,7 @@ LUM_DEV void sincos_det(float x, float& s_out, float& c_out) {
   s_out = (q == 0) ? s : (q == 1) ? c : (q == 2) ? -s : -c;
   c_out = (q == 0) ? c : (q == 1) ? -s : (q == 2) ? -c : s;
 }
+#endif
 LUM_DEV float atan_pos(float x) {
   float y0;
   if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -1.0f / x; }
@@ -91,6 +109,10 @@ LUM_DEV float atan2_det(float y, float x) {
 
 // ---- log2 / exp2 / pow as fixed sequences (relative error < 3e-7), used where the reference calls log2f / powf ----
 // log2 for positive normal floats: exponent + 2*atanh((m-1)/(m+1)) / ln 2 with m in [sqrt(1/2), sqrt(2)).
+#if LUM_FAST
+LUM_DEV float log2_det(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+LUM_DEV float exp2_det(float x) { return __builtin_amdgcn_exp2f(fminf(fmaxf(x, -126.0f), 127.0f)); }  // v_exp_f32
+#else
 LUM_DEV float log2_det(float x) {
   const uint32_t bits = fbits(x);
   int e = (int) ((bits >> 23) & 0xFFu) - 127;
@@ -122,6 +144,7 @@ LUM_DEV float exp2_det(float x) {
   p = p * f + 1.0f;
   return ldexpf(p, (int) n);
 }
+#endif
 LUM_DEV float pow_det(float x, float y) { return (x > 0.0f) ? exp2_det(y * log2_det(x)) : 0.0f; }
 
 // ---- vectors (math.cuh:19-218) ----
@@ -312,4 +335,4 @@ LUM_DEV float ior_decompress(uint32_t c) { return ((bitsf(0x3F800000u | (c << 15
 LUM_DEV float medium_ior_peek(uint32_t stack, bool previous) { return ior_decompress((previous ? stack >> 8 : stack) & 0xFFu); }
 LUM_DEV uint32_t medium_ior_modify(uint32_t stack, float ior, bool push) { return push ? ((stack << 8) | ior_compress(ior)) : (stack >> 8); }
 
-}  // namespace lum
+LUM_NS_END

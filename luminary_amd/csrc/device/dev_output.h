@@ -11,7 +11,7 @@
 
 #include "dev_sampler.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 struct OutputParams {
   uint32_t src_width, src_height;  // rendered frame
@@ -182,6 +182,7 @@ LUM_DEV Col display_transform(const OutputParams& p, Col px, uint32_t x, uint32_
   return tonemap_curve(p, px);
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // generate_final_image, kernels.cuh:503-556 (with accumulation_generate_result's division by the sample count folded in): planar input
 // image of (src >> stage) pixels -> planar display-referred RGB of (src >> max(stage, supersampling)) pixels; every output pixel is the
 // mean of the output_scale^2 tone-mapped input pixels below it, summed row by row.
@@ -207,7 +208,9 @@ __global__ __launch_bounds__(256) void k_final_image(OutputParams p, const float
     frame_output[i] = color.r; frame_output[n + i] = color.g; frame_output[2 * n + i] = color.b;
   }
 }
+#endif
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // accumulation_generate_result_undersampling, accumulation.cuh:192-254: while the first sample is rendered coarse to fine, block (x, y) of
 // 2^stage pixels shows the mean of the 4 - iteration pixels of it that exist so far (pattern of kernels.cuh:20-45). Output: compact
 // planar image of (width >> stage) x (height >> stage).
@@ -228,6 +231,7 @@ __global__ __launch_bounds__(256) void k_result_undersampled(const float* __rest
     result[i] = sum.r; result[n + i] = sum.g; result[2 * n + i] = sum.b;
   }
 }
+#endif
 
 // post_sample_buffer_clamp, post_common.cuh:6-59. `width`/`height` are the nominal output size; a coarser image in memory is addressed
 // through mem_scale = 2^-k, whose index arithmetic the reference carries out in float (kept: it decides the rounding of the row offset).
@@ -270,6 +274,7 @@ LUM_DEV float sample_plane_border(const float* __restrict__ plane, float x, floa
   r += p11 * (fx * fy);
   return r * weight;
 }
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ __launch_bounds__(256) void k_post_downsample(const float* __restrict__ src, uint32_t sw, uint32_t sh, float* __restrict__ dst, uint32_t tw, uint32_t th) {
   const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
   const uint32_t n = tw * th;
@@ -294,6 +299,8 @@ __global__ __launch_bounds__(256) void k_post_downsample(const float* __restrict
     dst[i] = fmaxf(p, 0.0f);  // threshold 0 (device_post.c:82)
   }
 }
+#endif
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // dst may be the base image (every thread reads only its own base pixel)
 __global__ __launch_bounds__(256) void k_post_upsample(const float* __restrict__ src, uint32_t sw, uint32_t sh, float* dst, uint32_t tw, uint32_t th, float sa, float sb) {
   const float scale_x = 1.0f / (tw - 1), scale_y = 1.0f / (th - 1), step_x = 1.0f / (sw - 1), step_y = 1.0f / (sh - 1);
@@ -317,6 +324,7 @@ __global__ __launch_bounds__(256) void k_post_upsample(const float* __restrict__
     dst[i] = p + base;
   }
 }
+#endif
 
 LUM_DEV float dither_mask(const uint16_t* __restrict__ bluenoise_1d, uint32_t x, uint32_t y) { return unit_float16(bluenoise_1d[(x & 255u) + (y & 255u) * 256u]); }
 
@@ -355,6 +363,7 @@ LUM_DEV Col apply_filter(const OutputParams& p, const uint16_t* __restrict__ bn,
   }
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // convert_RGBF_to_ARGB8, kernels.cuh:558-644 (bytes b, g, r, a)
 __global__ __launch_bounds__(256) void k_to_argb8(OutputParams p, const float* __restrict__ frame_output, const uint16_t* __restrict__ bluenoise_1d,
                                                   uint32_t* __restrict__ dst) {
@@ -385,5 +394,6 @@ __global__ __launch_bounds__(256) void k_to_argb8(OutputParams p, const float* _
     dst[i] = 0xFF000000u | (f2u_sat(r) << 16) | (f2u_sat(g) << 8) | f2u_sat(b);
   }
 }
+#endif
 
-}  // namespace lum
+LUM_NS_END

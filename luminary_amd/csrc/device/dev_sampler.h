@@ -5,7 +5,7 @@
 
 #include "dev_math.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 // random.cuh:24-66 - every allocation skips one slot: START_next = START + count * sets + 1.
 enum RandomTarget : uint32_t {
@@ -65,4 +65,4 @@ struct Sampler {
   LUM_DEV float next1(uint32_t target) const { return unit_float(raw2(target).x); }
 };
 
-}  // namespace lum
+LUM_NS_END

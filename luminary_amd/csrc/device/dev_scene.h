@@ -121,6 +121,23 @@ struct ShadowQueue {
   uint32_t capacity;
 };
 
+// One wavefront pass over `batch` consecutive sample ids of `num_pixels` pixels (k_generate).
+struct PassParams {
+  const uint32_t* pixels;  // pixel index (x + y*width) per local pixel, or nullptr for identity
+  uint32_t num_pixels, batch, first_sample;
+};
+
+// Adaptive sampling bookkeeping shared by host and kernels (dev_adaptive.h).
+constexpr uint32_t kAdaptiveStages = 4;          // ADAPTIVE_SAMPLER_NUM_STAGES, device_utils.h:331
+struct AdaptiveView {
+  const uint32_t* stage_counts;    // per block
+  const uint32_t* block_task_end;  // inclusive prefix sum over blocks of 16 * count(current stage); tasks of block b: [end[b-1], end[b])
+  uint32_t blocks_x, blocks_y, num_blocks;
+  uint32_t executions[kAdaptiveStages + 1];  // completed executions per stage (stage_sample_offsets)
+  uint32_t stage_id;
+};
+struct AdaptivePass { uint32_t task_begin, task_end, block_begin, block_end, executions; };
+
 enum PathState : uint32_t {  // cuda/utils.cuh:114-121
   kStDeltaPath = 1, kStCameraDirection = 2, kStVolumeScattered = 4, kStAllowEmission = 8, kStAllowAmbient = 16, kStUseIgnoreHandle = 32
 };

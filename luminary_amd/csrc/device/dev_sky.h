@@ -13,7 +13,7 @@
 #include "dev_sampler.h"
 #include "dev_scene.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 constexpr float kSkyEarthRadius = 6371.0f, kSkySunRadius = 696340.0f, kSkySunDistance = 149597870.0f, kSkyAtmoHeight = 100.0f;  // sky_defines.h
 constexpr float kSkyMoonRadius = 1737.4f;
@@ -251,6 +251,7 @@ LUM_DEV Spectrum sky_optical_depth(const SkyView& s, float r, float mu) {
   }
   return depth;
 }
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ __launch_bounds__(64) void k_sky_transmittance_lut(DeviceScene sc, float4* __restrict__ dst) {
   const int id = blockIdx.x * 64 + threadIdx.x;
   if (id >= kSkyTmWidth * kSkyTmHeight) return;
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(64) void k_sky_transmittance_lut(DeviceScene sc, fl
   dst[id] = make_float4(t.v[0], t.v[1], t.v[2], t.v[3]);
   dst[kSkyTmWidth * kSkyTmHeight + id] = make_float4(t.v[4], t.v[5], t.v[6], t.v[7]);
 }
+#endif
 
 struct SkyMsResult { Spectrum L, ms_as_1; };
 // sky_compute_multiscattering_integration, sky.cuh:186-273
@@ -310,6 +312,7 @@ LUM_DEV SkyMsResult sky_multiscattering_integration(const SkyView& s, V3 origin,
   }
   return res;
 }
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // sky_compute_multiscattering_lut, sky.cuh:276-332: one workgroup of 256 directions per texel, shared-memory tree reduction
 __global__ __launch_bounds__(256) void k_sky_multiscattering_lut(DeviceScene sc, float4* __restrict__ dst) {
   __shared__ Spectrum lum_shared[kSkyMsIter], ms_shared[kSkyMsIter];
@@ -342,6 +345,7 @@ __global__ __launch_bounds__(256) void k_sky_multiscattering_lut(DeviceScene sc,
   dst[id] = make_float4(L.v[0], L.v[1], L.v[2], L.v[3]);
   dst[kSkyMsSize * kSkyMsSize + id] = make_float4(L.v[4], L.v[5], L.v[6], L.v[7]);
 }
+#endif
 
 LUM_DEV Spectrum sky_moon_solar_flux() { return Spectrum{{1.7f, 1.8f, 2.0f, 1.9f, 1.87f, 1.7f, 1.65f, 1.55f}}; }  // sky_utils.cuh:272
 // math.cuh:781-789
@@ -472,6 +476,7 @@ LUM_DEV float sky_hdri_median_of_means(float* buckets, uint32_t num_buckets) {  
   for (uint32_t b = c; b < num_buckets - c; b++) output += buckets[b];
   return output / (float) (num_buckets - 2u * c);
 }
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, float oy, float oz, uint32_t dim, uint32_t sample_count, float4* __restrict__ dst) {
   __shared__ float values[256];
   const uint32_t pixel = (blockIdx.x * 256u + threadIdx.x) >> 5, lane = threadIdx.x & 31u;
@@ -505,6 +510,7 @@ __global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, floa
   }
   if (lane == 0u && in_range) dst[x + y * dim] = make_float4(out[0], out[1], out[2], 0.0f);
 }
+#endif
 
 // ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ----
 LUM_DEV bool sphere_hit(V3 ray, V3 origin, V3 p, float r) {  // math.cuh:679-696
@@ -625,4 +631,4 @@ LUM_DEV bool sample_sun(const DeviceScene& sc, const SkyView& sky, const LocalFr
   return true;
 }
 
-}  // namespace lum
+LUM_NS_END

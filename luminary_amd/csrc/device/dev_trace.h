@@ -21,7 +21,7 @@
 
 #include "dev_light.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 constexpr uint32_t kHitSky        = 0xFFFFFFFEu;  // cuda/utils.cuh:50-64
 constexpr uint32_t kLeaveInstance = 0xFFFFFFFDu;  // stack marker: back from a bottom-level BVH to the top level
@@ -113,8 +113,28 @@ LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tm
 // workgroup of the persistent ray kernels: a divergent 16-byte LDS read costs a fraction of a divergent L1 access.
 struct NodeSource { const Bvh4Node* global; const char* lds; uint32_t lds_count; };
 
-template <bool kOrdered>
-LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, uint2* __restrict__ stk, int& sp, uint2& top, RayStats& st) {
+// Traversal stack entry. Closest-hit rays keep the child's entry distance next to its index so that a pop can drop what lies beyond the hit
+// found meanwhile (8 bytes). A visibility ray's segment never shrinks, every stacked child stays within reach, so its entries are the
+// index alone (4 bytes): half the scratch traffic of the kernel that writes most of it (rocprofv3 WRITE_SIZE, C3: 4.9 GB per launch of which
+// 0.33 GB are results; the stacks of the 196 k resident lanes do not fit the 4 MB L2 of an XCD next to the nodes).
+template <bool kCull> struct StackEntry;
+template <> struct StackEntry<true> {
+  using E = uint2;
+  static LUM_DEV E make(uint32_t node, float tnear) { return make_uint2(node, fbits(tnear)); }
+  static LUM_DEV uint32_t node(E e) { return e.x; }
+  static LUM_DEV bool reachable(E e, float tmax) { return bitsf(e.y) <= __builtin_fmaf(tmax, 1.000004f, 1e-30f); }
+};
+template <> struct StackEntry<false> {
+  using E = uint32_t;
+  static LUM_DEV E make(uint32_t node, float) { return node; }
+  static LUM_DEV uint32_t node(E e) { return e; }
+  static LUM_DEV bool reachable(E, float) { return true; }
+};
+
+template <bool kOrdered, bool kCull>
+LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+                            typename StackEntry<kCull>::E& top, RayStats& st) {
+  using SE = StackEntry<kCull>;
   const uint32_t b = cur << 7;
   float4 nx, ny, nz, fx, fy, fz;
   uint4 ch;
@@ -140,23 +160,39 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
     cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
   }
   const float inf = __builtin_inff();
+#ifndef LUM_PUSH_COND
+#define LUM_PUSH_COND 0
+#endif
+#if LUM_PUSH_COND
+  // Pushes only what is real. After the sort the children the ray may touch come first, so "child j is real" implies the same of every
+  // child before it: one branch skips all three pushes in the common case of at most one child hit, and nothing is written for children the
+  // ray misses (branch-free pushes store 3 entries per visit, used or not: most of the kernel's L2 requests were those stores).
+  if (k1 < inf) {
+    if (k2 < inf) {
+      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
+      stk[sp] = top; sp++; top = SE::make(c2, k2);
+    }
+    stk[sp] = top; sp++; top = SE::make(c1, k1);
+  }
+#else
   // Branch-free pushes. The newest entry lives in registers (`top`), older ones in scratch: a push spills the old top to a slot
   // that is only kept if the push is real, so a pop never waits for a scratch load before it can fetch the next node.
   {
     const bool v = k3 < inf;
     stk[sp] = top; sp += v ? 1 : 0;
-    top = v ? make_uint2(c3, fbits(k3)) : top;
+    top = v ? SE::make(c3, k3) : top;
   }
   {
     const bool v = k2 < inf;
     stk[sp] = top; sp += v ? 1 : 0;
-    top = v ? make_uint2(c2, fbits(k2)) : top;
+    top = v ? SE::make(c2, k2) : top;
   }
   {
     const bool v = k1 < inf;
     stk[sp] = top; sp += v ? 1 : 0;
-    top = v ? make_uint2(c1, fbits(k1)) : top;
+    top = v ? SE::make(c1, k1) : top;
   }
+#endif
   return (k0 < inf) ? c0 : kBvhEmpty;
 }
 
@@ -168,7 +204,8 @@ LUM_DEV uint2 stack_pop(uint2* __restrict__ stk, int& sp, uint2& top) {
   else top = make_uint2(kTraversalDone, 0u);
   return e;
 }
-LUM_DEV void stack_push(uint2* __restrict__ stk, int& sp, uint2& top, uint2 e) { stk[sp] = top; sp++; top = e; }
+template <typename E>
+LUM_DEV void stack_push(E* __restrict__ stk, int& sp, E& top, E e) { stk[sp] = top; sp++; top = e; }
 
 LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
 
@@ -193,7 +230,9 @@ struct LeafTris {
 // matrix (an affine map preserves distances along the ray, so tmax and the stacked entry distances stay valid across levels).
 template <class Q>
 LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays, uint32_t lds_count) {
-  uint2 stk[kStackSize];
+  using SE = StackEntry<Q::kCull>;
+  using E = typename SE::E;
+  E stk[kStackSize];
   int sp = 0;
   TRay r;
   V3 wo = v3(0.0f, 0.0f, 0.0f), wd = v3(0.0f, 0.0f, 1.0f);
@@ -212,7 +251,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   }
   const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
 
-  uint2 top = make_uint2(kTraversalDone, 0u);
+  E top = SE::make(kTraversalDone, 0.0f);
 #ifdef LUM_PHASE_STATS
   uint32_t phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -222,17 +261,17 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     // made every ray register loop-carried (two dozen v_mov per iteration). The bottom of the stack is the kTraversalDone sentinel, so
     // any other entry has something below it.
     bool left_instance = false, again;
-    uint2 e;
+    E e;
     do {
       e = top;
-      const bool done = e.x == kTraversalDone, leave = e.x == kLeaveInstance;
+      const bool done = SE::node(e) == kTraversalDone, leave = SE::node(e) == kLeaveInstance;
       // (an unconditional load, with the sentinel kept in memory or selected afterwards, was measured 2-16 % slower: the loaded entry
       // must flow into `top` untouched so that nothing waits for it before the next node's loads are in flight)
       if (!done) { sp--; top = stk[sp]; }
       left_instance |= leave;
-      again = !done && (leave || !within(bitsf(e.y), tmax));
+      again = !done && (leave || !SE::reachable(e, tmax));
     } while (again);
-    cur = e.x;
+    cur = SE::node(e);
     if (left_instance) { inst = kNoInstance; r.set(wo, wd); }
   };
 
@@ -259,7 +298,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
         const uint32_t rank = (uint32_t) __popcll(idle & below);
         if (cur == kTraversalDone && rank < avail) {
           idx = chunk_next + rank;
-          if (q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; top = make_uint2(kTraversalDone, 0u); inst = kNoInstance; rays++; }
+          if (q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; top = SE::make(kTraversalDone, 0.0f); inst = kNoInstance; rays++; }
         }
         chunk_next += min(want, avail);
       }
@@ -303,7 +342,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           const V3 od = v3(mat_row_apply(r0.x, r0.y, r0.z, wd.x, wd.y, wd.z), mat_row_apply(r1.x, r1.y, r1.z, wd.x, wd.y, wd.z),
                            mat_row_apply(r2.x, r2.y, r2.z, wd.x, wd.y, wd.z));
           r.set(oo, od);
-          stack_push(stk, sp, top, make_uint2(kLeaveInstance, 0u));
+          stack_push(stk, sp, top, SE::make(kLeaveInstance, 0.0f));
           cur = fbits(meta.y);
         }
       }
@@ -311,7 +350,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
         if (do_node) {
           LUM_PHASE(0);
           st.nodes++;
-          cur = visit_node<Q::kOrdered>(nodes, cur, r, tmax, stk, sp, top, st);
+          cur = visit_node<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
           if (cur == kBvhEmpty) {
             pop();
             if (cur == kTraversalDone) q.finish(sc, idx);
@@ -331,6 +370,7 @@ struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
 struct ClosestState {
   static constexpr bool kOrdered = true;
+  static constexpr bool kCull = true;  // stack entries carry the entry distance: a pop drops children beyond the nearest hit so far
   bool use_ignore;
   uint32_t ign_inst, ign_tri;
   Hit best;
@@ -366,6 +406,10 @@ struct ClosestState {
 // beyond that) and rounded to binary32 once at the end; the oracle does the same.
 struct ShadowState {
   static constexpr bool kOrdered = true;  // an unordered visit was measured: fewer instructions, same time, so the common path is kept
+#ifndef LUM_SHADOW_CULL
+#define LUM_SHADOW_CULL 0
+#endif
+  static constexpr bool kCull = LUM_SHADOW_CULL != 0;  // the segment never shrinks: 4-byte stack entries (StackEntry<false>)
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
   double tr, tg, tb;
@@ -422,7 +466,7 @@ LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, Ray
     }
     else {
       st.nodes++;
-      cur = visit_node<true>(NodeSource{sc.light_nodes, nullptr, 0u}, cur, r, tmax, stk, sp, top, st);
+      cur = visit_node<true, true>(NodeSource{sc.light_nodes, nullptr, 0u}, cur, r, tmax, stk, sp, top, st);
     }
     if (cur == kBvhEmpty) {
       while (true) {
@@ -475,4 +519,4 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
   return best_id;
 }
 
-}  // namespace lum
+LUM_NS_END

@@ -16,7 +16,7 @@
 #include "dev_trace.h"
 #include "dev_sky.h"
 
-namespace lum {
+LUM_NS_BEGIN
 
 constexpr int kBlock = 256;
 #ifndef LUM_TRACE_BLOCK
@@ -27,11 +27,6 @@ constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
 #endif
-
-struct PassParams {
-  const uint32_t* pixels;  // pixel index (x + y*width) per local pixel, or nullptr for identity
-  uint32_t num_pixels, batch, first_sample;
-};
 
 LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
                          uint32_t lds_counter = kCntCount) {
@@ -616,6 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
   }
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // ---- accumulation (cuda/accumulation.cuh:63-84): samples of a pixel are added in sample order ----
 __global__ __launch_bounds__(kBlock) void k_accumulate(const float4* results, uint32_t num_pixels, uint32_t batch, float* first_moment, float* second_moment) {
   for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < num_pixels; p += gridDim.x * kBlock) {
@@ -643,6 +639,8 @@ __global__ __launch_bounds__(kBlock) void k_accumulate_scatter(const float4* res
   }
 }
 
+#endif
+
 // ---- standalone closest-hit entry for traversal tests and the trace micro-benchmark ----
 struct RaysQuery : ClosestState {
   const float* origins; const float* dirs; const uint32_t* ignore; uint32_t* out;
@@ -668,6 +666,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_rays(DeviceScene sc, uint
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 // ---- camera ray of one pixel (first sample id), for pixel queries ----
 __global__ void k_pixel_ray(DeviceScene sc, uint32_t x, uint32_t y, uint32_t sample_id, float* origin, float* dir) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -729,4 +728,6 @@ __global__ void k_generate_lut(const uint32_t* bluenoise, int table, uint32_t co
   dst[id] = quantise_energy(sum);
 }
 
-}  // namespace lum
+#endif
+
+LUM_NS_END

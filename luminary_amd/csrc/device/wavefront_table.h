@@ -1,0 +1,36 @@
+// The wavefront kernels as a table of launchers, one table per arithmetic flavour (flavour.h). The host side (csrc/host/core.hip) picks a
+// table per context (lumc_set_flavour) and launches through it; everything in the signatures is a plain layout from dev_scene.h.
+// Kernels that produce data both flavours must agree on (BSDF / sky tables, panorama bake), bookkeeping (accumulation, adaptive rates) and
+// the display chain exist once, in the exact flavour.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "dev_scene.h"
+
+namespace lum {
+
+struct WavefrontKernels {
+  const char* flavour;
+  // dynamic LDS of the persistent ray kernels (the staged tree top); returns a hipError_t
+  int (*set_ray_kernel_lds)(size_t bytes);
+  void (*generate)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count);
+  void (*generate_adaptive)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const AdaptiveView& a, const AdaptivePass& pass, const PathQueue& q, float4* results,
+                            uint32_t* count);
+  void (*trace)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes);
+  void (*sky_inscattering)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const);
+  void (*shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
+                uint32_t* ctrl, uint32_t depth_const, uint64_t* counters);
+  void (*sky)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const);
+  void (*light_query)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl, uint32_t depth_const,
+                      uint64_t* counters);
+  void (*shadow_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes);
+  void (*resolve)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
+  void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
+                     uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);
+};
+
+const WavefrontKernels* wavefront_kernels_exact();  // csrc/host/core.hip
+const WavefrontKernels* wavefront_kernels_fast();   // csrc/device/wavefront_fast.hip
+
+}  // namespace lum

@@ -1,0 +1,64 @@
+// Defines this translation unit's WavefrontKernels table (include once, after kernels.h and dev_adaptive.h).
+#pragma once
+
+#include "dev_adaptive.h"
+#include "wavefront_table.h"
+
+LUM_NS_BEGIN
+namespace table {
+
+static int set_ray_kernel_lds(size_t bytes) {
+  hipError_t e = hipFuncSetAttribute((const void*) k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_shadow_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+  return (int) e;
+}
+static void generate(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count) {
+  hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, sc, pp, q, results, count);
+}
+static void generate_adaptive(uint32_t grid, hipStream_t s, const DeviceScene& sc, const AdaptiveView& a, const AdaptivePass& pass, const PathQueue& q, float4* results,
+                              uint32_t* count) {
+  hipLaunchKernelGGL(k_generate_adaptive, dim3(grid), dim3(kBlock), 0, s, sc, a, pass, q, results, count);
+}
+static void trace(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kTraceBlock), lds, s, sc, q, ctrl, counters, lds_nodes);
+}
+static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_sky_inscattering, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
+}
+static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
+                  uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
+  auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri> : k_shade<kSkyConstantColor>;
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters);
+}
+static void sky(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_sky, dim3(grid), dim3(kBlock), 0, s, sc, in, sq, results, ctrl, depth_const);
+}
+static void light_query(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl, uint32_t depth_const,
+                        uint64_t* counters) {
+  hipLaunchKernelGGL(k_light_query, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, ctrl, depth_const, counters);
+}
+static void shadow_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_shadow_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, sq, ctrl, counters, lds_nodes);
+}
+static void resolve(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);
+}
+static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
+                       uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
+}
+
+static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
+                                        sky,              light_query,        shadow_rays, resolve,           trace_rays};
+
+}  // namespace table
+LUM_NS_END
+
+namespace lum {
+#if LUM_FAST
+const WavefrontKernels* wavefront_kernels_fast() { return &fast::table::kTable; }
+#else
+const WavefrontKernels* wavefront_kernels_exact() { return &exact::table::kTable; }
+#endif
+}  // namespace lum

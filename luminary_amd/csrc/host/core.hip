@@ -18,6 +18,7 @@
 #include "../device/kernels.h"
 #include "../device/dev_output.h"
 #include "../device/dev_adaptive.h"
+#include "../device/wavefront_table_impl.h"  // this translation unit holds the exact flavour; the fast one is csrc/device/wavefront_fast.hip
 #include <hipcub/hipcub.hpp>
 #include "bvh_build.h"
 
@@ -26,6 +27,7 @@ using namespace lum;
 struct LumContext {
   int device = 0;
   std::string error;
+  const WavefrontKernels* wf = wavefront_kernels_fast();  // flavour of the wavefront kernels (lumc_set_flavour; LUM_FLAVOUR=exact|fast overrides the default)
   std::vector<void*> scene_allocs;
   DeviceScene scene{};
   bool has_scene = false;
@@ -281,6 +283,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
   if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : 0;
+  if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
   HIP_TRY(ctx, hipGetDeviceCount(&count));
@@ -493,9 +496,8 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
     const size_t dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_shadow_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
-    HIP_TRY(ctx, hipFuncSetAttribute((const void*) k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) dyn));
+    HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->set_ray_kernel_lds(dyn));
+    HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->set_ray_kernel_lds(dyn));
   }
   // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
   {
@@ -693,39 +695,38 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const uint32_t max_depth = sc.max_ray_depth;
   const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
   int cur = 0;
+  const WavefrontKernels& wf = *ctx->wf;
   for (uint32_t depth = 0; depth <= max_depth; depth++) {
     // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
     const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
     uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-      hipLaunchKernelGGL(k_trace, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
+      wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
-      hipLaunchKernelGGL(k_sky_inscattering, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
+      wf.sky_inscattering(grid_for(N), stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      auto* shade = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri> : k_shade<kSkyConstantColor>;
-      hipLaunchKernelGGL(shade, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const,
-                         ctx->d_counters);
+      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters);
     }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
-      hipLaunchKernelGGL(k_sky, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, depth_const);
+      wf.sky(grid_for(N), stream, sc, ctx->queue[cur], ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
-      hipLaunchKernelGGL(k_light_query, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
+      wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
-      hipLaunchKernelGGL(k_shadow_rays, dim3(grid_persistent(ctx, N)), dim3(kTraceBlock), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
+      wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
-      hipLaunchKernelGGL(k_resolve, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
+      wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
     }
     cur ^= 1;
   }
@@ -756,7 +757,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (max_depth + 2), stream));
     {
       Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
-      hipLaunchKernelGGL(k_generate, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
+      ctx->wf->generate(grid_for(N), stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
     }
     if (wavefront_depths(ctx, stream, N)) return 1;
     {
@@ -812,7 +813,7 @@ int lumc_render_undersampled(LumContext* ctx, uint32_t stage, uint32_t iteration
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (sc.max_ray_depth + 2), stream));
   {
     Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
-    hipLaunchKernelGGL(k_generate, dim3(grid_for(n)), dim3(kBlock), 0, stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
+    ctx->wf->generate(grid_for(n), stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
   }
   if (wavefront_depths(ctx, stream, n)) return 1;
   {
@@ -914,7 +915,7 @@ int adaptive_execute(LumContext* ctx, hipStream_t stream, uint32_t merged) {
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * (sc.max_ray_depth + 2), stream));
     {
       Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
-      hipLaunchKernelGGL(k_generate_adaptive, dim3(grid_for(N)), dim3(kBlock), 0, stream, sc, view, pass, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
+      ctx->wf->generate_adaptive(grid_for(N), stream, sc, view, pass, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
     }
     if (wavefront_depths(ctx, stream, N)) return 1;
     {
@@ -1333,8 +1334,8 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
   HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  hipLaunchKernelGGL(k_trace_rays, dim3(grid_persistent(ctx, n)), dim3(kTraceBlock), (size_t) ctx->lds_nodes * sizeof(Bvh4Node), stream, ctx->scene, n, d_origins, d_dirs, d_ignore,
-                     d_out, cursor, ctx->d_counters, ctx->lds_nodes);
+  ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * sizeof(Bvh4Node), stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
+                      ctx->lds_nodes);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
 }
@@ -1384,6 +1385,13 @@ extern "C" int lumc_debug_phase_stats(uint64_t out[16], int reset) {
   return 0;
 }
 #endif
+
+int lumc_set_flavour(LumContext* ctx, int flavour) {
+  if (!ctx || flavour < 0 || flavour > 1) { if (ctx) ctx->error = "lumc_set_flavour: 0 (exact) or 1 (fast)"; return 1; }
+  ctx->wf = flavour == LUMC_FLAVOUR_FAST ? wavefront_kernels_fast() : wavefront_kernels_exact();
+  return 0;
+}
+int lumc_get_flavour(const LumContext* ctx) { return (ctx && ctx->wf == wavefront_kernels_exact()) ? LUMC_FLAVOUR_EXACT : LUMC_FLAVOUR_FAST; }
 
 int lumc_set_bvh_builder(LumContext* ctx, int builder) {
   if (!ctx || builder < 0 || builder > 1) { if (ctx) ctx->error = "lumc_set_bvh_builder: 0 (SAH, host) or 1 (LBVH, GPU)"; return 1; }

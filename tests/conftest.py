@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+# The parity tests compare the HIP path with the oracle bit for bit, which is the contract of the EXACT arithmetic flavour of the device
+# code (luminary_amd/csrc/device/flavour.h). The library's own default is the fast flavour; tests/test_flavours.py gates that one against
+# exact and selects flavours through the API.
+os.environ["LUM_FLAVOUR"] = "exact"
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

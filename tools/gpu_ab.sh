@@ -1,8 +1,10 @@
-# A/B of compile-time variants on the GPU box: bash tools/gpu_ab.sh "<flags 1>" "<flags 2>" ...   (workloads in $WORKLOADS, default both)
+# A/B of compile-time variants on the GPU box: bash tools/gpu_ab.sh "<flags 1>" "<flags 2>" ...   (workloads in $WORKLOADS, default hall scan;
+# extra bench arguments in $BENCH_ARGS, e.g. "--flavour exact"). The default build is restored on exit, whatever happens.
+trap 'python -m luminary_amd.build --force > /dev/null 2>&1' EXIT
 for flags in "$@"; do
-  LUM_CXXFLAGS="$flags" python -m luminary_amd.build --force > /dev/null 2>&1
-  for w in ${WORKLOADS:-example hall}; do
-    echo -n "[$flags] $w: "
-    python bench.py --steps 3 --warmup 1 --cpu-budget 0 --workload $w 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); k=d['config']['kernel_ms_rank0']; print(round(d['value'],1),'Mrays/s trace %.1f shade %.1f shadow %.1f' % (k['trace'], k['shade'], k['shadow']))"
+  LUM_CXXFLAGS="$flags" python -m luminary_amd.build --force > /dev/null 2>&1 || { echo "[$flags] build failed"; continue; }
+  for w in ${WORKLOADS:-hall scan}; do
+    echo -n "[$flags] $w $BENCH_ARGS: "
+    LUM_CXXFLAGS="$flags" python bench.py --steps 3 --warmup 1 --cpu-budget 0 --secondary none --workload $w $BENCH_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); k=d['config']['kernel_ms_rank0']; p=d['config']['per_ray_rank0']; print(round(d['value'],1),'Mrays/s trace %.1f shade %.1f shadow %.1f lq %.1f res %.1f | nodes %.2f/%.2f' % (k['trace'], k['shade'], k['shadow'], k['light_query'], k['resolve'], p['nodes_closest'], p['nodes_shadow']))"
   done
 done
