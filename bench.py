@@ -280,7 +280,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     total_ms = sum(v[0] for v in times.values()) or 1.0
     out = {
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour,
+        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "ray_sorting": core.ray_sorting,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
+    ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
     ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
                     help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")
     args = ap.parse_args()
@@ -335,6 +336,8 @@ def main():
     core = Core(local_rank)
     if args.flavour:
         core.set_flavour(args.flavour)
+    if args.sort is not None:
+        core.set_ray_sorting(args.sort)
     head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True)
     # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
     cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1 and args.sky == "constant" and rank == 0) else None

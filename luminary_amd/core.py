@@ -6,7 +6,7 @@ import numpy as np
 from . import DeviceSceneView, _lib
 
 CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
-KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky")
+KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky", "sort")
 
 
 class CoreError(RuntimeError):
@@ -77,6 +77,16 @@ class Core:
             return "exact"
         fn.restype = C.c_int
         return "fast" if fn(self._ctx) == 1 else "exact"
+
+    @property
+    def ray_sorting(self):
+        fn = self._lib.lumc_get_ray_sorting
+        fn.restype = C.c_int
+        return int(fn(self._ctx))
+
+    def set_ray_sorting(self, mode):
+        """0 queue order, 1 closest-hit rays of depth >= 1 sorted by (origin cell, direction octant), 2 visibility rays too."""
+        self._call("lumc_set_ray_sorting", C.c_int(mode))
 
     def set_flavour(self, name):
         self._call("lumc_set_flavour", C.c_int({"exact": 0, "fast": 1}[name]))

@@ -13,6 +13,17 @@
 
 #include "flavour.h"
 
+// Parts of the fast flavour, individually switchable for diagnosis (tools/flavour_diff.py): all on by default.
+#ifndef LUM_FAST_RSQ
+#define LUM_FAST_RSQ LUM_FAST
+#endif
+#ifndef LUM_FAST_SINCOS
+#define LUM_FAST_SINCOS LUM_FAST
+#endif
+#ifndef LUM_FAST_EXPLOG
+#define LUM_FAST_EXPLOG LUM_FAST
+#endif
+
 #define LUM_DEV __device__ __forceinline__
 
 // Diagnostic build (-DLUM_PHASE_STATS, tools/phase_stats.py): how many lanes are active where. LUM_STAT(i, l) adds one to
@@ -50,7 +61,7 @@ LUM_DEV uint32_t f2u_sat(float v) {
   return (uint32_t) v;
 }
 LUM_DEV float saturate(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
-#if LUM_FAST
+#if LUM_FAST_RSQ
 LUM_DEV float rsqrt_ieee(float x) { return __builtin_amdgcn_rsqf(x); }  // v_rsq_f32, 1 ulp (the reference: rsqrtf under --use_fast_math)
 #else
 LUM_DEV float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }
@@ -58,7 +69,7 @@ LUM_DEV float rsqrt_ieee(float x) { return 1.0f / sqrtf(x); }
 LUM_DEV float exp2i(int e) { return ldexpf(1.0f, e); }
 
 // sin/cos: Cody-Waite reduction by pi/2, minimax polynomials on [-pi/4, pi/4].
-#if LUM_FAST
+#if LUM_FAST_SINCOS
 // fast flavour: the hardware's v_sin_f32 / v_cos_f32 on x / 2pi (what __sinf / __cosf are under --use_fast_math in the reference)
 LUM_DEV void sincos_det(float x, float& s_out, float& c_out) {
   const float r = x * 0.15915494309189532f;
@@ -109,7 +120,7 @@ LUM_DEV float atan2_det(float y, float x) {
 
 // ---- log2 / exp2 / pow as fixed sequences (relative error < 3e-7), used where the reference calls log2f / powf ----
 // log2 for positive normal floats: exponent + 2*atanh((m-1)/(m+1)) / ln 2 with m in [sqrt(1/2), sqrt(2)).
-#if LUM_FAST
+#if LUM_FAST_EXPLOG
 LUM_DEV float log2_det(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
 LUM_DEV float exp2_det(float x) { return __builtin_amdgcn_exp2f(fminf(fmaxf(x, -126.0f), 127.0f)); }  // v_exp_f32
 #else

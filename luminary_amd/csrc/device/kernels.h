@@ -98,9 +98,15 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams 
 }
 
 // ---- closest-hit pass (replaces optix/optix_kernel_raytrace.cu:147-183) ----
+// `order` (optional): the queue is traced in the order of a sort by ray origin cell and direction octant (k_ray_sort_keys, core.hip), so
+// that the lanes of a wave and the waves of a CU walk the same part of the tree; the queue itself is not moved.
 struct TraceQuery : ClosestState {
   PathQueue q;
-  LUM_DEV bool load(const DeviceScene&, uint32_t i, V3& o, V3& d, float& tmax) {
+  const uint32_t* order;
+  uint32_t item;
+  LUM_DEV bool load(const DeviceScene&, uint32_t j, V3& o, V3& d, float& tmax) {
+    const uint32_t i = order ? order[j] : j;
+    item = i;
     const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
     const uint32_t state = q.aux[i].w;
     const uint2 ign = *reinterpret_cast<const uint2*>(&q.hit_id[i]);
@@ -108,7 +114,8 @@ struct TraceQuery : ClosestState {
     o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = kFltMax;
     return true;
   }
-  LUM_DEV void finish(const DeviceScene&, uint32_t i) {
+  LUM_DEV void finish(const DeviceScene&, uint32_t) {
+    const uint32_t i = item;
     const Hit h = result();
     reinterpret_cast<float*>(&q.origin_t[i])[3] = h.t;
     *reinterpret_cast<uint2*>(&q.hit_id[i]) = make_uint2(h.instance_id, h.tri_id);
@@ -116,11 +123,13 @@ struct TraceQuery : ClosestState {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene sc, PathQueue q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene sc, PathQueue q, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
   TraceQuery tq;
   tq.q = q;
+  tq.order = order;
+  tq.item = 0;
   trace_items(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
@@ -545,8 +554,10 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
 // ---- visibility rays (optix/optix_kernel_shadow.cu:15-100, cuda/optix_anyhit.cuh:49-139) ----
 struct ShadowQuery : ShadowState {
   ShadowQueue sq;
+  const uint32_t* order;
   uint32_t out;
-  LUM_DEV bool load(const DeviceScene&, uint32_t j, V3& o, V3& d, float& tmax) {
+  LUM_DEV bool load(const DeviceScene&, uint32_t slot, V3& o, V3& d, float& tmax) {
+    const uint32_t j = order ? order[slot] : slot;
     const float4 o4 = sq.origin_dist[j], d4 = sq.dir_out[j];
     begin(sq.ids[j], o4.w);
     out = fbits(d4.w);
@@ -563,11 +574,12 @@ struct ShadowQuery : ShadowState {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+__global__ __launch_bounds__(kTraceBlock) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
   ShadowQuery q;
   q.sq = sq;
+  q.order = order;
   trace_items(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow, kCntNodesLdsShadow);
 }

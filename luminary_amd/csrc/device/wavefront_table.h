@@ -17,14 +17,16 @@ struct WavefrontKernels {
   void (*generate)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count);
   void (*generate_adaptive)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const AdaptiveView& a, const AdaptivePass& pass, const PathQueue& q, float4* results,
                             uint32_t* count);
-  void (*trace)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes);
+  void (*trace)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
+                uint32_t lds_nodes);
   void (*sky_inscattering)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
                 uint32_t* ctrl, uint32_t depth_const, uint64_t* counters);
   void (*sky)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*light_query)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl, uint32_t depth_const,
                       uint64_t* counters);
-  void (*shadow_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes);
+  void (*shadow_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
+                      uint32_t lds_nodes);
   void (*resolve)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
   void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                      uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);

@@ -20,8 +20,9 @@ static void generate_adaptive(uint32_t grid, hipStream_t s, const DeviceScene& s
                               uint32_t* count) {
   hipLaunchKernelGGL(k_generate_adaptive, dim3(grid), dim3(kBlock), 0, s, sc, a, pass, q, results, count);
 }
-static void trace(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
-  hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kTraceBlock), lds, s, sc, q, ctrl, counters, lds_nodes);
+static void trace(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const PathQueue& q, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
+                  uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kTraceBlock), lds, s, sc, q, order, ctrl, counters, lds_nodes);
 }
 static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
   hipLaunchKernelGGL(k_sky_inscattering, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
@@ -38,8 +39,9 @@ static void light_query(uint32_t grid, hipStream_t s, const DeviceScene& sc, con
                         uint64_t* counters) {
   hipLaunchKernelGGL(k_light_query, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, ctrl, depth_const, counters);
 }
-static void shadow_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
-  hipLaunchKernelGGL(k_shadow_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, sq, ctrl, counters, lds_nodes);
+static void shadow_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
+                        uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_shadow_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, sq, order, ctrl, counters, lds_nodes);
 }
 static void resolve(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);

@@ -84,6 +84,15 @@ struct LumContext {
   std::vector<uint32_t> sky_hdri_key;  // what the bake was made from (sky parameters, origin, dim, samples): an unchanged key reuses it
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
+  // ray ordering (N1): keys + permutation, double-buffered for hipcub's radix sort; sized for the visibility items (4 per path)
+  int sort_mode = 0;              // 0 queue order, 1 closest-hit rays of depth >= 1 sorted, 2 visibility rays too (lumc_set_ray_sorting, LUM_SORT)
+  int sort_key = 0;               // 0 position-major (Morton cell | direction octant), 1 direction-major
+  uint32_t* d_sort_keys[2] = {nullptr, nullptr};
+  uint32_t* d_sort_vals[2] = {nullptr, nullptr};
+  void* d_sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
+  uint32_t sort_capacity = 0;
+  float world_lo[3] = {0, 0, 0}, world_hi[3] = {1, 1, 1};  // bounds of the top-level BVH
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
   // profiling
@@ -273,6 +282,73 @@ bool instance_world_box(const float4 rows[3], const Aabb& ob, Aabb& wb) {
   return true;
 }
 
+// ---- ray ordering (north star: "ray-sorted wavefront"; the reference sorts its tasks by hit type every depth, cuda/kernels.cuh:391-484) ----
+// Key = Morton code of the ray origin's cell in a 64^3 grid over the scene bounds (18 bits) combined with the direction's octant (3 bits).
+// Flavour-neutral: the order in which a queue is traced never changes a result (every path owns its slots), it only decides which rays
+// share a wave, a CU's L1 and an XCD's L2.
+struct SortGrid { float lo[3], scale[3]; uint32_t direction_major; };
+
+__device__ __forceinline__ uint32_t spread6(uint32_t v) {  // 6 bits -> every third bit
+  v &= 0x3Fu;
+  v = (v | (v << 8)) & 0x300Fu;
+  v = (v | (v << 4)) & 0x30C3u;
+  v = (v | (v << 2)) & 0x9249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_ray_sort_keys(const float4* __restrict__ origin, const float4* __restrict__ dir, const uint32_t* __restrict__ count, uint32_t capacity,
+                                                       SortGrid g, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+  const uint32_t n = min(*count, capacity);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < capacity; i += gridDim.x * 256u) {
+    uint32_t key = 0x1FFFFFu;  // beyond the live items: sorts to the end
+    if (i < n) {
+      const float4 o = origin[i], d = dir[i];
+      const uint32_t cx = (uint32_t) fminf(fmaxf((o.x - g.lo[0]) * g.scale[0], 0.0f), 63.0f), cy = (uint32_t) fminf(fmaxf((o.y - g.lo[1]) * g.scale[1], 0.0f), 63.0f),
+                     cz = (uint32_t) fminf(fmaxf((o.z - g.lo[2]) * g.scale[2], 0.0f), 63.0f);
+      const uint32_t morton = spread6(cx) | (spread6(cy) << 1) | (spread6(cz) << 2);
+      const uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+      key = g.direction_major ? ((octant << 18) | morton) : ((morton << 3) | octant);
+    }
+    keys[i] = key;
+    vals[i] = i;
+  }
+}
+
+int ensure_sort(LumContext* ctx, uint32_t items) {
+  if (items <= ctx->sort_capacity) return 0;
+  for (int k = 0; k < 2; k++) {
+    if (ctx->d_sort_keys[k]) (void) hipFree(ctx->d_sort_keys[k]);
+    if (ctx->d_sort_vals[k]) (void) hipFree(ctx->d_sort_vals[k]);
+    ctx->d_sort_keys[k] = ctx->d_sort_vals[k] = nullptr;
+  }
+  if (ctx->d_sort_temp) (void) hipFree(ctx->d_sort_temp);
+  ctx->d_sort_temp = nullptr; ctx->sort_capacity = 0;
+  for (int k = 0; k < 2; k++) {
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sort_keys[k], sizeof(uint32_t) * (size_t) items));
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sort_vals[k], sizeof(uint32_t) * (size_t) items));
+  }
+  hipcub::DoubleBuffer<uint32_t> keys(ctx->d_sort_keys[0], ctx->d_sort_keys[1]), vals(ctx->d_sort_vals[0], ctx->d_sort_vals[1]);
+  HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, ctx->sort_temp_bytes, keys, vals, (int) items, 0, 21, (hipStream_t) 0));
+  HIP_TRY(ctx, hipMalloc(&ctx->d_sort_temp, std::max<size_t>(ctx->sort_temp_bytes, 16)));
+  ctx->sort_capacity = items;
+  return 0;
+}
+
+// Sorted order of the first *count items of (origin, dir); returns the permutation (device pointer) or nullptr on failure.
+const uint32_t* sort_rays(LumContext* ctx, hipStream_t stream, const float4* origin, const float4* dir, const uint32_t* count, uint32_t capacity) {
+  if (ensure_sort(ctx, capacity)) return nullptr;
+  SortGrid g;
+  for (int k = 0; k < 3; k++) { g.lo[k] = ctx->world_lo[k]; const float e = ctx->world_hi[k] - ctx->world_lo[k]; g.scale[k] = e > 0.0f ? 64.0f / e : 0.0f; }
+  g.direction_major = ctx->sort_key == 1 ? 1u : 0u;
+  Launch l(ctx, stream, LUMC_KERNEL_SORT);
+  const uint32_t blocks = std::min<uint32_t>((capacity + 255u) / 256u, 4096u);
+  hipLaunchKernelGGL(k_ray_sort_keys, dim3(blocks ? blocks : 1), dim3(256), 0, stream, origin, dir, count, capacity, g, ctx->d_sort_keys[0], ctx->d_sort_vals[0]);
+  hipcub::DoubleBuffer<uint32_t> keys(ctx->d_sort_keys[0], ctx->d_sort_keys[1]), vals(ctx->d_sort_vals[0], ctx->d_sort_vals[1]);
+  size_t bytes = ctx->sort_temp_bytes;
+  if (hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_temp, bytes, keys, vals, (int) capacity, 0, 21, stream) != hipSuccess) return nullptr;
+  return vals.Current();
+}
+
 }  // namespace
 
 extern "C" {
@@ -283,6 +359,8 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
   if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : 0;
+  if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
+  if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -307,6 +385,8 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_first_moment) (void) hipFree(ctx->d_first_moment);
   if (ctx->d_second_moment) (void) hipFree(ctx->d_second_moment);
   if (ctx->d_ctrl) (void) hipFree(ctx->d_ctrl);
+  for (int k = 0; k < 2; k++) { if (ctx->d_sort_keys[k]) (void) hipFree(ctx->d_sort_keys[k]); if (ctx->d_sort_vals[k]) (void) hipFree(ctx->d_sort_vals[k]); }
+  if (ctx->d_sort_temp) (void) hipFree(ctx->d_sort_temp);
   if (ctx->d_frame_output) (void) hipFree(ctx->d_frame_output);
   if (ctx->d_bluenoise_1d) (void) hipFree(ctx->d_bluenoise_1d);
   if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
@@ -386,6 +466,10 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       boxes.push_back(wb);
       ids.push_back(i);
     }
+    for (int k = 0; k < 3; k++) { ctx->world_lo[k] = FLT_MAX; ctx->world_hi[k] = -FLT_MAX; }
+    for (const Aabb& b : boxes)
+      for (int k = 0; k < 3; k++) { ctx->world_lo[k] = std::min(ctx->world_lo[k], b.lo[k]); ctx->world_hi[k] = std::max(ctx->world_hi[k], b.hi[k]); }
+    if (boxes.empty()) for (int k = 0; k < 3; k++) { ctx->world_lo[k] = 0.0f; ctx->world_hi[k] = 1.0f; }
     Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1, 16);  // one instance per top-level leaf (dev_trace.h)
     if (tlas.nodes.empty()) { ctx->error = "top-level BVH exceeds 16 levels"; return 1; }
     tlas_order.resize(tlas.prims.size());
@@ -700,9 +784,15 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
     const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
     uint32_t* ctrl = ctx->d_ctrl + kCtlStride * depth;
+    // camera rays leave k_generate in pixel order, which is as coherent as rays get; later depths are sorted on request
+    const uint32_t* order = nullptr;
+    if (ctx->sort_mode >= 1 && depth >= 1) {
+      order = sort_rays(ctx, stream, ctx->queue[cur].origin_t, ctx->queue[cur].dir_slot, ctrl + kCtlPaths, N);
+      if (!order) { ctx->error = "ray sorting failed"; return 1; }
+    }
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-      wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], ctrl, ctx->d_counters, ctx->lds_nodes);
+      wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
@@ -720,9 +810,14 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
       wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
     }
+    const uint32_t* shadow_order = nullptr;
+    if (ctx->sort_mode >= 2) {
+      shadow_order = sort_rays(ctx, stream, ctx->shadow.origin_dist, ctx->shadow.dir_out, ctrl + kCtlShadowItems, 4u * ctx->shadow.capacity < 4u * N ? 4u * ctx->shadow.capacity : 4u * N);
+      if (!shadow_order) { ctx->error = "ray sorting failed"; return 1; }
+    }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
-      wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, ctrl, ctx->d_counters, ctx->lds_nodes);
+      wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, shadow_order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
@@ -1385,6 +1480,13 @@ extern "C" int lumc_debug_phase_stats(uint64_t out[16], int reset) {
   return 0;
 }
 #endif
+
+int lumc_set_ray_sorting(LumContext* ctx, int mode) {
+  if (!ctx || mode < 0 || mode > 2) { if (ctx) ctx->error = "lumc_set_ray_sorting: 0 (queue order), 1 (closest-hit rays sorted), 2 (visibility rays too)"; return 1; }
+  ctx->sort_mode = mode;
+  return 0;
+}
+int lumc_get_ray_sorting(const LumContext* ctx) { return ctx ? ctx->sort_mode : 0; }
 
 int lumc_set_flavour(LumContext* ctx, int flavour) {
   if (!ctx || flavour < 0 || flavour > 1) { if (ctx) ctx->error = "lumc_set_flavour: 0 (exact) or 1 (fast)"; return 1; }

@@ -245,6 +245,34 @@ def test_full_size_frame_properties_scan_10m(core):
     _full_size_frame_properties(core, scenes.scan_scene(1920, 1080, 8, triangles=10_000_000), 10_000_000)
 
 
+def test_ray_sorting_does_not_change_results(core):
+    """Ray ordering (lumc_set_ray_sorting): tracing the closest-hit rays of depth >= 1 (mode 1) and the visibility rays (mode 2) in the order
+    of a sort by origin cell and direction octant gives bit-identical moments and counters - every path owns its slots."""
+    host = scenes.example_scene(256, 144, 8, sphere_segments=10, ground_res=24, num_objects=32, num_lights=8)
+    view = oracle_lib.with_luts(host.device_scene())
+    core.upload(view)
+    core.set_pixels(None)
+    ref = None
+    try:
+        for mode in (0, 1, 2):
+            core.set_ray_sorting(mode)
+            core.clear()
+            core.reset_counters()
+            core.render(0, 4, samples_per_pass=2)
+            fm, sm = core.accumulators()
+            cnt = core.counters()[:10]
+            if ref is None:
+                ref = (fm, sm, cnt)
+                ofm, osm, _ = oracle_lib.render(view, 0, 4, pixels=np.arange(0, 256 * 144, 37, dtype=np.uint32))
+                _assert_same(fm[:, ::37], ofm, "unsorted render vs oracle (strided pixels)")
+            else:
+                _assert_same(fm, ref[0], "first moment, sort mode %d" % mode)
+                _assert_same(sm, ref[1], "second moment, sort mode %d" % mode)
+                assert cnt == ref[2], "counters, sort mode %d" % mode
+    finally:
+        core.set_ray_sorting(0)
+
+
 def test_render_parity_emission_textures(core):
     """Emission textures: textured emitters seen directly, sampled as lights (colour from the texel at the sampled point, alpha from the
     albedo texture), weighed in the light tree by their integrated texture maximum."""

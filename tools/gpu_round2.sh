@@ -21,3 +21,13 @@ if has pmc; then
   extra=""; has calib && extra="--calib"
   timeout 3000 python tools/pmc_collect.py $out/pmc $extra --workloads ${PMC_WORKLOADS:-hall,example,scan} > $out/pmc.log 2>&1; tail -40 $out/pmc.log
 fi
+if has flavourdiag; then
+  trap 'python -m luminary_amd.build --force > /dev/null 2>&1' EXIT
+  for ff in "-ffp-contract=fast -fno-hip-fp32-correctly-rounded-divide-sqrt -freciprocal-math|" "-ffp-contract=off -fno-fast-math|-DLUM_FAST_RSQ=0 -DLUM_FAST_SINCOS=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=fast|-DLUM_FAST_RSQ=0 -DLUM_FAST_SINCOS=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=off -fno-hip-fp32-correctly-rounded-divide-sqrt|-DLUM_FAST_RSQ=0 -DLUM_FAST_SINCOS=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=off -freciprocal-math|-DLUM_FAST_RSQ=0 -DLUM_FAST_SINCOS=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=off|-DLUM_FAST_SINCOS=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=off|-DLUM_FAST_RSQ=0 -DLUM_FAST_EXPLOG=0" "-ffp-contract=off|-DLUM_FAST_RSQ=0 -DLUM_FAST_SINCOS=0"; do
+    fast_flags="${ff%%|*}"; cxx="${ff##*|}"
+    echo "=== LUM_FAST_FLAGS=[$fast_flags] LUM_CXXFLAGS=[$cxx]"
+    LUM_FAST_FLAGS="$fast_flags" LUM_CXXFLAGS="$cxx" python -m luminary_amd.build --force > /dev/null 2>&1
+    LUM_FAST_FLAGS="$fast_flags" LUM_CXXFLAGS="$cxx" python tools/flavour_diff.py zoo 256 1024 2>&1 | tail -4
+  done > $out/flavourdiag.txt 2>&1
+  cat $out/flavourdiag.txt
+fi
