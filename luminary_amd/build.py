@@ -21,7 +21,8 @@ EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 EXACT = ["-ffp-contract=off", "-fno-fast-math"]  # the numerics contract of the exact flavour and of all host code
 # the fast flavour of the wavefront kernels (csrc/device/flavour.h): contraction, hardware reciprocal / sqrt, reciprocal-multiply for x / y
-FAST = ["-DLUM_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-math-errno"]
+FAST = ["-DLUM_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-math-errno",
+        "-fgpu-flush-denormals-to-zero"]  # denormals flushed like the reference's --use_fast_math build: a/b is v_rcp + v_mul, sqrt is v_sqrt (measured +1 %)
 if os.environ.get("LUM_FAST_FLAGS") is not None:  # diagnosis only (tools/flavour_diff.py): which part of the fast flavour moves the image
     FAST = ["-DLUM_FAST=1"] + os.environ["LUM_FAST_FLAGS"].split()
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring f32 multiplies/adds into v_pk_* and pays for it with register

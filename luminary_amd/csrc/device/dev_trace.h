@@ -412,9 +412,14 @@ struct ShadowState {
   static constexpr bool kCull = LUM_SHADOW_CULL != 0;  // the segment never shrinks: 4-byte stack entries (StackEntry<false>)
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
-  double tr, tg, tb;
+#if LUM_FAST
+  using Acc = float;   // the fast flavour does not promise the last bit: the product in traversal order, three registers fewer
+#else
+  using Acc = double;
+#endif
+  Acc tr, tg, tb;
   bool blocked;
-  LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; tr = tg = tb = 1.0; blocked = false; }
+  LUM_DEV void begin(uint4 ids, float d) { tgt_inst = ids.x; tgt_tri = ids.y; self_inst = ids.z; self_tri = ids.w; dist = d; tr = tg = tb = (Acc) 1.0; blocked = false; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float&, RayStats& st) {
     LeafTris lt;
     lt.load(sc.blas_tris, first, count);
@@ -443,7 +448,7 @@ struct ShadowState {
       if (alpha == 0.0f && !colored) continue;
       const float tp = 1.0f - alpha;
       const Col f = colored ? albedo * tp : splat(tp);
-      tr *= (double) f.r; tg *= (double) f.g; tb *= (double) f.b;
+      tr *= (Acc) f.r; tg *= (Acc) f.g; tb *= (Acc) f.b;
     }
     return false;
   }

@@ -19,6 +19,12 @@
 LUM_NS_BEGIN
 
 constexpr int kBlock = 256;
+#ifndef LUM_TRACE_BLOCK_FAST
+#define LUM_TRACE_BLOCK_FAST 768
+#endif
+#if LUM_FAST && !defined(LUM_TRACE_BLOCK)
+#define LUM_TRACE_BLOCK LUM_TRACE_BLOCK_FAST
+#endif
 #ifndef LUM_TRACE_BLOCK
 #define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
                              // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)

@@ -12,6 +12,7 @@ namespace lum {
 
 struct WavefrontKernels {
   const char* flavour;
+  uint32_t trace_block;  // threads per workgroup of the persistent ray kernels (one workgroup per CU)
   // dynamic LDS of the persistent ray kernels (the staged tree top); returns a hipError_t
   int (*set_ray_kernel_lds)(size_t bytes);
   void (*generate)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count);

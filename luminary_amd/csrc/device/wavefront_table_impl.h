@@ -51,7 +51,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
-static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
+static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
                                         sky,              light_query,        shadow_rays, resolve,           trace_rays};
 
 }  // namespace table

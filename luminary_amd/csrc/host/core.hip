@@ -187,7 +187,8 @@ inline uint32_t grid_for(uint32_t n) {
 
 // Persistent ray kernels: one workgroup per CU (kTraceBlock threads, its own LDS copy of the tree top); waves pull work from a cursor.
 inline uint32_t grid_persistent(const LumContext* ctx, uint32_t n) {
-  const uint32_t blocks = (n + kTraceBlock - 1) / kTraceBlock;
+  const uint32_t tb = ctx->wf->trace_block;
+  const uint32_t blocks = (n + tb - 1) / tb;
   return blocks < 1 ? 1 : (blocks > ctx->trace_blocks ? ctx->trace_blocks : blocks);
 }
 
@@ -573,7 +574,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     size_t lds_bytes = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
     // the ray kernels need ~160 VGPRs: 3 waves per SIMD = 12 waves per CU = one workgroup of kTraceBlock = 768 threads
-    const int blocks_per_cu = std::max(1, 768 / kTraceBlock);
+    const int blocks_per_cu = 1;  // both flavours launch one workgroup of 768 (3 waves per SIMD) or 1024 (4) threads per CU
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
     lds_bytes = lds_bytes > 4096 ? lds_bytes - 2048 : 0;
     ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / sizeof(Bvh4Node), nodes.size());
