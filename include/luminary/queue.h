@@ -1,0 +1,6 @@
+/* Forwarding header: a frontend written against the reference's <luminary/queue.h> (reference include/luminary/queue.h) compiles against
+ * libluminary_amd.so unchanged. Every declaration of the reference's public headers lives in ../luminary_amd.h. */
+#ifndef LUMINARY_AMD_FORWARD_QUEUE_H
+#define LUMINARY_AMD_FORWARD_QUEUE_H
+#include "../luminary_amd.h"
+#endif

@@ -10,10 +10,13 @@
  *   path                       path.h:24-31
  *   host functions             host.h:29-129
  *   init / shutdown            luminary.h:44-49
- * Scope of this implementation: the triangle / BSDF / NEE path with thin-lens camera and constant-colour
- * or black sky. Entities outside that scope (ocean, clouds, fog, particles, procedural sky) are stored and returned
- * unchanged but do not influence the image; functions whose effect lies outside the scope return
- * LUMINARY_ERROR_NOT_IMPLEMENTED instead of silently doing something else.
+ * A frontend's own includes - <luminary/luminary.h>, <luminary/host.h>, <luminary/structs.h>, ... - are served by the forwarding headers in
+ * include/luminary/, which all lead here: compile the frontend with -I<this repo>/include and link it with -lluminary_amd.
+ * Scope of this implementation: the triangle / BSDF / NEE path with the thin-lens camera under every sky mode
+ * (constant colour, procedural atmosphere with sun, moon and stars, baked panorama), textures, adaptive sampling, the undersampling
+ * preview, the display chain with bloom, and the debug shading modes. Rendering runs on the library's own "Device" thread once
+ * luminary_host_start_new_render was called, like the reference's. Ocean, clouds, fog, particles and the physical camera are stored and
+ * returned unchanged but do not influence the image yet.
  *
  * Additive extension (the reference only returns tone-mapped ARGB8): the luminary_ext_* functions at the
  * end give access to float radiance, ray counters and batch rendering. Existing symbols are untouched.
@@ -386,6 +389,12 @@ LUMINARY_API LuminaryResult luminary_ext_render_samples(
  * built after adaptive_sampling_update_interval << stage allocations); otherwise one sample id per pixel. Outputs (recurring and
  * requested) are produced through the result image: local error minimisation and adaptive_sampling_output_mode apply. */
 LUMINARY_API LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples);
+/* Asynchronous rendering is started by luminary_host_start_new_render, as in the reference (host.c:406-414): the host's "Device" worker
+ * then renders until the host is destroyed, restarting the accumulation whenever an edit dirties the integration, and the frontend polls
+ * luminary_host_try_await_output / luminary_host_acquire_output. Additive controls: stop that worker (returns once the running iteration
+ * has ended; the accumulated frame stays and the luminary_ext_render* calls can drive the loop synchronously), and query it. */
+LUMINARY_API LuminaryResult luminary_ext_stop_render(LuminaryHost* host);
+LUMINARY_API LuminaryResult luminary_ext_is_rendering(LuminaryHost* host, bool* rendering, uint32_t* accumulated_samples);
 /* Planar float accumulators of the pixels given to luminary_ext_render_samples: first moment [R|G|B] and luminance second moment. */
 LUMINARY_API LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels);
 /* Radiance = first moment / sample_count for the full frame (rgb interleaved, width*height*3 floats). */

@@ -305,7 +305,31 @@ class Host:
             _call("luminary_path_destroy", C.byref(p))
 
     def start_new_render(self):
+        """Restarts the accumulation and starts the library's render thread (reference host.c:406-414); poll try_await_output /
+        acquire_output for images."""
         _call("luminary_host_start_new_render", self._h)
+
+    def stop_render(self):
+        _call("luminary_ext_stop_render", self._h)
+
+    def is_rendering(self):
+        """(render thread active, samples accumulated so far)"""
+        r, n = C.c_bool(), C.c_uint32()
+        _call("luminary_ext_is_rendering", self._h, C.byref(r), C.byref(n))
+        return bool(r.value), int(n.value)
+
+    def queue_workers(self):
+        """[(name, current task or None, seconds)] of the library's queue workers (reference host.c:615-703)."""
+        n = C.c_uint32()
+        _call("luminary_host_get_num_queue_workers", self._h, C.byref(n))
+        out = []
+        for i in range(n.value):
+            name, string, t = C.c_char_p(), C.c_char_p(), C.c_double()
+            _call("luminary_host_get_queue_worker_name", self._h, C.c_uint32(i), C.byref(name))
+            _call("luminary_host_get_queue_worker_string", self._h, C.c_uint32(i), C.byref(string))
+            _call("luminary_host_get_queue_worker_time", self._h, C.c_uint32(i), C.byref(t))
+            out.append((name.value.decode() if name.value else None, string.value.decode() if string.value else None, float(t.value)))
+        return out
 
     # ---- additive extension ----
     def add_mesh(self, positions, material_ids, normals=None, uvs=None):

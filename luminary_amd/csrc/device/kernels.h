@@ -455,6 +455,47 @@ __global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene s
   if ((threadIdx.x & 63) == 0 && vertices) atomicAdd((unsigned long long*) &counters[kCntVertices], (unsigned long long) vertices);
 }
 
+// ---- debug shading modes (settings.shading_mode != DEFAULT): one closest-hit pass, then a colour per hit (geometry_process_tasks_debug,
+// cuda/geometry.cuh:182-246) or per miss (sky_process_tasks_debug, cuda/sky.cuh:635-665); queue: device/device_renderer.c:136-181 ----
+__global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl) {
+  const uint32_t n = ctrl[kCtlPaths];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+    const uint4 aux = in.aux[i], hid = in.hit_id[i];
+    const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
+    Col result = splat(0.0f);
+    if (hid.x == kHitSky) {
+      if (sc.shading_mode == 1u) {  // ALBEDO: sky_color_main(origin, ray, STATE_FLAG_CAMERA_DIRECTION)
+        if (sc.sky_mode == kSkyDefault) {
+          if (sc.sky_lut_transmittance && sc.sky_lut_multiscattering) {
+            const SkyView sky = sky_view(sc);
+            const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, 0u};
+            result = sky_get_color(sc, sky, world_to_sky(sky, origin), ray, kFltMax, true, (int) sky.steps, smp.next1(kRndSkyStepOffset));
+          }
+        }
+        else if (sc.sky_mode == kSkyHdri) result = sky_hdri_color(sc, origin, ray, kStCameraDirection);
+        else result = col(sc.sky_constant_color[0], sc.sky_constant_color[1], sc.sky_constant_color[2]);
+      }
+      else if (sc.shading_mode == 4u) result = col(0.0f, 0.63f, 1.0f);  // IDENTIFICATION
+    }
+    else {
+      const V3 hit_origin = origin + ray * o4.w;
+      if (sc.shading_mode == 2u) result = splat(saturate((1.0f / o4.w) * 2.0f));  // DEPTH
+      else if (sc.shading_mode == 4u) {                                            // IDENTIFICATION
+        const uint32_t v = squares32(0x55555555u, (hid.x << 16) | hid.y);
+        result = col(((float) (v & 0x7FFu)) / 0x7FF, ((float) ((v >> 10) & 0x7FFu)) / 0x7FF, ((float) ((v >> 20) & 0x7FFu)) / 0x7FF);
+      }
+      else if (sc.shading_mode == 1u || sc.shading_mode == 3u || sc.shading_mode == 5u) {
+        const GeoContext g = build_context(sc, hit_origin, ray, aux.w, hid.x, hid.y, in.hit_scene_tri[i], aux.z);
+        if (sc.shading_mode == 1u) result = g.params.albedo() + g.params.emission();                    // ALBEDO
+        else if (sc.shading_mode == 3u) result = col(saturate(g.normal.x), saturate(g.normal.y), saturate(g.normal.z));  // NORMAL
+        else result = g.params.albedo() * 0.025f + g.params.emission();                                   // LIGHTS
+      }
+    }
+    add_to_result(results, fbits(d4.w), result);
+  }
+}
+
 // ---- paths that left the scene, procedural sky: sky_process_tasks (cuda/sky.cuh:609-633) with sky_color_main's DEFAULT branch ----
 __global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, ShadowQueue sq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlSkyItems];

@@ -32,6 +32,9 @@ static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const Pat
   auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri> : k_shade<kSkyConstantColor>;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters);
 }
+static void shade_debug(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_shade_debug, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl);
+}
 static void sky(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
   hipLaunchKernelGGL(k_sky, dim3(grid), dim3(kBlock), 0, s, sc, in, sq, results, ctrl, depth_const);
 }
@@ -52,7 +55,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        sky,              light_query,        shadow_rays, resolve,           trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           trace_rays};
 
 }  // namespace table
 LUM_NS_END

@@ -1,15 +1,21 @@
 // Implementation of the Luminary C host API (include/luminary_amd.h) on top of the host scene store and the HIP core.
 // Reference behaviour: src/luminary/host/host.c (function by function, cited below), src/luminary/luminary.c:7-31,
 // src/luminary/path.c, src/luminary/error.c. The reference runs these calls through a Host queue thread and a Device queue
-// thread; this implementation applies scene edits immediately on the caller's thread and renders synchronously inside the
-// luminary_ext_* calls (one process drives one GPU; DESIGN.md "Threading").
+// thread. Here scene edits are applied on the caller's thread under the host's mutex, and rendering happens either
+//   * asynchronously, as in the reference: luminary_host_start_new_render starts the host's "Device" worker thread, which renders sample
+//     allocation after sample allocation (restarting by itself whenever an edit dirties the integration) and produces the outputs that
+//     are due, while the frontend only polls luminary_host_try_await_output / luminary_host_acquire_output (mandarin_duck.c:140-244); or
+//   * synchronously inside the additive luminary_ext_render* calls (tests, batch tools), when no render was started.
+// (DESIGN.md "Threading".)
+#include <atomic>
 #include <cmath>
 #include <cfloat>
 #include <chrono>
-#include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <string>
 #include <vector>
@@ -44,6 +50,26 @@ struct LuminaryHost {
   double last_sample_ms = 0.0;  // wall time of the most recent render chunk per sample allocation, in milliseconds (device_sampletime.c)
   std::vector<std::string> log;
   std::mutex mutex;
+  // ---- asynchronous rendering: the "Device" queue worker (device_manager.c:127-148, :874) ----
+  std::thread worker;
+  std::mutex worker_mutex;             // guards the four flags below
+  std::condition_variable worker_cv;
+  bool worker_started = false, worker_stop = false;
+  bool async_active = false;           // a render was started and not stopped
+  bool async_failed = false;           // the last iteration failed: wait for the next edit or start instead of spinning
+  std::atomic<int> api_waiting{0};     // callers waiting for `mutex`: the worker lets them in between two iterations
+  LuminaryThreadStatus* status_host = nullptr;    // queue worker 0 "Host" (edits are applied on the caller's thread: always idle)
+  LuminaryThreadStatus* status_device = nullptr;  // queue worker 1 "Device"
+};
+
+// Lock of the host's mutex taken by API calls: announces itself so that the render worker, which would otherwise re-take the mutex at
+// once, yields between two iterations (std::mutex makes no fairness promise).
+struct ApiLock {
+  LuminaryHost* h;
+  explicit ApiLock(LuminaryHost* host) : h(host) { h->api_waiting.fetch_add(1); h->mutex.lock(); h->api_waiting.fetch_sub(1); }
+  ~ApiLock() { h->mutex.unlock(); }
+  ApiLock(const ApiLock&) = delete;
+  ApiLock& operator=(const ApiLock&) = delete;
 };
 
 namespace {
@@ -55,7 +81,11 @@ std::vector<uint32_t> embedded_bluenoise() {
   return v;
 }
 
-void invalidate(LuminaryHost* h) { h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false; }
+void invalidate(LuminaryHost* h) {
+  h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false;
+  { std::lock_guard<std::mutex> l(h->worker_mutex); h->async_failed = false; }  // the edit may have repaired what failed
+  h->worker_cv.notify_all();
+}
 
 #define CHECK_NULL(p) do { if (!(p)) return LUMINARY_ERROR_ARGUMENT_NULL; } while (0)
 
@@ -169,23 +199,101 @@ LuminaryResult luminary_host_create(LuminaryHost** host, LuminaryHostCreateInfo 
   if (info.device_mask != 0) while (!((info.device_mask >> ordinal) & 1u) && ordinal < 31) ordinal++;
   if (const char* lr = std::getenv("LOCAL_RANK")) { if (info.device_mask == LUMINARY_HOST_CREATE_INFO_DEVICE_MASK_ALL_DEVICES) ordinal = std::atoi(lr); }
   h->device_ordinal = ordinal;
+  // the reference names its queue workers "Host", "Device" and "Worker n" (host.c:318-330, device_manager.c:874)
+  if (thread_status_create(&h->status_host) || thread_status_create(&h->status_device)) { delete h; return LUMINARY_ERROR_OUT_OF_MEMORY; }
+  thread_status_set_worker_name(h->status_host, "Host");
+  thread_status_set_worker_name(h->status_device, "Device");
   *host = h;
   return LUMINARY_SUCCESS;
 }
+
+namespace {
+void stop_worker(LuminaryHost* h, bool join) {
+  {
+    std::lock_guard<std::mutex> l(h->worker_mutex);
+    h->async_active = false;
+    if (join) h->worker_stop = true;
+  }
+  h->worker_cv.notify_all();
+  if (join && h->worker_started) { h->worker.join(); h->worker_started = false; }
+  else { ApiLock wait_for_the_running_iteration(h); }
+}
+
+// The "Device" worker: one iteration = the next sample allocations of the running accumulation (luminary_ext_render, which also rebuilds
+// the scene after an edit and produces the outputs that are due). Small chunks first, so that the first images of a new accumulation
+// appear quickly, then 8 sample ids per wavefront pass.
+void worker_main(LuminaryHost* h) {
+  for (;;) {
+    {
+      std::unique_lock<std::mutex> l(h->worker_mutex);
+      h->worker_cv.wait(l, [&] { return h->worker_stop || (h->async_active && !h->async_failed); });
+      if (h->worker_stop) break;
+    }
+    while (h->api_waiting.load() > 0) std::this_thread::yield();  // edits first
+    uint32_t accumulated;
+    bool scene_ready;
+    { ApiLock lock(h); accumulated = h->accumulated_samples; scene_ready = h->core_scene_valid; }
+    if (accumulated >= (1u << 20)) {  // every sample id is used up (MAX_NUM_GLOBAL_SAMPLES, device_utils.h:39): idle until the next edit
+      std::unique_lock<std::mutex> l(h->worker_mutex);
+      h->worker_cv.wait_for(l, std::chrono::milliseconds(50));
+      continue;
+    }
+    thread_status_start(h->status_device, scene_ready ? "Rendering" : "Updating scene");
+    const uint32_t chunk = accumulated < 1u ? 1u : (accumulated < 8u ? accumulated : 8u);
+    const LuminaryResult r = luminary_ext_render(h, chunk);
+    thread_status_stop(h->status_device);
+    if (r != LUMINARY_SUCCESS) {
+      std::fprintf(stderr, "[luminary_amd] render worker: %s; waiting for the next scene edit or luminary_host_start_new_render\n", luminary_result_to_string(r));
+      std::lock_guard<std::mutex> l(h->worker_mutex);
+      h->async_failed = true;
+    }
+  }
+}
+}  // namespace
+
 LuminaryResult luminary_host_destroy(LuminaryHost** host) {
   CHECK_NULL(host); CHECK_NULL(*host);
+  stop_worker(*host, true);
   if ((*host)->core) lumc_context_destroy((*host)->core);
+  thread_status_destroy(&(*host)->status_host);
+  thread_status_destroy(&(*host)->status_device);
   delete *host;
   *host = nullptr;
   return LUMINARY_SUCCESS;
 }
 
-// host.c:406-414: restarts integration
+// host.c:406-414: marks the integration dirty, i.e. the accumulation restarts; the reference's Device thread then renders until the host
+// is destroyed. Here this call is what starts the "Device" worker (both modes of Mandarin Duck call it before polling for outputs,
+// mandarin_duck.c:153, :200).
 LuminaryResult luminary_host_start_new_render(LuminaryHost* host) {
   CHECK_NULL(host);
-  std::lock_guard<std::mutex> lock(host->mutex);
-  host->accumulated_samples = 0;
-  if (host->core && host->num_pixels) lumc_clear_accumulators(host->core);
+  {
+    ApiLock lock(host);
+    host->accumulated_samples = 0;
+    host->render_seconds = 0.0;
+    host->adaptive_active = false;
+    if (host->core && host->num_pixels) lumc_clear_accumulators(host->core);
+  }
+  {
+    std::lock_guard<std::mutex> l(host->worker_mutex);
+    host->async_active = true;
+    host->async_failed = false;
+    if (!host->worker_started) { host->worker_stop = false; host->worker = std::thread(worker_main, host); host->worker_started = true; }
+  }
+  host->worker_cv.notify_all();
+  return LUMINARY_SUCCESS;
+}
+// Additive: stops the asynchronous rendering started by luminary_host_start_new_render (returns once the running iteration has ended); the
+// accumulated frame stays. The luminary_ext_render* calls drive the same loop synchronously afterwards.
+LuminaryResult luminary_ext_stop_render(LuminaryHost* host) {
+  CHECK_NULL(host);
+  stop_worker(host, false);
+  return LUMINARY_SUCCESS;
+}
+LuminaryResult luminary_ext_is_rendering(LuminaryHost* host, bool* rendering, uint32_t* accumulated_samples) {
+  CHECK_NULL(host);
+  { std::lock_guard<std::mutex> l(host->worker_mutex); if (rendering) *rendering = host->async_active && !host->async_failed; }
+  if (accumulated_samples) { ApiLock lock(host); *accumulated_samples = host->accumulated_samples; }
   return LUMINARY_SUCCESS;
 }
 
@@ -210,7 +318,7 @@ LuminaryResult luminary_host_shutdown_device(LuminaryHost* host, uint32_t index)
 // host.c:35-100 (+ :472-532)
 LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* path) {
   CHECK_NULL(host); CHECK_NULL(path);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   lum::HostMesh mesh;
   std::vector<LuminaryMaterial> mats;
   std::vector<std::string> warnings;
@@ -232,25 +340,35 @@ LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* pat
 // host.c:534-605
 LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* path) {
   CHECK_NULL(host); CHECK_NULL(path);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   lum::LumFileContent content;
   lum::default_settings(&content.settings); lum::default_camera(&content.camera); lum::default_ocean(&content.ocean); lum::default_sky(&content.sky);
   lum::default_cloud(&content.cloud); lum::default_fog(&content.fog); lum::default_particles(&content.particles);
   std::vector<std::string> warnings;
   std::string err;
   if (!lum::load_lum_v4(path->value, &content, &warnings, &err)) { std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
+  // every mesh file is read before anything is committed: a file that fails to load leaves the host's scene exactly as it was
+  std::vector<lum::HostMesh> new_meshes;
+  std::vector<LuminaryMaterial> new_materials;
+  std::vector<lum::HostTexture> new_textures;
   for (const std::string& obj : content.obj_files) {
     lum::HostMesh mesh;
     std::vector<LuminaryMaterial> mats;
     std::vector<lum::HostTexture> textures;
-    if (!lum::load_obj(lum::extend_path(path->value, obj), content.obj_args, (uint32_t) host->scene.materials.size(), &mesh, &mats, &warnings, &err, &textures, (uint32_t) host->scene.textures.size())) {
+    if (!lum::load_obj(lum::extend_path(path->value, obj), content.obj_args, (uint32_t) (host->scene.materials.size() + new_materials.size()), &mesh, &mats, &warnings, &err, &textures,
+                       (uint32_t) (host->scene.textures.size() + new_textures.size()))) {
       std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str());
       return LUMINARY_ERROR_API_EXCEPTION;
     }
+    new_materials.insert(new_materials.end(), mats.begin(), mats.end());
+    for (auto& t : textures) new_textures.push_back(std::move(t));
+    new_meshes.push_back(std::move(mesh));
+  }
+  host->scene.materials.insert(host->scene.materials.end(), new_materials.begin(), new_materials.end());
+  for (auto& t : new_textures) host->scene.textures.push_back(std::move(t));
+  for (auto& m : new_meshes) {
     const uint32_t mesh_id = (uint32_t) host->scene.meshes.size();
-    host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
-    for (auto& t : textures) host->scene.textures.push_back(std::move(t));
-    host->scene.meshes.push_back(std::move(mesh));
+    host->scene.meshes.push_back(std::move(m));
     lum::HostInstance inst;
     inst.mesh_id = mesh_id;
     host->scene.instances.push_back(inst);
@@ -265,11 +383,29 @@ LuminaryResult luminary_host_load_lum_file(LuminaryHost* host, LuminaryPath* pat
 
 // host.c:607-613 -> sample_time_get_time (device_sampletime.c:32-45): with one device, the time its latest sample took (milliseconds; 0 before the first)
 LuminaryResult luminary_host_get_current_sample_time(LuminaryHost* host, double* time) { CHECK_NULL(host); CHECK_NULL(time); *time = host->last_sample_ms; return LUMINARY_SUCCESS; }
-// host.c:615-703: no queue-worker threads exist in this implementation
-LuminaryResult luminary_host_get_num_queue_workers(const LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = 0; return LUMINARY_SUCCESS; }
-LuminaryResult luminary_host_get_queue_worker_name(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
-LuminaryResult luminary_host_get_queue_worker_string(const LuminaryHost* host, uint32_t id, const char** string) { CHECK_NULL(host); CHECK_NULL(string); (void) id; *string = nullptr; return LUMINARY_SUCCESS; }
-LuminaryResult luminary_host_get_queue_worker_time(const LuminaryHost* host, uint32_t id, double* time) { CHECK_NULL(host); CHECK_NULL(time); (void) id; *time = 0.0; return LUMINARY_SUCCESS; }
+// host.c:615-703. Two queue workers exist here: 0 "Host" (scene edits are applied on the caller's thread, so it never reports a task) and
+// 1 "Device", the render worker, with what it is doing and for how long (thread_status.h). The reference adds 16 "Worker n" threads that
+// load mesh files in parallel (host.c:15-20); files are loaded on the caller's thread here.
+LuminaryResult luminary_host_get_num_queue_workers(const LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = 2; return LUMINARY_SUCCESS; }
+static LuminaryThreadStatus* queue_worker_status(const LuminaryHost* host, uint32_t id) { return id == 0 ? host->status_host : id == 1 ? host->status_device : nullptr; }
+LuminaryResult luminary_host_get_queue_worker_name(const LuminaryHost* host, uint32_t id, const char** string) {
+  CHECK_NULL(host); CHECK_NULL(string);
+  LuminaryThreadStatus* st = queue_worker_status(host, id);
+  if (!st) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  return thread_status_get_worker_name(st, string);
+}
+LuminaryResult luminary_host_get_queue_worker_string(const LuminaryHost* host, uint32_t id, const char** string) {
+  CHECK_NULL(host); CHECK_NULL(string);
+  LuminaryThreadStatus* st = queue_worker_status(host, id);
+  if (!st) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  return thread_status_get_string(st, string);
+}
+LuminaryResult luminary_host_get_queue_worker_time(const LuminaryHost* host, uint32_t id, double* time) {
+  CHECK_NULL(host); CHECK_NULL(time);
+  LuminaryThreadStatus* st = queue_worker_status(host, id);
+  if (!st) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  return thread_status_get_time(st, time);
+}
 
 // ---- output chain (host.c:930-1075, host_output_handler.c, device_output.c:178-343) ----
 // Rendering is synchronous here (luminary_ext_render_samples), so outputs are produced on the caller's thread right after the pass
@@ -292,7 +428,7 @@ LuminaryResult luminary_host_release_output(LuminaryHost* host, LuminaryOutputHa
 // here the pixel's first-sample camera ray is traced on demand, which gives the same fields at any time.
 LuminaryResult luminary_host_get_pixel_info(LuminaryHost* host, uint16_t x, uint16_t y, LuminaryPixelQueryResult* result) {
   CHECK_NULL(host); CHECK_NULL(result);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   std::memset(result, 0, sizeof(*result));
   result->instance_id = 0xFFFFFFFFu; result->material_id = 0xFFFF; result->depth = -1.0f;  // DEPTH_INVALID / MATERIAL_ID_INVALID, utils.h:30-33
   if (ensure_core(host)) return LUMINARY_SUCCESS;  // no device: the query has no data, like a G-buffer that is not ready
@@ -330,7 +466,7 @@ LuminaryResult luminary_host_save_png(LuminaryHost* host, LuminaryOutputHandle h
 LuminaryResult luminary_ext_add_texture(LuminaryHost* host, const uint8_t* rgba8, uint32_t width, uint32_t height, float gamma, uint16_t* texture_id) {
   CHECK_NULL(host); CHECK_NULL(rgba8); CHECK_NULL(texture_id);
   if (width == 0 || height == 0 || host->scene.textures.size() >= 0xFFFF) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   lum::HostTexture t;
   t.width = width; t.height = height; t.gamma = gamma;
   t.texels.resize((size_t) width * height);
@@ -344,7 +480,7 @@ LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, u
 // host.c:1077-1084 -> scene_set_hdri_dirty (scene.c:712-722): the panorama is baked again, seen from the camera's current position
 LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
   CHECK_NULL(host);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   host->hdri_origin_pending = true;
   invalidate(host);
   return LUMINARY_SUCCESS;
@@ -354,13 +490,13 @@ LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
 #define ENTITY_ACCESSORS(NAME, TYPE, FIELD)                                                             \
   LuminaryResult luminary_host_get_##NAME(LuminaryHost* host, TYPE* out) {                              \
     CHECK_NULL(host); CHECK_NULL(out);                                                                  \
-    std::lock_guard<std::mutex> lock(host->mutex);                                                      \
+    ApiLock lock(host);                                                      \
     *out = host->scene.FIELD;                                                                           \
     return LUMINARY_SUCCESS;                                                                            \
   }                                                                                                     \
   LuminaryResult luminary_host_set_##NAME(LuminaryHost* host, const TYPE* in) {                         \
     CHECK_NULL(host); CHECK_NULL(in);                                                                   \
-    std::lock_guard<std::mutex> lock(host->mutex);                                                      \
+    ApiLock lock(host);                                                      \
     if (std::memcmp(&host->scene.FIELD, in, sizeof(TYPE)) != 0) {                                       \
       const bool restarts = change_restarts(*in, host->scene.FIELD);                                    \
       host->scene.FIELD = *in;                                                                          \
@@ -379,14 +515,14 @@ ENTITY_ACCESSORS(particles, LuminaryParticles, particles)
 
 LuminaryResult luminary_host_get_material(LuminaryHost* host, uint16_t id, LuminaryMaterial* material) {
   CHECK_NULL(host); CHECK_NULL(material);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (id >= host->scene.materials.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   *material = host->scene.materials[id];
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_host_set_material(LuminaryHost* host, uint16_t id, const LuminaryMaterial* material) {
   CHECK_NULL(host); CHECK_NULL(material);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (id >= host->scene.materials.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   host->scene.materials[id] = *material;
   host->scene.materials[id].id = id;
@@ -395,7 +531,7 @@ LuminaryResult luminary_host_set_material(LuminaryHost* host, uint16_t id, const
 }
 LuminaryResult luminary_host_get_instance(LuminaryHost* host, uint32_t id, LuminaryInstance* instance) {
   CHECK_NULL(host); CHECK_NULL(instance);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (id >= host->scene.instances.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   const lum::HostInstance& i = host->scene.instances[id];
   instance->id = id; instance->mesh_id = i.mesh_id; instance->position = i.translation; instance->rotation = i.rotation; instance->scale = i.scale;
@@ -403,7 +539,7 @@ LuminaryResult luminary_host_get_instance(LuminaryHost* host, uint32_t id, Lumin
 }
 LuminaryResult luminary_host_set_instance(LuminaryHost* host, const LuminaryInstance* instance) {
   CHECK_NULL(host); CHECK_NULL(instance);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (instance->id >= host->scene.instances.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   lum::HostInstance& i = host->scene.instances[instance->id];
   i.mesh_id = instance->mesh_id; i.translation = instance->position; i.rotation = instance->rotation; i.scale = instance->scale; i.active = true;
@@ -413,7 +549,7 @@ LuminaryResult luminary_host_set_instance(LuminaryHost* host, const LuminaryInst
 // host.c:902-930: writes defaults and the new id back to the caller
 LuminaryResult luminary_host_new_instance(LuminaryHost* host, LuminaryInstance* instance) {
   CHECK_NULL(host); CHECK_NULL(instance);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   lum::HostInstance i;
   i.mesh_id = 0;
   host->scene.instances.push_back(i);
@@ -430,7 +566,7 @@ LuminaryResult luminary_host_get_num_instances(LuminaryHost* host, uint32_t* n) 
 LuminaryResult luminary_ext_add_mesh(LuminaryHost* host, const float* positions, const float* normals, const float* uvs, const uint16_t* material_ids,
                                      uint32_t triangle_count, uint32_t* mesh_id) {
   CHECK_NULL(host); CHECK_NULL(positions); CHECK_NULL(material_ids);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   lum::HostMesh m;
   m.positions.assign(positions, positions + 9 * (size_t) triangle_count);
   m.material_ids.assign(material_ids, material_ids + triangle_count);
@@ -454,7 +590,7 @@ LuminaryResult luminary_ext_add_mesh(LuminaryHost* host, const float* positions,
 }
 LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id) {
   CHECK_NULL(host); CHECK_NULL(material);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (host->scene.materials.size() >= 0xFFFF) return LUMINARY_ERROR_API_EXCEPTION;
   host->scene.materials.push_back(*material);
   host->scene.materials.back().id = (uint32_t) host->scene.materials.size() - 1;
@@ -464,7 +600,7 @@ LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMater
 }
 LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const LumDeviceSceneView** view) {
   CHECK_NULL(host); CHECK_NULL(view);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   const LuminaryResult r = ensure_device_scene(host);
   if (r) return r;
   *view = &host->device_scene.view;
@@ -570,7 +706,7 @@ LuminaryResult produce_outputs(LuminaryHost* h, PreviewState preview = PreviewSt
 LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
                                            uint32_t samples_per_pass) {
   CHECK_NULL(host);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   LuminaryResult r = ensure_core(host);
   if (r) return r;
   const bool all = pixels == nullptr;
@@ -628,11 +764,13 @@ static LuminaryResult render_first_sample_as_preview(LuminaryHost* host, bool* r
 // settings.enable_adaptive_sampling the stage schedule of the adaptive sampler, otherwise one sample id per pixel and allocation.
 LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
   CHECK_NULL(host);
-  const LuminaryRendererSettings settings = host->scene.settings;
+  LuminaryRendererSettings settings;
+  { ApiLock lock(host); settings = host->scene.settings; }
   if (!settings.enable_adaptive_sampling) {
-    uint32_t first = host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0;
+    uint32_t first;
+    { ApiLock lock(host); first = host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0; }
     if (first == 0 && num_samples > 0) {  // a new accumulation: its first sample may be due as the undersampling preview
-      std::lock_guard<std::mutex> lock(host->mutex);
+      ApiLock lock(host);
       const LuminaryResult r = ensure_core(host);
       if (r) return r;
       if (!preview_schedule(host).empty()) {
@@ -650,7 +788,7 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
     }
     return luminary_ext_render_samples(host, nullptr, 0, first, num_samples, 8);
   }
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   LuminaryResult r = ensure_core(host);
   if (r) return r;
   if (!host->adaptive_active) {
@@ -698,7 +836,7 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
 }
 LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels) {
   CHECK_NULL(host);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (num_pixels) *num_pixels = host->num_pixels;
   if (!host->core || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
   if ((first_moment || second_moment) && lumc_download_accumulators(host->core, first_moment, second_moment)) return LUMINARY_ERROR_CUDA;
@@ -706,7 +844,7 @@ LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_mo
 }
 LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_t* sample_count, uint32_t width, uint32_t height) {
   CHECK_NULL(host); CHECK_NULL(rgb);
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (!host->core || !host->pixels_all || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
   const LumDeviceSceneView& v = host->device_scene.view;
   if (width != v.width || height != v.height) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
@@ -756,7 +894,7 @@ LuminaryResult luminary_ext_change_restarts_integration(int entity, const void* 
 }
 void* luminary_ext_get_core_context(LuminaryHost* host) {
   if (!host) return nullptr;
-  std::lock_guard<std::mutex> lock(host->mutex);
+  ApiLock lock(host);
   if (ensure_core(host)) return nullptr;
   return host->core;
 }

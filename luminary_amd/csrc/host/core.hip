@@ -781,6 +781,15 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
   int cur = 0;
   const WavefrontKernels& wf = *ctx->wf;
+  if (sc.shading_mode != 0u) {  // debug shading modes: one closest-hit pass and a colour per path (device_renderer.c:136-181)
+    {
+      Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+      wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[0], nullptr, ctx->d_ctrl, ctx->d_counters, ctx->lds_nodes);
+    }
+    Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+    wf.shade_debug(grid_for(N), stream, sc, ctx->queue[0], ctx->d_results, (const uint32_t*) ctx->d_ctrl);
+    return 0;
+  }
   for (uint32_t depth = 0; depth <= max_depth; depth++) {
     // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
     const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;

@@ -173,7 +173,60 @@ static bool russian_roulette(const OracleScene* s, const Sampler* smp, uint16_t 
   return true;
 }
 
+/* Debug shading modes: one closest-hit pass, then a colour per hit (geometry_process_tasks_debug, cuda/geometry.cuh:182-246) or per miss
+ * (sky_process_tasks_debug, cuda/sky.cuh:635-665); queue: device/device_renderer.c:136-181. */
+static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
+  Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
+  RGBF result = c_splat(0.0f);
+  vec3 origin, ray;
+  camera_sample(s, &smp, &origin, &ray);
+  const uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
+  const uint32_t medium = medium_ior_modify(0, 1.0f, true);
+  const OHit hit = trace_closest(tr, origin, ray, false, 0, 0);
+  cnt[ORACLE_CNT_TRACE]++;
+  if (hit.instance_id == HIT_TYPE_SKY) {
+    if (s->shading_mode == 1) { /* ALBEDO: sky_color_main(origin, ray, STATE_FLAG_CAMERA_DIRECTION) */
+      RGBF sky = c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]);
+      if (s->sky_mode == SKY_MODE_DEFAULT) {
+        sky = c_splat(0.0f);
+        if (s->sky_lut_transmittance && s->sky_lut_multiscattering) {
+          const OSky view = osky_view(s);
+          sky = sky_get_color(&view, world_to_sky(&view, origin), ray, FLT_MAX, true, (int) view.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET));
+        }
+      }
+      else if (s->sky_mode == SKY_MODE_HDRI) sky = sky_hdri_color(s, origin, ray, ST_CAMERA_DIRECTION);
+      beauty_add(&result, sky);
+    }
+    else if (s->shading_mode == 4) beauty_add(&result, c3(0.0f, 0.63f, 1.0f)); /* IDENTIFICATION */
+    return result;
+  }
+  cnt[ORACLE_CNT_VERTICES]++;
+  const vec3 hit_origin = v_add(origin, v_scale(ray, hit.t));
+  switch (s->shading_mode) {
+    case 1: { /* ALBEDO */
+      const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
+      beauty_add(&result, c_add(mp_albedo(&g.params), mp_emission(&g.params)));
+    } break;
+    case 2: beauty_add(&result, c_splat(o_saturate((1.0f / hit.t) * 2.0f))); break; /* DEPTH */
+    case 3: { /* NORMAL */
+      const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
+      beauty_add(&result, c3(o_saturate(g.normal.x), o_saturate(g.normal.y), o_saturate(g.normal.z)));
+    } break;
+    case 4: { /* IDENTIFICATION */
+      const uint32_t v = squares32(0x55555555u, (hit.instance_id << 16) | hit.tri_id);
+      beauty_add(&result, c3(((float) (v & 0x7ffu)) / 0x7ff, ((float) ((v >> 10) & 0x7ffu)) / 0x7ff, ((float) ((v >> 20) & 0x7ffu)) / 0x7ff));
+    } break;
+    case 5: { /* LIGHTS */
+      const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
+      beauty_add(&result, c_add(c_scale(mp_albedo(&g.params), 0.025f), mp_emission(&g.params)));
+    } break;
+    default: break;
+  }
+  return result;
+}
+
 static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
+  if (s->shading_mode != 0) return render_path_debug(s, tr, px, py, sample_id, cnt);
   const OLuts luts = scene_luts(s);
   const bool lights_present = s->light_tree_root != NULL && s->num_lights > 0;
   Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};

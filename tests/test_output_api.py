@@ -195,6 +195,109 @@ def test_c_frontend_renders_the_same_png_as_the_python_binding(tmp_path):
     assert _decode_png(str(tmp_path / "c.png")).shape == (s.height, s.width, 4)
 
 
+def _build_unchanged_frontend(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    luminary_amd._lib()
+    exe = str(tmp_path / "lum_bench")
+    lib_dir = os.path.join(root, "luminary_amd", "lib")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "luminary_bench_unchanged.c"), "-L",
+                           lib_dir, "-lluminary_amd", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_unchanged_frontend_compiles_against_the_forwarding_headers(tmp_path):
+    """examples/luminary_bench_unchanged.c is Mandarin Duck's benchmark loop written against <luminary/*.h> and the reference's functions
+    only (no luminary_ext_*): include/luminary/ forwards every header of the reference's include/luminary/ to luminary_amd.h."""
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for name in ("luminary", "host", "structs", "error", "path", "api_utils", "array", "queue", "ringbuffer", "host_memory", "log", "thread_status", "name_strings"):
+        assert os.path.exists(os.path.join(root, "include", "luminary", name + ".h")), name
+    exe = _build_unchanged_frontend(tmp_path)
+    assert os.path.exists(exe)
+    src = open(os.path.join(root, "examples", "luminary_bench_unchanged.c")).read()
+    assert "luminary_ext_" not in src.split("*/", 1)[1]
+
+
+def test_queue_workers_are_named_like_the_reference(tmp_path):
+    host = luminary_amd.Host()
+    workers = host.queue_workers()
+    assert [w[0] for w in workers] == ["Host", "Device"] and all(w[1] is None for w in workers)
+
+
+@pytest.mark.gpu
+def test_unchanged_frontend_renders_on_the_library_thread(tmp_path):
+    """The benchmark loop of an unchanged frontend: request outputs at 1, 2, 3, 4, 6, 8 samples, luminary_host_start_new_render, poll
+    luminary_host_try_await_output. The library's Device worker renders; every requested image arrives, with the bytes the synchronous
+    loop produces for the same sample count (default .lum settings: adaptive sampling on, supersampling 1)."""
+    import subprocess
+    exe = _build_unchanged_frontend(tmp_path)
+    scenes.cornell_box_files(str(tmp_path), 48, 32, 3)
+    lum = str(tmp_path / "cornell.lum")
+    out = tmp_path / "out"
+    out.mkdir()
+    r = subprocess.run([exe, lum, "3", "cornell", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [l.split(",") for l in open(str(out / "BenchResults-cornell.txt")).read().strip().split("\n")]
+    assert sorted(int(l[0]) for l in lines) == [1, 2, 3, 4, 6, 8]
+    assert "queue worker 1: Device" in r.stdout and "queue worker 0: Host" in r.stdout
+    host = luminary_amd.Host()
+    host.load_lum_file(lum)
+    s = host.get_settings()
+    host.set_output_properties(0, 0, enabled=False)
+    for count, more in ((3, 3), (8, 5)):
+        promise = host.request_output(count, s.width, s.height)
+        host.render(more)
+        handle = host.try_await_output(promise)
+        host.save_png(handle, str(tmp_path / ("py%d.png" % count)))
+        assert open(str(out / ("Bench-%05d-cornell.png" % count)), "rb").read() == open(str(tmp_path / ("py%d.png" % count)), "rb").read(), count
+
+
+@pytest.mark.gpu
+def test_render_thread_restarts_on_edits_and_stops(tmp_path):
+    """luminary_host_start_new_render starts the Device worker; images keep arriving through luminary_host_acquire_output; a camera move
+    restarts the accumulation by itself; luminary_ext_stop_render hands control back to the synchronous calls."""
+    import time
+    w, h = 48, 32
+    host = scenes.cornell_host(str(tmp_path), w, h, 2)
+    host.set_output_properties(w, h)
+    host.start_new_render()
+    deadline = time.time() + 60
+    count = 0
+    while count < 12 and time.time() < deadline:
+        handle = host.acquire_output()
+        if handle is not None:
+            _, count, _ = host.get_image(handle)
+            host.release_output(handle)
+        time.sleep(0.002)
+    assert count >= 12, "the render thread keeps accumulating"
+    assert host.is_rendering()[0]
+    cam = host.get_camera()
+    cam.pos.x += 0.05
+    host.set_camera(cam)  # dirties the integration: the worker starts over on its own
+    seen_restart = False
+    deadline = time.time() + 60
+    while time.time() < deadline and not seen_restart:
+        handle = host.acquire_output()
+        if handle is not None:
+            _, c2, _ = host.get_image(handle)
+            host.release_output(handle)
+            seen_restart = c2 < count
+        time.sleep(0.001)
+    assert seen_restart, "a camera move restarts the accumulation"
+    host.stop_render()
+    running, n = host.is_rendering()
+    assert not running
+    time.sleep(0.05)
+    assert host.is_rendering()[1] == n, "nothing renders after luminary_ext_stop_render"
+    # the accumulated frame is the deterministic one: n samples of the moved camera
+    view = oracle_lib.with_luts(host.device_scene())
+    fm, _ = host.accumulators()
+    ofm, _, _ = oracle_lib.render(view, 0, n)
+    assert np.array_equal(fm, ofm), "asynchronously rendered frame == oracle at %d samples" % n
+
+
 @pytest.mark.gpu
 def test_output_only_changes_keep_the_accumulated_frame(tmp_path):
     """camera.c:80-147: exposure, tone curve, filter, bloom ... only change how the frame is shown (SCENE_DIRTY_FLAG_OUTPUT); moving the
