@@ -33,6 +33,11 @@ constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
 #endif
+// The constant-colour-sky instantiation of the fast flavour is compiled for 3 waves per SIMD: 168 VGPRs with 25 of them spilled to scratch
+// still runs 4 % faster than 196 VGPRs at 2 waves (hall 154.3 -> 148.0 ms per 3 steps); the instantiations with sun sampling would spill 56-63.
+#ifndef LUM_SHADE_WAVES_CONSTANT_SKY
+#define LUM_SHADE_WAVES_CONSTANT_SKY (LUM_FAST ? 3 : LUM_SHADE_WAVES)
+#endif
 
 LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
                          uint32_t lds_counter = kCntCount) {
@@ -225,7 +230,7 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 // texel + sun disk; CONSTANT: the colour), whether the bounce direction is an ambient sample (not DEFAULT), and whether the sun is
 // sampled (not CONSTANT).
 template <uint32_t kSkyMode>
-__global__ __launch_bounds__(kBlock, LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
+__global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
