@@ -173,18 +173,32 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     pixels = tile_pixels(view.width, view.height, rank, world) if world > 1 else None
     core.set_pixels(pixels)
     P = core.num_pixels
-    fm = torch.zeros(3 * P, dtype=torch.float32, device="cuda")
-    sm = torch.zeros(P, dtype=torch.float32, device="cuda")
+    frame_pixels = view.width * view.height
     stream = torch.cuda.current_stream().cuda_stream
     spp_step = args.samples_per_pass * world  # per-GPU paths per step stay W*H*samples_per_pass
+    cabi = dist is not None and getattr(core, "_bench_comm", False)  # the library's own communicator is up (main): reduce behind the C ABI
+    if cabi:
+        fm = sm = None  # the context's own accumulators; lumc_frame_assemble scatters and reduces them
 
-    def step(i):
-        core.render(i * spp_step, spp_step, spp_step, fm.data_ptr(), sm.data_ptr(), stream)
+        def step(i):
+            core.render(i * spp_step, spp_step, spp_step, 0, 0, stream)
+
+        def assemble():
+            core.frame_assemble(frame_pixels, 0, stream)
+    else:
+        fm = torch.zeros(3 * P, dtype=torch.float32, device="cuda")
+        sm = torch.zeros(P, dtype=torch.float32, device="cuda")
+
+        def step(i):
+            core.render(i * spp_step, spp_step, spp_step, fm.data_ptr(), sm.data_ptr(), stream)
+
+        def assemble():
+            assemble_frame(fm, sm, pixels, frame_pixels, dist, 0)
 
     for i in range(warmup):
         step(i)
     if dist is not None:
-        assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)  # untimed: creates the RCCL communicator and its buffers
+        assemble()  # untimed: first use of the communicator and its buffers
     torch.cuda.synchronize()
     core.synchronize()
     core.reset_counters()
@@ -197,8 +211,9 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         step(warmup + i)
     if dist is not None:
         # assemble the frame on rank 0: every rank scatters its pixels into a zero frame, one reduce over xGMI
-        assemble_frame(fm, sm, pixels, view.width * view.height, dist, 0)
+        assemble()
     torch.cuda.synchronize()
+    core.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -282,6 +297,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "ray_sorting": core.ray_sorting,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
+                   "frame_reduce": None if world == 1 else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
@@ -309,6 +325,8 @@ def main():
     ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
+    ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
+                    help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
     ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
                     help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")
@@ -338,6 +356,18 @@ def main():
         core.set_flavour(args.flavour)
     if args.sort is not None:
         core.set_ray_sorting(args.sort)
+    if dist is not None and args.reduce == "cabi":
+        # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes to the other ranks
+        try:
+            ids = [Core.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            core.comm_init_rank(world, rank, ids[0])
+            ok = torch.ones(1, device="cuda")
+        except Exception as e:  # noqa: BLE001 - any failure here falls back to torch's reduce, on every rank
+            sys.stderr.write("rank %d: C-ABI communicator failed (%s); torch.distributed reduces instead\n" % (rank, e))
+            ok = torch.zeros(1, device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        core._bench_comm = bool(ok.item() > 0)
     head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True)
     # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
     cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1 and args.sky == "constant" and rank == 0) else None

@@ -88,6 +88,11 @@ class PixelQueryResult(C.Structure):
     _fields_ = [("pixel_query_is_valid", C.c_bool), ("instance_id", C.c_uint32), ("material_id", C.c_uint16), ("depth", C.c_float), ("rel_hit_pos", Vec3)]
 
 
+class DeviceInfo(C.Structure):
+    _fields_ = [("is_main_device", C.c_bool), ("is_unavailable", C.c_bool), ("is_enabled", C.c_bool), ("name", C.c_char * 256), ("memory_size", C.c_size_t),
+                ("allocated_memory_size", C.c_size_t)]
+
+
 class OutputProperties(C.Structure):
     _fields_ = [("enabled", C.c_bool), ("width", C.c_uint32), ("height", C.c_uint32)]
 
@@ -308,6 +313,19 @@ class Host:
         """Restarts the accumulation and starts the library's render thread (reference host.c:406-414); poll try_await_output /
         acquire_output for images."""
         _call("luminary_host_start_new_render", self._h)
+
+    def get_device_count(self):
+        n = C.c_uint32()
+        _call("luminary_host_get_device_count", self._h, C.byref(n))
+        return int(n.value)
+
+    def get_device_info(self, device_id):
+        info = DeviceInfo()
+        _call("luminary_host_get_device_info", self._h, C.c_uint32(device_id), C.byref(info))
+        return info
+
+    def set_device_enable(self, device_id, enable):
+        _call("luminary_host_set_device_enable", self._h, C.c_uint32(device_id), C.c_bool(enable))
 
     def stop_render(self):
         _call("luminary_ext_stop_render", self._h)

@@ -96,7 +96,7 @@ def build(force=False, verbose=False):
             if verbose:
                 print(out)
             objs.append(o)
-    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-o", LIB])
+    _run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-lz", "-L", os.path.join(ROCM, "lib"), "-lrccl", "-o", LIB])
     with open(STAMP, "w") as f:
         f.write(_flags_identity())
     return LIB

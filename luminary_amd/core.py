@@ -78,6 +78,47 @@ class Core:
         fn.restype = C.c_int
         return "fast" if fn(self._ctx) == 1 else "exact"
 
+    # ---- multi-GPU (lumc_comm_*, lumc_frame_*) ----
+    @staticmethod
+    def device_count():
+        return int(_lib().lumc_device_count())
+
+    @staticmethod
+    def tile_pixels(width, height, rank, world, tile=32):
+        """The C ABI's tile deal (== luminary_amd.distributed.tile_pixels)."""
+        lib = _lib()
+        n = C.c_uint32()
+        if lib.lumc_tile_pixels(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(world), C.c_uint32(tile), C.c_void_p(0), C.byref(n)):
+            raise CoreError("lumc_tile_pixels: bad arguments")
+        out = np.zeros(max(n.value, 1), dtype=np.uint32)
+        lib.lumc_tile_pixels(C.c_uint32(width), C.c_uint32(height), C.c_uint32(rank), C.c_uint32(world), C.c_uint32(tile), out.ctypes.data_as(C.c_void_p), C.byref(n))
+        return out[:n.value]
+
+    @staticmethod
+    def comm_unique_id():
+        """128 bytes identifying a new RCCL communicator (made on one rank, handed to all)."""
+        buf = (C.c_uint8 * 128)()
+        if _lib().lumc_comm_unique_id(buf):
+            raise CoreError("lumc_comm_unique_id failed")
+        return bytes(buf)
+
+    def comm_init_rank(self, world, rank, unique_id):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._call("lumc_comm_init_rank", C.c_int(world), C.c_int(rank), buf)
+
+    def frame_assemble(self, frame_pixels, root=0, stream=0):
+        """This rank's accumulators scattered into its [4][frame_pixels] frame and reduced (RCCL SUM) to `root`; returns the device pointer of
+        this rank's frame (complete on root)."""
+        ptr = C.c_void_p()
+        self._call("lumc_frame_assemble", C.c_uint32(frame_pixels), C.c_int(root), C.c_void_p(stream), C.byref(ptr))
+        return ptr.value
+
+    def frame_download(self, frame_pixels):
+        fm = np.zeros(3 * frame_pixels, dtype=np.float32)
+        sm = np.zeros(frame_pixels, dtype=np.float32)
+        self._call("lumc_frame_download", C.c_uint32(frame_pixels), fm.ctypes.data_as(C.c_void_p), sm.ctypes.data_as(C.c_void_p))
+        return fm.reshape(3, -1), sm
+
     @property
     def ray_sorting(self):
         fn = self._lib.lumc_get_ray_sorting

@@ -37,8 +37,14 @@ struct LuminaryHost {
   lum::DeviceSceneBuffers device_scene;
   bool device_scene_valid = false;
   bool core_scene_valid = false;
-  LumContext* core = nullptr;
-  int device_ordinal = 0;
+  LumContext* core = nullptr;        // context of the main device: renders (its tiles) and produces every output
+  int device_ordinal = 0;            // HIP ordinal of the main device
+  // every visible device (device_manager.c:776-862 creates one Device per masked id); the frame is tiled over the enabled ones
+  struct DeviceSlot { int ordinal = 0; bool enabled = false; LumContext* core = nullptr; bool scene_valid = false; };
+  std::vector<DeviceSlot> devices;
+  uint32_t main_slot = 0;
+  uint32_t partition_n = 0;          // devices the current accumulation is tiled over (0 or 1: the main device renders every pixel)
+  bool comm_ready = false;           // the slots of the current partition share an RCCL communicator
   std::vector<uint32_t> pixels;  // pixel set of the current accumulation
   bool pixels_all = true;
   uint32_t num_pixels = 0;
@@ -83,6 +89,7 @@ std::vector<uint32_t> embedded_bluenoise() {
 
 void invalidate(LuminaryHost* h) {
   h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false;
+  for (auto& slot : h->devices) slot.scene_valid = false;
   { std::lock_guard<std::mutex> l(h->worker_mutex); h->async_failed = false; }  // the edit may have repaired what failed
   h->worker_cv.notify_all();
 }
@@ -155,6 +162,43 @@ LuminaryResult ensure_core(LuminaryHost* h) {
   return LUMINARY_SUCCESS;
 }
 
+// The enabled devices, main device first. Rendering is tiled over them when the whole frame is rendered uniformly; adaptive sampling, render
+// regions / pixel subsets and the undersampling preview run on the main device alone.
+std::vector<LuminaryHost::DeviceSlot*> enabled_slots(LuminaryHost* h) {
+  std::vector<LuminaryHost::DeviceSlot*> out;
+  if (h->main_slot < h->devices.size()) out.push_back(&h->devices[h->main_slot]);
+  for (uint32_t i = 0; i < h->devices.size(); i++)
+    if (i != h->main_slot && h->devices[i].enabled) out.push_back(&h->devices[i]);
+  return out;
+}
+
+// Contexts with the current scene on every device of the partition; slot 0 of the result is the main device (h->core).
+LuminaryResult ensure_partition_cores(LuminaryHost* h, std::vector<LumContext*>* cores) {
+  const LuminaryResult r = ensure_core(h);
+  if (r) return r;
+  cores->clear();
+  for (LuminaryHost::DeviceSlot* slot : enabled_slots(h)) {
+    if (slot == &h->devices[h->main_slot]) { slot->core = h->core; slot->scene_valid = true; cores->push_back(h->core); continue; }
+    if (!slot->core) {
+      if (lumc_context_create(slot->ordinal, &slot->core)) {
+        std::fprintf(stderr, "[luminary_amd] device %d: %s\n", slot->ordinal, lumc_last_error(slot->core));
+        lumc_context_destroy(slot->core);
+        slot->core = nullptr;
+        return LUMINARY_ERROR_CUDA;
+      }
+      lumc_set_flavour(slot->core, lumc_get_flavour(h->core));
+      slot->scene_valid = false;
+    }
+    if (!slot->scene_valid) {
+      if (lumc_scene_upload(slot->core, &h->device_scene.view)) { std::fprintf(stderr, "[luminary_amd] device %d: %s\n", slot->ordinal, lumc_last_error(slot->core)); return LUMINARY_ERROR_CUDA; }
+      slot->scene_valid = true;
+      h->partition_n = 0;  // its pixel set is gone with the old scene
+    }
+    cores->push_back(slot->core);
+  }
+  return LUMINARY_SUCCESS;
+}
+
 }  // namespace
 
 extern "C" {
@@ -199,6 +243,32 @@ LuminaryResult luminary_host_create(LuminaryHost** host, LuminaryHostCreateInfo 
   if (info.device_mask != 0) while (!((info.device_mask >> ordinal) & 1u) && ordinal < 31) ordinal++;
   if (const char* lr = std::getenv("LOCAL_RANK")) { if (info.device_mask == LUMINARY_HOST_CREATE_INFO_DEVICE_MASK_ALL_DEVICES) ordinal = std::atoi(lr); }
   h->device_ordinal = ordinal;
+  // One slot per visible device; the mask enables them (device_manager.c:791-822), the lowest enabled one is the main device. Under a
+  // one-process-per-GPU launcher (LOCAL_RANK set, default mask) the process drives its own GPU only. LUM_MAX_DEVICES caps the number of
+  // devices a host uses; LUM_FAKE_DEVICES=n (tests on a single-GPU box) presents device 0 n times.
+  {
+    int count = lumc_device_count();
+    const char* fake = std::getenv("LUM_FAKE_DEVICES");
+    const int fake_n = fake ? std::atoi(fake) : 0;
+    if (fake_n > 1 && count >= 1) count = fake_n;
+    int cap = 32;
+    if (const char* e = std::getenv("LUM_MAX_DEVICES")) cap = std::max(1, std::atoi(e));
+    const bool own_gpu_only = std::getenv("LOCAL_RANK") && info.device_mask == LUMINARY_HOST_CREATE_INFO_DEVICE_MASK_ALL_DEVICES;
+    int enabled = 0;
+    for (int i = 0; i < count && i < 32; i++) {
+      LuminaryHost::DeviceSlot slot;
+      slot.ordinal = fake_n > 1 ? 0 : i;
+      slot.enabled = own_gpu_only ? (i == ordinal) : (((info.device_mask >> i) & 1u) != 0 && enabled < cap);
+      if (slot.enabled) enabled++;
+      h->devices.push_back(slot);
+    }
+    if (h->devices.empty()) { LuminaryHost::DeviceSlot slot; slot.ordinal = ordinal; slot.enabled = true; h->devices.push_back(slot); }  // no GPU visible: calls that need one fail later
+    h->main_slot = 0;
+    bool found = false;
+    for (uint32_t i = 0; i < h->devices.size() && !found; i++) if (h->devices[i].enabled) { h->main_slot = i; found = true; }
+    if (!found) { h->devices[0].enabled = true; h->main_slot = 0; }
+    h->device_ordinal = h->devices[h->main_slot].ordinal;
+  }
   // the reference names its queue workers "Host", "Device" and "Worker n" (host.c:318-330, device_manager.c:874)
   if (thread_status_create(&h->status_host) || thread_status_create(&h->status_device)) { delete h; return LUMINARY_ERROR_OUT_OF_MEMORY; }
   thread_status_set_worker_name(h->status_host, "Host");
@@ -254,6 +324,8 @@ void worker_main(LuminaryHost* h) {
 LuminaryResult luminary_host_destroy(LuminaryHost** host) {
   CHECK_NULL(host); CHECK_NULL(*host);
   stop_worker(*host, true);
+  for (uint32_t i = 0; i < (*host)->devices.size(); i++)
+    if (i != (*host)->main_slot && (*host)->devices[i].core) lumc_context_destroy((*host)->devices[i].core);
   if ((*host)->core) lumc_context_destroy((*host)->core);
   thread_status_destroy(&(*host)->status_host);
   thread_status_destroy(&(*host)->status_device);
@@ -297,23 +369,52 @@ LuminaryResult luminary_ext_is_rendering(LuminaryHost* host, bool* rendering, ui
   return LUMINARY_SUCCESS;
 }
 
-// host.c:416-470 - this process drives exactly one device
-LuminaryResult luminary_host_get_device_count(LuminaryHost* host, uint32_t* device_count) { CHECK_NULL(host); CHECK_NULL(device_count); *device_count = 1; return LUMINARY_SUCCESS; }
+// host.c:416-470, device_manager.c:529-572: the visible devices, which of them render, and the main device (renders its tiles and produces
+// every output; re-elected as the lowest enabled device when it is disabled)
+LuminaryResult luminary_host_get_device_count(LuminaryHost* host, uint32_t* device_count) {
+  CHECK_NULL(host); CHECK_NULL(device_count);
+  *device_count = (uint32_t) host->devices.size();
+  return LUMINARY_SUCCESS;
+}
 LuminaryResult luminary_host_get_device_info(LuminaryHost* host, uint32_t device_id, LuminaryDeviceInfo* info) {
   CHECK_NULL(host); CHECK_NULL(info);
-  if (device_id != 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  if (device_id >= host->devices.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  ApiLock lock(host);
   std::memset(info, 0, sizeof(*info));
-  info->is_main_device = true; info->is_enabled = true; info->is_unavailable = false;
-  std::snprintf(info->name, sizeof(info->name), "HIP device %d (gfx950 path-tracing core)", host->device_ordinal);
+  info->is_main_device = device_id == host->main_slot; info->is_enabled = host->devices[device_id].enabled; info->is_unavailable = false;
+  char name[200];
+  if (lumc_device_name(host->devices[device_id].ordinal, name, sizeof(name))) { std::snprintf(name, sizeof(name), "HIP device %d", host->devices[device_id].ordinal); info->is_unavailable = true; }
+  std::snprintf(info->name, sizeof(info->name), "%s", name);
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_host_set_device_enable(LuminaryHost* host, uint32_t device_id, bool enable) {
   CHECK_NULL(host);
-  if (device_id != 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
-  return enable ? LUMINARY_SUCCESS : LUMINARY_ERROR_NOT_IMPLEMENTED;
+  if (device_id >= host->devices.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  ApiLock lock(host);
+  if (host->devices[device_id].enabled == enable) return LUMINARY_SUCCESS;
+  if (!enable) {
+    uint32_t others = 0;
+    for (uint32_t i = 0; i < host->devices.size(); i++) if (i != device_id && host->devices[i].enabled) others++;
+    if (others == 0) return LUMINARY_ERROR_INVALID_API_ARGUMENT;  // "No device could be selected as the main device" (device_manager.c:44-46)
+  }
+  host->devices[device_id].enabled = enable;
+  if (!enable && device_id == host->main_slot) {  // the main device changes: its context (accumulators, outputs in flight) goes with it
+    if (host->core) { lumc_context_destroy(host->core); host->core = nullptr; }
+    host->devices[device_id].core = nullptr;
+    for (uint32_t i = 0; i < host->devices.size(); i++) if (host->devices[i].enabled) { host->main_slot = i; break; }
+    LuminaryHost::DeviceSlot& m = host->devices[host->main_slot];
+    host->device_ordinal = m.ordinal;
+    if (m.core) { host->core = m.core; }  // its render context becomes the main context
+    host->core_scene_valid = false;
+    host->num_pixels = 0;
+  }
+  host->partition_n = 0;
+  host->comm_ready = false;
+  invalidate(host);  // the integration restarts with the new partition
+  return LUMINARY_SUCCESS;
 }
-LuminaryResult luminary_host_start_device(LuminaryHost* host, uint32_t index) { CHECK_NULL(host); return index == 0 ? LUMINARY_SUCCESS : LUMINARY_ERROR_INVALID_API_ARGUMENT; }
-LuminaryResult luminary_host_shutdown_device(LuminaryHost* host, uint32_t index) { CHECK_NULL(host); (void) index; return LUMINARY_ERROR_NOT_IMPLEMENTED; }
+LuminaryResult luminary_host_start_device(LuminaryHost* host, uint32_t index) { return luminary_host_set_device_enable(host, index, true); }
+LuminaryResult luminary_host_shutdown_device(LuminaryHost* host, uint32_t index) { return luminary_host_set_device_enable(host, index, false); }
 
 // host.c:35-100 (+ :472-532)
 LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* path) {
@@ -638,6 +739,7 @@ std::vector<PreviewState> preview_schedule(LuminaryHost* h) {
   std::vector<PreviewState> out;
   const LuminaryRendererSettings& st = h->scene.settings;
   if (!h->outputs.properties().enabled || !(st.region_width >= 1.0f && st.region_height >= 1.0f)) return out;
+  if (enabled_slots(h).size() > 1) return out;  // a tiled render has no coarse first sample: every device starts on its tiles at once
   for (uint32_t stage = st.undersampling & 31u; stage > 0; stage--)
     for (uint32_t it = (stage == (st.undersampling & 31u)) ? 4u : 3u; it-- > 0;) { PreviewState ps; ps.stage = stage; ps.iteration = it; out.push_back(ps); }
   return out;
@@ -673,9 +775,26 @@ int result_image(LuminaryHost* h, LumOutputParams* p, PreviewState preview) {
 
 // device_output_generate_output, device_output.c:203-270: the recurring output if enabled, then every request that is due now
 // `preview`: the state of the iteration just rendered (device.c:1509-1536 generates the output before the state advances).
+// Tiled render: the moments of all devices on the main device (one grouped RCCL reduce; peer copies without a communicator), which the
+// result / output entry points of the main context then read.
+LuminaryResult assemble_partition(LuminaryHost* h) {
+  if (h->partition_n <= 1) return LUMINARY_SUCCESS;
+  std::vector<LumContext*> cores;
+  for (LuminaryHost::DeviceSlot* slot : enabled_slots(h)) if (slot->core) cores.push_back(slot->core);
+  if (cores.size() != h->partition_n || cores[0] != h->core) return LUMINARY_ERROR_API_EXCEPTION;
+  const LumDeviceSceneView& v = h->device_scene.view;
+  if (lumc_frame_assemble_all(cores.data(), (int) cores.size(), v.width * v.height, 0, nullptr) || lumc_use_assembled_frame(h->core, 1)) {
+    std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(h->core));
+    return LUMINARY_ERROR_CUDA;
+  }
+  return LUMINARY_SUCCESS;
+}
+
 LuminaryResult produce_outputs(LuminaryHost* h, PreviewState preview = PreviewState()) {
   if (!h->pixels_all || (h->accumulated_samples == 0 && preview.stage == 0)) return LUMINARY_SUCCESS;
   const LuminaryOutputProperties props = h->outputs.properties();
+  const bool wanted = (props.enabled && props.width >= 2 && props.height >= 2) || !h->outputs.pending_requests().empty();
+  if (wanted) { const LuminaryResult ra = assemble_partition(h); if (ra) return ra; }
   lum::OutputMeta meta;
   meta.sample_count = h->accumulated_samples;
   meta.time = (float) h->render_seconds;
@@ -707,18 +826,40 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
                                            uint32_t samples_per_pass) {
   CHECK_NULL(host);
   ApiLock lock(host);
-  LuminaryResult r = ensure_core(host);
+  std::vector<LumContext*> cores;
+  LuminaryResult r = ensure_partition_cores(host, &cores);
   if (r) return r;
   const bool all = pixels == nullptr;
-  bool same = (host->num_pixels != 0) && (all == host->pixels_all);
+  // the whole frame is tiled over the enabled devices (32x32 tiles dealt round-robin, lumc_tile_pixels); pixel subsets stay on the main device
+  const uint32_t want_n = (all && cores.size() > 1) ? (uint32_t) cores.size() : 1u;
+  bool same = (host->num_pixels != 0) && (all == host->pixels_all) && (host->partition_n == want_n);
   if (same && !all) same = (host->pixels.size() == num_pixels) && std::memcmp(host->pixels.data(), pixels, sizeof(uint32_t) * num_pixels) == 0;
   if (host->adaptive_active) same = false;  // leaving adaptive mode restarts the accumulation
   if (!same) {
-    if (lumc_set_pixels(host->core, pixels, num_pixels)) return LUMINARY_ERROR_CUDA;
+    const LumDeviceSceneView& v = host->device_scene.view;
+    if (want_n > 1) {
+      std::vector<uint32_t> tiles;
+      for (uint32_t k = 0; k < want_n; k++) {
+        uint32_t count = 0;
+        lumc_tile_pixels(v.width, v.height, k, want_n, 32, nullptr, &count);
+        tiles.resize(count ? count : 1);
+        lumc_tile_pixels(v.width, v.height, k, want_n, 32, tiles.data(), &count);
+        if (lumc_set_pixels(cores[k], tiles.data(), count)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(cores[k])); return LUMINARY_ERROR_CUDA; }
+      }
+      if (!host->comm_ready) {  // one RCCL communicator over the partition's GPUs; without one the frame is assembled through peer copies
+        if (lumc_comm_init_all(cores.data(), (int) want_n) == 0) host->comm_ready = true;
+        else std::fprintf(stderr, "[luminary_amd] no RCCL communicator (%s): frames are assembled through peer copies\n", lumc_last_error(cores[0]));
+      }
+    }
+    else {
+      lumc_use_assembled_frame(host->core, 0);
+      if (lumc_set_pixels(host->core, pixels, num_pixels)) return LUMINARY_ERROR_CUDA;
+    }
+    host->partition_n = want_n;
     host->adaptive_active = false;
     host->pixels_all = all;
     if (!all) host->pixels.assign(pixels, pixels + num_pixels);
-    host->num_pixels = all ? host->device_scene.view.width * host->device_scene.view.height : num_pixels;
+    host->num_pixels = all ? v.width * v.height : num_pixels;
     host->accumulated_samples = 0;
     host->render_seconds = 0.0;
   }
@@ -729,8 +870,11 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
     for (const LuminaryOutputRequestProperties& req : host->outputs.pending_requests())
       if (req.sample_count > host->accumulated_samples && req.sample_count - host->accumulated_samples < chunk) chunk = req.sample_count - host->accumulated_samples;
     const auto t0 = std::chrono::steady_clock::now();
-    if (lumc_render(host->core, first_sample + done, chunk, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
-    if (lumc_synchronize(host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+    // every device gets its kernels enqueued before the first one is waited for: the GPUs run side by side
+    for (uint32_t k = 0; k < want_n; k++)
+      if (lumc_render(cores[k], first_sample + done, chunk, samples_per_pass, nullptr, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(cores[k])); return LUMINARY_ERROR_CUDA; }
+    for (uint32_t k = 0; k < want_n; k++)
+      if (lumc_synchronize(cores[k])) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(cores[k])); return LUMINARY_ERROR_CUDA; }
     { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); host->render_seconds += dt; host->last_sample_ms = 1e3 * dt / (chunk ? chunk : 1u); }
     host->accumulated_samples += chunk;
     done += chunk;
@@ -774,7 +918,9 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
       const LuminaryResult r = ensure_core(host);
       if (r) return r;
       if (!preview_schedule(host).empty()) {
+        lumc_use_assembled_frame(host->core, 0);
         if (lumc_set_pixels(host->core, nullptr, 0)) return LUMINARY_ERROR_CUDA;
+        host->partition_n = 1;
         host->adaptive_active = false;
         host->pixels_all = true;
         host->num_pixels = host->device_scene.view.width * host->device_scene.view.height;
@@ -792,7 +938,9 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
   LuminaryResult r = ensure_core(host);
   if (r) return r;
   if (!host->adaptive_active) {
+    lumc_use_assembled_frame(host->core, 0);
     if (lumc_set_pixels(host->core, nullptr, 0)) return LUMINARY_ERROR_CUDA;
+    host->partition_n = 1;  // adaptive sampling runs on the main device
     host->pixels_all = true;
     host->num_pixels = host->device_scene.view.width * host->device_scene.view.height;
     host->accumulated_samples = 0;
@@ -839,6 +987,12 @@ LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_mo
   ApiLock lock(host);
   if (num_pixels) *num_pixels = host->num_pixels;
   if (!host->core || host->num_pixels == 0) return LUMINARY_ERROR_API_EXCEPTION;
+  if (host->partition_n > 1) {  // tiled render: the assembled frame
+    if (!(first_moment || second_moment)) return LUMINARY_SUCCESS;
+    const LuminaryResult ra = assemble_partition(host);
+    if (ra) return ra;
+    return lumc_frame_download(host->core, host->num_pixels, first_moment, second_moment) ? LUMINARY_ERROR_CUDA : LUMINARY_SUCCESS;
+  }
   if ((first_moment || second_moment) && lumc_download_accumulators(host->core, first_moment, second_moment)) return LUMINARY_ERROR_CUDA;
   return LUMINARY_SUCCESS;
 }
@@ -857,7 +1011,12 @@ LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_
     return LUMINARY_SUCCESS;
   }
   std::vector<float> fm(3 * (size_t) host->num_pixels);
-  if (lumc_download_accumulators(host->core, fm.data(), nullptr)) return LUMINARY_ERROR_CUDA;
+  if (host->partition_n > 1) {
+    const LuminaryResult ra = assemble_partition(host);
+    if (ra) return ra;
+    if (lumc_frame_download(host->core, host->num_pixels, fm.data(), nullptr)) return LUMINARY_ERROR_CUDA;
+  }
+  else if (lumc_download_accumulators(host->core, fm.data(), nullptr)) return LUMINARY_ERROR_CUDA;
   const float norm = host->accumulated_samples ? 1.0f / host->accumulated_samples : 0.0f;  // accumulation.cuh:149-153
   for (size_t p = 0; p < host->num_pixels; p++)
     for (int c = 0; c < 3; c++) rgb[3 * p + c] = fm[(size_t) c * host->num_pixels + p] * norm;
@@ -867,7 +1026,18 @@ LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_
 LuminaryResult luminary_ext_get_ray_counters(LuminaryHost* host, uint64_t out[8]) {
   CHECK_NULL(host); CHECK_NULL(out);
   if (!host->core) return LUMINARY_ERROR_API_EXCEPTION;
-  return lumc_counters(host->core, out) ? LUMINARY_ERROR_CUDA : LUMINARY_SUCCESS;
+  ApiLock lock(host);
+  uint64_t all[LUMC_CNT_COUNT] = {0};  // the core keeps more counters than this call returns
+  if (lumc_counters(host->core, all)) return LUMINARY_ERROR_CUDA;
+  if (host->partition_n > 1)  // rays of every device of the tiled render
+    for (LuminaryHost::DeviceSlot* slot : enabled_slots(host)) {
+      if (!slot->core || slot->core == host->core) continue;
+      uint64_t c[LUMC_CNT_COUNT] = {0};
+      if (lumc_counters(slot->core, c)) return LUMINARY_ERROR_CUDA;
+      for (int k = 0; k < LUMC_CNT_COUNT; k++) all[k] += c[k];
+    }
+  for (int k = 0; k < 8; k++) out[k] = all[k];
+  return LUMINARY_SUCCESS;
 }
 // host_math.c:6-21 as the instance transforms use it (exposed so that it can be checked against the reference's own function)
 LuminaryResult luminary_ext_euler_to_quaternion(const float rotation[3], float quaternion[4]) {

@@ -20,6 +20,7 @@
 #include "../device/dev_adaptive.h"
 #include "../device/wavefront_table_impl.h"  // this translation unit holds the exact flavour; the fast one is csrc/device/wavefront_fast.hip
 #include <hipcub/hipcub.hpp>
+#include <rccl/rccl.h>
 #include "bvh_build.h"
 
 using namespace lum;
@@ -93,6 +94,12 @@ struct LumContext {
   size_t sort_temp_bytes = 0;
   uint32_t sort_capacity = 0;
   float world_lo[3] = {0, 0, 0}, world_hi[3] = {1, 1, 1};  // bounds of the top-level BVH
+  // image-tile multi-GPU (lumc_comm_*, lumc_frame_assemble*): this rank's communicator and its [4][frame pixels] assembly buffer
+  ncclComm_t comm = nullptr;
+  int comm_rank = 0, comm_world = 1;
+  float* d_frame = nullptr;
+  uint32_t frame_capacity = 0;
+  bool use_frame = false;         // the result / output entry points read the assembled frame instead of this context's own accumulators
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
   // profiling
@@ -385,6 +392,8 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_pixels) (void) hipFree(ctx->d_pixels);
   if (ctx->d_first_moment) (void) hipFree(ctx->d_first_moment);
   if (ctx->d_second_moment) (void) hipFree(ctx->d_second_moment);
+  if (ctx->comm) { (void) ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+  if (ctx->d_frame) (void) hipFree(ctx->d_frame);
   if (ctx->d_ctrl) (void) hipFree(ctx->d_ctrl);
   for (int k = 0; k < 2; k++) { if (ctx->d_sort_keys[k]) (void) hipFree(ctx->d_sort_keys[k]); if (ctx->d_sort_vals[k]) (void) hipFree(ctx->d_sort_vals[k]); }
   if (ctx->d_sort_temp) (void) hipFree(ctx->d_sort_temp);
@@ -1182,13 +1191,16 @@ int lumc_adaptive_end(LumContext* ctx) {
 
 int lumc_generate_result(LumContext* ctx, uint32_t mode, uint32_t local_error_minimization, uint32_t uniform_samples, float exposure, const LumOutputParams* tone,
                          float* d_result, void* stream_) {
-  if (!ctx || !ctx->has_scene || !ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height) {
+  const bool framed = ctx && ctx->use_frame && ctx->d_frame && ctx->has_scene && ctx->frame_capacity == ctx->scene.width * ctx->scene.height;
+  if (!ctx || !ctx->has_scene || (!framed && (!ctx->d_first_moment || ctx->d_pixels || ctx->num_pixels != ctx->scene.width * ctx->scene.height))) {
     if (ctx) ctx->error = "lumc_generate_result: needs the full-frame accumulators";
     return 1;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t stream = (hipStream_t) stream_;
-  const uint32_t n = ctx->num_pixels;
+  const uint32_t n = ctx->scene.width * ctx->scene.height;
+  const float* src_fm = framed ? ctx->d_frame : ctx->d_first_moment;
+  const float* src_sm = framed ? ctx->d_frame + 3 * (size_t) n : ctx->d_second_moment;
   if (!d_result) {
     if (ctx->frame_result_pixels != n) {
       if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
@@ -1207,7 +1219,7 @@ int lumc_generate_result(LumContext* ctx, uint32_t mode, uint32_t local_error_mi
   const OutputParams op = tone_params(tone);
   {
     Launch l(ctx, stream, LUMC_KERNEL_OUTPUT);
-    hipLaunchKernelGGL(k_generate_result, dim3(grid_for(n)), dim3(256), 0, stream, view, rp, op, (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment, d_result);
+    hipLaunchKernelGGL(k_generate_result, dim3(grid_for(n)), dim3(256), 0, stream, view, rp, op, src_fm, src_sm, d_result);
   }
   HIP_TRY(ctx, hipGetLastError());
   return 0;
@@ -1218,7 +1230,7 @@ int lumc_generate_result_host(LumContext* ctx, uint32_t mode, uint32_t local_err
   if (!ctx || !result) { if (ctx) ctx->error = "lumc_generate_result_host: null argument"; return 1; }
   if (lumc_generate_result(ctx, mode, local_error_minimization, uniform_samples, exposure, tone, nullptr, nullptr)) return 1;
   HIP_TRY(ctx, hipDeviceSynchronize());
-  HIP_TRY(ctx, hipMemcpy(result, ctx->d_frame_result, sizeof(float) * 3 * (size_t) ctx->num_pixels, hipMemcpyDeviceToHost));
+  HIP_TRY(ctx, hipMemcpy(result, ctx->d_frame_result, sizeof(float) * 3 * (size_t) ctx->scene.width * ctx->scene.height, hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -1490,6 +1502,200 @@ extern "C" int lumc_debug_phase_stats(uint64_t out[16], int reset) {
   return 0;
 }
 #endif
+
+// ---- multi-GPU: the image is dealt to the GPUs in 32x32 tiles, every GPU accumulates its own pixels, and ONE reduce per output assembles
+// the four moment planes on the display GPU. Replaces the reference's sample partition with host-staged sums
+// (device/device_result_interface.c:107-299, at most four devices). Transport: RCCL over xGMI - one communicator rank per context, created
+// either per process (lumc_comm_init_rank, launched as one process per GPU) or for all GPUs of one process (lumc_comm_init_all). ----
+namespace {
+__global__ __launch_bounds__(256) void k_frame_scatter(const float* __restrict__ fm, const float* __restrict__ sm, const uint32_t* __restrict__ pixels, uint32_t n,
+                                                       uint32_t frame_pixels, float* __restrict__ frame) {
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const uint32_t index = pixels ? pixels[p] : p;
+    if (index >= frame_pixels) continue;
+    frame[index] = fm[p]; frame[frame_pixels + index] = fm[n + p]; frame[2u * frame_pixels + index] = fm[2u * n + p];
+    frame[3u * frame_pixels + index] = sm[p];
+  }
+}
+__global__ __launch_bounds__(256) void k_frame_add(const float4* __restrict__ src, float4* __restrict__ dst, uint32_t count4) {  // buffer_add, cuda/kernels.cuh:646-675
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < count4; i += gridDim.x * 256u) {
+    const float4 a = src[i]; float4 b = dst[i];
+    b.x += a.x; b.y += a.y; b.z += a.z; b.w += a.w;
+    dst[i] = b;
+  }
+}
+#define NCCL_TRY(ctx, expr)                                                                          \
+  do {                                                                                               \
+    const ncclResult_t r__ = (expr);                                                                 \
+    if (r__ != ncclSuccess) { (ctx)->error = std::string(#expr) + " failed: " + ncclGetErrorString(r__); return 1; } \
+  } while (0)
+
+// this context's pixels scattered into its zeroed [4][frame_pixels] frame buffer
+int frame_scatter(LumContext* ctx, uint32_t frame_pixels, hipStream_t stream) {
+  if (!ctx->d_first_moment || ctx->num_pixels == 0) { ctx->error = "lumc_frame_assemble: no accumulators (lumc_set_pixels)"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint32_t padded = frame_pixels;  // 4 planes of n floats = n float4s: the add kernel walks the whole buffer, planes keep stride n
+  if (ctx->frame_capacity != padded) {
+    if (ctx->d_frame) (void) hipFree(ctx->d_frame);
+    ctx->d_frame = nullptr; ctx->frame_capacity = 0;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_frame, sizeof(float) * 4 * (size_t) padded));
+    ctx->frame_capacity = padded;
+  }
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_frame, 0, sizeof(float) * 4 * (size_t) ctx->frame_capacity, stream));
+  hipLaunchKernelGGL(k_frame_scatter, dim3(grid_for(ctx->num_pixels)), dim3(256), 0, stream, (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment,
+                     (const uint32_t*) ctx->d_pixels, ctx->num_pixels, ctx->frame_capacity, ctx->d_frame);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+int lumc_device_count(void) {
+  int n = 0;
+  return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+// Tile t of the row-major grid of `tile` x `tile` pixel tiles belongs to rank t % world (load balance: neighbouring tiles go to different
+// GPUs). Writes the rank's pixel indices (x + y * width) in tile order, rows within a tile; `out` may be NULL to query the count.
+int lumc_tile_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t tile, uint32_t* out, uint32_t* count) {
+  if (!count || world == 0 || rank >= world || tile == 0) return 1;
+  const uint32_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
+  uint32_t n = 0;
+  for (uint32_t t = rank; t < tx * ty; t += world) {
+    const uint32_t x0 = (t % tx) * tile, y0 = (t / tx) * tile;
+    for (uint32_t y = y0; y < std::min(y0 + tile, height); y++)
+      for (uint32_t x = x0; x < std::min(x0 + tile, width); x++) { if (out) out[n] = x + y * width; n++; }
+  }
+  *count = n;
+  return 0;
+}
+
+int lumc_comm_unique_id(uint8_t id[LUMC_COMM_ID_BYTES]) {
+  static_assert(sizeof(ncclUniqueId) <= LUMC_COMM_ID_BYTES, "unique id does not fit");
+  if (!id) return 1;
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess) return 1;
+  std::memset(id, 0, LUMC_COMM_ID_BYTES);
+  std::memcpy(id, &u, sizeof(u));
+  return 0;
+}
+
+int lumc_comm_init_rank(LumContext* ctx, int world, int rank, const uint8_t id[LUMC_COMM_ID_BYTES]) {
+  if (!ctx || !id || world < 1 || rank < 0 || rank >= world) { if (ctx) ctx->error = "lumc_comm_init_rank: bad arguments"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ctx->comm) { (void) ncclCommDestroy(ctx->comm); ctx->comm = nullptr; }
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof(u));
+  NCCL_TRY(ctx, ncclCommInitRank(&ctx->comm, world, u, rank));
+  ctx->comm_rank = rank; ctx->comm_world = world;
+  return 0;
+}
+
+int lumc_comm_init_all(LumContext** ctxs, int n) {
+  if (!ctxs || n < 1) return 1;
+  std::vector<int> devices(n);
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return 1;
+    devices[i] = ctxs[i]->device;
+    for (int j = 0; j < i; j++)
+      if (devices[j] == devices[i]) { ctxs[0]->error = "lumc_comm_init_all: two contexts on one device (RCCL needs one GPU per rank)"; return 1; }
+  }
+  std::vector<ncclComm_t> comms(n, nullptr);
+  NCCL_TRY(ctxs[0], ncclCommInitAll(comms.data(), n, devices.data()));
+  for (int i = 0; i < n; i++) {
+    if (ctxs[i]->comm) (void) ncclCommDestroy(ctxs[i]->comm);
+    ctxs[i]->comm = comms[i]; ctxs[i]->comm_rank = i; ctxs[i]->comm_world = n;
+  }
+  return 0;
+}
+
+void lumc_comm_destroy(LumContext* ctx) {
+  if (ctx && ctx->comm) { (void) hipSetDevice(ctx->device); (void) ncclCommDestroy(ctx->comm); ctx->comm = nullptr; ctx->comm_world = 1; ctx->comm_rank = 0; }
+}
+
+// One process per GPU: this rank's pixels into its frame buffer, then ncclReduce(SUM) to `root` (every pixel has one owner, so the sum is
+// a gather: 16 bytes per pixel and rank, once per output). Without a communicator (single GPU) the scatter alone is the frame.
+int lumc_frame_assemble(LumContext* ctx, uint32_t frame_pixels, int root, void* stream_, float** d_frame_out) {
+  if (!ctx) return 1;
+  hipStream_t stream = (hipStream_t) stream_;
+  if (frame_scatter(ctx, frame_pixels, stream)) return 1;
+  if (ctx->comm) {
+    if (root < 0 || root >= ctx->comm_world) { ctx->error = "lumc_frame_assemble: bad root"; return 1; }
+    NCCL_TRY(ctx, ncclReduce(ctx->d_frame, ctx->d_frame, 4 * (size_t) ctx->frame_capacity, ncclFloat, ncclSum, root, ctx->comm, stream));
+  }
+  if (d_frame_out) *d_frame_out = ctx->d_frame;
+  return 0;
+}
+
+// One process, several GPUs: all contexts scatter, then one grouped ncclReduce to `root` (lumc_comm_init_all). Contexts without a common
+// communicator (RCCL unavailable, or test set-ups with two contexts on one device) are summed through peer copies and the add kernel
+// instead - the reference's own transport (device_result_interface.c:177-215), kept as the fallback.
+int lumc_frame_assemble_all(LumContext** ctxs, int n, uint32_t frame_pixels, int root, float** d_frame_root) {
+  if (!ctxs || n < 1 || root < 0 || root >= n) return 1;
+  bool rccl = n > 1;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return 1;
+    if (frame_scatter(ctxs[i], frame_pixels, (hipStream_t) 0)) { if (i) ctxs[0]->error = ctxs[i]->error; return 1; }
+    rccl = rccl && ctxs[i]->comm && ctxs[i]->comm_world == n && ctxs[i]->comm_rank == i;
+  }
+  LumContext* r = ctxs[root];
+  if (rccl) {
+    NCCL_TRY(r, ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+      (void) hipSetDevice(ctxs[i]->device);
+      const ncclResult_t e = ncclReduce(ctxs[i]->d_frame, ctxs[i]->d_frame, 4 * (size_t) ctxs[i]->frame_capacity, ncclFloat, ncclSum, root, ctxs[i]->comm, (hipStream_t) 0);
+      if (e != ncclSuccess) { (void) ncclGroupEnd(); r->error = std::string("ncclReduce failed: ") + ncclGetErrorString(e); return 1; }
+    }
+    NCCL_TRY(r, ncclGroupEnd());
+    for (int i = 0; i < n; i++) { HIP_TRY(r, hipSetDevice(ctxs[i]->device)); HIP_TRY(r, hipDeviceSynchronize()); }
+  }
+  else if (n > 1) {
+    float* staging = nullptr;
+    HIP_TRY(r, hipSetDevice(r->device));
+    const size_t bytes = sizeof(float) * 4 * (size_t) r->frame_capacity;
+    HIP_TRY(r, hipMalloc((void**) &staging, bytes));
+    for (int i = 0; i < n; i++) {
+      if (i == root) continue;
+      HIP_TRY(r, hipSetDevice(ctxs[i]->device));
+      HIP_TRY(r, hipDeviceSynchronize());
+      HIP_TRY(r, hipSetDevice(r->device));
+      HIP_TRY(r, hipMemcpyPeer(staging, r->device, ctxs[i]->d_frame, ctxs[i]->device, bytes));
+      hipLaunchKernelGGL(k_frame_add, dim3(grid_for(r->frame_capacity)), dim3(256), 0, 0, (const float4*) staging, (float4*) r->d_frame, r->frame_capacity);
+      HIP_TRY(r, hipGetLastError());
+    }
+    HIP_TRY(r, hipDeviceSynchronize());
+    (void) hipFree(staging);
+  }
+  if (d_frame_root) *d_frame_root = r->d_frame;
+  return 0;
+}
+
+// The assembled frame of this context (valid on the root after lumc_frame_assemble*): planar first moment [3][frame_pixels] and second moment.
+int lumc_frame_download(LumContext* ctx, uint32_t frame_pixels, float* first_moment, float* second_moment) {
+  if (!ctx || !ctx->d_frame || frame_pixels > ctx->frame_capacity) { if (ctx) ctx->error = "lumc_frame_download: no assembled frame"; return 1; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const size_t cap = ctx->frame_capacity;
+  if (first_moment)
+    for (int c = 0; c < 3; c++) HIP_TRY(ctx, hipMemcpy(first_moment + (size_t) c * frame_pixels, ctx->d_frame + (size_t) c * cap, sizeof(float) * frame_pixels, hipMemcpyDeviceToHost));
+  if (second_moment) HIP_TRY(ctx, hipMemcpy(second_moment, ctx->d_frame + 3 * cap, sizeof(float) * frame_pixels, hipMemcpyDeviceToHost));
+  return 0;
+}
+uint32_t lumc_frame_plane_stride(const LumContext* ctx) { return ctx ? ctx->frame_capacity : 0; }
+// The display entry points of this context (lumc_generate_result*, and through them the output chain) read the assembled full frame instead
+// of the context's own accumulators: what the display GPU of a tiled render shows.
+int lumc_use_assembled_frame(LumContext* ctx, int on) {
+  if (!ctx) return 1;
+  if (on && (!ctx->d_frame || !ctx->has_scene || ctx->frame_capacity != ctx->scene.width * ctx->scene.height)) { ctx->error = "lumc_use_assembled_frame: no assembled frame of this scene's size"; return 1; }
+  ctx->use_frame = on != 0;
+  return 0;
+}
+int lumc_device_name(int ordinal, char* out, size_t size) {
+  if (!out || size == 0) return 1;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, ordinal) != hipSuccess) { out[0] = 0; return 1; }
+  std::snprintf(out, size, "%s", prop.name);
+  return 0;
+}
 
 int lumc_set_ray_sorting(LumContext* ctx, int mode) {
   if (!ctx || mode < 0 || mode > 2) { if (ctx) ctx->error = "lumc_set_ray_sorting: 0 (queue order), 1 (closest-hit rays sorted), 2 (visibility rays too)"; return 1; }

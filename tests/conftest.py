@@ -12,6 +12,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # code (luminary_amd/csrc/device/flavour.h). The library's own default is the fast flavour; tests/test_flavours.py gates that one against
 # exact and selects flavours through the API.
 os.environ["LUM_FLAVOUR"] = "exact"
+# A host tiles whole-frame renders over every visible GPU (luminary_amd/csrc/host/api.cpp); the single-device tests pin it to one so that
+# they mean the same on any box. tests/test_multi_gpu.py lifts the cap where it tests the tiled path.
+os.environ["LUM_MAX_DEVICES"] = "1"
 
 
 def pytest_configure(config):

@@ -8,7 +8,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tmp, result_file):
+def _worker(rank, world, port, tmp, result_file, width=48, height=32, tile=8):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -19,8 +19,8 @@ def _worker(rank, world, port, tmp, result_file):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    view = oracle_lib.with_luts(scenes.cornell_host(os.path.join(tmp, "r%d" % rank), 48, 32, 2).device_scene())
-    px = tile_pixels(view.width, view.height, rank, world, tile=8)
+    view = oracle_lib.with_luts(scenes.cornell_host(os.path.join(tmp, "r%d" % rank), width, height, 2).device_scene())
+    px = tile_pixels(view.width, view.height, rank, world, tile=tile)
     fm, sm, _ = oracle_lib.render(view, 0, 2, pixels=px, threads=2)
     full = assemble_frame(torch.from_numpy(fm.reshape(-1)), torch.from_numpy(sm), px, view.width * view.height, dist, 0)
     if rank == 0:
@@ -39,7 +39,17 @@ def test_two_rank_tile_partition_and_reduce(tmp_path):
     assert open(result).read() == "ok"
 
 
-def _adaptive_worker(rank, world, port, tmp, result_file):
+def test_four_rank_uneven_tiles_and_reduce(tmp_path):
+    """World size 4 on a frame that is not a multiple of the tile (50 x 37 with 16-pixel tiles: 4 x 3 tiles, ragged right and bottom edges,
+    12 tiles over 4 ranks; 1080 / 32 is not integral either): the reduce still assembles exactly the single-process frame."""
+    import torch.multiprocessing as mp
+    port = 33500 + (os.getpid() % 2000)
+    result = os.path.join(str(tmp_path), "result4.txt")
+    mp.spawn(_worker, args=(4, port, str(tmp_path), result, 50, 37, 16), nprocs=4, join=True)
+    assert open(result).read() == "ok"
+
+
+def _adaptive_worker(rank, world, port, tmp, result_file, w=40, h=24, tile=8):
     """Adaptive rendering partitioned over two ranks: luminary_amd.distributed.adaptive_render drives a per-rank renderer (the oracle
     standing in for the GPU core, same interface) and exchanges the block variances with one all-reduce per stage build."""
     sys.path.insert(0, ROOT)
@@ -53,11 +63,10 @@ def _adaptive_worker(rank, world, port, tmp, result_file):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    w, h = 40, 24
     view = oracle_lib.with_luts(scenes.cornell_host(os.path.join(tmp, "a%d" % rank), w, h, 2).device_scene())
     tone = default_output_params(w, h, 1)
     core = oracle_lib.AdaptiveOracle(view, 5, 2, 1, exposure=1.0, tone=tone, threads=2)
-    core.adaptive_set_partition(block_mask(w, h, rank, world, tile=8))
+    core.adaptive_set_partition(block_mask(w, h, rank, world, tile=tile))
     adaptive_render(core, 1 + 2 + 3, dist)
     frame = torch.from_numpy(np.concatenate([core.fm, core.sm]))
     dist.reduce(frame, dst=0, op=dist.ReduceOp.SUM)  # every pixel has one owner: the sum assembles the frame
@@ -76,4 +85,14 @@ def test_two_rank_adaptive_rendering(tmp_path):
     port = 31500 + (os.getpid() % 2000)
     result = os.path.join(str(tmp_path), "result_adaptive.txt")
     mp.spawn(_adaptive_worker, args=(2, port, str(tmp_path), result), nprocs=2, join=True)
+    assert open(result).read() == "ok"
+
+
+def test_four_rank_adaptive_rendering_uneven(tmp_path):
+    """Adaptive rendering over four ranks on a frame whose size is neither a multiple of the tile nor of the 4 x 4 adaptive block (42 x 27):
+    the one all-reduce of block variances per stage build gives every rank the rates of the single-process run."""
+    import torch.multiprocessing as mp
+    port = 35500 + (os.getpid() % 2000)
+    result = os.path.join(str(tmp_path), "result_adaptive4.txt")
+    mp.spawn(_adaptive_worker, args=(4, port, str(tmp_path), result, 42, 27, 8), nprocs=4, join=True)
     assert open(result).read() == "ok"

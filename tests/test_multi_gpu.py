@@ -1,0 +1,114 @@
+"""Multi-GPU behind the C ABI (include/lum_core.h lumc_tile_pixels / lumc_comm_* / lumc_frame_*, and the host API's device functions):
+the frame is dealt to the GPUs in 32x32 tiles and assembled with one RCCL reduce per output. Reference: device_manager.c:776-862 (device
+enumeration), device_result_interface.c:107-299 (its sample partition with host-staged sums, which this replaces).
+
+What can run where: the tile deal and the API shape on the CPU; on the single-GPU test box the RCCL call path with a one-rank communicator,
+and the host's partition / assembly logic with device 0 presented several times (LUM_FAKE_DEVICES; RCCL refuses two ranks on one GPU, so
+that run assembles through the peer-copy transport). The N-rank RCCL reduce itself first runs in the driver's multi-GPU bench."""
+import numpy as np
+import pytest
+
+import luminary_amd
+import oracle_lib
+from luminary_amd import scenes
+from luminary_amd.core import Core
+from luminary_amd.distributed import tile_pixels
+
+
+def test_tile_deal_of_the_c_abi_matches_the_python_one_and_covers_the_frame():
+    for (w, h, world) in ((1920, 1080, 8), (100, 70, 3), (33, 31, 4), (64, 64, 1), (50, 37, 4)):
+        seen = np.zeros(w * h, dtype=np.int32)
+        for rank in range(world):
+            px = Core.tile_pixels(w, h, rank, world)
+            assert np.array_equal(px, tile_pixels(w, h, rank, world)), (w, h, world, rank)
+            seen[px] += 1
+        assert (seen == 1).all(), "every pixel has exactly one owner"
+
+
+def test_the_library_links_rccl():
+    """The C library itself carries the RCCL reduce (north star: 'the C host ... tiles the image across the GPUs with an RCCL reduce')."""
+    import subprocess
+    out = subprocess.run(["ldd", luminary_amd.LIB_PATH], capture_output=True, text=True).stdout
+    assert "librccl" in out
+    lib = luminary_amd._lib()
+    for name in ("lumc_comm_unique_id", "lumc_comm_init_rank", "lumc_comm_init_all", "lumc_frame_assemble", "lumc_frame_assemble_all", "lumc_device_count"):
+        assert hasattr(lib, name), name
+
+
+def test_host_without_gpu_still_answers_device_queries():
+    host = luminary_amd.Host()
+    assert host.get_device_count() >= 1
+
+
+@pytest.mark.gpu
+def test_rccl_frame_assembly_with_a_one_rank_communicator():
+    """lumc_comm_unique_id -> lumc_comm_init_rank -> lumc_frame_assemble: scatter + ncclReduce on the GPU box's one GPU. The assembled frame
+    holds this rank's pixels at their frame positions and zeros elsewhere."""
+    host = scenes.example_scene(160, 96, 3, sphere_segments=8, ground_res=12, num_objects=16, num_lights=4)
+    view = oracle_lib.with_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(view)
+        px = Core.tile_pixels(160, 96, 1, 3)
+        core.set_pixels(px)
+        core.render(0, 2, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        core.comm_init_rank(1, 0, Core.comm_unique_id())
+        assert core.frame_assemble(160 * 96, 0) != 0
+        ffm, fsm = core.frame_download(160 * 96)
+    finally:
+        core.close()
+    want = np.zeros((3, 160 * 96), dtype=np.float32)
+    want[:, px] = fm
+    want_sm = np.zeros(160 * 96, dtype=np.float32)
+    want_sm[px] = sm
+    assert np.array_equal(ffm, want) and np.array_equal(fsm, want_sm)
+    ofm, osm, _ = oracle_lib.render(view, 0, 2, pixels=px)
+    assert np.array_equal(fm, ofm)
+
+
+@pytest.mark.gpu
+def test_host_tiles_the_frame_over_its_devices(tmp_path, monkeypatch):
+    """The host API with three device slots (device 0 three times on this box): luminary_host_get_device_count / _get_device_info report
+    them, a whole-frame render is dealt to them in tiles, and accumulators, ray counters and the ARGB8 output equal the single-device
+    render bit for bit; disabling devices (including the main one) re-elects the main device and restarts."""
+    w, h = 100, 70  # not a multiple of the 32-pixel tile
+    single = scenes.cornell_host(str(tmp_path / "one"), w, h, 3)
+    single.set_output_properties(w, h)
+    single.render(4)
+    fm1, sm1 = single.accumulators()
+    img1, n1, _ = single.get_image(single.acquire_output())
+    cnt1 = single.ray_counters()
+
+    monkeypatch.setenv("LUM_FAKE_DEVICES", "3")
+    monkeypatch.setenv("LUM_MAX_DEVICES", "8")
+    multi = scenes.cornell_host(str(tmp_path / "three"), w, h, 3)
+    assert multi.get_device_count() == 3
+    infos = [multi.get_device_info(i) for i in range(3)]
+    assert [i.is_main_device for i in infos] == [True, False, False] and all(i.is_enabled for i in infos)
+    multi.set_output_properties(w, h)
+    multi.render(4)
+    fm3, sm3 = multi.accumulators()
+    img3, n3, _ = multi.get_image(multi.acquire_output())
+    assert n1 == n3 == 4
+    assert np.array_equal(fm3, fm1) and np.array_equal(sm3, sm1), "tiled accumulation == single device"
+    assert np.array_equal(img3, img1), "same ARGB8 output"
+    assert multi.ray_counters()[:4] == cnt1[:4], "ray counters add up over the devices"
+    view = oracle_lib.with_luts(multi.device_scene())
+    ofm, osm, _ = oracle_lib.render(view, 0, 4)
+    assert np.array_equal(fm3, ofm) and np.array_equal(sm3, osm)
+
+    multi.set_device_enable(0, False)  # the main device leaves: device 1 takes over, the integration restarts on two devices
+    infos = [multi.get_device_info(i) for i in range(3)]
+    assert [i.is_main_device for i in infos] == [False, True, False] and [i.is_enabled for i in infos] == [False, True, True]
+    multi.render(2)
+    fm2, _ = multi.accumulators()
+    ofm2, _, _ = oracle_lib.render(view, 0, 2)
+    assert np.array_equal(fm2, ofm2)
+    multi.set_device_enable(2, False)
+    multi.render(3)
+    fmx, _ = multi.accumulators()
+    ofm3, _, _ = oracle_lib.render(view, 0, 3)
+    assert np.array_equal(fmx, ofm3), "one device left: the untiled path"
+    with pytest.raises(luminary_amd.LuminaryError):
+        multi.set_device_enable(1, False)  # the last device cannot be disabled
