@@ -314,6 +314,21 @@ class Host:
         acquire_output for images."""
         _call("luminary_host_start_new_render", self._h)
 
+    def get_num_meshes(self):
+        n = C.c_uint32()
+        _call("luminary_host_get_num_meshes", self._h, C.byref(n))
+        return int(n.value)
+
+    def get_num_materials(self):
+        n = C.c_uint32()
+        _call("luminary_host_get_num_materials", self._h, C.byref(n))
+        return int(n.value)
+
+    def get_num_instances(self):
+        n = C.c_uint32()
+        _call("luminary_host_get_num_instances", self._h, C.byref(n))
+        return int(n.value)
+
     def get_device_count(self):
         n = C.c_uint32()
         _call("luminary_host_get_device_count", self._h, C.byref(n))

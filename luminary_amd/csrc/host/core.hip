@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -671,11 +672,34 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMemcpy(ctx->d_luts[t], host_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyHostToDevice));
   }
   else {
-    for (int t = 0; t < 4; t++) {
-      hipLaunchKernelGGL(k_generate_lut, dim3((lut_count[t] + 63) / 64), dim3(64), 0, 0, sc.bluenoise_2d, t, lut_count[t], ctx->d_luts[0], ctx->d_luts[t]);
-      HIP_TRY(ctx, hipGetLastError());
+    // The tables are a function of the embedded blue-noise mask alone (65 536 samples per texel, one thread per texel: 0.29 s of GPU time):
+    // generated once per process, every later upload copies them.
+    static std::mutex lut_mutex;
+    static std::vector<uint16_t> lut_cache[4];
+    static std::vector<uint32_t> lut_cache_mask;
+    std::lock_guard<std::mutex> lock(lut_mutex);
+    const bool cached = !lut_cache[0].empty() && lut_cache_mask.size() == 65536 && std::memcmp(lut_cache_mask.data(), v->bluenoise_2d, sizeof(uint32_t) * 65536) == 0;
+    if (cached) {
+      for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMemcpy(ctx->d_luts[t], lut_cache[t].data(), sizeof(uint16_t) * lut_count[t], hipMemcpyHostToDevice));
     }
-    HIP_TRY(ctx, hipDeviceSynchronize());
+    else {
+      // the two big tables and the conductor table are independent: side by side on three streams; the glossy table divides by the conductor's
+      hipStream_t streams[3];
+      for (auto& st : streams) HIP_TRY(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      const int first_wave[3] = {0, 2, 3};
+      for (int k = 0; k < 3; k++) {
+        const int t = first_wave[k];
+        hipLaunchKernelGGL(k_generate_lut, dim3((lut_count[t] + 63) / 64), dim3(64), 0, streams[k], sc.bluenoise_2d, t, lut_count[t], ctx->d_luts[0], ctx->d_luts[t]);
+      }
+      hipLaunchKernelGGL(k_generate_lut, dim3((lut_count[1] + 63) / 64), dim3(64), 0, streams[0], sc.bluenoise_2d, 1, lut_count[1], ctx->d_luts[0], ctx->d_luts[1]);
+      HIP_TRY(ctx, hipGetLastError());
+      for (auto& st : streams) { HIP_TRY(ctx, hipStreamSynchronize(st)); (void) hipStreamDestroy(st); }
+      for (int t = 0; t < 4; t++) {
+        lut_cache[t].resize(lut_count[t]);
+        HIP_TRY(ctx, hipMemcpy(lut_cache[t].data(), ctx->d_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyDeviceToHost));
+      }
+      lut_cache_mask.assign(v->bluenoise_2d, v->bluenoise_2d + 65536);
+    }
   }
   sc.lut_conductor = ctx->d_luts[0]; sc.lut_glossy = ctx->d_luts[1]; sc.lut_dielectric = ctx->d_luts[2]; sc.lut_dielectric_inv = ctx->d_luts[3];
   // ---- sky panorama (HDRI mode): the caller's, or baked here from the procedural sky as the reference's device manager does when the
@@ -1108,8 +1132,9 @@ int lumc_adaptive_render(LumContext* ctx, uint32_t executions, void* stream_) {
     }
     executions -= run;
     if (s < kAdaptiveStages && a.executions[s] >= ((uint64_t) a.params.update_interval << s)) {
-      // partitioned: the rates need the block variances of every rank; stop here and let the caller exchange them
-      if (a.d_block_mask) { a.build_pending = true; return 0; }
+      // partitioned: the rates need the block variances of every rank; stop here and let the caller exchange them. The exchange entry
+      // points (lumc_adaptive_variance / _build_from) work on the null stream: everything queued on the caller's stream is finished first.
+      if (a.d_block_mask) { a.build_pending = true; HIP_TRY(ctx, hipStreamSynchronize(stream)); return 0; }
       if (adaptive_build_stage(ctx, stream)) return 1;
     }
   }
@@ -1123,7 +1148,7 @@ int lumc_adaptive_note_first_sample(LumContext* ctx, void* stream_) {
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   a.executions[0] = 1;
   if (a.executions[0] >= (uint64_t) a.params.update_interval) {
-    if (a.d_block_mask) { a.build_pending = true; return 0; }
+    if (a.d_block_mask) { a.build_pending = true; HIP_TRY(ctx, hipStreamSynchronize((hipStream_t) stream_)); return 0; }
     if (adaptive_build_stage(ctx, (hipStream_t) stream_)) return 1;
   }
   return 0;

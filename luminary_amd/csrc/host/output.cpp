@@ -234,6 +234,7 @@ bool read_png_memory(const uint8_t* data, size_t size, const std::string& path, 
   static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
   if (file.size() < 33 || std::memcmp(file.data(), sig, 8) != 0) { *err = path + " is not a PNG file"; return false; }
   uint32_t w = 0, h = 0, depth = 0, colour = 0, interlace = 0;
+  bool have_ihdr = false;
   std::vector<uint8_t> idat, palette, trns;
   *gamma = 1.0f;
   size_t pos = 8;
@@ -243,7 +244,7 @@ bool read_png_memory(const uint8_t* data, size_t size, const std::string& path, 
     if (pos + 12 + (size_t) len > file.size()) { *err = path + ": truncated chunk"; return false; }
     const uint8_t* body = &file[pos + 8];
     if (be32(body + len) != (uint32_t) crc32(0L, &file[pos + 4], (uInt) (len + 4))) { *err = path + ": chunk checksum mismatch"; return false; }
-    if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = be32(body); h = be32(body + 4); depth = body[8]; colour = body[9]; interlace = body[12]; }
+    if (!std::memcmp(type, "IHDR", 4) && len >= 13) { w = be32(body); h = be32(body + 4); depth = body[8]; colour = body[9]; interlace = body[12]; have_ihdr = true; }
     else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
     else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
     else if (!std::memcmp(type, "gAMA", 4) && len == 4 && be32(body) != 0) *gamma = 100000.0f / (float) be32(body);
@@ -252,13 +253,20 @@ bool read_png_memory(const uint8_t* data, size_t size, const std::string& path, 
     pos += 12 + (size_t) len;
   }
   static const int channels_of[7] = {1, 0, 3, 1, 2, 0, 4};
-  if (w == 0 || h == 0 || colour > 6 || channels_of[colour] == 0 || interlace != 0 || (depth != 8 && depth != 16 && !(depth < 8 && (colour == 0 || colour == 3)))) {
-    *err = path + ": unsupported PNG layout (interlaced or unusual bit depth)";
+  // bit depths the PNG specification allows per colour type (section 11.2.2): 1, 2, 4 only for greyscale and palette images, 16 not for palettes
+  const bool depth_ok = depth == 8 || (depth == 16 && colour != 3) || ((depth == 1 || depth == 2 || depth == 4) && (colour == 0 || colour == 3));
+  if (!have_ihdr || w == 0 || h == 0 || colour > 6 || channels_of[colour] == 0 || interlace != 0 || !depth_ok) {
+    *err = path + ": unsupported PNG layout (no header, interlaced or a bit depth the format does not allow)";
     return false;
   }
+  // textures named in a scene's .mtl are untrusted input: bound the size before anything is allocated from it (16384 is also the limit
+  // of the device texture table's 14-bit coordinates elsewhere in the pipeline)
+  if (w > 16384 || h > 16384) { *err = path + ": image larger than 16384 x 16384"; return false; }
   const uint32_t channels = (uint32_t) channels_of[colour];
   const size_t bits_per_pixel = (size_t) channels * depth, bpp = std::max<size_t>(1, bits_per_pixel / 8), stride = (bits_per_pixel * w + 7) / 8;
-  std::vector<uint8_t> raw((stride + 1) * (size_t) h);
+  std::vector<uint8_t> raw;
+  try { raw.resize((stride + 1) * (size_t) h); rgba8->assign((size_t) w * h, 0); }
+  catch (const std::bad_alloc&) { *err = path + ": out of memory for a " + std::to_string(w) + " x " + std::to_string(h) + " image"; return false; }
   uLongf raw_len = (uLongf) raw.size();
   if (uncompress(raw.data(), &raw_len, idat.data(), (uLong) idat.size()) != Z_OK || raw_len != raw.size()) { *err = path + ": corrupt image data"; return false; }
   // undo the scanline filters in place (PNG specification, section 9)
@@ -279,7 +287,6 @@ bool read_png_memory(const uint8_t* data, size_t size, const std::string& path, 
     }
     std::memcpy(prev.data(), px, stride);
   }
-  rgba8->assign((size_t) w * h, 0);
   for (uint32_t y = 0; y < h; y++) {
     const uint8_t* px = &raw[(stride + 1) * (size_t) y + 1];
     for (uint32_t x = 0; x < w; x++) {

@@ -185,3 +185,32 @@ def test_obj_loader_reads_texture_maps(tmp_path):
     # the packed uvs reach the device format and the oracle renders the textured quad
     host2 = oracle_lib.with_luts(v)
     assert host2.num_textures == 5
+
+
+def test_png_reader_rejects_malformed_headers(tmp_path):
+    """Textures named in a scene's .mtl are untrusted input: bit depths the format does not allow (0, 3, 5, 6, 7; 16 for palettes), absurd
+    dimensions and a missing header end in 'texture ignored', never in a division by zero, a negative shift or an allocation failure."""
+    import struct
+    import zlib
+
+    import luminary_amd
+
+    def chunk(t, body):
+        return struct.pack(">I", len(body)) + t + body + struct.pack(">I", zlib.crc32(t + body))
+
+    def png(path, w, h, depth, colour, raw, header=True):
+        data = b"\x89PNG\r\n\x1a\n" + (chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, colour, 0, 0, 0)) if header else b"") + chunk(b"IDAT", zlib.compress(raw)) + chunk(b"IEND", b"")
+        open(path, "wb").write(data)
+
+    cases = {"d0": (4, 4, 0, 0), "d3": (4, 4, 3, 0), "d5": (4, 4, 5, 3), "d7": (8, 2, 7, 0), "pal16": (2, 2, 16, 3), "huge": (0x7FFFFFFF, 0x7FFFFFFF, 8, 6), "wide": (20000, 1, 8, 0)}
+    for name, (w, h, depth, colour) in cases.items():
+        png(str(tmp_path / (name + ".png")), w, h, depth, colour, b"\x00" * 64)
+    png(str(tmp_path / "nohdr.png"), 2, 2, 8, 0, b"\x00" * 6, header=False)
+    names = list(cases) + ["nohdr"]
+    (tmp_path / "m.mtl").write_text("".join("newmtl m_%s\nKd 0.5 0.5 0.5\nmap_Kd %s.png\n" % (n, n) for n in names))
+    (tmp_path / "m.obj").write_text("mtllib m.mtl\no thing\nv 0 0 0\nv 1 0 0\nv 0 1 0\n" + "".join("usemtl m_%s\nf 1 2 3\n" % n for n in names))
+    host = luminary_amd.Host()
+    host.load_obj_file(str(tmp_path / "m.obj"))  # must return: every bad texture is dropped with a warning
+    assert host.get_num_meshes() == 1
+    for i in range(host.get_num_materials()):
+        assert host.get_material(i).albedo_tex == 0xFFFF, "no texture was created from a malformed file"
