@@ -144,7 +144,8 @@ enum PathState : uint32_t {  // cuda/utils.cuh:114-121
 enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 // Per-depth control words (zeroed once per pass).
-enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlTraceCursor = 3, kCtlShadowCursor = 4, kCtlSkyItems = 5, kCtlStride = 8 };
+// kCtlTraceCursor / kCtlShadowCursor are 8 words each: one work cursor per XCD range (dev_trace.h LUM_XCD_RANGES; word 0 alone otherwise).
+enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlSkyItems = 3, kCtlTraceCursor = 8, kCtlShadowCursor = 16, kCtlStride = 24 };
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow, kCntCount };

@@ -42,6 +42,7 @@ constexpr int kStackSize = 128;
 #endif
 
 struct RayStats { uint32_t nodes, tris, lds_nodes; };
+constexpr uint32_t kPrefetchSinkWords = 64u * 16u;  // one dword per lane for up to 16 waves of a ray workgroup (LUM_PREFETCH)
 
 // Diagnostic build (-DLUM_PHASE_STATS): wave-level iteration counts of the traversal phases, to see where lanes idle.
 //   0 node-phase iterations   1 instance-entry iterations   2 lanes entering   3 triangle-phase iterations   4 lanes in them
@@ -220,6 +221,19 @@ struct LeafTris {
   }
 };
 
+// Experiment (LUM_PREFETCH, off): after a node visit the entry that will be popped next is known (`top`); its 128-byte line is requested with
+// an LDS-DMA load into a per-wave junk area (no destination register, nothing waits for the data), so that the later visit finds it in L1/L2.
+#ifndef LUM_PREFETCH
+#define LUM_PREFETCH 0
+#endif
+LUM_DEV void prefetch_line(const void* p, uint32_t* wave_sink) {
+#if LUM_PREFETCH
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*) p, (void __attribute__((address_space(3)))*) wave_sink, 4, 0, 0);
+#else
+  (void) p; (void) wave_sink;
+#endif
+}
+
 // ---- the persistent two-level traversal ----
 // A query type Q provides (all per lane):
 //   bool load(sc, idx, origin, dir, tmax)   read item idx; false = nothing to trace
@@ -250,6 +264,10 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     __syncthreads();
   }
   const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
+#if LUM_PREFETCH
+  __shared__ uint32_t prefetch_sink[kPrefetchSinkWords];
+  uint32_t* wave_sink = prefetch_sink + (threadIdx.x >> 6) * 64u;
+#endif
 
   E top = SE::make(kTraversalDone, 0.0f);
 #ifdef LUM_PHASE_STATS
@@ -281,17 +299,41 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   uint32_t chunk = n / (waves * 2u);
   chunk = (min(max(chunk, 64u), LUM_CHUNK_MAX) + 63u) & ~63u;
   uint32_t chunk_next = 0, chunk_end = 0;
+#ifndef LUM_XCD_RANGES
+#define LUM_XCD_RANGES 0
+#endif
+#if LUM_XCD_RANGES
+  // Experiment: every XCD has its own L2. The queue is cut into 8 contiguous ranges (the queue order is pixel order at depth 0 and stays
+  // roughly that through the compactions), XCD x works on range x first and helps with the others when its own is used up, so that the eight
+  // L2s hold different parts of the scene instead of eight copies of the same hot set. `cursor` then points at 8 words.
+  const uint32_t xcd = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 7u;  // HW_REG_XCC_ID
+  const uint32_t range_len = (n + 7u) / 8u;
+  uint32_t ranges_left = 8u, range = xcd;
+#endif
 
   while (true) {
     const unsigned long long idle = __ballot(cur == kTraversalDone);
     if (idle != 0ull && more) {  // wave-uniform
       if (chunk_next >= chunk_end) {
+#if LUM_XCD_RANGES
+        while (ranges_left > 0u) {
+          const uint32_t lo = min(range * range_len, n), hi = min(lo + range_len, n);
+          uint32_t base = 0;
+          if (lane == 0) base = atomicAdd(cursor + range, chunk);
+          base = __builtin_amdgcn_readfirstlane(base) + lo;
+          if (base < hi) { chunk_next = base; chunk_end = min(base + chunk, hi); break; }
+          range = (range + 1u) & 7u;  // this range is handed out completely: help with the next one
+          ranges_left--;
+        }
+        more = ranges_left > 0u;
+#else
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(cursor, chunk);
         base = __builtin_amdgcn_readfirstlane(base);
         chunk_next = base;
         chunk_end = min(base + chunk, n);
         more = base < n;
+#endif
       }
       if (more) {
         const uint32_t avail = chunk_end - chunk_next, want = (uint32_t) __popcll(idle);
@@ -351,6 +393,15 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           LUM_PHASE(0);
           st.nodes++;
           cur = visit_node<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
+#if LUM_PREFETCH
+          {
+            const uint32_t t = SE::node(top);
+            if (!(t & kBvhLeafBit)) { if (t >= lds_count) prefetch_line(sc.bvh_nodes + t, wave_sink); }
+#if LUM_PREFETCH >= 2
+            else if (t < kTraversalDone && inst != kNoInstance) prefetch_line(sc.blas_tris + (t & 0x0FFFFFFFu), wave_sink);
+#endif
+          }
+#endif
           if (cur == kBvhEmpty) {
             pop();
             if (cur == kTraversalDone) q.finish(sc, idx);

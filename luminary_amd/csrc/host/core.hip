@@ -586,7 +586,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     // the ray kernels need ~160 VGPRs: 3 waves per SIMD = 12 waves per CU = one workgroup of kTraceBlock = 768 threads
     const int blocks_per_cu = 1;  // both flavours launch one workgroup of 768 (3 waves per SIMD) or 1024 (4) threads per CU
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
-    lds_bytes = lds_bytes > 4096 ? lds_bytes - 2048 : 0;
+    lds_bytes = lds_bytes > 16384 ? lds_bytes - 8192 : 0;  // margin: the ray kernels' static LDS (the prefetch experiment's sink) and the runtime's own
     ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / sizeof(Bvh4Node), nodes.size());
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
@@ -1474,7 +1474,7 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   if (n == 0) return 0;
   hipStream_t stream = (hipStream_t) stream_;
   uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
-  HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t), stream));
+  HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t) * 8, stream));  // up to 8 work cursors (dev_trace.h LUM_XCD_RANGES)
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
   ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * sizeof(Bvh4Node), stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
                       ctx->lds_nodes);
