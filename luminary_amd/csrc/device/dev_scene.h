@@ -144,8 +144,17 @@ enum PathState : uint32_t {  // cuda/utils.cuh:114-121
 enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 };
 
 // Per-depth control words (zeroed once per pass).
-// kCtlTraceCursor / kCtlShadowCursor are 8 words each: one work cursor per XCD range (dev_trace.h LUM_XCD_RANGES; word 0 alone otherwise).
-enum CtrlWord : uint32_t { kCtlPaths = 0, kCtlShadowItems = 1, kCtlLightItems = 2, kCtlSkyItems = 3, kCtlTraceCursor = 8, kCtlShadowCursor = 16, kCtlStride = 24 };
+// One row per depth. The three words k_shade's waves bump with an atomic per 64 vertices (survivors of the NEXT row, visibility items, light
+// queries) sit on 128-byte lines of their own: a single word takes ~88 atomics per microsecond (MI355X_MICROARCH.md, "dequeue"), and with all
+// three on one line the shade kernel was bound by that (measured: spreading them took 13 % off k_shade). The work cursors of the persistent
+// ray kernels have a line each as well (8 words: LUM_XCD_RANGES experiment; word 0 alone otherwise).
+#ifndef LUM_CTL_LINE
+#define LUM_CTL_LINE 32u  // words between the hot counters (32 words = 128 bytes)
+#endif
+enum CtrlWord : uint32_t {
+  kCtlPaths = 0, kCtlShadowItems = LUM_CTL_LINE, kCtlLightItems = 2u * LUM_CTL_LINE, kCtlSkyItems = 2u * LUM_CTL_LINE + 1u, kCtlTraceCursor = 3u * LUM_CTL_LINE,
+  kCtlShadowCursor = 3u * LUM_CTL_LINE + 8u, kCtlStride = 4u * LUM_CTL_LINE
+};
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow, kCntCount };
