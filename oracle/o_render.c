@@ -655,3 +655,100 @@ void oracle_sky_hdri_color(const OracleScene* scene, const float origin_world[3]
 void oracle_sky_hdri(const OracleScene* scene, const float origin_world[3], uint32_t dim, uint32_t samples, float* rgba) {
   sky_hdri_bake(scene, v3(origin_world[0], origin_world[1], origin_world[2]), dim, samples, rgba);
 }
+
+/* ---- probes for the analytic checks of the restatement (tests/test_oracle_analytic.py): single functions of the path on caller-made
+ * shading contexts. Nothing here is on a rendering path. ---- */
+static GeoCtx probe_context(const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3]) {
+  GeoCtx g;
+  g.instance_id = 0xFFFFFFF0u; g.tri_id = 0;
+  g.position = v3(position[0], position[1], position[2]);
+  g.normal = v_norm(v3(normal[0], normal[1], normal[2]));
+  g.V = v_norm(v3(V[0], V[1], V[2]));
+  g.face_normal = normal_pack(g.normal);
+  g.state = 0;
+  g.params.data[0] = g.params.data[1] = g.params.data[2] = 0;
+  g.params.flags = m->flags;
+  mp_set_albedo(&g.params, c3(m->albedo[0], m->albedo[1], m->albedo[2]));
+  mp_set_opacity(&g.params, m->opacity);
+  mp_set_roughness(&g.params, m->roughness);
+  mp_set_emission(&g.params, c_splat(0.0f));
+  mp_set_ior(&g.params, m->ior_ratio);
+  return g;
+}
+/* bsdf_sample<GEOMETRY> for sample ids first..first+count-1 of pixel (px, py), depth constant 0: direction, weight, flags (1 transparent pass, 2 microfacet based) */
+void oracle_probe_bsdf_sample(const OracleScene* s, const OracleProbeMaterial* m, const float normal[3], const float V[3], uint32_t px, uint32_t py, uint32_t first,
+                              uint32_t count, float* rays, float* weights, uint32_t* flags) {
+  const OLuts luts = scene_luts(s);
+  const float origin[3] = {0.0f, 0.0f, 0.0f};
+  const GeoCtx g = probe_context(m, origin, normal, V);
+  for (uint32_t i = 0; i < count; i++) {
+    const Sampler smp = {s->bluenoise_2d, px, py, first + i, 0};
+    const BSDFSample b = bsdf_sample(&luts, &g, &smp, 0);
+    rays[3 * i] = b.ray.x; rays[3 * i + 1] = b.ray.y; rays[3 * i + 2] = b.ray.z;
+    weights[3 * i] = b.weight.r; weights[3 * i + 1] = b.weight.g; weights[3 * i + 2] = b.weight.b;
+    if (flags) flags[i] = (b.is_transparent_pass ? 1u : 0u) | (b.is_microfacet_based ? 2u : 0u);
+  }
+}
+/* bsdf_evaluate (general hint) for `count` directions L: value = f * |cos| * inv_pdf as the path tracer uses it */
+void oracle_probe_bsdf_eval(const OracleScene* s, const OracleProbeMaterial* m, const float normal[3], const float V[3], uint32_t count, const float* L, float inv_pdf,
+                            float* values) {
+  const OLuts luts = scene_luts(s);
+  const float origin[3] = {0.0f, 0.0f, 0.0f};
+  const GeoCtx g = probe_context(m, origin, normal, V);
+  for (uint32_t i = 0; i < count; i++) {
+    bool is_refraction;
+    const RGBF v = bsdf_evaluate(&luts, &g, v3(L[3 * i], L[3 * i + 1], L[3 * i + 2]), 0, &is_refraction, inv_pdf);
+    values[3 * i] = v.r; values[3 * i + 1] = v.g; values[3 * i + 2] = v.b;
+  }
+}
+/* bsdf_microfacet_pdf of the bounded VNDF for reflected directions L (local frame: normal = +z) */
+void oracle_probe_microfacet_pdf(const float V[3], float roughness, uint32_t count, const float* L, float* pdf) {
+  const vec3 v = v_norm(v3(V[0], V[1], V[2]));
+  for (uint32_t i = 0; i < count; i++) {
+    const vec3 l = v3(L[3 * i], L[3 * i + 1], L[3 * i + 2]);
+    const vec3 h = v_norm(v_add(v, l));
+    pdf[i] = (l.z > 0.0f) ? microfacet_pdf(v, roughness, h.z, v.z) : 0.0f;
+  }
+}
+/* light_triangle_sample_solid_angle for caller-supplied random pairs: ok flag, direction, reported solid angle */
+void oracle_probe_triangle_sample(const float origin[3], const float tri[9], int bidirectional, uint32_t count, const float* rnd, float* rays, float* solid_angles,
+                                  uint32_t* ok) {
+  const vec3 o = v3(origin[0], origin[1], origin[2]), p0 = v3(tri[0], tri[1], tri[2]);
+  const vec3 e1 = v_sub(v3(tri[3], tri[4], tri[5]), p0), e2 = v_sub(v3(tri[6], tri[7], tri[8]), p0);
+  for (uint32_t i = 0; i < count; i++) {
+    vec3 ray = v3(0.0f, 0.0f, 0.0f);
+    float sa = 0.0f;
+    const float2_t r = {rnd[2 * i], rnd[2 * i + 1]};
+    ok[i] = light_triangle_sample_solid_angle(o, p0, e1, e2, r, bidirectional != 0, &ray, &sa) ? 1u : 0u;
+    rays[3 * i] = ray.x; rays[3 * i + 1] = ray.y; rays[3 * i + 2] = ray.z;
+    solid_angles[i] = sa;
+  }
+}
+/* the light tree at a shading point: for sample ids first..first+count-1 the eight resampling lanes' picks and their weights (1 / (8 p)) */
+void oracle_probe_light_tree(const OracleScene* s, const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3], uint32_t px, uint32_t py,
+                             uint32_t first, uint32_t count, uint32_t* light_ids, float* weights, float* root_sums) {
+  const GeoCtx g = probe_context(m, position, normal, V);
+  for (uint32_t i = 0; i < count; i++) {
+    const Sampler smp = {s->bluenoise_2d, px, py, first + i, 0};
+    const LTWork work = light_tree_prepass(s, &g, &smp);
+    if (root_sums) root_sums[i] = work.root_sum;
+    for (uint32_t lane = 0; lane < LIGHT_TREE_NUM_OUTPUTS; lane++) {
+      const LTResult r = light_tree_postpass(s, &g, &smp, lane, &work);
+      light_ids[i * LIGHT_TREE_NUM_OUTPUTS + lane] = r.light_id;
+      weights[i * LIGHT_TREE_NUM_OUTPUTS + lane] = r.weight;
+    }
+  }
+}
+/* light_sample: the resampled light sample of a vertex (direction, colour = radiance x BSDF x MIS x resampling weight, distance) */
+void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3], uint32_t px, uint32_t py,
+                               uint32_t first, uint32_t count, uint32_t* light_ids, float* rays, float* colors, float* dists) {
+  const GeoCtx g = probe_context(m, position, normal, V);
+  for (uint32_t i = 0; i < count; i++) {
+    const Sampler smp = {s->bluenoise_2d, px, py, first + i, 0};
+    const LightSample ls = light_sample(s, &g, &smp);
+    light_ids[i] = ls.light_id;
+    rays[3 * i] = ls.ray.x; rays[3 * i + 1] = ls.ray.y; rays[3 * i + 2] = ls.ray.z;
+    colors[3 * i] = ls.light_color.r; colors[3 * i + 1] = ls.light_color.g; colors[3 * i + 2] = ls.light_color.b;
+    dists[i] = ls.dist;
+  }
+}

@@ -167,4 +167,18 @@ float oracle_pow(float x, float y);
 }
 #endif
 
+/* ---- probes for the analytic checks (tests/test_oracle_analytic.py); see o_render.c ---- */
+typedef struct { float albedo[3]; float opacity, roughness, ior_ratio; uint32_t flags; /* 1 translucent, 2 inside, 4 metallic, 8 coloured transparency */ } OracleProbeMaterial;
+void oracle_probe_bsdf_sample(const OracleScene* s, const OracleProbeMaterial* m, const float normal[3], const float V[3], uint32_t px, uint32_t py, uint32_t first,
+                              uint32_t count, float* rays, float* weights, uint32_t* flags);
+void oracle_probe_bsdf_eval(const OracleScene* s, const OracleProbeMaterial* m, const float normal[3], const float V[3], uint32_t count, const float* L, float inv_pdf,
+                            float* values);
+void oracle_probe_microfacet_pdf(const float V[3], float roughness, uint32_t count, const float* L, float* pdf);
+void oracle_probe_triangle_sample(const float origin[3], const float tri[9], int bidirectional, uint32_t count, const float* rnd, float* rays, float* solid_angles,
+                                  uint32_t* ok);
+void oracle_probe_light_tree(const OracleScene* s, const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3], uint32_t px, uint32_t py,
+                             uint32_t first, uint32_t count, uint32_t* light_ids, float* weights, float* root_sums);
+void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3], uint32_t px, uint32_t py,
+                               uint32_t first, uint32_t count, uint32_t* light_ids, float* rays, float* colors, float* dists);
+
 #endif
