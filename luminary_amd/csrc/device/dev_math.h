@@ -51,6 +51,47 @@ constexpr float kPi  = 3.14159265358979323846f;
 constexpr float kEps = 1.1920928955078125e-7f;  // FLT_EPSILON (cuda/utils.cuh:41-43)
 constexpr float kFltMax = 3.402823466e+38f;
 
+// Streaming accesses of the wavefront queues (experiment LUM_NT_STREAMS): every queue word is written once and read once or twice per depth,
+// gigabytes per launch that flow through L2 and the 256 MB Infinity Cache between two ray kernels and evict the scene (nodes + triangles,
+// 130 MB on the hall) those kernels gather from. `nt` marks them non-temporal.
+#ifndef LUM_NT_STREAMS
+#define LUM_NT_STREAMS 0
+#endif
+typedef float lum_v4f __attribute__((ext_vector_type(4)));
+typedef uint32_t lum_v4u __attribute__((ext_vector_type(4)));
+LUM_DEV float4 ld_stream(const float4* p) {
+#if LUM_NT_STREAMS
+  const lum_v4f v = __builtin_nontemporal_load(reinterpret_cast<const lum_v4f*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+LUM_DEV uint4 ld_stream(const uint4* p) {
+#if LUM_NT_STREAMS
+  const lum_v4u v = __builtin_nontemporal_load(reinterpret_cast<const lum_v4u*>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+#else
+  return *p;
+#endif
+}
+LUM_DEV void st_stream(float4* p, float4 v) {
+#if LUM_NT_STREAMS
+  lum_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<lum_v4f*>(p));
+#else
+  *p = v;
+#endif
+}
+LUM_DEV void st_stream(uint4* p, uint4 v) {
+#if LUM_NT_STREAMS
+  lum_v4u w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w;
+  __builtin_nontemporal_store(w, reinterpret_cast<lum_v4u*>(p));
+#else
+  *p = v;
+#endif
+}
+
 LUM_DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 LUM_DEV float bitsf(uint32_t u) { return __uint_as_float(u); }
 

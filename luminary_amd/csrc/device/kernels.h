@@ -118,7 +118,7 @@ struct TraceQuery : ClosestState {
   LUM_DEV bool load(const DeviceScene&, uint32_t j, V3& o, V3& d, float& tmax) {
     const uint32_t i = order ? order[j] : j;
     item = i;
-    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
+    const float4 o4 = ld_stream(&q.origin_t[i]), d4 = ld_stream(&q.dir_slot[i]);
     const uint32_t state = q.aux[i].w;
     const uint2 ign = *reinterpret_cast<const uint2*>(&q.hit_id[i]);
     begin((state & kStUseIgnoreHandle) != 0, ign.x, ign.y);
@@ -290,8 +290,8 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
     if (valid) {
-      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
-      const uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const float4 o4 = ld_stream(&in.origin_t[i]), d4 = ld_stream(&in.dir_slot[i]);
+      const uint4 aux = ld_stream(&in.aux[i]), hid = ld_stream(&in.hit_id[i]);
       const uint32_t slot = fbits(d4.w), state = aux.w;
       const Col record_in = record_unpack(U2{aux.x, aux.y});
       {
@@ -357,11 +357,11 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
               s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
             }
           }
-          nee.sun[i] = sun;
+          st_stream(&nee.sun[i], sun);
         }
-        nee.geo_color_light[i] = geo_cl;
-        nee.bsdf_ray_prob[i] = bs_rp; nee.bsdf_weight_sum[i] = bs_ws;
-        nee.ambient[i] = amb;
+        st_stream(&nee.geo_color_light[i], geo_cl);
+        st_stream(&nee.bsdf_ray_prob[i], bs_rp); st_stream(&nee.bsdf_weight_sum[i], bs_ws);
+        st_stream(&nee.ambient[i], amb);
 
         // delta-path classification (geometry.cuh:80-101)
         const float roughness = g.params.roughness();
@@ -419,7 +419,7 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
       base = __builtin_amdgcn_readfirstlane(base);
       if (survive) {
         const uint32_t j = base + (uint32_t) __popcll(ballot & below);
-        out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
+        st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
       }
     }
     const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun);
@@ -430,21 +430,21 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
       base = __builtin_amdgcn_readfirstlane(base);
       if (want_geo) {
         const uint32_t j = base + (uint32_t) __popcll(bg & below);
-        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w);
-        sq.dir_out[j] = make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i));
-        sq.ids[j] = s_geo_ids;
+        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
+        st_stream(&sq.dir_out[j], make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i)));
+        st_stream(&sq.ids[j], s_geo_ids);
       }
       if (want_amb) {
         const uint32_t j = base + ng + (uint32_t) __popcll(ba & below);
-        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w);
-        sq.dir_out[j] = make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i));
-        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w));
+        st_stream(&sq.dir_out[j], make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i)));
+        st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
       }
       if (want_sun) {
         const uint32_t j = base + ng + na + (uint32_t) __popcll(bn & below);
-        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w);
-        sq.dir_out[j] = make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i));
-        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w));
+        st_stream(&sq.dir_out[j], make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i)));
+        st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
       }
     }
     const unsigned long long bl = __ballot(want_lq);
@@ -610,8 +610,8 @@ struct ShadowQuery : ShadowState {
   uint32_t out;
   LUM_DEV bool load(const DeviceScene&, uint32_t slot, V3& o, V3& d, float& tmax) {
     const uint32_t j = order ? order[slot] : slot;
-    const float4 o4 = sq.origin_dist[j], d4 = sq.dir_out[j];
-    begin(sq.ids[j], o4.w);
+    const float4 o4 = ld_stream(&sq.origin_dist[j]), d4 = ld_stream(&sq.dir_out[j]);
+    begin(ld_stream(&sq.ids[j]), o4.w);
     out = fbits(d4.w);
     o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = o4.w;
     return true;
@@ -621,7 +621,7 @@ struct ShadowQuery : ShadowState {
 #ifdef LUM_EXPERIMENT_VIS_IN_ITEM_ORDER
     sq.vis[j] = make_float4(v.r, v.g, v.b, 0.0f);
 #else
-    sq.vis[out] = make_float4(v.r, v.g, v.b, 0.0f);
+    st_stream(&sq.vis[out], make_float4(v.r, v.g, v.b, 0.0f));
 #endif
   }
 };
@@ -648,15 +648,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
     const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
     Col acc = splat(0.0f);
     {  // sampled light (direct_lighting.cuh:445-464)
-      const float4 cl = nee.geo_color_light[i];
+      const float4 cl = ld_stream(&nee.geo_color_light[i]);
       Col vis = splat(0.0f);
-      if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = sq.vis[i]; vis = col(v.x, v.y, v.z); }
+      if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = ld_stream(&sq.vis[i]); vis = col(v.x, v.y, v.z); }
       acc = acc + col(cl.x, cl.y, cl.z) * vis;
     }
     {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
-      const float4 lc = nee.bsdf_weight_sum[i];
+      const float4 lc = ld_stream(&nee.bsdf_weight_sum[i]);
       Col vis = splat(0.0f);
-      if (lc.w != 0.0f) { const float4 v = sq.vis[sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+      if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
       acc = acc + col(lc.x, lc.y, lc.z) * vis;
     }
     if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
@@ -666,9 +666,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
     }
     {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
-      const uint4 amb = nee.ambient[i];
+      const uint4 amb = ld_stream(&nee.ambient[i]);
       Col vis = splat(0.0f);
-      if (amb.x != 0 || amb.y != 0) { const float4 v = sq.vis[2u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+      if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
       acc = acc + record_unpack(U2{amb.x, amb.y}) * vis;
     }
     add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
