@@ -55,7 +55,7 @@ constexpr float kFltMax = 3.402823466e+38f;
 // gigabytes per launch that flow through L2 and the 256 MB Infinity Cache between two ray kernels and evict the scene (nodes + triangles,
 // 130 MB on the hall) those kernels gather from. `nt` marks them non-temporal.
 #ifndef LUM_NT_STREAMS
-#define LUM_NT_STREAMS 0
+#define LUM_NT_STREAMS 1  // measured: +1.7 % (hall), +1.0 % (scan), +1.2 % (example)
 #endif
 typedef float lum_v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t lum_v4u __attribute__((ext_vector_type(4)));

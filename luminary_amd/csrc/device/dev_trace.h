@@ -197,6 +197,70 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
   return (k0 < inf) ? c0 : kBvhEmpty;
 }
 
+struct NodeData { float4 nx, ny, nz, fx, fy, fz; uint4 ch; };
+LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, RayStats& st) {
+  NodeData n;
+  const uint32_t b = id << 7;
+  if (id < src.lds_count) {
+    const char* p = src.lds + b;
+    n.nx = *reinterpret_cast<const float4*>(p + r.nx); n.ny = *reinterpret_cast<const float4*>(p + r.ny); n.nz = *reinterpret_cast<const float4*>(p + r.nz);
+    n.fx = *reinterpret_cast<const float4*>(p + r.fx); n.fy = *reinterpret_cast<const float4*>(p + r.fy); n.fz = *reinterpret_cast<const float4*>(p + r.fz);
+    n.ch = *reinterpret_cast<const uint4*>(p + 96u);
+    st.lds_nodes++;
+  }
+  else {
+    const Bvh4Node* __restrict__ nodes = src.global;
+    n.nx = node_f4(nodes, b + r.nx); n.ny = node_f4(nodes, b + r.ny); n.nz = node_f4(nodes, b + r.nz);
+    n.fx = node_f4(nodes, b + r.fx); n.fy = node_f4(nodes, b + r.fy); n.fz = node_f4(nodes, b + r.fz);
+    n.ch = node_u4(nodes, b + 96u);
+  }
+  return n;
+}
+
+// Visibility rays visit every stacked node anyway (their segment never shrinks), so a lane whose newest stack entry is an inner node of the same
+// level takes it along: both nodes' lines are requested before either is tested, which halves the dependent round trips of a ray - the kernels
+// are bound by those, not by arithmetic (VALU issue 0.25). `second` = kBvhEmpty for lanes without such an entry. Every child of the second node
+// that the ray may touch is pushed; of the first node's children the nearest is continued with, as in visit_node.
+template <bool kCull>
+LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t second, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk,
+                                 int& sp, typename StackEntry<kCull>::E& top, RayStats& st) {
+  using SE = StackEntry<kCull>;
+  const float inf = __builtin_inff();
+  const NodeData a = load_node(src, cur, r, st);
+  NodeData b;
+  const bool two = second != kBvhEmpty;
+  if (two) b = load_node(src, second, r, st);
+  {
+    float e0 = inf, e1 = inf, e2 = inf, e3 = inf;
+    uint32_t d0 = kBvhEmpty, d1 = kBvhEmpty, d2 = kBvhEmpty, d3 = kBvhEmpty;
+    if (two) {
+      e0 = child_entry(b.nx.x, b.ny.x, b.nz.x, b.fx.x, b.fy.x, b.fz.x, r, tmax);
+      e1 = child_entry(b.nx.y, b.ny.y, b.nz.y, b.fx.y, b.fy.y, b.fz.y, r, tmax);
+      e2 = child_entry(b.nx.z, b.ny.z, b.nz.z, b.fx.z, b.fy.z, b.fz.z, r, tmax);
+      e3 = child_entry(b.nx.w, b.ny.w, b.nz.w, b.fx.w, b.fy.w, b.fz.w, r, tmax);
+      d0 = b.ch.x; d1 = b.ch.y; d2 = b.ch.z; d3 = b.ch.w;
+      if (e3 < inf) { stk[sp] = top; sp++; top = SE::make(d3, e3); }
+      if (e2 < inf) { stk[sp] = top; sp++; top = SE::make(d2, e2); }
+      if (e1 < inf) { stk[sp] = top; sp++; top = SE::make(d1, e1); }
+      if (e0 < inf) { stk[sp] = top; sp++; top = SE::make(d0, e0); }
+    }
+  }
+  float k0 = child_entry(a.nx.x, a.ny.x, a.nz.x, a.fx.x, a.fy.x, a.fz.x, r, tmax);
+  float k1 = child_entry(a.nx.y, a.ny.y, a.nz.y, a.fx.y, a.fy.y, a.fz.y, r, tmax);
+  float k2 = child_entry(a.nx.z, a.ny.z, a.nz.z, a.fx.z, a.fy.z, a.fz.z, r, tmax);
+  float k3 = child_entry(a.nx.w, a.ny.w, a.nz.w, a.fx.w, a.fy.w, a.fz.w, r, tmax);
+  uint32_t c0 = a.ch.x, c1 = a.ch.y, c2 = a.ch.z, c3 = a.ch.w;
+  cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
+  if (k1 < inf) {
+    if (k2 < inf) {
+      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
+      stk[sp] = top; sp++; top = SE::make(c2, k2);
+    }
+    stk[sp] = top; sp++; top = SE::make(c1, k1);
+  }
+  return (k0 < inf) ? c0 : kBvhEmpty;
+}
+
 // Pops the newest entry into (node, tnear) and refills the register top from scratch. The bottom of the stack is a sentinel
 // (kTraversalDone) that is never removed.
 LUM_DEV uint2 stack_pop(uint2* __restrict__ stk, int& sp, uint2& top) {
@@ -246,7 +310,10 @@ template <class Q>
 LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays, uint32_t lds_count) {
   using SE = StackEntry<Q::kCull>;
   using E = typename SE::E;
-  E stk[kStackSize];
+  // Dual visits (visit_two_nodes) push all four children of the second node, which is not depth-first any more: the guard below allows them only
+  // while fewer than kDualLimit entries are stacked, after which single visits need at most 3 more per remaining level (<= 126): 256 entries.
+  constexpr int kDualLimit = 120;
+  E stk[(LUM_DUAL_VISIT && Q::kDual) ? 2 * kStackSize : kStackSize];
   int sp = 0;
   TRay r;
   V3 wo = v3(0.0f, 0.0f, 0.0f), wd = v3(0.0f, 0.0f, 1.0f);
@@ -392,6 +459,20 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
         if (do_node) {
           LUM_PHASE(0);
           st.nodes++;
+#if LUM_DUAL_VISIT
+          if (Q::kDual) {
+            uint32_t second = kBvhEmpty;
+            const uint32_t t = SE::node(top);
+            if (!(t & kBvhLeafBit) && sp < kDualLimit) {  // the newest entry is an inner node (markers and leaves carry the leaf bit): same level as `cur`
+              second = t;
+              st.nodes++;
+              if (sp > 0) { sp--; top = stk[sp]; }
+              else top = SE::make(kTraversalDone, 0.0f);
+            }
+            cur = visit_two_nodes<Q::kCull>(nodes, cur, second, r, tmax, stk, sp, top, st);
+          }
+          else
+#endif
           cur = visit_node<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
 #if LUM_PREFETCH
           {
@@ -419,7 +500,11 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
+#ifndef LUM_DUAL_VISIT
+#define LUM_DUAL_VISIT 0
+#endif
 struct ClosestState {
+  static constexpr bool kDual = false;
   static constexpr bool kOrdered = true;
   static constexpr bool kCull = true;  // stack entries carry the entry distance: a pop drops children beyond the nearest hit so far
   bool use_ignore;
@@ -461,6 +546,7 @@ struct ShadowState {
 #define LUM_SHADOW_CULL 0
 #endif
   static constexpr bool kCull = LUM_SHADOW_CULL != 0;  // the segment never shrinks: 4-byte stack entries (StackEntry<false>)
+  static constexpr bool kDual = true;                  // two nodes per visit where the stack offers a second one (visit_two_nodes)
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
 #if LUM_FAST
