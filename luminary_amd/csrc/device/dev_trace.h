@@ -41,6 +41,9 @@ constexpr int kStackSize = 128;
 #define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
 #endif
 
+#ifndef LUM_DUAL_VISIT
+#define LUM_DUAL_VISIT 0  // experiment, measured negative (visibility kernel +18 % on the hall): see visit_two_nodes
+#endif
 struct RayStats { uint32_t nodes, tris, lds_nodes; };
 constexpr uint32_t kPrefetchSinkWords = 64u * 16u;  // one dword per lane for up to 16 waves of a ray workgroup (LUM_PREFETCH)
 
@@ -219,7 +222,9 @@ LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, Ra
 
 // Visibility rays visit every stacked node anyway (their segment never shrinks), so a lane whose newest stack entry is an inner node of the same
 // level takes it along: both nodes' lines are requested before either is tested, which halves the dependent round trips of a ray - the kernels
-// are bound by those, not by arithmetic (VALU issue 0.25). `second` = kBvhEmpty for lanes without such an entry. Every child of the second node
+// are bound by those, not by arithmetic (VALU issue 0.25). Measured (LUM_DUAL_VISIT=1): NOT faster - visibility kernel 121.9 -> 144.4 ms per 3 steps
+// on the hall, 32.6 -> 36.1 on the scan: rays that find an occluder have fetched a node they would never have visited (nodes per ray 15.2 -> 16.2),
+// lanes with and without a second node diverge, and the iteration carries twice the registers. Off. `second` = kBvhEmpty for lanes without such an entry. Every child of the second node
 // that the ray may touch is pushed; of the first node's children the nearest is continued with, as in visit_node.
 template <bool kCull>
 LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t second, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk,
@@ -500,9 +505,6 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
-#ifndef LUM_DUAL_VISIT
-#define LUM_DUAL_VISIT 0
-#endif
 struct ClosestState {
   static constexpr bool kDual = false;
   static constexpr bool kOrdered = true;
