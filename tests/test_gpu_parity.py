@@ -176,7 +176,7 @@ def test_trace_parity_material_zoo(core):
     _assert_same(got, want, "closest hits (rotated, non-uniformly scaled instances) vs brute force")
 
 
-def _full_size_frame_properties(core, host, min_triangles):
+def _full_size_frame_properties(core, host, min_triangles, width=1920, height=1080):
     """Size-independent properties of a 1920x1080, 8-bounce frame instead of a full oracle frame: a strided sample of pixels equals the
     oracle exactly (moments and, for those pixels alone, the ray counters), two sample ids rendered in one pass equal two passes, and
     a 3-way tile partition reproduces the full frame bit for bit (exact equality and a checksum of the bit patterns)."""
@@ -188,10 +188,10 @@ def _full_size_frame_properties(core, host, min_triangles):
     core.render(0, 2, samples_per_pass=2)
     full, full_sm = core.accumulators()
     cnt = core.counters()
-    assert np.isfinite(full).all() and full.max() > 0.0 and cnt[0] > 2 * 1920 * 1080
+    assert np.isfinite(full).all() and full.max() > 0.0 and cnt[0] > 2 * width * height
     checksum = int(full.view(np.uint32).astype(np.uint64).sum() + full_sm.view(np.uint32).astype(np.uint64).sum())
 
-    px = np.arange(0, 1920 * 1080, 977, dtype=np.uint32)  # 2123 pixels across the frame
+    px = np.arange(0, width * height, 977 * (width * height // (1920 * 1080)), dtype=np.uint32)  # 2123 pixels across the frame
     ofm, osm, ocnt = oracle_lib.render(view, 0, 2, pixels=px)
     _assert_same(full[:, px], ofm, "strided pixels of the full-size frame vs oracle")
     _assert_same(full_sm[px], osm, "second moment of the strided pixels")
@@ -213,7 +213,7 @@ def _full_size_frame_properties(core, host, min_triangles):
     acc = np.zeros_like(full)
     acc_sm = np.zeros_like(full_sm)
     for rank in range(3):
-        tiles = bench.tile_pixels(1920, 1080, rank, 3)
+        tiles = bench.tile_pixels(width, height, rank, 3)
         core.set_pixels(tiles)
         core.render(0, 2, samples_per_pass=2)
         part, part_sm = core.accumulators()
@@ -232,6 +232,12 @@ def core_total_triangles(view):
 def test_full_size_frame_properties(core):
     """BASELINE config 2 at its full size (Example-class scene, 1920x1080, 8 bounces, ~100 k triangles, 72 instances)."""
     _full_size_frame_properties(core, scenes.example_scene(1920, 1080, 8), 14_000)  # unique triangles; ~100 k once instanced
+
+
+def test_full_size_frame_properties_4k(core):
+    """BASELINE config 4's frame (Example-class scene at 3840x2160) on one GPU: 16.6 M paths per 2-sample pass, the same size-independent
+    properties; the 3-way tile partition is what the 8-GPU run of that config does with 8."""
+    _full_size_frame_properties(core, scenes.example_scene(3840, 2160, 8), 14_000, 3840, 2160)
 
 
 def test_full_size_frame_properties_hall_1m(core):
