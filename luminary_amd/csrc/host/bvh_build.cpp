@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
 
@@ -25,7 +26,11 @@ inline float half_area(const Aabb& b) {
   return dx * dy + dy * dz + dz * dx;
 }
 
-constexpr int kBins = 16;
+constexpr int kMaxBins = 64;
+// Builder knobs for experiments (environment; defaults = what the measured trees were built with): LUM_BVH_BINS, LUM_BVH_MAX_LEAF,
+// LUM_BVH_SAH_LEAF=<traversal cost>: a set that fits a leaf is still split when the SAH says the split is cheaper than testing all its triangles.
+int env_int(const char* name, int def) { const char* e = std::getenv(name); return e ? std::atoi(e) : def; }
+float env_float(const char* name, float def) { const char* e = std::getenv(name); return e ? (float) std::atof(e) : def; }
 
 struct Builder {
   const Aabb* boxes;
@@ -34,6 +39,8 @@ struct Builder {
   std::vector<BinNode> nodes;
   bool balanced;
   uint32_t max_leaf;
+  int kBins = 16;
+  float sah_leaf_traversal_cost = -1.0f;  // < 0: every set that fits a leaf becomes one
 
   uint32_t build(uint32_t first, uint32_t count, int depth) {
     const uint32_t idx = (uint32_t) nodes.size();
@@ -46,7 +53,8 @@ struct Builder {
     }
     nodes[idx].box = box;
     nodes[idx].first = first;
-    if (count <= max_leaf) { nodes[idx].count = count; return idx; }
+    const bool fits_leaf = count <= max_leaf;
+    if (fits_leaf && (count <= 1 || sah_leaf_traversal_cost < 0.0f || balanced)) { nodes[idx].count = count; return idx; }
 
     int axis = 0;
     if (chi[1] - clo[1] > chi[axis] - clo[axis]) axis = 1;
@@ -60,8 +68,8 @@ struct Builder {
       for (int a = 0; a < 3; a++) {
         const float ext = chi[a] - clo[a];
         if (!(ext > 0.0f)) continue;
-        Aabb bin_box[kBins];
-        uint32_t bin_cnt[kBins];
+        Aabb bin_box[kMaxBins];
+        uint32_t bin_cnt[kMaxBins];
         for (int b = 0; b < kBins; b++) { bin_box[b] = empty_box(); bin_cnt[b] = 0; }
         const float scale = kBins / ext;
         for (uint32_t i = first; i < first + count; i++) {
@@ -70,8 +78,8 @@ struct Builder {
           grow(bin_box[b], boxes[order[i]]);
           bin_cnt[b]++;
         }
-        float right_area[kBins];
-        uint32_t right_cnt[kBins];
+        float right_area[kMaxBins];
+        uint32_t right_cnt[kMaxBins];
         Aabb acc = empty_box();
         uint32_t c = 0;
         for (int b = kBins - 1; b > 0; b--) { grow(acc, bin_box[b]); c += bin_cnt[b]; right_area[b] = half_area(acc); right_cnt[b] = c; }
@@ -82,6 +90,10 @@ struct Builder {
           const float cost = half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
           if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
         }
+      }
+      if (fits_leaf) {  // SAH leaf termination: split only if cheaper than testing the whole set
+        const float area = half_area(box);
+        if (best_axis < 0 || !(area > 0.0f) || sah_leaf_traversal_cost + best_cost / area >= (float) count) { nodes[idx].count = count; return idx; }
       }
       if (best_axis < 0) use_median = true;
       else {
@@ -193,6 +205,9 @@ Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t m
     b.boxes = boxes;
     b.balanced = attempt == 1;
     b.max_leaf = max_leaf < 1 ? 1 : (max_leaf > kBvhLeafMaxTri ? kBvhLeafMaxTri : max_leaf);
+    if (max_leaf > 1) b.max_leaf = (uint32_t) std::min<int>(std::max(env_int("LUM_BVH_MAX_LEAF", (int) b.max_leaf), 1), (int) kBvhLeafMaxTri);  // not the top level (one instance per leaf)
+    b.kBins = std::min(std::max(env_int("LUM_BVH_BINS", 16), 4), kMaxBins);
+    if (max_leaf > 1) b.sah_leaf_traversal_cost = env_float("LUM_BVH_SAH_LEAF", -1.0f);
     b.centroid.resize(3 * (size_t) count);
     for (uint32_t i = 0; i < count; i++)
       for (int k = 0; k < 3; k++) b.centroid[3 * (size_t) i + k] = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]);
