@@ -5,6 +5,6 @@ for flags in "$@"; do
   LUM_CXXFLAGS="$flags" python -m luminary_amd.build --force > /dev/null 2>&1 || { echo "[$flags] build failed"; continue; }
   for w in ${WORKLOADS:-hall scan}; do
     echo -n "[$flags] $w $BENCH_ARGS: "
-    LUM_CXXFLAGS="$flags" python bench.py --steps 3 --warmup 1 --cpu-budget 0 --secondary none --workload $w $BENCH_ARGS 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().split('\n')[-1]); k=d['config']['kernel_ms_rank0']; p=d['config']['per_ray_rank0']; print(round(d['value'],1),'Mrays/s trace %.1f shade %.1f shadow %.1f lq %.1f res %.1f | nodes %.2f/%.2f' % (k['trace'], k['shade'], k['shadow'], k['light_query'], k['resolve'], p['nodes_closest'], p['nodes_shadow']))"
+    LUM_CXXFLAGS="$flags" python bench.py --steps 3 --warmup 1 --cpu-budget 0 --secondary none --workload $w $BENCH_ARGS 2>/dev/null | python tools/ab_line.py
   done
 done
