@@ -170,7 +170,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     t_up = time.time()
     core.upload(view)  # builds the BVHs, generates the BSDF tables on the GPU
     upload_s = time.time() - t_up
-    pixels = tile_pixels(view.width, view.height, rank, world) if world > 1 else None
+    pixels = tile_pixels(view.width, view.height, rank, world) if dist is not None else None
     core.set_pixels(pixels)
     P = core.num_pixels
     frame_pixels = view.width * view.height
@@ -224,7 +224,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     core.set_profiling(False)
     # output chain (tone map + ARGB8 of the frame just rendered), outside the timed region: streaming kernels, 40 B/pixel algorithmic
     output_chain = None
-    if want_output_chain and world == 1:
+    if want_output_chain and dist is None:
         from luminary_amd.core import default_output_params
         core.set_profiling(True)
         op = default_output_params(view.width, view.height, max(spp_step * (steps + warmup), 1))
@@ -248,7 +248,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     del fm, sm
 
     # ---- rooflines (rank 0's kernels) ----
-    pmc = pmc_record(name, args.samples_per_pass, core.flavour) if world == 1 else None
+    pmc = pmc_record(name, args.samples_per_pass, core.flavour) if (world == 1 and dist is None) else None
     nodes_trace, tris_trace, nodes_shadow, tris_shadow = cnt[CNT_NODES], cnt[CNT_TRIS], cnt[6], cnt[7]
     alg = {"trace": nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES,
            "shadow": nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES}
@@ -296,8 +296,8 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     out = {
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "ray_sorting": core.ray_sorting,
-                   "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if world > 1 else "single GPU",
-                   "frame_reduce": None if world == 1 else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
+                   "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if dist is not None else "single GPU",
+                   "frame_reduce": None if dist is None else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
@@ -345,7 +345,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "WORLD_SIZE" in os.environ:  # under torchrun the distributed path runs even with one rank (exercises it on a single-GPU box)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -370,9 +370,9 @@ def main():
         core._bench_comm = bool(ok.item() > 0)
     head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True)
     # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
-    cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and world == 1 and args.sky == "constant" and rank == 0) else None
+    cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and dist is None and args.sky == "constant" and rank == 0) else None
     secondary = {}
-    if world == 1 and args.secondary != "none":
+    if dist is None and args.secondary != "none":
         for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
             sec, _ = run_workload(core, name, args, rank, world, None, args.secondary_steps, 1, False)
             secondary[name] = sec
