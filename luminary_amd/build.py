@@ -20,8 +20,10 @@ HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "hos
 EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 EXACT = ["-ffp-contract=off", "-fno-fast-math"]  # the numerics contract of the exact flavour and of all host code
-# the fast flavour of the wavefront kernels (csrc/device/flavour.h): contraction, hardware reciprocal / sqrt, reciprocal-multiply for x / y
-FAST = ["-DLUM_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-math-errno",
+# the fast flavour of the wavefront kernels (csrc/device/flavour.h): contraction, hardware reciprocal / sqrt, reciprocal-multiply for x / y.
+# -fapprox-func: without it 28 divisions of k_shade stay correctly rounded (v_div_scale / v_div_fmas / v_div_fixup with two denormal-mode
+# switches each) although the 2.5-ulp division is allowed - the reciprocals -freciprocal-math creates lose that permission
+FAST = ["-DLUM_FAST=1", "-ffp-contract=fast", "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-freciprocal-math", "-fno-math-errno", "-fapprox-func",
         "-fgpu-flush-denormals-to-zero"]  # denormals flushed like the reference's --use_fast_math build: a/b is v_rcp + v_mul, sqrt is v_sqrt (measured +1 %)
 if os.environ.get("LUM_FAST_FLAGS") is not None:  # diagnosis only (tools/flavour_diff.py): which part of the fast flavour moves the image
     FAST = ["-DLUM_FAST=1"] + os.environ["LUM_FAST_FLAGS"].split()
