@@ -76,6 +76,11 @@ class Sky(C.Structure):
                [("hdri_dim", C.c_uint32), ("hdri_samples", C.c_uint32), ("aerial_perspective", C.c_bool), ("constant_color", RGBF), ("mode", C.c_int)]
 
 
+class Fog(C.Structure):
+    """LuminaryFog (include/luminary_amd.h): a homogeneous scattering volume around the camera (fog.c:6-16 for the defaults)."""
+    _fields_ = [("active", C.c_bool), ("density", C.c_float), ("droplet_diameter", C.c_float), ("height", C.c_float), ("dist", C.c_float)]
+
+
 class Material(C.Structure):
     _fields_ = [("id", C.c_uint32), ("base_substrate", C.c_int), ("albedo", RGBAF), ("emission", RGBF), ("emission_scale", C.c_float),
                 ("roughness", C.c_float), ("roughness_clamp", C.c_float), ("refraction_index", C.c_float), ("emission_active", C.c_bool),
@@ -131,7 +136,9 @@ class DeviceSceneView(C.Structure):
                 ("sky_mie_phase", C.c_float * 4), ("sky_lut_transmittance", C.c_void_p), ("sky_lut_multiscattering", C.c_void_p),
                 ("sky_moon_pos", C.c_float * 3), ("sky_moon_tex_offset", C.c_float), ("sky_moon_albedo_tex", C.c_uint32), ("sky_moon_normal_tex", C.c_uint32),
                 ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p),
-                ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3), ("sky_aerial_perspective", C.c_uint32)]
+                ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3), ("sky_aerial_perspective", C.c_uint32),
+                ("fog_active", C.c_uint32), ("fog_density", C.c_float), ("fog_dist", C.c_float), ("fog_height", C.c_float), ("fog_phase", C.c_float * 4),
+                ("bridge_lut", C.c_void_p), ("bridge_max_num_vertices", C.c_uint32)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -233,6 +240,12 @@ class Host:
 
     def set_sky(self, s):
         _call("luminary_host_set_sky", self._h, C.byref(s))
+
+    def get_fog(self):
+        return self._get("fog", Fog)
+
+    def set_fog(self, f):
+        _call("luminary_host_set_fog", self._h, C.byref(f))
 
     def get_material(self, i):
         m = Material()

@@ -80,7 +80,8 @@ def build(force=False, verbose=False):
     bn1 = os.path.join(ROOT, "data", "bluenoise_1D.bin")
     moon = [os.path.join(ROOT, "data", n) for n in ("moon_albedo.png", "moon_normal.png")]
     _run(["gcc", "-c", "-DLUM_BLUENOISE_PATH=\"%s\"" % bn, "-DLUM_BLUENOISE_1D_PATH=\"%s\"" % bn1, "-DLUM_MOON_ALBEDO_PATH=\"%s\"" % moon[0],
-          "-DLUM_MOON_NORMAL_PATH=\"%s\"" % moon[1], os.path.join(CSRC, "host", "embed.S"), "-o", o])
+          "-DLUM_MOON_NORMAL_PATH=\"%s\"" % moon[1], "-DLUM_BRIDGE_LUT_PATH=\"%s\"" % os.path.join(ROOT, "data", "bridge_lut.bin"),
+          os.path.join(CSRC, "host", "embed.S"), "-o", o])
     objs.append(o)
     from concurrent.futures import ThreadPoolExecutor
 

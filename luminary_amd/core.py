@@ -6,7 +6,7 @@ import numpy as np
 from . import DeviceSceneView, _lib
 
 CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
-KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky", "sort")
+KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky", "sort", "volume")
 
 
 class CoreError(RuntimeError):

@@ -56,7 +56,12 @@ LUM_DEV float tree_importance(const GeoContext& g, float power, V3 mean, float s
 LUM_DEV uint32_t byte_of(uint32_t lo, uint32_t hi, uint32_t i) { return ((i < 4 ? lo : hi) >> ((i & 3) * 8)) & 0xFFu; }
 
 struct ChildBlock { uint32_t mx0, mx1, my0, my1, mz0, mz1, sd0, sd1; };  // 4 x 8 bytes: rel mean x,y,z, rel std dev
-LUM_DEV float child_importance(const GeoContext& g, const ChildBlock& b, uint32_t power_q, V3 base, V3 ex, float exp_v, uint32_t i) {
+// The tree is walked for a surface vertex or for a ray segment through the fog (VolContext, dev_volume.h): the contexts differ in
+// tree_importance() and in the random set they draw from (material.cuh:60-63, :78-81).
+struct GeoTreeTargets { static constexpr uint32_t kPrepass = kRndLightTreePrepass, kPostpass = kRndLightTreePostpass; };
+template <class Ctx> struct TreeTargets : GeoTreeTargets {};
+template <class Ctx>
+LUM_DEV float child_importance(const Ctx& g, const ChildBlock& b, uint32_t power_q, V3 base, V3 ex, float exp_v, uint32_t i) {
   if (power_q == 0) return 0.0f;
   const float power = (float) power_q;
   const float std_dev = byte_of(b.sd0, b.sd1, i) * exp_v;
@@ -67,7 +72,8 @@ LUM_DEV float child_importance(const GeoContext& g, const ChildBlock& b, uint32_
 struct TreeWork { uint32_t cont[kLightTreeOutputs]; float root_sum; };  // cont: is_light | index << 1 | probability(20 bit) << 9
 
 // Root pass (light_tree.cuh:191-255): one scan over <= 128 children feeds 8 independent resampling lanes.
-LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const Sampler& smp) {
+template <class Ctx>
+LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler& smp) {
   const uint4 h = sc.light_tree_root[0];
   const uint32_t num_root_lights = h.y >> 16, num_sections = (h.z >> 16) & 0xFFu;
   const V3 base = v3(bfloat_unpack(h.x), bfloat_unpack(h.x >> 16), bfloat_unpack(h.y));
@@ -77,7 +83,7 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const 
   uint32_t lane_pick[kLightTreeOutputs];
 #pragma unroll
   for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
-    lane_random[l] = smp.next1(kRndLightTreePrepass + l);
+    lane_random[l] = smp.next1(TreeTargets<Ctx>::kPrepass + l);
     lane_target[l] = 0.0f;
     lane_pick[l] = 0;
   }
@@ -127,7 +133,8 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const GeoContext& g, const 
 struct TreePick { uint32_t light_id; float weight; };
 
 // Descent of one lane through the 8-wide nodes (light_tree.cuh:257-320).
-LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, uint32_t lane, const TreeWork& w) {
+template <class Ctx>
+LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const Ctx& g, const Sampler& smp, uint32_t lane, const TreeWork& w) {
   const uint32_t cont = w.cont[lane];
   const float cp = (cont >> 9) * (1.0f / 1048575.0f) * kLightTreeOutputs;
   TreePick r;
@@ -138,7 +145,7 @@ LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const GeoContext& g, const
   if (cont & 1u) { r.light_id = index; return r; }
   uint32_t node_id = index;
   Reservoir rv;
-  rv.random = smp.next1(kRndLightTreePostpass + lane);
+  rv.random = smp.next1(TreeTargets<Ctx>::kPostpass + lane);
   rv.reset();
   while (r.light_id == kLightIdInvalid) {
     LUM_STAT(12, 13);

@@ -91,6 +91,12 @@ struct DeviceScene {
   const float4* sky_hdri;             // [dim][dim] baked panorama (k_sky_hdri), read when sky_mode == HDRI; alpha unused
   uint32_t sky_hdri_dim;
   uint32_t sky_aerial_perspective;    // the air between a ray's origin and its hit is marched too (k_sky_inscattering)
+  // fog (dev_volume.h): homogeneous, scattering only; bounded by a disk of radius fog_dist around the camera and by y <= fog_height
+  uint32_t fog_active;
+  float fog_density, fog_dist, fog_height;
+  float fog_phase[4];        // Jendersie-Eon g_hg, g_d, alpha, w_d of the droplet diameter
+  const float* bridge_lut;   // 64 x 21 floats
+  uint32_t bridge_max_num_vertices;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).
@@ -119,6 +125,17 @@ struct ShadowQueue {
   float4* vis;          // [4 * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun
   uint32_t* light_items;  // path indices that need a light-BVH query
   uint32_t capacity;
+};
+
+// What the fog scatters into the rays of one depth (k_volume_inscatter -> visibility rays -> k_volume_resolve), indexed like the path queue.
+// The visibility rays of this pass use the ShadowQueue with 17 kinds per path: 0..14 the segments of the bridge to the sampled light, 15 the
+// sun, 16 the ambient sample.
+constexpr uint32_t kVolumeShadowKinds = 17, kVolumeKindSun = 15, kVolumeKindAmbient = 16;
+struct VolumeQueue {
+  float4* bridge;        // light colour rgb (already weighted) | number of segments (uint bits; 0 = no bridge)
+  uint4* sky;            // sun colour (record format) xy | ambient colour zw; zero = no sample
+  float4* weight;        // weight of the vertex the sun and the ambient sample start from | fog transmittance along the ambient ray | unused
+  uint32_t* items;       // paths that scattered in the fog at this depth (k_volume_events), bounced by k_volume_bounce
 };
 
 // One wavefront pass over `batch` consecutive sample ids of `num_pixels` pixels (k_generate).
@@ -153,8 +170,12 @@ enum SkyMode : uint32_t { kSkyDefault = 0, kSkyHdri = 1, kSkyConstantColor = 2 }
 #endif
 enum CtrlWord : uint32_t {
   kCtlPaths = 0, kCtlShadowItems = LUM_CTL_LINE, kCtlLightItems = 2u * LUM_CTL_LINE, kCtlSkyItems = 2u * LUM_CTL_LINE + 1u, kCtlTraceCursor = 3u * LUM_CTL_LINE,
-  kCtlShadowCursor = 3u * LUM_CTL_LINE + 8u, kCtlStride = 4u * LUM_CTL_LINE
+  kCtlShadowCursor = 3u * LUM_CTL_LINE + 8u, kCtlStride = 4u * LUM_CTL_LINE,
+  // the fog's own visibility pass runs k_shadow_rays on `ctrl + kCtlVolumeShift`: its item count and cursor are these two words
+  kCtlVolumeShift = 16u, kCtlVolumeShadowItems = kCtlShadowItems + kCtlVolumeShift, kCtlVolumeShadowCursor = kCtlShadowCursor + kCtlVolumeShift,
+  kCtlVolumeItems = 2u * LUM_CTL_LINE + 2u
 };
+static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow, kCntCount };

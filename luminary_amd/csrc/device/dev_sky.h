@@ -22,7 +22,7 @@ constexpr float kSkyAtmoRadius = kSkyAtmoHeight + kSkyEarthRadius;
 constexpr float kSkyHeightOffset = 0.0005f;
 constexpr int kSkyTmWidth = 256, kSkyTmHeight = 64, kSkyMsSize = 32, kSkyMsBase = 16, kSkyMsIter = 256;
 // RANDOM_TARGET_SKY_STEP_OFFSET and RandomSet::LIGHT_SUN<0> (geometry, material.cuh:61) by the allocation rule of random.cuh:24-66
-constexpr uint32_t kRndSkyStepOffset = 77, kRndSkyInscatteringStep = 78, kRndSunBsdf = 346, kRndSunBsdfMethod = 349, kRndSunRay = 352, kRndSunResampling = 355;
+constexpr uint32_t kRndSkyStepOffset = 77, kRndSkyInscatteringStep = 79, kRndSunBsdf = 346, kRndSunBsdfMethod = 349, kRndSunRay = 352, kRndSunResampling = 355;
 constexpr float kSkyMieScattering = 3.996f * 0.001f, kSkyMieExtinction = 4.440f * 0.001f;
 
 struct Spectrum { float v[8]; };

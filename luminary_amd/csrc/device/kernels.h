@@ -15,6 +15,7 @@
 
 #include "dev_trace.h"
 #include "dev_sky.h"
+#include "dev_volume.h"
 
 LUM_NS_BEGIN
 
@@ -252,7 +253,8 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
       bool is_hit = false, is_sky = false;
       if (i < n) {
-        if (in.hit_id[i].x == kHitSky) {
+        const uint32_t hit_type = in.hit_id[i].x;
+        if (hit_type == kHitSky) {
           const uint4 aux = in.aux[i];
           if (aux.w & kStAllowAmbient) {
             if (kSkyMode == kSkyDefault) is_sky = true;  // the atmosphere is ray-marched by k_sky
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
             else add_to_result(results, fbits(in.dir_slot[i].w), sky * record_unpack(U2{aux.x, aux.y}));
           }
         }
-        else is_hit = true;
+        else is_hit = hit_type <= kHitTriangleLimit;  // fog: scattering events are bounced by k_volume_bounce, kHitInvalid ended in k_volume_events
       }
       const unsigned long long bs = __ballot(is_sky);
       if (bs) {  // the list grows downwards from the end of the light-query list: a path is in at most one of the two
@@ -315,6 +317,7 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
           else ls = sample_light(sc, g, smp);
+          if (sc.fog_active) ls.color = ls.color * fog_transmittance(sc, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
           if (ls.light_id != kLightIdInvalid) {
             want_geo = true;
@@ -349,6 +352,7 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
           uint4 sun = make_uint4(0u, 0u, 0u, 0u);
           Col sun_light; V3 sun_dir;
           if (sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir)) {
+            if (sc.fog_active) sun_light = sun_light * fog_transmittance(sc, g.position, sun_dir, kFltMax);  // direct_lighting.cuh:104-108
             const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
             sun = make_uint4(c.x, c.y, r.x, r.y);
             if (c.x != 0 || c.y != 0) {
@@ -578,7 +582,10 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
         }
         else valid = false;
       }
-      nee.bsdf_weight_sum[i] = make_float4(lc.r, lc.g, lc.b, valid ? 1.0f : 0.0f);
+      // .w: 0 = no visibility ray; otherwise the fog's transmittance up to the light (direct_lighting.cuh:661-666), 1 without fog
+      float seen = valid ? 1.0f : 0.0f;
+      if (valid && sc.fog_active) seen = fog_transmittance(sc, hit_origin, ray, dist);
+      nee.bsdf_weight_sum[i] = make_float4(lc.r, lc.g, lc.b, seen);
       if (valid) {
         want = true;
         s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, dist);
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
-    if (hid.x == kHitSky) continue;
+    if (hid.x > kHitTriangleLimit) continue;  // sky, and with fog: scattering events and ended paths
     const uint4 aux = in.aux[i];
     const uint32_t slot = fbits(in.dir_slot[i].w);
     const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
@@ -657,7 +664,9 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       const float4 lc = ld_stream(&nee.bsdf_weight_sum[i]);
       Col vis = splat(0.0f);
       if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
-      acc = acc + col(lc.x, lc.y, lc.z) * vis;
+      Col seen = col(lc.x, lc.y, lc.z) * vis;
+      if (sc.fog_active) seen = seen * lc.w;
+      acc = acc + seen;
     }
     if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
       const uint4 sun = nee.sun[i];
@@ -669,9 +678,248 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       const uint4 amb = ld_stream(&nee.ambient[i]);
       Col vis = splat(0.0f);
       if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
-      acc = acc + record_unpack(U2{amb.x, amb.y}) * vis;
+      Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
+      if (sc.fog_active) {  // direct_lighting.cuh:561-563
+        const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+        seen = seen * fog_transmittance(sc, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
+      }
+      acc = acc + seen;
     }
     add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
+  }
+}
+
+
+// ---- fog (cuda/volume.cuh; queue order device/device_renderer.c:64-76, :114-118) ----
+// volume_process_inscattering (volume.cuh:31-98): what the fog scatters into the ray between its origin and its end point (the hit, or infinity
+// for a ray that left the scene): a bridge to a sampled emissive triangle on delta paths, the sun and the ambient sample from a vertex on the
+// ray. The visibility rays go through the ShadowQueue (17 kinds per path), k_volume_resolve sums up (optix_kernel_shadow_volume.cu:13-98).
+__global__ __launch_bounds__(kBlock) void k_volume_inscatter(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    const bool valid = i < n;
+    uint32_t segments = 0;
+    BridgeWalk walk;
+    bool want_sun = false, want_amb = false;
+    float4 sky_origin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    V3 sun_dir = v3(0.0f, 0.0f, 1.0f), amb_dir = v3(0.0f, 0.0f, 1.0f);
+    Sampler smp{sc.bluenoise_2d, 0u, 0u, 0u, depth_const};
+    if (valid) {
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
+      const uint32_t state = aux.w;
+      smp.px = hid.z & 0xFFFFu; smp.py = hid.z >> 16; smp.sample_id = hid.w;
+      VolContext ctx = volume_context(sc, origin, ray, state, o4.w);
+      float4 bridge = make_float4(0.0f, 0.0f, 0.0f, bitsf(0u));
+      const bool bridges_allowed = lights_present && (state & kStDeltaPath) != 0 && (state & kStVolumeScattered) == 0;  // direct_lighting.cuh:296-306
+      if (bridges_allowed) {
+        const BridgeSample bs = volume_light_sample(sc, ctx, smp);
+        if (bs.light_id != kLightIdInvalid && bs.seed != 0xFFFFFFFFu) {
+          walk = bridge_walk_begin(sc, ctx, bs, smp);
+          segments = walk.vertex_count;
+          bridge = make_float4(bs.color.r, bs.color.g, bs.color.b, bitsf(segments));
+        }
+      }
+      const float w = volume_sky_initial_vertex(ctx, smp);  // the vertex the sun and the ambient sample start from
+      sky_origin = make_float4(ctx.position.x, ctx.position.y, ctx.position.z, kFltMax);
+      uint4 sky_words = make_uint4(0u, 0u, 0u, 0u);
+      if (sun_allowed) {
+        Col lc; V3 dir;
+        if (volume_sun_sample(sc, sky_view(sc), ctx, smp, lc, dir)) {
+          const U2 c = record_pack(lc), r = ray_pack(dir);
+          sky_words.x = c.x; sky_words.y = c.y;
+          if (c.x != 0 || c.y != 0) { want_sun = true; sun_dir = ray_unpack(r); }
+        }
+      }
+      const V3 bounce = volume_bsdf_sample(sc, ctx, smp, kRndVolAmbientResampling, kRndVolAmbientDiffuse);
+      float amb_transmittance = 1.0f;
+      if (sc.sky_mode != kSkyDefault) {  // direct_lighting.cuh:385-403, :521-584
+        const U2 c = record_pack(sky_color_no_compute(sc, ctx.position, bounce, 0u) * splat(1.0f)), r = ray_pack(bounce);
+        sky_words.z = c.x; sky_words.w = c.y;
+        if (c.x != 0 || c.y != 0) {
+          want_amb = true;
+          amb_dir = ray_unpack(r);
+          amb_transmittance = fog_transmittance(sc, ctx.position, amb_dir, kFltMax);
+        }
+      }
+      vq.bridge[i] = bridge;
+      vq.sky[i] = sky_words;
+      vq.weight[i] = make_float4(w, amb_transmittance, 0.0f, 0.0f);
+    }
+    // visibility rays, wave-aggregated: the segments of the bridges one at a time (a bridge has 1..15 of them), then sun and ambient
+    for (uint32_t k = 0; k < kBridgesMaxVertexCount; k++) {
+      const bool want = k < segments;
+      const unsigned long long b = __ballot(want);
+      if (!b) break;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlVolumeShadowItems, (uint32_t) __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want) {
+        const uint32_t j = base + (uint32_t) __popcll(b & below);
+        sq.origin_dist[j] = make_float4(walk.vertex.x, walk.vertex.y, walk.vertex.z, walk.dist);
+        sq.dir_out[j] = make_float4(walk.dir.x, walk.dir.y, walk.dir.z, bitsf(k * sq.capacity + i));
+        sq.ids[j] = make_uint4(walk.light.x, walk.light.y, 0xFFFFFFFFu, 0u);  // the segment that reaches the light leaves that light out
+        if (k + 1 < segments) bridge_walk_next(walk, smp, k + 1);
+      }
+    }
+    const unsigned long long bs = __ballot(want_sun), ba = __ballot(want_amb);
+    if (bs | ba) {
+      const uint32_t ns = (uint32_t) __popcll(bs);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlVolumeShadowItems, ns + (uint32_t) __popcll(ba));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_sun) {
+        const uint32_t j = base + (uint32_t) __popcll(bs & below);
+        sq.origin_dist[j] = sky_origin;
+        sq.dir_out[j] = make_float4(sun_dir.x, sun_dir.y, sun_dir.z, bitsf(kVolumeKindSun * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+      if (want_amb) {
+        const uint32_t j = base + ns + (uint32_t) __popcll(ba & below);
+        sq.origin_dist[j] = sky_origin;
+        sq.dir_out[j] = make_float4(amb_dir.x, amb_dir.y, amb_dir.z, bitsf(kVolumeKindAmbient * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+    }
+  }
+}
+
+// optix_kernel_shadow_volume.cu:38-97: bridge colour x the visibilities of its segments, + (sun + ambient) x the weight of their vertex, x throughput
+__global__ __launch_bounds__(kBlock) void k_volume_resolve(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, float4* results, const uint32_t* ctrl) {
+  const uint32_t n = ctrl[kCtlPaths];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 bridge = vq.bridge[i], wt = vq.weight[i];
+    const uint4 sky = vq.sky[i];
+    const uint32_t segments = fbits(bridge.w);
+    Col acc = splat(0.0f);
+    if (segments) {
+      const float4 v0 = sq.vis[i];
+      Col shadow = col(v0.x, v0.y, v0.z);
+      for (uint32_t k = 1; k < segments; k++) { const float4 v = sq.vis[k * sq.capacity + i]; shadow = shadow * col(v.x, v.y, v.z); }
+      acc = acc + col(bridge.x, bridge.y, bridge.z) * shadow;
+    }
+    if (sky.x != 0 || sky.y != 0) {
+      const float4 v = sq.vis[kVolumeKindSun * sq.capacity + i];
+      acc = acc + (record_unpack(U2{sky.x, sky.y}) * col(v.x, v.y, v.z)) * wt.x;
+    }
+    if (sky.z != 0 || sky.w != 0) {
+      const float4 v = sq.vis[kVolumeKindAmbient * sq.capacity + i];
+      Col lc = record_unpack(U2{sky.z, sky.w}) * col(v.x, v.y, v.z);
+      lc = lc * wt.y;
+      acc = acc + lc * wt.x;
+    }
+    const uint4 aux = in.aux[i];
+    add_to_result(results, fbits(in.dir_slot[i].w), acc * record_unpack(U2{aux.x, aux.y}));
+  }
+}
+
+// volume_process_events (volume.cuh:100-229): the distance to the next scattering event is sampled in closed form; a path that scatters before
+// its hit becomes a volume hit (listed for k_volume_bounce), every path's throughput takes the transmittance over the sampling density. In the
+// non-procedural sky modes a ray that left the scene adds the sky here and ends ("sky fast path").
+__global__ __launch_bounds__(kBlock) void k_volume_events(DeviceScene sc, PathQueue in, VolumeQueue vq, float4* results, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const Volume vol = fog_volume(sc);
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    bool scattered = false;
+    if (i < n) {
+      float4 o4 = in.origin_t[i];
+      const float4 d4 = in.dir_slot[i];
+      uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
+      const uint32_t state = aux.w;
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      VolumePath path = volume_compute_path(sc, vol, origin, ray, o4.w);
+      Col record = record_unpack(U2{aux.x, aux.y});
+      uint32_t hit_inst = hid.x, hit_tri = hid.y;
+      const bool sky_fast_path = hit_inst == kHitSky && sc.sky_mode != kSkyDefault && (state & kStAllowAmbient) != 0;
+      if (sky_fast_path) {
+        Col sky = sky_color_no_compute(sc, origin, ray, state) * record;
+        sky = sky * volume_transmittance_length(vol, path.length);
+        add_to_result(results, fbits(d4.w), sky);
+        hit_inst = kHitInvalid;
+      }
+      const float intersection_probability = (state & kStDeltaPath) ? 0.5f : 1.0f;  // bounds the variance of highlights seen through the fog
+      const F2 randoms = smp.next2(kRndVolumeIntersection);
+      float pdf = 1.0f;
+      if (randoms.y < intersection_probability) {
+        const float volume_dist = volume_sample_intersection(vol, path.start, path.length, randoms.x);
+        if (volume_dist < o4.w) {
+          const float sample_pdf = volume_sample_intersection_pdf(vol, path.start, volume_dist);
+          o4.w = volume_dist; hit_inst = kHitVolumeFog; hit_tri = 0u;
+          record = record * vol.scattering;
+          pdf *= intersection_probability;
+          pdf *= sample_pdf;
+          scattered = true;
+          path.length = o4.w - path.start;
+        }
+      }
+      if (!scattered && !sky_fast_path) pdf *= (1.0f - intersection_probability) + intersection_probability * volume_miss_probability(vol, path.length);
+      record = record * volume_transmittance_length(vol, path.length);
+      record = record * (1.0f / pdf);
+      const U2 rp = record_pack(record);
+      aux.x = rp.x; aux.y = rp.y;
+      hid.x = hit_inst; hid.y = hit_tri;
+      in.origin_t[i] = o4; in.aux[i] = aux; in.hit_id[i] = hid;
+    }
+    const unsigned long long b = __ballot(scattered);
+    if (b) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlVolumeItems, (uint32_t) __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (scattered) vq.items[base + (uint32_t) __popcll(b & below)] = i;
+    }
+  }
+}
+
+// volume_process_tasks (volume.cuh:231-288): the paths that scattered in the fog continue in a direction drawn from the phase function
+__global__ __launch_bounds__(kBlock) void k_volume_bounce(DeviceScene sc, PathQueue in, PathQueue out, VolumeQueue vq, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlVolumeItems];
+  uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t k = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    const bool valid = k < n;
+    float4 n_o, n_d; uint4 n_aux, n_hid;
+    if (valid) {
+      const uint32_t i = vq.items[k];
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      const V3 ray = v3(d4.x, d4.y, d4.z);
+      const V3 origin = v3(o4.x, o4.y, o4.z) + ray * o4.w;
+      const VolContext ctx = volume_context(sc, origin, ray, aux.w, 0.0f);
+      const V3 bounce = volume_bsdf_sample(sc, ctx, smp, kRndVolGiResampling, kRndVolGiDiffuse);
+      uint32_t state = aux.w & ~(kStDeltaPath | kStCameraDirection | kStAllowEmission | kStUseIgnoreHandle);
+      if (sc.sky_mode != kSkyDefault) state &= ~kStAllowAmbient; else state |= kStAllowAmbient;
+      state |= kStVolumeScattered;
+      n_o = make_float4(origin.x, origin.y, origin.z, kFltMax);
+      n_d = make_float4(bounce.x, bounce.y, bounce.z, d4.w);
+      n_aux = make_uint4(aux.x, aux.y, aux.z, state);
+      n_hid = make_uint4(0u, 0u, hid.z, hid.w);
+    }
+    const unsigned long long b = __ballot(valid);
+    if (b) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count_out, (uint32_t) __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (valid) {
+        const uint32_t j = base + (uint32_t) __popcll(b & below);
+        out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
+      }
+    }
   }
 }
 

@@ -30,6 +30,14 @@ struct WavefrontKernels {
   void (*shadow_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
                       uint32_t lds_nodes);
   void (*resolve)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
+  // fog (dev_volume.h): light scattered into the rays of a depth, its summation, the scattering events and their bounce
+  void (*volume_inscatter)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
+                           uint32_t depth_const);
+  void (*volume_resolve)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, float4* results,
+                         const uint32_t* ctrl);
+  void (*volume_events)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, float4* results, uint32_t* ctrl, uint32_t depth_const);
+  void (*volume_bounce)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const VolumeQueue& vq, uint32_t* ctrl,
+                        uint32_t depth_const);
   void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                      uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);
 };

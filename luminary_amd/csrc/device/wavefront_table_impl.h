@@ -49,13 +49,29 @@ static void shadow_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSc
 static void resolve(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);
 }
+static void volume_inscatter(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
+                             uint32_t depth_const) {
+  hipLaunchKernelGGL(k_volume_inscatter, dim3(grid), dim3(kBlock), 0, s, sc, in, vq, sq, ctrl, depth_const);
+}
+static void volume_resolve(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, float4* results,
+                           const uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_volume_resolve, dim3(grid), dim3(kBlock), 0, s, sc, in, vq, sq, results, ctrl);
+}
+static void volume_events(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, float4* results, uint32_t* ctrl,
+                          uint32_t depth_const) {
+  hipLaunchKernelGGL(k_volume_events, dim3(grid), dim3(kBlock), 0, s, sc, in, vq, results, ctrl, depth_const);
+}
+static void volume_bounce(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const VolumeQueue& vq, uint32_t* ctrl,
+                          uint32_t depth_const) {
+  hipLaunchKernelGGL(k_volume_bounce, dim3(grid), dim3(kBlock), 0, s, sc, in, out, vq, ctrl, depth_const);
+}
 static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                        uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_rays};
 
 }  // namespace table
 LUM_NS_END

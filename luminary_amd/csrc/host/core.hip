@@ -52,6 +52,8 @@ struct LumContext {
   PathQueue queue[2]{};
   NeeQueue nee{};
   ShadowQueue shadow{};
+  VolumeQueue volume{};           // fog (dev_volume.h); allocated with the work block when the scene's fog is active
+  uint32_t work_shadow_kinds = 0; // visibility-ray kinds per path the work block was sized for (4, or 17 with fog)
   float4* d_results = nullptr;
   float* d_frame_output = nullptr;  // display-referred planes of the output chain [3 * W * H]
   uint32_t frame_output_pixels = 0;
@@ -152,14 +154,19 @@ void free_work(LumContext* ctx) {
   if (ctx->work_block) (void) hipFree(ctx->work_block);
   ctx->work_block = nullptr;
   ctx->capacity = 0;
+  ctx->work_shadow_kinds = 0;
 }
 
 int ensure_work(LumContext* ctx, uint32_t paths) {
-  if (paths <= ctx->capacity) return 0;
+  // with fog a path can ask for 17 visibility rays in the in-scattering pass (15 bridge segments, sun, ambient) instead of 4 at a surface
+  const uint32_t kinds = ctx->scene.fog_active ? kVolumeShadowKinds : 4u;
+  if (paths <= ctx->capacity && kinds <= ctx->work_shadow_kinds) return 0;
+  if (paths < ctx->capacity) paths = ctx->capacity;
   free_work(ctx);
-  // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to 4 visibility rays x (48 B + 16 B result) + 4 B light-query index
+  // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to `kinds` visibility rays x (48 B + 16 B result) + 4 B light-query index
+  // (+ the fog's 48 B of in-scattering records and 4 B scattering-event index)
   const size_t n = paths;
-  const size_t bytes = n * (2 * 68 + 80 + 16 + 4 * 64 + 4) + 32 * 256;
+  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 52 : 0)) + 40 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
@@ -176,12 +183,20 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   ctx->nee.ambient         = (uint4*) take(n * 16);
   ctx->nee.sun             = (uint4*) take(n * 16);
   ctx->d_results           = (float4*) take(n * 16);
-  ctx->shadow.origin_dist  = (float4*) take(4 * n * 16);
-  ctx->shadow.dir_out      = (float4*) take(4 * n * 16);
-  ctx->shadow.ids          = (uint4*) take(4 * n * 16);
-  ctx->shadow.vis          = (float4*) take(4 * n * 16);
+  ctx->shadow.origin_dist  = (float4*) take(kinds * n * 16);
+  ctx->shadow.dir_out      = (float4*) take(kinds * n * 16);
+  ctx->shadow.ids          = (uint4*) take(kinds * n * 16);
+  ctx->shadow.vis          = (float4*) take(kinds * n * 16);
   ctx->shadow.light_items  = (uint32_t*) take(n * 4);
   ctx->shadow.capacity     = paths;
+  ctx->volume = VolumeQueue{};
+  if (kinds > 4u) {
+    ctx->volume.bridge = (float4*) take(n * 16);
+    ctx->volume.sky    = (uint4*) take(n * 16);
+    ctx->volume.weight = (float4*) take(n * 16);
+    ctx->volume.items  = (uint32_t*) take(n * 4);
+  }
+  ctx->work_shadow_kinds = kinds;
   ctx->capacity = paths;
   return 0;
 }
@@ -646,6 +661,20 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   sc.sky_lut_transmittance = nullptr; sc.sky_lut_multiscattering = nullptr;
   sc.sky_hdri = nullptr; sc.sky_hdri_dim = 0;
   sc.sky_aerial_perspective = v->sky_aerial_perspective;
+  // ---- fog ----
+  sc.fog_active = v->fog_active ? 1u : 0u;
+  sc.fog_density = v->fog_density; sc.fog_dist = v->fog_dist; sc.fog_height = v->fog_height;
+  std::memcpy(sc.fog_phase, v->fog_phase, sizeof(sc.fog_phase));
+  sc.bridge_max_num_vertices = v->bridge_max_num_vertices;
+  sc.bridge_lut = nullptr;
+  if (sc.fog_active) {
+    if (!(sc.fog_density > 0.0f)) { ctx->error = "lumc_scene_upload: fog needs a positive density"; return 1; }
+    if (sc.num_lights > 0) {  // bridges to the emissive triangles need the vertex-count table and at least one vertex
+      if (!v->bridge_lut) { ctx->error = "lumc_scene_upload: fog with emissive triangles needs bridge_lut"; return 1; }
+      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
+      if (upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
+    }
+  }
   if (sc.sky_mode != kSkyConstantColor) {  // HDRI mode bakes from them and samples the sun through them
     const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
     if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
@@ -837,6 +866,19 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
+    if (sc.fog_active) {  // device_renderer.c:64-76: in-scattering with its own visibility pass, then the scattering events
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
+        wf.volume_inscatter(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->shadow, ctrl, depth_const);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
+        wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, nullptr, ctrl + kCtlVolumeShift, ctx->d_counters, ctx->lds_nodes);
+      }
+      Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
+      wf.volume_resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
+      wf.volume_events(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->d_results, ctrl, depth_const);
+    }
     if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
       wf.sky_inscattering(grid_for(N), stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
@@ -865,6 +907,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
       wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
+    }
+    if (sc.fog_active && depth != max_depth) {  // device_renderer.c:114-118
+      Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
+      wf.volume_bounce(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->volume, ctrl, depth_const);
     }
     cur ^= 1;
   }

@@ -126,6 +126,7 @@ bool generate_stars(uint32_t seed, uint32_t count, std::vector<float>* stars, st
   return true;
 }
 
+extern "C" const unsigned char lum_embedded_bridge_lut[];  // 16-byte aligned (embed.S)
 extern "C" const unsigned char lum_embedded_moon_albedo[];
 extern "C" const unsigned char lum_embedded_moon_albedo_end[];
 extern "C" const unsigned char lum_embedded_moon_normal[];
@@ -993,6 +994,12 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   v.sky_hdri_dim = sky.hdri_dim ? sky.hdri_dim : 1u; v.sky_hdri_samples = sky.hdri_samples ? sky.hdri_samples : 1u;
   std::memcpy(v.sky_hdri_origin, scene.hdri_origin, sizeof(v.sky_hdri_origin));
   v.sky_aerial_perspective = sky.aerial_perspective ? 1u : 0u;
+  // fog (device_struct_fog_convert, device_structs.c:219-231); the phase function's parameters depend on the droplet diameter only
+  v.fog_active = scene.fog.active ? 1u : 0u;
+  v.fog_density = scene.fog.density; v.fog_dist = scene.fog.dist; v.fog_height = scene.fog.height;
+  jendersie_eon_parameters(scene.fog.droplet_diameter, v.fog_phase);
+  v.bridge_lut = reinterpret_cast<const float*>(lum_embedded_bridge_lut);  // device_embedded_data.c:50-60
+  v.bridge_max_num_vertices = st.bridge_max_num_vertices & 15u;             // device_structs.h:11
   return std::string();
 }
 

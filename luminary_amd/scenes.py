@@ -690,3 +690,15 @@ def edge_scene(kind, width=48, height=32, bounces=4):
         raise ValueError(kind)
     set_camera(host, (0.0, 2.0, 9.0), (-0.1, 0.0, 0.0), fov=0.8)
     return host
+
+
+def probe_light_scene(directory, triangle, emission, width=8, height=8, bounces=0):
+    """One bidirectional emissive triangle under a black sky, the camera at (3, 0, 0) looking down -z past it: what tests/test_fog.py integrates
+    the fog's single scattering over. `directory` is unused (kept for symmetry with the file-based scenes)."""
+    host = Host()
+    apply_benchmark_settings(host, width, height, bounces, sky=(0.0, 0.0, 0.0))
+    glow = host.add_material(_material((0.0, 0.0, 0.0), 0.9, emission=emission, bidirectional=True))
+    t = np.asarray(triangle, dtype=np.float32).reshape(1, 9)
+    host.new_instance(host.add_mesh(t, np.full(1, glow, dtype=np.uint16)))
+    set_camera(host, (3.0, 0.0, 0.0), (0.0, 0.0, 0.0), fov=0.05)
+    return host

@@ -135,14 +135,23 @@ static inline float light_tree_importance(const GeoCtx* g, float power, vec3 mea
   const float NdotL = o_saturate(v_dot(PO, g->normal) * sqrtf(inv));
   return r * (NdotL * (1.0f - t) + t);
 }
+/* The tree is walked for a surface vertex (light_tree_importance<GEOMETRY>) or for a ray segment through a volume (<VOLUME>, light_tree.cuh:91-122,
+ * defined in o_volume.h); the two contexts draw from different random sets (material.cuh:60-63, :78-81). */
+struct VolCtx;
+static inline float light_tree_importance_volume(const struct VolCtx* c, float power, vec3 mean, float std_dev);
+typedef struct { const GeoCtx* geo; const struct VolCtx* vol; uint32_t rt_prepass, rt_postpass; } LTQuery;
+static inline LTQuery lt_query_geometry(const GeoCtx* g) { LTQuery q = {g, NULL, RT_LIGHT_GEO_TREE_PREPASS, RT_LIGHT_GEO_TREE_POSTPASS}; return q; }
+static inline float lt_importance(const LTQuery* q, float power, vec3 mean, float std_dev) {
+  return q->vol ? light_tree_importance_volume(q->vol, power, mean, std_dev) : light_tree_importance(q->geo, power, mean, std_dev);
+}
 /* light_tree.cuh:133-161: rel_* arrays are 8 entries each; power is u16 in root sections, u8 in nodes */
-static inline float lt_child_importance(const GeoCtx* g, const uint8_t* mx, const uint8_t* my, const uint8_t* mz, const uint8_t* sd, uint32_t power_q,
+static inline float lt_child_importance(const LTQuery* g, const uint8_t* mx, const uint8_t* my, const uint8_t* mz, const uint8_t* sd, uint32_t power_q,
                                         vec3 base, vec3 exp, float exp_v, uint32_t i) {
   if (power_q == 0) return 0.0f;
   const float power = (float) power_q;
   const float std_dev = sd[i] * exp_v;
   const vec3 mean = v_add(v_mul(v3(mx[i], my[i], mz[i]), exp), base);
-  return fmaxf(light_tree_importance(g, power, mean, std_dev), 0.0f);
+  return fmaxf(lt_importance(g, power, mean, std_dev), 0.0f);
 }
 /* light_tree.cuh:176-189 */
 static inline LTCont lt_cont_pack(uint32_t child_index, float probability, bool is_light) {
@@ -157,7 +166,7 @@ static inline LTCont lt_cont_pack(uint32_t child_index, float probability, bool 
 static inline float lt_cont_prob(LTCont c) { return c.probability * (1.0f / 0xFFFFF) * LIGHT_TREE_NUM_OUTPUTS; }
 
 /* light_tree.cuh:191-255. Root header (device_utils.h:304-317): u16 x,y,z,num_root_lights,power_normalization; u8 num_sections,pad; s8 exp x,y,z,std */
-static inline LTWork light_tree_prepass(const OracleScene* s, const GeoCtx* g, const Sampler* smp) {
+static inline LTWork light_tree_prepass(const OracleScene* s, const LTQuery* g, const Sampler* smp) {
   const uint8_t* root = s->light_tree_root;
   uint16_t h16[5]; memcpy(h16, root, 10);
   const uint32_t num_sections = root[10];
@@ -168,7 +177,7 @@ static inline LTWork light_tree_prepass(const OracleScene* s, const GeoCtx* g, c
   RISLane lane[LIGHT_TREE_NUM_OUTPUTS];
   uint32_t selected[LIGHT_TREE_NUM_OUTPUTS];
   for (uint32_t i = 0; i < LIGHT_TREE_NUM_OUTPUTS; i++) {
-    lane[i].random = rnd1(smp, RT_LIGHT_GEO_TREE_PREPASS + i);
+    lane[i].random = rnd1(smp, g->rt_prepass + i);
     lane[i].selected_target = 0.0f;
     selected[i] = 0;
   }
@@ -202,7 +211,7 @@ static inline LTWork light_tree_prepass(const OracleScene* s, const GeoCtx* g, c
 }
 
 /* light_tree.cuh:257-320. Node (device_utils.h:283-302): u16 x,y,z,pad; s8 exp x,y,z,std; u8 num_lights,pad; u16 pad; u32 child_ptr, light_ptr; 5 x u8[8] */
-static inline LTResult light_tree_postpass(const OracleScene* s, const GeoCtx* g, const Sampler* smp, uint32_t lane_id, const LTWork* work) {
+static inline LTResult light_tree_postpass(const OracleScene* s, const LTQuery* g, const Sampler* smp, uint32_t lane_id, const LTWork* work) {
   const LTCont cont = work->data[lane_id];
   const float cp = lt_cont_prob(cont);
   LTResult res;
@@ -211,7 +220,7 @@ static inline LTResult light_tree_postpass(const OracleScene* s, const GeoCtx* g
   if (cp == 0.0f) return res;
   if (cont.is_light) { res.light_id = cont.child_index; return res; }
   const uint8_t* node = s->light_tree_nodes + 64 * (size_t) cont.child_index;
-  RISReservoir rv = ris_init(rnd1(smp, RT_LIGHT_GEO_TREE_POSTPASS + lane_id));
+  RISReservoir rv = ris_init(rnd1(smp, g->rt_postpass + lane_id));
   while (res.light_id == LIGHT_ID_INVALID) {
     uint16_t b16[3]; memcpy(b16, node, 6);
     const int8_t ex = (int8_t) node[8], ey = (int8_t) node[9], ez = (int8_t) node[10], es = (int8_t) node[11];
@@ -404,13 +413,14 @@ typedef struct { uint32_t light_id; vec3 ray; RGBF light_color; float dist; floa
 
 static inline LightSample light_sample(const OracleScene* s, const GeoCtx* g, const Sampler* smp) {
   const OLuts luts = scene_luts(s);
-  const LTWork work = light_tree_prepass(s, g, smp);
+  const LTQuery query = lt_query_geometry(g);
+  const LTWork work = light_tree_prepass(s, &query, smp);
   LightSample res;
   res.light_id = LIGHT_ID_INVALID;
   res.ray = v3(0.0f, 0.0f, 0.0f); res.light_color = c_splat(0.0f); res.dist = 0.0f;
   RISReservoir rv = ris_init(rnd1(smp, RT_LIGHT_GEO_RESAMPLING));
   for (uint32_t out = 0; out < LIGHT_TREE_NUM_OUTPUTS; out++) {
-    const LTResult o = light_tree_postpass(s, g, smp, out, &work);
+    const LTResult o = light_tree_postpass(s, &query, smp, out, &work);
     if (o.light_id == LIGHT_ID_INVALID) continue;
     const uint32_t inst = s->light_tri_handles[2 * o.light_id], tri = s->light_tri_handles[2 * o.light_id + 1];
     if (inst == g->instance_id && tri == g->tri_id) continue;

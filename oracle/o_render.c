@@ -24,6 +24,7 @@
 #include "o_adaptive.h"
 enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 #include "o_sky.h"
+#include "o_volume.h"
 
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
 #define GEOMETRY_DELTA_PATH_CUTOFF 0.05f
@@ -225,6 +226,108 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
   return result;
 }
 
+
+/* ---- fog: what the volume kernels do to one path at one depth (cuda/volume.cuh, optix/optix_kernel_shadow_volume.cu) ---- */
+/* light_sample<MATERIAL_VOLUME> (light.cuh:84-159): the eight tree outputs are bridge candidates (light_evaluate_candidate<VOLUME>, :84-98) */
+static BridgeSample volume_light_sample(const OracleScene* s, const VolCtx* c, const Sampler* smp) {
+  LTQuery query = {NULL, c, RT_VOL_TREE_PREPASS, RT_VOL_TREE_POSTPASS};
+  const LTWork work = light_tree_prepass(s, &query, smp);
+  BridgeSample res;
+  res.light_id = LIGHT_ID_INVALID; res.light_color = c_splat(0.0f); res.seed = 0; res.rotation.x = res.rotation.y = res.rotation.z = 0.0f; res.rotation.w = 1.0f; res.scale = 0.0f;
+  RISReservoir rv = ris_init(rnd1(smp, RT_VOL_GEO_RESAMPLING));
+  for (uint32_t out = 0; out < LIGHT_TREE_NUM_OUTPUTS; out++) {
+    const LTResult o = light_tree_postpass(s, &query, smp, out, &work);
+    if (o.light_id == LIGHT_ID_INVALID) continue;
+    const uint32_t inst = s->light_tri_handles[2 * o.light_id], tri = s->light_tri_handles[2 * o.light_id + 1];
+    uint32_t uvp[3];
+    TriLight tl = light_triangle_init(s, inst, tri, uvp);
+    float target, weight;
+    const BridgeSample bs = bridges_sample(s, c, &tl, o.light_id, uvp, smp, out, &target, &weight);
+    if (ris_add(&rv, target, weight * o.weight)) res = bs;
+  }
+  res.light_color = c_scale(res.light_color, ris_sampling_weight(&rv));
+  return res;
+}
+/* bridges_sample_apply_shadowing (light_bridges.cuh:356-446): the path is rebuilt from its seed, rotated by the 16-bit quaternion of the task
+ * and scaled; one visibility ray per segment (the segment that reaches the light leaves that light out) */
+static RGBF bridges_apply_shadowing(const OracleScene* s, const OTracer* tr, const VolCtx* c, const BridgeSample* task, const Sampler* smp, uint64_t* cnt) {
+  const uint32_t seed = task->seed;
+  const uint32_t l_inst = s->light_tri_handles[2 * task->light_id], l_tri = s->light_tri_handles[2 * task->light_id + 1];
+  uint32_t uvp[3];
+  TriLight light = light_triangle_init(s, l_inst, l_tri, uvp);
+  const vec3 point_on_light = light_triangle_sample_bridges(&light, rnd2(smp, RT_BRIDGE_LIGHT_POINT + seed));
+  float att, ipdf;
+  const vec3 initial_vertex = bridges_sample_initial_vertex(c, point_on_light, smp, seed, &att, &ipdf);
+  vec3 light_dir; float area, light_dist;
+  light_triangle_finalize_bridges(&light, uvp, initial_vertex, point_on_light, &light_dir, &light_dist, &area);
+  const vec3 light_vector = v_scale(light_dir, light_dist);
+  float vc_pdf;
+  const uint32_t vertex_count = bridges_sample_vertex_count(s, &c->vol, v_len(light_vector), seed, smp, &vc_pdf);
+  const Quat16 rotation = quaternion_pack16(task->rotation);
+  const float scale = task->scale;
+  vec3 current_vertex = initial_vertex;
+  vec3 dir_sampled = v_norm(light_vector);
+  vec3 dir = q16_apply(rotation, dir_sampled);
+  float dist = -o_log(rnd1(smp, RT_BRIDGE_DISTANCE + seed * LIGHT_GEO_MAX_BRIDGE_LENGTH + 0)) * scale;
+  cnt[ORACLE_CNT_SHADOW]++;
+  RGBF shadow = trace_shadow(tr, current_vertex, dir, dist, l_inst, l_tri, 0xFFFFFFFFu, 0);
+  for (uint32_t v = 1; v < BRIDGES_MAX_VERTEX_COUNT; v++) {
+    if (v >= vertex_count) break; /* OPTIX_TRACE_STATUS_OPTIONAL_UNUSED: visibility 1 */
+    current_vertex = v_add(current_vertex, v_scale(dir, dist));
+    dir_sampled = bridges_phase_sample(dir_sampled, rnd2(smp, RT_BRIDGE_PHASE + seed * LIGHT_GEO_MAX_BRIDGE_LENGTH + v));
+    dir = q16_apply(rotation, dir_sampled);
+    dist = -o_log(rnd1(smp, RT_BRIDGE_DISTANCE + seed * LIGHT_GEO_MAX_BRIDGE_LENGTH + v)) * scale;
+    cnt[ORACLE_CNT_SHADOW]++;
+    shadow = c_mul(shadow, trace_shadow(tr, current_vertex, dir, dist, l_inst, l_tri, 0xFFFFFFFFu, 0));
+  }
+  return c_mul(task->light_color, shadow);
+}
+/* sky_color_no_compute (sky.cuh:534-565) */
+static RGBF sky_color_no_compute(const OracleScene* s, vec3 origin, vec3 ray, uint16_t state) {
+  if (s->sky_mode == SKY_MODE_HDRI) return sky_hdri_color(s, origin, ray, state);
+  if (s->sky_mode == SKY_MODE_CONSTANT_COLOR) return c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]);
+  return c_splat(0.0f);
+}
+/* volume_process_inscattering (volume.cuh:31-98) + the shadow pass over its three tasks (optix_kernel_shadow_volume.cu:13-98): light that the
+ * fog scatters into the ray between its origin and its end point (`depth_t`: the hit distance, FLT_MAX for a ray that left the scene) */
+static RGBF volume_inscattering(const OracleScene* s, const OTracer* tr, const Sampler* smp, vec3 origin, vec3 ray, uint16_t state, float depth_t, bool lights_present,
+                                uint64_t* cnt) {
+  VolCtx ctx = volume_context(s, origin, ray, state, depth_t);
+  RGBF acc = c_splat(0.0f);
+  const bool bridges_allowed = lights_present && (state & ST_DELTA_PATH) != 0 && (state & ST_VOLUME_SCATTERED) == 0; /* direct_lighting.cuh:296-306 */
+  if (bridges_allowed) {
+    const BridgeSample bs = volume_light_sample(s, &ctx, smp);
+    if (bs.light_id != LIGHT_ID_INVALID && bs.seed != 0xFFFFFFFFu) acc = c_add(acc, bridges_apply_shadowing(s, tr, &ctx, &bs, smp, cnt));
+  }
+  const float w = volume_sky_initial_vertex(&ctx, smp); /* the vertex the sun and the ambient sample start from */
+  const bool sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
+  if (sun_allowed) {
+    const OSky sky_v = osky_view(s);
+    RGBF lc; vec3 dir;
+    uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
+    if (volume_sun_sample(s, &sky_v, &ctx, smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+    if (sun_color.x != 0 || sun_color.y != 0) {
+      cnt[ORACLE_CNT_SHADOW]++;
+      const RGBF vis = trace_shadow(tr, ctx.position, ray_unpack(sun_ray), FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
+      acc = c_add(acc, c_scale(c_mul(record_unpack(sun_color), vis), w));
+    }
+  }
+  const vec3 bounce = volume_bsdf_sample(s, &ctx, smp, RT_VOL_AMBIENT_RESAMPLING, RT_VOL_AMBIENT_DIFFUSE);
+  if (s->sky_mode != SKY_MODE_DEFAULT) { /* direct_lighting.cuh:385-403, :521-584 */
+    const uint2_t amb_color = record_pack(c_mul(sky_color_no_compute(s, ctx.position, bounce, 0), c_splat(1.0f)));
+    const uint2_t amb_ray = ray_pack(bounce);
+    if (amb_color.x != 0 || amb_color.y != 0) {
+      const vec3 ar = ray_unpack(amb_ray);
+      cnt[ORACLE_CNT_SHADOW]++;
+      const RGBF vis = trace_shadow(tr, ctx.position, ar, FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
+      RGBF lc = c_mul(record_unpack(amb_color), vis);
+      lc = c_scale(lc, fog_transmittance(s, ctx.position, ar, FLT_MAX));
+      acc = c_add(acc, c_scale(lc, w));
+    }
+  }
+  return acc;
+}
+
 static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
   if (s->shading_mode != 0) return render_path_debug(s, tr, px, py, sample_id, cnt);
   const OLuts luts = scene_luts(s);
@@ -241,8 +344,43 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
 
   for (uint32_t depth = 0; depth <= s->max_ray_depth; depth++) {
     smp.depth = (depth == s->max_ray_depth && depth > 0) ? depth - 1 : depth;
-    const OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
+    OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
     cnt[ORACLE_CNT_TRACE]++;
+    if (s->fog_active) {
+      /* device_renderer.c:64-76: in-scattering and its shadow pass, then the distance sampling (volume_process_events, volume.cuh:100-229) */
+      const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, cnt);
+      beauty_add(&result, c_mul(in, record_unpack(record_p)));
+      const OVolume vol = fog_volume(s);
+      OVolumePath path = volume_compute_path(s, &vol, origin, ray, hit.t);
+      RGBF record = record_unpack(record_p);
+      const bool sky_fast_path = hit.instance_id == HIT_TYPE_SKY && s->sky_mode != SKY_MODE_DEFAULT && (state & ST_ALLOW_AMBIENT) != 0;
+      if (sky_fast_path) {
+        RGBF sky = c_mul(sky_color_no_compute(s, origin, ray, state), record);
+        sky = c_scale(sky, volume_transmittance_length(&vol, path.length));
+        beauty_add(&result, sky);
+        hit.instance_id = HIT_TYPE_INVALID;
+      }
+      const float intersection_probability = (state & ST_DELTA_PATH) ? 0.5f : 1.0f; /* bounds the variance of highlights seen through the fog */
+      const float2_t randoms = rnd2(&smp, RT_VOLUME_INTERSECTION);
+      bool sampled = false;
+      float pdf = 1.0f;
+      if (randoms.y < intersection_probability) {
+        const float volume_dist = volume_sample_intersection(&vol, path.start, path.length, randoms.x);
+        if (volume_dist < hit.t) {
+          const float sample_pdf = volume_sample_intersection_pdf(&vol, path.start, volume_dist);
+          hit.t = volume_dist; hit.instance_id = HIT_TYPE_VOLUME_FOG; hit.tri_id = 0;
+          record = c_scale(record, vol.scattering);
+          pdf *= intersection_probability;
+          pdf *= sample_pdf;
+          sampled = true;
+          path.length = hit.t - path.start;
+        }
+      }
+      if (!sampled && !sky_fast_path) pdf *= (1.0f - intersection_probability) + intersection_probability * volume_miss_probability(&vol, path.length);
+      record = c_scale(record, volume_transmittance_length(&vol, path.length));
+      record = c_scale(record, 1.0f / pdf);
+      record_p = record_pack(record);
+    }
     if (hit.instance_id == HIT_TYPE_SKY) {
       if (state & ST_ALLOW_AMBIENT) {
         RGBF sky = sky_color;
@@ -265,6 +403,17 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       beauty_add(&result, c);
       record_p = record_pack(record);
     }
+    if (hit.instance_id == HIT_TYPE_INVALID) break; /* the sky fast path of the volume events ended the path (no task type counts it) */
+    if (hit.instance_id == HIT_TYPE_VOLUME_FOG) { /* volume_process_tasks (volume.cuh:231-288); not queued at the last depth (device_renderer.c:114) */
+      if (depth == s->max_ray_depth) break;
+      origin = v_add(origin, v_scale(ray, hit.t));
+      const VolCtx vctx = volume_context(s, origin, ray, state, 0.0f);
+      ray = volume_bsdf_sample(s, &vctx, &smp, RT_VOL_GI_RESAMPLING, RT_VOL_GI_DIFFUSE);
+      state &= ~(ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
+      if (s->sky_mode != SKY_MODE_DEFAULT) state &= ~ST_ALLOW_AMBIENT; else state |= ST_ALLOW_AMBIENT;
+      state |= ST_VOLUME_SCATTERED;
+      continue;
+    }
     cnt[ORACLE_CNT_VERTICES]++;
     const vec3 hit_origin = v_add(origin, v_scale(ray, hit.t));
     const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
@@ -273,7 +422,10 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     float root_sum = 0.0f;
     LightSample ls; ls.light_id = LIGHT_ID_INVALID; ls.light_color = c_splat(0.0f); ls.ray = v3(0, 0, 0); ls.dist = 0.0f;
     const bool geo_allowed = lights_present && ((state & ST_VOLUME_SCATTERED) == 0);
-    if (geo_allowed) { ls = light_sample(s, &g, &smp); root_sum = ls.root_sum; }
+    if (geo_allowed) {
+      ls = light_sample(s, &g, &smp); root_sum = ls.root_sum;
+      if (s->fog_active) ls.light_color = c_scale(ls.light_color, fog_transmittance(s, g.position, ls.ray, ls.dist)); /* direct_lighting.cuh:329-337 */
+    }
     LightBSDFSample lb; lb.sampling_probability = 0.0f; lb.weight = c_splat(0.0f); lb.ray = v3(0, 0, 1);
     const bool bsdf_allowed = geo_allowed;
     if (bsdf_allowed) lb = light_bsdf_get_sample(&luts, &g, &smp);
@@ -285,7 +437,10 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     if (sun_allowed) {
       const OSky sky_v = osky_view(s);
       RGBF lc; vec3 dir;
-      if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+      if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) {
+        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, g.position, dir, FLT_MAX)); /* direct_lighting.cuh:104-108 */
+        sun_color = record_pack(lc); sun_ray = ray_pack(dir);
+      }
     }
     uint2_t amb_color = {0, 0}, amb_ray = {0, 0};
     if (ambient_allowed) { /* direct_lighting.cuh:385-403 */
@@ -349,7 +504,9 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
         }
         RGBF vis = c_splat(0.0f);
         if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, lb.ray, dist, lh_inst, lh_tri, hit.instance_id, hit.tri_id); }
-        acc = c_add(acc, c_mul(lc, vis));
+        lc = c_mul(lc, vis);
+        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, hit_origin, lb.ray, dist)); /* direct_lighting.cuh:661-666 */
+        acc = c_add(acc, lc);
       }
       { /* direct_lighting.cuh:466-519 without ocean caustics */
         const bool valid = (sun_color.x != 0 || sun_color.y != 0) && sun_allowed;
@@ -366,6 +523,7 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
         RGBF vis = c_splat(0.0f);
         if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, ar, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, hit.tri_id); }
         RGBF lc = c_mul(record_unpack(amb_color), vis);
+        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, hit_origin, ar, FLT_MAX)); /* direct_lighting.cuh:561-563 */
         if (!ambient_allowed) lc = c_splat(0.0f);
         acc = c_add(acc, lc);
       }
@@ -730,10 +888,11 @@ void oracle_probe_light_tree(const OracleScene* s, const OracleProbeMaterial* m,
   const GeoCtx g = probe_context(m, position, normal, V);
   for (uint32_t i = 0; i < count; i++) {
     const Sampler smp = {s->bluenoise_2d, px, py, first + i, 0};
-    const LTWork work = light_tree_prepass(s, &g, &smp);
+    const LTQuery query = lt_query_geometry(&g);
+    const LTWork work = light_tree_prepass(s, &query, &smp);
     if (root_sums) root_sums[i] = work.root_sum;
     for (uint32_t lane = 0; lane < LIGHT_TREE_NUM_OUTPUTS; lane++) {
-      const LTResult r = light_tree_postpass(s, &g, &smp, lane, &work);
+      const LTResult r = light_tree_postpass(s, &query, &smp, lane, &work);
       light_ids[i * LIGHT_TREE_NUM_OUTPUTS + lane] = r.light_id;
       weights[i * LIGHT_TREE_NUM_OUTPUTS + lane] = r.weight;
     }
@@ -751,4 +910,32 @@ void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* 
     colors[3 * i] = ls.light_color.r; colors[3 * i + 1] = ls.light_color.g; colors[3 * i + 2] = ls.light_color.b;
     dists[i] = ls.dist;
   }
+}
+
+/* ---- probes of the fog's building blocks (tests/test_fog.py) ---- */
+void oracle_probe_volume_path(const float cam_pos[3], float dist, float height, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out) {
+  OracleScene sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.cam_pos[0] = cam_pos[0]; sc.cam_pos[1] = cam_pos[1]; sc.cam_pos[2] = cam_pos[2];
+  sc.fog_active = 1; sc.fog_density = 1.0f; sc.fog_dist = dist; sc.fog_height = height;
+  const OVolume vol = fog_volume(&sc);
+  for (uint32_t i = 0; i < count; i++) {
+    const OVolumePath p = volume_compute_path(&sc, &vol, v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), limits[i]);
+    out[2 * i] = p.start; out[2 * i + 1] = p.length;
+  }
+}
+void oracle_probe_fog_phase(const OracleScene* s, uint32_t count, const float* cos_angle, float* out) {
+  for (uint32_t i = 0; i < count; i++) out[i] = fog_phase_function(s, cos_angle[i]);
+}
+/* rnd: 3 numbers per sample (direction x, direction y, lobe choice); out: the cosine between the incoming and the sampled direction */
+void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const float* rnd, float* out) {
+  const vec3 in = v_norm(v3(0.3f, -0.5f, 0.8f));
+  for (uint32_t i = 0; i < count; i++) {
+    const float2_t r = {rnd[3 * i], rnd[3 * i + 1]};
+    out[i] = v_dot(fog_phase_sample(s, in, r, rnd[3 * i + 2]), in);
+  }
+}
+void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf) {
+  const OVolume v = {scattering, 1.0f, 1.0f, 0.0f};
+  for (uint32_t i = 0; i < count; i++) { t[i] = volume_sample_bounded(&v, max_length, rnd[i]); pdf[i] = volume_sample_bounded_pdf(&v, max_length, t[i]); }
 }

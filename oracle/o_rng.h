@@ -14,8 +14,15 @@ enum {
   RT_LENS_METHOD = 0, RT_LENS = 33, RT_LENS_BLADE = 35, RT_LENS_WAVELENGTH = 37,
   RT_BSDF_REFLECTION = 39, RT_BSDF_DIFFUSE = 43, RT_BSDF_REFRACTION = 47, RT_BSDF_RESAMPLING = 51, RT_BSDF_OPACITY = 55,
   RT_VOLUME_INTERSECTION = 59, RT_RUSSIAN_ROULETTE = 61, RT_CAMERA_JITTER = 63, RT_CAMERA_TIME = 65,
+  RT_LIGHT_SUN_INITIAL_VERTEX = 344,
   RT_LIGHT_GEO_INITIAL_VERTEX = 358, RT_LIGHT_GEO_RAY = 367, RT_LIGHT_GEO_RESAMPLING = 384,
   RT_LIGHT_GEO_TREE_PREPASS = 387, RT_LIGHT_GEO_TREE_POSTPASS = 404,
+  RT_BRIDGE_DISTANCE = 421, RT_BRIDGE_PHASE = 486, RT_BRIDGE_LIGHT_POINT = 551, RT_BRIDGE_VERTEX_COUNT = 560,
+  /* the volume context's random sets (material.cuh:76-81): LIGHT_SUN<1>, LIGHT_GEO<1>, BSDF<0> for the bounce, BSDF<2> for the ambient sample;
+   * element of set k = base + k * allocation size (random.cuh:72) */
+  RT_VOL_SUN_BSDF = 346 + 1, RT_VOL_SUN_BSDF_METHOD = 349 + 1, RT_VOL_SUN_RAY = 352 + 1, RT_VOL_SUN_RESAMPLING = 355 + 1,
+  RT_VOL_GEO_RESAMPLING = 384 + 1, RT_VOL_TREE_PREPASS = 387 + 8, RT_VOL_TREE_POSTPASS = 404 + 8,
+  RT_VOL_GI_DIFFUSE = 43, RT_VOL_GI_RESAMPLING = 51, RT_VOL_AMBIENT_DIFFUSE = 43 + 2, RT_VOL_AMBIENT_RESAMPLING = 51 + 2,
   RT_LIGHT_BSDF_CHOICE = 569, RT_LIGHT_BSDF_DIRECTION = 571, RT_LIGHT_BSDF_TRACE = 573, RT_LIGHT_BSDF_RR = 575,
   RT_COUNT = 577
 };

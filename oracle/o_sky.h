@@ -29,7 +29,7 @@
 #define SKY_MS_SIZE 32
 #define SKY_MS_BASE 16
 #define SKY_MS_ITER 256
-#define RANDOM_TARGET_SKY_INSCATTERING_STEP 78u
+#define RANDOM_TARGET_SKY_INSCATTERING_STEP 79u
 #define RANDOM_TARGET_SKY_STEP_OFFSET 77u /* allocation rule of random.cuh:24-66; the sun targets are RandomSet::LIGHT_SUN<0> (material.cuh:61) */
 #define RT_SUN_BSDF 346u
 #define RT_SUN_BSDF_METHOD 349u

@@ -79,6 +79,13 @@ typedef struct OracleScene {
   uint32_t sky_hdri_dim, sky_hdri_samples;
   float sky_hdri_origin[3];
   uint32_t sky_aerial_perspective; /* sky.aerial_perspective: in-scattering and extinction along rays that hit geometry (not in constant-colour mode) */
+  /* fog volume (device_structs.c:219-231, cuda/volume_utils.cuh:8-27): a homogeneous scattering volume bounded by a disk of radius fog_dist around
+   * the camera and by y <= fog_height; scattering coefficient 0.001 * fog_density, no absorption */
+  uint32_t fog_active;
+  float fog_density, fog_dist, fog_height;
+  float fog_phase[4];               /* Jendersie-Eon g_hg, g_d, alpha, w_d of fog.droplet_diameter (math.cuh:1189-1232) */
+  const float* bridge_lut;          /* 64 x 21 floats (data/bridge): vertex-count importance of the bridge sampler (light_bridges.cuh:67-108) */
+  uint32_t bridge_max_num_vertices; /* settings.bridge_max_num_vertices (a 4-bit field on the device, device_structs.h:11) */
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -180,5 +187,11 @@ void oracle_probe_light_tree(const OracleScene* s, const OracleProbeMaterial* m,
                              uint32_t first, uint32_t count, uint32_t* light_ids, float* weights, float* root_sums);
 void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* m, const float position[3], const float normal[3], const float V[3], uint32_t px, uint32_t py,
                                uint32_t first, uint32_t count, uint32_t* light_ids, float* rays, float* colors, float* dists);
+
+/* fog (o_volume.h) */
+void oracle_probe_volume_path(const float cam_pos[3], float dist, float height, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out);
+void oracle_probe_fog_phase(const OracleScene* s, uint32_t count, const float* cos_angle, float* out);
+void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const float* rnd, float* out);
+void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf);
 
 #endif
