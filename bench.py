@@ -165,6 +165,11 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         sky.mode = 0
         host.set_sky(sky)
         label += " under the procedural sky (mode DEFAULT)"
+    if args.fog > 0.0:  # not a BASELINE configuration: the same scene inside the reference's fog volume (f4), for the kernel table
+        fog = host.get_fog()
+        fog.active, fog.density = True, args.fog
+        host.set_fog(fog)
+        label += " in fog of density %g" % args.fog
     view = host.device_scene()
     build_s = time.time() - t_build
     t_up = time.time()
@@ -328,6 +333,7 @@ def main():
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
+    ap.add_argument("--fog", type=float, default=0.0, help="density of the fog volume the scene is put in (0 = none, the BASELINE configurations)")
     ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
                     help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")
     args = ap.parse_args()

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueu
       }
       else if (sc.shading_mode == 4u) result = col(0.0f, 0.63f, 1.0f);  // IDENTIFICATION
     }
-    else {
+    else if (hid.x <= kHitTriangleLimit) {  // with fog: scattering events and paths the sky fast path ended have no debug colour
       const V3 hit_origin = origin + ray * o4.w;
       if (sc.shading_mode == 2u) result = splat(saturate((1.0f / o4.w) * 2.0f));  // DEPTH
       else if (sc.shading_mode == 4u) {                                            // IDENTIFICATION

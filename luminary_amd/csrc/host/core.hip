@@ -848,6 +848,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[0], nullptr, ctx->d_ctrl, ctx->d_counters, ctx->lds_nodes);
     }
+    if (sc.fog_active) {  // the debug queue keeps volume_process_events (device_renderer.c:145-147)
+      Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
+      wf.volume_events(grid_for(N), stream, sc, ctx->queue[0], ctx->volume, ctx->d_results, ctx->d_ctrl, 0u);
+    }
     Launch l(ctx, stream, LUMC_KERNEL_SHADE);
     wf.shade_debug(grid_for(N), stream, sc, ctx->queue[0], ctx->d_results, (const uint32_t*) ctx->d_ctrl);
     return 0;

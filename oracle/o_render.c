@@ -176,6 +176,7 @@ static bool russian_roulette(const OracleScene* s, const Sampler* smp, uint16_t 
 
 /* Debug shading modes: one closest-hit pass, then a colour per hit (geometry_process_tasks_debug, cuda/geometry.cuh:182-246) or per miss
  * (sky_process_tasks_debug, cuda/sky.cuh:635-665); queue: device/device_renderer.c:136-181. */
+static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p);
 static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
   Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
   RGBF result = c_splat(0.0f);
@@ -183,8 +184,13 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
   camera_sample(s, &smp, &origin, &ray);
   const uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
   const uint32_t medium = medium_ior_modify(0, 1.0f, true);
-  const OHit hit = trace_closest(tr, origin, ray, false, 0, 0);
+  OHit hit = trace_closest(tr, origin, ray, false, 0, 0);
   cnt[ORACLE_CNT_TRACE]++;
+  if (s->fog_active) { /* the debug queue keeps volume_process_events (device_renderer.c:145-147): the sky fast path shows through, a scattering event stays black */
+    uint2_t record_p = record_pack(c_splat(1.0f));
+    volume_events(s, &smp, origin, ray, state, &hit, &record_p, &result);
+    if (hit.instance_id == HIT_TYPE_INVALID || hit.instance_id == HIT_TYPE_VOLUME_FOG) return result;
+  }
   if (hit.instance_id == HIT_TYPE_SKY) {
     if (s->shading_mode == 1) { /* ALBEDO: sky_color_main(origin, ray, STATE_FLAG_CAMERA_DIRECTION) */
       RGBF sky = c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]);
@@ -328,28 +334,14 @@ static RGBF volume_inscattering(const OracleScene* s, const OTracer* tr, const S
   return acc;
 }
 
-static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
-  if (s->shading_mode != 0) return render_path_debug(s, tr, px, py, sample_id, cnt);
-  const OLuts luts = scene_luts(s);
-  const bool lights_present = s->light_tree_root != NULL && s->num_lights > 0;
-  Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
-  RGBF result = c_splat(0.0f);
-  vec3 origin, ray;
-  camera_sample(s, &smp, &origin, &ray);
-  uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
-  uint2_t record_p = record_pack(c_splat(1.0f));
-  uint32_t medium = medium_ior_modify(0, 1.0f, true); /* kernels.cuh:172-174 with bsdf_refraction_index_ambient == 1 */
-  uint32_t ign_inst = 0, ign_tri = 0;
-  const RGBF sky_color = (s->sky_mode == SKY_MODE_CONSTANT_COLOR) ? c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]) : c_splat(0.0f);
-
-  for (uint32_t depth = 0; depth <= s->max_ray_depth; depth++) {
-    smp.depth = (depth == s->max_ray_depth && depth > 0) ? depth - 1 : depth;
-    OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
-    cnt[ORACLE_CNT_TRACE]++;
-    if (s->fog_active) {
-      /* device_renderer.c:64-76: in-scattering and its shadow pass, then the distance sampling (volume_process_events, volume.cuh:100-229) */
-      const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, cnt);
-      beauty_add(&result, c_mul(in, record_unpack(record_p)));
+/* volume_process_events (volume.cuh:100-229): closed-form distance sampling. A path that scatters before its hit becomes a volume hit, the throughput
+ * takes transmittance over sampling density; in the non-procedural sky modes a ray that left the scene adds the sky here and ends (sky fast path). */
+static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p) {
+  const Sampler smp = *smp_p;
+  OHit hit = *hit_p;
+  uint2_t record_p = *record_pp;
+  RGBF result = *result_p;
+  {
       const OVolume vol = fog_volume(s);
       OVolumePath path = volume_compute_path(s, &vol, origin, ray, hit.t);
       RGBF record = record_unpack(record_p);
@@ -380,6 +372,33 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       record = c_scale(record, volume_transmittance_length(&vol, path.length));
       record = c_scale(record, 1.0f / pdf);
       record_p = record_pack(record);
+  }
+  *hit_p = hit; *record_pp = record_p; *result_p = result;
+}
+
+static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
+  if (s->shading_mode != 0) return render_path_debug(s, tr, px, py, sample_id, cnt);
+  const OLuts luts = scene_luts(s);
+  const bool lights_present = s->light_tree_root != NULL && s->num_lights > 0;
+  Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
+  RGBF result = c_splat(0.0f);
+  vec3 origin, ray;
+  camera_sample(s, &smp, &origin, &ray);
+  uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
+  uint2_t record_p = record_pack(c_splat(1.0f));
+  uint32_t medium = medium_ior_modify(0, 1.0f, true); /* kernels.cuh:172-174 with bsdf_refraction_index_ambient == 1 */
+  uint32_t ign_inst = 0, ign_tri = 0;
+  const RGBF sky_color = (s->sky_mode == SKY_MODE_CONSTANT_COLOR) ? c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]) : c_splat(0.0f);
+
+  for (uint32_t depth = 0; depth <= s->max_ray_depth; depth++) {
+    smp.depth = (depth == s->max_ray_depth && depth > 0) ? depth - 1 : depth;
+    OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
+    cnt[ORACLE_CNT_TRACE]++;
+    if (s->fog_active) {
+      /* device_renderer.c:64-76: in-scattering and its shadow pass, then the distance sampling (volume_process_events, volume.cuh:100-229) */
+      const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, cnt);
+      beauty_add(&result, c_mul(in, record_unpack(record_p)));
+      volume_events(s, &smp, origin, ray, state, &hit, &record_p, &result);
     }
     if (hit.instance_id == HIT_TYPE_SKY) {
       if (state & ST_ALLOW_AMBIENT) {

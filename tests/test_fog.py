@@ -22,8 +22,11 @@ def _fogged(host, density=40.0, height=500.0, dist=500.0, diameter=10.0):
 
 
 def _view(host):
-    plain = host.device_scene()
     sky = host.get_sky()
+    if sky.mode == SKY_MODE_HDRI and sky.hdri_dim > 32:  # a small panorama: the oracle bakes it on the CPU
+        sky.hdri_dim, sky.hdri_samples = 32, 3
+        host.set_sky(sky)
+    plain = host.device_scene()
     if sky.mode == SKY_MODE_HDRI:
         return oracle_lib.with_sky_hdri(plain)
     if sky.mode == SKY_MODE_DEFAULT:
@@ -289,6 +292,30 @@ def test_few_bridge_vertices_and_a_scene_without_lights(tmp_path):
     dark = scenes.edge_scene("no_lights", 40, 28, 3)
     _fogged(dark, density=60.0)
     _parity(dark, samples=3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [1, 2, 4])
+def test_debug_shading_modes_see_the_fog_events(mode):
+    """The debug queue keeps the scattering-event kernel (device_renderer.c:145-147): rays that leave the scene show the sky through the fog (fast path),
+    paths that scatter stay black, surface hits keep their debug colour."""
+    from luminary_amd.core import Core
+    host = _fogged(scenes.zoo_scene(64, 40, 4), density=40.0, height=30.0, dist=50.0)
+    st = host.get_settings(); st.shading_mode = mode; host.set_settings(st)
+    view = _view(host)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.render(0, 3, samples_per_pass=3)
+        fm, sm = core.accumulators()
+        ofm, osm, _ = oracle_lib.render(view, 0, 3)
+        assert np.array_equal(fm, ofm) and np.array_equal(sm, osm)
+        plain = scenes.zoo_scene(64, 40, 4)
+        st = plain.get_settings(); st.shading_mode = mode; plain.set_settings(st)
+        assert not np.array_equal(ofm, oracle_lib.render(_view(plain), 0, 3)[0]), "the events change the debug image"
+    finally:
+        core.close()
 
 
 @pytest.mark.gpu
