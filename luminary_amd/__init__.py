@@ -81,6 +81,12 @@ class Fog(C.Structure):
     _fields_ = [("active", C.c_bool), ("density", C.c_float), ("droplet_diameter", C.c_float), ("height", C.c_float), ("dist", C.c_float)]
 
 
+class Particles(C.Structure):
+    """LuminaryParticles (include/luminary_amd.h; defaults particles.c:6-24)."""
+    _fields_ = [("active", C.c_bool), ("seed", C.c_uint32), ("count", C.c_uint32), ("albedo", RGBF), ("speed", C.c_float), ("direction_altitude", C.c_float),
+                ("direction_azimuth", C.c_float), ("phase_diameter", C.c_float), ("scale", C.c_float), ("size", C.c_float), ("size_variation", C.c_float)]
+
+
 class Material(C.Structure):
     _fields_ = [("id", C.c_uint32), ("base_substrate", C.c_int), ("albedo", RGBAF), ("emission", RGBF), ("emission_scale", C.c_float),
                 ("roughness", C.c_float), ("roughness_clamp", C.c_float), ("refraction_index", C.c_float), ("emission_active", C.c_bool),
@@ -138,7 +144,10 @@ class DeviceSceneView(C.Structure):
                 ("sky_stars_intensity", C.c_float), ("sky_stars_count", C.c_uint32), ("sky_stars", C.c_void_p), ("sky_stars_offsets", C.c_void_p),
                 ("sky_hdri", C.c_void_p), ("sky_hdri_dim", C.c_uint32), ("sky_hdri_samples", C.c_uint32), ("sky_hdri_origin", C.c_float * 3), ("sky_aerial_perspective", C.c_uint32),
                 ("fog_active", C.c_uint32), ("fog_density", C.c_float), ("fog_dist", C.c_float), ("fog_height", C.c_float), ("fog_phase", C.c_float * 4),
-                ("bridge_lut", C.c_void_p), ("bridge_max_num_vertices", C.c_uint32)]
+                ("bridge_lut", C.c_void_p), ("bridge_max_num_vertices", C.c_uint32),
+                ("particles_active", C.c_uint32), ("particles_count", C.c_uint32), ("particles_scale", C.c_float), ("particles_speed", C.c_float),
+                ("particles_albedo", C.c_float * 3), ("particles_direction", C.c_float * 3), ("particles_phase", C.c_float * 4),
+                ("particle_vertices", C.c_void_p), ("particle_normals", C.c_void_p)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -246,6 +255,12 @@ class Host:
 
     def set_fog(self, f):
         _call("luminary_host_set_fog", self._h, C.byref(f))
+
+    def get_particles(self):
+        return self._get("particles", Particles)
+
+    def set_particles(self, p):
+        _call("luminary_host_set_particles", self._h, C.byref(p))
 
     def get_material(self, i):
         m = Material()

@@ -97,6 +97,15 @@ struct DeviceScene {
   float fog_phase[4];        // Jendersie-Eon g_hg, g_d, alpha, w_d of the droplet diameter
   const float* bridge_lut;   // 64 x 21 floats
   uint32_t bridge_max_num_vertices;
+  // particles (dev_particle.h): quads of the unit cell, tiled 25^3 times in a space scaled by particles_scale; their own two-level tree
+  uint32_t particles_active, particles_count;
+  float particles_scale, particles_speed;
+  float particles_albedo[3], particles_direction[3], particles_phase[4];
+  const float4* particle_normals;
+  const Bvh4Node* particle_bvh_nodes;
+  const BvhTri* particle_tris;
+  const float4* particle_leaves;
+  uint32_t particle_tlas_num_nodes;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).
@@ -173,7 +182,8 @@ enum CtrlWord : uint32_t {
   kCtlShadowCursor = 3u * LUM_CTL_LINE + 8u, kCtlStride = 4u * LUM_CTL_LINE,
   // the fog's own visibility pass runs k_shadow_rays on `ctrl + kCtlVolumeShift`: its item count and cursor are these two words
   kCtlVolumeShift = 16u, kCtlVolumeShadowItems = kCtlShadowItems + kCtlVolumeShift, kCtlVolumeShadowCursor = kCtlShadowCursor + kCtlVolumeShift,
-  kCtlVolumeItems = 2u * LUM_CTL_LINE + 2u
+  kCtlVolumeItems = 2u * LUM_CTL_LINE + 2u,
+  kCtlParticleCursor = LUM_CTL_LINE + 8u  // work cursor of the particle pass of the closest-hit kernel (8 words, like the other cursors)
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 

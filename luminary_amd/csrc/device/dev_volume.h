@@ -88,10 +88,10 @@ LUM_DEV float fog_transmittance(const DeviceScene& sc, V3 origin, V3 ray, float 
 
 // ---- phase functions (math.cuh:1169-1322) ----
 LUM_DEV float draine_phase(float c, float g, float alpha) { return hg_phase(c, g) * ((1.0f + alpha * c * c) / (1.0f + (alpha / 3.0f) * (1.0f + 2.0f * g * g))); }
-LUM_DEV float fog_phase_function(const DeviceScene& sc, float c) {
-  const float g_hg = sc.fog_phase[0], g_d = sc.fog_phase[1], alpha = sc.fog_phase[2], w_d = sc.fog_phase[3];
-  return (1.0f - w_d) * hg_phase(c, g_hg) + w_d * draine_phase(c, g_d, alpha);
+LUM_DEV float je_phase_function(const float* p, float c) {  // jendersie_eon_phase_function, math.cuh:1234-1239; p = g_hg, g_d, alpha, w_d
+  return (1.0f - p[3]) * hg_phase(c, p[0]) + p[3] * draine_phase(c, p[1], p[2]);
 }
+LUM_DEV float fog_phase_function(const DeviceScene& sc, float c) { return je_phase_function(sc.fog_phase, c); }
 LUM_DEV V3 phase_sample_basis(float alpha, float beta, V3 basis) {  // math.cuh:1249-1272
   V3 u1, u2;
   if (basis.z < -0.9999805689f) { u1 = v3(0.0f, -1.0f, 0.0f); u2 = v3(-1.0f, 0.0f, 0.0f); }
@@ -124,10 +124,11 @@ LUM_DEV float draine_phase_sample(float g, float alpha, float r) {  // math.cuh:
   const float h = sqrtf(6.0f * (1.0f + g2) - t8 + 8.0f * t4 / (t0 * t9)) - t9;
   return 0.5f * g + ((1.0f / (2.0f * g)) - (1.0f / (8.0f * g)) * (h * h));
 }
-LUM_DEV V3 fog_phase_sample(const DeviceScene& sc, V3 ray, F2 r_dir, float r_choice) {  // jendersie_eon_phase_sample, math.cuh:1311-1323
-  const float cos_angle = (r_choice < sc.fog_phase[3]) ? draine_phase_sample(sc.fog_phase[1], sc.fog_phase[2], r_dir.x) : hg_phase_sample(sc.fog_phase[0], r_dir.x);
+LUM_DEV V3 je_phase_sample(const float* p, V3 ray, F2 r_dir, float r_choice) {  // jendersie_eon_phase_sample, math.cuh:1311-1323
+  const float cos_angle = (r_choice < p[3]) ? draine_phase_sample(p[1], p[2], r_dir.x) : hg_phase_sample(p[0], r_dir.x);
   return phase_sample_basis(cos_angle, r_dir.y, ray);
 }
+LUM_DEV V3 fog_phase_sample(const DeviceScene& sc, V3 ray, F2 r_dir, float r_choice) { return je_phase_sample(sc.fog_phase, ray, r_dir, r_choice); }
 
 // ---- the volume's shading context (material.cuh:76-89, volume_utils.cuh:310-321) ----
 struct VolContext { Volume vol; V3 position, V; uint32_t state; float max_dist; };

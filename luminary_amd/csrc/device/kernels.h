@@ -16,6 +16,7 @@
 #include "dev_trace.h"
 #include "dev_sky.h"
 #include "dev_volume.h"
+#include "dev_particle.h"
 
 LUM_NS_BEGIN
 
@@ -487,6 +488,18 @@ __global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueu
       }
       else if (sc.shading_mode == 4u) result = col(0.0f, 0.63f, 1.0f);  // IDENTIFICATION
     }
+    else if (particle_is_hit(hid.x)) {  // particle_process_tasks_debug, particle.cuh:110-163
+      if (sc.shading_mode == 1u) result = particles_albedo(sc);
+      else if (sc.shading_mode == 2u) result = splat(saturate((1.0f / o4.w) * 2.0f));
+      else if (sc.shading_mode == 3u) {
+        const V3 nrm = particle_context(sc, origin, ray, aux.w, hid.x).normal;
+        result = col(saturate(nrm.x), saturate(nrm.y), saturate(nrm.z));
+      }
+      else if (sc.shading_mode == 4u) {
+        const uint32_t v = squares32(0x55555555u, hid.x);
+        result = col(((float) (v & 0x7FFu)) / 0x7FF, ((float) ((v >> 10) & 0x7FFu)) / 0x7FF, ((float) ((v >> 20) & 0x7FFu)) / 0x7FF);
+      }
+    }
     else if (hid.x <= kHitTriangleLimit) {  // with fog: scattering events and paths the sky fast path ended have no debug colour
       const V3 hit_origin = origin + ray * o4.w;
       if (sc.shading_mode == 2u) result = splat(saturate((1.0f / o4.w) * 2.0f));  // DEPTH
@@ -649,7 +662,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
-    if (hid.x > kHitTriangleLimit) continue;  // sky, and with fog: scattering events and ended paths
+    if (hid.x > kHitTriangleLimit && !particle_is_hit(hid.x)) continue;  // sky, and with fog: scattering events and ended paths
     const uint4 aux = in.aux[i];
     const uint32_t slot = fbits(in.dir_slot[i].w);
     const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
@@ -689,6 +702,195 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
   }
 }
 
+
+// ---- particles ----
+// The particle pass of the closest-hit kernel (optix_kernel_raytrace.cu:97-131): delta paths are traced against the tiled particle cell, in a
+// space scaled by 1 / particles_scale so that ray parameters stay world distances; a hit closer than the surface hit replaces it. Runs the
+// same traversal on the particle tree (the scene argument carries that tree in place of the surfaces').
+struct ParticleQuery {
+  static constexpr bool kDual = false;
+  static constexpr bool kOrdered = true;
+  static constexpr bool kCull = true;
+  PathQueue q;
+  float best_t;
+  uint32_t best_inst, best_tri;
+  float particles_scale, particles_speed;
+  V3 direction;
+  const uint32_t* bluenoise;
+  LUM_DEV bool load(const DeviceScene&, uint32_t i, V3& o, V3& d, float& tmax) {
+    const uint4 aux = q.aux[i];
+    if ((aux.w & kStDeltaPath) == 0) return false;  // particles are invisible to non-delta paths (negligible contribution)
+    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
+    const uint4 hid = q.hit_id[i];
+    const Sampler smp{bluenoise, hid.z & 0xFFFFu, hid.z >> 16, hid.w, 0u};  // random_1D_consistent: depth 0
+    const float time = smp.next1(kRndCameraTime);
+    const V3 motion_offset = direction * (time * particles_speed);
+    d = v3(d4.x, d4.y, d4.z) * (1.0f / particles_scale);
+    V3 pos = (v3(o4.x, o4.y, o4.z) + motion_offset) * (1.0f / particles_scale);
+    pos.x = pos.x - floorf(pos.x); pos.y = pos.y - floorf(pos.y); pos.z = pos.z - floorf(pos.z);
+    o = pos;
+    tmax = o4.w;
+    best_t = o4.w; best_inst = 0xFFFFFFFFu; best_tri = 0xFFFFFFFFu;
+    return true;
+  }
+  LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
+    LeafTris lt;
+    lt.load(sc.blas_tris, first, count);
+#pragma unroll
+    for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
+      if (j >= count) break;
+      const float4 a = lt.a[j], b = lt.b[j], c = lt.c[j];
+      const uint32_t id = fbits(a.w);
+      st.tris++;
+      F2 uv;
+      const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
+      if (t < best_t || (t == best_t && t != kFltMax && best_tri != 0xFFFFFFFFu && (inst < best_inst || (inst == best_inst && id < best_tri)))) {
+        const float dx = uv.x - 0.5f, dy = uv.y - 0.5f;  // particle_opacity_cutout, optix_common.cuh:67-74
+        if (dx * dx + dy * dy > 0.25f) continue;
+        best_t = t; best_inst = inst; best_tri = id; tmax = t;
+      }
+    }
+    return false;
+  }
+  LUM_DEV void finish(const DeviceScene&, uint32_t i) {
+    if (best_tri == 0xFFFFFFFFu) return;
+    q.origin_t[i].w = best_t;
+    uint4 hid = q.hit_id[i];
+    hid.x = kHitParticleMin + (best_tri >> 1); hid.y = 0u;
+    q.hit_id[i] = hid;
+  }
+};
+
+__global__ __launch_bounds__(kTraceBlock) void k_trace_particles(DeviceScene particle_tree, PathQueue q, uint32_t* ctrl, uint32_t lds_nodes) {
+  RayStats st{0, 0, 0};
+  uint32_t rays = 0;
+  ParticleQuery pq;
+  pq.q = q;
+  pq.particles_scale = particle_tree.particles_scale; pq.particles_speed = particle_tree.particles_speed;
+  pq.direction = v3(particle_tree.particles_direction[0], particle_tree.particles_direction[1], particle_tree.particles_direction[2]);
+  pq.bluenoise = particle_tree.bluenoise_2d;
+  trace_items(particle_tree, ctrl[kCtlPaths], ctrl + kCtlParticleCursor, pq, st, rays, lds_nodes);
+}
+
+// particle_process_tasks (particle.cuh:7-108): light sample, sun, phase-function bounce whose direction doubles as the ambient sample. The
+// records go where a surface vertex puts them, so k_resolve and the visibility pass treat both alike (optix_kernel_shadow.cu covers both).
+__global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
+  const Col albedo = particles_albedo(sc);
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    bool survive = false, want_geo = false, want_amb = false, want_sun = false;
+    float4 n_o, n_d; uint4 n_aux, n_hid;
+    float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
+    if (i < n && particle_is_hit(in.hit_id[i].x)) {
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const uint32_t state = aux.w;
+      const V3 ray = v3(d4.x, d4.y, d4.z);
+      const V3 position = v3(o4.x, o4.y, o4.z) + ray * o4.w;
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      const ParticleContext pc = particle_context(sc, position, ray, state, hid.x);
+      s_origin = make_float4(position.x, position.y, position.z, 0.0f);
+      s_geo_ids = make_uint4(0xFFFFFFFFu, 0u, hid.x, 0u);
+      float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
+      if (lights_present && (state & kStVolumeScattered) == 0) {
+        LightSample ls = particle_light_sample(sc, pc, smp);
+        if (sc.fog_active) ls.color = ls.color * fog_transmittance(sc, position, ls.ray, ls.dist);
+        geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
+        if (ls.light_id != kLightIdInvalid) {
+          want_geo = true;
+          const uint2 target = sc.light_tri_handles[ls.light_id];
+          s_geo_dir = make_float4(ls.ray.x, ls.ray.y, ls.ray.z, ls.dist);
+          s_geo_ids.x = target.x; s_geo_ids.y = target.y;
+        }
+      }
+      uint4 sun = make_uint4(0u, 0u, 0u, 0u);
+      if (sun_allowed) {
+        Col sun_light; V3 sun_dir;
+        if (particle_sun_sample(sc, sky_view(sc), pc, smp, sun_light, sun_dir)) {
+          const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
+          sun = make_uint4(c.x, c.y, r.x, r.y);
+          if (c.x != 0 || c.y != 0) { want_sun = true; const V3 ar = ray_unpack(r); s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax); }
+        }
+      }
+      // bsdf_sample<MATERIAL_PARTICLE> with RANDOM_GI (bsdf.cuh:320-331): weight = albedo
+      const float random_choice = smp.next1(kRndBsdfGiResampling);
+      const F2 random_dir = smp.next2(kRndBsdfGiDiffuse);
+      const V3 bounce = je_phase_sample(sc.particles_phase, ray, random_dir, random_choice);
+      uint4 amb = make_uint4(0u, 0u, 0u, 0u);
+      if (sc.sky_mode != kSkyDefault) {
+        const U2 c = record_pack(sky_color_no_compute(sc, position, bounce, 0u) * albedo), r = ray_pack(bounce);
+        amb = make_uint4(c.x, c.y, r.x, r.y);
+        if (c.x != 0 || c.y != 0) { want_amb = true; const V3 ar = ray_unpack(r); s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax); }
+      }
+      nee.geo_color_light[i] = geo_cl;
+      nee.bsdf_ray_prob[i] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+      nee.bsdf_weight_sum[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);  // no BSDF-sampled light for particles (direct_lighting.cuh:308-317)
+      nee.ambient[i] = amb;
+      if (sc.sky_mode != kSkyConstantColor) nee.sun[i] = sun;
+      uint32_t new_state = state & ~(kStDeltaPath | kStCameraDirection | kStAllowEmission | kStUseIgnoreHandle);
+      if (sc.sky_mode != kSkyDefault) new_state &= ~kStAllowAmbient; else new_state |= kStAllowAmbient;
+      Col record = record_unpack(U2{aux.x, aux.y}) * albedo;
+      survive = true;
+      if ((state & kStDeltaPath) == 0) {  // directives.cuh:11-32
+        const float value = importance(record);
+        if (value < sc.cam_rr_threshold) {
+          const float p = (value > 0.0f) ? fmaxf(value / sc.cam_rr_threshold, 1.0f / 8.0f) : 0.0f;
+          if (smp.next1(kRndRussianRoulette) > p) survive = false;
+          else record = record * (1.0f / p);
+        }
+      }
+      if (survive) {
+        const U2 rp = record_pack(record);
+        n_o = make_float4(position.x, position.y, position.z, kFltMax);
+        n_d = make_float4(bounce.x, bounce.y, bounce.z, d4.w);
+        n_aux = make_uint4(rp.x, rp.y, aux.z, new_state);
+        n_hid = make_uint4(0u, 0u, hid.z, hid.w);
+      }
+    }
+    const unsigned long long ballot = __ballot(survive);
+    if (ballot) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count_out, (uint32_t) __popcll(ballot));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (survive) {
+        const uint32_t j = base + (uint32_t) __popcll(ballot & below);
+        out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
+      }
+    }
+    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun);
+    if (bg | ba | bn) {
+      const uint32_t ng = (uint32_t) __popcll(bg), na = (uint32_t) __popcll(ba);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, ng + na + (uint32_t) __popcll(bn));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_geo) {
+        const uint32_t j = base + (uint32_t) __popcll(bg & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w);
+        sq.dir_out[j] = make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i));
+        sq.ids[j] = s_geo_ids;
+      }
+      if (want_amb) {
+        const uint32_t j = base + ng + (uint32_t) __popcll(ba & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w);
+        sq.dir_out[j] = make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+      }
+      if (want_sun) {
+        const uint32_t j = base + ng + na + (uint32_t) __popcll(bn & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w);
+        sq.dir_out[j] = make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
+      }
+    }
+  }
+}
 
 // ---- fog (cuda/volume.cuh; queue order device/device_renderer.c:64-76, :114-118) ----
 // volume_process_inscattering (volume.cuh:31-98): what the fog scatters into the ray between its origin and its end point (the hit, or infinity
@@ -849,7 +1051,7 @@ __global__ __launch_bounds__(kBlock) void k_volume_events(DeviceScene sc, PathQu
         add_to_result(results, fbits(d4.w), sky);
         hit_inst = kHitInvalid;
       }
-      const float intersection_probability = (state & kStDeltaPath) ? 0.5f : 1.0f;  // bounds the variance of highlights seen through the fog
+      const float intersection_probability = ((state & kStDeltaPath) && !particle_is_hit(hit_inst)) ? 0.5f : 1.0f;  // bounds the variance of highlights seen through the fog
       const F2 randoms = smp.next2(kRndVolumeIntersection);
       float pdf = 1.0f;
       if (randoms.y < intersection_probability) {

@@ -38,6 +38,11 @@ struct WavefrontKernels {
   void (*volume_events)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, float4* results, uint32_t* ctrl, uint32_t depth_const);
   void (*volume_bounce)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const VolumeQueue& vq, uint32_t* ctrl,
                         uint32_t depth_const);
+  // particles (dev_particle.h): the particle pass of the closest-hit kernel (`particle_tree`: the scene with the particle tree in place of the
+  // surfaces' tree) and the shading of particle hits
+  void (*trace_particles)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& particle_tree, const PathQueue& q, uint32_t* ctrl, uint32_t lds_nodes);
+  void (*particle_shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq,
+                         uint32_t* ctrl, uint32_t depth_const);
   void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                      uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);
 };

@@ -11,6 +11,7 @@ static int set_ray_kernel_lds(size_t bytes) {
   hipError_t e = hipFuncSetAttribute((const void*) k_trace, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_shadow_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+  if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_trace_particles, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
   return (int) e;
 }
 static void generate(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count) {
@@ -65,13 +66,20 @@ static void volume_bounce(uint32_t grid, hipStream_t s, const DeviceScene& sc, c
                           uint32_t depth_const) {
   hipLaunchKernelGGL(k_volume_bounce, dim3(grid), dim3(kBlock), 0, s, sc, in, out, vq, ctrl, depth_const);
 }
+static void trace_particles(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& particle_tree, const PathQueue& q, uint32_t* ctrl, uint32_t lds_nodes) {
+  hipLaunchKernelGGL(k_trace_particles, dim3(grid), dim3(kTraceBlock), lds, s, particle_tree, q, ctrl, lds_nodes);
+}
+static void particle_shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq,
+                           uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_particle_shade, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, ctrl, depth_const);
+}
 static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                        uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_rays};
 
 }  // namespace table
 LUM_NS_END

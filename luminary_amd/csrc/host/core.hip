@@ -52,6 +52,7 @@ struct LumContext {
   PathQueue queue[2]{};
   NeeQueue nee{};
   ShadowQueue shadow{};
+  uint32_t particle_lds_nodes = 0;
   VolumeQueue volume{};           // fog (dev_volume.h); allocated with the work block when the scene's fog is active
   uint32_t work_shadow_kinds = 0; // visibility-ray kinds per path the work block was sized for (4, or 17 with fog)
   float4* d_results = nullptr;
@@ -428,6 +429,66 @@ void lumc_context_destroy(LumContext* ctx) {
 const char* lumc_last_error(const LumContext* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 uint32_t lumc_scene_view_sizeof(void) { return (uint32_t) sizeof(LumDeviceSceneView); }
 
+// The particle tree (device_particle.c:23-131, optix_bvh.c's particle GAS / IAS): one bottom-level tree over the 2 x count triangles of the unit
+// cell, and a top level over its 25 x 25 x 25 integer translations, instance id = (xi * 25 + yi) * 25 + zi as the reference numbers them. The
+// top-level leaves hold the translation as an exact affine map (rows of the identity), so entering an instance is one subtraction per axis.
+static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, DeviceScene& sc) {
+  sc.particle_bvh_nodes = nullptr; sc.particle_tris = nullptr; sc.particle_leaves = nullptr; sc.particle_tlas_num_nodes = 0; sc.particle_normals = nullptr;
+  if (!sc.particles_active) return 0;
+  if (!v->particle_vertices || !v->particle_normals) { ctx->error = "lumc_scene_upload: active particles without particle_vertices / particle_normals"; return 1; }
+  const uint32_t nt = 2u * sc.particles_count;
+  std::vector<Aabb> tri_boxes(nt);
+  Aabb cell{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+  for (uint32_t t = 0; t < nt; t++) {
+    const float* p = v->particle_vertices + (size_t) t * 12;
+    tri_boxes[t] = tri_box(p, p + 4, p + 8);
+    for (int k = 0; k < 3; k++) { cell.lo[k] = std::min(cell.lo[k], tri_boxes[t].lo[k]); cell.hi[k] = std::max(cell.hi[k], tri_boxes[t].hi[k]); }
+  }
+  constexpr int kDim = 25;  // PARTICLES_BLOCK_DIM
+  std::vector<Aabb> boxes((size_t) kDim * kDim * kDim);
+  std::vector<float> offsets(3 * boxes.size());
+  uint32_t id = 0;
+  for (int xi = 0; xi < kDim; xi++)
+    for (int yi = 0; yi < kDim; yi++)
+      for (int zi = 0; zi < kDim; zi++, id++) {
+        const float off[3] = {(float) (xi - (kDim >> 1)), (float) (yi - (kDim >> 1)), (float) (zi - (kDim >> 1))};
+        for (int k = 0; k < 3; k++) { offsets[3 * id + k] = off[k]; boxes[id].lo[k] = cell.lo[k] + off[k] - 1e-5f; boxes[id].hi[k] = cell.hi[k] + off[k] + 1e-5f; }
+      }
+  Bvh4 tlas = build_bvh4(boxes.data(), (uint32_t) boxes.size(), 1, 16);
+  Bvh4 blas = build_bvh4(tri_boxes.data(), nt, kBvhLeafMaxTri, 26);
+  if (tlas.nodes.empty() || blas.nodes.empty()) { ctx->error = "particle BVH exceeds the traversal's depth limits"; return 1; }
+  std::vector<Bvh4Node> nodes = tlas.nodes;
+  const uint32_t base = (uint32_t) nodes.size();
+  for (Bvh4Node n : blas.nodes) {
+    for (int k = 0; k < 4; k++) if (n.child[k] != kBvhEmpty && !(n.child[k] & kBvhLeafBit)) n.child[k] += base;
+    nodes.push_back(n);
+  }
+  std::vector<BvhTri> tris((size_t) nt + 1);
+  std::memset(tris.data(), 0, sizeof(BvhTri) * tris.size());
+  for (uint32_t i = 0; i < nt; i++) {
+    const uint32_t t = blas.prims[i];
+    const float* p = v->particle_vertices + (size_t) t * 12;
+    for (int k = 0; k < 3; k++) { tris[i].p0[k] = p[k]; tris[i].e1[k] = p[4 + k] - p[k]; tris[i].e2[k] = p[8 + k] - p[k]; }
+    tris[i].id = t; tris[i].scene_index = t; tris[i].albedo_tex = kBvhTriNoTexture;
+  }
+  std::vector<float4> leaves(4 * tlas.prims.size() + 4);
+  for (size_t i = 0; i < tlas.prims.size(); i++) {
+    const uint32_t inst = tlas.prims[i];
+    leaves[4 * i + 0] = make_float4(1.0f, 0.0f, 0.0f, offsets[3 * inst + 0]);
+    leaves[4 * i + 1] = make_float4(0.0f, 1.0f, 0.0f, offsets[3 * inst + 1]);
+    leaves[4 * i + 2] = make_float4(0.0f, 0.0f, 1.0f, offsets[3 * inst + 2]);
+    const uint32_t words[4] = {inst, base, 0u, 0u};
+    std::memcpy(&leaves[4 * i + 3], words, 16);
+  }
+  if (upload(ctx, nodes.data(), nodes.size(), &sc.particle_bvh_nodes)) return 1;
+  if (upload(ctx, tris.data(), tris.size(), &sc.particle_tris)) return 1;
+  if (upload(ctx, leaves.data(), leaves.size(), &sc.particle_leaves)) return 1;
+  if (upload(ctx, (const float4*) v->particle_normals, (size_t) sc.particles_count, &sc.particle_normals)) return 1;
+  sc.particle_tlas_num_nodes = (uint32_t) tlas.nodes.size();
+  ctx->particle_lds_nodes = (uint32_t) std::min<size_t>(ctx->lds_nodes, nodes.size());
+  return 0;
+}
+
 int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   if (!ctx || !v) return 1;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -675,6 +736,14 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       if (upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
     }
   }
+  // ---- particles ----
+  sc.particles_active = (v->particles_active && v->particles_count) ? 1u : 0u;
+  sc.particles_count = sc.particles_active ? v->particles_count : 0u;
+  sc.particles_scale = v->particles_scale; sc.particles_speed = v->particles_speed;
+  std::memcpy(sc.particles_albedo, v->particles_albedo, sizeof(sc.particles_albedo));
+  std::memcpy(sc.particles_direction, v->particles_direction, sizeof(sc.particles_direction));
+  std::memcpy(sc.particles_phase, v->particles_phase, sizeof(sc.particles_phase));
+  if (build_particle_tree(ctx, v, sc)) return 1;
   if (sc.sky_mode != kSkyConstantColor) {  // HDRI mode bakes from them and samples the sun through them
     const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
     if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
@@ -836,6 +905,14 @@ int lumc_clear_accumulators(LumContext* ctx) {
   return 0;
 }
 
+// The particle pass of the closest-hit kernel: the same traversal on the particle tree (the scene copy carries it in place of the surfaces' tree).
+static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue& q, uint32_t* ctrl, uint32_t N) {
+  DeviceScene tree = ctx->scene;
+  tree.bvh_nodes = tree.particle_bvh_nodes; tree.blas_tris = tree.particle_tris; tree.tlas_leaves = tree.particle_leaves; tree.tlas_num_nodes = tree.particle_tlas_num_nodes;
+  Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+  ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * sizeof(Bvh4Node), stream, tree, q, ctrl, ctx->particle_lds_nodes);
+}
+
 // The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
 static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const DeviceScene& sc = ctx->scene;
@@ -848,6 +925,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[0], nullptr, ctx->d_ctrl, ctx->d_counters, ctx->lds_nodes);
     }
+    if (sc.particles_active) trace_particles(ctx, stream, ctx->queue[0], ctx->d_ctrl, N);
     if (sc.fog_active) {  // the debug queue keeps volume_process_events (device_renderer.c:145-147)
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_events(grid_for(N), stream, sc, ctx->queue[0], ctx->volume, ctx->d_results, ctx->d_ctrl, 0u);
@@ -870,6 +948,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
+    if (sc.particles_active) trace_particles(ctx, stream, ctx->queue[cur], ctrl, N);  // optix_kernel_raytrace.cu:171
     if (sc.fog_active) {  // device_renderer.c:64-76: in-scattering with its own visibility pass, then the scattering events
       {
         Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
@@ -890,6 +969,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
       wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters);
+    }
+    if (sc.particles_active) {  // device_renderer.c:99-103
+      Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+      wf.particle_shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctrl, depth_const);
     }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
       Launch l(ctx, stream, LUMC_KERNEL_SKY);

@@ -857,6 +857,57 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
 // Scene -> device format
 // ---------------------------------------------------------------------------------------------------------------------
 
+// ---- particles: particle_generate (cuda/particle.cuh:165-211) evaluated by the host layer (the reference runs it on the GPU at scene update,
+// device_particle.c:99-131). white_noise_offset = the 16-bit Squares generator (random.cuh:196-211, :297-307). ----
+static float particle_white_noise(uint32_t offset) {
+  const uint32_t key = 0xfcbd6e15u, counter = offset;
+  uint32_t x = counter * key, y = counter * key, z = y + key;
+  x = x * x + y; x = (x >> 16) | (x << 16);
+  x = x * x + z; x = (x >> 16) | (x << 16);
+  const uint32_t v = ((x * x + y) >> 16) & 0xFFFFu;
+  return bits_float(0x3F800000u | (v << 7)) - 1.0f;
+}
+void generate_particles(const LuminaryParticles& p, std::vector<float>* vertices, std::vector<float>* normals) {
+  const uint32_t count = p.count;
+  vertices->assign((size_t) count * 24, 0.0f);
+  normals->assign((size_t) count * 4, 0.0f);
+  const float size = p.size * 0.001f;
+  for (uint32_t id = 0; id < count; id++) {
+    const uint32_t base = p.seed + id * 6;
+    const float px = particle_white_noise(base + 0), py = particle_white_noise(base + 1), pz = particle_white_noise(base + 2);
+    const float r1 = 2.0f * particle_white_noise(base + 3) - 1.0f, r2 = particle_white_noise(base + 4);
+    float n[3];  // sample_ray_sphere, math.cuh:326-344
+    if (std::fabs(r1) > 1.0f - FLT_EPSILON) { n[0] = 0.0f; n[1] = 0.0f; n[2] = std::copysign(1.0f, r1); }
+    else {
+      const float a = std::sqrt(1.0f - r1 * r1), b = 2.0f * 3.14159265358979323846f * r2;
+      n[0] = a * std::cos(b); n[1] = a * std::sin(b); n[2] = r1;
+    }
+    // create_basis, math.cuh:301-321
+    const float sign = std::copysign(1.0f, n[2]);
+    const float a = -1.0f / (sign + n[2]);
+    const float b = n[0] * n[1] * a;
+    const float u1[3] = {1.0f + sign * n[0] * n[0] * a, sign * b, -sign * n[0]};
+    const float u2[3] = {b, sign + n[1] * n[1] * a, -n[1]};
+    const float random_size = 2.0f * particle_white_noise(base + 5) - 1.0f;
+    const float s = size * (1.0f + random_size * p.size_variation);
+    auto corner = [&](float cx, float cy, float* o) {  // p + transform_vec3(basis, (cx, cy, 0)), math.cuh:445-453
+      o[0] = px + ((u1[0] * cx + u2[0] * cy) + n[0] * 0.0f);
+      o[1] = py + ((u1[1] * cx + u2[1] * cy) + n[1] * 0.0f);
+      o[2] = pz + ((u1[2] * cx + u2[2] * cy) + n[2] * 0.0f);
+    };
+    float a00[3], a01[3], a10[3], a11[3];
+    corner(s, s, a00); corner(s, -s, a01); corner(-s, s, a10); corner(-s, -s, a11);
+    const float* order[6] = {a00, a01, a10, a11, a01, a10};
+    float* v = vertices->data() + (size_t) id * 24;
+    for (int k = 0; k < 6; k++) { v[4 * k] = order[k][0]; v[4 * k + 1] = order[k][1]; v[4 * k + 2] = order[k][2]; v[4 * k + 3] = 1.0f; }
+    const float e1[3] = {a01[0] - a00[0], a01[1] - a00[1], a01[2] - a00[2]}, e2[3] = {a10[0] - a00[0], a10[1] - a00[1], a10[2] - a00[2]};
+    float c[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const float inv = 1.0f / std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    float* q = normals->data() + (size_t) id * 4;
+    q[0] = c[0] * inv; q[1] = c[1] * inv; q[2] = c[2] * inv;
+  }
+}
+
 std::string build_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, DeviceSceneBuffers* out) {
   if (bluenoise.size() != 65536) return "blue-noise mask must hold 65536 texels";
   const LuminaryRendererSettings& st = scene.settings;
@@ -1000,6 +1051,24 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   jendersie_eon_parameters(scene.fog.droplet_diameter, v.fog_phase);
   v.bridge_lut = reinterpret_cast<const float*>(lum_embedded_bridge_lut);  // device_embedded_data.c:50-60
   v.bridge_max_num_vertices = st.bridge_max_num_vertices & 15u;             // device_structs.h:11
+  // particles (device_particle.c:84-131: nothing exists while they are inactive)
+  const LuminaryParticles& pt = scene.particles;
+  v.particles_active = (pt.active && pt.count > 0) ? 1u : 0u;
+  v.particles_count = v.particles_active ? pt.count : 0u;
+  v.particles_scale = pt.scale; v.particles_speed = pt.speed;
+  v.particles_albedo[0] = pt.albedo.r; v.particles_albedo[1] = pt.albedo.g; v.particles_albedo[2] = pt.albedo.b;
+  v.particles_direction[0] = std::cos(pt.direction_azimuth) * std::cos(pt.direction_altitude);  // angles_to_direction, math.cuh:781-788
+  v.particles_direction[1] = std::sin(pt.direction_altitude);
+  v.particles_direction[2] = std::sin(pt.direction_azimuth) * std::cos(pt.direction_altitude);
+  jendersie_eon_parameters(pt.phase_diameter, v.particles_phase);
+  b.particle_vertices.clear(); b.particle_normals.clear();
+  if (v.particles_active) {
+    if (pt.count > (1u << 22)) return "particles: more than 4 M particles";
+    if (!(pt.scale > 0.0f)) return "particles: scale must be positive";
+    generate_particles(pt, &b.particle_vertices, &b.particle_normals);
+  }
+  v.particle_vertices = b.particle_vertices.empty() ? nullptr : b.particle_vertices.data();
+  v.particle_normals = b.particle_normals.empty() ? nullptr : b.particle_normals.data();
   return std::string();
 }
 

@@ -81,6 +81,8 @@ struct DeviceSceneBuffers {
   std::vector<uint32_t> texture_table, texels;
   std::vector<float> sky_stars;            // 4 floats per star, grid order
   std::vector<uint32_t> sky_stars_offsets; // 64 x 32 + 1
+  std::vector<float> particle_vertices;    // 24 floats per particle
+  std::vector<float> particle_normals;     // 4 floats per particle
 };
 
 // Fills `out` from the scene. `bluenoise` must hold 65536 texels. Returns an empty string or an error message.

@@ -139,9 +139,14 @@ static inline float light_tree_importance(const GeoCtx* g, float power, vec3 mea
  * defined in o_volume.h); the two contexts draw from different random sets (material.cuh:60-63, :78-81). */
 struct VolCtx;
 static inline float light_tree_importance_volume(const struct VolCtx* c, float power, vec3 mean, float std_dev);
-typedef struct { const GeoCtx* geo; const struct VolCtx* vol; uint32_t rt_prepass, rt_postpass; } LTQuery;
-static inline LTQuery lt_query_geometry(const GeoCtx* g) { LTQuery q = {g, NULL, RT_LIGHT_GEO_TREE_PREPASS, RT_LIGHT_GEO_TREE_POSTPASS}; return q; }
+typedef struct { const GeoCtx* geo; const struct VolCtx* vol; uint32_t rt_prepass, rt_postpass; const vec3* particle_position; } LTQuery;
+static inline LTQuery lt_query_geometry(const GeoCtx* g) { LTQuery q = {g, NULL, RT_LIGHT_GEO_TREE_PREPASS, RT_LIGHT_GEO_TREE_POSTPASS, NULL}; return q; }
 static inline float lt_importance(const LTQuery* q, float power, vec3 mean, float std_dev) {
+  if (q->particle_position) { /* light_tree_importance<PARTICLE>, light_tree.cuh:124-131 */
+    const vec3 PO = v_sub(mean, *q->particle_position);
+    const float dist_sq = v_dot(PO, PO) + std_dev * std_dev;
+    return power / dist_sq;
+  }
   return q->vol ? light_tree_importance_volume(q->vol, power, mean, std_dev) : light_tree_importance(q->geo, power, mean, std_dev);
 }
 /* light_tree.cuh:133-161: rel_* arrays are 8 entries each; power is u16 in root sections, u8 in nodes */

@@ -177,6 +177,9 @@ static bool russian_roulette(const OracleScene* s, const Sampler* smp, uint16_t 
 /* Debug shading modes: one closest-hit pass, then a colour per hit (geometry_process_tasks_debug, cuda/geometry.cuh:182-246) or per miss
  * (sky_process_tasks_debug, cuda/sky.cuh:635-665); queue: device/device_renderer.c:136-181. */
 static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p);
+static void particles_trace(const OracleScene* s, const OTracer* tr, const Sampler* smp, vec3 origin, vec3 ray, uint16_t state, OHit* hit);
+static inline bool particle_is_hit(uint32_t instance_id);
+#define HIT_TYPE_PARTICLE_MASK 0x7FFFFFFFu
 static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t px, uint32_t py, uint32_t sample_id, uint64_t* cnt) {
   Sampler smp = {s->bluenoise_2d, px, py, sample_id, 0};
   RGBF result = c_splat(0.0f);
@@ -186,6 +189,7 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
   const uint32_t medium = medium_ior_modify(0, 1.0f, true);
   OHit hit = trace_closest(tr, origin, ray, false, 0, 0);
   cnt[ORACLE_CNT_TRACE]++;
+  particles_trace(s, tr, &smp, origin, ray, state, &hit);
   if (s->fog_active) { /* the debug queue keeps volume_process_events (device_renderer.c:145-147): the sky fast path shows through, a scattering event stays black */
     uint2_t record_p = record_pack(c_splat(1.0f));
     volume_events(s, &smp, origin, ray, state, &hit, &record_p, &result);
@@ -205,6 +209,24 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
       beauty_add(&result, sky);
     }
     else if (s->shading_mode == 4) beauty_add(&result, c3(0.0f, 0.63f, 1.0f)); /* IDENTIFICATION */
+    return result;
+  }
+  if (particle_is_hit(hit.instance_id)) { /* particle_process_tasks_debug, particle.cuh:110-163 */
+    switch (s->shading_mode) {
+      case 1: beauty_add(&result, c3(s->particles_albedo[0], s->particles_albedo[1], s->particles_albedo[2])); break;
+      case 2: beauty_add(&result, c_splat(o_saturate((1.0f / hit.t) * 2.0f))); break;
+      case 3: {
+        const float* qn = s->particle_normals + 4 * (size_t) (hit.instance_id & HIT_TYPE_PARTICLE_MASK);
+        const vec3 quad_normal = v3(qn[0], qn[1], qn[2]);
+        const vec3 n = (v_dot(ray, quad_normal) < 0.0f) ? quad_normal : v_scale(quad_normal, -1.0f);
+        beauty_add(&result, c3(o_saturate(n.x), o_saturate(n.y), o_saturate(n.z)));
+      } break;
+      case 4: {
+        const uint32_t v = squares32(0x55555555u, hit.instance_id);
+        beauty_add(&result, c3(((float) (v & 0x7ffu)) / 0x7ff, ((float) ((v >> 10) & 0x7ffu)) / 0x7ff, ((float) ((v >> 20) & 0x7ffu)) / 0x7ff));
+      } break;
+      default: break;
+    }
     return result;
   }
   cnt[ORACLE_CNT_VERTICES]++;
@@ -236,7 +258,7 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
 /* ---- fog: what the volume kernels do to one path at one depth (cuda/volume.cuh, optix/optix_kernel_shadow_volume.cu) ---- */
 /* light_sample<MATERIAL_VOLUME> (light.cuh:84-159): the eight tree outputs are bridge candidates (light_evaluate_candidate<VOLUME>, :84-98) */
 static BridgeSample volume_light_sample(const OracleScene* s, const VolCtx* c, const Sampler* smp) {
-  LTQuery query = {NULL, c, RT_VOL_TREE_PREPASS, RT_VOL_TREE_POSTPASS};
+  LTQuery query = {NULL, c, RT_VOL_TREE_PREPASS, RT_VOL_TREE_POSTPASS, NULL};
   const LTWork work = light_tree_prepass(s, &query, smp);
   BridgeSample res;
   res.light_id = LIGHT_ID_INVALID; res.light_color = c_splat(0.0f); res.seed = 0; res.rotation.x = res.rotation.y = res.rotation.z = 0.0f; res.rotation.w = 1.0f; res.scale = 0.0f;
@@ -334,6 +356,84 @@ static RGBF volume_inscattering(const OracleScene* s, const OTracer* tr, const S
   return acc;
 }
 
+
+/* ---- particles (optix_kernel_raytrace.cu:97-131, cuda/particle.cuh:7-108, particle_utils.cuh) ---- */
+#define HIT_TYPE_PARTICLE_MIN 0x80000000u
+#define HIT_TYPE_PARTICLE_MAX 0xEFFFFFFFu
+#define RT_CAMERA_TIME_TARGET 65u
+static inline bool particle_is_hit(uint32_t instance_id) { return instance_id <= HIT_TYPE_PARTICLE_MAX && instance_id >= HIT_TYPE_PARTICLE_MIN; }
+/* the particle pass of the closest-hit kernel: only delta paths see particles; a hit closer than the surface replaces it */
+static void particles_trace(const OracleScene* s, const OTracer* tr, const Sampler* smp, vec3 origin, vec3 ray, uint16_t state, OHit* hit) {
+  if (!s->particles_active || (state & ST_DELTA_PATH) == 0) return;
+  Sampler first = *smp;
+  first.depth = 0; /* random_1D_consistent, random.cuh:356-361 */
+  const float time = rnd1(&first, RT_CAMERA_TIME_TARGET);
+  const vec3 motion_offset = v_scale(v3(s->particles_direction[0], s->particles_direction[1], s->particles_direction[2]), time * s->particles_speed);
+  const vec3 scaled_ray = v_scale(ray, 1.0f / s->particles_scale);
+  vec3 pos = v_scale(v_add(origin, motion_offset), 1.0f / s->particles_scale);
+  pos.x = pos.x - floorf(pos.x); pos.y = pos.y - floorf(pos.y); pos.z = pos.z - floorf(pos.z);
+  float t;
+  const uint32_t tri = trace_particles(tr, pos, scaled_ray, hit->t, &t);
+  if (tri != 0xFFFFFFFFu) { hit->instance_id = HIT_TYPE_PARTICLE_MIN + (tri >> 1); hit->tri_id = 0; hit->t = t; }
+}
+typedef struct { vec3 position, normal, V; uint16_t state; } ParticleCtx;
+static float particle_phase(const OracleScene* s, const ParticleCtx* c, vec3 L) { return je_phase_function(s->particles_phase, -v_dot(c->V, L)); }
+/* light_sample<MATERIAL_PARTICLE> (light.cuh:49-82, :100-159): BSDF value = albedo x phase function, MIS weight 1 (mis.cuh:41-47) */
+static LightSample particle_light_sample(const OracleScene* s, const ParticleCtx* c, const Sampler* smp) {
+  LTQuery query = {NULL, NULL, RT_LIGHT_GEO_TREE_PREPASS, RT_LIGHT_GEO_TREE_POSTPASS, &c->position};
+  const LTWork work = light_tree_prepass(s, &query, smp);
+  const RGBF albedo = c3(s->particles_albedo[0], s->particles_albedo[1], s->particles_albedo[2]);
+  LightSample res;
+  res.light_id = LIGHT_ID_INVALID; res.ray = v3(0.0f, 0.0f, 0.0f); res.light_color = c_splat(0.0f); res.dist = 0.0f; res.root_sum = 0.0f;
+  RISReservoir rv = ris_init(rnd1(smp, RT_LIGHT_GEO_RESAMPLING));
+  for (uint32_t out = 0; out < LIGHT_TREE_NUM_OUTPUTS; out++) {
+    const LTResult o = light_tree_postpass(s, &query, smp, out, &work);
+    if (o.light_id == LIGHT_ID_INVALID) continue;
+    const uint32_t inst = s->light_tri_handles[2 * o.light_id], tri = s->light_tri_handles[2 * o.light_id + 1];
+    uint32_t uvp[3];
+    TriLight tl = light_triangle_init(s, inst, tri, uvp);
+    vec3 ray; float dist, sa;
+    if (!light_triangle_finalize(&tl, uvp, c->position, rnd2(smp, RT_LIGHT_GEO_RAY + out), &ray, &dist, &sa)) continue;
+    RGBF lc = light_get_color(s, &tl);
+    const RGBF bw = c_scale(albedo, particle_phase(s, c, ray) * 1.0f);
+    lc = c_scale(c_mul(lc, bw), 1.0f);
+    if (ris_add(&rv, c_importance(lc), o.weight * sa)) { res.light_id = o.light_id; res.ray = ray; res.light_color = lc; res.dist = dist; }
+  }
+  res.light_color = c_scale(res.light_color, ris_sampling_weight(&rv));
+  return res;
+}
+/* direct_lighting_sun_create_task / _direct for a particle (direct_lighting.cuh:20-121, :352-383; random set LIGHT_SUN<0>) */
+static bool particle_sun_sample(const OracleScene* s, const OSky* sky, const ParticleCtx* c, const Sampler* smp, RGBF* light_out, vec3* dir_out) {
+  const vec3 sky_pos = world_to_sky(sky, c->position);
+  const bool sun_below_horizon = sph_hit_p0(v_norm(v_sub(sky->sun_pos, sky_pos)), sky_pos, SKY_EARTH_RADIUS);
+  const bool inside_earth = v_len(sky_pos) < SKY_EARTH_RADIUS;
+  if (sun_below_horizon || inside_earth) return false;
+  const RGBF albedo = c3(s->particles_albedo[0], s->particles_albedo[1], s->particles_albedo[2]);
+  const float2_t random_dir = rnd2(smp, RT_SUN_BSDF);
+  const float random_method = rnd1(smp, RT_SUN_BSDF_METHOD);
+  const vec3 dir_bsdf = je_phase_sample(s->particles_phase, v_scale(c->V, -1.0f), random_dir, random_method);
+  RGBF light_bsdf = c_splat(0.0f);
+  if (sphere_hit(dir_bsdf, sky_pos, sky->sun_pos, SKY_SUN_RADIUS)) light_bsdf = c_mul(sky_sun_color(sky, sky_pos, dir_bsdf), c_scale(albedo, particle_phase(s, c, dir_bsdf) * 1.0f));
+  float solid_angle;
+  const vec3 dir_sa = sample_sphere(sky->sun_pos, SKY_SUN_RADIUS, sky_pos, rnd2(smp, RT_SUN_RAY), &solid_angle);
+  const RGBF light_sa = c_mul(sky_sun_color(sky, sky_pos, dir_sa), c_scale(albedo, particle_phase(s, c, dir_sa) * 1.0f));
+  const float target_bsdf = c_importance(light_bsdf), target_sa = c_importance(light_sa);
+  const float mis_bsdf = solid_angle / (particle_phase(s, c, dir_bsdf) * solid_angle + 1.0f);
+  const float mis_sa = solid_angle / (particle_phase(s, c, dir_sa) * solid_angle + 1.0f);
+  const float weight_bsdf = target_bsdf * mis_bsdf, weight_sa = target_sa * mis_sa;
+  const float sum_weights = weight_bsdf + weight_sa;
+  if (sum_weights == 0.0f) return false;
+  float target;
+  RGBF light;
+  if (rnd1(smp, RT_SUN_RESAMPLING) * sum_weights < weight_bsdf) { *dir_out = dir_bsdf; target = target_bsdf; light = light_bsdf; }
+  else { *dir_out = dir_sa; target = target_sa; light = light_sa; }
+  light = c_scale(light, sum_weights / target);
+  if (target == 0.0f) return false;
+  if (c_importance(light) == 0.0f) return false;
+  *light_out = s->fog_active ? c_scale(light, fog_transmittance(s, c->position, *dir_out, FLT_MAX)) : light;
+  return true;
+}
+
 /* volume_process_events (volume.cuh:100-229): closed-form distance sampling. A path that scatters before its hit becomes a volume hit, the throughput
  * takes transmittance over sampling density; in the non-procedural sky modes a ray that left the scene adds the sky here and ends (sky fast path). */
 static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p) {
@@ -352,7 +452,7 @@ static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origi
         beauty_add(&result, sky);
         hit.instance_id = HIT_TYPE_INVALID;
       }
-      const float intersection_probability = (state & ST_DELTA_PATH) ? 0.5f : 1.0f; /* bounds the variance of highlights seen through the fog */
+      const float intersection_probability = ((state & ST_DELTA_PATH) && !particle_is_hit(hit.instance_id)) ? 0.5f : 1.0f; /* bounds the variance of highlights seen through the fog */
       const float2_t randoms = rnd2(&smp, RT_VOLUME_INTERSECTION);
       bool sampled = false;
       float pdf = 1.0f;
@@ -394,6 +494,7 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     smp.depth = (depth == s->max_ray_depth && depth > 0) ? depth - 1 : depth;
     OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
     cnt[ORACLE_CNT_TRACE]++;
+    particles_trace(s, tr, &smp, origin, ray, state, &hit);
     if (s->fog_active) {
       /* device_renderer.c:64-76: in-scattering and its shadow pass, then the distance sampling (volume_process_events, volume.cuh:100-229) */
       const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, cnt);
@@ -431,6 +532,68 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       state &= ~(ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
       if (s->sky_mode != SKY_MODE_DEFAULT) state &= ~ST_ALLOW_AMBIENT; else state |= ST_ALLOW_AMBIENT;
       state |= ST_VOLUME_SCATTERED;
+      continue;
+    }
+    if (particle_is_hit(hit.instance_id)) { /* particle_process_tasks (particle.cuh:7-108) and its share of the shadow pass (optix_kernel_shadow.cu) */
+      ParticleCtx pc;
+      pc.position = v_add(origin, v_scale(ray, hit.t));
+      const float* qn = s->particle_normals + 4 * (size_t) (hit.instance_id & HIT_TYPE_PARTICLE_MASK);
+      const vec3 quad_normal = v3(qn[0], qn[1], qn[2]);
+      pc.normal = (v_dot(ray, quad_normal) < 0.0f) ? quad_normal : v_scale(quad_normal, -1.0f);
+      pc.V = v_scale(ray, -1.0f);
+      pc.state = state;
+      const RGBF albedo = c3(s->particles_albedo[0], s->particles_albedo[1], s->particles_albedo[2]);
+      const bool p_geo_allowed = lights_present && ((state & ST_VOLUME_SCATTERED) == 0);
+      LightSample ls; ls.light_id = LIGHT_ID_INVALID; ls.light_color = c_splat(0.0f); ls.ray = v3(0, 0, 0); ls.dist = 0.0f;
+      if (p_geo_allowed) {
+        ls = particle_light_sample(s, &pc, &smp);
+        if (s->fog_active) ls.light_color = c_scale(ls.light_color, fog_transmittance(s, pc.position, ls.ray, ls.dist));
+      }
+      const bool p_sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
+      uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
+      if (p_sun_allowed) {
+        const OSky sky_v = osky_view(s);
+        RGBF lc; vec3 dir;
+        if (particle_sun_sample(s, &sky_v, &pc, &smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+      }
+      /* bsdf_sample<MATERIAL_PARTICLE> with RANDOM_GI (bsdf.cuh:320-331): weight = albedo */
+      const float random_choice = rnd1(&smp, RT_BSDF_RESAMPLING);
+      const float2_t random_dir = rnd2(&smp, RT_BSDF_DIFFUSE);
+      const vec3 bounce = je_phase_sample(s->particles_phase, ray, random_dir, random_choice);
+      const bool p_ambient_allowed = s->sky_mode != SKY_MODE_DEFAULT;
+      uint2_t amb_color = {0, 0}, amb_ray = {0, 0};
+      if (p_ambient_allowed) { amb_color = record_pack(c_mul(sky_color_no_compute(s, pc.position, bounce, 0), albedo)); amb_ray = ray_pack(bounce); }
+      const RGBF record_in = record_unpack(record_p);
+      {
+        RGBF acc = c_splat(0.0f);
+        if (ls.light_id != LIGHT_ID_INVALID && p_geo_allowed) {
+          cnt[ORACLE_CNT_SHADOW]++;
+          const RGBF vis = trace_shadow(tr, pc.position, ls.ray, ls.dist, s->light_tri_handles[2 * ls.light_id], s->light_tri_handles[2 * ls.light_id + 1], hit.instance_id, 0);
+          acc = c_add(acc, c_mul(ls.light_color, vis));
+        }
+        if ((sun_color.x != 0 || sun_color.y != 0) && p_sun_allowed) {
+          cnt[ORACLE_CNT_SHADOW]++;
+          const RGBF vis = trace_shadow(tr, pc.position, ray_unpack(sun_ray), FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, 0);
+          acc = c_add(acc, c_mul(record_unpack(sun_color), vis));
+        }
+        if ((amb_color.x != 0 || amb_color.y != 0) && p_ambient_allowed) {
+          const vec3 ar = ray_unpack(amb_ray);
+          cnt[ORACLE_CNT_SHADOW]++;
+          const RGBF vis = trace_shadow(tr, pc.position, ar, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, 0);
+          RGBF lc = c_mul(record_unpack(amb_color), vis);
+          if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, pc.position, ar, FLT_MAX));
+          acc = c_add(acc, lc);
+        }
+        beauty_add(&result, c_mul(acc, record_in));
+      }
+      uint16_t new_state = state & ~(ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
+      if (s->sky_mode != SKY_MODE_DEFAULT) new_state &= ~ST_ALLOW_AMBIENT; else new_state |= ST_ALLOW_AMBIENT;
+      RGBF record = c_mul(record_in, albedo);
+      if (!russian_roulette(s, &smp, state, &record)) break;
+      record_p = record_pack(record);
+      state = new_state;
+      origin = pc.position;
+      ray = bounce;
       continue;
     }
     cnt[ORACLE_CNT_VERTICES]++;
@@ -957,4 +1120,16 @@ void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const f
 void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf) {
   const OVolume v = {scattering, 1.0f, 1.0f, 0.0f};
   for (uint32_t i = 0; i < count; i++) { t[i] = volume_sample_bounded(&v, max_length, rnd[i]); pdf[i] = volume_sample_bounded_pdf(&v, max_length, t[i]); }
+}
+
+/* lattice tracer of the particles on explicit rays (tests/test_particles.py): pos in [0,1)^3, dir = direction / particles_scale */
+void oracle_probe_particle_trace(const OracleScene* s, uint32_t count, const float* pos, const float* dir, const float* tmax, float* out_t, uint32_t* out_tri) {
+  OTracer tr;
+  tracer_init(&tr, s, 1);
+  for (uint32_t i = 0; i < count; i++) {
+    float t = tmax[i];
+    out_tri[i] = trace_particles(&tr, v3(pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]), v3(dir[3 * i], dir[3 * i + 1], dir[3 * i + 2]), tmax[i], &t);
+    out_t[i] = t;
+  }
+  tracer_free(&tr);
 }

@@ -32,6 +32,7 @@ typedef struct {
   const OracleScene* scene;
   OBvh* mesh_bvh;  /* per mesh, NULL when brute force */
   OBvh light_bvh;  /* over world-space light triangles */
+  OBvh particle_bvh; /* over the 2 x particles_count triangles of the particle unit cell */
   float* inst_inv; /* 12 per instance: rows (m_i0, m_i1, m_i2, T_i) of the world->object matrix */
   int use_bvh;
 } OTracer;
@@ -133,10 +134,21 @@ static void bvh_build(OBvh* b, uint32_t count, OTri (*get)(const OracleScene*, u
   free(prims);
 }
 static OTri light_tri_adapter(const OracleScene* s, uint32_t mesh, uint32_t i) { (void) mesh; return light_tri(s, i); }
+static OTri particle_tri(const OracleScene* s, uint32_t mesh, uint32_t i) { /* triangle i of the particle vertex buffer (particle.cuh:202-207) */
+  (void) mesh;
+  const float* p = s->particle_vertices + (size_t) i * 12;
+  OTri t;
+  t.p0 = v3(p[0], p[1], p[2]);
+  t.e1 = v_sub(v3(p[4], p[5], p[6]), t.p0);
+  t.e2 = v_sub(v3(p[8], p[9], p[10]), t.p0);
+  return t;
+}
 
 static void tracer_init(OTracer* t, const OracleScene* s, int use_bvh) {
   t->scene = s; t->use_bvh = use_bvh; t->mesh_bvh = NULL;
   t->light_bvh.nodes = NULL; t->light_bvh.tri_ids = NULL; t->light_bvh.num_nodes = 0;
+  t->particle_bvh.nodes = NULL; t->particle_bvh.tri_ids = NULL; t->particle_bvh.num_nodes = 0;
+  if (s->particles_active && s->particle_vertices) bvh_build(&t->particle_bvh, 2 * s->particles_count, particle_tri, s, 0); /* also for brute-force scenes */
   t->inst_inv = (float*) malloc(sizeof(float) * 12 * ((size_t) s->num_instances + 1));
   for (uint32_t i = 0; i < s->num_instances; i++) {
     const OTransform tf = scene_transform(s, i);
@@ -158,6 +170,7 @@ static void tracer_free(OTracer* t) {
     free(t->mesh_bvh);
   }
   free(t->light_bvh.nodes); free(t->light_bvh.tri_ids);
+  free(t->particle_bvh.nodes); free(t->particle_bvh.tri_ids);
 }
 
 static inline bool slab_hit(const OBvhNode* n, vec3 o, vec3 inv, float tmax) {
@@ -223,6 +236,49 @@ static inline OHit trace_closest(const OTracer* tr, vec3 origin, vec3 dir, bool 
   }
   if (best.t == FLT_MAX) { best.instance_id = HIT_TYPE_SKY; best.tri_id = 0; }
   return best;
+}
+
+/*
+ * Particles (optix_kernel_raytrace.cu:97-131, device_particle.c:23-82): the unit cell of quads is instanced on the 25 x 25 x 25 integer lattice around
+ * the origin; `pos` lies in [0, 1)^3 and `dir` is the path's direction divided by the particle scale, so ray parameters are world distances. Nearest
+ * hit closer than `tmax` whose barycentrics lie inside the disc of optix_common.cuh:67-74; returns the triangle index or 0xFFFFFFFF. Every lattice cell
+ * whose (padded) box the segment touches is searched - no acceleration structure over the cells, unlike the product's top-level tree.
+ */
+#define PARTICLES_BLOCK_DIM 25
+static inline uint32_t trace_particles(const OTracer* tr, vec3 pos, vec3 dir, float tmax, float* t_out) {
+  const OBvh* bvh = &tr->particle_bvh;
+  if (!bvh->nodes) return 0xFFFFFFFFu;
+  const OracleScene* s = tr->scene;
+  const OBvhNode* root = &bvh->nodes[0];
+  const vec3 inv = v3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
+  float best_t = tmax;
+  uint32_t best_tri = 0xFFFFFFFFu, best_cell = 0xFFFFFFFFu;
+  const float id_x[3] = {1.0f, 0.0f, 0.0f}, id_y[3] = {0.0f, 1.0f, 0.0f}, id_z[3] = {0.0f, 0.0f, 1.0f};
+  uint32_t cell = 0;
+  for (int xi = 0; xi < PARTICLES_BLOCK_DIM; xi++)
+    for (int yi = 0; yi < PARTICLES_BLOCK_DIM; yi++)
+      for (int zi = 0; zi < PARTICLES_BLOCK_DIM; zi++, cell++) {
+        const float cx = (float) (xi - (PARTICLES_BLOCK_DIM >> 1)), cy = (float) (yi - (PARTICLES_BLOCK_DIM >> 1)), cz = (float) (zi - (PARTICLES_BLOCK_DIM >> 1));
+        OBvhNode box = *root;
+        box.lo[0] += cx; box.hi[0] += cx; box.lo[1] += cy; box.hi[1] += cy; box.lo[2] += cz; box.hi[2] += cz;
+        for (int k = 0; k < 3; k++) { box.lo[k] -= 1e-4f; box.hi[k] += 1e-4f; }
+        if (!slab_hit(&box, pos, inv, best_t)) continue;
+        /* the instance's world->object map, rows (1,0,0 | cx) ... as the product's top-level leaf holds them */
+        const float px = pos.x - cx, py = pos.y - cy, pz = pos.z - cz;
+        const vec3 o = v3(mat_row_apply(id_x, px, py, pz), mat_row_apply(id_y, px, py, pz), mat_row_apply(id_z, px, py, pz));
+        const vec3 d = v3(mat_row_apply(id_x, dir.x, dir.y, dir.z), mat_row_apply(id_y, dir.x, dir.y, dir.z), mat_row_apply(id_z, dir.x, dir.y, dir.z));
+        OBVH_FOREACH_TRI(bvh, 2 * s->particles_count, o, d, best_t, tri, {
+          const OTri t = particle_tri(s, 0, tri);
+          float2_t c;
+          const float th = tri_intersect(t.p0, t.e1, t.e2, o, d, &c);
+          if (th < best_t || (th == best_t && th != FLT_MAX && best_tri != 0xFFFFFFFFu && (cell < best_cell || (cell == best_cell && tri < best_tri)))) {
+            const float dx = c.x - 0.5f, dy = c.y - 0.5f;
+            if (!(dx * dx + dy * dy > 0.25f)) { best_t = th; best_tri = tri; best_cell = cell; }
+          }
+        });
+      }
+  *t_out = best_t;
+  return best_tri;
 }
 
 /*

@@ -96,10 +96,10 @@ static inline float fog_transmittance(const OracleScene* s, vec3 origin, vec3 ra
 
 /* ---- phase functions (math.cuh:1169-1322); the Jendersie-Eon parameters of the droplet diameter come with the scene ---- */
 static inline float draine_phase(float c, float g, float alpha) { return hg_phase(c, g) * ((1.0f + alpha * c * c) / (1.0f + (alpha / 3.0f) * (1.0f + 2.0f * g * g))); }
-static inline float fog_phase_function(const OracleScene* s, float c) {
-  const float g_hg = s->fog_phase[0], g_d = s->fog_phase[1], alpha = s->fog_phase[2], w_d = s->fog_phase[3];
-  return (1.0f - w_d) * hg_phase(c, g_hg) + w_d * draine_phase(c, g_d, alpha);
+static inline float je_phase_function(const float p[4], float c) { /* jendersie_eon_phase_function, math.cuh:1234-1239; p = g_hg, g_d, alpha, w_d */
+  return (1.0f - p[3]) * hg_phase(c, p[0]) + p[3] * draine_phase(c, p[1], p[2]);
 }
+static inline float fog_phase_function(const OracleScene* s, float c) { return je_phase_function(s->fog_phase, c); }
 static inline vec3 phase_sample_basis(float alpha, float beta, vec3 basis) { /* math.cuh:1249-1272 */
   vec3 u1, u2;
   if (basis.z < -0.9999805689f) { u1 = v3(0.0f, -1.0f, 0.0f); u2 = v3(-1.0f, 0.0f, 0.0f); }
@@ -132,10 +132,11 @@ static inline float draine_phase_sample(float g, float alpha, float r) { /* math
   const float h = sqrtf(6.0f * (1.0f + g2) - t8 + 8.0f * t4 / (t0 * t9)) - t9;
   return 0.5f * g + ((1.0f / (2.0f * g)) - (1.0f / (8.0f * g)) * (h * h));
 }
-static inline vec3 fog_phase_sample(const OracleScene* s, vec3 ray, float2_t r_dir, float r_choice) { /* jendersie_eon_phase_sample, math.cuh:1311-1323 */
-  const float cos_angle = (r_choice < s->fog_phase[3]) ? draine_phase_sample(s->fog_phase[1], s->fog_phase[2], r_dir.x) : hg_phase_sample(s->fog_phase[0], r_dir.x);
+static inline vec3 je_phase_sample(const float p[4], vec3 ray, float2_t r_dir, float r_choice) { /* jendersie_eon_phase_sample, math.cuh:1311-1323 */
+  const float cos_angle = (r_choice < p[3]) ? draine_phase_sample(p[1], p[2], r_dir.x) : hg_phase_sample(p[0], r_dir.x);
   return phase_sample_basis(cos_angle, r_dir.y, ray);
 }
+static inline vec3 fog_phase_sample(const OracleScene* s, vec3 ray, float2_t r_dir, float r_choice) { return je_phase_sample(s->fog_phase, ray, r_dir, r_choice); }
 
 /* ---- the volume's shading context (material.cuh:76-89, volume_utils.cuh:310-321) ---- */
 typedef struct VolCtx { OVolume vol; vec3 position, V; uint16_t state; float max_dist; } VolCtx;

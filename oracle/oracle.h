@@ -86,6 +86,15 @@ typedef struct OracleScene {
   float fog_phase[4];               /* Jendersie-Eon g_hg, g_d, alpha, w_d of fog.droplet_diameter (math.cuh:1189-1232) */
   const float* bridge_lut;          /* 64 x 21 floats (data/bridge): vertex-count importance of the bridge sampler (light_bridges.cuh:67-108) */
   uint32_t bridge_max_num_vertices; /* settings.bridge_max_num_vertices (a 4-bit field on the device, device_structs.h:11) */
+  /* particles (device_particle.c, cuda/particle.cuh:165-211): `particles_count` camera-facing-agnostic quads scattered in the unit cube, tiled 25 x 25 x 25
+   * times around the ray's start in a space scaled by particles_scale; hit only by delta paths. Generated by the host layer. */
+  uint32_t particles_active, particles_count;
+  float particles_scale, particles_speed;
+  float particles_albedo[3];
+  float particles_direction[3];       /* angles_to_direction(direction_altitude, direction_azimuth) (math.cuh:781-788) */
+  float particles_phase[4];           /* Jendersie-Eon parameters of phase_diameter */
+  const float* particle_vertices;     /* 6 x float4 per particle: two triangles (a00, a01, a10), (a11, a01, a10), w = 1 */
+  const float* particle_normals;      /* float4 per particle: the quad's normal */
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -192,6 +201,7 @@ void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* 
 void oracle_probe_volume_path(const float cam_pos[3], float dist, float height, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out);
 void oracle_probe_fog_phase(const OracleScene* s, uint32_t count, const float* cos_angle, float* out);
 void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const float* rnd, float* out);
+void oracle_probe_particle_trace(const OracleScene* s, uint32_t count, const float* pos, const float* dir, const float* tmax, float* out_t, uint32_t* out_tri);
 void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf);
 
 #endif
