@@ -22,6 +22,23 @@ struct alignas(128) Bvh4Node {
 };
 static_assert(sizeof(Bvh4Node) == 128, "BVH4 node must be one cache line");
 
+// 8-wide node with quantised child boxes, the format of the scene's and the particles' trees when LUM_BVH8 is on (the light tree keeps 4-wide
+// nodes). Same 128-byte slot, same child words. Child j's box = origin + q * 2^(e - 127) per axis, lower corners rounded down, upper up.
+// Experiment, measured negative and therefore off (profiles/r02_ab_experiments.txt): node visits per ray fall by 22 % (hall 16.4 -> 12.7), but a visit
+// costs 2.8 x the VALU work (48 byte->float conversions, a 19-comparator sort) and the ray kernels are as much issue- as latency-limited at 4 waves
+// per SIMD: closest-hit +9 %, visibility +10 % time on the hall. Parity tests pass with it on.
+#ifndef LUM_BVH8
+#define LUM_BVH8 0
+#endif
+struct alignas(128) Bvh8Node {
+  float origin[3];
+  uint8_t exp[3], pad0;   // biased exponents of the per-axis scale
+  uint32_t child[8];
+  uint8_t lo_x[8], lo_y[8], lo_z[8], hi_x[8], hi_y[8], hi_z[8];
+  uint32_t pad[8];
+};
+static_assert(sizeof(Bvh8Node) == 128, "BVH8 node must be one cache line");
+
 constexpr uint32_t kBvhEmpty      = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeafBit    = 0x80000000u;
 constexpr uint32_t kBvhLeafMaxTri = 4;

@@ -82,6 +82,10 @@ struct TRay {
     ny = (inv.y < 0.0f) ? 64u : 16u; fy = 80u - ny;    // lo_y at 16, hi_y at 64
     nz = (inv.z < 0.0f) ? 80u : 32u; fz = 112u - nz;   // lo_z at 32, hi_z at 80
   }
+  // the same for an 8-wide quantised node (Bvh8Node, dev_scene.h): lo_x at 48, lo_y 56, lo_z 64, hi_x 72, hi_y 80, hi_z 88
+  LUM_DEV uint32_t nx8() const { return (inv.x < 0.0f) ? 72u : 48u; }
+  LUM_DEV uint32_t ny8() const { return (inv.y < 0.0f) ? 80u : 56u; }
+  LUM_DEV uint32_t nz8() const { return (inv.z < 0.0f) ? 88u : 64u; }
 };
 
 LUM_DEV float4 node_f4(const Bvh4Node* nodes, uint32_t byte_offset) {
@@ -198,6 +202,93 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
   }
 #endif
   return (k0 < inf) ? c0 : kBvhEmpty;
+}
+
+// ---- 8-wide nodes with quantised child boxes (Bvh8Node): the scene's and the particles' trees ----
+// A ray kernel's time is the chain of dependent node fetches (VALU issue 0.25): eight children per 128-byte line instead of
+// four shorten that chain by a third to a half for the same bytes per visit; the boxes are 8-bit offsets from the node's corner in units of a
+// power of two per axis, rounded outwards by the builder (after Ylitie, Karras, Laine 2017, without their octant ordering: the eight entry
+// distances are sorted by a 19-comparator network).
+LUM_DEV float byte_f(uint32_t w, uint32_t k) { return (float) ((w >> (8u * k)) & 0xFFu); }  // v_cvt_f32_ubyte{k}
+template <bool kOrdered, bool kCull>
+LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+                             typename StackEntry<kCull>::E& top, RayStats& st) {
+  using SE = StackEntry<kCull>;
+  const uint32_t b = cur << 7;
+  const uint32_t onx = r.nx8(), ony = r.ny8(), onz = r.nz8();
+  float4 head;
+  uint4 ca, cb;
+  uint2 qnx, qny, qnz, qfx, qfy, qfz;
+  if (cur < src.lds_count) {
+    const char* p = src.lds + b;
+    head = *reinterpret_cast<const float4*>(p); ca = *reinterpret_cast<const uint4*>(p + 16u); cb = *reinterpret_cast<const uint4*>(p + 32u);
+    qnx = *reinterpret_cast<const uint2*>(p + onx); qny = *reinterpret_cast<const uint2*>(p + ony); qnz = *reinterpret_cast<const uint2*>(p + onz);
+    qfx = *reinterpret_cast<const uint2*>(p + (120u - onx)); qfy = *reinterpret_cast<const uint2*>(p + (136u - ony)); qfz = *reinterpret_cast<const uint2*>(p + (152u - onz));
+    st.lds_nodes++;
+  }
+  else {
+    const char* __restrict__ p = reinterpret_cast<const char*>(src.global) + b;
+    head = *reinterpret_cast<const float4*>(p); ca = *reinterpret_cast<const uint4*>(p + 16u); cb = *reinterpret_cast<const uint4*>(p + 32u);
+    qnx = *reinterpret_cast<const uint2*>(p + onx); qny = *reinterpret_cast<const uint2*>(p + ony); qnz = *reinterpret_cast<const uint2*>(p + onz);
+    qfx = *reinterpret_cast<const uint2*>(p + (120u - onx)); qfy = *reinterpret_cast<const uint2*>(p + (136u - ony)); qfz = *reinterpret_cast<const uint2*>(p + (152u - onz));
+  }
+  // plane distance = (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv + noi)
+  const uint32_t ew = fbits(head.w);
+  const float sx = bitsf((ew & 0xFFu) << 23) * r.inv.x, sy = bitsf(((ew >> 8) & 0xFFu) << 23) * r.inv.y, sz = bitsf(((ew >> 16) & 0xFFu) << 23) * r.inv.z;
+  const float bx = __builtin_fmaf(head.x, r.inv.x, r.noi.x), by = __builtin_fmaf(head.y, r.inv.y, r.noi.y), bz = __builtin_fmaf(head.z, r.inv.z, r.noi.z);
+  const float inf = __builtin_inff();
+  const float lim = vmin2(tmax, inf);
+  float k[8];
+  uint32_t c[8] = {ca.x, ca.y, ca.z, ca.w, cb.x, cb.y, cb.z, cb.w};
+#pragma unroll
+  for (uint32_t j = 0; j < 8; j++) {
+    const uint32_t wnx = j < 4 ? qnx.x : qnx.y, wny = j < 4 ? qny.x : qny.y, wnz = j < 4 ? qnz.x : qnz.y;
+    const uint32_t wfx = j < 4 ? qfx.x : qfx.y, wfy = j < 4 ? qfy.x : qfy.y, wfz = j < 4 ? qfz.x : qfz.y;
+    const float ax = __builtin_fmaf(byte_f(wnx, j & 3u), sx, bx), ay = __builtin_fmaf(byte_f(wny, j & 3u), sy, by), az = __builtin_fmaf(byte_f(wnz, j & 3u), sz, bz);
+    const float fx = __builtin_fmaf(byte_f(wfx, j & 3u), sx, bx), fy = __builtin_fmaf(byte_f(wfy, j & 3u), sy, by), fz = __builtin_fmaf(byte_f(wfz, j & 3u), sz, bz);
+    const float tn = vmax3(ax, ay, vmax0(az));
+    const float tf = vmin3(fx, fy, vmin2(fz, lim));
+    k[j] = (c[j] != kBvhEmpty && tn <= __builtin_fmaf(tf, 1.000004f, 1e-30f)) ? tn : inf;
+  }
+  if (kOrdered) {  // Batcher's odd-even merge sort, 19 comparators
+    cswap(k[0], c[0], k[1], c[1]); cswap(k[2], c[2], k[3], c[3]); cswap(k[4], c[4], k[5], c[5]); cswap(k[6], c[6], k[7], c[7]);
+    cswap(k[0], c[0], k[2], c[2]); cswap(k[1], c[1], k[3], c[3]); cswap(k[4], c[4], k[6], c[6]); cswap(k[5], c[5], k[7], c[7]);
+    cswap(k[1], c[1], k[2], c[2]); cswap(k[5], c[5], k[6], c[6]);
+    cswap(k[0], c[0], k[4], c[4]); cswap(k[1], c[1], k[5], c[5]); cswap(k[2], c[2], k[6], c[6]); cswap(k[3], c[3], k[7], c[7]);
+    cswap(k[2], c[2], k[4], c[4]); cswap(k[3], c[3], k[5], c[5]);
+    cswap(k[1], c[1], k[2], c[2]); cswap(k[3], c[3], k[4], c[4]); cswap(k[5], c[5], k[6], c[6]);
+    // pushes only what is real, far to near; sorted, so "child j is real" implies the same of every child before it
+    if (k[1] < inf) {
+      if (k[2] < inf) {
+        if (k[3] < inf) {
+          if (k[4] < inf) {
+            if (k[5] < inf) {
+              if (k[6] < inf) {
+                if (k[7] < inf) { stk[sp] = top; sp++; top = SE::make(c[7], k[7]); }
+                stk[sp] = top; sp++; top = SE::make(c[6], k[6]);
+              }
+              stk[sp] = top; sp++; top = SE::make(c[5], k[5]);
+            }
+            stk[sp] = top; sp++; top = SE::make(c[4], k[4]);
+          }
+          stk[sp] = top; sp++; top = SE::make(c[3], k[3]);
+        }
+        stk[sp] = top; sp++; top = SE::make(c[2], k[2]);
+      }
+      stk[sp] = top; sp++; top = SE::make(c[1], k[1]);
+    }
+    return (k[0] < inf) ? c[0] : kBvhEmpty;
+  }
+  // unordered: continue with the first real child, push the others
+  uint32_t next = kBvhEmpty;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; j++) {
+    if (k[j] < inf) {
+      if (next == kBvhEmpty) next = c[j];
+      else { stk[sp] = top; sp++; top = SE::make(c[j], k[j]); }
+    }
+  }
+  return next;
 }
 
 struct NodeData { float4 nx, ny, nz, fx, fy, fz; uint4 ch; };
@@ -478,7 +569,11 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           }
           else
 #endif
+#if LUM_BVH8
+          cur = visit_node8<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
+#else
           cur = visit_node<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
+#endif
 #if LUM_PREFETCH
           {
             const uint32_t t = SE::node(top);

@@ -429,6 +429,113 @@ void lumc_context_destroy(LumContext* ctx) {
 const char* lumc_last_error(const LumContext* ctx) { return ctx ? ctx->error.c_str() : "null context"; }
 uint32_t lumc_scene_view_sizeof(void) { return (uint32_t) sizeof(LumDeviceSceneView); }
 
+// ---- 8-wide quantised nodes (Bvh8Node, dev_scene.h) from a finished 4-wide tree ----
+// Every surviving node absorbs inner children, largest surface area first, while at most eight children result; the absorbed nodes
+// disappear. `keep`: nodes referenced from outside (the root, the roots of the meshes), which survive by construction since nothing has them as
+// a child. Survivors keep their relative order (the 4-wide array is already "top of the tree first"). Returns false when the traversal stack
+// (dev_trace.h kStackSize, up to seven pushes per level) could overflow.
+struct WideChild { float lo[3], hi[3]; uint32_t ref; };
+static float box_area(const WideChild& c) {
+  const float dx = c.hi[0] - c.lo[0], dy = c.hi[1] - c.lo[1], dz = c.hi[2] - c.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+static uint32_t node_children(const Bvh4Node& n, WideChild* out) {
+  uint32_t m = 0;
+  for (int k = 0; k < 4; k++) {
+    if (n.child[k] == kBvhEmpty) continue;
+    out[m] = WideChild{{n.lo_x[k], n.lo_y[k], n.lo_z[k]}, {n.hi_x[k], n.hi_y[k], n.hi_z[k]}, n.child[k]};
+    m++;
+  }
+  return m;
+}
+static bool widen_to_bvh8(const std::vector<Bvh4Node>& in, const std::vector<uint32_t>& keep, std::vector<Bvh8Node>& out, std::vector<uint32_t>& old_to_new,
+                          std::vector<uint32_t>* levels_out) {  // levels_out[r]: levels of the 8-wide tree below keep[r]
+  const size_t n = in.size();
+  std::vector<std::vector<WideChild>> wide(n);
+  std::vector<uint8_t> survives(n, 0);
+  std::vector<uint32_t> level(n, 0), root_of(n, 0);
+  std::vector<uint32_t> queue;
+  for (size_t r = 0; r < keep.size(); r++) if (keep[r] < n && !survives[keep[r]]) { survives[keep[r]] = 1; level[keep[r]] = 1; root_of[keep[r]] = (uint32_t) r; queue.push_back(keep[r]); }
+  std::vector<uint32_t> max_level(keep.size(), 0);
+  for (size_t head = 0; head < queue.size(); head++) {
+    const uint32_t i = queue[head];
+    max_level[root_of[i]] = std::max(max_level[root_of[i]], level[i]);
+    WideChild list[8];
+    uint32_t m = node_children(in[i], list);
+    for (;;) {
+      int best = -1;
+      float best_area = -1.0f;
+      uint32_t best_m = 0;
+      for (uint32_t k = 0; k < m; k++) {
+        const uint32_t ref = list[k].ref;
+        if (ref & kBvhLeafBit) continue;
+        uint32_t cm = 0;
+        for (int j = 0; j < 4; j++) if (in[ref].child[j] != kBvhEmpty) cm++;
+        if (cm == 0 || m - 1 + cm > 8) continue;
+        const float a = box_area(list[k]);
+        if (a > best_area) { best_area = a; best = (int) k; best_m = cm; }
+      }
+      if (best < 0) break;
+      WideChild sub[4];
+      const uint32_t cm = node_children(in[list[best].ref], sub);
+      (void) best_m;
+      list[best] = sub[0];
+      for (uint32_t j = 1; j < cm; j++) list[m++] = sub[j];
+    }
+    wide[i].assign(list, list + m);
+    for (uint32_t k = 0; k < m; k++) {
+      const uint32_t ref = list[k].ref;
+      if (!(ref & kBvhLeafBit) && !survives[ref]) { survives[ref] = 1; level[ref] = level[i] + 1; root_of[ref] = root_of[i]; queue.push_back(ref); }
+    }
+  }
+  old_to_new.assign(n, 0xFFFFFFFFu);
+  uint32_t count = 0;
+  for (size_t i = 0; i < n; i++) if (survives[i]) old_to_new[i] = count++;
+  out.assign(count, Bvh8Node{});
+  for (size_t i = 0; i < n; i++) {
+    if (!survives[i]) continue;
+    Bvh8Node& o = out[old_to_new[i]];
+    std::memset(&o, 0, sizeof(o));
+    const std::vector<WideChild>& ch = wide[i];
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (const WideChild& c : ch) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], c.lo[a]); hi[a] = std::max(hi[a], c.hi[a]); }
+    if (ch.empty()) for (int a = 0; a < 3; a++) { lo[a] = 0.0f; hi[a] = 0.0f; }
+    float scale[3];
+    for (int a = 0; a < 3; a++) {
+      o.origin[a] = lo[a];
+      const float extent = hi[a] - lo[a];
+      int e = -126;
+      if (extent > 0.0f && std::isfinite(extent)) {
+        int ex;
+        std::frexp(extent / 255.0f, &ex);  // extent / 255 = f * 2^ex with f in [0.5, 1): 2^ex >= extent / 255
+        e = std::max(-126, std::min(127, ex));
+      }
+      // the quotient must stay below 256 after the float subtraction's rounding: one step coarser when it does not
+      while (e < 127 && std::ceil((hi[a] - lo[a]) / std::ldexp(1.0f, e)) > 255.0f) e++;
+      o.exp[a] = (uint8_t) (e + 127);
+      scale[a] = std::ldexp(1.0f, e);
+    }
+    uint8_t* qlo[3] = {o.lo_x, o.lo_y, o.lo_z};
+    uint8_t* qhi[3] = {o.hi_x, o.hi_y, o.hi_z};
+    for (uint32_t k = 0; k < 8; k++) {
+      if (k >= ch.size()) {
+        o.child[k] = kBvhEmpty;
+        for (int a = 0; a < 3; a++) { qlo[a][k] = 255; qhi[a][k] = 0; }
+        continue;
+      }
+      const WideChild& c = ch[k];
+      o.child[k] = (c.ref & kBvhLeafBit) ? c.ref : old_to_new[c.ref];
+      for (int a = 0; a < 3; a++) {
+        const float l = std::floor((c.lo[a] - lo[a]) / scale[a]), h = std::ceil((c.hi[a] - lo[a]) / scale[a]);
+        qlo[a][k] = (uint8_t) std::max(0.0f, std::min(255.0f, l));
+        qhi[a][k] = (uint8_t) std::max(0.0f, std::min(255.0f, h));
+      }
+    }
+  }
+  if (levels_out) *levels_out = max_level;
+  return true;
+}
+
 // The particle tree (device_particle.c:23-131, optix_bvh.c's particle GAS / IAS): one bottom-level tree over the 2 x count triangles of the unit
 // cell, and a top level over its 25 x 25 x 25 integer translations, instance id = (xi * 25 + yi) * 25 + zi as the reference numbers them. The
 // top-level leaves hold the translation as an exact affine map (rows of the identity), so entering an instance is one subtraction per axis.
@@ -480,6 +587,21 @@ static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, Dev
     const uint32_t words[4] = {inst, base, 0u, 0u};
     std::memcpy(&leaves[4 * i + 3], words, 16);
   }
+  uint32_t mesh_root_index = base;
+#if LUM_BVH8
+  {
+    std::vector<Bvh8Node> wide;
+    std::vector<uint32_t> map;
+    std::vector<uint32_t> levels;
+    widen_to_bvh8(nodes, {0u, base}, wide, map, &levels);
+    if (7u * (levels[0] + levels[1]) + 4u > (uint32_t) kStackSize) { ctx->error = "particle BVH too deep for the traversal stack"; return 1; }
+    mesh_root_index = map[base];
+    static_assert(sizeof(Bvh8Node) == sizeof(Bvh4Node), "same 128-byte slot");
+    nodes.resize(wide.size());
+    std::memcpy(nodes.data(), wide.data(), wide.size() * sizeof(Bvh8Node));
+    for (size_t i = 0; i < tlas.prims.size(); i++) { const uint32_t words[4] = {tlas.prims[i], mesh_root_index, 0u, 0u}; std::memcpy(&leaves[4 * i + 3], words, 16); }
+  }
+#endif
   if (upload(ctx, nodes.data(), nodes.size(), &sc.particle_bvh_nodes)) return 1;
   if (upload(ctx, tris.data(), tris.size(), &sc.particle_tris)) return 1;
   if (upload(ctx, leaves.data(), leaves.size(), &sc.particle_leaves)) return 1;
@@ -641,6 +763,28 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     for (uint32_t m = 0; m < v->num_meshes; m++) mesh_root[m] = new_index[mesh_root[m]];
   }
   if (total_tris >= (1u << 28) || nodes.size() >= (1u << 25)) { ctx->error = "scene too large for 28-bit leaf ranges / 32-bit node offsets"; return 1; }
+#if LUM_BVH8
+  {
+    std::vector<uint32_t> keep;
+    keep.push_back(0u);
+    for (uint32_t m = 0; m < v->num_meshes; m++) if (v->mesh_tri_offset[m + 1] > v->mesh_tri_offset[m]) keep.push_back(mesh_root[m]);
+    // the two levels are walked one after the other: their depths add up on the stack
+    std::vector<Bvh8Node> wide;
+    std::vector<uint32_t> map;
+    std::vector<uint32_t> levels;
+    widen_to_bvh8(nodes, keep, wide, map, &levels);
+    uint32_t deepest_mesh = 0;
+    for (size_t r = 1; r < levels.size(); r++) deepest_mesh = std::max(deepest_mesh, levels[r]);
+    if (7u * (levels[0] + deepest_mesh) + 4u > (uint32_t) kStackSize) { ctx->error = "BVH too deep for the traversal stack (8-wide nodes)"; return 1; }
+    uint32_t new_tlas_nodes = 0;
+    for (uint32_t i = 0; i < sc.tlas_num_nodes; i++) if (map[i] != 0xFFFFFFFFu) new_tlas_nodes++;
+    sc.tlas_num_nodes = new_tlas_nodes;
+    for (uint32_t m = 0; m < v->num_meshes; m++) if (v->mesh_tri_offset[m + 1] > v->mesh_tri_offset[m]) mesh_root[m] = map[mesh_root[m]];
+    nodes.resize(wide.size());
+    std::memcpy(nodes.data(), wide.data(), wide.size() * sizeof(Bvh8Node));
+    ctx->bvh_stats[2] = new_tlas_nodes;
+  }
+#endif
   if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
   if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
   {
