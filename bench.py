@@ -10,8 +10,9 @@ Example-class scene (config 2) and the 10 M-triangle scan (config 5's scene) are
 same JSON line (`--secondary none` skips them).
 
 Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x1080 frame through all 9 depth passes (8 bounces) for
-         --samples-per-pass (default 8) x N sample ids, i.e. 1920*1080*8 paths per GPU and step whatever N is (weak scaling: the
-         frame gains 8*N samples per step). Deep bounces keep few paths alive, so several sample ids share a pass to keep 256 CUs busy.
+         --samples-per-pass (default 32) x N sample ids, i.e. 1920*1080*32 = 66 M paths (33 GB of queues) per GPU and step whatever N is
+         (weak scaling: the frame gains 32*N samples per step). Deep bounces keep few paths alive, so many sample ids share a pass to keep
+         256 CUs busy: 4 / 8 / 16 / 32 ids per pass give 2610 / 2769 / 2861 / 2907 Mrays/s on the hall (profiles/r02_ab_experiments.txt).
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
@@ -327,7 +328,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--samples-per-pass", type=int, default=8, help="sample ids per wavefront pass = per step")
+    ap.add_argument("--samples-per-pass", type=int, default=32, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],

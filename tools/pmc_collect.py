@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--workloads", default="hall,example,scan")
     ap.add_argument("--flavour", default=None)
     ap.add_argument("--calib", action="store_true")
-    ap.add_argument("--spp", type=int, default=8)
+    ap.add_argument("--spp", type=int, default=32)
     args = ap.parse_args()
     os.makedirs(args.out_dir, exist_ok=True)
     os.environ.setdefault("TMPDIR", "/tmp")
