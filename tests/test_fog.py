@@ -340,3 +340,52 @@ def test_fast_flavour_renders_the_same_fog(tmp_path):
     rel_l2 = np.linalg.norm(a - b) / np.linalg.norm(a)
     assert rel_l2 < 0.05, rel_l2                      # two 256-spp estimates with decorrelating roundings
     assert abs(b.sum() / a.sum() - 1.0) < 5e-3        # no bias in the frame sum
+
+
+@pytest.mark.gpu
+def test_tile_partition_and_adaptive_pass_shapes_with_fog_and_particles(tmp_path):
+    """What the multi-GPU path and the batching rely on, with the volume kernels in the loop: a 3-way tile partition of the frame reproduces the full frame
+    bit for bit (every path owns its in-scattering records and its 17 visibility slots), and so do two sample ids in one pass vs two passes."""
+    from luminary_amd.core import Core
+    from luminary_amd.distributed import tile_pixels
+    host = _fogged(scenes.cornell_host(str(tmp_path), 96, 64, 4), density=70.0)
+    p = host.get_particles(); p.active, p.count, p.size, p.scale = True, 600, 5.0, 1.5; host.set_particles(p)
+    view = _view(host)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.render(0, 2, samples_per_pass=2)
+        full, full_sm = core.accumulators()
+        ofm, osm, _ = oracle_lib.render(view, 0, 2)
+        assert np.array_equal(full, ofm) and np.array_equal(full_sm, osm)
+        core.render(0, 1, samples_per_pass=1)
+        core.render(1, 1, samples_per_pass=1)
+        two, two_sm = core.accumulators()
+        assert np.array_equal(two, full) and np.array_equal(two_sm, full_sm)
+        acc, acc_sm = np.zeros_like(full), np.zeros_like(full_sm)
+        for rank in range(3):
+            tiles = tile_pixels(96, 64, rank, 3, tile=16)
+            core.set_pixels(tiles)
+            core.render(0, 2, samples_per_pass=2)
+            part, part_sm = core.accumulators()
+            acc[:, tiles] = part
+            acc_sm[tiles] = part_sm
+        assert np.array_equal(acc, full) and np.array_equal(acc_sm, full_sm)
+    finally:
+        core.close()
+
+
+@pytest.mark.gpu
+def test_fog_and_particles_through_the_host_api(tmp_path):
+    """luminary_host_set_fog / set_particles, then the library's own render entry (luminary_ext_render_samples): its accumulators equal the oracle's."""
+    host = scenes.cornell_host(str(tmp_path), 48, 32, 3)
+    _fogged(host, density=80.0)
+    p = host.get_particles(); p.active, p.count, p.size, p.scale = True, 400, 6.0, 1.5; host.set_particles(p)
+    assert host.get_fog().active and host.get_particles().count == 400
+    host.render_samples(0, 2)
+    fm, sm = host.accumulators()
+    ofm, osm, _ = oracle_lib.render(_view(host), 0, 2)
+    assert np.array_equal(fm, ofm) and np.array_equal(sm, osm)
+    plain = scenes.cornell_host(str(tmp_path / "plain"), 48, 32, 3)
+    assert not np.array_equal(ofm, oracle_lib.render(_view(plain), 0, 2)[0])
