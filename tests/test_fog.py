@@ -359,6 +359,7 @@ def test_tile_partition_and_adaptive_pass_shapes_with_fog_and_particles(tmp_path
         full, full_sm = core.accumulators()
         ofm, osm, _ = oracle_lib.render(view, 0, 2)
         assert np.array_equal(full, ofm) and np.array_equal(full_sm, osm)
+        core.set_pixels(None)  # resets the accumulators
         core.render(0, 1, samples_per_pass=1)
         core.render(1, 1, samples_per_pass=1)
         two, two_sm = core.accumulators()
