@@ -14,10 +14,11 @@
  * include/luminary/, which all lead here: compile the frontend with -I<this repo>/include and link it with -lluminary_amd.
  * Scope of this implementation: the triangle / BSDF / NEE path with the thin-lens camera under every sky mode
  * (constant colour, procedural atmosphere with sun, moon and stars, baked panorama), the fog volume (scattering events, light scattered in
- * from sun, sky and - over multi-vertex bridges - emissive triangles), particles, textures, adaptive sampling, the undersampling preview,
- * the display chain with bloom, and the debug shading modes. Rendering runs on the library's own "Device" thread once
- * luminary_host_start_new_render was called, like the reference's. Ocean, clouds and the physical camera are stored and returned unchanged
- * but do not influence the image yet.
+ * from sun, sky and - over multi-vertex bridges - emissive triangles), particles, the ocean (ray-marched height field, Jerlov water volume,
+ * sun and sky light through the surface with caustics), textures, adaptive sampling, the undersampling preview, the display chain with
+ * bloom, and the debug shading modes. Rendering runs on the library's own "Device" thread once luminary_host_start_new_render was
+ * called, like the reference's. Clouds and the physical camera are stored and returned unchanged but do not influence the image yet
+ * (DESIGN.md section 7).
  *
  * Additive extension (the reference only returns tone-mapped ARGB8): the luminary_ext_* functions at the
  * end give access to float radiance, ray counters and batch rendering. Existing symbols are untouched.

@@ -81,6 +81,13 @@ class Fog(C.Structure):
     _fields_ = [("active", C.c_bool), ("density", C.c_float), ("droplet_diameter", C.c_float), ("height", C.c_float), ("dist", C.c_float)]
 
 
+class Ocean(C.Structure):
+    """LuminaryOcean (include/luminary_amd.h; defaults ocean.c:6-22)."""
+    _fields_ = [("active", C.c_bool), ("height", C.c_float), ("amplitude", C.c_float), ("frequency", C.c_float), ("refractive_index", C.c_float),
+                ("water_type", C.c_int), ("caustics_active", C.c_bool), ("caustics_ris_sample_count", C.c_uint32), ("caustics_domain_scale", C.c_float),
+                ("multiscattering", C.c_bool), ("triangle_light_contribution", C.c_bool)]
+
+
 class Particles(C.Structure):
     """LuminaryParticles (include/luminary_amd.h; defaults particles.c:6-24)."""
     _fields_ = [("active", C.c_bool), ("seed", C.c_uint32), ("count", C.c_uint32), ("albedo", RGBF), ("speed", C.c_float), ("direction_altitude", C.c_float),
@@ -147,7 +154,11 @@ class DeviceSceneView(C.Structure):
                 ("bridge_lut", C.c_void_p), ("bridge_max_num_vertices", C.c_uint32),
                 ("particles_active", C.c_uint32), ("particles_count", C.c_uint32), ("particles_scale", C.c_float), ("particles_speed", C.c_float),
                 ("particles_albedo", C.c_float * 3), ("particles_direction", C.c_float * 3), ("particles_phase", C.c_float * 4),
-                ("particle_vertices", C.c_void_p), ("particle_normals", C.c_void_p)]
+                ("particle_vertices", C.c_void_p), ("particle_normals", C.c_void_p),
+                ("ocean_active", C.c_uint32), ("ocean_height", C.c_float), ("ocean_amplitude", C.c_float), ("ocean_frequency", C.c_float),
+                ("ocean_refractive_index", C.c_float), ("ocean_scattering", C.c_float * 3), ("ocean_absorption", C.c_float * 3),
+                ("ocean_molecular_weight", C.c_float), ("ocean_caustics_active", C.c_uint32), ("ocean_caustics_ris_sample_count", C.c_uint32),
+                ("ocean_caustics_domain_scale", C.c_float), ("ocean_multiscattering", C.c_uint32), ("ocean_triangle_light_contribution", C.c_uint32)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -255,6 +266,12 @@ class Host:
 
     def set_fog(self, f):
         _call("luminary_host_set_fog", self._h, C.byref(f))
+
+    def get_ocean(self):
+        return self._get("ocean", Ocean)
+
+    def set_ocean(self, o):
+        _call("luminary_host_set_ocean", self._h, C.byref(o))
 
     def get_particles(self):
         return self._get("particles", Particles)

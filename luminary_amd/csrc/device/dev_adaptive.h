@@ -181,8 +181,8 @@ __global__ __launch_bounds__(256) void k_generate_adaptive(DeviceScene sc, Adapt
         const U2 rec = record_pack(splat(1.0f));
         q.origin_t[i] = make_float4(o.x, o.y, o.z, kFltMax);
         q.dir_slot[i] = make_float4(d.x, d.y, d.z, bitsf(slot));
-        q.aux[i]      = make_uint4(rec.x, rec.y, medium_ior_modify(0u, 1.0f, true), kStDeltaPath | kStCameraDirection | kStAllowEmission | kStAllowAmbient);
-        q.hit_id[i]   = make_uint4(0u, 0u, x | (y << 16), sample_id);
+        q.aux[i]      = make_uint4(rec.x, rec.y, initial_medium(sc, o), kStDeltaPath | kStCameraDirection | kStAllowEmission | kStAllowAmbient);
+        q.hit_id[i]   = make_uint4(0u, 0u, x | (y << 16), initial_volumes(sc, o, sample_id));
       }
     }
   }

@@ -114,6 +114,14 @@ struct DeviceScene {
   float fog_phase[4];        // Jendersie-Eon g_hg, g_d, alpha, w_d of the droplet diameter
   const float* bridge_lut;   // 64 x 21 floats
   uint32_t bridge_max_num_vertices;
+  // ocean (dev_ocean.h, dev_water.h): procedural height field at ocean_height, Jerlov water below it
+  uint32_t ocean_active;
+  float ocean_height, ocean_amplitude, ocean_frequency, ocean_refractive_index;
+  float ocean_scattering[3], ocean_absorption[3];
+  float ocean_molecular_weight;
+  uint32_t ocean_caustics_active, ocean_caustics_ris_sample_count;
+  float ocean_caustics_domain_scale;
+  uint32_t ocean_multiscattering, ocean_triangle_light_contribution;
   // particles (dev_particle.h): quads of the unit cell, tiled 25^3 times in a space scaled by particles_scale; their own two-level tree
   uint32_t particles_active, particles_count;
   float particles_scale, particles_speed;
@@ -141,6 +149,10 @@ struct NeeQueue {
   float4* bsdf_weight_sum;  // shade: bsdf weight rgb | light-tree root sum; after the light query: light colour rgb | valid flag
   uint4* ambient;           // packed colour (record format) xy | packed ray zw
   uint4* sun;               // same for the sun sample (written and read unless the sky is a constant colour)
+  // only with an active ocean (dev_water.h): what lies between the two visibility segments of a sun / ambient sample taken under water
+  float4* sun_water;        // 1 - Fresnel reflection at the surface | - | - | flags (uint bits: second segment, total reflection)
+  float4* amb_t1;           // transmittance of the vertex's volume up to the surface rgb | 1 - Fresnel reflection
+  float4* amb_t2;           // transmittance of the volume beyond the surface rgb | flags
 };
 
 // Visibility rays, compacted: every entry is one any-hit ray whose transparency goes to vis[out].
@@ -148,7 +160,7 @@ struct ShadowQueue {
   float4* origin_dist;  // origin.xyz | distance
   float4* dir_out;      // direction.xyz | output index (uint bits) = kind * capacity + path index
   uint4* ids;           // target instance, target triangle (the sampled light) | self instance, self triangle
-  float4* vis;          // [4 * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun
+  float4* vis;          // [kinds * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun; with an ocean 4 ambient's and 5 sun's second segment
   uint32_t* light_items;  // path indices that need a light-BVH query
   uint32_t capacity;
 };
@@ -156,12 +168,16 @@ struct ShadowQueue {
 // What the fog scatters into the rays of one depth (k_volume_inscatter -> visibility rays -> k_volume_resolve), indexed like the path queue.
 // The visibility rays of this pass use the ShadowQueue with 17 kinds per path: 0..14 the segments of the bridge to the sampled light, 15 the
 // sun, 16 the ambient sample.
-constexpr uint32_t kVolumeShadowKinds = 17, kVolumeKindSun = 15, kVolumeKindAmbient = 16;
+constexpr uint32_t kVolumeShadowKinds = 19, kVolumeKindSun = 15, kVolumeKindAmbient = 16, kVolumeKindSun2 = 17, kVolumeKindAmbient2 = 18;
+constexpr uint32_t kShadowKindAmbient2 = 4, kShadowKindSun2 = 5, kSurfaceShadowKindsWater = 6;
 struct VolumeQueue {
   float4* bridge;        // light colour rgb (already weighted) | number of segments (uint bits; 0 = no bridge)
   uint4* sky;            // sun colour (record format) xy | ambient colour zw; zero = no sample
-  float4* weight;        // weight of the vertex the sun and the ambient sample start from | fog transmittance along the ambient ray | unused
-  uint32_t* items;       // paths that scattered in the fog at this depth (k_volume_events), bounced by k_volume_bounce
+  float4* weight;        // weight rgb of the vertex the sun and the ambient sample start from
+  float4* sun_water;     // as in NeeQueue
+  float4* amb_t1;
+  float4* amb_t2;
+  uint32_t* items;       // paths that scattered in a volume at this depth (k_volume_events), bounced by k_volume_bounce
 };
 
 // One wavefront pass over `batch` consecutive sample ids of `num_pixels` pixels (k_generate).

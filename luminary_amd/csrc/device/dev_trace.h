@@ -503,7 +503,16 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
         const uint32_t rank = (uint32_t) __popcll(idle & below);
         if (cur == kTraversalDone && rank < avail) {
           idx = chunk_next + rank;
-          if (q.load(sc, idx, wo, wd, tmax)) { r.set(wo, wd); cur = 0; sp = 0; top = SE::make(kTraversalDone, 0.0f); inst = kNoInstance; rays++; }
+          if (q.load(sc, idx, wo, wd, tmax)) {
+            rays++;
+            // A ray with a non-finite origin or direction hits nothing (every comparison of the CPU oracle's slab test is false for it). Here
+            // the hardware's min/max drop NaN operands, which would make every child slot - the empty ones too - look entered.
+            const uint32_t e = 0x7F800000u;
+            const bool finite = (fbits(wo.x) & e) != e && (fbits(wo.y) & e) != e && (fbits(wo.z) & e) != e && (fbits(wd.x) & e) != e && (fbits(wd.y) & e) != e &&
+                                (fbits(wd.z) & e) != e;
+            if (finite) { r.set(wo, wd); cur = 0; sp = 0; top = SE::make(kTraversalDone, 0.0f); inst = kNoInstance; }
+            else q.finish(sc, idx);
+          }
         }
         chunk_next += min(want, avail);
       }

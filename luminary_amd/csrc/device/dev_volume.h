@@ -2,16 +2,28 @@
 // the phase-function bounce. Reference: cuda/volume_utils.cuh (descriptor, path through the disk-box, sampling, transmittance),
 // cuda/volume.cuh (the three kernels), cuda/light_bridges.cuh + light_common.cuh:17-32 (bridges), cuda/math.cuh:1169-1322 (phase functions),
 // cuda/bsdf.cuh:302-318,:404-421,:458-474, cuda/direct_lighting.cuh:20-121,:385-403,:521-584, optix/optix_kernel_shadow_volume.cu.
-// Only the fog exists here (no ocean): tasks_create pushes it on the medium's volume stack (kernels.cuh:177-179) and nothing pops it, so a
-// path is inside the fog iff sc.fog_active. Numerics contract as everywhere: expf := exp_det, logf := log2_det * ln 2,
-// cbrtf := exp2_det(log2_det / 3).
+// Two volume types: the fog (scalar scattering, no absorption, a disk-box around the camera) and the ocean's water (RGB Jerlov coefficients,
+// everything below the surface). A path carries the stack of the volumes it is in (medium_stack.cuh:29-45) in the upper bits of its sample-id
+// word: the fog from k_generate on, the water when the camera starts below the surface or the path refracts through it.
+// Numerics contract as everywhere: expf := exp_det, logf := log2_det * ln 2, cbrtf := exp2_det(log2_det / 3).
 #pragma once
 
-#include "dev_sky.h"
+#include "dev_ocean.h"
 
 LUM_NS_BEGIN
 
-constexpr uint32_t kHitInvalid = 0xFFFFFFFFu, kHitVolumeFog = 0xFFFE0001u, kHitTriangleLimit = 0x7FFFFFFFu;  // cuda/utils.cuh:51-63,:85 (VOLUME_TYPE_FOG = 1)
+constexpr uint32_t kHitInvalid = 0xFFFFFFFFu, kHitVolumeBase = 0xFFFE0000u, kHitVolumeMax = 0xFFFEFFFFu, kHitTriangleLimit = 0x7FFFFFFFu;  // cuda/utils.cuh:51-63, :84-85
+enum VolumeType : uint32_t { kVolumeNone = 0, kVolumeFog = 1, kVolumeOcean = 2 };  // utils.h:39
+LUM_DEV bool volume_is_hit(uint32_t instance_id) { return instance_id >= kHitVolumeBase && instance_id <= kHitVolumeMax; }
+// The path's volume stack: four 2-bit ids above the 20-bit sample id (hit_id.w), newest lowest (medium_stack_volume_peek / _modify with 16-bit ids).
+constexpr uint32_t kSampleIdMask = 0xFFFFFu;
+LUM_DEV uint32_t path_sample_id(uint32_t w) { return w & kSampleIdMask; }
+LUM_DEV uint32_t volume_stack_peek(uint32_t w, bool previous) { return (w >> (previous ? 22u : 20u)) & 3u; }
+LUM_DEV uint32_t volume_stack_modify(uint32_t w, uint32_t id, bool push) {
+  const uint32_t stack = (w >> 20) & 0xFFu;
+  const uint32_t next = push ? ((stack << 2) | id) & 0xFFu : stack >> 2;
+  return (w & kSampleIdMask) | (next << 20);
+}
 constexpr float kBridgesHgG = 0.85f, kBridgesForwardProb = 0.95f;                                              // light_common.cuh:21-22
 constexpr uint32_t kBridgesMaxVertexCount = 15, kBridgeLengthStride = 8;                                       // light_common.cuh:23, device_utils.h:51
 // random.cuh:24-66; the volume context draws from LIGHT_SUN<1>, LIGHT_GEO<1>, BSDF<0> (bounce) and BSDF<2> (ambient): material.cuh:76-81
@@ -25,17 +37,39 @@ LUM_DEV float log_det(float x) { return log2_det(x) * 0.693147181f; }
 LUM_DEV float cbrt_det(float x) { return (x == 0.0f) ? 0.0f : copysignf(exp2_det(log2_det(fabsf(x)) * 0.333333333f), x); }
 LUM_DEV float clampf(float x, float a, float b) { return fminf(b, fmaxf(a, x)); }
 
-// ---- descriptor (volume_utils.cuh:8-27): scalar scattering, no absorption ----
-struct Volume { float scattering, dist, max_height, min_height; };
-LUM_DEV Volume fog_volume(const DeviceScene& sc) { return Volume{0.001f * sc.fog_density, sc.fog_dist, sc.fog_height, -65535.0f}; }
+// ---- descriptors (volume_utils.cuh:8-57); `scattering` is the reference's max_scattering: what distances are sampled with ----
+struct Volume { float scattering, dist, max_height, min_height; Col scat, absorb; float max_absorption; uint32_t type; };
+LUM_DEV Volume volume_descriptor(const DeviceScene& sc, uint32_t type) {
+  Volume v{0.0f, 0.0f, 0.0f, 0.0f, splat(0.0f), splat(0.0f), 0.0f, type};
+  if (type == kVolumeFog) {
+    v.scattering = 0.001f * sc.fog_density;
+    v.scat = splat(v.scattering);
+    v.dist = sc.fog_dist; v.max_height = sc.fog_height;
+    v.min_height = sc.ocean_active ? ocean_max_height(sc) : -65535.0f;
+  }
+  else if (type == kVolumeOcean) {
+    v.absorb = col(sc.ocean_absorption[0], sc.ocean_absorption[1], sc.ocean_absorption[2]);
+    v.scat = col(sc.ocean_scattering[0], sc.ocean_scattering[1], sc.ocean_scattering[2]);
+    v.dist = 10000.0f; v.max_height = 65535.0f; v.min_height = -65535.0f;
+    v.max_absorption = importance(v.absorb);
+    v.scattering = importance(v.scat);
+  }
+  return v;
+}
+LUM_DEV Volume fog_volume(const DeviceScene& sc) { return volume_descriptor(sc, kVolumeFog); }
 
 struct VolumePath { float start, length; };  // start >= 0 iff the ray passes through the volume within the limit
-LUM_DEV VolumePath volume_compute_path(const DeviceScene& sc, const Volume& vol, V3 origin, V3 ray, float limit) {  // volume_utils.cuh:88-170
+LUM_DEV VolumePath volume_compute_path(const DeviceScene& sc, const Volume& vol, V3 origin, V3 ray, float limit, bool ocean_fast_path) {  // volume_utils.cuh:88-170
   const VolumePath none{-kFltMax, 0.0f};
   if (limit <= 0.0f) return none;
   if (vol.max_height <= vol.min_height) return none;
+  if (vol.type == kVolumeNone) return none;
   float start_y, end_y;
-  if (fabsf(ray.y) < 0.005f) {
+  if (vol.type == kVolumeOcean) {
+    start_y = 0.0f;
+    end_y = ocean_fast_path ? limit : ocean_intersection_distance(sc, origin, ray, limit);
+  }
+  else if (fabsf(ray.y) < 0.005f) {
     if (origin.y >= vol.min_height && origin.y <= vol.max_height) { start_y = 0.0f; end_y = vol.dist; }
     else return none;
   }
@@ -78,12 +112,15 @@ LUM_DEV float volume_sample_bounded_pdf(const Volume& v, float max_length, float
   const float prob_hit_at_max = 1.0f - exp_det(-v.scattering * max_length);
   return v.scattering * exp_det(-v.scattering * t) / prob_hit_at_max;
 }
-LUM_DEV float volume_transmittance_length(const Volume& v, float length) { return exp_det(-length * v.scattering); }  // volume_utils.cuh:245-254
-// volume_integrate_transmittance (volume_utils.cuh:292-308) of the volume a vertex is in; callers test sc.fog_active
-LUM_DEV float fog_transmittance(const DeviceScene& sc, V3 origin, V3 ray, float depth) {
-  const Volume v = fog_volume(sc);
-  const VolumePath p = volume_compute_path(sc, v, origin, ray, depth);
-  return (p.start >= 0.0f) ? exp_det(-p.length * v.scattering) : 1.0f;
+LUM_DEV Col volume_transmittance_length(const Volume& v, float length) {  // volume_utils.cuh:245-254
+  return col(exp_det(-length * (v.absorb.r + v.scat.r)), exp_det(-length * (v.absorb.g + v.scat.g)), exp_det(-length * (v.absorb.b + v.scat.b)));
+}
+// volume_integrate_transmittance (volume_utils.cuh:292-308) of the volume a vertex is in: 1 without one
+LUM_DEV Col volume_transmittance(const DeviceScene& sc, uint32_t type, V3 origin, V3 ray, float depth) {
+  if (type == kVolumeNone) return splat(1.0f);
+  const Volume v = volume_descriptor(sc, type);
+  const VolumePath p = volume_compute_path(sc, v, origin, ray, depth, false);
+  return (p.start >= 0.0f) ? volume_transmittance_length(v, p.length) : splat(1.0f);
 }
 
 // ---- phase functions (math.cuh:1169-1322) ----
@@ -130,25 +167,35 @@ LUM_DEV V3 je_phase_sample(const float* p, V3 ray, F2 r_dir, float r_choice) {  
 }
 LUM_DEV V3 fog_phase_sample(const DeviceScene& sc, V3 ray, F2 r_dir, float r_choice) { return je_phase_sample(sc.fog_phase, ray, r_dir, r_choice); }
 
+// the phase function is drawn from by volume type (bsdf.cuh:310-314; ocean_phase_sampling, ocean_utils.cuh:412-425)
+LUM_DEV V3 volume_phase_sample(const DeviceScene& sc, uint32_t type, V3 ray, F2 r_dir, float r_choice) {
+  if (type == kVolumeOcean) return phase_sample_basis(ocean_phase_sample_cos(sc, r_dir.x, r_choice), r_dir.y, ray);
+  return fog_phase_sample(sc, ray, r_dir, r_choice);
+}
+
 // ---- the volume's shading context (material.cuh:76-89, volume_utils.cuh:310-321) ----
 struct VolContext { Volume vol; V3 position, V; uint32_t state; float max_dist; };
 template <> struct TreeTargets<VolContext> { static constexpr uint32_t kPrepass = kRndVolTreePrepass, kPostpass = kRndVolTreePostpass; };
-LUM_DEV VolContext volume_context(const DeviceScene& sc, V3 origin, V3 ray, uint32_t state, float max_dist) {
-  return VolContext{fog_volume(sc), origin, ray * -1.0f, state, max_dist};
+LUM_DEV VolContext volume_context(const DeviceScene& sc, uint32_t type, V3 origin, V3 ray, uint32_t state, float max_dist) {
+  return VolContext{volume_descriptor(sc, type), origin, ray * -1.0f, state, max_dist};
 }
 // bsdf_sample<MATERIAL_VOLUME> (bsdf.cuh:302-318); the weight is 1
 LUM_DEV V3 volume_bsdf_sample(const DeviceScene& sc, const VolContext& c, const Sampler& smp, uint32_t rnd_resampling, uint32_t rnd_diffuse) {
   const float random_choice = smp.next1(rnd_resampling);
   const F2 random_dir = smp.next2(rnd_diffuse);
-  return fog_phase_sample(sc, c.V * -1.0f, random_dir, random_choice);
+  return volume_phase_sample(sc, c.vol.type, c.V * -1.0f, random_dir, random_choice);
 }
-LUM_DEV float volume_phase_evaluate(const DeviceScene& sc, const VolContext& c, V3 L) { return fog_phase_function(sc, -dot(c.V, L)); }  // volume_utils.cuh:216-243
+LUM_DEV float volume_phase_evaluate(const DeviceScene& sc, const VolContext& c, V3 L) {  // volume_utils.cuh:216-243
+  const float cos_angle = -dot(c.V, L);
+  return (c.vol.type == kVolumeOcean) ? ocean_phase(sc, cos_angle) : fog_phase_function(sc, cos_angle);
+}
 
 // volume_sample_sky_dl_initial_vertex (volume_utils.cuh:323-352): moves the context to a vertex on the ray, returns its weight
-LUM_DEV float volume_sky_initial_vertex(VolContext& c, const Sampler& smp) {
+LUM_DEV Col volume_sky_initial_vertex(VolContext& c, const Sampler& smp) {
   const float dist = volume_sample_bounded(c.vol, c.max_dist, smp.next1(kRndSunInitialVertex));
   c.position = c.position + c.V * -dist;
-  const float w = exp_det(-dist * c.vol.scattering) * c.vol.scattering;
+  const Col w = col(exp_det(-dist * (c.vol.absorb.r + c.vol.scat.r)) * c.vol.scat.r, exp_det(-dist * (c.vol.absorb.g + c.vol.scat.g)) * c.vol.scat.g,
+                    exp_det(-dist * (c.vol.absorb.b + c.vol.scat.b)) * c.vol.scat.b);
   return w * (1.0f / volume_sample_bounded_pdf(c.vol, c.max_dist, dist));
 }
 
@@ -160,7 +207,7 @@ LUM_DEV bool volume_sun_sample(const DeviceScene& sc, const SkyView& sky, const 
   if (sun_below_horizon || inside_earth) return false;
   const F2 random_dir = smp.next2(kRndVolSunBsdf);
   const float random_method = smp.next1(kRndVolSunBsdfMethod);
-  const V3 dir_bsdf = fog_phase_sample(sc, c.V * -1.0f, random_dir, random_method);
+  const V3 dir_bsdf = volume_phase_sample(sc, c.vol.type, c.V * -1.0f, random_dir, random_method);
   Col light_bsdf = splat(0.0f);
   if (sphere_hit(dir_bsdf, sky_pos, sky.sun_pos, kSkySunRadius)) light_bsdf = sky_sun_color(sky, sky_pos, dir_bsdf) * splat(volume_phase_evaluate(sc, c, dir_bsdf) * 1.0f);
   float solid_angle;
@@ -179,7 +226,7 @@ LUM_DEV bool volume_sun_sample(const DeviceScene& sc, const SkyView& sky, const 
   light = light * (sum_weights / target);
   if (target == 0.0f) return false;
   if (importance(light) == 0.0f) return false;
-  light_out = light * fog_transmittance(sc, c.position, dir_out, kFltMax);  // direct_lighting.cuh:104-108
+  light_out = light * volume_transmittance(sc, c.vol.type, c.position, dir_out, kFltMax);  // direct_lighting.cuh:104-108
   return true;
 }
 
@@ -248,8 +295,8 @@ LUM_DEV uint32_t bridges_sample_vertex_count(const DeviceScene& sc, const Volume
   pdf = (rv.sum_weight > 0.0f) ? rv.selected_target / rv.sum_weight : 1.0f;
   return 1 + selected;
 }
-// :142-222; the path weight's three channels are equal (grey scattering, no absorption)
-LUM_DEV float bridges_sample_bridge(const DeviceScene& sc, const VolContext& c, V3 light_point, V3 initial_vertex, uint32_t seed, const Sampler& smp, float& path_pdf, V3& end_vertex,
+// :142-222
+LUM_DEV Col bridges_sample_bridge(const DeviceScene& sc, const VolContext& c, V3 light_point, V3 initial_vertex, uint32_t seed, const Sampler& smp, float& path_pdf, V3& end_vertex,
                                     float& scale) {
   const V3 light_vector = light_point - initial_vertex;
   const float target_scale = length(light_vector);
@@ -269,17 +316,18 @@ LUM_DEV float bridges_sample_bridge(const DeviceScene& sc, const VolContext& c, 
     sum_dist += dist;
   }
   const float actual_scale = length(current_vertex - initial_vertex);
-  if (actual_scale == 0.0f) { path_pdf = 0.0f; return 0.0f; }
+  if (actual_scale == 0.0f) { path_pdf = 0.0f; return splat(0.0f); }
   scale = target_scale / actual_scale;
   sum_dist *= scale;
   end_vertex = current_vertex;
-  const float s = c.vol.scattering;
-  const float w = exp_det(vertex_count * log_det(s) - sum_dist * (s + 0.0f));
+  const Col s = c.vol.scat, a = c.vol.absorb;
+  const Col w = col(exp_det(vertex_count * log_det(s.r) - sum_dist * (s.r + a.r)), exp_det(vertex_count * log_det(s.g) - sum_dist * (s.g + a.g)),
+                    exp_det(vertex_count * log_det(s.b) - sum_dist * (s.b + a.b)));
   const float log_path_pdf = bridges_log_factorial(vertex_count) - vertex_count * log_det(sum_dist);
   path_pdf = vertex_count_pdf * exp_det(log_path_pdf) * target_scale * target_scale * target_scale;
   return w;
 }
-LUM_DEV V3 bridges_sample_initial_vertex(const VolContext& c, V3 point_on_light, const Sampler& smp, uint32_t output_id, float& attenuation, float& pdf) {  // :224-266
+LUM_DEV V3 bridges_sample_initial_vertex(const VolContext& c, V3 point_on_light, const Sampler& smp, uint32_t output_id, Col& attenuation, float& pdf) {  // :224-266
   float random_intersection = smp.next1(kRndGeoInitialVertex + output_id);
   const V3 PO = point_on_light - c.position;
   const float dist_to_light = fmaxf(-dot(PO, c.V), 0.0f);
@@ -298,7 +346,8 @@ LUM_DEV V3 bridges_sample_initial_vertex(const VolContext& c, V3 point_on_light,
     pdf = 1.0f - forward_prob;
   }
   const float t = t_offset + volume_sample_bounded(c.vol, max_dist, random_intersection);
-  attenuation = exp_det(-t * c.vol.scattering) * c.vol.scattering;
+  attenuation = col(exp_det(-t * (c.vol.absorb.r + c.vol.scat.r)) * c.vol.scat.r, exp_det(-t * (c.vol.absorb.g + c.vol.scat.g)) * c.vol.scat.g,
+                    exp_det(-t * (c.vol.absorb.b + c.vol.scat.b)) * c.vol.scat.b);
   pdf *= volume_sample_bounded_pdf(c.vol, max_dist, t - t_offset);
   return c.position + c.V * -t;
 }
@@ -326,9 +375,9 @@ LUM_DEV BridgeSample bridges_sample(const DeviceScene& sc, const VolContext& c, 
   BridgeSample res{kLightIdInvalid, splat(0.0f), 0u, Quat{0.0f, 0.0f, 0.0f, 1.0f}, 0.0f};
   target = 0.0f; weight = 1.0f;
   const V3 point_on_light = tri_light_sample_bridges(light, smp.next2(kRndBridgeLightPoint + output_id));
-  float initial_attenuation, initial_pdf;
+  Col initial_attenuation; float initial_pdf;
   const V3 initial_vertex = bridges_sample_initial_vertex(c, point_on_light, smp, output_id, initial_attenuation, initial_pdf);
-  if (initial_pdf == 0.0f || initial_attenuation == 0.0f) return res;
+  if (initial_pdf == 0.0f || importance(initial_attenuation) == 0.0f) return res;
   V3 light_dir; float area, light_dist; F2 uv;
   tri_light_finalize_bridges(light, initial_vertex, point_on_light, light_dir, light_dist, area, uv);
   if (light_dist == kFltMax || area < kEps) return res;
@@ -338,14 +387,14 @@ LUM_DEV BridgeSample bridges_sample(const DeviceScene& sc, const VolContext& c, 
   if (light_point.y < c.vol.min_height || light_point.y > c.vol.max_height) return res;
   float sample_weight = area / initial_pdf;
   float path_pdf, path_scale; V3 path_end;
-  const float path_w = bridges_sample_bridge(sc, c, light_point, initial_vertex, output_id, smp, path_pdf, path_end, path_scale);
+  const Col path_w = bridges_sample_bridge(sc, c, light_point, initial_vertex, output_id, smp, path_pdf, path_end, path_scale);
   if (path_pdf == 0.0f) return res;
   sample_weight *= 1.0f / path_pdf;
   const Quat rot = bridges_compute_rotation(initial_vertex, light_point, path_end);
   const V3 rotated = qapply(rot, light_dir);
   const float cos_angle = -dot(rotated, c.V);
   light_color = light_color * hg_phase(cos_angle, kBridgesHgG);
-  const Col path_weight = splat(path_w) * light_color;
+  const Col path_weight = path_w * light_color;
   target = importance(path_weight); weight = sample_weight;
   return BridgeSample{light_id, path_weight, output_id, rot, path_scale};
 }
@@ -360,7 +409,7 @@ LUM_DEV float tree_importance(const VolContext& c, float power, V3 mean, float s
   const float falloff = 1.0f / (perp_sq + std_dev);
   const float variance = std_dev * std_dev;
   const float transmittance_depth = fmaxf(perp_sq + clamped * clamped - variance, 0.0f);
-  const float transmittance = exp_det(-0.0f * transmittance_depth);
+  const float transmittance = exp_det(-c.vol.max_absorption * transmittance_depth);
   const float scattering = 1.0f - exp_det(-c.vol.scattering * (variance + clamped));
   return power * falloff * transmittance * scattering;
 }
@@ -401,7 +450,7 @@ LUM_DEV BridgeWalk bridge_walk_begin(const DeviceScene& sc, const VolContext& c,
   w.light = sc.light_tri_handles[task.light_id];
   const TriLight light = load_tri_light(sc, w.light.x, w.light.y);
   const V3 point_on_light = tri_light_sample_bridges(light, smp.next2(kRndBridgeLightPoint + w.seed));
-  float att, ipdf;
+  Col att; float ipdf;
   const V3 initial_vertex = bridges_sample_initial_vertex(c, point_on_light, smp, w.seed, att, ipdf);
   V3 light_dir; float area, light_dist; F2 uv;
   tri_light_finalize_bridges(light, initial_vertex, point_on_light, light_dir, light_dist, area, uv);

@@ -17,6 +17,7 @@
 #include "dev_sky.h"
 #include "dev_volume.h"
 #include "dev_particle.h"
+#include "dev_water.h"
 
 LUM_NS_BEGIN
 
@@ -91,6 +92,18 @@ LUM_DEV void camera_ray(const DeviceScene& sc, const Sampler& smp, V3& origin, V
   ray = qapply(q, normalize(focal_point - aperture));
 }
 
+// kernels.cuh:146, :172-186: the medium the camera is in (bsdf_refraction_index_ambient, bsdf_utils.cuh:128-133) and the volumes around it, in the
+// upper bits of the sample-id word (dev_volume.h)
+LUM_DEV uint32_t initial_medium(const DeviceScene& sc, V3 origin) {
+  return medium_ior_modify(0u, (sc.ocean_active && origin.y < sc.ocean_height) ? sc.ocean_refractive_index : 1.0f, true);
+}
+LUM_DEV uint32_t initial_volumes(const DeviceScene& sc, V3 origin, uint32_t sample_id) {
+  uint32_t w = sample_id;
+  if (sc.fog_active) w = volume_stack_modify(w, kVolumeFog, true);
+  if (sc.ocean_active && ocean_is_underwater(sc, origin)) w = volume_stack_modify(w, kVolumeOcean, true);
+  return w;
+}
+
 __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams pp, PathQueue q, float4* results, uint32_t* count) {
   const uint32_t total = pp.num_pixels * pp.batch;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < total; i += gridDim.x * kBlock) {
@@ -103,8 +116,8 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams 
     const U2 rec = record_pack(splat(1.0f));
     q.origin_t[i] = make_float4(o.x, o.y, o.z, kFltMax);
     q.dir_slot[i] = make_float4(d.x, d.y, d.z, bitsf(i));
-    q.aux[i]      = make_uint4(rec.x, rec.y, medium_ior_modify(0u, 1.0f, true), kStDeltaPath | kStCameraDirection | kStAllowEmission | kStAllowAmbient);
-    q.hit_id[i]   = make_uint4(0u, 0u, x | (y << 16), pp.first_sample + b);
+    q.aux[i]      = make_uint4(rec.x, rec.y, initial_medium(sc, o), kStDeltaPath | kStCameraDirection | kStAllowEmission | kStAllowAmbient);
+    q.hit_id[i]   = make_uint4(0u, 0u, x | (y << 16), initial_volumes(sc, o, pp.first_sample + b));
     results[i]    = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) *count = total;
@@ -231,8 +244,10 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 // (direct_lighting.cuh:257-283, sky.cuh:534-606): what a path that left the scene adds (DEFAULT: ray-marched by k_sky; HDRI: panorama
 // texel + sun disk; CONSTANT: the colour), whether the bounce direction is an ambient sample (not DEFAULT), and whether the sun is
 // sampled (not CONSTANT).
-template <uint32_t kSkyMode>
-__global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
+// kWater (the scene has an ocean): a path's volume is read from its stack, a vertex under water takes the sun through the surface and its sun and
+// ambient samples get a second visibility segment beyond it (dev_water.h); without an ocean none of that code exists in the kernel.
+template <uint32_t kSkyMode, bool kWater>
+__global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
@@ -292,6 +307,8 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
     bool survive = false, want_geo = false, want_amb = false, want_sun = false, want_lq = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
+    bool want_amb2 = false, want_sun2 = false;  // kWater: second segments beyond the water surface
+    float4 s_amb2_o, s_amb2_d, s_sun2_o, s_sun2_d;
     if (valid) {
       const float4 o4 = ld_stream(&in.origin_t[i]), d4 = ld_stream(&in.dir_slot[i]);
       const uint4 aux = ld_stream(&in.aux[i]), hid = ld_stream(&in.hit_id[i]);
@@ -301,8 +318,11 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
         vertices++;
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
-        const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+        const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
         const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i], aux.z);
+        // the volume the vertex is in: without an ocean the stack holds the fog or nothing for the whole path
+        const uint32_t top_volume = kWater ? volume_stack_peek(hid.w, false) : (sc.fog_active ? (uint32_t) kVolumeFog : (uint32_t) kVolumeNone);
+        const uint32_t second_volume = kWater ? volume_stack_peek(hid.w, true) : (uint32_t) kVolumeNone;
 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
           else ls = sample_light(sc, g, smp);
-          if (sc.fog_active) ls.color = ls.color * fog_transmittance(sc, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
+          if (top_volume != kVolumeNone) ls.color = ls.color * volume_transmittance(sc, top_volume, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
           if (ls.light_id != kLightIdInvalid) {
             want_geo = true;
@@ -344,22 +364,54 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
           const U2 c = record_pack(ambient * bounce.weight), r = ray_pack(bounce.ray);
           amb = make_uint4(c.x, c.y, r.x, r.y);
           if (c.x != 0 || c.y != 0) {
-            want_amb = true;
             const V3 ar = ray_unpack(r);
-            s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+            if (kWater) {
+              const SkyRayPlan plan = plan_ambient_ray(sc, hit_origin, hid.x, top_volume, second_volume, true, ar);
+              if (!plan.valid) amb = make_uint4(0u, 0u, r.x, r.y);
+              else {
+                want_amb = true;
+                s_amb_dir = make_float4(ar.x, ar.y, ar.z, plan.limit);
+                nee.amb_t1[i] = make_float4(plan.t1.r, plan.t1.g, plan.t1.b, plan.fresnel_factor);
+                nee.amb_t2[i] = make_float4(plan.t2.r, plan.t2.g, plan.t2.b, bitsf(sky_ray_flags(plan)));
+                if (plan.second && !plan.total_reflection) {
+                  want_amb2 = true;
+                  s_amb2_o = make_float4(plan.second_origin.x, plan.second_origin.y, plan.second_origin.z, kFltMax);
+                  s_amb2_d = make_float4(plan.second_dir.x, plan.second_dir.y, plan.second_dir.z, 0.0f);
+                }
+              }
+            }
+            else {
+              want_amb = true;
+              s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+            }
           }
         }
         if (kSkyMode != kSkyConstantColor) {  // the sun: its own record and the fourth kind of visibility ray
           uint4 sun = make_uint4(0u, 0u, 0u, 0u);
           Col sun_light; V3 sun_dir;
-          if (sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir)) {
-            if (sc.fog_active) sun_light = sun_light * fog_transmittance(sc, g.position, sun_dir, kFltMax);  // direct_lighting.cuh:104-108
+          bool have_sun;
+          if (kWater && top_volume == kVolumeOcean) have_sun = sun_caustic_sample(sc, sky_view(sc), g, smp, 0u, top_volume, second_volume, sun_light, sun_dir);  // direct_lighting.cuh:368-380
+          else {
+            have_sun = sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir);
+            if (have_sun && top_volume != kVolumeNone) sun_light = sun_light * volume_transmittance(sc, top_volume, g.position, sun_dir, kFltMax);  // direct_lighting.cuh:104-108
+          }
+          if (have_sun) {
             const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
             sun = make_uint4(c.x, c.y, r.x, r.y);
             if (c.x != 0 || c.y != 0) {
               want_sun = true;
               const V3 ar = ray_unpack(r);
               s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+              if (kWater) {
+                const SkyRayPlan plan = plan_sun_ray(sc, hit_origin, hid.x, top_volume, true, ar);
+                s_sun_dir.w = plan.limit;
+                nee.sun_water[i] = make_float4(plan.fresnel_factor, 0.0f, 0.0f, bitsf(sky_ray_flags(plan)));
+                if (plan.second && !plan.total_reflection) {
+                  want_sun2 = true;
+                  s_sun2_o = make_float4(plan.second_origin.x, plan.second_origin.y, plan.second_origin.z, kFltMax);
+                  s_sun2_d = make_float4(plan.second_dir.x, plan.second_dir.y, plan.second_dir.z, 0.0f);
+                }
+              }
             }
           }
           st_stream(&nee.sun[i], sun);
@@ -452,6 +504,27 @@ __global__ __launch_bounds__(kBlock, kSkyMode == kSkyConstantColor ? LUM_SHADE_W
         st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
       }
     }
+    if (kWater) {
+      const unsigned long long b2a = __ballot(want_amb2), b2s = __ballot(want_sun2);
+      if (b2a | b2s) {
+        const uint32_t na2 = (uint32_t) __popcll(b2a);
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, na2 + (uint32_t) __popcll(b2s));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (want_amb2) {
+          const uint32_t j = base + (uint32_t) __popcll(b2a & below);
+          sq.origin_dist[j] = s_amb2_o;
+          sq.dir_out[j] = make_float4(s_amb2_d.x, s_amb2_d.y, s_amb2_d.z, bitsf(kShadowKindAmbient2 * sq.capacity + i));
+          sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        }
+        if (want_sun2) {
+          const uint32_t j = base + na2 + (uint32_t) __popcll(b2s & below);
+          sq.origin_dist[j] = s_sun2_o;
+          sq.dir_out[j] = make_float4(s_sun2_d.x, s_sun2_d.y, s_sun2_d.z, bitsf(kShadowKindSun2 * sq.capacity + i));
+          sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+        }
+      }
+    }
     const unsigned long long bl = __ballot(want_lq);
     if (bl) {
       uint32_t base = 0;
@@ -479,7 +552,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueu
         if (sc.sky_mode == kSkyDefault) {
           if (sc.sky_lut_transmittance && sc.sky_lut_multiscattering) {
             const SkyView sky = sky_view(sc);
-            const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, 0u};
+            const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), 0u};
             result = sky_get_color(sc, sky, world_to_sky(sky, origin), ray, kFltMax, true, (int) sky.steps, smp.next1(kRndSkyStepOffset));
           }
         }
@@ -487,6 +560,14 @@ __global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueu
         else result = col(sc.sky_constant_color[0], sc.sky_constant_color[1], sc.sky_constant_color[2]);
       }
       else if (sc.shading_mode == 4u) result = col(0.0f, 0.63f, 1.0f);  // IDENTIFICATION
+    }
+    else if (hid.x == kHitOcean) {  // ocean_process_tasks_debug, ocean.cuh:104-145
+      if (sc.shading_mode == 2u) result = splat(saturate((1.0f / o4.w) * 2.0f));
+      else if (sc.shading_mode == 3u) {
+        const V3 nrm = ocean_get_normal(sc, origin + ray * o4.w);
+        result = col(saturate(0.5f * nrm.x + 0.5f), saturate(0.5f * nrm.y + 0.5f), saturate(0.5f * nrm.z + 0.5f));
+      }
+      else if (sc.shading_mode == 4u) result = col(0.0f, 0.0f, 1.0f);
     }
     else if (particle_is_hit(hid.x)) {  // particle_process_tasks_debug, particle.cuh:110-163
       if (sc.shading_mode == 1u) result = particles_albedo(sc);
@@ -526,7 +607,7 @@ __global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, Sh
     const uint32_t i = sq.light_items[sq.capacity - 1u - k];
     const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
     const uint4 aux = in.aux[i], hid = in.hit_id[i];
-    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
     const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z));
     const bool include_sun = (aux.w & (kStCameraDirection | kStAllowEmission)) != 0;
     const Col c = sky_get_color(sc, sky, sky_origin, v3(d4.x, d4.y, d4.z), kFltMax, include_sun, (int) sky.steps, smp.next1(kRndSkyStepOffset));
@@ -543,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void k_sky_inscattering(DeviceScene sc, Pat
     if (hid.x == kHitSky) continue;
     const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
     uint4 aux = in.aux[i];
-    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
     Col record = record_unpack(U2{aux.x, aux.y});
     const Col c = sky_trace_inscattering(sc, sky, world_to_sky(sky, v3(o4.x, o4.y, o4.z)), v3(d4.x, d4.y, d4.z), o4.w * 0.001f, record, depth_const == 0u,
                                          smp.next1(kRndSkyInscatteringStep), smp.next1(kRndSkyStepOffset));
@@ -574,7 +655,7 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
       const V3 hit_origin = v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w;
       const float4 rp = nee.bsdf_ray_prob[i], ws = nee.bsdf_weight_sum[i];
       const V3 ray = v3(rp.x, rp.y, rp.z);
-      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
       uint32_t num_hits = 0;
       const uint32_t light_id = light_query(sc, hit_origin, ray, hid.x, hid.y, smp.next1(kRndLightBsdfTrace), num_hits, st);
       light_queries++;
@@ -595,10 +676,11 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
         }
         else valid = false;
       }
-      // .w: 0 = no visibility ray; otherwise the fog's transmittance up to the light (direct_lighting.cuh:661-666), 1 without fog
-      float seen = valid ? 1.0f : 0.0f;
-      if (valid && sc.fog_active) seen = fog_transmittance(sc, hit_origin, ray, dist);
-      nee.bsdf_weight_sum[i] = make_float4(lc.r, lc.g, lc.b, seen);
+      nee.bsdf_weight_sum[i] = make_float4(lc.r, lc.g, lc.b, valid ? 1.0f : 0.0f);
+      if (valid && (sc.fog_active || sc.ocean_active)) {  // the volume's transmittance up to the light (direct_lighting.cuh:661-666) replaces the direction, which is used up
+        const Col seen = volume_transmittance(sc, sc.ocean_active ? volume_stack_peek(hid.w, false) : (uint32_t) kVolumeFog, hit_origin, ray, dist);
+        nee.bsdf_ray_prob[i] = make_float4(seen.r, seen.g, seen.b, 0.0f);
+      }
       if (valid) {
         want = true;
         s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, dist);
@@ -662,7 +744,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
-    if (hid.x > kHitTriangleLimit && !particle_is_hit(hid.x)) continue;  // sky, and with fog: scattering events and ended paths
+    if (hid.x > kHitTriangleLimit && !particle_is_hit(hid.x) && hid.x != kHitOcean) continue;  // sky, and with volumes: scattering events and ended paths
     const uint4 aux = in.aux[i];
     const uint32_t slot = fbits(in.dir_slot[i].w);
     const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
@@ -678,23 +760,37 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
       Col vis = splat(0.0f);
       if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
       Col seen = col(lc.x, lc.y, lc.z) * vis;
-      if (sc.fog_active) seen = seen * lc.w;
+      if (lc.w != 0.0f && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
       acc = acc + seen;
     }
     if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
       const uint4 sun = nee.sun[i];
       Col vis = splat(0.0f);
       if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
-      acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
+      if (sc.ocean_active && (sun.x != 0 || sun.y != 0)) {
+        const float4 w = nee.sun_water[i];
+        Col vis2 = splat(1.0f);
+        if ((fbits(w.w) & kSkyRaySecond) && !(fbits(w.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindSun2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+        acc = acc + combine_sun_ray(record_unpack(U2{sun.x, sun.y}), vis, w.x, fbits(w.w), vis2);
+      }
+      else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
     }
     {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
       const uint4 amb = ld_stream(&nee.ambient[i]);
       Col vis = splat(0.0f);
       if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
       Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
-      if (sc.fog_active) {  // direct_lighting.cuh:561-563
+      if (sc.ocean_active) {
+        if (amb.x != 0 || amb.y != 0) {
+          const float4 t1 = nee.amb_t1[i], t2 = nee.amb_t2[i];
+          Col vis2 = splat(1.0f);
+          if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindAmbient2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+          seen = combine_ambient_ray(record_unpack(U2{amb.x, amb.y}), vis, col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2);
+        }
+      }
+      else if (sc.fog_active) {  // direct_lighting.cuh:561-563
         const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
-        seen = seen * fog_transmittance(sc, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
+        seen = seen * volume_transmittance(sc, kVolumeFog, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
       }
       acc = acc + seen;
     }
@@ -722,7 +818,7 @@ struct ParticleQuery {
     if ((aux.w & kStDeltaPath) == 0) return false;  // particles are invisible to non-delta paths (negligible contribution)
     const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
     const uint4 hid = q.hit_id[i];
-    const Sampler smp{bluenoise, hid.z & 0xFFFFu, hid.z >> 16, hid.w, 0u};  // random_1D_consistent: depth 0
+    const Sampler smp{bluenoise, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), 0u};  // random_1D_consistent: depth 0
     const float time = smp.next1(kRndCameraTime);
     const V3 motion_offset = direction * (time * particles_speed);
     d = v3(d4.x, d4.y, d4.z) * (1.0f / particles_scale);
@@ -785,23 +881,25 @@ __global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQ
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
   for (uint32_t round = 0; round < rounds; round++) {
     const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
-    bool survive = false, want_geo = false, want_amb = false, want_sun = false;
+    bool survive = false, want_geo = false, want_amb = false, want_sun = false, want_amb2 = false, want_sun2 = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
+    float4 s_amb2_o, s_amb2_d, s_sun2_o, s_sun2_d;
     if (i < n && particle_is_hit(in.hit_id[i].x)) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
       const uint32_t state = aux.w;
       const V3 ray = v3(d4.x, d4.y, d4.z);
       const V3 position = v3(o4.x, o4.y, o4.z) + ray * o4.w;
-      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
       const ParticleContext pc = particle_context(sc, position, ray, state, hid.x);
+      const uint32_t top_volume = volume_stack_peek(hid.w, false), second_volume = volume_stack_peek(hid.w, true);
       s_origin = make_float4(position.x, position.y, position.z, 0.0f);
       s_geo_ids = make_uint4(0xFFFFFFFFu, 0u, hid.x, 0u);
       float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
       if (lights_present && (state & kStVolumeScattered) == 0) {
         LightSample ls = particle_light_sample(sc, pc, smp);
-        if (sc.fog_active) ls.color = ls.color * fog_transmittance(sc, position, ls.ray, ls.dist);
+        if (top_volume != kVolumeNone) ls.color = ls.color * volume_transmittance(sc, top_volume, position, ls.ray, ls.dist);
         geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
         if (ls.light_id != kLightIdInvalid) {
           want_geo = true;
@@ -813,10 +911,26 @@ __global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQ
       uint4 sun = make_uint4(0u, 0u, 0u, 0u);
       if (sun_allowed) {
         Col sun_light; V3 sun_dir;
-        if (particle_sun_sample(sc, sky_view(sc), pc, smp, sun_light, sun_dir)) {
+        const bool have_sun = (top_volume == kVolumeOcean) ? sun_caustic_sample(sc, sky_view(sc), pc, smp, 0u, top_volume, second_volume, sun_light, sun_dir)
+                                                            : particle_sun_sample(sc, sky_view(sc), pc, top_volume, smp, sun_light, sun_dir);
+        if (have_sun) {
           const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
           sun = make_uint4(c.x, c.y, r.x, r.y);
-          if (c.x != 0 || c.y != 0) { want_sun = true; const V3 ar = ray_unpack(r); s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax); }
+          if (c.x != 0 || c.y != 0) {
+            want_sun = true;
+            const V3 ar = ray_unpack(r);
+            s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+            if (sc.ocean_active) {
+              const SkyRayPlan plan = plan_sun_ray(sc, position, hid.x, top_volume, true, ar);
+              s_sun_dir.w = plan.limit;
+              nee.sun_water[i] = make_float4(plan.fresnel_factor, 0.0f, 0.0f, bitsf(sky_ray_flags(plan)));
+              if (plan.second && !plan.total_reflection) {
+                want_sun2 = true;
+                s_sun2_o = make_float4(plan.second_origin.x, plan.second_origin.y, plan.second_origin.z, kFltMax);
+                s_sun2_d = make_float4(plan.second_dir.x, plan.second_dir.y, plan.second_dir.z, 0.0f);
+              }
+            }
+          }
         }
       }
       // bsdf_sample<MATERIAL_PARTICLE> with RANDOM_GI (bsdf.cuh:320-331): weight = albedo
@@ -827,7 +941,25 @@ __global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQ
       if (sc.sky_mode != kSkyDefault) {
         const U2 c = record_pack(sky_color_no_compute(sc, position, bounce, 0u) * albedo), r = ray_pack(bounce);
         amb = make_uint4(c.x, c.y, r.x, r.y);
-        if (c.x != 0 || c.y != 0) { want_amb = true; const V3 ar = ray_unpack(r); s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax); }
+        if (c.x != 0 || c.y != 0) {
+          const V3 ar = ray_unpack(r);
+          if (sc.ocean_active) {
+            const SkyRayPlan plan = plan_ambient_ray(sc, position, hid.x, top_volume, second_volume, true, ar);
+            if (!plan.valid) amb = make_uint4(0u, 0u, r.x, r.y);
+            else {
+              want_amb = true;
+              s_amb_dir = make_float4(ar.x, ar.y, ar.z, plan.limit);
+              nee.amb_t1[i] = make_float4(plan.t1.r, plan.t1.g, plan.t1.b, plan.fresnel_factor);
+              nee.amb_t2[i] = make_float4(plan.t2.r, plan.t2.g, plan.t2.b, bitsf(sky_ray_flags(plan)));
+              if (plan.second && !plan.total_reflection) {
+                want_amb2 = true;
+                s_amb2_o = make_float4(plan.second_origin.x, plan.second_origin.y, plan.second_origin.z, kFltMax);
+                s_amb2_d = make_float4(plan.second_dir.x, plan.second_dir.y, plan.second_dir.z, 0.0f);
+              }
+            }
+          }
+          else { want_amb = true; s_amb_dir = make_float4(ar.x, ar.y, ar.z, kFltMax); }
+        }
       }
       nee.geo_color_light[i] = geo_cl;
       nee.bsdf_ray_prob[i] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
@@ -889,6 +1021,153 @@ __global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQ
         sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w);
       }
     }
+    const unsigned long long b2a = __ballot(want_amb2), b2s = __ballot(want_sun2);
+    if (b2a | b2s) {  // second segments beyond the water surface
+      const uint32_t na2 = (uint32_t) __popcll(b2a);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, na2 + (uint32_t) __popcll(b2s));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_amb2) {
+        const uint32_t j = base + (uint32_t) __popcll(b2a & below);
+        sq.origin_dist[j] = s_amb2_o;
+        sq.dir_out[j] = make_float4(s_amb2_d.x, s_amb2_d.y, s_amb2_d.z, bitsf(kShadowKindAmbient2 * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+      if (want_sun2) {
+        const uint32_t j = base + na2 + (uint32_t) __popcll(b2s & below);
+        sq.origin_dist[j] = s_sun2_o;
+        sq.dir_out[j] = make_float4(s_sun2_d.x, s_sun2_d.y, s_sun2_d.z, bitsf(kShadowKindSun2 * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+    }
+  }
+}
+
+// ---- ocean ----
+// optix_raytrace_ocean (optix_kernel_raytrace.cu:134-144): after the surfaces and the particles, every path is marched against the height field up
+// to its current hit; a closer water surface replaces the hit.
+__global__ __launch_bounds__(kBlock) void k_trace_ocean(DeviceScene sc, PathQueue q, const uint32_t* ctrl) {
+  const uint32_t n = ctrl[kCtlPaths];
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
+    const float depth = ocean_intersection_distance(sc, v3(o4.x, o4.y, o4.z), v3(d4.x, d4.y, d4.z), o4.w);
+    if (depth < o4.w) {
+      q.origin_t[i].w = depth;
+      uint4 hid = q.hit_id[i];
+      hid.x = kHitOcean; hid.y = 0u;
+      q.hit_id[i] = hid;
+    }
+  }
+}
+
+// ocean_process_tasks (ocean.cuh:12-102): the water surface is a smooth dielectric; BSDF-sampled light and the sun, no sampled light and no
+// ambient sample. A refracted path enters or leaves the water: its medium and volume stacks change. Records go where a surface vertex puts them.
+__global__ __launch_bounds__(kBlock) void k_ocean_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    bool survive = false, want_sun = false, want_lq = false;
+    float4 n_o, n_d; uint4 n_aux, n_hid;
+    float4 s_origin, s_sun_dir;
+    if (i < n && in.hit_id[i].x == kHitOcean) {
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const uint4 aux = in.aux[i], hid = in.hit_id[i];
+      const uint32_t state = aux.w;
+      const V3 ray = v3(d4.x, d4.y, d4.z);
+      const V3 position = v3(o4.x, o4.y, o4.z) + ray * o4.w;
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+      const GeoContext g = ocean_context(sc, position, ray, state, aux.z);
+      const uint32_t top_volume = volume_stack_peek(hid.w, false);
+      const LocalFrame lf = local_frame(sc, g);
+      s_origin = make_float4(position.x, position.y, position.z, 0.0f);
+      float4 bs_rp = make_float4(0.0f, 0.0f, 1.0f, 0.0f), bs_ws = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      if (lights_present && (state & kStVolumeScattered) == 0) {
+        const LightDirSample lb = sample_light_direction(lf, g, smp);
+        bs_rp = make_float4(lb.ray.x, lb.ray.y, lb.ray.z, lb.probability);
+        if (lb.probability != 0.0f) { want_lq = true; bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, 0.0f); }
+      }
+      uint4 sun = make_uint4(0u, 0u, 0u, 0u);
+      if (sun_allowed) {
+        Col sun_light; V3 sun_dir;
+        if (sample_sun(sc, sky_view(sc), lf, g, smp, sun_light, sun_dir)) {
+          sun_light = sun_light * volume_transmittance(sc, top_volume, g.position, sun_dir, kFltMax);
+          const U2 c = record_pack(sun_light), r = ray_pack(sun_dir);
+          sun = make_uint4(c.x, c.y, r.x, r.y);
+          if (c.x != 0 || c.y != 0) {
+            want_sun = true;
+            const V3 ar = ray_unpack(r);
+            s_sun_dir = make_float4(ar.x, ar.y, ar.z, kFltMax);
+            nee.sun_water[i] = make_float4(1.0f, 0.0f, 0.0f, bitsf(0u));  // the surface's own sun sample is never a caustics path
+          }
+        }
+      }
+      const BounceSample bounce = sample_bounce(lf, g, smp, 0);
+      nee.geo_color_light[i] = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
+      nee.bsdf_ray_prob[i] = bs_rp; nee.bsdf_weight_sum[i] = bs_ws;
+      nee.ambient[i] = make_uint4(0u, 0u, 0u, 0u);
+      if (sc.sky_mode != kSkyConstantColor) nee.sun[i] = sun;
+      Col record = record_unpack(U2{aux.x, aux.y}) * bounce.weight;
+      const float shift_length = 8.0f * kEps * (1.0f + sc.ocean_amplitude) * (1.0f + fabsf(sc.ocean_height));  // ocean_shift_vector, ocean_utils.cuh:519-523
+      const V3 bounce_pos = g.position + g.normal * (bounce.transparent_pass ? -shift_length : shift_length);
+      const uint32_t new_state = state & ~(kStCameraDirection | kStAllowEmission | kStUseIgnoreHandle);
+      survive = true;
+      if ((state & kStDeltaPath) == 0) {  // directives.cuh:11-32
+        const float value = importance(record);
+        if (value < sc.cam_rr_threshold) {
+          const float p = (value > 0.0f) ? fmaxf(value / sc.cam_rr_threshold, 1.0f / 8.0f) : 0.0f;
+          if (smp.next1(kRndRussianRoulette) > p) survive = false;
+          else record = record * (1.0f / p);
+        }
+      }
+      if (survive) {
+        uint32_t medium = aux.z, volumes = hid.w;
+        if (bounce.transparent_pass) {
+          const bool inside = (g.params.flags & kMatRefractionInside) != 0;
+          medium = medium_ior_modify(medium, sc.ocean_refractive_index, !inside);
+          volumes = volume_stack_modify(volumes, kVolumeOcean, !inside);
+        }
+        const U2 rp = record_pack(record);
+        n_o = make_float4(bounce_pos.x, bounce_pos.y, bounce_pos.z, kFltMax);
+        n_d = make_float4(bounce.ray.x, bounce.ray.y, bounce.ray.z, d4.w);
+        n_aux = make_uint4(rp.x, rp.y, medium, new_state);
+        n_hid = make_uint4(0u, 0u, hid.z, volumes);
+      }
+    }
+    const unsigned long long ballot = __ballot(survive);
+    if (ballot) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(count_out, (uint32_t) __popcll(ballot));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (survive) {
+        const uint32_t j = base + (uint32_t) __popcll(ballot & below);
+        out.origin_t[j] = n_o; out.dir_slot[j] = n_d; out.aux[j] = n_aux; out.hit_id[j] = n_hid;
+      }
+    }
+    const unsigned long long bn = __ballot(want_sun);
+    if (bn) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, (uint32_t) __popcll(bn));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_sun) {
+        const uint32_t j = base + (uint32_t) __popcll(bn & below);
+        sq.origin_dist[j] = make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w);
+        sq.dir_out[j] = make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, kHitOcean, 0u);
+      }
+    }
+    const unsigned long long bl = __ballot(want_lq);
+    if (bl) {
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlLightItems, (uint32_t) __popcll(bl));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_lq) sq.light_items[base + (uint32_t) __popcll(bl & below)] = i;
+    }
   }
 }
 
@@ -908,19 +1187,23 @@ __global__ __launch_bounds__(kBlock) void k_volume_inscatter(DeviceScene sc, Pat
     const bool valid = i < n;
     uint32_t segments = 0;
     BridgeWalk walk;
-    bool want_sun = false, want_amb = false;
+    bool want_sun = false, want_amb = false, want_sun2 = false, want_amb2 = false;
     float4 sky_origin = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     V3 sun_dir = v3(0.0f, 0.0f, 1.0f), amb_dir = v3(0.0f, 0.0f, 1.0f);
+    float sun_limit = kFltMax, amb_limit = kFltMax;
+    V3 sun2_o = v3(0.0f, 0.0f, 0.0f), sun2_d = v3(0.0f, 0.0f, 1.0f), amb2_o = v3(0.0f, 0.0f, 0.0f), amb2_d = v3(0.0f, 0.0f, 1.0f);
     Sampler smp{sc.bluenoise_2d, 0u, 0u, 0u, depth_const};
     if (valid) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
       const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
       const uint32_t state = aux.w;
-      smp.px = hid.z & 0xFFFFu; smp.py = hid.z >> 16; smp.sample_id = hid.w;
-      VolContext ctx = volume_context(sc, origin, ray, state, o4.w);
+      smp.px = hid.z & 0xFFFFu; smp.py = hid.z >> 16; smp.sample_id = path_sample_id(hid.w);
+      const uint32_t top_volume = volume_stack_peek(hid.w, false), second_volume = volume_stack_peek(hid.w, true);
+      VolContext ctx = volume_context(sc, top_volume, origin, ray, state, o4.w);
       float4 bridge = make_float4(0.0f, 0.0f, 0.0f, bitsf(0u));
-      const bool bridges_allowed = lights_present && (state & kStDeltaPath) != 0 && (state & kStVolumeScattered) == 0;  // direct_lighting.cuh:296-306
+      const bool bridges_allowed = top_volume != kVolumeNone && lights_present && (state & kStDeltaPath) != 0 && (state & kStVolumeScattered) == 0 &&
+                                   (top_volume != kVolumeOcean || sc.ocean_triangle_light_contribution);  // direct_lighting.cuh:296-306
       if (bridges_allowed) {
         const BridgeSample bs = volume_light_sample(sc, ctx, smp);
         if (bs.light_id != kLightIdInvalid && bs.seed != 0xFFFFFFFFu) {
@@ -929,31 +1212,48 @@ __global__ __launch_bounds__(kBlock) void k_volume_inscatter(DeviceScene sc, Pat
           bridge = make_float4(bs.color.r, bs.color.g, bs.color.b, bitsf(segments));
         }
       }
-      const float w = volume_sky_initial_vertex(ctx, smp);  // the vertex the sun and the ambient sample start from
-      sky_origin = make_float4(ctx.position.x, ctx.position.y, ctx.position.z, kFltMax);
+      Col w = splat(0.0f);
       uint4 sky_words = make_uint4(0u, 0u, 0u, 0u);
-      if (sun_allowed) {
-        Col lc; V3 dir;
-        if (volume_sun_sample(sc, sky_view(sc), ctx, smp, lc, dir)) {
-          const U2 c = record_pack(lc), r = ray_pack(dir);
-          sky_words.x = c.x; sky_words.y = c.y;
-          if (c.x != 0 || c.y != 0) { want_sun = true; sun_dir = ray_unpack(r); }
+      if (top_volume != kVolumeNone) {
+        w = volume_sky_initial_vertex(ctx, smp);  // the vertex the sun and the ambient sample start from
+        sky_origin = make_float4(ctx.position.x, ctx.position.y, ctx.position.z, kFltMax);
+        if (sun_allowed) {
+          Col lc; V3 dir;
+          const bool have = (top_volume == kVolumeOcean) ? sun_caustic_sample(sc, sky_view(sc), ctx, smp, 1u, top_volume, second_volume, lc, dir)  // direct_lighting.cuh:370-380
+                                                         : volume_sun_sample(sc, sky_view(sc), ctx, smp, lc, dir);
+          if (have) {
+            const U2 c = record_pack(lc), r = ray_pack(dir);
+            sky_words.x = c.x; sky_words.y = c.y;
+            if (c.x != 0 || c.y != 0) {
+              want_sun = true;
+              sun_dir = ray_unpack(r);
+              const SkyRayPlan plan = plan_sun_ray(sc, ctx.position, 0xFFFFFFFFu, top_volume, true, sun_dir);
+              sun_limit = plan.limit;
+              vq.sun_water[i] = make_float4(plan.fresnel_factor, 0.0f, 0.0f, bitsf(sky_ray_flags(plan)));
+              if (plan.second && !plan.total_reflection) { want_sun2 = true; sun2_o = plan.second_origin; sun2_d = plan.second_dir; }
+            }
+          }
         }
-      }
-      const V3 bounce = volume_bsdf_sample(sc, ctx, smp, kRndVolAmbientResampling, kRndVolAmbientDiffuse);
-      float amb_transmittance = 1.0f;
-      if (sc.sky_mode != kSkyDefault) {  // direct_lighting.cuh:385-403, :521-584
-        const U2 c = record_pack(sky_color_no_compute(sc, ctx.position, bounce, 0u) * splat(1.0f)), r = ray_pack(bounce);
-        sky_words.z = c.x; sky_words.w = c.y;
-        if (c.x != 0 || c.y != 0) {
-          want_amb = true;
-          amb_dir = ray_unpack(r);
-          amb_transmittance = fog_transmittance(sc, ctx.position, amb_dir, kFltMax);
+        const V3 bounce = volume_bsdf_sample(sc, ctx, smp, kRndVolAmbientResampling, kRndVolAmbientDiffuse);
+        if (sc.sky_mode != kSkyDefault) {  // direct_lighting.cuh:385-403, :521-584
+          const U2 c = record_pack(sky_color_no_compute(sc, ctx.position, bounce, 0u) * splat(1.0f)), r = ray_pack(bounce);
+          if (c.x != 0 || c.y != 0) {
+            amb_dir = ray_unpack(r);
+            const SkyRayPlan plan = plan_ambient_ray(sc, ctx.position, 0xFFFFFFFFu, top_volume, second_volume, true, amb_dir);
+            if (plan.valid) {
+              sky_words.z = c.x; sky_words.w = c.y;
+              want_amb = true;
+              amb_limit = plan.limit;
+              vq.amb_t1[i] = make_float4(plan.t1.r, plan.t1.g, plan.t1.b, plan.fresnel_factor);
+              vq.amb_t2[i] = make_float4(plan.t2.r, plan.t2.g, plan.t2.b, bitsf(sky_ray_flags(plan)));
+              if (plan.second && !plan.total_reflection) { want_amb2 = true; amb2_o = plan.second_origin; amb2_d = plan.second_dir; }
+            }
+          }
         }
       }
       vq.bridge[i] = bridge;
       vq.sky[i] = sky_words;
-      vq.weight[i] = make_float4(w, amb_transmittance, 0.0f, 0.0f);
+      vq.weight[i] = make_float4(w.r, w.g, w.b, 0.0f);
     }
     // visibility rays, wave-aggregated: the segments of the bridges one at a time (a bridge has 1..15 of them), then sun and ambient
     for (uint32_t k = 0; k < kBridgesMaxVertexCount; k++) {
@@ -979,14 +1279,33 @@ __global__ __launch_bounds__(kBlock) void k_volume_inscatter(DeviceScene sc, Pat
       base = __builtin_amdgcn_readfirstlane(base);
       if (want_sun) {
         const uint32_t j = base + (uint32_t) __popcll(bs & below);
-        sq.origin_dist[j] = sky_origin;
+        sq.origin_dist[j] = make_float4(sky_origin.x, sky_origin.y, sky_origin.z, sun_limit);
         sq.dir_out[j] = make_float4(sun_dir.x, sun_dir.y, sun_dir.z, bitsf(kVolumeKindSun * sq.capacity + i));
         sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
       }
       if (want_amb) {
         const uint32_t j = base + ns + (uint32_t) __popcll(ba & below);
-        sq.origin_dist[j] = sky_origin;
+        sq.origin_dist[j] = make_float4(sky_origin.x, sky_origin.y, sky_origin.z, amb_limit);
         sq.dir_out[j] = make_float4(amb_dir.x, amb_dir.y, amb_dir.z, bitsf(kVolumeKindAmbient * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+    }
+    const unsigned long long b2s = __ballot(want_sun2), b2a = __ballot(want_amb2);
+    if (b2s | b2a) {  // second segments beyond the water surface
+      const uint32_t ns2 = (uint32_t) __popcll(b2s);
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlVolumeShadowItems, ns2 + (uint32_t) __popcll(b2a));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want_sun2) {
+        const uint32_t j = base + (uint32_t) __popcll(b2s & below);
+        sq.origin_dist[j] = make_float4(sun2_o.x, sun2_o.y, sun2_o.z, kFltMax);
+        sq.dir_out[j] = make_float4(sun2_d.x, sun2_d.y, sun2_d.z, bitsf(kVolumeKindSun2 * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+      if (want_amb2) {
+        const uint32_t j = base + ns2 + (uint32_t) __popcll(b2a & below);
+        sq.origin_dist[j] = make_float4(amb2_o.x, amb2_o.y, amb2_o.z, kFltMax);
+        sq.dir_out[j] = make_float4(amb2_d.x, amb2_d.y, amb2_d.z, bitsf(kVolumeKindAmbient2 * sq.capacity + i));
         sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
       }
     }
@@ -1007,15 +1326,18 @@ __global__ __launch_bounds__(kBlock) void k_volume_resolve(DeviceScene sc, PathQ
       for (uint32_t k = 1; k < segments; k++) { const float4 v = sq.vis[k * sq.capacity + i]; shadow = shadow * col(v.x, v.y, v.z); }
       acc = acc + col(bridge.x, bridge.y, bridge.z) * shadow;
     }
+    const Col w = col(wt.x, wt.y, wt.z);
     if (sky.x != 0 || sky.y != 0) {
-      const float4 v = sq.vis[kVolumeKindSun * sq.capacity + i];
-      acc = acc + (record_unpack(U2{sky.x, sky.y}) * col(v.x, v.y, v.z)) * wt.x;
+      const float4 v = sq.vis[kVolumeKindSun * sq.capacity + i], sw = vq.sun_water[i];
+      Col vis2 = splat(1.0f);
+      if ((fbits(sw.w) & kSkyRaySecond) && !(fbits(sw.w) & kSkyRayTotalReflection)) { const float4 v2 = sq.vis[kVolumeKindSun2 * sq.capacity + i]; vis2 = col(v2.x, v2.y, v2.z); }
+      acc = acc + combine_sun_ray(record_unpack(U2{sky.x, sky.y}), col(v.x, v.y, v.z), sw.x, fbits(sw.w), vis2) * w;
     }
     if (sky.z != 0 || sky.w != 0) {
-      const float4 v = sq.vis[kVolumeKindAmbient * sq.capacity + i];
-      Col lc = record_unpack(U2{sky.z, sky.w}) * col(v.x, v.y, v.z);
-      lc = lc * wt.y;
-      acc = acc + lc * wt.x;
+      const float4 v = sq.vis[kVolumeKindAmbient * sq.capacity + i], t1 = vq.amb_t1[i], t2 = vq.amb_t2[i];
+      Col vis2 = splat(1.0f);
+      if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v2 = sq.vis[kVolumeKindAmbient2 * sq.capacity + i]; vis2 = col(v2.x, v2.y, v2.z); }
+      acc = acc + combine_ambient_ray(record_unpack(U2{sky.z, sky.w}), col(v.x, v.y, v.z), col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2) * w;
     }
     const uint4 aux = in.aux[i];
     add_to_result(results, fbits(in.dir_slot[i].w), acc * record_unpack(U2{aux.x, aux.y}));
@@ -1029,19 +1351,20 @@ __global__ __launch_bounds__(kBlock) void k_volume_events(DeviceScene sc, PathQu
   const uint32_t n = ctrl[kCtlPaths];
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
-  const Volume vol = fog_volume(sc);
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
   for (uint32_t round = 0; round < rounds; round++) {
     const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
     bool scattered = false;
-    if (i < n) {
+    if (i < n && volume_stack_peek(in.hit_id[i].w, false) != kVolumeNone) {
       float4 o4 = in.origin_t[i];
       const float4 d4 = in.dir_slot[i];
       uint4 aux = in.aux[i], hid = in.hit_id[i];
       const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
       const uint32_t state = aux.w;
-      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
-      VolumePath path = volume_compute_path(sc, vol, origin, ray, o4.w);
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+      const uint32_t volume_type = volume_stack_peek(hid.w, false);
+      const Volume vol = volume_descriptor(sc, volume_type);
+      VolumePath path = volume_compute_path(sc, vol, origin, ray, o4.w, true);
       Col record = record_unpack(U2{aux.x, aux.y});
       uint32_t hit_inst = hid.x, hit_tri = hid.y;
       const bool sky_fast_path = hit_inst == kHitSky && sc.sky_mode != kSkyDefault && (state & kStAllowAmbient) != 0;
@@ -1051,15 +1374,16 @@ __global__ __launch_bounds__(kBlock) void k_volume_events(DeviceScene sc, PathQu
         add_to_result(results, fbits(d4.w), sky);
         hit_inst = kHitInvalid;
       }
-      const float intersection_probability = ((state & kStDeltaPath) && !particle_is_hit(hit_inst)) ? 0.5f : 1.0f;  // bounds the variance of highlights seen through the fog
+      float intersection_probability = ((state & kStDeltaPath) && !particle_is_hit(hit_inst)) ? 0.5f : 1.0f;  // bounds the variance of highlights seen through the volume
+      if (volume_type == kVolumeOcean && !sc.ocean_multiscattering && (state & kStDeltaPath) == 0) intersection_probability = 0.0f;  // single scattering in the water
       const F2 randoms = smp.next2(kRndVolumeIntersection);
       float pdf = 1.0f;
       if (randoms.y < intersection_probability) {
         const float volume_dist = volume_sample_intersection(vol, path.start, path.length, randoms.x);
         if (volume_dist < o4.w) {
           const float sample_pdf = volume_sample_intersection_pdf(vol, path.start, volume_dist);
-          o4.w = volume_dist; hit_inst = kHitVolumeFog; hit_tri = 0u;
-          record = record * vol.scattering;
+          o4.w = volume_dist; hit_inst = kHitVolumeBase | volume_type; hit_tri = 0u;
+          record = record * vol.scat;
           pdf *= intersection_probability;
           pdf *= sample_pdf;
           scattered = true;
@@ -1099,10 +1423,10 @@ __global__ __launch_bounds__(kBlock) void k_volume_bounce(DeviceScene sc, PathQu
       const uint32_t i = vq.items[k];
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
-      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, hid.w, depth_const};
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
       const V3 ray = v3(d4.x, d4.y, d4.z);
       const V3 origin = v3(o4.x, o4.y, o4.z) + ray * o4.w;
-      const VolContext ctx = volume_context(sc, origin, ray, aux.w, 0.0f);
+      const VolContext ctx = volume_context(sc, volume_stack_peek(hid.w, false), origin, ray, aux.w, 0.0f);
       const V3 bounce = volume_bsdf_sample(sc, ctx, smp, kRndVolGiResampling, kRndVolGiDiffuse);
       uint32_t state = aux.w & ~(kStDeltaPath | kStCameraDirection | kStAllowEmission | kStUseIgnoreHandle);
       if (sc.sky_mode != kSkyDefault) state &= ~kStAllowAmbient; else state |= kStAllowAmbient;

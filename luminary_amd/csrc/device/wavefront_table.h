@@ -43,6 +43,10 @@ struct WavefrontKernels {
   void (*trace_particles)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& particle_tree, const PathQueue& q, uint32_t* ctrl, uint32_t lds_nodes);
   void (*particle_shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq,
                          uint32_t* ctrl, uint32_t depth_const);
+  // ocean (dev_ocean.h, dev_water.h): the height-field pass of the closest-hit kernel and the shading of water-surface hits
+  void (*trace_ocean)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& q, const uint32_t* ctrl);
+  void (*ocean_shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl,
+                      uint32_t depth_const);
   void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                      uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);
 };

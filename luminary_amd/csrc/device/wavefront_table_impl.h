@@ -30,7 +30,8 @@ static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc
 }
 static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
                   uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
-  auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri> : k_shade<kSkyConstantColor>;
+  auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false> : k_shade<kSkyConstantColor, false>;
+  if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true> : k_shade<kSkyConstantColor, true>;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters);
 }
 static void shade_debug(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl) {
@@ -73,13 +74,20 @@ static void particle_shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, 
                            uint32_t* ctrl, uint32_t depth_const) {
   hipLaunchKernelGGL(k_particle_shade, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, ctrl, depth_const);
 }
+static void trace_ocean(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& q, const uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_trace_ocean, dim3(grid), dim3(kBlock), 0, s, sc, q, ctrl);
+}
+static void ocean_shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq,
+                        uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_ocean_shade, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, ctrl, depth_const);
+}
 static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                        uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, trace_rays};
 
 }  // namespace table
 LUM_NS_END

@@ -90,6 +90,7 @@ struct LumContext {
   float* d_frame_result = nullptr;  // mean radiance planes of lumc_generate_result [3 * W * H]
   uint32_t frame_result_pixels = 0;
   // ray ordering (N1): keys + permutation, double-buffered for hipcub's radix sort; sized for the visibility items (4 per path)
+  bool sync_debug = false;
   int sort_mode = 0;              // 0 queue order, 1 closest-hit rays of depth >= 1 sorted, 2 visibility rays too (lumc_set_ray_sorting, LUM_SORT)
   int sort_key = 0;               // 0 position-major (Morton cell | direction octant), 1 direction-major
   uint32_t* d_sort_keys[2] = {nullptr, nullptr};
@@ -159,15 +160,17 @@ void free_work(LumContext* ctx) {
 }
 
 int ensure_work(LumContext* ctx, uint32_t paths) {
-  // with fog a path can ask for 17 visibility rays in the in-scattering pass (15 bridge segments, sun, ambient) instead of 4 at a surface
-  const uint32_t kinds = ctx->scene.fog_active ? kVolumeShadowKinds : 4u;
+  // in a volume a path can ask for 19 visibility rays in the in-scattering pass (15 bridge segments, sun and ambient in up to two segments each)
+  // instead of 4 at a surface (6 with an ocean: the second segments of the sun and ambient samples of a vertex under water)
+  const bool volumes = ctx->scene.fog_active || ctx->scene.ocean_active;
+  const uint32_t kinds = volumes ? kVolumeShadowKinds : 4u;
   if (paths <= ctx->capacity && kinds <= ctx->work_shadow_kinds) return 0;
   if (paths < ctx->capacity) paths = ctx->capacity;
   free_work(ctx);
   // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to `kinds` visibility rays x (48 B + 16 B result) + 4 B light-query index
-  // (+ the fog's 48 B of in-scattering records and 4 B scattering-event index)
+  // (+ the volumes' 96 B of in-scattering records, 4 B scattering-event index and 48 B of water-surface factors of the surface vertices)
   const size_t n = paths;
-  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 52 : 0)) + 40 * 256;
+  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 100 + 48 : 0)) + 48 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
@@ -191,11 +194,18 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   ctx->shadow.light_items  = (uint32_t*) take(n * 4);
   ctx->shadow.capacity     = paths;
   ctx->volume = VolumeQueue{};
+  ctx->nee.sun_water = nullptr; ctx->nee.amb_t1 = nullptr; ctx->nee.amb_t2 = nullptr;
   if (kinds > 4u) {
     ctx->volume.bridge = (float4*) take(n * 16);
     ctx->volume.sky    = (uint4*) take(n * 16);
     ctx->volume.weight = (float4*) take(n * 16);
+    ctx->volume.sun_water = (float4*) take(n * 16);
+    ctx->volume.amb_t1 = (float4*) take(n * 16);
+    ctx->volume.amb_t2 = (float4*) take(n * 16);
     ctx->volume.items  = (uint32_t*) take(n * 4);
+    ctx->nee.sun_water = (float4*) take(n * 16);
+    ctx->nee.amb_t1    = (float4*) take(n * 16);
+    ctx->nee.amb_t2    = (float4*) take(n * 16);
   }
   ctx->work_shadow_kinds = kinds;
   ctx->capacity = paths;
@@ -232,6 +242,10 @@ struct Launch {
   }
   ~Launch() {
     if (idx != (size_t) -1) (void) hipEventRecord(ctx->stamps[idx].b, stream);
+    if (ctx->sync_debug) {  // LUM_SYNC_DEBUG=1: name the launch group a device fault belongs to
+      const hipError_t e = hipStreamSynchronize(stream);
+      std::fprintf(stderr, "[lum] launch group %d: %s\n", kernel, hipGetErrorString(e));
+    }
   }
 };
 
@@ -385,6 +399,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   ctx->device = device_ordinal;
   if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : 0;
   if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
+  if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;
   if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
@@ -880,6 +895,26 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       if (upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
     }
   }
+  // ---- ocean ----
+  sc.ocean_active = v->ocean_active ? 1u : 0u;
+  sc.ocean_height = v->ocean_height; sc.ocean_amplitude = v->ocean_amplitude; sc.ocean_frequency = v->ocean_frequency;
+  sc.ocean_refractive_index = v->ocean_refractive_index;
+  std::memcpy(sc.ocean_scattering, v->ocean_scattering, sizeof(sc.ocean_scattering));
+  std::memcpy(sc.ocean_absorption, v->ocean_absorption, sizeof(sc.ocean_absorption));
+  sc.ocean_molecular_weight = v->ocean_molecular_weight;
+  sc.ocean_caustics_active = v->ocean_caustics_active ? 1u : 0u;
+  sc.ocean_caustics_ris_sample_count = v->ocean_caustics_ris_sample_count;
+  sc.ocean_caustics_domain_scale = v->ocean_caustics_domain_scale;
+  sc.ocean_multiscattering = v->ocean_multiscattering ? 1u : 0u;
+  sc.ocean_triangle_light_contribution = v->ocean_triangle_light_contribution ? 1u : 0u;
+  if (sc.ocean_active) {
+    if (!(sc.ocean_refractive_index >= 1.0f)) { ctx->error = "lumc_scene_upload: the ocean needs a refractive index of at least 1"; return 1; }
+    if (sc.ocean_triangle_light_contribution && sc.num_lights > 0) {  // bridges in the water
+      if (!v->bridge_lut) { ctx->error = "lumc_scene_upload: an ocean lit by emissive triangles needs bridge_lut"; return 1; }
+      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
+      if (!sc.bridge_lut && upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
+    }
+  }
   // ---- particles ----
   sc.particles_active = (v->particles_active && v->particles_count) ? 1u : 0u;
   sc.particles_count = sc.particles_active ? v->particles_count : 0u;
@@ -1064,13 +1099,18 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
   int cur = 0;
   const WavefrontKernels& wf = *ctx->wf;
+  const bool render_volumes = sc.fog_active || sc.ocean_active;  // device_manager.c:478
   if (sc.shading_mode != 0u) {  // debug shading modes: one closest-hit pass and a colour per path (device_renderer.c:136-181)
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[0], nullptr, ctx->d_ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     if (sc.particles_active) trace_particles(ctx, stream, ctx->queue[0], ctx->d_ctrl, N);
-    if (sc.fog_active) {  // the debug queue keeps volume_process_events (device_renderer.c:145-147)
+    if (sc.ocean_active) {
+      Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+      wf.trace_ocean(grid_for(N), stream, sc, ctx->queue[0], (const uint32_t*) ctx->d_ctrl);
+    }
+    if (render_volumes) {  // the debug queue keeps volume_process_events (device_renderer.c:145-147)
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_events(grid_for(N), stream, sc, ctx->queue[0], ctx->volume, ctx->d_results, ctx->d_ctrl, 0u);
     }
@@ -1093,7 +1133,11 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
     if (sc.particles_active) trace_particles(ctx, stream, ctx->queue[cur], ctrl, N);  // optix_kernel_raytrace.cu:171
-    if (sc.fog_active) {  // device_renderer.c:64-76: in-scattering with its own visibility pass, then the scattering events
+    if (sc.ocean_active) {  // optix_kernel_raytrace.cu:134-144, :172
+      Launch l(ctx, stream, LUMC_KERNEL_TRACE);
+      wf.trace_ocean(grid_for(N), stream, sc, ctx->queue[cur], (const uint32_t*) ctrl);
+    }
+    if (render_volumes) {  // device_renderer.c:64-76: in-scattering with its own visibility pass, then the scattering events
       {
         Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
         wf.volume_inscatter(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->shadow, ctrl, depth_const);
@@ -1118,6 +1162,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
       wf.particle_shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctrl, depth_const);
     }
+    if (sc.ocean_active) {  // device_renderer.c:104-108
+      Launch l(ctx, stream, LUMC_KERNEL_SHADE);
+      wf.ocean_shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctrl, depth_const);
+    }
     if (sc.sky_mode == kSkyDefault) {  // paths that left the scene into the procedural sky (listed by k_shade)
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
       wf.sky(grid_for(N), stream, sc, ctx->queue[cur], ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, depth_const);
@@ -1128,7 +1176,8 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     const uint32_t* shadow_order = nullptr;
     if (ctx->sort_mode >= 2) {
-      shadow_order = sort_rays(ctx, stream, ctx->shadow.origin_dist, ctx->shadow.dir_out, ctrl + kCtlShadowItems, 4u * ctx->shadow.capacity < 4u * N ? 4u * ctx->shadow.capacity : 4u * N);
+      shadow_order = sort_rays(ctx, stream, ctx->shadow.origin_dist, ctx->shadow.dir_out, ctrl + kCtlShadowItems,
+                               (sc.ocean_active ? kSurfaceShadowKindsWater : 4u) * (ctx->shadow.capacity < N ? ctx->shadow.capacity : N));
       if (!shadow_order) { ctx->error = "ray sorting failed"; return 1; }
     }
     {
@@ -1139,7 +1188,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
       wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
     }
-    if (sc.fog_active && depth != max_depth) {  // device_renderer.c:114-118
+    if (render_volumes && depth != max_depth) {  // device_renderer.c:114-118
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_bounce(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->volume, ctrl, depth_const);
     }

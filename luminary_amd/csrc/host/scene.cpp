@@ -1069,6 +1069,24 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   }
   v.particle_vertices = b.particle_vertices.empty() ? nullptr : b.particle_vertices.data();
   v.particle_normals = b.particle_normals.empty() ? nullptr : b.particle_normals.data();
+  // ocean (device_struct_ocean_convert, device_structs.c:87-105); Jerlov coefficients: ocean_utils.cuh:291-385
+  const LuminaryOcean& oc = scene.ocean;
+  v.ocean_active = oc.active ? 1u : 0u;
+  v.ocean_height = oc.height; v.ocean_amplitude = oc.amplitude; v.ocean_frequency = oc.frequency; v.ocean_refractive_index = oc.refractive_index;
+  {
+    static const float scattering[10][3] = {{0.001f, 0.002f, 0.004f}, {0.002f, 0.004f, 0.007f}, {0.045f, 0.054f, 0.07f}, {0.27f, 0.365f, 0.516f}, {0.737f, 0.998f, 1.413f},
+                                            {0.274f, 0.372f, 0.526f}, {0.904f, 1.071f, 1.532f}, {3.589f, 1.382f, 1.857f}, {1.772f, 2.394f, 3.376f}, {2.347f, 3.18f, 4.496f}};
+    static const float absorption[10][3] = {{0.309f, 0.053f, 0.009f}, {0.309f, 0.054f, 0.014f}, {0.309f, 0.054f, 0.015f}, {0.31f, 0.054f, 0.016f}, {0.31f, 0.056f, 0.031f},
+                                            {0.316f, 0.067f, 0.105f}, {0.508f, 0.052f, 0.161f}, {4.638f, 0.222f, 0.216f}, {0.351f, 0.188f, 0.574f}, {0.398f, 0.349f, 0.995f}};
+    static const float molecular_weight[10] = {0.93f, 0.44f, 0.06f, 0.007f, 0.003f, 0.005f, 0.003f, 0.001f, 0.0f, 0.0f};
+    const uint32_t type = (uint32_t) oc.water_type;
+    for (int k = 0; k < 3; k++) { v.ocean_scattering[k] = type < 10 ? scattering[type][k] : 0.0f; v.ocean_absorption[k] = type < 10 ? absorption[type][k] : 0.0f; }
+    v.ocean_molecular_weight = type < 10 ? molecular_weight[type] : 0.0f;
+  }
+  v.ocean_caustics_active = oc.caustics_active ? 1u : 0u;
+  v.ocean_caustics_ris_sample_count = std::max(oc.caustics_ris_sample_count, 1u) - 1u;  // device_structs.c:94
+  v.ocean_caustics_domain_scale = oc.caustics_domain_scale;
+  v.ocean_multiscattering = oc.multiscattering ? 1u : 0u; v.ocean_triangle_light_contribution = oc.triangle_light_contribution ? 1u : 0u;
   return std::string();
 }
 

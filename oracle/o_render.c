@@ -5,12 +5,15 @@
  *   trace                        optix/optix_kernel_raytrace.cu:147-183          (o_trace.h)
  *   geometry_process_tasks       cuda/geometry.cuh:11-180, cuda/geometry_utils.cuh:54-221, cuda/direct_lighting.cuh:352-443
  *   shadow                       optix/optix_kernel_shadow.cu:15-100, cuda/direct_lighting.cuh:445-669
- *   sky_process_tasks            cuda/sky.cuh:567-633 (constant-colour branch)
+ *   sky_process_tasks            cuda/sky.cuh:567-633                               (o_sky.h)
+ *   volume_process_* (fog, water) cuda/volume.cuh, cuda/light_bridges.cuh             (o_volume.h)
+ *   particle_process_tasks       cuda/particle.cuh:7-108, optix_kernel_raytrace.cu:97-131
+ *   ocean_process_tasks          cuda/ocean.cuh:12-102, cuda/caustics.cuh, optix_kernel_raytrace.cu:134-144 (o_ocean.h)
  *   accumulate                   cuda/memory.cuh:359-368, cuda/accumulation.cuh:63-84
  * Paths are independent (all randomness is a function of pixel, sample id, depth and target), so the oracle walks
  * them one at a time instead of in wavefronts; per path the order of every floating-point operation is the reference's.
  * Quirk kept: the depth constant the sampler sees is not advanced before the last pass (device_renderer.c:126-130).
- * Out of scope: textures, volumes, ocean, particles, procedural sky/sun, physical camera.
+ * Out of scope: clouds, physical camera.
  */
 #define _GNU_SOURCE /* qsort_r (o_trace.h) */
 #include <stdio.h>
@@ -176,7 +179,7 @@ static bool russian_roulette(const OracleScene* s, const Sampler* smp, uint16_t 
 
 /* Debug shading modes: one closest-hit pass, then a colour per hit (geometry_process_tasks_debug, cuda/geometry.cuh:182-246) or per miss
  * (sky_process_tasks_debug, cuda/sky.cuh:635-665); queue: device/device_renderer.c:136-181. */
-static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p);
+static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, uint32_t volume_type, OHit* hit_p, uint2_t* record_pp, RGBF* result_p);
 static void particles_trace(const OracleScene* s, const OTracer* tr, const Sampler* smp, vec3 origin, vec3 ray, uint16_t state, OHit* hit);
 static inline bool particle_is_hit(uint32_t instance_id);
 #define HIT_TYPE_PARTICLE_MASK 0x7FFFFFFFu
@@ -186,14 +189,30 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
   vec3 origin, ray;
   camera_sample(s, &smp, &origin, &ray);
   const uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
-  const uint32_t medium = medium_ior_modify(0, 1.0f, true);
+  const uint32_t medium = medium_ior_modify(0, (s->ocean_active && origin.y < s->ocean_height) ? s->ocean_refractive_index : 1.0f, true);
   OHit hit = trace_closest(tr, origin, ray, false, 0, 0);
   cnt[ORACLE_CNT_TRACE]++;
   particles_trace(s, tr, &smp, origin, ray, state, &hit);
-  if (s->fog_active) { /* the debug queue keeps volume_process_events (device_renderer.c:145-147): the sky fast path shows through, a scattering event stays black */
+  if (s->ocean_active) {
+    const float ocean_depth = ocean_intersection_distance(s, origin, ray, hit.t);
+    if (ocean_depth < hit.t) { hit.t = ocean_depth; hit.instance_id = HIT_TYPE_OCEAN; hit.tri_id = 0; }
+  }
+  uint32_t volumes = 0;
+  if (s->fog_active) volumes = volume_stack_modify(volumes, VOLUME_TYPE_FOG, true);
+  if (s->ocean_active && ocean_is_underwater(s, origin)) volumes = volume_stack_modify(volumes, VOLUME_TYPE_OCEAN, true);
+  if (volume_stack_peek(volumes, false) != VOLUME_TYPE_NONE) { /* the debug queue keeps volume_process_events (device_renderer.c:145-147): the sky fast path shows through, a scattering event stays black */
     uint2_t record_p = record_pack(c_splat(1.0f));
-    volume_events(s, &smp, origin, ray, state, &hit, &record_p, &result);
-    if (hit.instance_id == HIT_TYPE_INVALID || hit.instance_id == HIT_TYPE_VOLUME_FOG) return result;
+    volume_events(s, &smp, origin, ray, state, volume_stack_peek(volumes, false), &hit, &record_p, &result);
+    if (hit.instance_id == HIT_TYPE_INVALID || (hit.instance_id >= HIT_TYPE_VOLUME_BASE && hit.instance_id <= HIT_TYPE_VOLUME_MAX)) return result;
+  }
+  if (hit.instance_id == HIT_TYPE_OCEAN) { /* ocean_process_tasks_debug, ocean.cuh:104-145 */
+    if (s->shading_mode == 2) beauty_add(&result, c_splat(o_saturate((1.0f / hit.t) * 2.0f)));
+    else if (s->shading_mode == 3) {
+      const vec3 n = ocean_get_normal(s, v_add(origin, v_scale(ray, hit.t)));
+      beauty_add(&result, c3(o_saturate(0.5f * n.x + 0.5f), o_saturate(0.5f * n.y + 0.5f), o_saturate(0.5f * n.z + 0.5f)));
+    }
+    else if (s->shading_mode == 4) beauty_add(&result, c3(0.0f, 0.0f, 1.0f));
+    return result;
   }
   if (hit.instance_id == HIT_TYPE_SKY) {
     if (s->shading_mode == 1) { /* ALBEDO: sky_color_main(origin, ray, STATE_FLAG_CAMERA_DIRECTION) */
@@ -255,6 +274,181 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
 }
 
 
+/* ---- evaluation of the sun and ambient samples of a vertex (direct_lighting.cuh:466-584): one visibility ray, or two when the vertex is under water -
+ * up to the water surface, then along the direction refracted there, weighted by the Fresnel transmission and the second volume's transmittance ---- */
+static RGBF sun_evaluate(const OracleScene* s, const OTracer* tr, uint64_t* cnt, vec3 origin, uint32_t self_inst, uint32_t self_tri, uint32_t volume_id, uint2_t color_p,
+                         uint2_t ray_p, bool allowed) {
+  const vec3 ray = ray_unpack(ray_p);
+  float limit = FLT_MAX;
+  const bool is_caustics_path = volume_id == VOLUME_TYPE_OCEAN && self_inst != HIT_TYPE_OCEAN;
+  if (is_caustics_path && ray.y > 0.0f) {
+    const float dist = (ocean_max_height(s) - origin.y) / ray.y;
+    limit = (dist > 0.0f) ? dist : FLT_MAX;
+  }
+  const bool valid = (color_p.x != 0 || color_p.y != 0) && allowed;
+  RGBF vis = c_splat(0.0f);
+  if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, origin, ray, limit, 0xFFFFFFFFu, 0, self_inst, self_tri); }
+  RGBF light = c_mul(record_unpack(color_p), vis);
+  RGBF vis2 = c_splat(1.0f); /* OPTIX_TRACE_STATUS_OPTIONAL_UNUSED */
+  if (valid && is_caustics_path && limit != FLT_MAX) {
+    const vec3 ocean_pos = v_add(origin, v_scale(ray, limit));
+    /* caustics_is_fast_path<GEOMETRY> (caustics.cuh:50-58; its fourth term is constant false by operator precedence) */
+    const bool fast_path = s->ocean_amplitude == 0.0f || !s->ocean_caustics_active;
+    const vec3 ocean_normal = fast_path ? v3(0.0f, -1.0f, 0.0f) : v_scale(ocean_get_normal(s, ocean_pos), -1.0f);
+    bool total_reflection;
+    const vec3 refraction = refract_vector(v_scale(ray, -1.0f), ocean_normal, s->ocean_refractive_index, &total_reflection);
+    const float fresnel = ocean_reflection_coefficient(ocean_normal, ray, refraction, 1.0f / s->ocean_refractive_index);
+    light = c_scale(light, 1.0f - fresnel);
+    if (total_reflection) vis2 = c_splat(0.0f);
+    else { cnt[ORACLE_CNT_SHADOW]++; vis2 = trace_shadow(tr, ocean_pos, refraction, FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0); }
+  }
+  if (!valid) vis2 = c_splat(1.0f);
+  return c_mul(light, vis2);
+}
+static RGBF ambient_evaluate(const OracleScene* s, const OTracer* tr, uint64_t* cnt, vec3 origin, uint32_t self_inst, uint32_t self_tri, uint32_t volume_id, uint32_t second_volume,
+                             uint2_t color_p, uint2_t ray_p, bool allowed) {
+  const vec3 ray = ray_unpack(ray_p);
+  float limit = FLT_MAX;
+  const bool is_caustics_path = volume_id == VOLUME_TYPE_OCEAN && self_inst != HIT_TYPE_OCEAN;
+  bool valid = (color_p.x != 0 || color_p.y != 0) && allowed;
+  if (is_caustics_path && ray.y > 0.0f) {
+    const float dist = (ocean_max_height(s) - origin.y) / ray.y;
+    limit = (dist > 0.0f) ? dist : FLT_MAX;
+  }
+  else if (ray.y < 0.0f && s->ocean_active && origin.y > ocean_min_height(s)) valid = false; /* the sample would have to cross the water from above */
+  RGBF vis = c_splat(0.0f);
+  if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, origin, ray, limit, 0xFFFFFFFFu, 0, self_inst, self_tri); }
+  RGBF light = c_mul(record_unpack(color_p), vis);
+  light = c_mul(light, volume_transmittance(s, volume_id, origin, ray, limit));
+  RGBF vis2 = c_splat(1.0f);
+  if (valid && is_caustics_path && limit != FLT_MAX) {
+    const vec3 ocean_pos = v_add(origin, v_scale(ray, limit));
+    const vec3 ocean_normal = v_scale(ocean_get_normal(s, ocean_pos), -1.0f);
+    const vec3 ocean_V = v_scale(ray, -1.0f);
+    bool total_reflection;
+    const vec3 refraction = refract_vector(ocean_V, ocean_normal, s->ocean_refractive_index, &total_reflection);
+    const float fresnel_term = bsdf_fresnel(ocean_normal, ocean_V, refraction, s->ocean_refractive_index);
+    light = c_scale(light, 1.0f - fresnel_term);
+    light = c_mul(light, volume_transmittance(s, second_volume, ocean_pos, refraction, FLT_MAX));
+    if (total_reflection) vis2 = c_splat(0.0f);
+    else { cnt[ORACLE_CNT_SHADOW]++; vis2 = trace_shadow(tr, ocean_pos, refraction, FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0); }
+  }
+  if (!valid) vis2 = c_splat(1.0f);
+  return c_mul(light, vis2);
+}
+
+/* ---- the sun seen from under water: direct_lighting_sun_caustic (direct_lighting.cuh:123-243) with caustics.cuh. A point on the water surface connects the
+ * vertex to the sun: the point straight "below" the refracted sun direction (fast path), or one resampled from a patch of the surface around it ---- */
+typedef struct { int kind; /* 0 surface, 1 volume, 2 particle */ vec3 position; uint16_t state; const void* ctx; const OLuts* luts; } SunCtx;
+typedef struct { vec3 position, normal, V; uint16_t state; } ParticleCtx;
+static float particle_phase(const OracleScene* s, const ParticleCtx* c, vec3 L);
+static RGBF sunctx_evaluate(const OracleScene* s, const SunCtx* c, vec3 dir, float one_over_pdf) {
+  if (c->kind == 0) { bool r; return bsdf_evaluate(c->luts, (const GeoCtx*) c->ctx, dir, HINT_GENERAL, &r, one_over_pdf); }
+  if (c->kind == 1) return c_splat(volume_phase_evaluate(s, (const VolCtx*) c->ctx, dir) * one_over_pdf);
+  return c_scale(c3(s->particles_albedo[0], s->particles_albedo[1], s->particles_albedo[2]), particle_phase(s, (const ParticleCtx*) c->ctx, dir) * one_over_pdf);
+}
+typedef struct { bool valid; vec3 base, edge1, edge2; float area, ior; bool fast_path; } CausticsDomain;
+static CausticsDomain caustics_get_domain(const OracleScene* s, const OSky* sky, const SunCtx* c, vec3 L) { /* caustics.cuh:21-35, :60-123, under water */
+  bool total_reflection;
+  vec3 ray = refract_vector(L, v3(0.0f, 1.0f, 0.0f), 1.0f / s->ocean_refractive_index, &total_reflection);
+  ray = v_scale(ray, -1.0f);
+  const float dist = ocean_intersection_distance(s, c->position, ray, FLT_MAX);
+  const vec3 center = v_add(c->position, v_scale(ray, dist));
+  CausticsDomain d;
+  d.valid = dist != FLT_MAX;
+  d.ior = s->ocean_refractive_index;
+  d.fast_path = (c->kind != 0) || s->ocean_amplitude == 0.0f || !s->ocean_caustics_active;
+  if (d.fast_path) {
+    d.base = center; d.edge1 = v3(0.0f, 0.0f, 0.0f); d.edge2 = v3(0.0f, 0.0f, 0.0f);
+    d.area = sphere_solid_angle(sky->sun_pos, SKY_SUN_RADIUS, world_to_sky(sky, c->position));
+    return d;
+  }
+  const vec3 center_dir = v_norm(v_sub(center, c->position));
+  float altitude = o_asin(center_dir.y), azimuth = o_atan2(center_dir.z, center_dir.x); /* direction_to_angles, math.cuh:790-797 */
+  if (azimuth < 0.0f) azimuth += 2.0f * O_PI;
+  const float angle = 0.3f * s->ocean_caustics_domain_scale, plane_height = center.y;
+  vec3 vd[3];
+  const float alts[3] = {altitude - angle, altitude - angle, altitude + angle}, azis[3] = {azimuth - angle, azimuth + angle, azimuth - angle};
+  for (int k = 0; k < 3; k++) { /* angles_to_direction, math.cuh:781-788 */
+    float sa, ca, sz, cz; o_sincos(alts[k], &sa, &ca); o_sincos(azis[k], &sz, &cz);
+    const vec3 dir = v3(cz * ca, sa, sz * ca);
+    const float dd = fabsf(c->position.y - plane_height) / fmaxf(0.01f, fabsf(dir.y));
+    vd[k] = v_add(c->position, v_scale(dir, dd));
+  }
+  d.base = vd[0]; d.edge1 = v_sub(vd[1], vd[0]); d.edge2 = v_sub(vd[2], vd[0]);
+  d.area = v_len(v_cross(d.edge1, d.edge2));
+  return d;
+}
+static bool caustics_find_connection_point(const OracleScene* s, const OSky* sky, const SunCtx* c, const Sampler* smp, uint32_t rt_initial, const CausticsDomain* d, uint32_t iteration,
+                                           uint32_t num_iterations, vec3* point, float* sample_weight) { /* caustics.cuh:125-163, refraction */
+  if (d->fast_path) { *point = d->base; *sample_weight = d->area; return true; }
+  const float2_t r = rnd2(smp, rt_initial + iteration);
+  const float sx = (iteration + r.x) * (1.0f / num_iterations), sy = r.y; /* ris_transform_stratum_2D, ris.cuh:166-174 */
+  *point = v_add(d->base, v_add(v_scale(d->edge1, sx), v_scale(d->edge2, sy)));
+  vec3 V = v_sub(c->position, *point);
+  const float dist_sq = v_dot(V, V);
+  V = v_scale(V, o_rsqrt(dist_sq));
+  const vec3 normal = v_scale(ocean_get_normal_fast(s, *point), -1.0f);
+  if (v_dot(V, normal) < 0.0f) return false;
+  bool total_reflection;
+  const vec3 L = refract_vector(V, normal, s->ocean_refractive_index, &total_reflection);
+  if (!sphere_hit(L, world_to_sky(sky, *point), sky->sun_pos, SKY_SUN_RADIUS)) return false;
+  *sample_weight = fabsf(V.y) * d->area / dist_sq;
+  return true;
+}
+static bool sun_caustic_sample(const OracleScene* s, const OSky* sky, const SunCtx* c, const Sampler* smp, uint32_t set, uint32_t volume_type, uint32_t second_volume,
+                               RGBF* light_out, vec3* dir_out) {
+  const uint32_t rt_initial = 81u + 128u * set, rt_resampling = 338u + set, rt_sun_ray = 341u + set; /* CAUSTIC_INITIAL / _RESAMPLING / _SUN_RAY of LIGHT_SUN<set> */
+  const vec3 sky_pos = world_to_sky(sky, c->position);
+  float solid_angle;
+  const vec3 sun_dir = sample_sphere(sky->sun_pos, SKY_SUN_RADIUS, sky_pos, rnd2(smp, rt_sun_ray), &solid_angle);
+  const CausticsDomain domain = caustics_get_domain(s, sky, c, sun_dir);
+  if (!domain.valid) return false;
+  vec3 connection_point = v3(0.0f, 0.0f, 0.0f);
+  float connection_weight;
+  if (domain.fast_path) caustics_find_connection_point(s, sky, c, smp, rt_initial, &domain, 0, 1, &connection_point, &connection_weight);
+  else {
+    const uint32_t num_samples = s->ocean_caustics_ris_sample_count + 1;
+    /* ris_stratified_reservoir (ris.cuh:176-259): strata are taken from both ends, the side whose weight sum lags behind the random split is extended */
+    uint32_t iteration = 0, index_front = 0xFFFFFFFFu, index_back = num_samples;
+    float sum_front = 0.0f, sum_back = 0.0f, selected_target = 0.0f;
+    const float random = rnd1(smp, rt_resampling);
+    const float mis_weight = 1.0f / num_samples;
+    for (;;) {
+      if (iteration > num_samples) break;
+      const bool compute_front = sum_front <= random * (sum_front + sum_back);
+      if (!compute_front && iteration == num_samples) break;
+      iteration++;
+      const uint32_t index = compute_front ? ++index_front : --index_back;
+      if (index == num_samples) break;
+      vec3 sample_point; float sample_weight = 0.0f;
+      const bool valid_hit = caustics_find_connection_point(s, sky, c, smp, rt_initial, &domain, index, num_samples, &sample_point, &sample_weight);
+      const float target = valid_hit ? 1.0f : 0.0f;
+      sample_weight = valid_hit ? mis_weight * sample_weight : 0.0f;
+      const float weight = target * sample_weight;
+      if (weight == 0.0f) continue;
+      const bool front = sum_front <= random * (sum_front + sum_back);
+      selected_target = front ? target : selected_target;
+      if (iteration <= num_samples) { if (front) sum_front += weight; else sum_back += weight; }
+      if (front) connection_point = sample_point;
+    }
+    connection_weight = (selected_target > 0.0f) ? (sum_front + sum_back) / selected_target : 0.0f;
+    connection_weight *= s->ocean_refractive_index * s->ocean_refractive_index;
+    connection_weight *= s->ocean_refractive_index * s->ocean_refractive_index * 2.0f;
+  }
+  if (connection_weight == 0.0f) return false;
+  const vec3 pos_to_ocean = v_sub(connection_point, c->position);
+  const float dist = v_len(pos_to_ocean);
+  const vec3 dir = v_norm(pos_to_ocean);
+  RGBF light = sky_sun_color(sky, world_to_sky(sky, connection_point), sun_dir);
+  light = c_mul(light, sunctx_evaluate(s, c, dir, connection_weight));
+  if (c_importance(light) == 0.0f) return false;
+  light = c_mul(light, volume_transmittance(s, volume_type, c->position, dir, dist));
+  light = c_mul(light, volume_transmittance(s, second_volume, connection_point, sun_dir, FLT_MAX));
+  *light_out = light; *dir_out = dir;
+  return true;
+}
+
 /* ---- fog: what the volume kernels do to one path at one depth (cuda/volume.cuh, optix/optix_kernel_shadow_volume.cu) ---- */
 /* light_sample<MATERIAL_VOLUME> (light.cuh:84-159): the eight tree outputs are bridge candidates (light_evaluate_candidate<VOLUME>, :84-98) */
 static BridgeSample volume_light_sample(const OracleScene* s, const VolCtx* c, const Sampler* smp) {
@@ -284,7 +478,7 @@ static RGBF bridges_apply_shadowing(const OracleScene* s, const OTracer* tr, con
   uint32_t uvp[3];
   TriLight light = light_triangle_init(s, l_inst, l_tri, uvp);
   const vec3 point_on_light = light_triangle_sample_bridges(&light, rnd2(smp, RT_BRIDGE_LIGHT_POINT + seed));
-  float att, ipdf;
+  RGBF att; float ipdf;
   const vec3 initial_vertex = bridges_sample_initial_vertex(c, point_on_light, smp, seed, &att, &ipdf);
   vec3 light_dir; float area, light_dist;
   light_triangle_finalize_bridges(&light, uvp, initial_vertex, point_on_light, &light_dir, &light_dist, &area);
@@ -319,39 +513,35 @@ static RGBF sky_color_no_compute(const OracleScene* s, vec3 origin, vec3 ray, ui
 /* volume_process_inscattering (volume.cuh:31-98) + the shadow pass over its three tasks (optix_kernel_shadow_volume.cu:13-98): light that the
  * fog scatters into the ray between its origin and its end point (`depth_t`: the hit distance, FLT_MAX for a ray that left the scene) */
 static RGBF volume_inscattering(const OracleScene* s, const OTracer* tr, const Sampler* smp, vec3 origin, vec3 ray, uint16_t state, float depth_t, bool lights_present,
-                                uint64_t* cnt) {
-  VolCtx ctx = volume_context(s, origin, ray, state, depth_t);
+                                uint32_t volume_type, uint32_t second_volume, uint64_t* cnt) {
+  VolCtx ctx = volume_context(s, volume_type, origin, ray, state, depth_t);
   RGBF acc = c_splat(0.0f);
-  const bool bridges_allowed = lights_present && (state & ST_DELTA_PATH) != 0 && (state & ST_VOLUME_SCATTERED) == 0; /* direct_lighting.cuh:296-306 */
+  const bool bridges_allowed = lights_present && (state & ST_DELTA_PATH) != 0 && (state & ST_VOLUME_SCATTERED) == 0 &&
+                               (volume_type != VOLUME_TYPE_OCEAN || s->ocean_triangle_light_contribution); /* direct_lighting.cuh:296-306 */
   if (bridges_allowed) {
     const BridgeSample bs = volume_light_sample(s, &ctx, smp);
     if (bs.light_id != LIGHT_ID_INVALID && bs.seed != 0xFFFFFFFFu) acc = c_add(acc, bridges_apply_shadowing(s, tr, &ctx, &bs, smp, cnt));
   }
-  const float w = volume_sky_initial_vertex(&ctx, smp); /* the vertex the sun and the ambient sample start from */
+  const RGBF w = volume_sky_initial_vertex(&ctx, smp); /* the vertex the sun and the ambient sample start from */
   const bool sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
   if (sun_allowed) {
     const OSky sky_v = osky_view(s);
     RGBF lc; vec3 dir;
     uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
-    if (volume_sun_sample(s, &sky_v, &ctx, smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
-    if (sun_color.x != 0 || sun_color.y != 0) {
-      cnt[ORACLE_CNT_SHADOW]++;
-      const RGBF vis = trace_shadow(tr, ctx.position, ray_unpack(sun_ray), FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
-      acc = c_add(acc, c_scale(c_mul(record_unpack(sun_color), vis), w));
+    bool have;
+    if (volume_type == VOLUME_TYPE_OCEAN) { /* direct_lighting.cuh:370-380: under water the sun arrives through the surface */
+      const SunCtx sc = {1, ctx.position, state, &ctx, NULL};
+      have = sun_caustic_sample(s, &sky_v, &sc, smp, 1, volume_type, second_volume, &lc, &dir);
     }
+    else have = volume_sun_sample(s, &sky_v, &ctx, smp, &lc, &dir);
+    if (have) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+    acc = c_add(acc, c_mul(sun_evaluate(s, tr, cnt, ctx.position, 0xFFFFFFFFu, 0, volume_type, sun_color, sun_ray, true), w));
   }
   const vec3 bounce = volume_bsdf_sample(s, &ctx, smp, RT_VOL_AMBIENT_RESAMPLING, RT_VOL_AMBIENT_DIFFUSE);
   if (s->sky_mode != SKY_MODE_DEFAULT) { /* direct_lighting.cuh:385-403, :521-584 */
     const uint2_t amb_color = record_pack(c_mul(sky_color_no_compute(s, ctx.position, bounce, 0), c_splat(1.0f)));
     const uint2_t amb_ray = ray_pack(bounce);
-    if (amb_color.x != 0 || amb_color.y != 0) {
-      const vec3 ar = ray_unpack(amb_ray);
-      cnt[ORACLE_CNT_SHADOW]++;
-      const RGBF vis = trace_shadow(tr, ctx.position, ar, FLT_MAX, 0xFFFFFFFFu, 0, 0xFFFFFFFFu, 0);
-      RGBF lc = c_mul(record_unpack(amb_color), vis);
-      lc = c_scale(lc, fog_transmittance(s, ctx.position, ar, FLT_MAX));
-      acc = c_add(acc, c_scale(lc, w));
-    }
+    acc = c_add(acc, c_mul(ambient_evaluate(s, tr, cnt, ctx.position, 0xFFFFFFFFu, 0, volume_type, second_volume, amb_color, amb_ray, true), w));
   }
   return acc;
 }
@@ -376,7 +566,6 @@ static void particles_trace(const OracleScene* s, const OTracer* tr, const Sampl
   const uint32_t tri = trace_particles(tr, pos, scaled_ray, hit->t, &t);
   if (tri != 0xFFFFFFFFu) { hit->instance_id = HIT_TYPE_PARTICLE_MIN + (tri >> 1); hit->tri_id = 0; hit->t = t; }
 }
-typedef struct { vec3 position, normal, V; uint16_t state; } ParticleCtx;
 static float particle_phase(const OracleScene* s, const ParticleCtx* c, vec3 L) { return je_phase_function(s->particles_phase, -v_dot(c->V, L)); }
 /* light_sample<MATERIAL_PARTICLE> (light.cuh:49-82, :100-159): BSDF value = albedo x phase function, MIS weight 1 (mis.cuh:41-47) */
 static LightSample particle_light_sample(const OracleScene* s, const ParticleCtx* c, const Sampler* smp) {
@@ -403,7 +592,7 @@ static LightSample particle_light_sample(const OracleScene* s, const ParticleCtx
   return res;
 }
 /* direct_lighting_sun_create_task / _direct for a particle (direct_lighting.cuh:20-121, :352-383; random set LIGHT_SUN<0>) */
-static bool particle_sun_sample(const OracleScene* s, const OSky* sky, const ParticleCtx* c, const Sampler* smp, RGBF* light_out, vec3* dir_out) {
+static bool particle_sun_sample(const OracleScene* s, const OSky* sky, const ParticleCtx* c, uint32_t volume_type, const Sampler* smp, RGBF* light_out, vec3* dir_out) {
   const vec3 sky_pos = world_to_sky(sky, c->position);
   const bool sun_below_horizon = sph_hit_p0(v_norm(v_sub(sky->sun_pos, sky_pos)), sky_pos, SKY_EARTH_RADIUS);
   const bool inside_earth = v_len(sky_pos) < SKY_EARTH_RADIUS;
@@ -430,29 +619,88 @@ static bool particle_sun_sample(const OracleScene* s, const OSky* sky, const Par
   light = c_scale(light, sum_weights / target);
   if (target == 0.0f) return false;
   if (c_importance(light) == 0.0f) return false;
-  *light_out = s->fog_active ? c_scale(light, fog_transmittance(s, c->position, *dir_out, FLT_MAX)) : light;
+  *light_out = c_mul(light, volume_transmittance(s, volume_type, c->position, *dir_out, FLT_MAX));
   return true;
+}
+
+
+/* direct_lighting_bsdf_evaluate_task (direct_lighting.cuh:586-667): the BSDF-sampled direction against the light-only BVH, then a visibility ray */
+static RGBF bsdf_light_evaluate(const OracleScene* s, const OTracer* tr, uint64_t* cnt, const Sampler* smp, vec3 hit_origin, uint32_t self_inst, uint32_t self_tri,
+                                const LightBSDFSample* lb, float root_sum, uint32_t volume_id, bool allowed) {
+  bool valid = allowed && lb->sampling_probability != 0.0f;
+  uint32_t light_id = LIGHT_ID_INVALID, num_hits = 0;
+  if (valid) {
+    cnt[ORACLE_CNT_LIGHT_BVH]++;
+    light_id = trace_light_bvh(tr, hit_origin, lb->ray, self_inst, self_tri, rnd1(smp, RT_LIGHT_BSDF_TRACE), &num_hits);
+  }
+  valid = valid && light_id != LIGHT_ID_INVALID;
+  float dist = FLT_MAX;
+  uint32_t lh_inst = 0xFFFFFFFFu, lh_tri = 0;
+  RGBF lc = c_splat(0.0f);
+  if (light_id != LIGHT_ID_INVALID) {
+    lh_inst = s->light_tri_handles[2 * light_id]; lh_tri = s->light_tri_handles[2 * light_id + 1];
+    uint32_t uvp[3];
+    TriLight tl = light_triangle_init(s, lh_inst, lh_tri, uvp);
+    if (light_triangle_finalize_dist(&tl, uvp, hit_origin, lb->ray, &dist)) {
+      lc = light_get_color(s, &tl);
+      const float mis = mis_weight_gi(hit_origin, &tl, lc, dist, lb->sampling_probability, root_sum);
+      lc = c_scale(lc, mis * num_hits);
+      lc = c_mul(lc, lb->weight);
+    }
+    else valid = false;
+  }
+  RGBF vis = c_splat(0.0f);
+  if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, lb->ray, dist, lh_inst, lh_tri, self_inst, self_tri); }
+  lc = c_mul(lc, vis);
+  return c_mul(lc, volume_transmittance(s, volume_id, hit_origin, lb->ray, dist)); /* direct_lighting.cuh:661-666 */
+}
+/* ocean_get_context (ocean_utils.cuh:477-517): the water surface as a smooth translucent material */
+static GeoCtx ocean_get_context(const OracleScene* s, vec3 position, vec3 ray, uint16_t state, uint32_t medium) {
+  vec3 normal = ocean_get_normal(s, position);
+  const bool inside_water = v_dot(ray, normal) > 0.0f;
+  if (inside_water) normal = v_scale(normal, -1.0f);
+  uint32_t flags = MAT_TRANSLUCENT;
+  if (inside_water) flags |= MAT_REFRACTION_IS_INSIDE;
+  const float other_ior = medium_ior_peek(medium, inside_water);
+  const float ior_ratio = inside_water ? s->ocean_refractive_index / other_ior : other_ior / s->ocean_refractive_index;
+  const float roughness = (state & ST_DELTA_PATH) ? 0.02f * 2.0f : 0.25f; /* BSDF_ROUGHNESS_CLAMP * 2 */
+  GeoCtx g;
+  g.instance_id = HIT_TYPE_OCEAN; g.tri_id = 0;
+  g.normal = normal;
+  g.face_normal = normal_pack(normal);
+  g.position = position;
+  g.V = v_scale(ray, -1.0f);
+  g.state = state;
+  g.params.data[0] = g.params.data[1] = g.params.data[2] = 0;
+  g.params.flags = flags;
+  mp_set_albedo(&g.params, c_splat(1.0f));
+  mp_set_opacity(&g.params, 1.0f);
+  mp_set_roughness(&g.params, roughness);
+  mp_set_emission(&g.params, c_splat(0.0f));
+  mp_set_ior(&g.params, ior_ratio);
+  return g;
 }
 
 /* volume_process_events (volume.cuh:100-229): closed-form distance sampling. A path that scatters before its hit becomes a volume hit, the throughput
  * takes transmittance over sampling density; in the non-procedural sky modes a ray that left the scene adds the sky here and ends (sky fast path). */
-static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, OHit* hit_p, uint2_t* record_pp, RGBF* result_p) {
+static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origin, vec3 ray, uint16_t state, uint32_t volume_type, OHit* hit_p, uint2_t* record_pp, RGBF* result_p) {
   const Sampler smp = *smp_p;
   OHit hit = *hit_p;
   uint2_t record_p = *record_pp;
   RGBF result = *result_p;
   {
-      const OVolume vol = fog_volume(s);
-      OVolumePath path = volume_compute_path(s, &vol, origin, ray, hit.t);
+      const OVolume vol = volume_descriptor(s, volume_type);
+      OVolumePath path = volume_compute_path(s, &vol, origin, ray, hit.t, true);
       RGBF record = record_unpack(record_p);
       const bool sky_fast_path = hit.instance_id == HIT_TYPE_SKY && s->sky_mode != SKY_MODE_DEFAULT && (state & ST_ALLOW_AMBIENT) != 0;
       if (sky_fast_path) {
         RGBF sky = c_mul(sky_color_no_compute(s, origin, ray, state), record);
-        sky = c_scale(sky, volume_transmittance_length(&vol, path.length));
+        sky = c_mul(sky, volume_transmittance_length(&vol, path.length));
         beauty_add(&result, sky);
         hit.instance_id = HIT_TYPE_INVALID;
       }
-      const float intersection_probability = ((state & ST_DELTA_PATH) && !particle_is_hit(hit.instance_id)) ? 0.5f : 1.0f; /* bounds the variance of highlights seen through the fog */
+      float intersection_probability = ((state & ST_DELTA_PATH) && !particle_is_hit(hit.instance_id)) ? 0.5f : 1.0f; /* bounds the variance of highlights seen through the volume */
+      if (volume_type == VOLUME_TYPE_OCEAN && !s->ocean_multiscattering && (state & ST_DELTA_PATH) == 0) intersection_probability = 0.0f; /* single scattering in the water */
       const float2_t randoms = rnd2(&smp, RT_VOLUME_INTERSECTION);
       bool sampled = false;
       float pdf = 1.0f;
@@ -460,8 +708,8 @@ static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origi
         const float volume_dist = volume_sample_intersection(&vol, path.start, path.length, randoms.x);
         if (volume_dist < hit.t) {
           const float sample_pdf = volume_sample_intersection_pdf(&vol, path.start, volume_dist);
-          hit.t = volume_dist; hit.instance_id = HIT_TYPE_VOLUME_FOG; hit.tri_id = 0;
-          record = c_scale(record, vol.scattering);
+          hit.t = volume_dist; hit.instance_id = HIT_TYPE_VOLUME_BASE | volume_type; hit.tri_id = 0;
+          record = c_mul(record, vol.scat);
           pdf *= intersection_probability;
           pdf *= sample_pdf;
           sampled = true;
@@ -469,7 +717,7 @@ static void volume_events(const OracleScene* s, const Sampler* smp_p, vec3 origi
         }
       }
       if (!sampled && !sky_fast_path) pdf *= (1.0f - intersection_probability) + intersection_probability * volume_miss_probability(&vol, path.length);
-      record = c_scale(record, volume_transmittance_length(&vol, path.length));
+      record = c_mul(record, volume_transmittance_length(&vol, path.length));
       record = c_scale(record, 1.0f / pdf);
       record_p = record_pack(record);
   }
@@ -486,7 +734,13 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
   camera_sample(s, &smp, &origin, &ray);
   uint16_t state = ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_ALLOW_AMBIENT;
   uint2_t record_p = record_pack(c_splat(1.0f));
-  uint32_t medium = medium_ior_modify(0, 1.0f, true); /* kernels.cuh:172-174 with bsdf_refraction_index_ambient == 1 */
+  /* kernels.cuh:146, :172-186: the medium the camera is in (bsdf_refraction_index_ambient, bsdf_utils.cuh:128-133) and the volumes around it */
+  const float ambient_ior = (s->ocean_active && origin.y < s->ocean_height) ? s->ocean_refractive_index : 1.0f;
+  uint32_t medium = medium_ior_modify(0, ambient_ior, true);
+  uint32_t volumes = 0;
+  if (s->fog_active) volumes = volume_stack_modify(volumes, VOLUME_TYPE_FOG, true);
+  if (s->ocean_active && ocean_is_underwater(s, origin)) volumes = volume_stack_modify(volumes, VOLUME_TYPE_OCEAN, true);
+  const bool render_volumes = s->fog_active || s->ocean_active; /* device_manager.c:478 */
   uint32_t ign_inst = 0, ign_tri = 0;
   const RGBF sky_color = (s->sky_mode == SKY_MODE_CONSTANT_COLOR) ? c3(s->sky_constant_color[0], s->sky_constant_color[1], s->sky_constant_color[2]) : c_splat(0.0f);
 
@@ -495,11 +749,16 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     OHit hit = trace_closest(tr, origin, ray, (state & ST_USE_IGNORE_HANDLE) != 0, ign_inst, ign_tri);
     cnt[ORACLE_CNT_TRACE]++;
     particles_trace(s, tr, &smp, origin, ray, state, &hit);
-    if (s->fog_active) {
+    if (s->ocean_active) { /* optix_raytrace_ocean, optix_kernel_raytrace.cu:134-144 */
+      const float ocean_depth = ocean_intersection_distance(s, origin, ray, hit.t);
+      if (ocean_depth < hit.t) { hit.t = ocean_depth; hit.instance_id = HIT_TYPE_OCEAN; hit.tri_id = 0; }
+    }
+    const uint32_t top_volume = volume_stack_peek(volumes, false), second_volume = volume_stack_peek(volumes, true);
+    if (render_volumes && top_volume != VOLUME_TYPE_NONE) {
       /* device_renderer.c:64-76: in-scattering and its shadow pass, then the distance sampling (volume_process_events, volume.cuh:100-229) */
-      const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, cnt);
+      const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, top_volume, second_volume, cnt);
       beauty_add(&result, c_mul(in, record_unpack(record_p)));
-      volume_events(s, &smp, origin, ray, state, &hit, &record_p, &result);
+      volume_events(s, &smp, origin, ray, state, top_volume, &hit, &record_p, &result);
     }
     if (hit.instance_id == HIT_TYPE_SKY) {
       if (state & ST_ALLOW_AMBIENT) {
@@ -524,10 +783,10 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       record_p = record_pack(record);
     }
     if (hit.instance_id == HIT_TYPE_INVALID) break; /* the sky fast path of the volume events ended the path (no task type counts it) */
-    if (hit.instance_id == HIT_TYPE_VOLUME_FOG) { /* volume_process_tasks (volume.cuh:231-288); not queued at the last depth (device_renderer.c:114) */
+    if (hit.instance_id >= HIT_TYPE_VOLUME_BASE && hit.instance_id <= HIT_TYPE_VOLUME_MAX) { /* volume_process_tasks (volume.cuh:231-288); not queued at the last depth (device_renderer.c:114) */
       if (depth == s->max_ray_depth) break;
       origin = v_add(origin, v_scale(ray, hit.t));
-      const VolCtx vctx = volume_context(s, origin, ray, state, 0.0f);
+      const VolCtx vctx = volume_context(s, top_volume, origin, ray, state, 0.0f);
       ray = volume_bsdf_sample(s, &vctx, &smp, RT_VOL_GI_RESAMPLING, RT_VOL_GI_DIFFUSE);
       state &= ~(ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
       if (s->sky_mode != SKY_MODE_DEFAULT) state &= ~ST_ALLOW_AMBIENT; else state |= ST_ALLOW_AMBIENT;
@@ -547,14 +806,17 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       LightSample ls; ls.light_id = LIGHT_ID_INVALID; ls.light_color = c_splat(0.0f); ls.ray = v3(0, 0, 0); ls.dist = 0.0f;
       if (p_geo_allowed) {
         ls = particle_light_sample(s, &pc, &smp);
-        if (s->fog_active) ls.light_color = c_scale(ls.light_color, fog_transmittance(s, pc.position, ls.ray, ls.dist));
+        ls.light_color = c_mul(ls.light_color, volume_transmittance(s, top_volume, pc.position, ls.ray, ls.dist));
       }
       const bool p_sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
       uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
       if (p_sun_allowed) {
         const OSky sky_v = osky_view(s);
         RGBF lc; vec3 dir;
-        if (particle_sun_sample(s, &sky_v, &pc, &smp, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+        bool have;
+        if (top_volume == VOLUME_TYPE_OCEAN) { const SunCtx sc = {2, pc.position, state, &pc, NULL}; have = sun_caustic_sample(s, &sky_v, &sc, &smp, 0, top_volume, second_volume, &lc, &dir); }
+        else have = particle_sun_sample(s, &sky_v, &pc, top_volume, &smp, &lc, &dir);
+        if (have) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
       }
       /* bsdf_sample<MATERIAL_PARTICLE> with RANDOM_GI (bsdf.cuh:320-331): weight = albedo */
       const float random_choice = rnd1(&smp, RT_BSDF_RESAMPLING);
@@ -571,19 +833,8 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
           const RGBF vis = trace_shadow(tr, pc.position, ls.ray, ls.dist, s->light_tri_handles[2 * ls.light_id], s->light_tri_handles[2 * ls.light_id + 1], hit.instance_id, 0);
           acc = c_add(acc, c_mul(ls.light_color, vis));
         }
-        if ((sun_color.x != 0 || sun_color.y != 0) && p_sun_allowed) {
-          cnt[ORACLE_CNT_SHADOW]++;
-          const RGBF vis = trace_shadow(tr, pc.position, ray_unpack(sun_ray), FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, 0);
-          acc = c_add(acc, c_mul(record_unpack(sun_color), vis));
-        }
-        if ((amb_color.x != 0 || amb_color.y != 0) && p_ambient_allowed) {
-          const vec3 ar = ray_unpack(amb_ray);
-          cnt[ORACLE_CNT_SHADOW]++;
-          const RGBF vis = trace_shadow(tr, pc.position, ar, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, 0);
-          RGBF lc = c_mul(record_unpack(amb_color), vis);
-          if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, pc.position, ar, FLT_MAX));
-          acc = c_add(acc, lc);
-        }
+        if (p_sun_allowed) acc = c_add(acc, sun_evaluate(s, tr, cnt, pc.position, hit.instance_id, 0, top_volume, sun_color, sun_ray, true));
+        if (p_ambient_allowed) acc = c_add(acc, ambient_evaluate(s, tr, cnt, pc.position, hit.instance_id, 0, top_volume, second_volume, amb_color, amb_ray, true));
         beauty_add(&result, c_mul(acc, record_in));
       }
       uint16_t new_state = state & ~(ST_DELTA_PATH | ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
@@ -596,6 +847,46 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       ray = bounce;
       continue;
     }
+    if (hit.instance_id == HIT_TYPE_OCEAN) { /* ocean_process_tasks (ocean.cuh:12-102) and its share of the shadow pass */
+      const vec3 position = v_add(origin, v_scale(ray, hit.t));
+      const GeoCtx g = ocean_get_context(s, position, ray, state, medium);
+      const bool o_bsdf_allowed = lights_present && ((state & ST_VOLUME_SCATTERED) == 0);
+      LightBSDFSample lb; lb.sampling_probability = 0.0f; lb.weight = c_splat(0.0f); lb.ray = v3(0, 0, 1);
+      if (o_bsdf_allowed) lb = light_bsdf_get_sample(&luts, &g, &smp);
+      const bool o_sun_allowed = s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering;
+      uint2_t sun_color = {0, 0}, sun_ray = {0, 0};
+      if (o_sun_allowed) {
+        const OSky sky_v = osky_view(s);
+        RGBF lc; vec3 dir;
+        if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) {
+          lc = c_mul(lc, volume_transmittance(s, top_volume, g.position, dir, FLT_MAX));
+          sun_color = record_pack(lc); sun_ray = ray_pack(dir);
+        }
+      }
+      const BSDFSample bounce = bsdf_sample(&luts, &g, &smp, 0);
+      const RGBF record_in = record_unpack(record_p);
+      RGBF record = c_mul(record_in, bounce.weight);
+      const float shift_length = 8.0f * O_EPS * (1.0f + s->ocean_amplitude) * (1.0f + fabsf(s->ocean_height)); /* ocean_shift_vector, ocean_utils.cuh:519-523 */
+      const vec3 bounce_pos = v_add(g.position, v_scale(g.normal, bounce.is_transparent_pass ? -shift_length : shift_length));
+      {
+        RGBF acc = c_splat(0.0f);
+        acc = c_add(acc, bsdf_light_evaluate(s, tr, cnt, &smp, position, HIT_TYPE_OCEAN, 0, &lb, 0.0f, top_volume, o_bsdf_allowed));
+        if (o_sun_allowed) acc = c_add(acc, sun_evaluate(s, tr, cnt, position, HIT_TYPE_OCEAN, 0, top_volume, sun_color, sun_ray, true));
+        beauty_add(&result, c_mul(acc, record_in));
+      }
+      const uint16_t new_state = state & ~(ST_CAMERA_DIRECTION | ST_ALLOW_EMISSION | ST_USE_IGNORE_HANDLE);
+      if (!russian_roulette(s, &smp, state, &record)) break;
+      record_p = record_pack(record);
+      if (bounce.is_transparent_pass) {
+        const bool refr_inside = (g.params.flags & MAT_REFRACTION_IS_INSIDE) != 0;
+        medium = medium_ior_modify(medium, s->ocean_refractive_index, !refr_inside);
+        volumes = volume_stack_modify(volumes, VOLUME_TYPE_OCEAN, !refr_inside);
+      }
+      state = new_state;
+      origin = bounce_pos;
+      ray = bounce.ray;
+      continue;
+    }
     cnt[ORACLE_CNT_VERTICES]++;
     const vec3 hit_origin = v_add(origin, v_scale(ray, hit.t));
     const GeoCtx g = geometry_get_context(s, hit_origin, ray, state, hit.instance_id, hit.tri_id, medium);
@@ -606,7 +897,7 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     const bool geo_allowed = lights_present && ((state & ST_VOLUME_SCATTERED) == 0);
     if (geo_allowed) {
       ls = light_sample(s, &g, &smp); root_sum = ls.root_sum;
-      if (s->fog_active) ls.light_color = c_scale(ls.light_color, fog_transmittance(s, g.position, ls.ray, ls.dist)); /* direct_lighting.cuh:329-337 */
+      ls.light_color = c_mul(ls.light_color, volume_transmittance(s, top_volume, g.position, ls.ray, ls.dist)); /* direct_lighting.cuh:329-337 */
     }
     LightBSDFSample lb; lb.sampling_probability = 0.0f; lb.weight = c_splat(0.0f); lb.ray = v3(0, 0, 1);
     const bool bsdf_allowed = geo_allowed;
@@ -619,8 +910,12 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
     if (sun_allowed) {
       const OSky sky_v = osky_view(s);
       RGBF lc; vec3 dir;
-      if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) {
-        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, g.position, dir, FLT_MAX)); /* direct_lighting.cuh:104-108 */
+      if (top_volume == VOLUME_TYPE_OCEAN) { /* direct_lighting.cuh:368-380: a surface under water receives the sun through the water surface */
+        const SunCtx sc = {0, g.position, state, &g, &luts};
+        if (sun_caustic_sample(s, &sky_v, &sc, &smp, 0, top_volume, second_volume, &lc, &dir)) { sun_color = record_pack(lc); sun_ray = ray_pack(dir); }
+      }
+      else if (sun_sample(&sky_v, &luts, &g, &smp, &lc, &dir)) {
+        lc = c_mul(lc, volume_transmittance(s, top_volume, g.position, dir, FLT_MAX)); /* direct_lighting.cuh:104-108 */
         sun_color = record_pack(lc); sun_ray = ray_pack(dir);
       }
     }
@@ -661,51 +956,14 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
         }
         acc = c_add(acc, c_mul(ls.light_color, vis));
       }
-      { /* direct_lighting.cuh:586-667 */
-        bool valid = bsdf_allowed && lb.sampling_probability != 0.0f;
-        uint32_t light_id = LIGHT_ID_INVALID, num_hits = 0;
-        if (valid) {
-          cnt[ORACLE_CNT_LIGHT_BVH]++;
-          light_id = trace_light_bvh(tr, hit_origin, lb.ray, hit.instance_id, hit.tri_id, rnd1(&smp, RT_LIGHT_BSDF_TRACE), &num_hits);
-        }
-        valid = valid && light_id != LIGHT_ID_INVALID;
-        float dist = FLT_MAX;
-        uint32_t lh_inst = 0xFFFFFFFFu, lh_tri = 0;
-        RGBF lc = c_splat(0.0f);
-        if (light_id != LIGHT_ID_INVALID) {
-          lh_inst = s->light_tri_handles[2 * light_id]; lh_tri = s->light_tri_handles[2 * light_id + 1];
-          uint32_t uvp[3];
-          TriLight tl = light_triangle_init(s, lh_inst, lh_tri, uvp);
-          if (light_triangle_finalize_dist(&tl, uvp, hit_origin, lb.ray, &dist)) {
-            lc = light_get_color(s, &tl);
-            const float mis = mis_weight_gi(hit_origin, &tl, lc, dist, lb.sampling_probability, root_sum);
-            lc = c_scale(lc, mis * num_hits);
-            lc = c_mul(lc, lb.weight);
-          }
-          else valid = false;
-        }
-        RGBF vis = c_splat(0.0f);
-        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, lb.ray, dist, lh_inst, lh_tri, hit.instance_id, hit.tri_id); }
-        lc = c_mul(lc, vis);
-        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, hit_origin, lb.ray, dist)); /* direct_lighting.cuh:661-666 */
-        acc = c_add(acc, lc);
-      }
-      { /* direct_lighting.cuh:466-519 without ocean caustics */
-        const bool valid = (sun_color.x != 0 || sun_color.y != 0) && sun_allowed;
-        const vec3 sr = ray_unpack(sun_ray);
-        RGBF vis = c_splat(0.0f);
-        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, sr, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, hit.tri_id); }
-        RGBF lc = c_mul(record_unpack(sun_color), vis);
+      acc = c_add(acc, bsdf_light_evaluate(s, tr, cnt, &smp, hit_origin, hit.instance_id, hit.tri_id, &lb, root_sum, top_volume, bsdf_allowed));
+      { /* direct_lighting.cuh:466-519 */
+        RGBF lc = sun_evaluate(s, tr, cnt, hit_origin, hit.instance_id, hit.tri_id, top_volume, sun_color, sun_ray, sun_allowed);
         if (!sun_allowed) lc = c_splat(0.0f);
         acc = c_add(acc, lc);
       }
       { /* direct_lighting.cuh:521-584 */
-        const bool valid = (amb_color.x != 0 || amb_color.y != 0) && ambient_allowed;
-        const vec3 ar = ray_unpack(amb_ray);
-        RGBF vis = c_splat(0.0f);
-        if (valid) { cnt[ORACLE_CNT_SHADOW]++; vis = trace_shadow(tr, hit_origin, ar, FLT_MAX, 0xFFFFFFFFu, 0, hit.instance_id, hit.tri_id); }
-        RGBF lc = c_mul(record_unpack(amb_color), vis);
-        if (s->fog_active) lc = c_scale(lc, fog_transmittance(s, hit_origin, ar, FLT_MAX)); /* direct_lighting.cuh:561-563 */
+        RGBF lc = ambient_evaluate(s, tr, cnt, hit_origin, hit.instance_id, hit.tri_id, top_volume, second_volume, amb_color, amb_ray, ambient_allowed);
         if (!ambient_allowed) lc = c_splat(0.0f);
         acc = c_add(acc, lc);
       }
@@ -1102,7 +1360,7 @@ void oracle_probe_volume_path(const float cam_pos[3], float dist, float height, 
   sc.fog_active = 1; sc.fog_density = 1.0f; sc.fog_dist = dist; sc.fog_height = height;
   const OVolume vol = fog_volume(&sc);
   for (uint32_t i = 0; i < count; i++) {
-    const OVolumePath p = volume_compute_path(&sc, &vol, v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), limits[i]);
+    const OVolumePath p = volume_compute_path(&sc, &vol, v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), limits[i], false);
     out[2 * i] = p.start; out[2 * i + 1] = p.length;
   }
 }
@@ -1118,8 +1376,38 @@ void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const f
   }
 }
 void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf) {
-  const OVolume v = {scattering, 1.0f, 1.0f, 0.0f};
+  OVolume v;
+  memset(&v, 0, sizeof(v));
+  v.scattering = scattering; v.dist = 1.0f; v.max_height = 1.0f; v.type = VOLUME_TYPE_FOG;
   for (uint32_t i = 0; i < count; i++) { t[i] = volume_sample_bounded(&v, max_length, rnd[i]); pdf[i] = volume_sample_bounded_pdf(&v, max_length, t[i]); }
+}
+
+void oracle_probe_ocean_height(const OracleScene* s, uint32_t count, const float* xz, float* out) {
+  for (uint32_t i = 0; i < count; i++) out[i] = ocean_get_height(s, v3(xz[2 * i], 0.0f, xz[2 * i + 1]), OCEAN_ITERATIONS);
+}
+void oracle_probe_ocean_trace(const OracleScene* s, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out_t, float* out_residual,
+                              float* out_normal) {
+  for (uint32_t i = 0; i < count; i++) {
+    const vec3 o = v3(origins[3 * i], origins[3 * i + 1], origins[3 * i + 2]), d = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]);
+    const float t = ocean_intersection_distance(s, o, d, limits[i]);
+    out_t[i] = t;
+    out_residual[i] = 0.0f; out_normal[3 * i] = out_normal[3 * i + 1] = out_normal[3 * i + 2] = 0.0f;
+    if (t < limits[i]) {
+      const vec3 p = v_add(o, v_scale(d, t));
+      const vec3 n = ocean_get_normal(s, p);
+      out_residual[i] = ocean_relative_height(s, p, OCEAN_ITERATIONS);
+      out_normal[3 * i] = n.x; out_normal[3 * i + 1] = n.y; out_normal[3 * i + 2] = n.z;
+    }
+  }
+}
+void oracle_probe_ocean_fresnel(float ior, uint32_t count, const float* dirs, float* out_reflection, float* out_refracted) {
+  for (uint32_t i = 0; i < count; i++) {
+    const vec3 ray = v3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), normal = v3(0.0f, 1.0f, 0.0f);
+    bool total_reflection;
+    const vec3 refraction = refract_vector(v_scale(ray, -1.0f), normal, 1.0f / ior, &total_reflection);
+    out_reflection[i] = ocean_reflection_coefficient(normal, ray, refraction, 1.0f / ior);
+    out_refracted[3 * i] = refraction.x; out_refracted[3 * i + 1] = refraction.y; out_refracted[3 * i + 2] = refraction.z;
+  }
 }
 
 /* lattice tracer of the particles on explicit rays (tests/test_particles.py): pos in [0,1)^3, dir = direction / particles_scale */

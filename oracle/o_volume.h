@@ -4,15 +4,18 @@
  * transmittance), cuda/volume.cuh (in-scattering, events, bounce), cuda/light_bridges.cuh + light_common.cuh:17-32 (bridges to emissive
  * triangles), cuda/math.cuh:1169-1322 (phase functions), cuda/bsdf.cuh:302-318,:404-421,:458-474 (phase sampling as the volume's "BSDF"),
  * cuda/direct_lighting.cuh:20-121 (sun), :385-403,:521-584 (ambient), optix/optix_kernel_shadow_volume.cu.
- * Only the fog exists here (no ocean): the medium's volume stack holds the fog from tasks_create on (kernels.cuh:177-179) and nothing pops
- * it, so a path is in the fog iff fog_active. Numerics contract as everywhere: expf := o_exp, logf := o_log2 * ln 2, cbrtf := o_exp2(o_log2 / 3).
+ * Two volume types: the fog (scalar scattering, no absorption, a disk-box around the camera) and the ocean's water (RGB Jerlov coefficients, everything
+ * below the surface). A path carries a stack of the volumes it is in (medium_stack.cuh:29-45): the fog from tasks_create on, the water when the camera
+ * starts below the surface or a path refracts through it. Numerics contract as everywhere: expf := o_exp, logf := o_log2 * ln 2, cbrtf := o_exp2(o_log2 / 3).
  */
 #ifndef ORACLE_O_VOLUME_H
 #define ORACLE_O_VOLUME_H
 
-#include "o_sky.h"
+#include "o_ocean.h"
 
-#define HIT_TYPE_VOLUME_FOG 0xFFFE0001u /* VOLUME_ID_TO_HIT_ID(VOLUME_TYPE_FOG) = HIT_TYPE_VOLUME_BASE | 1 (cuda/utils.cuh:61,:85; utils.h:39) */
+#define HIT_TYPE_VOLUME_BASE 0xFFFE0000u /* VOLUME_ID_TO_HIT_ID(type) = HIT_TYPE_VOLUME_BASE | type (cuda/utils.cuh:61-63, :84-85; utils.h:39) */
+#define HIT_TYPE_VOLUME_MAX 0xFFFEFFFFu
+#define HIT_TYPE_VOLUME_FOG 0xFFFE0001u
 #define BRIDGES_HG_G 0.85f
 #define BRIDGES_FORWARD_PROB 0.95f
 #define BRIDGES_MAX_VERTEX_COUNT 15u
@@ -22,25 +25,47 @@ static inline float o_log(float x) { return o_log2(x) * 0.693147181f; }
 static inline float o_cbrt(float x) { return (x == 0.0f) ? 0.0f : copysignf(o_exp2(o_log2(fabsf(x)) * 0.333333333f), x); }
 static inline float o_clamp(float x, float a, float b) { return fminf(b, fmaxf(a, x)); }
 
-/* ---- descriptor (volume_utils.cuh:8-27: fog has a scalar scattering coefficient and no absorption) ---- */
-typedef struct { float scattering, dist, max_height, min_height; } OVolume;
-static inline OVolume fog_volume(const OracleScene* s) {
+/* ---- descriptors (volume_utils.cuh:8-57). `scattering` is the reference's max_scattering: what distances are sampled with ---- */
+enum { VOLUME_TYPE_NONE = 0, VOLUME_TYPE_FOG = 1, VOLUME_TYPE_OCEAN = 2 }; /* utils.h:39 */
+typedef struct { float scattering, dist, max_height, min_height; RGBF scat, absorb; float max_absorption; uint32_t type; } OVolume;
+static inline OVolume volume_descriptor(const OracleScene* s, uint32_t type) {
   OVolume v;
-  v.scattering = 0.001f * s->fog_density;
-  v.dist = s->fog_dist;
-  v.max_height = s->fog_height;
-  v.min_height = -65535.0f; /* no ocean */
+  memset(&v, 0, sizeof(v));
+  v.type = type;
+  if (type == VOLUME_TYPE_FOG) {
+    v.scattering = 0.001f * s->fog_density;
+    v.scat = c_splat(v.scattering); v.absorb = c_splat(0.0f); v.max_absorption = 0.0f;
+    v.dist = s->fog_dist;
+    v.max_height = s->fog_height;
+    v.min_height = s->ocean_active ? ocean_max_height(s) : -65535.0f;
+  }
+  else if (type == VOLUME_TYPE_OCEAN) {
+    v.absorb = c3(s->ocean_absorption[0], s->ocean_absorption[1], s->ocean_absorption[2]);
+    v.scat = c3(s->ocean_scattering[0], s->ocean_scattering[1], s->ocean_scattering[2]);
+    v.dist = 10000.0f; v.max_height = 65535.0f; v.min_height = -65535.0f;
+    v.max_absorption = c_importance(v.absorb);
+    v.scattering = c_importance(v.scat);
+  }
   return v;
 }
+static inline OVolume fog_volume(const OracleScene* s) { return volume_descriptor(s, VOLUME_TYPE_FOG); }
+/* the path's volume stack: four 8-bit ids, newest in the low byte (medium_stack_volume_peek / _modify, medium_stack.cuh:29-45, with 16-bit ids there) */
+static inline uint32_t volume_stack_peek(uint32_t stack, bool previous) { return previous ? (stack >> 8) & 0xFFu : stack & 0xFFu; }
+static inline uint32_t volume_stack_modify(uint32_t stack, uint32_t id, bool push) { return push ? (stack << 8) | id : stack >> 8; }
 
 /* volume_utils.cuh:88-170: start >= 0 iff the ray passes through the volume within `limit` */
 typedef struct { float start, length; } OVolumePath;
-static inline OVolumePath volume_compute_path(const OracleScene* s, const OVolume* vol, vec3 origin, vec3 ray, float limit) {
+static inline OVolumePath volume_compute_path(const OracleScene* s, const OVolume* vol, vec3 origin, vec3 ray, float limit, bool ocean_fast_path) {
   const OVolumePath none = {-FLT_MAX, 0.0f};
   if (limit <= 0.0f) return none;
   if (vol->max_height <= vol->min_height) return none;
+  if (vol->type == VOLUME_TYPE_NONE) return none;
   float start_y, end_y;
-  if (fabsf(ray.y) < 0.005f) {
+  if (vol->type == VOLUME_TYPE_OCEAN) {
+    start_y = 0.0f;
+    end_y = ocean_fast_path ? limit : ocean_intersection_distance(s, origin, ray, limit);
+  }
+  else if (fabsf(ray.y) < 0.005f) {
     if (origin.y >= vol->min_height && origin.y <= vol->max_height) { start_y = 0.0f; end_y = vol->dist; }
     else return none;
   }
@@ -84,14 +109,15 @@ static inline float volume_sample_bounded_pdf(const OVolume* v, float max_length
   const float prob_hit_at_max = 1.0f - o_exp(-v->scattering * max_length);
   return v->scattering * o_exp(-v->scattering * t) / prob_hit_at_max;
 }
-/* volume_integrate_transmittance_precomputed (volume_utils.cuh:245-254): the three channels are equal for the fog */
-static inline float volume_transmittance_length(const OVolume* v, float length) { return o_exp(-length * v->scattering); }
-/* volume_integrate_transmittance (volume_utils.cuh:292-308) of the volume a vertex is in: 1 without fog */
-static inline float fog_transmittance(const OracleScene* s, vec3 origin, vec3 ray, float depth) {
-  if (!s->fog_active) return 1.0f;
-  const OVolume v = fog_volume(s);
-  const OVolumePath p = volume_compute_path(s, &v, origin, ray, depth);
-  return (p.start >= 0.0f) ? o_exp(-p.length * v.scattering) : 1.0f;
+/* volume_integrate_transmittance_precomputed (volume_utils.cuh:245-254) */
+static inline RGBF volume_transmittance_length(const OVolume* v, float length) {
+  return c3(o_exp(-length * (v->absorb.r + v->scat.r)), o_exp(-length * (v->absorb.g + v->scat.g)), o_exp(-length * (v->absorb.b + v->scat.b)));
+}
+/* volume_integrate_transmittance (volume_utils.cuh:292-308) of the volume a vertex is in: 1 without one */
+static inline RGBF volume_transmittance(const OracleScene* s, uint32_t type, vec3 origin, vec3 ray, float depth) {
+  const OVolume v = volume_descriptor(s, type);
+  const OVolumePath p = volume_compute_path(s, &v, origin, ray, depth, false);
+  return (p.start >= 0.0f) ? volume_transmittance_length(&v, p.length) : c_splat(1.0f);
 }
 
 /* ---- phase functions (math.cuh:1169-1322); the Jendersie-Eon parameters of the droplet diameter come with the scene ---- */
@@ -138,28 +164,38 @@ static inline vec3 je_phase_sample(const float p[4], vec3 ray, float2_t r_dir, f
 }
 static inline vec3 fog_phase_sample(const OracleScene* s, vec3 ray, float2_t r_dir, float r_choice) { return je_phase_sample(s->fog_phase, ray, r_dir, r_choice); }
 
+/* the phase function is drawn from by volume type (bsdf.cuh:310-314; ocean_phase_sampling, ocean_utils.cuh:412-425) */
+static inline vec3 volume_phase_sample(const OracleScene* s, uint32_t type, vec3 ray, float2_t r_dir, float r_choice) {
+  if (type == VOLUME_TYPE_OCEAN) return phase_sample_basis(ocean_phase_sample_cos(s, r_dir.x, r_choice), r_dir.y, ray);
+  return fog_phase_sample(s, ray, r_dir, r_choice);
+}
+
 /* ---- the volume's shading context (material.cuh:76-89, volume_utils.cuh:310-321) ---- */
 typedef struct VolCtx { OVolume vol; vec3 position, V; uint16_t state; float max_dist; } VolCtx;
-static inline VolCtx volume_context(const OracleScene* s, vec3 origin, vec3 ray, uint16_t state, float max_dist) {
+static inline VolCtx volume_context(const OracleScene* s, uint32_t type, vec3 origin, vec3 ray, uint16_t state, float max_dist) {
   VolCtx c;
-  c.vol = fog_volume(s); c.position = origin; c.V = v_scale(ray, -1.0f); c.state = state; c.max_dist = max_dist;
+  c.vol = volume_descriptor(s, type); c.position = origin; c.V = v_scale(ray, -1.0f); c.state = state; c.max_dist = max_dist;
   return c;
 }
 /* bsdf_sample<MATERIAL_VOLUME> (bsdf.cuh:302-318): the weight is 1 */
 static inline vec3 volume_bsdf_sample(const OracleScene* s, const VolCtx* c, const Sampler* smp, uint32_t rt_resampling, uint32_t rt_diffuse) {
   const float random_choice = rnd1(smp, rt_resampling);
   const float2_t random_dir = rnd2(smp, rt_diffuse);
-  return fog_phase_sample(s, v_scale(c->V, -1.0f), random_dir, random_choice);
+  return volume_phase_sample(s, c->vol.type, v_scale(c->V, -1.0f), random_dir, random_choice);
 }
 /* volume_phase_evaluate (volume_utils.cuh:216-243) = bsdf_evaluate<VOLUME> = bsdf_sample_for_sun_pdf<VOLUME> */
-static inline float volume_phase_evaluate(const OracleScene* s, const VolCtx* c, vec3 L) { return fog_phase_function(s, -v_dot(c->V, L)); }
+static inline float volume_phase_evaluate(const OracleScene* s, const VolCtx* c, vec3 L) {
+  const float cos_angle = -v_dot(c->V, L);
+  return (c->vol.type == VOLUME_TYPE_OCEAN) ? ocean_phase(s, cos_angle) : fog_phase_function(s, cos_angle);
+}
 
 /* volume_sample_sky_dl_initial_vertex (volume_utils.cuh:323-352): moves the context to a vertex on the ray; returns its weight */
-static inline float volume_sky_initial_vertex(VolCtx* c, const Sampler* smp) {
+static inline RGBF volume_sky_initial_vertex(VolCtx* c, const Sampler* smp) {
   const float dist = volume_sample_bounded(&c->vol, c->max_dist, rnd1(smp, RT_LIGHT_SUN_INITIAL_VERTEX));
   c->position = v_add(c->position, v_scale(c->V, -dist));
-  const float w = o_exp(-dist * c->vol.scattering) * c->vol.scattering;
-  return w * (1.0f / volume_sample_bounded_pdf(&c->vol, c->max_dist, dist));
+  const RGBF w = c3(o_exp(-dist * (c->vol.absorb.r + c->vol.scat.r)) * c->vol.scat.r, o_exp(-dist * (c->vol.absorb.g + c->vol.scat.g)) * c->vol.scat.g,
+                    o_exp(-dist * (c->vol.absorb.b + c->vol.scat.b)) * c->vol.scat.b);
+  return c_scale(w, 1.0f / volume_sample_bounded_pdf(&c->vol, c->max_dist, dist));
 }
 
 /* direct_lighting_sun_create_task + direct_lighting_sun_direct for a volume vertex (direct_lighting.cuh:20-121, :352-383; random set LIGHT_SUN<1>) */
@@ -171,7 +207,7 @@ static inline bool volume_sun_sample(const OracleScene* s, const OSky* sky, cons
   /* bsdf_sample_for_sun<VOLUME>, bsdf.cuh:404-421 */
   const float2_t random_dir = rnd2(smp, RT_VOL_SUN_BSDF);
   const float random_method = rnd1(smp, RT_VOL_SUN_BSDF_METHOD);
-  const vec3 dir_bsdf = fog_phase_sample(s, v_scale(c->V, -1.0f), random_dir, random_method);
+  const vec3 dir_bsdf = volume_phase_sample(s, c->vol.type, v_scale(c->V, -1.0f), random_dir, random_method);
   RGBF light_bsdf = c_splat(0.0f);
   if (sphere_hit(dir_bsdf, sky_pos, sky->sun_pos, SKY_SUN_RADIUS)) light_bsdf = c_mul(sky_sun_color(sky, sky_pos, dir_bsdf), c_splat(volume_phase_evaluate(s, c, dir_bsdf) * 1.0f));
   float solid_angle;
@@ -191,7 +227,7 @@ static inline bool volume_sun_sample(const OracleScene* s, const OSky* sky, cons
   if (target == 0.0f) return false;
   if (c_importance(light) == 0.0f) return false;
   /* volume transmittance towards the sun (direct_lighting.cuh:104-108) */
-  *light_out = c_scale(light, fog_transmittance(s, c->position, *dir_out, FLT_MAX));
+  *light_out = c_mul(light, volume_transmittance(s, c->vol.type, c->position, *dir_out, FLT_MAX));
   return true;
 }
 
@@ -277,14 +313,15 @@ static inline RGBF bridges_sample_bridge(const OracleScene* s, const VolCtx* c, 
   *scale = target_scale / actual_scale;
   sum_dist *= *scale;
   *end_vertex = current_vertex;
-  const float sc = c->vol.scattering; /* absorption 0 */
-  const float w = o_exp(vertex_count * o_log(sc) - sum_dist * (sc + 0.0f));
+  const RGBF sc = c->vol.scat, ab = c->vol.absorb;
+  const RGBF w = c3(o_exp(vertex_count * o_log(sc.r) - sum_dist * (sc.r + ab.r)), o_exp(vertex_count * o_log(sc.g) - sum_dist * (sc.g + ab.g)),
+                    o_exp(vertex_count * o_log(sc.b) - sum_dist * (sc.b + ab.b)));
   const float log_path_pdf = bridges_log_factorial(vertex_count) - vertex_count * o_log(sum_dist);
   *path_pdf = vertex_count_pdf * o_exp(log_path_pdf) * target_scale * target_scale * target_scale;
-  return c_splat(w);
+  return w;
 }
 /* :224-266 */
-static inline vec3 bridges_sample_initial_vertex(const VolCtx* c, vec3 point_on_light, const Sampler* smp, uint32_t output_id, float* attenuation, float* pdf) {
+static inline vec3 bridges_sample_initial_vertex(const VolCtx* c, vec3 point_on_light, const Sampler* smp, uint32_t output_id, RGBF* attenuation, float* pdf) {
   float random_intersection = rnd1(smp, RT_LIGHT_GEO_INITIAL_VERTEX + output_id);
   const vec3 PO = v_sub(point_on_light, c->position);
   const float dist_to_light = fmaxf(-v_dot(PO, c->V), 0.0f);
@@ -303,7 +340,8 @@ static inline vec3 bridges_sample_initial_vertex(const VolCtx* c, vec3 point_on_
     *pdf = 1.0f - forward_prob;
   }
   const float t = t_offset + volume_sample_bounded(&c->vol, max_dist, random_intersection);
-  *attenuation = o_exp(-t * c->vol.scattering) * c->vol.scattering;
+  *attenuation = c3(o_exp(-t * (c->vol.absorb.r + c->vol.scat.r)) * c->vol.scat.r, o_exp(-t * (c->vol.absorb.g + c->vol.scat.g)) * c->vol.scat.g,
+                    o_exp(-t * (c->vol.absorb.b + c->vol.scat.b)) * c->vol.scat.b);
   *pdf *= volume_sample_bounded_pdf(&c->vol, max_dist, t - t_offset);
   return v_add(c->position, v_scale(c->V, -t));
 }
@@ -332,13 +370,13 @@ static inline BridgeSample bridges_sample(const OracleScene* s, const VolCtx* c,
   res.light_id = LIGHT_ID_INVALID; res.light_color = c_splat(0.0f); res.seed = 0; res.rotation.x = res.rotation.y = res.rotation.z = 0.0f; res.rotation.w = 1.0f; res.scale = 0.0f;
   *target = 0.0f; *weight = 1.0f;
   const vec3 point_on_light = light_triangle_sample_bridges(light, rnd2(smp, RT_BRIDGE_LIGHT_POINT + output_id));
-  float initial_attenuation, initial_pdf;
+  RGBF initial_attenuation; float initial_pdf;
   const vec3 initial_vertex = bridges_sample_initial_vertex(c, point_on_light, smp, output_id, &initial_attenuation, &initial_pdf);
-  if (initial_pdf == 0.0f || initial_attenuation == 0.0f) return res;
+  if (initial_pdf == 0.0f || c_importance(initial_attenuation) == 0.0f) return res;
   vec3 light_dir; float area, light_dist;
   light_triangle_finalize_bridges(light, uvp, initial_vertex, point_on_light, &light_dir, &light_dist, &area);
   if (light_dist == FLT_MAX || area < O_EPS) return res;
-  RGBF light_color = c_scale(light_get_color(s, light), initial_attenuation);
+  RGBF light_color = c_mul(light_get_color(s, light), initial_attenuation);
   if (c_importance(light_color) == 0.0f) return res;
   const vec3 light_point = v_add(initial_vertex, v_scale(light_dir, light_dist));
   if (light_point.y < c->vol.min_height || light_point.y > c->vol.max_height) return res;
@@ -367,7 +405,7 @@ static inline float light_tree_importance_volume(const VolCtx* c, float power, v
   const float falloff = 1.0f / (perp_sq + std_dev);
   const float variance = std_dev * std_dev;
   const float transmittance_depth = fmaxf(perp_sq + clamped * clamped - variance, 0.0f);
-  const float transmittance = o_exp(-0.0f * transmittance_depth);
+  const float transmittance = o_exp(-c->vol.max_absorption * transmittance_depth);
   const float scattering = 1.0f - o_exp(-c->vol.scattering * (variance + clamped));
   return power * falloff * transmittance * scattering;
 }

@@ -95,6 +95,15 @@ typedef struct OracleScene {
   float particles_phase[4];           /* Jendersie-Eon parameters of phase_diameter */
   const float* particle_vertices;     /* 6 x float4 per particle: two triangles (a00, a01, a10), (a11, a01, a10), w = 1 */
   const float* particle_normals;      /* float4 per particle: the quad's normal */
+  /* ocean (device_structs.c ocean convert; cuda/ocean_utils.cuh): a procedural height field at y = ocean_height, water below it (the second volume type).
+   * The Jerlov water type's coefficients (ocean_utils.cuh:291-385) are looked up by the host layer. */
+  uint32_t ocean_active;
+  float ocean_height, ocean_amplitude, ocean_frequency, ocean_refractive_index;
+  float ocean_scattering[3], ocean_absorption[3];
+  float ocean_molecular_weight;
+  uint32_t ocean_caustics_active, ocean_caustics_ris_sample_count;
+  float ocean_caustics_domain_scale;
+  uint32_t ocean_multiscattering, ocean_triangle_light_contribution;
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -203,5 +212,12 @@ void oracle_probe_fog_phase(const OracleScene* s, uint32_t count, const float* c
 void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const float* rnd, float* out);
 void oracle_probe_particle_trace(const OracleScene* s, uint32_t count, const float* pos, const float* dir, const float* tmax, float* out_t, uint32_t* out_tri);
 void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf);
+
+/* ocean (o_ocean.h): heights at (x, z) pairs; per ray the intersection distance, the height of the end point above the surface and the normal there;
+ * the Fresnel reflection coefficient of the flat surface per incident direction (from above: index_in_over_out = 1 / ior) */
+void oracle_probe_ocean_height(const OracleScene* s, uint32_t count, const float* xz, float* out);
+void oracle_probe_ocean_trace(const OracleScene* s, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out_t, float* out_residual,
+                              float* out_normal);
+void oracle_probe_ocean_fresnel(float ior, uint32_t count, const float* dirs, float* out_reflection, float* out_refracted);
 
 #endif
