@@ -171,6 +171,11 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         fog.active, fog.density = True, args.fog
         host.set_fog(fog)
         label += " in fog of density %g" % args.fog
+    if args.ocean is not None:  # not a BASELINE configuration either: the same scene with the reference's ocean at this height (f4)
+        oc = host.get_ocean()
+        oc.active, oc.height = True, args.ocean
+        host.set_ocean(oc)
+        label += " with the ocean at height %g" % args.ocean
     view = host.device_scene()
     build_s = time.time() - t_build
     t_up = time.time()
@@ -334,6 +339,7 @@ def main():
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
+    ap.add_argument("--ocean", type=float, default=None, help="height of an ocean surface put into the scene (default: none, the BASELINE configurations)")
     ap.add_argument("--fog", type=float, default=0.0, help="density of the fog volume the scene is put in (0 = none, the BASELINE configurations)")
     ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],
                     help="constant = the benchmark settings (SURVEY §8d); procedural = sky mode DEFAULT: ray-marched atmosphere and sun sampling")

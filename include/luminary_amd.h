@@ -15,10 +15,10 @@
  * Scope of this implementation: the triangle / BSDF / NEE path with the thin-lens camera under every sky mode
  * (constant colour, procedural atmosphere with sun, moon and stars, baked panorama), the fog volume (scattering events, light scattered in
  * from sun, sky and - over multi-vertex bridges - emissive triangles), particles, the ocean (ray-marched height field, Jerlov water volume,
- * sun and sky light through the surface with caustics), textures, adaptive sampling, the undersampling preview, the display chain with
- * bloom, and the debug shading modes. Rendering runs on the library's own "Device" thread once luminary_host_start_new_render was
- * called, like the reference's. Clouds and the physical camera are stored and returned unchanged but do not influence the image yet
- * (DESIGN.md section 7).
+ * sun and sky light through the surface with caustics), clouds (three ray-marched layers over generated noise textures, procedural sky
+ * mode, baked into the panorama in HDRI mode; their shadow in the aerial perspective), textures, adaptive sampling, the undersampling preview, the display chain with bloom,
+ * and the debug shading modes. Rendering runs on the library's own "Device" thread once luminary_host_start_new_render was called,
+ * like the reference's. The physical camera is stored and returned unchanged but does not influence the image yet.
  *
  * Additive extension (the reference only returns tone-mapped ARGB8): the luminary_ext_* functions at the
  * end give access to float radiance, ray counters and batch rendering. Existing symbols are untouched.

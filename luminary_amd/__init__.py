@@ -88,6 +88,19 @@ class Ocean(C.Structure):
                 ("multiscattering", C.c_bool), ("triangle_light_contribution", C.c_bool)]
 
 
+class CloudLayer(C.Structure):
+    _fields_ = [("active", C.c_bool), ("height_max", C.c_float), ("height_min", C.c_float), ("coverage", C.c_float), ("coverage_min", C.c_float),
+                ("type", C.c_float), ("type_min", C.c_float), ("wind_speed", C.c_float), ("wind_angle", C.c_float)]
+
+
+class Cloud(C.Structure):
+    """LuminaryCloud (include/luminary_amd.h; defaults cloud.c:6-52)."""
+    _fields_ = [("active", C.c_bool), ("initialized", C.c_bool), ("atmosphere_scattering", C.c_bool), ("low", CloudLayer), ("mid", CloudLayer),
+                ("top", CloudLayer), ("offset_x", C.c_float), ("offset_z", C.c_float), ("density", C.c_float), ("seed", C.c_uint32),
+                ("droplet_diameter", C.c_float), ("steps", C.c_uint32), ("shadow_steps", C.c_uint32), ("noise_shape_scale", C.c_float),
+                ("noise_detail_scale", C.c_float), ("noise_weather_scale", C.c_float), ("mipmap_bias", C.c_float), ("octaves", C.c_uint32)]
+
+
 class Particles(C.Structure):
     """LuminaryParticles (include/luminary_amd.h; defaults particles.c:6-24)."""
     _fields_ = [("active", C.c_bool), ("seed", C.c_uint32), ("count", C.c_uint32), ("albedo", RGBF), ("speed", C.c_float), ("direction_altitude", C.c_float),
@@ -158,7 +171,12 @@ class DeviceSceneView(C.Structure):
                 ("ocean_active", C.c_uint32), ("ocean_height", C.c_float), ("ocean_amplitude", C.c_float), ("ocean_frequency", C.c_float),
                 ("ocean_refractive_index", C.c_float), ("ocean_scattering", C.c_float * 3), ("ocean_absorption", C.c_float * 3),
                 ("ocean_molecular_weight", C.c_float), ("ocean_caustics_active", C.c_uint32), ("ocean_caustics_ris_sample_count", C.c_uint32),
-                ("ocean_caustics_domain_scale", C.c_float), ("ocean_multiscattering", C.c_uint32), ("ocean_triangle_light_contribution", C.c_uint32)]
+                ("ocean_caustics_domain_scale", C.c_float), ("ocean_multiscattering", C.c_uint32), ("ocean_triangle_light_contribution", C.c_uint32),
+                ("cloud_active", C.c_uint32), ("cloud_atmosphere_scattering", C.c_uint32), ("cloud_steps", C.c_uint32), ("cloud_shadow_steps", C.c_uint32),
+                ("cloud_octaves", C.c_uint32), ("cloud_seed", C.c_uint32), ("cloud_offset_x", C.c_float), ("cloud_offset_z", C.c_float),
+                ("cloud_density", C.c_float), ("cloud_noise_shape_scale", C.c_float), ("cloud_noise_detail_scale", C.c_float),
+                ("cloud_noise_weather_scale", C.c_float), ("cloud_phase", C.c_float * 4), ("cloud_layers", (C.c_float * 10) * 3),
+                ("cloud_noise_shape", C.c_void_p), ("cloud_noise_detail", C.c_void_p), ("cloud_noise_weather", C.c_void_p)]
 
 
 SKY_MODE_DEFAULT, SKY_MODE_HDRI, SKY_MODE_CONSTANT_COLOR = 0, 1, 2
@@ -272,6 +290,12 @@ class Host:
 
     def set_ocean(self, o):
         _call("luminary_host_set_ocean", self._h, C.byref(o))
+
+    def get_cloud(self):
+        return self._get("cloud", Cloud)
+
+    def set_cloud(self, c):
+        _call("luminary_host_set_cloud", self._h, C.byref(c))
 
     def get_particles(self):
         return self._get("particles", Particles)

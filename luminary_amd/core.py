@@ -182,6 +182,13 @@ class Core:
         self._call("lumc_download_sky_luts", tm.ctypes.data_as(C.c_void_p), ms.ctypes.data_as(C.c_void_p))
         return tm, ms
 
+    def cloud_noise_generate(self, seed):
+        """The clouds' noise textures as the core generates them: (shape [128^3], detail [32^3], weather [1024^2]) as uint32 RGBA8."""
+        shape, detail, weather = np.zeros(128 ** 3, np.uint32), np.zeros(32 ** 3, np.uint32), np.zeros(1024 ** 2, np.uint32)
+        self._call("lumc_cloud_noise_generate", C.c_uint32(seed), shape.ctypes.data_as(C.c_void_p), detail.ctypes.data_as(C.c_void_p),
+                   weather.ctypes.data_as(C.c_void_p))
+        return shape, detail, weather
+
     def sky_hdri_build(self, origin, dim, samples):
         """Bakes the procedural sky seen from `origin` (world space) and returns it as [dim, dim, 4] float32."""
         o = (C.c_float * 3)(*[float(x) for x in origin])

@@ -122,6 +122,15 @@ struct DeviceScene {
   uint32_t ocean_caustics_active, ocean_caustics_ris_sample_count;
   float ocean_caustics_domain_scale;
   uint32_t ocean_multiscattering, ocean_triangle_light_contribution;
+  // clouds (dev_cloud.h): layer rows = active, height_max, height_min, coverage, coverage_min, type, type_min, wind_speed, cos, sin of wind_angle;
+  // RGBA8 noise: shape 128^3, detail 32^3, weather 1024^2
+  uint32_t cloud_active, cloud_atmosphere_scattering, cloud_steps, cloud_shadow_steps, cloud_octaves;
+  float cloud_offset_x, cloud_offset_z, cloud_density, cloud_noise_shape_scale, cloud_noise_detail_scale, cloud_noise_weather_scale;
+  float cloud_phase[4];
+  float cloud_layers[3][10];
+  const uint32_t* cloud_noise_shape;
+  const uint32_t* cloud_noise_detail;
+  const uint32_t* cloud_noise_weather;
   // particles (dev_particle.h): quads of the unit cell, tiled 25^3 times in a space scaled by particles_scale; their own two-level tree
   uint32_t particles_active, particles_count;
   float particles_scale, particles_speed;

@@ -122,6 +122,8 @@ struct SkyView {
   uint32_t moon_albedo_tex, moon_normal_tex, stars_count;
   const float4* stars;
   const uint32_t* stars_offsets;
+  const float4* cloud_hdri;  // the panorama when its fourth channel (the baked clouds' transmittance) dims the sun: HDRI mode with active clouds
+  uint32_t cloud_hdri_dim;
 };
 
 LUM_DEV SkyView sky_view(const DeviceScene& sc) {
@@ -138,6 +140,8 @@ LUM_DEV SkyView sky_view(const DeviceScene& sc) {
   s.moon_tex_offset = sc.sky_moon_tex_offset; s.stars_intensity = sc.sky_stars_intensity;
   s.moon_albedo_tex = sc.sky_moon_albedo_tex; s.moon_normal_tex = sc.sky_moon_normal_tex; s.stars_count = sc.sky_stars_count;
   s.stars = sc.sky_stars; s.stars_offsets = sc.sky_stars_offsets;
+  const bool cloud_hdri = sc.cloud_active && sc.sky_mode == kSkyHdri && sc.sky_hdri != nullptr && sc.sky_hdri_dim != 0u;
+  s.cloud_hdri = cloud_hdri ? sc.sky_hdri : nullptr; s.cloud_hdri_dim = cloud_hdri ? sc.sky_hdri_dim : 0u;
   return s;
 }
 
@@ -355,10 +359,14 @@ LUM_DEV V3 angles_to_direction(float altitude, float azimuth) {
   return v3(cz * ca, sa, sz * ca);
 }
 
-// ---- sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars (no clouds: their shadow term is 1).
-// `transmittance_out` is multiplied by the transmittance of the marched segment. ----
-LUM_DEV Spectrum sky_compute_atmosphere(const DeviceScene& sc, const SkyView& s, Spectrum& transmittance_out, V3 origin, V3 ray, float limit, bool celestials, int steps,
-                                        float random_offset) {
+LUM_NS_END
+#include "dev_cloud.h"
+LUM_NS_BEGIN
+
+// ---- sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars. `cloud_shadows`: the sun's single scattering
+// is shadowed by the cloud layers (dev_cloud.h). `transmittance_out` is multiplied by the transmittance of the marched segment. ----
+LUM_DEV Spectrum sky_compute_atmosphere(const DeviceScene& sc, const SkyView& s, Spectrum& transmittance_out, V3 origin, V3 ray, float limit, bool celestials, bool cloud_shadows,
+                                        int steps, float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const F2 path = sky_compute_path(origin, ray, kSkyEarthRadius, kSkyAtmoRadius);
   const float start = path.x, distance = fminf(path.y, limit - start);
@@ -376,7 +384,7 @@ LUM_DEV Spectrum sky_compute_atmosphere(const DeviceScene& sc, const SkyView& s,
       const float cos_angle = dot(ray, ray_scatter);
       const float zenith_cos = dot(normalize(pos), ray_scatter);
       const float phase_r = sky_rayleigh_phase(cos_angle), phase_m = sky_mie_phase(s, cos_angle);
-      const float shadow = sph_hit_p0(ray_scatter, pos, kSkyEarthRadius) ? 0.0f : 1.0f;
+      const float shadow = sph_hit_p0(ray_scatter, pos, kSkyEarthRadius) ? 0.0f : (cloud_shadows ? cloud_shadow(sc, pos, ray_scatter) : 1.0f);
       const F2 uv = sky_transmittance_uv(height, zenith_cos);
       const Spectrum extinction_sun = sky_lut_fetch(s.tm, kSkyTmWidth, kSkyTmHeight, uv.x, uv.y);
       const SkyMedium m = sky_medium(s, height);
@@ -442,7 +450,7 @@ LUM_DEV Spectrum sky_compute_atmosphere(const DeviceScene& sc, const SkyView& s,
 // sky_get_color, sky.cuh:508-515
 LUM_DEV Col sky_get_color(const DeviceScene& sc, const SkyView& s, V3 origin, V3 ray, float limit, bool celestials, int steps, float random_offset) {
   Spectrum unused = sp_set1(0.0f);
-  return sky_color_from_spectrum(sky_compute_atmosphere(sc, s, unused, origin, ray, limit, celestials, steps, random_offset));
+  return sky_color_from_spectrum(sky_compute_atmosphere(sc, s, unused, origin, ray, limit, celestials, false, steps, random_offset));
 }
 // Aerial perspective, sky_trace_inscattering (sky.cuh:517-532): the air between a ray's origin and its hit scatters sun light towards the
 // viewer and dims what lies behind. `limit` in sky units (km); returns the in-scattered colour times `record`, and dims `record`.
@@ -450,7 +458,7 @@ LUM_DEV Col sky_trace_inscattering(const DeviceScene& sc, const SkyView& s, V3 o
   Spectrum transmittance = sp_set1(1.0f);
   const float base_range = primary_ray ? 40.0f : 80.0f;
   const int steps = (int) (fminf(fmaxf(0.5f, limit / base_range), 2.0f) * (float) (s.steps / 6u) + step_random - 0.5f);
-  const Spectrum radiance = sky_compute_atmosphere(sc, s, transmittance, origin, ray, limit, false, steps, random_offset);
+  const Spectrum radiance = sky_compute_atmosphere(sc, s, transmittance, origin, ray, limit, false, true, steps, random_offset);
   const Col inscattering = sky_color_from_spectrum(radiance) * record;
   record = record * sky_color_from_spectrum(transmittance);
   return inscattering;
@@ -476,41 +484,7 @@ LUM_DEV float sky_hdri_median_of_means(float* buckets, uint32_t num_buckets) {  
   for (uint32_t b = c; b < num_buckets - c; b++) output += buckets[b];
   return output / (float) (num_buckets - 2u * c);
 }
-#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
-__global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, float oy, float oz, uint32_t dim, uint32_t sample_count, float4* __restrict__ dst) {
-  __shared__ float values[256];
-  const uint32_t pixel = (blockIdx.x * 256u + threadIdx.x) >> 5, lane = threadIdx.x & 31u;
-  const bool in_range = pixel < dim * dim;
-  const uint32_t y = in_range ? pixel / dim : 0u, x = in_range ? pixel - y * dim : 0u;
-  const SkyView sky = sky_view(sc);
-  const float step_size = 1.0f / (float) (dim - 1u);
-  Col color = splat(0.0f);
-  uint32_t num_samples = 0;
-  if (in_range) {
-    for (uint32_t sample_id = lane; sample_id < sample_count; sample_id += 32u) {
-      const Sampler smp{sc.bluenoise_2d, x, y, sample_id, 0};
-      const F2 jitter = smp.next2(kRndCameraJitter);
-      const float u = ((float) x + jitter.x) * step_size, v = 1.0f - ((float) y + jitter.y) * step_size;
-      const float altitude = kPi * v - 0.5f * kPi, azimuth = 2.0f * kPi * u - kPi;
-      const V3 ray = angles_to_direction(altitude, azimuth);
-      color = color + sky_get_color(sc, sky, world_to_sky(sky, v3(ox, oy, oz)), ray, kFltMax, false, (int) sky.steps, smp.next1(kRndSkyStepOffset));
-      num_samples++;
-    }
-  }
-  const uint32_t buckets = min(32u, sample_count);
-  float* group = values + (threadIdx.x & ~31u);
-  float out[3];
-  const float mean[3] = {num_samples ? color.r / (float) num_samples : 0.0f, num_samples ? color.g / (float) num_samples : 0.0f, num_samples ? color.b / (float) num_samples : 0.0f};
-#pragma unroll
-  for (int ch = 0; ch < 3; ch++) {
-    __syncthreads();
-    values[threadIdx.x] = mean[ch];
-    __syncthreads();
-    out[ch] = (lane == 0u && in_range) ? sky_hdri_median_of_means(group, buckets) : 0.0f;
-  }
-  if (lane == 0u && in_range) dst[x + y * dim] = make_float4(out[0], out[1], out[2], 0.0f);
-}
-#endif
+// (the bake kernel k_sky_hdri is in kernels.h: it marches the clouds, dev_cloud_march.h)
 
 // ---- sun next-event estimation (cuda/direct_lighting.cuh:21-119, :352-383; cuda/bsdf.cuh:355-458) ----
 LUM_DEV bool sphere_hit(V3 ray, V3 origin, V3 p, float r) {  // math.cuh:679-696
@@ -550,12 +524,22 @@ LUM_DEV V3 sample_sphere(V3 p, float r, V3 origin, F2 random, float& area) {
   return normalize(sample_hemisphere_basis(u, v, dir));
 }
 // sky_utils.cuh:318-347 (no clouds, no HDRI)
-LUM_DEV Col sky_sun_color(const SkyView& s, V3 origin, V3 ray) {
+// sky_get_sun_color (sky_utils.cuh:318-347); `include_cloud_hdri`: in HDRI mode with active clouds the panorama's fourth channel dims the sun
+LUM_DEV Col sky_sun_color(const SkyView& s, V3 origin, V3 ray, bool include_cloud_hdri = true) {
   const float height = sky_height(origin);
   const float zenith_cos = dot(normalize(origin), ray);
   const F2 uv = sky_transmittance_uv(height, zenith_cos);
   const Spectrum extinction_sun = sp_mul(sp_ident(), sky_lut_fetch(s.tm, kSkyTmWidth, kSkyTmHeight, uv.x, uv.y));
-  return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(sky_sun_radiance(), s.sun_strength)));
+  Col sun_color = sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(sky_sun_radiance(), s.sun_strength)));
+  if (include_cloud_hdri && s.cloud_hdri != nullptr) {
+    const float theta = atan2_det(ray.z, ray.x), phi = asin_det(ray.y);
+    const float u = (theta + kRefPi) / (2.0f * kRefPi);
+    const float v = 1.0f - ((phi + 0.5f * kRefPi) / kRefPi);
+    const float dim = (float) s.cloud_hdri_dim;
+    const uint32_t x = (uint32_t) ((u - floorf(u)) * dim) % s.cloud_hdri_dim, y = (uint32_t) ((v - floorf(v)) * dim) % s.cloud_hdri_dim;
+    sun_color = sun_color * s.cloud_hdri[x + (size_t) y * s.cloud_hdri_dim].w;
+  }
+  return sun_color;
 }
 // ---- baked panorama as the sky (sky mode HDRI) ----
 // sky_hdri_sample, sky_utils.cuh:49-63: equirectangular lookup, nearest texel (device_sky.c:352), wrap addressing (texture_create's

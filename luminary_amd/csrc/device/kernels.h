@@ -18,6 +18,7 @@
 #include "dev_volume.h"
 #include "dev_particle.h"
 #include "dev_water.h"
+#include "dev_cloud_march.h"
 
 LUM_NS_BEGIN
 
@@ -1170,6 +1171,90 @@ __global__ __launch_bounds__(kBlock) void k_ocean_shade(DeviceScene sc, PathQueu
     }
   }
 }
+
+// ---- clouds ----
+// cloud_process_tasks (cloud.cuh:340-384; device_renderer.c:78-82): after the volume events, every path is marched through the cloud layers up to its
+// hit. The scattered light goes to the path's result, its throughput takes the layers' (and, with atmosphere_scattering, the air's) transmittance,
+// and its origin moves up to the last layer entered so that the aerial-perspective pass and the sky see the rest of the ray.
+__global__ __launch_bounds__(kBlock) void k_clouds(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const SkyView sky = sky_view(sc);
+  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const uint4 hid = in.hit_id[i];
+    if (hid.x == kHitInvalid) continue;  // ended by the sky fast path of the volume events (no task exists for it in the reference)
+    float4 o4 = in.origin_t[i];
+    const float4 d4 = in.dir_slot[i];
+    uint4 aux = in.aux[i];
+    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+    const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
+    Col record = record_unpack(U2{aux.x, aux.y});
+    Col color = splat(0.0f);
+    float cloud_transmittance = 1.0f;
+    const float cloud_offset = clouds_render(sc, sky, smp, world_to_sky(sky, origin), ray, o4.w * 0.001f, color, record, cloud_transmittance);
+    if (sc.cloud_atmosphere_scattering && cloud_offset != kFltMax && cloud_offset > 0.0f) {
+      const float cloud_world_offset = cloud_offset * 1000.0f;
+      const V3 moved = origin + ray * cloud_world_offset;
+      o4.x = moved.x; o4.y = moved.y; o4.z = moved.z;
+      if (o4.w != kFltMax) o4.w -= cloud_world_offset;
+      in.origin_t[i] = o4;
+    }
+    const U2 rp = record_pack(record);
+    aux.x = rp.x; aux.y = rp.y;
+    in.aux[i] = aux;
+    add_to_result(results, fbits(d4.w), color);
+  }
+}
+
+// ---- HDRI bake (cuda/sky_hdri.cuh:13-160, device/device_sky.c:283-316): the sky without celestial bodies - and with the clouds, when active - seen from
+// `origin`, as an equirectangular dim x dim image. 32 lanes per texel share its samples; their means go through the reference's trimmed mean. ----
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
+__global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, float oy, float oz, uint32_t dim, uint32_t sample_count, float4* __restrict__ dst) {
+  __shared__ float values[256];
+  const uint32_t pixel = (blockIdx.x * 256u + threadIdx.x) >> 5, lane = threadIdx.x & 31u;
+  const bool in_range = pixel < dim * dim;
+  const uint32_t y = in_range ? pixel / dim : 0u, x = in_range ? pixel - y * dim : 0u;
+  const SkyView sky = sky_view(sc);
+  const float step_size = 1.0f / (float) (dim - 1u);
+  Col color = splat(0.0f);
+  float alpha = 0.0f;
+  uint32_t num_samples = 0;
+  const bool clouds = sc.cloud_active && sc.cloud_noise_shape != nullptr;
+  if (in_range) {
+    for (uint32_t sample_id = lane; sample_id < sample_count; sample_id += 32u) {
+      const Sampler smp{sc.bluenoise_2d, x, y, sample_id, 0};
+      const F2 jitter = smp.next2(kRndCameraJitter);
+      const float u = ((float) x + jitter.x) * step_size, v = 1.0f - ((float) y + jitter.y) * step_size;
+      const float altitude = kPi * v - 0.5f * kPi, azimuth = 2.0f * kPi * u - kPi;
+      const V3 ray = angles_to_direction(altitude, azimuth);
+      Col sky_color = splat(0.0f), transmittance = splat(1.0f);
+      float cloud_transmittance = 1.0f;
+      V3 sky_origin = world_to_sky(sky, v3(ox, oy, oz));
+      if (clouds) {  // sky_hdri.cuh:88-92: the clouds in front, the sky behind them dimmed by their transmittance
+        const float offset = clouds_render(sc, sky, smp, sky_origin, ray, kFltMax, sky_color, transmittance, cloud_transmittance);
+        sky_origin = sky_origin + ray * offset;
+      }
+      const Col behind = sky_get_color(sc, sky, sky_origin, ray, kFltMax, false, (int) sky.steps, smp.next1(kRndSkyStepOffset));
+      sky_color = sky_color + behind * transmittance;
+      color = color + sky_color;
+      alpha += cloud_transmittance;
+      num_samples++;
+    }
+  }
+  const uint32_t buckets = min(32u, sample_count);
+  float* group = values + (threadIdx.x & ~31u);
+  float out[4];
+  const float mean[4] = {num_samples ? color.r / (float) num_samples : 0.0f, num_samples ? color.g / (float) num_samples : 0.0f, num_samples ? color.b / (float) num_samples : 0.0f,
+                         num_samples ? alpha / (float) num_samples : 0.0f};
+#pragma unroll
+  for (int ch = 0; ch < 4; ch++) {
+    __syncthreads();
+    values[threadIdx.x] = mean[ch];
+    __syncthreads();
+    out[ch] = (lane == 0u && in_range) ? sky_hdri_median_of_means(group, buckets) : 0.0f;
+  }
+  if (lane == 0u && in_range) dst[x + y * dim] = make_float4(out[0], out[1], out[2], out[3]);  // .w: the clouds' own transmittance (the reference's separate shadow texture), 1 without clouds
+}
+#endif
 
 // ---- fog (cuda/volume.cuh; queue order device/device_renderer.c:64-76, :114-118) ----
 // volume_process_inscattering (volume.cuh:31-98): what the fog scatters into the ray between its origin and its end point (the hit, or infinity

@@ -81,13 +81,16 @@ static void ocean_shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, con
                         uint32_t* ctrl, uint32_t depth_const) {
   hipLaunchKernelGGL(k_ocean_shade, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, ctrl, depth_const);
 }
+static void clouds(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_clouds, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
+}
 static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                        uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds, trace_rays};
 
 }  // namespace table
 LUM_NS_END

@@ -80,6 +80,10 @@ struct LumContext {
     uint8_t* d_block_mask = nullptr; // image-tile partition over GPUs: blocks this context renders (nullptr = all)
     bool build_pending = false;      // partitioned: a stage is due and waits for the block variances of all ranks
   } adaptive;
+  uint32_t* d_cloud_noise[3] = {nullptr, nullptr, nullptr};  // the clouds' shape / detail / weather textures generated here (kept across scene uploads)
+  bool cloud_noise_static = false;  // shape and detail do not depend on the seed
+  uint32_t cloud_noise_seed = 0;
+  bool cloud_noise_weather_valid = false;
   float4* d_sky_hdri = nullptr;     // baked sky (lumc_sky_hdri_build): dim x dim equirectangular, rgb + 0
   uint32_t sky_hdri_dim = 0;
   std::vector<float*> bloom_mips;  // mip chain of lumc_post_bloom, level i of (width >> (i + 1)) x (height >> (i + 1))
@@ -435,6 +439,7 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
   if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
+  for (uint32_t*& t : ctx->d_cloud_noise) { if (t) (void) hipFree(t); t = nullptr; }
   if (ctx->d_undersampling_pixels) (void) hipFree(ctx->d_undersampling_pixels);
   for (float* m : ctx->bloom_mips) (void) hipFree(m);
   free_adaptive(ctx);
@@ -549,6 +554,38 @@ static bool widen_to_bvh8(const std::vector<Bvh4Node>& in, const std::vector<uin
   }
   if (levels_out) *levels_out = max_level;
   return true;
+}
+
+// The clouds' noise textures (device_cloud.c:62-101): shape and detail once per context, the weather map per seed.
+static int ensure_cloud_noise(LumContext* ctx, uint32_t seed) {
+  const size_t counts[3] = {(size_t) kCloudShapeRes * kCloudShapeRes * kCloudShapeRes, (size_t) kCloudDetailRes * kCloudDetailRes * kCloudDetailRes,
+                            (size_t) kCloudWeatherRes * kCloudWeatherRes};
+  for (int k = 0; k < 3; k++)
+    if (!ctx->d_cloud_noise[k]) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_cloud_noise[k], sizeof(uint32_t) * counts[k]));
+  if (!ctx->cloud_noise_static) {
+    hipLaunchKernelGGL(exact::k_cloud_noise_shape, dim3(2048), dim3(256), 0, 0, ctx->d_cloud_noise[0], (uint32_t) kCloudShapeRes);
+    hipLaunchKernelGGL(exact::k_cloud_noise_detail, dim3(128), dim3(256), 0, 0, ctx->d_cloud_noise[1], (uint32_t) kCloudDetailRes);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->cloud_noise_static = true;
+  }
+  if (!ctx->cloud_noise_weather_valid || ctx->cloud_noise_seed != seed) {
+    hipLaunchKernelGGL(exact::k_cloud_noise_weather, dim3(2048), dim3(256), 0, 0, ctx->d_cloud_noise[2], (uint32_t) kCloudWeatherRes, (float) seed);
+    HIP_TRY(ctx, hipGetLastError());
+    ctx->cloud_noise_seed = seed; ctx->cloud_noise_weather_valid = true;
+  }
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  return 0;
+}
+int lumc_cloud_noise_generate(LumContext* ctx, uint32_t seed, uint32_t* shape, uint32_t* detail, uint32_t* weather) {
+  if (!ctx) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  if (ensure_cloud_noise(ctx, seed)) return 1;
+  uint32_t* out[3] = {shape, detail, weather};
+  const size_t counts[3] = {(size_t) kCloudShapeRes * kCloudShapeRes * kCloudShapeRes, (size_t) kCloudDetailRes * kCloudDetailRes * kCloudDetailRes,
+                            (size_t) kCloudWeatherRes * kCloudWeatherRes};
+  for (int k = 0; k < 3; k++)
+    if (out[k]) HIP_TRY(ctx, hipMemcpy(out[k], ctx->d_cloud_noise[k], sizeof(uint32_t) * counts[k], hipMemcpyDeviceToHost));
+  return 0;
 }
 
 // The particle tree (device_particle.c:23-131, optix_bvh.c's particle GAS / IAS): one bottom-level tree over the 2 x count triangles of the unit
@@ -915,6 +952,27 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       if (!sc.bridge_lut && upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
     }
   }
+  // ---- clouds ----
+  sc.cloud_active = v->cloud_active ? 1u : 0u;
+  sc.cloud_atmosphere_scattering = v->cloud_atmosphere_scattering ? 1u : 0u;
+  sc.cloud_steps = v->cloud_steps & 0x3FFu; sc.cloud_shadow_steps = v->cloud_shadow_steps & 0x3FFu; sc.cloud_octaves = v->cloud_octaves & 0xFu;  // DeviceCloud's bit fields
+  sc.cloud_offset_x = v->cloud_offset_x; sc.cloud_offset_z = v->cloud_offset_z; sc.cloud_density = v->cloud_density;
+  sc.cloud_noise_shape_scale = v->cloud_noise_shape_scale; sc.cloud_noise_detail_scale = v->cloud_noise_detail_scale; sc.cloud_noise_weather_scale = v->cloud_noise_weather_scale;
+  std::memcpy(sc.cloud_phase, v->cloud_phase, sizeof(sc.cloud_phase));
+  std::memcpy(sc.cloud_layers, v->cloud_layers, sizeof(sc.cloud_layers));
+  sc.cloud_noise_shape = nullptr; sc.cloud_noise_detail = nullptr; sc.cloud_noise_weather = nullptr;
+  if (sc.cloud_active) {
+    if (sc.cloud_steps == 0 || sc.cloud_shadow_steps == 0) { ctx->error = "lumc_scene_upload: clouds need positive step counts"; return 1; }
+    if (v->cloud_noise_shape && v->cloud_noise_detail && v->cloud_noise_weather) {
+      if (upload(ctx, (const uint32_t*) v->cloud_noise_shape, (size_t) kCloudShapeRes * kCloudShapeRes * kCloudShapeRes, &sc.cloud_noise_shape)) return 1;
+      if (upload(ctx, (const uint32_t*) v->cloud_noise_detail, (size_t) kCloudDetailRes * kCloudDetailRes * kCloudDetailRes, &sc.cloud_noise_detail)) return 1;
+      if (upload(ctx, (const uint32_t*) v->cloud_noise_weather, (size_t) kCloudWeatherRes * kCloudWeatherRes, &sc.cloud_noise_weather)) return 1;
+    }
+    else {
+      if (ensure_cloud_noise(ctx, v->cloud_seed)) return 1;
+      sc.cloud_noise_shape = ctx->d_cloud_noise[0]; sc.cloud_noise_detail = ctx->d_cloud_noise[1]; sc.cloud_noise_weather = ctx->d_cloud_noise[2];
+    }
+  }
   // ---- particles ----
   sc.particles_active = (v->particles_active && v->particles_count) ? 1u : 0u;
   sc.particles_count = sc.particles_active ? v->particles_count : 0u;
@@ -1012,7 +1070,7 @@ int lumc_download_sky_luts(LumContext* ctx, float* transmittance, float* multisc
 }
 
 // Everything the bake reads: the sky's parameters (not its tables: they are functions of the parameters), the star field's size, the moon.
-static std::vector<uint32_t> sky_hdri_key(const DeviceScene& sc, const float origin[3], uint32_t dim, uint32_t samples) {
+static std::vector<uint32_t> sky_hdri_key(const DeviceScene& sc, uint32_t ctx_cloud_seed, const float origin[3], uint32_t dim, uint32_t samples) {
   std::vector<uint32_t> key;
   auto put = [&](const void* p, size_t bytes) { const size_t at = key.size(); key.resize(at + (bytes + 3) / 4, 0u); std::memcpy(key.data() + at, p, bytes); };
   put(&sc.sky_steps, sizeof(sc.sky_steps)); put(&sc.sky_ozone_absorption, sizeof(sc.sky_ozone_absorption));
@@ -1022,6 +1080,14 @@ static std::vector<uint32_t> sky_hdri_key(const DeviceScene& sc, const float ori
   put(params, sizeof(params));
   put(sc.sky_sun_pos, sizeof(sc.sky_sun_pos)); put(sc.sky_mie_phase, sizeof(sc.sky_mie_phase)); put(sc.sky_moon_pos, sizeof(sc.sky_moon_pos));
   put(&sc.sky_stars_count, sizeof(sc.sky_stars_count));
+  put(&sc.cloud_active, sizeof(sc.cloud_active));
+  if (sc.cloud_active) {  // the clouds are baked in (sky_hdri.cuh:88-92)
+    const uint32_t ints[] = {sc.cloud_atmosphere_scattering, sc.cloud_steps, sc.cloud_shadow_steps, sc.cloud_octaves};
+    const float floats[] = {sc.cloud_offset_x, sc.cloud_offset_z, sc.cloud_density, sc.cloud_noise_shape_scale, sc.cloud_noise_detail_scale, sc.cloud_noise_weather_scale};
+    put(ints, sizeof(ints)); put(floats, sizeof(floats)); put(sc.cloud_phase, sizeof(sc.cloud_phase)); put(sc.cloud_layers, sizeof(sc.cloud_layers));
+    const uint64_t tex[] = {(uint64_t) (uintptr_t) sc.cloud_noise_shape, (uint64_t) (uintptr_t) sc.cloud_noise_weather, (uint64_t) ctx_cloud_seed};
+    put(tex, sizeof(tex));
+  }
   put(origin, 3 * sizeof(float)); put(&dim, sizeof(dim)); put(&samples, sizeof(samples));
   return key;
 }
@@ -1030,7 +1096,7 @@ int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, ui
   if (!ctx || !origin || !ctx->has_scene || !ctx->scene.sky_lut_transmittance) { if (ctx) ctx->error = "lumc_sky_hdri_build: the scene has no atmosphere (constant-colour sky)"; return 1; }
   if (dim < 2 || dim > 16384 || samples == 0) { ctx->error = "lumc_sky_hdri_build: dim must be in [2, 16384] and samples positive"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  std::vector<uint32_t> key = sky_hdri_key(ctx->scene, origin, dim, samples);
+  std::vector<uint32_t> key = sky_hdri_key(ctx->scene, ctx->cloud_noise_seed, origin, dim, samples);
   if (ctx->d_sky_hdri && key == ctx->sky_hdri_key) {
     if (ctx->scene.sky_mode == kSkyHdri) { ctx->scene.sky_hdri = ctx->d_sky_hdri; ctx->scene.sky_hdri_dim = dim; }
     return 0;
@@ -1114,6 +1180,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_events(grid_for(N), stream, sc, ctx->queue[0], ctx->volume, ctx->d_results, ctx->d_ctrl, 0u);
     }
+    if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // the debug queue keeps the in-scattering events (device_renderer.c:150-154)
+      Launch l(ctx, stream, LUMC_KERNEL_SKY);
+      wf.sky_inscattering(grid_for(N), stream, sc, ctx->queue[0], ctx->d_results, (const uint32_t*) ctx->d_ctrl, 0u);
+    }
     Launch l(ctx, stream, LUMC_KERNEL_SHADE);
     wf.shade_debug(grid_for(N), stream, sc, ctx->queue[0], ctx->d_results, (const uint32_t*) ctx->d_ctrl);
     return 0;
@@ -1149,6 +1219,10 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
       wf.volume_events(grid_for(N), stream, sc, ctx->queue[cur], ctx->volume, ctx->d_results, ctrl, depth_const);
+    }
+    if (sc.cloud_active && sc.sky_mode == kSkyDefault && sc.cloud_noise_shape) {  // device_manager.c:474, device_renderer.c:78-82
+      Launch l(ctx, stream, LUMC_KERNEL_SKY);
+      wf.clouds(grid_for(N), stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
       Launch l(ctx, stream, LUMC_KERNEL_SKY);

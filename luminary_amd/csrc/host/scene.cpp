@@ -1087,6 +1087,20 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   v.ocean_caustics_ris_sample_count = std::max(oc.caustics_ris_sample_count, 1u) - 1u;  // device_structs.c:94
   v.ocean_caustics_domain_scale = oc.caustics_domain_scale;
   v.ocean_multiscattering = oc.multiscattering ? 1u : 0u; v.ocean_triangle_light_contribution = oc.triangle_light_contribution ? 1u : 0u;
+  // clouds (device_struct_cloud_convert, device_structs.c:173-217)
+  const LuminaryCloud& cl = scene.cloud;
+  v.cloud_active = cl.active ? 1u : 0u; v.cloud_atmosphere_scattering = cl.atmosphere_scattering ? 1u : 0u;
+  v.cloud_steps = cl.steps; v.cloud_shadow_steps = cl.shadow_steps; v.cloud_octaves = cl.octaves; v.cloud_seed = cl.seed;
+  v.cloud_offset_x = cl.offset_x; v.cloud_offset_z = cl.offset_z; v.cloud_density = cl.density;
+  v.cloud_noise_shape_scale = cl.noise_shape_scale; v.cloud_noise_detail_scale = cl.noise_detail_scale; v.cloud_noise_weather_scale = cl.noise_weather_scale;
+  jendersie_eon_parameters(cl.droplet_diameter, v.cloud_phase);
+  const LuminaryCloudLayer* layers[3] = {&cl.low, &cl.mid, &cl.top};
+  for (int l = 0; l < 3; l++) {
+    const LuminaryCloudLayer& y = *layers[l];
+    const float row[10] = {y.active ? 1.0f : 0.0f, y.height_max, y.height_min, y.coverage, y.coverage_min, y.type, y.type_min, y.wind_speed, std::cos(y.wind_angle), std::sin(y.wind_angle)};
+    std::memcpy(v.cloud_layers[l], row, sizeof(row));
+  }
+  v.cloud_noise_shape = nullptr; v.cloud_noise_detail = nullptr; v.cloud_noise_weather = nullptr;
   return std::string();
 }
 

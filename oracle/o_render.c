@@ -28,6 +28,7 @@
 enum { ST_DELTA_PATH = 1, ST_CAMERA_DIRECTION = 2, ST_VOLUME_SCATTERED = 4, ST_ALLOW_EMISSION = 8, ST_ALLOW_AMBIENT = 16, ST_USE_IGNORE_HANDLE = 32 };
 #include "o_sky.h"
 #include "o_volume.h"
+#include "o_cloud.h"
 
 enum { SKY_MODE_DEFAULT = 0, SKY_MODE_HDRI = 1, SKY_MODE_CONSTANT_COLOR = 2 };
 #define GEOMETRY_DELTA_PATH_CUTOFF 0.05f
@@ -200,11 +201,18 @@ static RGBF render_path_debug(const OracleScene* s, const OTracer* tr, uint32_t 
   uint32_t volumes = 0;
   if (s->fog_active) volumes = volume_stack_modify(volumes, VOLUME_TYPE_FOG, true);
   if (s->ocean_active && ocean_is_underwater(s, origin)) volumes = volume_stack_modify(volumes, VOLUME_TYPE_OCEAN, true);
+  uint2_t record_p = record_pack(c_splat(1.0f));
   if (volume_stack_peek(volumes, false) != VOLUME_TYPE_NONE) { /* the debug queue keeps volume_process_events (device_renderer.c:145-147): the sky fast path shows through, a scattering event stays black */
-    uint2_t record_p = record_pack(c_splat(1.0f));
     volume_events(s, &smp, origin, ray, state, volume_stack_peek(volumes, false), &hit, &record_p, &result);
-    if (hit.instance_id == HIT_TYPE_INVALID || (hit.instance_id >= HIT_TYPE_VOLUME_BASE && hit.instance_id <= HIT_TYPE_VOLUME_MAX)) return result;
   }
+  if (s->sky_aerial_perspective && s->sky_mode != SKY_MODE_CONSTANT_COLOR && s->sky_lut_transmittance && s->sky_lut_multiscattering && hit.instance_id != HIT_TYPE_SKY) {
+    /* the debug queue keeps sky_process_inscattering_events (device_renderer.c:150-154): the air's light shows in every mode, on every task that is not a sky hit */
+    const OSky view = osky_view(s);
+    RGBF record = record_unpack(record_p);
+    beauty_add(&result, sky_trace_inscattering(&view, world_to_sky(&view, origin), ray, hit.t * 0.001f, &record, true, rnd1(&smp, RANDOM_TARGET_SKY_INSCATTERING_STEP),
+                                               rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET)));
+  }
+  if (hit.instance_id == HIT_TYPE_INVALID || (hit.instance_id >= HIT_TYPE_VOLUME_BASE && hit.instance_id <= HIT_TYPE_VOLUME_MAX)) return result;
   if (hit.instance_id == HIT_TYPE_OCEAN) { /* ocean_process_tasks_debug, ocean.cuh:104-145 */
     if (s->shading_mode == 2) beauty_add(&result, c_splat(o_saturate((1.0f / hit.t) * 2.0f)));
     else if (s->shading_mode == 3) {
@@ -759,6 +767,23 @@ static RGBF render_path(const OracleScene* s, const OTracer* tr, uint32_t px, ui
       const RGBF in = volume_inscattering(s, tr, &smp, origin, ray, state, hit.t, lights_present, top_volume, second_volume, cnt);
       beauty_add(&result, c_mul(in, record_unpack(record_p)));
       volume_events(s, &smp, origin, ray, state, top_volume, &hit, &record_p, &result);
+    }
+    if (s->cloud_active && s->sky_mode == SKY_MODE_DEFAULT && s->sky_lut_transmittance && s->sky_lut_multiscattering && s->cloud_noise_shape && s->cloud_noise_detail &&
+        s->cloud_noise_weather) {
+      /* cloud_process_tasks (cloud.cuh:340-384; device_renderer.c:78-82, device_manager.c:474): what the cloud layers scatter into the ray and take from
+       * it; with atmosphere_scattering the ray's origin moves up to the last layer it entered (the air up to there was marched here) */
+      const OSky view = osky_view(s);
+      RGBF record = record_unpack(record_p);
+      RGBF color = c_splat(0.0f);
+      float cloud_transmittance = 1.0f;
+      const float cloud_offset = clouds_render(s, &view, &smp, world_to_sky(&view, origin), ray, hit.t * 0.001f, &color, &record, &cloud_transmittance);
+      if (s->cloud_atmosphere_scattering && cloud_offset != FLT_MAX && cloud_offset > 0.0f) {
+        const float cloud_world_offset = cloud_offset * 1000.0f;
+        origin = v_add(origin, v_scale(ray, cloud_world_offset));
+        if (hit.t != FLT_MAX) hit.t -= cloud_world_offset;
+      }
+      record_p = record_pack(record);
+      beauty_add(&result, color);
     }
     if (hit.instance_id == HIT_TYPE_SKY) {
       if (state & ST_ALLOW_AMBIENT) {
@@ -1380,6 +1405,48 @@ void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t c
   memset(&v, 0, sizeof(v));
   v.scattering = scattering; v.dist = 1.0f; v.max_height = 1.0f; v.type = VOLUME_TYPE_FOG;
   for (uint32_t i = 0; i < count; i++) { t[i] = volume_sample_bounded(&v, max_length, rnd[i]); pdf[i] = volume_sample_bounded_pdf(&v, max_length, t[i]); }
+}
+
+/* clouds (o_cloud.h): the three noise textures, RGBA8 (shape 128^3, detail 32^3, weather 1024^2 from the seed) */
+void oracle_cloud_noise(uint32_t seed, uint32_t* shape, uint32_t* detail, uint32_t* weather) {
+  if (shape) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t) CLOUD_SHAPE_RES * CLOUD_SHAPE_RES * CLOUD_SHAPE_RES; i++) {
+      const uint32_t z = (uint32_t) (i / (CLOUD_SHAPE_RES * CLOUD_SHAPE_RES)), y = (uint32_t) ((i / CLOUD_SHAPE_RES) % CLOUD_SHAPE_RES), x = (uint32_t) (i % CLOUD_SHAPE_RES);
+      shape[i] = cloud_shape_texel(x, y, z, CLOUD_SHAPE_RES);
+    }
+  }
+  if (detail) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t) CLOUD_DETAIL_RES * CLOUD_DETAIL_RES * CLOUD_DETAIL_RES; i++) {
+      const uint32_t z = (uint32_t) (i / (CLOUD_DETAIL_RES * CLOUD_DETAIL_RES)), y = (uint32_t) ((i / CLOUD_DETAIL_RES) % CLOUD_DETAIL_RES), x = (uint32_t) (i % CLOUD_DETAIL_RES);
+      detail[i] = cloud_detail_texel(x, y, z, CLOUD_DETAIL_RES);
+    }
+  }
+  if (weather) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < (int64_t) CLOUD_WEATHER_RES * CLOUD_WEATHER_RES; i++)
+      weather[i] = cloud_weather_texel((uint32_t) (i % CLOUD_WEATHER_RES), (uint32_t) (i / CLOUD_WEATHER_RES), CLOUD_WEATHER_RES, (float) seed);
+  }
+}
+/* probes for tests/test_clouds.py: one value of the tiling Perlin / Worley octaves; the density and the shadow at points in sky space */
+void oracle_probe_cloud_noise(uint32_t count, const float* p, float scale, int octaves, float seed, float persistence, float* out_perlin, float* out_worley) {
+  for (uint32_t i = 0; i < count; i++) {
+    const vec3 q = v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]);
+    out_perlin[i] = perlin_octaves(q, scale, octaves, true);
+    out_worley[i] = worley_octaves(q, scale, octaves, seed, persistence);
+  }
+}
+void oracle_probe_cloud_density(const OracleScene* s, int layer, uint32_t count, const float* sky_pos, float* out_height, float* out_density) {
+  for (uint32_t i = 0; i < count; i++) {
+    const vec3 pos = v3(sky_pos[3 * i], sky_pos[3 * i + 1], sky_pos[3 * i + 2]);
+    const float height = cloud_height(s, pos, layer);
+    out_height[i] = height;
+    out_density[i] = 0.0f;
+    if (height < 0.0f || height > 1.0f) continue;
+    const CloudWeather w = cloud_weather(s, pos, height, layer);
+    if (cloud_significant_point(height, &w, layer)) out_density[i] = cloud_density(s, pos, height, &w, layer);
+  }
 }
 
 void oracle_probe_ocean_height(const OracleScene* s, uint32_t count, const float* xz, float* out) {

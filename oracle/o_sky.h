@@ -353,9 +353,11 @@ static inline vec3 angles_to_direction(float altitude, float azimuth) { /* math.
   return v3(cz * ca, sa, sz * ca);
 }
 
-/* sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars (no clouds: their shadow term is 1);
- * *transmittance_out is multiplied by the transmittance of the marched segment */
-static Spectrum sky_compute_atmosphere(const OSky* s, Spectrum* transmittance_out, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
+/* sky_compute_atmosphere (sky.cuh:338-505): ray-marched atmosphere, then sun disk, moon and stars; `cloud_shadows`: the sun's single scattering is
+ * shadowed by the cloud layers (o_cloud.h); *transmittance_out is multiplied by the transmittance of the marched segment */
+static float cloud_shadow(const OracleScene* s, vec3 origin, vec3 ray);
+static Spectrum sky_compute_atmosphere(const OSky* s, Spectrum* transmittance_out, vec3 origin, vec3 ray, float limit, bool celestials, bool cloud_shadows, int steps,
+                                       float random_offset) {
   Spectrum result = sp_set1(0.0f);
   const float2_t path = sky_compute_path(origin, ray, SKY_EARTH_RADIUS, SKY_ATMO_RADIUS);
   const float start = path.x, distance = fminf(path.y, limit - start);
@@ -373,7 +375,7 @@ static Spectrum sky_compute_atmosphere(const OSky* s, Spectrum* transmittance_ou
       const float cos_angle = v_dot(ray, ray_scatter);
       const float zenith_cos = v_dot(v_norm(pos), ray_scatter);
       const float phase_r = sky_rayleigh_phase(cos_angle), phase_m = sky_mie_phase(s, cos_angle);
-      const float shadow = sph_hit_p0(ray_scatter, pos, SKY_EARTH_RADIUS) ? 0.0f : 1.0f;
+      const float shadow = sph_hit_p0(ray_scatter, pos, SKY_EARTH_RADIUS) ? 0.0f : (cloud_shadows ? cloud_shadow(s->scene, pos, ray_scatter) : 1.0f);
       const float2_t uv = sky_transmittance_uv(height, zenith_cos);
       const Spectrum extinction_sun = sky_lut_fetch(s->tm, SKY_TM_W, SKY_TM_H, uv.x, uv.y);
       const SkyMedium m = sky_medium(s, height);
@@ -440,14 +442,14 @@ static Spectrum sky_compute_atmosphere(const OSky* s, Spectrum* transmittance_ou
 /* sky_get_color, sky.cuh:508-515 */
 static RGBF sky_get_color(const OSky* s, vec3 origin, vec3 ray, float limit, bool celestials, int steps, float random_offset) {
   Spectrum unused = sp_set1(0.0f);
-  return sky_color_from_spectrum(sky_compute_atmosphere(s, &unused, origin, ray, limit, celestials, steps, random_offset));
+  return sky_color_from_spectrum(sky_compute_atmosphere(s, &unused, origin, ray, limit, celestials, false, steps, random_offset));
 }
 /* aerial perspective: sky_trace_inscattering, sky.cuh:517-532 (limit in sky units; IS_PRIMARY_RAY = the depth constant is 0) */
 static RGBF sky_trace_inscattering(const OSky* s, vec3 origin, vec3 ray, float limit, RGBF* record, bool primary_ray, float step_random, float random_offset) {
   Spectrum transmittance = sp_set1(1.0f);
   const float base_range = primary_ray ? 40.0f : 80.0f;
   const int steps = (int) (fminf(fmaxf(0.5f, limit / base_range), 2.0f) * (float) (s->steps / 6u) + step_random - 0.5f);
-  const Spectrum radiance = sky_compute_atmosphere(s, &transmittance, origin, ray, limit, false, steps, random_offset);
+  const Spectrum radiance = sky_compute_atmosphere(s, &transmittance, origin, ray, limit, false, true, steps, random_offset);
   const RGBF inscattering = c_mul(sky_color_from_spectrum(radiance), *record);
   *record = c_mul(*record, sky_color_from_spectrum(transmittance));
   return inscattering;
@@ -472,16 +474,22 @@ static float sky_hdri_median_of_means(float* buckets, uint32_t num_buckets) {
   for (uint32_t b = c; b < num_buckets - c; b++) output += buckets[b];
   return output / (float) (num_buckets - 2u * c);
 }
+static float clouds_render(const OracleScene* s, const OSky* sky, const Sampler* smp, vec3 origin, vec3 ray, float limit, RGBF* color, RGBF* transmittance,
+                           float* transmittance_cloud_only); /* o_cloud.h */
+/* sky_compute_hdri (sky_hdri.cuh:58-159): with active clouds the ray is marched through them first and the sky behind is dimmed by their transmittance;
+ * the fourth channel is the clouds' own transmittance (the reference's separate "shadow" texture, same size and filter), 1 without clouds */
 static void sky_hdri_bake(const OracleScene* sc, vec3 origin_world, uint32_t dim, uint32_t sample_count, float* dst /* dim*dim*4 */) {
   const OSky sky = osky_view(sc);
+  const bool clouds = sc->cloud_active && sc->cloud_noise_shape && sc->cloud_noise_detail && sc->cloud_noise_weather;
   const float step_size = 1.0f / (float) (dim - 1u);
   const uint32_t buckets = sample_count < 32u ? sample_count : 32u;
 #pragma omp parallel for schedule(dynamic, 4)
   for (int64_t pixel = 0; pixel < (int64_t) dim * dim; pixel++) {
     const uint32_t y = (uint32_t) pixel / dim, x = (uint32_t) pixel - y * dim;
-    float mean[3][32];
+    float mean[4][32];
     for (uint32_t lane = 0; lane < 32; lane++) {
       RGBF color = c_splat(0.0f);
+      float alpha = 0.0f;
       uint32_t num_samples = 0;
       for (uint32_t sample_id = lane; sample_id < sample_count; sample_id += 32u) {
         const Sampler smp = {sc->bluenoise_2d, x, y, sample_id, 0};
@@ -489,15 +497,25 @@ static void sky_hdri_bake(const OracleScene* sc, vec3 origin_world, uint32_t dim
         const float u = ((float) x + jitter.x) * step_size, v = 1.0f - ((float) y + jitter.y) * step_size;
         const float altitude = O_PI * v - 0.5f * O_PI, azimuth = 2.0f * O_PI * u - O_PI;
         const vec3 ray = angles_to_direction(altitude, azimuth);
-        color = c_add(color, sky_get_color(&sky, world_to_sky(&sky, origin_world), ray, FLT_MAX, false, (int) sky.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET)));
+        RGBF sky_color = c_splat(0.0f), transmittance = c_splat(1.0f);
+        float cloud_transmittance = 1.0f;
+        vec3 sky_origin = world_to_sky(&sky, origin_world);
+        if (clouds) {
+          const float offset = clouds_render(sc, &sky, &smp, sky_origin, ray, FLT_MAX, &sky_color, &transmittance, &cloud_transmittance);
+          sky_origin = v_add(sky_origin, v_scale(ray, offset));
+        }
+        const RGBF behind = sky_get_color(&sky, sky_origin, ray, FLT_MAX, false, (int) sky.steps, rnd1(&smp, RANDOM_TARGET_SKY_STEP_OFFSET));
+        sky_color = c_add(sky_color, c_mul(behind, transmittance));
+        color = c_add(color, sky_color);
+        alpha += cloud_transmittance;
         num_samples++;
       }
       mean[0][lane] = num_samples ? color.r / (float) num_samples : 0.0f;
       mean[1][lane] = num_samples ? color.g / (float) num_samples : 0.0f;
       mean[2][lane] = num_samples ? color.b / (float) num_samples : 0.0f;
+      mean[3][lane] = num_samples ? alpha / (float) num_samples : 0.0f;
     }
-    for (int ch = 0; ch < 3; ch++) dst[4 * pixel + ch] = sky_hdri_median_of_means(mean[ch], buckets);
-    dst[4 * pixel + 3] = 0.0f;
+    for (int ch = 0; ch < 4; ch++) dst[4 * pixel + ch] = sky_hdri_median_of_means(mean[ch], buckets);
   }
 }
 
@@ -536,13 +554,26 @@ static inline vec3 sample_sphere(vec3 p, float r, vec3 origin, float2_t random, 
   const float u = sqrtf(r1) * angle, v = 2.0f * O_PI * r2;
   return v_norm(sample_hemisphere_basis(u, v, dir));
 }
-static inline RGBF sky_sun_color(const OSky* s, vec3 origin, vec3 ray) { /* sky_utils.cuh:318-347 */
+/* sky_get_sun_color, sky_utils.cuh:318-347; `include_cloud_hdri`: in HDRI mode with active clouds the panorama's fourth channel (the clouds' transmittance,
+ * point filter like the colour) dims the sun */
+static inline RGBF sky_sun_color_ex(const OSky* s, vec3 origin, vec3 ray, bool include_cloud_hdri) {
   const float height = sky_height(origin);
   const float zenith_cos = v_dot(v_norm(origin), ray);
   const float2_t uv = sky_transmittance_uv(height, zenith_cos);
   const Spectrum extinction_sun = sp_mul(SP_IDENT, sky_lut_fetch(s->tm, SKY_TM_W, SKY_TM_H, uv.x, uv.y));
-  return sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+  RGBF sun_color = sky_color_from_spectrum(sp_mul(extinction_sun, sp_scale(SKY_SUN_RADIANCE, s->sun_strength)));
+  const OracleScene* sc = s->scene;
+  if (include_cloud_hdri && sc->cloud_active && sc->sky_mode == 1u /* HDRI */ && sc->sky_hdri && sc->sky_hdri_dim) {
+    const float theta = o_atan2(ray.z, ray.x), phi = o_asin(ray.y);
+    const float u = (theta + REF_PI) / (2.0f * REF_PI);
+    const float v = 1.0f - ((phi + 0.5f * REF_PI) / REF_PI);
+    const float dim = (float) sc->sky_hdri_dim;
+    const uint32_t x = (uint32_t) ((u - floorf(u)) * dim) % sc->sky_hdri_dim, y = (uint32_t) ((v - floorf(v)) * dim) % sc->sky_hdri_dim;
+    sun_color = c_scale(sun_color, sc->sky_hdri[4 * ((size_t) x + (size_t) y * sc->sky_hdri_dim) + 3]);
+  }
+  return sun_color;
 }
+static inline RGBF sky_sun_color(const OSky* s, vec3 origin, vec3 ray) { return sky_sun_color_ex(s, origin, ray, true); }
 /* bsdf_sample_for_sun_pdf<GEOMETRY>, bsdf.cuh:438-458: the world-space V goes into the bounded-VNDF density as it does there */
 /* ---- baked panorama as the sky (sky mode HDRI) ----
  * sky_hdri_sample, sky_utils.cuh:49-63: equirectangular lookup, point filter (device_sky.c:352), wrap addressing (texture_create's default),

@@ -104,6 +104,17 @@ typedef struct OracleScene {
   uint32_t ocean_caustics_active, ocean_caustics_ris_sample_count;
   float ocean_caustics_domain_scale;
   uint32_t ocean_multiscattering, ocean_triangle_light_contribution;
+  /* clouds (device_structs.c:173-217; cuda/cloud.cuh): three layers of ray-marched noise-density clouds, rendered in sky mode DEFAULT only
+   * (device_manager.c:474). cloud_layers[l] (l = low, mid, top): active, height_max, height_min, coverage, coverage_min, type, type_min,
+   * wind_speed, cos and sin of wind_angle. The noise textures (RGBA8: shape 128^3, detail 32^3, weather 1024^2, device_cloud.c:9-11) are taken
+   * from here when all three are given, otherwise generated by the core from cloud_seed. */
+  uint32_t cloud_active, cloud_atmosphere_scattering, cloud_steps, cloud_shadow_steps, cloud_octaves, cloud_seed;
+  float cloud_offset_x, cloud_offset_z, cloud_density, cloud_noise_shape_scale, cloud_noise_detail_scale, cloud_noise_weather_scale;
+  float cloud_phase[4];               /* Jendersie-Eon parameters of droplet_diameter */
+  float cloud_layers[3][10];
+  const uint8_t* cloud_noise_shape;
+  const uint8_t* cloud_noise_detail;
+  const uint8_t* cloud_noise_weather;
 } OracleScene;
 
 /* counters[0] closest-hit rays, [1] shadow rays executed, [2] light-BVH queries executed, [3] path vertices shaded */
@@ -212,6 +223,11 @@ void oracle_probe_fog_phase(const OracleScene* s, uint32_t count, const float* c
 void oracle_probe_fog_phase_sample(const OracleScene* s, uint32_t count, const float* rnd, float* out);
 void oracle_probe_particle_trace(const OracleScene* s, uint32_t count, const float* pos, const float* dir, const float* tmax, float* out_t, uint32_t* out_tri);
 void oracle_probe_volume_sampling(float scattering, float max_length, uint32_t count, const float* rnd, float* t, float* pdf);
+
+/* clouds (o_cloud.h) */
+void oracle_cloud_noise(uint32_t seed, uint32_t* shape, uint32_t* detail, uint32_t* weather);
+void oracle_probe_cloud_noise(uint32_t count, const float* p, float scale, int octaves, float seed, float persistence, float* out_perlin, float* out_worley);
+void oracle_probe_cloud_density(const OracleScene* s, int layer, uint32_t count, const float* sky_pos, float* out_height, float* out_density);
 
 /* ocean (o_ocean.h): heights at (x, z) pairs; per ray the intersection distance, the height of the end point above the surface and the normal there;
  * the Fresnel reflection coefficient of the flat surface per incident direction (from above: index_in_over_out = 1 / ior) */

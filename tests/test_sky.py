@@ -228,7 +228,7 @@ def _oracle_hdri(view, origin, dim, samples):
 def test_oracle_hdri_bake_is_a_sky_panorama():
     v = _with_sky_luts(_scene().device_scene())
     img = _oracle_hdri(v, (0.0, 6.0, 28.0), 16, 3)
-    assert np.isfinite(img).all() and (img[..., 3] == 0.0).all()
+    assert np.isfinite(img).all() and (img[..., 3] == 1.0).all(), "fourth channel: the clouds' transmittance, 1 without clouds"
     assert img[:8, :, :3].mean() > 20.0 * img[9:, :, :3].mean(), "rows above the horizon hold the sky, rows below it the thin air above the ground"
     assert img[1:7, :, 2].mean() > img[1:7, :, 0].mean(), "blue overhead"
 
