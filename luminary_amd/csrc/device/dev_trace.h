@@ -735,6 +735,12 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
                              RayStats& st) {
   float tstar = kFltMax;
   uint32_t best_id = kLightIdInvalid, best_key = 0xFFFFFFFFu, n = 0;
+  {  // a non-finite ray hits no light (see trace_items): a BSDF-sampled direction can be NaN, e.g. at grazing refraction through the water surface
+    const uint32_t e = 0x7F800000u;
+    const bool finite = (fbits(origin.x) & e) != e && (fbits(origin.y) & e) != e && (fbits(origin.z) & e) != e && (fbits(dir.x) & e) != e && (fbits(dir.y) & e) != e &&
+                        (fbits(dir.z) & e) != e;
+    if (!finite) { num_hits = 0; return kLightIdInvalid; }
+  }
   for (int pass = 0; pass < 2; pass++) {
     float tmax = tstar;
     traverse_lights(sc, origin, dir, tmax, st, [&](uint32_t first, uint32_t count, float& tm) {
