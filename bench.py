@@ -176,6 +176,15 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         oc.active, oc.height = True, args.ocean
         host.set_ocean(oc)
         label += " with the ocean at height %g" % args.ocean
+    if args.clouds:  # likewise: the three cloud layers (procedural sky mode: the reference marches clouds there only)
+        from luminary_amd import SKY_MODE_DEFAULT
+        sky = host.get_sky()
+        sky.mode = SKY_MODE_DEFAULT
+        host.set_sky(sky)
+        cl = host.get_cloud()
+        cl.active = True
+        host.set_cloud(cl)
+        label += " under the procedural sky with clouds"
     view = host.device_scene()
     build_s = time.time() - t_build
     t_up = time.time()
@@ -339,6 +348,7 @@ def main():
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
+    ap.add_argument("--clouds", action="store_true", help="procedural sky with the three cloud layers active (not a BASELINE configuration)")
     ap.add_argument("--ocean", type=float, default=None, help="height of an ocean surface put into the scene (default: none, the BASELINE configurations)")
     ap.add_argument("--fog", type=float, default=0.0, help="density of the fog volume the scene is put in (0 = none, the BASELINE configurations)")
     ap.add_argument("--sky", default="constant", choices=["constant", "procedural"],

@@ -39,6 +39,12 @@ constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #endif
 // The constant-colour-sky instantiation of the fast flavour is compiled for 3 waves per SIMD: 168 VGPRs with 25 of them spilled to scratch
 // still runs 4 % faster than 196 VGPRs at 2 waves (hall 154.3 -> 148.0 ms per 3 steps); the instantiations with sun sampling would spill 56-63.
+#ifndef LUM_CLOUD_WAVES
+#define LUM_CLOUD_WAVES 4  // k_clouds: waves per SIMD it is compiled for (2 / 3 / 4 measured: 1602 / 1369 / 1283 ms, profiles/r02_ab_experiments.txt)
+#endif
+#ifndef LUM_FEATURE_WAVES
+#define LUM_FEATURE_WAVES 3  // the shading kernels of particles, ocean surface and volumes (without a bound k_particle_shade took 266 registers: one wave per SIMD)
+#endif
 #ifndef LUM_SHADE_WAVES_CONSTANT_SKY
 #define LUM_SHADE_WAVES_CONSTANT_SKY (LUM_FAST ? 3 : LUM_SHADE_WAVES)
 #endif
@@ -617,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_sky(DeviceScene sc, PathQueue in, Sh
 }
 
 // ---- aerial perspective: sky_process_inscattering_events (cuda/kernels.cuh:357-388), between the closest-hit pass and shading ----
-__global__ __launch_bounds__(kBlock) void k_sky_inscattering(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_sky_inscattering(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   const SkyView sky = sky_view(sc);
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -871,7 +877,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_trace_particles(DeviceScene par
 
 // particle_process_tasks (particle.cuh:7-108): light sample, sun, phase-function bounce whose direction doubles as the ambient sample. The
 // records go where a surface vertex puts them, so k_resolve and the visibility pass treat both alike (optix_kernel_shadow.cu covers both).
-__global__ __launch_bounds__(kBlock) void k_particle_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_particle_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
   const uint32_t lane = threadIdx.x & 63;
@@ -1063,7 +1069,7 @@ __global__ __launch_bounds__(kBlock) void k_trace_ocean(DeviceScene sc, PathQueu
 
 // ocean_process_tasks (ocean.cuh:12-102): the water surface is a smooth dielectric; BSDF-sampled light and the sun, no sampled light and no
 // ambient sample. A refracted path enters or leaves the water: its medium and volume stacks change. Records go where a surface vertex puts them.
-__global__ __launch_bounds__(kBlock) void k_ocean_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_ocean_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
   const uint32_t lane = threadIdx.x & 63;
@@ -1176,32 +1182,71 @@ __global__ __launch_bounds__(kBlock) void k_ocean_shade(DeviceScene sc, PathQueu
 // cloud_process_tasks (cloud.cuh:340-384; device_renderer.c:78-82): after the volume events, every path is marched through the cloud layers up to its
 // hit. The scattered light goes to the path's result, its throughput takes the layers' (and, with atmosphere_scattering, the air's) transmittance,
 // and its origin moves up to the last layer entered so that the aerial-perspective pass and the sky see the rest of the ray.
-__global__ __launch_bounds__(kBlock) void k_clouds(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   const SkyView sky = sky_view(sc);
-  for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint4 hid = in.hit_id[i];
-    if (hid.x == kHitInvalid) continue;  // ended by the sky fast path of the volume events (no task exists for it in the reference)
-    float4 o4 = in.origin_t[i];
-    const float4 d4 = in.dir_slot[i];
-    uint4 aux = in.aux[i];
-    const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
-    const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
-    Col record = record_unpack(U2{aux.x, aux.y});
-    Col color = splat(0.0f);
-    float cloud_transmittance = 1.0f;
-    const float cloud_offset = clouds_render(sc, sky, smp, world_to_sky(sky, origin), ray, o4.w * 0.001f, color, record, cloud_transmittance);
-    if (sc.cloud_atmosphere_scattering && cloud_offset != kFltMax && cloud_offset > 0.0f) {
-      const float cloud_world_offset = cloud_offset * 1000.0f;
-      const V3 moved = origin + ray * cloud_world_offset;
-      o4.x = moved.x; o4.y = moved.y; o4.z = moved.z;
-      if (o4.w != kFltMax) o4.w -= cloud_world_offset;
-      in.origin_t[i] = o4;
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // Only rays that reach a cloud layer before their hit are marched - after the first bounce about every second path, scattered over the queue.
+  // As in k_shade, a wave collects the indices of those paths in LDS and marches them 64 at a time, so that the others do not leave lanes idle
+  // during the expensive part. Paths are independent: the order changes nothing.
+  __shared__ uint32_t pending_marches[kBlock / 64][128];
+  uint32_t* pending = pending_marches[threadIdx.x >> 6];
+  uint32_t num_pending = 0;  // wave-uniform
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0;; round++) {
+    const bool input_done = round >= rounds;
+    if (!input_done) {
+      const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      bool march = false;
+      if (i < n && in.hit_id[i].x != kHitInvalid) {  // kHitInvalid: ended by the sky fast path of the volume events (no task exists for it in the reference)
+        const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+        const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z)), ray = v3(d4.x, d4.y, d4.z);
+        const float limit = o4.w * 0.001f;
+#pragma unroll
+        for (int l = 0; l < 3; l++) march |= cloud_layer_intersection(sc, sky_origin, ray, limit, l).x != kFltMax;
+        // (a path that reaches no layer leaves clouds_render with nothing added, its throughput and origin unchanged: record_pack(record_unpack(x)) == x)
+      }
+      const unsigned long long bm = __ballot(march);
+      if (march) pending[num_pending + (uint32_t) __popcll(bm & below)] = i;
+      num_pending += (uint32_t) __popcll(bm);
     }
-    const U2 rp = record_pack(record);
-    aux.x = rp.x; aux.y = rp.y;
-    in.aux[i] = aux;
-    add_to_result(results, fbits(d4.w), color);
+#ifndef LUM_CLOUD_COMPACT
+#define LUM_CLOUD_COMPACT 1  // 0 (measurement only): every round marches what it found, partial waves and all
+#endif
+    if (num_pending < (LUM_CLOUD_COMPACT ? 64u : 1u) && !(input_done && num_pending > 0u)) {
+      if (input_done) break;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t take = min(num_pending, 64u);
+    num_pending -= take;
+    const bool valid = lane < take;
+    const uint32_t i = valid ? pending[num_pending + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
+    if (valid) {
+      const uint4 hid = in.hit_id[i];
+      float4 o4 = in.origin_t[i];
+      const float4 d4 = in.dir_slot[i];
+      uint4 aux = in.aux[i];
+      const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+      const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
+      Col record = record_unpack(U2{aux.x, aux.y});
+      Col color = splat(0.0f);
+      float cloud_transmittance = 1.0f;
+      const float cloud_offset = clouds_render(sc, sky, smp, world_to_sky(sky, origin), ray, o4.w * 0.001f, color, record, cloud_transmittance);
+      if (sc.cloud_atmosphere_scattering && cloud_offset != kFltMax && cloud_offset > 0.0f) {
+        const float cloud_world_offset = cloud_offset * 1000.0f;
+        const V3 moved = origin + ray * cloud_world_offset;
+        o4.x = moved.x; o4.y = moved.y; o4.z = moved.z;
+        if (o4.w != kFltMax) o4.w -= cloud_world_offset;
+        in.origin_t[i] = o4;
+      }
+      const U2 rp = record_pack(record);
+      aux.x = rp.x; aux.y = rp.y;
+      in.aux[i] = aux;
+      add_to_result(results, fbits(d4.w), color);
+    }
   }
 }
 
@@ -1260,7 +1305,7 @@ __global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, floa
 // volume_process_inscattering (volume.cuh:31-98): what the fog scatters into the ray between its origin and its end point (the hit, or infinity
 // for a ray that left the scene): a bridge to a sampled emissive triangle on delta paths, the sun and the ambient sample from a vertex on the
 // ray. The visibility rays go through the ShadowQueue (17 kinds per path), k_volume_resolve sums up (optix_kernel_shadow_volume.cu:13-98).
-__global__ __launch_bounds__(kBlock) void k_volume_inscatter(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_volume_inscatter(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
