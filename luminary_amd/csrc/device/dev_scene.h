@@ -39,6 +39,22 @@ struct alignas(128) Bvh8Node {
 };
 static_assert(sizeof(Bvh8Node) == 128, "BVH8 node must be one cache line");
 
+// 4-wide node with quantised child boxes in half a cache line (LUM_BVH4Q): same tree, same node indices, same child words as Bvh4Node; child j's box =
+// origin + q * 2^(e - 127) per axis, lower corners rounded down, upper up (the boxes only grow). A visit fetches 64 instead of 112 bytes and the LDS
+// holds twice the nodes; it pays with 24 byte->float conversions. Scene and particle trees; the light tree keeps float boxes.
+#ifndef LUM_BVH4Q
+#define LUM_BVH4Q 0
+#endif
+struct alignas(64) Bvh4QNode {
+  float origin[3];
+  uint8_t exp[3], pad0;   // biased exponents of the per-axis scale
+  uint32_t child[4];
+  uint8_t lo_x[4], lo_y[4], lo_z[4], hi_x[4], hi_y[4], hi_z[4];
+  uint32_t pad[2];
+};
+static_assert(sizeof(Bvh4QNode) == 64, "quantised BVH4 node must be half a cache line");
+constexpr uint32_t kNodeBytes = LUM_BVH4Q ? 64u : 128u, kNodeShift = LUM_BVH4Q ? 6u : 7u;
+
 constexpr uint32_t kBvhEmpty      = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeafBit    = 0x80000000u;
 constexpr uint32_t kBvhLeafMaxTri = 4;

@@ -291,6 +291,60 @@ LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r,
   return next;
 }
 
+// ---- 4-wide nodes with quantised child boxes in 64 bytes (Bvh4QNode) ----
+template <bool kOrdered, bool kCull>
+LUM_DEV uint32_t visit_node_q(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+                              typename StackEntry<kCull>::E& top, RayStats& st) {
+  using SE = StackEntry<kCull>;
+  const uint32_t b = cur << 6;
+  float4 head;
+  uint4 ch, q0;
+  uint2 q1;
+  if (cur < src.lds_count) {
+    const char* p = src.lds + b;
+    head = *reinterpret_cast<const float4*>(p); ch = *reinterpret_cast<const uint4*>(p + 16u); q0 = *reinterpret_cast<const uint4*>(p + 32u); q1 = *reinterpret_cast<const uint2*>(p + 48u);
+    st.lds_nodes++;
+  }
+  else {
+    const char* __restrict__ p = reinterpret_cast<const char*>(src.global) + b;
+    head = *reinterpret_cast<const float4*>(p); ch = *reinterpret_cast<const uint4*>(p + 16u); q0 = *reinterpret_cast<const uint4*>(p + 32u); q1 = *reinterpret_cast<const uint2*>(p + 48u);
+  }
+  // q0 = lo_x, lo_y, lo_z, hi_x; q1 = hi_y, hi_z; near plane of an axis = the lower one unless the ray runs against it
+  const bool bx_neg = r.inv.x < 0.0f, by_neg = r.inv.y < 0.0f, bz_neg = r.inv.z < 0.0f;
+  const uint32_t wnx = bx_neg ? q0.w : q0.x, wfx = bx_neg ? q0.x : q0.w;
+  const uint32_t wny = by_neg ? q1.x : q0.y, wfy = by_neg ? q0.y : q1.x;
+  const uint32_t wnz = bz_neg ? q1.y : q0.z, wfz = bz_neg ? q0.z : q1.y;
+  // plane distance = (origin + q * scale - o) * inv = q * (scale * inv) + (origin * inv + noi)
+  const uint32_t ew = fbits(head.w);
+  const float sx = bitsf((ew & 0xFFu) << 23) * r.inv.x, sy = bitsf(((ew >> 8) & 0xFFu) << 23) * r.inv.y, sz = bitsf(((ew >> 16) & 0xFFu) << 23) * r.inv.z;
+  const float ox = __builtin_fmaf(head.x, r.inv.x, r.noi.x), oy = __builtin_fmaf(head.y, r.inv.y, r.noi.y), oz = __builtin_fmaf(head.z, r.inv.z, r.noi.z);
+  const float inf = __builtin_inff();
+  float k[4];
+  uint32_t c[4] = {ch.x, ch.y, ch.z, ch.w};
+#pragma unroll
+  for (uint32_t j = 0; j < 4; j++) {
+    const float ax = __builtin_fmaf(byte_f(wnx, j), sx, ox), ay = __builtin_fmaf(byte_f(wny, j), sy, oy), az = __builtin_fmaf(byte_f(wnz, j), sz, oz);
+    const float fx = __builtin_fmaf(byte_f(wfx, j), sx, ox), fy = __builtin_fmaf(byte_f(wfy, j), sy, oy), fz = __builtin_fmaf(byte_f(wfz, j), sz, oz);
+    const float tn = vmax3(ax, ay, vmax0(az));
+    const float tf = vmin3(fx, fy, vmin2(fz, tmax));
+    k[j] = (c[j] != kBvhEmpty && tn <= __builtin_fmaf(tf, 1.000004f, 1e-30f)) ? tn : inf;
+  }
+  float k0 = k[0], k1 = k[1], k2 = k[2], k3 = k[3];
+  uint32_t c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+  if (kOrdered) { cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2); }
+  else {  // unordered: real children first (stable), so that the conditional pushes below see them in front
+    cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
+  }
+  if (k1 < inf) {
+    if (k2 < inf) {
+      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
+      stk[sp] = top; sp++; top = SE::make(c2, k2);
+    }
+    stk[sp] = top; sp++; top = SE::make(c1, k1);
+  }
+  return (k0 < inf) ? c0 : kBvhEmpty;
+}
+
 struct NodeData { float4 nx, ny, nz, fx, fy, fz; uint4 ch; };
 LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, RayStats& st) {
   NodeData n;
@@ -423,7 +477,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   extern __shared__ float4 lds_top[];
   {
     const float4* __restrict__ g = reinterpret_cast<const float4*>(sc.bvh_nodes);
-    for (uint32_t i = threadIdx.x; i < lds_count * 8u; i += blockDim.x) lds_top[i] = g[i];
+    for (uint32_t i = threadIdx.x; i < lds_count * (kNodeBytes / 16u); i += blockDim.x) lds_top[i] = g[i];
     __syncthreads();
   }
   const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
@@ -580,6 +634,8 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 #endif
 #if LUM_BVH8
           cur = visit_node8<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
+#elif LUM_BVH4Q
+          cur = visit_node_q<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
 #else
           cur = visit_node<Q::kOrdered, Q::kCull>(nodes, cur, r, tmax, stk, sp, top, st);
 #endif

@@ -556,6 +556,53 @@ static bool widen_to_bvh8(const std::vector<Bvh4Node>& in, const std::vector<uin
   return true;
 }
 
+// ---- 64-byte quantised nodes (Bvh4QNode, dev_scene.h) from a finished 4-wide tree: node for node, same indices ----
+static void quantise_bvh4(std::vector<Bvh4Node>& nodes) {
+  std::vector<Bvh4QNode> out(nodes.size());
+  for (size_t i = 0; i < nodes.size(); i++) {
+    const Bvh4Node& n = nodes[i];
+    Bvh4QNode& o = out[i];
+    std::memset(&o, 0, sizeof(o));
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    bool any = false;
+    for (int k = 0; k < 4; k++) {
+      if (n.child[k] == kBvhEmpty) continue;
+      any = true;
+      const float clo[3] = {n.lo_x[k], n.lo_y[k], n.lo_z[k]}, chi[3] = {n.hi_x[k], n.hi_y[k], n.hi_z[k]};
+      for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], clo[a]); hi[a] = std::max(hi[a], chi[a]); }
+    }
+    if (!any) for (int a = 0; a < 3; a++) { lo[a] = 0.0f; hi[a] = 0.0f; }
+    float scale[3];
+    for (int a = 0; a < 3; a++) {
+      o.origin[a] = lo[a];
+      const float extent = hi[a] - lo[a];
+      int e = -126;
+      if (extent > 0.0f && std::isfinite(extent)) {
+        int ex;
+        std::frexp(extent / 255.0f, &ex);  // extent / 255 = f * 2^ex with f in [0.5, 1): 2^ex >= extent / 255
+        e = std::max(-126, std::min(127, ex));
+      }
+      while (e < 127 && std::ceil((hi[a] - lo[a]) / std::ldexp(1.0f, e)) > 255.0f) e++;  // the quotient must stay below 256 after the subtraction's rounding
+      o.exp[a] = (uint8_t) (e + 127);
+      scale[a] = std::ldexp(1.0f, e);
+    }
+    uint8_t* qlo[3] = {o.lo_x, o.lo_y, o.lo_z};
+    uint8_t* qhi[3] = {o.hi_x, o.hi_y, o.hi_z};
+    for (int k = 0; k < 4; k++) {
+      o.child[k] = n.child[k];
+      if (n.child[k] == kBvhEmpty) { for (int a = 0; a < 3; a++) { qlo[a][k] = 255; qhi[a][k] = 0; } continue; }
+      const float clo[3] = {n.lo_x[k], n.lo_y[k], n.lo_z[k]}, chi[3] = {n.hi_x[k], n.hi_y[k], n.hi_z[k]};
+      for (int a = 0; a < 3; a++) {
+        const float l = std::floor((clo[a] - lo[a]) / scale[a]), h = std::ceil((chi[a] - lo[a]) / scale[a]);
+        qlo[a][k] = (uint8_t) std::max(0.0f, std::min(255.0f, l));
+        qhi[a][k] = (uint8_t) std::max(0.0f, std::min(255.0f, h));
+      }
+    }
+  }
+  // the array keeps its element type for the upload: the first half of it now holds the 64-byte nodes
+  std::memcpy(nodes.data(), out.data(), out.size() * sizeof(Bvh4QNode));
+}
+
 // The clouds' noise textures (device_cloud.c:62-101): shape and detail once per context, the weather map per seed.
 static int ensure_cloud_noise(LumContext* ctx, uint32_t seed) {
   const size_t counts[3] = {(size_t) kCloudShapeRes * kCloudShapeRes * kCloudShapeRes, (size_t) kCloudDetailRes * kCloudDetailRes * kCloudDetailRes,
@@ -653,6 +700,9 @@ static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, Dev
     std::memcpy(nodes.data(), wide.data(), wide.size() * sizeof(Bvh8Node));
     for (size_t i = 0; i < tlas.prims.size(); i++) { const uint32_t words[4] = {tlas.prims[i], mesh_root_index, 0u, 0u}; std::memcpy(&leaves[4 * i + 3], words, 16); }
   }
+#endif
+#if LUM_BVH4Q
+  quantise_bvh4(nodes);
 #endif
   if (upload(ctx, nodes.data(), nodes.size(), &sc.particle_bvh_nodes)) return 1;
   if (upload(ctx, tris.data(), tris.size(), &sc.particle_tris)) return 1;
@@ -837,6 +887,9 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     ctx->bvh_stats[2] = new_tlas_nodes;
   }
 #endif
+#if LUM_BVH4Q
+  quantise_bvh4(nodes);
+#endif
   if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
   if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
   {
@@ -859,10 +912,10 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     const int blocks_per_cu = 1;  // both flavours launch one workgroup of 768 (3 waves per SIMD) or 1024 (4) threads per CU
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
     lds_bytes = lds_bytes > 16384 ? lds_bytes - 8192 : 0;  // margin: the ray kernels' static LDS (the prefetch experiment's sink) and the runtime's own
-    ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / sizeof(Bvh4Node), nodes.size());
+    ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / kNodeBytes, nodes.size());
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
-    const size_t dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
+    const size_t dyn = (size_t) ctx->lds_nodes * kNodeBytes;
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->set_ray_kernel_lds(dyn));
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->set_ray_kernel_lds(dyn));
   }
@@ -1155,14 +1208,14 @@ static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue
   DeviceScene tree = ctx->scene;
   tree.bvh_nodes = tree.particle_bvh_nodes; tree.blas_tris = tree.particle_tris; tree.tlas_leaves = tree.particle_leaves; tree.tlas_num_nodes = tree.particle_tlas_num_nodes;
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * sizeof(Bvh4Node), stream, tree, q, ctrl, ctx->particle_lds_nodes);
+  ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * kNodeBytes, stream, tree, q, ctrl, ctx->particle_lds_nodes);
 }
 
 // The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
 static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const DeviceScene& sc = ctx->scene;
   const uint32_t max_depth = sc.max_ray_depth;
-  const size_t lds_dyn = (size_t) ctx->lds_nodes * sizeof(Bvh4Node);
+  const size_t lds_dyn = (size_t) ctx->lds_nodes * kNodeBytes;
   int cur = 0;
   const WavefrontKernels& wf = *ctx->wf;
   const bool render_volumes = sc.fog_active || sc.ocean_active;  // device_manager.c:478
@@ -1876,7 +1929,7 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
   HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t) * 8, stream));  // up to 8 work cursors (dev_trace.h LUM_XCD_RANGES)
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * sizeof(Bvh4Node), stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
+  ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * kNodeBytes, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
                       ctx->lds_nodes);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
