@@ -34,6 +34,14 @@ constexpr int kBlock = 256;
                              // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)
 #endif
 constexpr int kTraceBlock = LUM_TRACE_BLOCK;
+#ifndef LUM_TRACE_MIN_WAVES
+#define LUM_TRACE_MIN_WAVES 0  // experiment: register budget of the ray kernels as waves per SIMD (0: whatever one workgroup of kTraceBlock threads per CU allows)
+#endif
+#if LUM_TRACE_MIN_WAVES
+#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock, LUM_TRACE_MIN_WAVES)
+#else
+#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
+#endif
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
 #endif
@@ -156,7 +164,7 @@ struct TraceQuery : ClosestState {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DeviceScene sc, PathQueue q, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+__global__ LUM_TRACE_BOUNDS void k_trace(DeviceScene sc, PathQueue q, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
   TraceQuery tq;
@@ -735,7 +743,7 @@ struct ShadowQuery : ShadowState {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_shadow_rays(DeviceScene sc, ShadowQueue sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
+__global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
   ShadowQuery q;
@@ -864,7 +872,7 @@ struct ParticleQuery {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_trace_particles(DeviceScene particle_tree, PathQueue q, uint32_t* ctrl, uint32_t lds_nodes) {
+__global__ LUM_TRACE_BOUNDS void k_trace_particles(DeviceScene particle_tree, PathQueue q, uint32_t* ctrl, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
   ParticleQuery pq;
@@ -1624,7 +1632,7 @@ struct RaysQuery : ClosestState {
   }
 };
 
-__global__ __launch_bounds__(kTraceBlock) void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
+__global__ LUM_TRACE_BOUNDS void k_trace_rays(DeviceScene sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore,
                                                            uint32_t* out, uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
   RayStats st{0, 0, 0};
   uint32_t rays = 0;
