@@ -376,3 +376,33 @@ def test_a_thousand_samples_of_everything_at_once(flavour):
         core.close()
     assert np.isfinite(fm).mean() > 0.999 and (fm[np.isfinite(fm)] >= 0).all()
     assert fm[np.isfinite(fm)].mean() > 0.0
+
+
+@pytest.mark.gpu
+def test_adaptive_sampling_with_ocean_fog_and_clouds_matches_the_oracle():
+    """The adaptive generator (k_generate_adaptive) starts its paths like k_generate: medium and volume stack of the camera position, then the whole schedule
+    with the ocean's, the fog's and the clouds' kernels. Moments, per-block rates and the result image against the oracle's adaptive run."""
+    from luminary_amd.core import Core, default_output_params
+    W, H = 30, 22
+    host = _with_ocean(scenes.zoo_scene(W, H, 3, sky_mode=SKY_MODE_DEFAULT), height=1.2)
+    f = host.get_fog(); f.active, f.density = True, 40.0; host.set_fog(f)
+    c = host.get_cloud(); c.active = True; host.set_cloud(c)
+    view = oracle_lib.with_cloud_noise(_view(host))
+    tone = default_output_params(W, H, 1)
+    executions = 2 + 4 + 3
+    o = oracle_lib.AdaptiveOracle(view, 6, 2, 2, exposure=0.0, tone=tone)
+    o.render(executions)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_pixels(None)
+        core.adaptive_begin(6, 2, 2, exposure=0.0, tone=tone)
+        core.adaptive_render(executions)
+        counts, variance = core.adaptive_download()
+        assert np.array_equal(counts, o.stage_counts) and np.array_equal(variance, o.block_variance)
+        fm, sm = core.accumulators()
+        assert np.array_equal(fm, o.fm.reshape(3, -1)) and np.array_equal(sm, o.sm)
+        assert np.array_equal(core.generate_result(mode=0, tone=tone), o.result(mode=0, tone=tone))
+        core.adaptive_end()
+    finally:
+        core.close()
