@@ -52,16 +52,37 @@ LUM_DEV CloudResult clouds_compute(const DeviceScene& sc, const SkyView& sky, co
   const F2 ambient_r = smp.next2(kRndCloudDir);
   const V3 ambient_ray = sample_ray_sphere(2.0f * ambient_r.x - 1.0f, ambient_r.y);
   const float ambient_cos_angle = dot(ray, ambient_ray);
+#ifndef LUM_CLOUD_SPLIT
+#define LUM_CLOUD_SPLIT 1  // 0 (measurement only): the reference's single loop, in-cloud and empty steps interleaved
+#endif
+  // The reference's loop, cut in two for SIMD execution: (A) advance to the next step that lies in a cloud - a cheap loop whose trip count differs from
+  // lane to lane - then (B) light that step, with every lane of the wave that found one. Interleaved as in the source, a wave would run the expensive
+  // part in every iteration in which any of its lanes is inside a cloud. Per lane the operations and their order are unchanged.
+  int i = 0;
 #pragma nounroll
-  for (int i = 0; i < step_count; i++) {
-    const V3 pos = origin + ray * reach;
-    if (!hit) hit_dist = reach;
-    const float height = cloud_height(sc, pos, layer);
-    if (height < 0.0f || height > 1.0f) break;
-    const CloudWeather w = cloud_weather(sc, pos, height, layer);
-    if (!cloud_significant_point(height, w, layer)) { reach += step_size; continue; }
-    const float density = cloud_density(sc, pos, height, w, layer);
-    if (density > 0.0f) {
+  for (;;) {
+    float density = 0.0f;
+    V3 pos = origin;
+    bool left_layer = false;
+#pragma nounroll
+    for (; i < step_count; i++) {
+      pos = origin + ray * reach;
+      if (!hit) hit_dist = reach;
+      const float height = cloud_height(sc, pos, layer);
+      if (height < 0.0f || height > 1.0f) { left_layer = true; break; }
+      const CloudWeather w = cloud_weather(sc, pos, height, layer);
+      if (!cloud_significant_point(height, w, layer)) {
+        reach += step_size;
+        if (!LUM_CLOUD_SPLIT) { i++; break; }
+        continue;
+      }
+      density = cloud_density(sc, pos, height, w, layer);
+      if (density > 0.0f) break;
+      reach += step_size;
+      if (!LUM_CLOUD_SPLIT) { i++; break; }
+    }
+    if (left_layer || !(density > 0.0f)) { if (left_layer || i >= step_count) break; else continue; }
+    {
       hit = true;
       const Col ambient_color = sky_get_color(sc, sky, pos, ambient_ray, kFltMax, false, (int) (sky.steps / 2u), smp.next1(kRndSkyStepOffset));
       float ambient_extinction = cloud_extinction(sc, pos, ambient_ray, layer);
@@ -98,6 +119,7 @@ LUM_DEV CloudResult clouds_compute(const DeviceScene& sc, const SkyView& sky, co
       if (transmittance < 0.1f) { transmittance = 0.0f; break; }
     }
     reach += step_size;
+    i++;
   }
   result.scattered_light = scattered_light; result.transmittance = transmittance; result.hit_dist = hit_dist;
   return result;
