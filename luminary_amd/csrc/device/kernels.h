@@ -50,6 +50,9 @@ constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_CLOUD_WAVES
 #define LUM_CLOUD_WAVES 4  // k_clouds: waves per SIMD it is compiled for (2 / 3 / 4 measured: 1602 / 1369 / 1283 ms, profiles/r02_ab_experiments.txt)
 #endif
+#ifndef LUM_HIT_COMPACT
+#define LUM_HIT_COMPACT 1  // 0 (measurement only): k_ocean_shade / k_particle_shade shade what every round finds, partial waves and all
+#endif
 #ifndef LUM_FEATURE_WAVES
 #define LUM_FEATURE_WAVES 3  // the shading kernels of particles, ocean surface and volumes (without a bound k_particle_shade took 266 registers: one wave per SIMD)
 #endif
@@ -893,14 +896,35 @@ __global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_particle_shade(De
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
   const Col albedo = particles_albedo(sc);
+  // Particle hits are a sparse subset of the queue: a wave collects their indices in LDS and shades them 64 at a time (as k_shade does with surface hits)
+  __shared__ uint32_t pending_hits[kBlock / 64][128];
+  uint32_t* pending = pending_hits[threadIdx.x >> 6];
+  uint32_t num_pending = 0;  // wave-uniform
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-  for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+  for (uint32_t round = 0;; round++) {
+    const bool input_done = round >= rounds;
+    if (!input_done) {
+      const uint32_t idx = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      const bool is_hit = idx < n && particle_is_hit(in.hit_id[idx].x);
+      const unsigned long long bh = __ballot(is_hit);
+      if (is_hit) pending[num_pending + (uint32_t) __popcll(bh & below)] = idx;
+      num_pending += (uint32_t) __popcll(bh);
+    }
+    if (num_pending < (LUM_HIT_COMPACT ? 64u : 1u) && !(input_done && num_pending > 0u)) {
+      if (input_done) break;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t take = min(num_pending, 64u);
+    num_pending -= take;
+    const bool valid = lane < take;
+    const uint32_t i = valid ? pending[num_pending + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
     bool survive = false, want_geo = false, want_amb = false, want_sun = false, want_amb2 = false, want_sun2 = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_geo_dir, s_amb_dir, s_sun_dir; uint4 s_geo_ids;
     float4 s_amb2_o, s_amb2_d, s_sun2_o, s_sun2_d;
-    if (i < n && particle_is_hit(in.hit_id[i].x)) {
+    if (valid) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
       const uint32_t state = aux.w;
@@ -1084,13 +1108,34 @@ __global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_ocean_shade(Devic
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
+  // Water-surface hits are a sparse subset of the queue: a wave collects their indices in LDS and shades them 64 at a time (as k_shade does with surface hits)
+  __shared__ uint32_t pending_hits[kBlock / 64][128];
+  uint32_t* pending = pending_hits[threadIdx.x >> 6];
+  uint32_t num_pending = 0;  // wave-uniform
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-  for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+  for (uint32_t round = 0;; round++) {
+    const bool input_done = round >= rounds;
+    if (!input_done) {
+      const uint32_t idx = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      const bool is_hit = idx < n && in.hit_id[idx].x == kHitOcean;
+      const unsigned long long bh = __ballot(is_hit);
+      if (is_hit) pending[num_pending + (uint32_t) __popcll(bh & below)] = idx;
+      num_pending += (uint32_t) __popcll(bh);
+    }
+    if (num_pending < (LUM_HIT_COMPACT ? 64u : 1u) && !(input_done && num_pending > 0u)) {
+      if (input_done) break;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t take = min(num_pending, 64u);
+    num_pending -= take;
+    const bool valid = lane < take;
+    const uint32_t i = valid ? pending[num_pending + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
     bool survive = false, want_sun = false, want_lq = false;
     float4 n_o, n_d; uint4 n_aux, n_hid;
     float4 s_origin, s_sun_dir;
-    if (i < n && in.hit_id[i].x == kHitOcean) {
+    if (valid) {
       const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
       const uint4 aux = in.aux[i], hid = in.hit_id[i];
       const uint32_t state = aux.w;
