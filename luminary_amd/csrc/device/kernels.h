@@ -1364,10 +1364,42 @@ __global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_volume_inscatter(
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   const bool sun_allowed = sc.sky_mode != kSkyConstantColor && sc.sky_lut_transmittance != nullptr && sc.sky_lut_multiscattering != nullptr;
+#ifndef LUM_INSCATTER_COMPACT
+#define LUM_INSCATTER_COMPACT 1  // 0 (measurement only): every round works on what it finds, partial waves and all
+#endif
+  // With an ocean only the paths inside a volume have work here (a fog holds every path): their indices are collected per wave in LDS and handled 64 at a
+  // time, the others get their empty records right away.
+  __shared__ uint32_t pending_paths[kBlock / 64][128];
+  uint32_t* pending = pending_paths[threadIdx.x >> 6];
+  uint32_t num_pending = 0;  // wave-uniform
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
-  for (uint32_t round = 0; round < rounds; round++) {
-    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
-    const bool valid = i < n;
+  for (uint32_t round = 0;; round++) {
+    const bool input_done = round >= rounds;
+    if (!input_done) {
+      const uint32_t idx = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      bool in_volume = false;
+      if (idx < n) {
+        in_volume = volume_stack_peek(in.hit_id[idx].w, false) != kVolumeNone;
+        if (!in_volume) {
+          vq.bridge[idx] = make_float4(0.0f, 0.0f, 0.0f, bitsf(0u));
+          vq.sky[idx] = make_uint4(0u, 0u, 0u, 0u);
+          vq.weight[idx] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+      }
+      const unsigned long long bv = __ballot(in_volume);
+      if (in_volume) pending[num_pending + (uint32_t) __popcll(bv & below)] = idx;
+      num_pending += (uint32_t) __popcll(bv);
+    }
+    if (num_pending < (LUM_INSCATTER_COMPACT ? 64u : 1u) && !(input_done && num_pending > 0u)) {
+      if (input_done) break;
+      continue;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t take = min(num_pending, 64u);
+    num_pending -= take;
+    const bool valid = lane < take;
+    const uint32_t i = valid ? pending[num_pending + lane] : 0u;
+    __builtin_amdgcn_wave_barrier();
     uint32_t segments = 0;
     BridgeWalk walk;
     bool want_sun = false, want_amb = false, want_sun2 = false, want_amb2 = false;
