@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--flavour", default=None)
     ap.add_argument("--calib", action="store_true")
     ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--extra", default="", help="extra bench.py arguments for every workload (e.g. '--clouds'): feature frames instead of the BASELINE ones")
+    ap.add_argument("--label", default="", help="suffix of the workload keys when --extra is given (e.g. 'clouds' -> 'example+clouds')")
     args = ap.parse_args()
     os.makedirs(args.out_dir, exist_ok=True)
     os.environ.setdefault("TMPDIR", "/tmp")
@@ -127,9 +129,12 @@ def main():
         cmd = ["python3", "bench.py", "--workload", w, "--steps", "2", "--warmup", "1", "--cpu-budget", "0", "--secondary", "none", "--samples-per-pass", str(args.spp)]
         if args.flavour:
             cmd += ["--flavour", args.flavour]
+        if args.extra:
+            cmd += args.extra.split()
+        wkey = w + ("+" + args.label if args.label else "")
         merged = defaultdict(dict)  # kernel -> counter -> value PER LAUNCH (every pass launches the same kernels the same number of times)
         for tag, counters in PASSES:
-            res = run_pass(args.out_dir, "%s_%s" % (w, tag), counters, cmd, kernel_key)
+            res = run_pass(args.out_dir, "%s_%s" % (wkey, tag), counters, cmd, kernel_key)
             for k, v in res.items():
                 if not k.startswith("k_"):
                     continue
@@ -139,7 +144,7 @@ def main():
                     merged[k][c] = x / n
         flavour = args.flavour
         try:
-            line = [l for l in open(os.path.join(args.out_dir, "%s_fetch.log" % w)) if l.startswith("{")][-1]
+            line = [l for l in open(os.path.join(args.out_dir, "%s_fetch.log" % wkey)) if l.startswith("{")][-1]
             flavour = json.loads(line)["config"].get("flavour", flavour)
         except (OSError, IndexError, ValueError, KeyError):
             pass
@@ -170,7 +175,9 @@ def main():
                     if v.get(c) is not None:
                         e[c.lower().replace("sq_", "") + "_per_launch"] = v[c]
             rec[key] = e
-        out["workloads"][w] = rec
+        if args.extra:
+            rec["bench_args"] = args.extra
+        out["workloads"][wkey] = rec
         json.dump(out, open(os.path.join(args.out_dir, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
     print(json.dumps({w: {k: {"MB/launch": round(e["bytes_per_launch"] / 1e6, 1), "l2_hit": e.get("l2_hit_rate")} for k, e in r.items() if isinstance(e, dict)}
                       for w, r in out["workloads"].items()}, indent=1))
