@@ -53,3 +53,36 @@ def test_rendering_without_gpu_fails_loudly():
         assert "no CPU fallback" in str(e)
     else:
         raise AssertionError("Core() must not succeed without a HIP device")
+
+
+def test_register_budgets_of_the_hot_kernels():
+    """The occupancy the measurements in DESIGN.md section 4 / 8 rest on, read from the compiler's resource report of the last build
+    (luminary_amd/lib/obj/kernel_resource_usage.txt): the fast flavour's ray kernels fit 128 registers (4 waves per SIMD, one 1024-thread workgroup per
+    CU) without spilling more than a handful, k_shade<constant sky> runs at 3 waves, k_clouds at 4, and no shading kernel falls to a single wave."""
+    import subprocess
+    path = os.path.join(ROOT, "luminary_amd", "lib", "obj", "kernel_resource_usage.txt")
+    assert os.path.exists(path), "run `python -m luminary_amd.build` first"
+    rows, cur = [], None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = {"name": m.group(1)}
+            rows.append(cur)
+            continue
+        if cur is None:
+            continue
+        for key, short in (("VGPRs", "vgpr"), ("Occupancy [waves/SIMD]", "occ"), ("VGPRs Spill", "spill")):
+            m = re.search(re.escape(key) + r": (\d+)", line)
+            if m:
+                cur[short] = int(m.group(1))
+    names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.split("\n")
+    table = {re.sub(r"\(.*", "", n).replace("void ", ""): r for r, n in zip(rows, names)}
+    for k in ("lum::fast::k_trace", "lum::fast::k_shadow_rays", "lum::fast::k_trace_particles"):
+        assert table[k]["occ"] == 4 and table[k]["vgpr"] <= 128 and table[k]["spill"] <= 16, (k, table[k])
+    assert table["lum::fast::k_shade<2u, false>"]["occ"] == 3, table["lum::fast::k_shade<2u, false>"]
+    assert table["lum::fast::k_clouds"]["occ"] == 4
+    for k, r in table.items():
+        if k.startswith("lum::fast::k_") and "occ" in r:
+            assert r["occ"] >= 2, (k, r)
+    for k in ("lum::fast::k_particle_shade", "lum::fast::k_ocean_shade", "lum::fast::k_volume_inscatter"):
+        assert table[k]["occ"] >= 3, (k, table[k])
