@@ -195,6 +195,13 @@ struct ShadowQueue {
 // sun, 16 the ambient sample.
 constexpr uint32_t kVolumeShadowKinds = 19, kVolumeKindSun = 15, kVolumeKindAmbient = 16, kVolumeKindSun2 = 17, kVolumeKindAmbient2 = 18;
 constexpr uint32_t kShadowKindAmbient2 = 4, kShadowKindSun2 = 5, kSurfaceShadowKindsWater = 6;
+// Clouds: the (path, layer) marches of a depth and their results (k_clouds_list -> k_clouds_march -> k_clouds)
+struct CloudQueue {
+  uint32_t* items;       // path index | layer << 30, for every layer a path's ray reaches before its hit
+  float4* result;        // [layer * capacity + path]: scattered light rgb | transmittance
+  float* hit_dist;       // [layer * capacity + path]
+  uint32_t capacity;
+};
 struct VolumeQueue {
   float4* bridge;        // light colour rgb (already weighted) | number of segments (uint bits; 0 = no bridge)
   uint4* sky;            // sun colour (record format) xy | ambient colour zw; zero = no sample
@@ -241,7 +248,8 @@ enum CtrlWord : uint32_t {
   // the fog's own visibility pass runs k_shadow_rays on `ctrl + kCtlVolumeShift`: its item count and cursor are these two words
   kCtlVolumeShift = 16u, kCtlVolumeShadowItems = kCtlShadowItems + kCtlVolumeShift, kCtlVolumeShadowCursor = kCtlShadowCursor + kCtlVolumeShift,
   kCtlVolumeItems = 2u * LUM_CTL_LINE + 2u,
-  kCtlParticleCursor = LUM_CTL_LINE + 8u  // work cursor of the particle pass of the closest-hit kernel (8 words, like the other cursors)
+  kCtlParticleCursor = LUM_CTL_LINE + 8u,  // work cursor of the particle pass of the closest-hit kernel (8 words, like the other cursors)
+  kCtlCloudItems = 2u * LUM_CTL_LINE + 3u, kCtlCloudCursor = LUM_CTL_LINE + 24u  // the cloud marches of a depth: their number and the persistent kernel's cursor
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 

@@ -50,6 +50,9 @@ constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 #ifndef LUM_CLOUD_WAVES
 #define LUM_CLOUD_WAVES 4  // k_clouds: waves per SIMD it is compiled for (2 / 3 / 4 measured: 1602 / 1369 / 1283 ms, profiles/r02_ab_experiments.txt)
 #endif
+#ifndef LUM_CLOUD_PERSISTENT
+#define LUM_CLOUD_PERSISTENT 1  // 0 (measurement only): one lane per path marches its three layers inside k_clouds, no list and no persistent lanes
+#endif
 #ifndef LUM_HIT_COMPACT
 #define LUM_HIT_COMPACT 1  // 0 (measurement only): k_ocean_shade / k_particle_shade shade what every round finds, partial waves and all
 #endif
@@ -1235,14 +1238,103 @@ __global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_ocean_shade(Devic
 // cloud_process_tasks (cloud.cuh:340-384; device_renderer.c:78-82): after the volume events, every path is marched through the cloud layers up to its
 // hit. The scattered light goes to the path's result, its throughput takes the layers' (and, with atmosphere_scattering, the air's) transmittance,
 // and its origin moves up to the last layer entered so that the aerial-perspective pass and the sky see the rest of the ray.
-__global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene sc, PathQueue in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+// Three kernels. The marches differ wildly in length - a ray meets nothing, or up to ~100 in-cloud steps each with a sky march and two cloud-shadow
+// marches of its own, and ends early below 10 % transmittance - so one lane per path leaves most lanes of a wave waiting for its longest ray (measured:
+// VALU lane utilisation 0.27). k_clouds_list therefore lists the (path, layer) marches, k_clouds_march runs them with persistent lanes that take the
+// next march as soon as theirs is over, and k_clouds composes the layers of a path in the order its ray enters them.
+__global__ __launch_bounds__(kBlock) void k_clouds_list(DeviceScene sc, PathQueue in, CloudQueue cq, uint32_t* ctrl) {
   const uint32_t n = ctrl[kCtlPaths];
   const SkyView sky = sky_view(sc);
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
-  // Only rays that reach a cloud layer before their hit are marched - after the first bounce about every second path, scattered over the queue.
-  // As in k_shade, a wave collects the indices of those paths in LDS and marches them 64 at a time, so that the others do not leave lanes idle
-  // during the expensive part. Paths are independent: the order changes nothing.
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    uint32_t mask = 0;
+    if (i < n && in.hit_id[i].x != kHitInvalid) {  // kHitInvalid: ended by the sky fast path of the volume events (no task exists for it in the reference)
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z)), ray = v3(d4.x, d4.y, d4.z);
+      const float limit = o4.w * 0.001f;
+#pragma unroll
+      for (int l = 0; l < 3; l++) if (cloud_layer_intersection(sc, sky_origin, ray, limit, l).x != kFltMax) mask |= 1u << l;
+    }
+#pragma unroll
+    for (uint32_t l = 0; l < 3; l++) {
+      const bool want = (mask >> l) & 1u;
+      const unsigned long long b = __ballot(want);
+      if (!b) continue;
+      uint32_t base = 0;
+      if (lane == 0) base = atomicAdd(ctrl + kCtlCloudItems, (uint32_t) __popcll(b));
+      base = __builtin_amdgcn_readfirstlane(base);
+      if (want) cq.items[base + (uint32_t) __popcll(b & below)] = i | (l << 30);
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds_march(DeviceScene sc, PathQueue in, CloudQueue cq, uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlCloudItems];
+  uint32_t* cursor = ctrl + kCtlCloudCursor;
+  const SkyView sky = sky_view(sc);
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  CloudMarch m;
+  uint32_t slot = 0;      // where this lane's result goes
+  bool active = false;
+  uint32_t chunk_next = 0, chunk_end = 0;
+  bool more = true;       // wave-uniform: the list may still hold marches
+  for (;;) {
+    // hand idle lanes the next marches: the wave reserves 64 list entries at a time
+    unsigned long long idle = __ballot(!active);
+    while (idle != 0ull && more) {
+      if (chunk_next >= chunk_end) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(cursor, 64u);
+        base = __builtin_amdgcn_readfirstlane(base);
+        chunk_next = base;
+        chunk_end = min(base + 64u, n);
+        more = base < n;
+        if (!more) break;
+      }
+      const uint32_t avail = chunk_end - chunk_next, want = (uint32_t) __popcll(idle);
+      const uint32_t rank = (uint32_t) __popcll(idle & below);
+      if (!active && rank < avail) {
+        const uint32_t item = cq.items[chunk_next + rank];
+        const uint32_t i = item & 0x3FFFFFFFu;
+        const int l = (int) (item >> 30);
+        const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+        const uint4 hid = in.hit_id[i];
+        const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+        const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z)), ray = v3(d4.x, d4.y, d4.z);
+        const F2 isect = cloud_layer_intersection(sc, sky_origin, ray, o4.w * 0.001f, l);
+        slot = (uint32_t) l * cq.capacity + i;
+        active = m.begin(sc, sky, smp, sky_origin, ray, isect.x, isect.y, l);
+        if (!active) { const CloudResult r = m.result(); cq.result[slot] = make_float4(r.scattered_light.r, r.scattered_light.g, r.scattered_light.b, r.transmittance); cq.hit_dist[slot] = r.hit_dist; }
+      }
+      chunk_next += min(want, avail);
+      idle = __ballot(!active);
+    }
+    if (__ballot(active) == 0ull) break;
+    V3 pos = m.origin;
+    float density = 0.0f;
+    bool over = false;
+    if (active) over = !m.find(sc, pos, density);
+    if (active && !over) over = !m.light(sc, sky, pos, density);
+    if (active && over) {
+      const CloudResult r = m.result();
+      cq.result[slot] = make_float4(r.scattered_light.r, r.scattered_light.g, r.scattered_light.b, r.transmittance);
+      cq.hit_dist[slot] = r.hit_dist;
+      active = false;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene sc, PathQueue in, CloudQueue cq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const SkyView sky = sky_view(sc);
+  const uint32_t lane = threadIdx.x & 63;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  // Only the paths whose ray reached a layer have something to compose (with atmosphere_scattering: an aerial-perspective march per layer entered);
+  // a wave collects them in LDS and handles them 64 at a time.
   __shared__ uint32_t pending_marches[kBlock / 64][128];
   uint32_t* pending = pending_marches[threadIdx.x >> 6];
   uint32_t num_pending = 0;  // wave-uniform
@@ -1252,7 +1344,7 @@ __global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene 
     if (!input_done) {
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
       bool march = false;
-      if (i < n && in.hit_id[i].x != kHitInvalid) {  // kHitInvalid: ended by the sky fast path of the volume events (no task exists for it in the reference)
+      if (i < n && in.hit_id[i].x != kHitInvalid) {
         const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
         const V3 sky_origin = world_to_sky(sky, v3(o4.x, o4.y, o4.z)), ray = v3(d4.x, d4.y, d4.z);
         const float limit = o4.w * 0.001f;
@@ -1264,10 +1356,7 @@ __global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene 
       if (march) pending[num_pending + (uint32_t) __popcll(bm & below)] = i;
       num_pending += (uint32_t) __popcll(bm);
     }
-#ifndef LUM_CLOUD_COMPACT
-#define LUM_CLOUD_COMPACT 1  // 0 (measurement only): every round marches what it found, partial waves and all
-#endif
-    if (num_pending < (LUM_CLOUD_COMPACT ? 64u : 1u) && !(input_done && num_pending > 0u)) {
+    if (num_pending < 64u && !(input_done && num_pending > 0u)) {
       if (input_done) break;
       continue;
     }
@@ -1287,7 +1376,17 @@ __global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene 
       Col record = record_unpack(U2{aux.x, aux.y});
       Col color = splat(0.0f);
       float cloud_transmittance = 1.0f;
-      const float cloud_offset = clouds_render(sc, sky, smp, world_to_sky(sky, origin), ray, o4.w * 0.001f, color, record, cloud_transmittance);
+      const float cloud_offset = clouds_render_with(sc, sky, smp, world_to_sky(sky, origin), ray, o4.w * 0.001f, color, record, cloud_transmittance,
+                                                    [&](int l, float start, float dist) {
+#if LUM_CLOUD_PERSISTENT
+                                                      (void) dist;
+                                                      if (start == kFltMax) return CloudResult{splat(0.0f), 1.0f, start};  // not reached: clouds_compute's empty result
+                                                      const float4 r = cq.result[(uint32_t) l * cq.capacity + i];
+                                                      return CloudResult{col(r.x, r.y, r.z), r.w, cq.hit_dist[(uint32_t) l * cq.capacity + i]};
+#else
+                                                      return clouds_compute(sc, sky, smp, world_to_sky(sky, origin), ray, start, dist, l);
+#endif
+                                                    });
       if (sc.cloud_atmosphere_scattering && cloud_offset != kFltMax && cloud_offset > 0.0f) {
         const float cloud_world_offset = cloud_offset * 1000.0f;
         const V3 moved = origin + ray * cloud_world_offset;

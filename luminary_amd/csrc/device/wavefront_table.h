@@ -48,7 +48,9 @@ struct WavefrontKernels {
   void (*ocean_shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl,
                       uint32_t depth_const);
   // clouds (dev_cloud.h, dev_cloud_march.h): the march through the cloud layers, sky mode DEFAULT only
-  void (*clouds)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const);
+  void (*clouds_list)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, uint32_t* ctrl);
+  void (*clouds_march)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, uint32_t* ctrl, uint32_t depth_const);
+  void (*clouds)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*trace_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                      uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes);
 };

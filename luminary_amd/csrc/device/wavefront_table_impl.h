@@ -81,8 +81,14 @@ static void ocean_shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, con
                         uint32_t* ctrl, uint32_t depth_const) {
   hipLaunchKernelGGL(k_ocean_shade, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, ctrl, depth_const);
 }
-static void clouds(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
-  hipLaunchKernelGGL(k_clouds, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
+static void clouds_list(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_clouds_list, dim3(grid), dim3(kBlock), 0, s, sc, in, cq, ctrl);
+}
+static void clouds_march(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_clouds_march, dim3(grid), dim3(kBlock), 0, s, sc, in, cq, ctrl, depth_const);
+}
+static void clouds(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const CloudQueue& cq, float4* results, const uint32_t* ctrl, uint32_t depth_const) {
+  hipLaunchKernelGGL(k_clouds, dim3(grid), dim3(kBlock), 0, s, sc, in, cq, results, ctrl, depth_const);
 }
 static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, uint32_t n, const float* origins, const float* dirs, const uint32_t* ignore, uint32_t* out,
                        uint32_t* cursor, uint64_t* counters, uint32_t lds_nodes) {
@@ -90,7 +96,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
 
 }  // namespace table
 LUM_NS_END

@@ -54,6 +54,7 @@ struct LumContext {
   ShadowQueue shadow{};
   uint32_t particle_lds_nodes = 0;
   VolumeQueue volume{};           // fog (dev_volume.h); allocated with the work block when the scene's fog is active
+  CloudQueue cloud{};             // the cloud marches of a depth (kernels.h k_clouds_*); allocated with the work block when clouds are marched
   uint32_t work_shadow_kinds = 0; // visibility-ray kinds per path the work block was sized for (4, or 17 with fog)
   float4* d_results = nullptr;
   float* d_frame_output = nullptr;  // display-referred planes of the output chain [3 * W * H]
@@ -161,6 +162,7 @@ void free_work(LumContext* ctx) {
   ctx->work_block = nullptr;
   ctx->capacity = 0;
   ctx->work_shadow_kinds = 0;
+  ctx->cloud = CloudQueue{};
 }
 
 int ensure_work(LumContext* ctx, uint32_t paths) {
@@ -168,13 +170,15 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   // instead of 4 at a surface (6 with an ocean: the second segments of the sun and ambient samples of a vertex under water)
   const bool volumes = ctx->scene.fog_active || ctx->scene.ocean_active;
   const uint32_t kinds = volumes ? kVolumeShadowKinds : 4u;
-  if (paths <= ctx->capacity && kinds <= ctx->work_shadow_kinds) return 0;
+  const bool clouds = ctx->scene.cloud_active && ctx->scene.sky_mode == kSkyDefault;
+  if (clouds && paths >= (1u << 30)) { ctx->error = "pass too large for the cloud march list (2^30 paths)"; return 1; }
+  if (paths <= ctx->capacity && kinds <= ctx->work_shadow_kinds && (!clouds || ctx->cloud.items)) return 0;
   if (paths < ctx->capacity) paths = ctx->capacity;
   free_work(ctx);
   // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to `kinds` visibility rays x (48 B + 16 B result) + 4 B light-query index
   // (+ the volumes' 96 B of in-scattering records, 4 B scattering-event index and 48 B of water-surface factors of the surface vertices)
   const size_t n = paths;
-  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 100 + 48 : 0)) + 48 * 256;
+  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 100 + 48 : 0) + (clouds ? 3 * (4 + 16 + 4) : 0)) + 56 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
@@ -210,6 +214,13 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
     ctx->nee.sun_water = (float4*) take(n * 16);
     ctx->nee.amb_t1    = (float4*) take(n * 16);
     ctx->nee.amb_t2    = (float4*) take(n * 16);
+  }
+  ctx->cloud = CloudQueue{};
+  if (clouds) {  // per path up to three marches: list entry, result, distance of the first cloud
+    ctx->cloud.items    = (uint32_t*) take(3 * n * 4);
+    ctx->cloud.result   = (float4*) take(3 * n * 16);
+    ctx->cloud.hit_dist = (float*) take(3 * n * 4);
+    ctx->cloud.capacity = paths;
   }
   ctx->work_shadow_kinds = kinds;
   ctx->capacity = paths;
@@ -1278,7 +1289,11 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     if (sc.cloud_active && sc.sky_mode == kSkyDefault && sc.cloud_noise_shape) {  // device_manager.c:474, device_renderer.c:78-82
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
-      wf.clouds(grid_for(N), stream, sc, ctx->queue[cur], ctx->d_results, (const uint32_t*) ctrl, depth_const);
+#if LUM_CLOUD_PERSISTENT
+      wf.clouds_list(grid_for(N), stream, sc, ctx->queue[cur], ctx->cloud, ctrl);
+      wf.clouds_march(ctx->trace_blocks * 4u, stream, sc, ctx->queue[cur], ctx->cloud, ctrl, depth_const);  // persistent: 4 workgroups of 256 per CU
+#endif
+      wf.clouds(grid_for(N), stream, sc, ctx->queue[cur], ctx->cloud, ctx->d_results, (const uint32_t*) ctrl, depth_const);
     }
     if (sc.sky_aerial_perspective && sc.sky_mode != kSkyConstantColor) {  // device_manager.c:475, device_renderer.c:84-88
       Launch l(ctx, stream, LUMC_KERNEL_SKY);
