@@ -327,3 +327,19 @@ def test_fast_flavour_renders_the_same_clouds():
     rel_l2 = np.linalg.norm(a - b) / np.linalg.norm(a)
     assert rel_l2 < 0.05, rel_l2
     assert abs(b.sum() / a.sum() - 1.0) < 5e-3, b.sum() / a.sum()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [SKY_MODE_DEFAULT, SKY_MODE_HDRI])
+def test_everything_at_once_matches_the_oracle(mode):
+    """Ocean, fog, particles, clouds and aerial perspective in one frame - every kernel of the schedule in one pass, in the procedural mode (clouds marched
+    per path) and in the panorama mode (clouds baked in, their transmittance dimming the sun)."""
+    from test_particles import _with_particles
+    host = scenes.zoo_scene(48, 32, 4, sky_mode=mode)
+    scenes.set_camera(host, (0.5, 3.2, 13.0), (0.12, 0.03, 0.0), fov=0.9)
+    k = host.get_sky(); k.aerial_perspective = True; k.hdri_dim, k.hdri_samples = 16, 2; host.set_sky(k)
+    o = host.get_ocean(); o.active, o.height, o.amplitude, o.frequency = True, 1.2, 0.3, 0.5; host.set_ocean(o)
+    f = host.get_fog(); f.active, f.density = True, 50.0; host.set_fog(f)
+    _with_particles(host, count=1500, size=20.0, scale=5.0)
+    _with_clouds(host)
+    _parity(host, samples=3)
