@@ -1248,6 +1248,9 @@ __global__ __launch_bounds__(kBlock) void k_clouds_list(DeviceScene sc, PathQueu
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  // one list reservation per 8 rounds of a wave (three per round, one per layer, kept the counter's atomic unit busier than the kernel's own work)
+  constexpr uint32_t kListRounds = 8;
+  uint32_t masks = 0;  // 3 bits per round: the layers this lane's path of that round reaches
   for (uint32_t round = 0; round < rounds; round++) {
     const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
     uint32_t mask = 0;
@@ -1258,15 +1261,26 @@ __global__ __launch_bounds__(kBlock) void k_clouds_list(DeviceScene sc, PathQueu
 #pragma unroll
       for (int l = 0; l < 3; l++) if (cloud_layer_intersection(sc, sky_origin, ray, limit, l).x != kFltMax) mask |= 1u << l;
     }
+    const uint32_t slot = round % kListRounds;
+    masks |= mask << (3u * slot);
+    if (slot + 1u == kListRounds || round + 1u == rounds) {
+      uint32_t total = 0;
 #pragma unroll
-    for (uint32_t l = 0; l < 3; l++) {
-      const bool want = (mask >> l) & 1u;
-      const unsigned long long b = __ballot(want);
-      if (!b) continue;
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(ctrl + kCtlCloudItems, (uint32_t) __popcll(b));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (want) cq.items[base + (uint32_t) __popcll(b & below)] = i | (l << 30);
+      for (uint32_t b = 0; b < 3u * kListRounds; b++) total += (uint32_t) __popcll(__ballot((masks >> b) & 1u));
+      if (total) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(ctrl + kCtlCloudItems, total);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const uint32_t group_start = round - slot;
+#pragma unroll
+        for (uint32_t b = 0; b < 3u * kListRounds; b++) {
+          const bool want = (masks >> b) & 1u;
+          const unsigned long long bal = __ballot(want);
+          if (want) cq.items[base + (uint32_t) __popcll(bal & below)] = (((group_start + b / 3u) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x) | ((b % 3u) << 30);
+          base += (uint32_t) __popcll(bal);
+        }
+      }
+      masks = 0;
     }
   }
 }
