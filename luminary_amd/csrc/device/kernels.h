@@ -489,70 +489,54 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         }
       }
     }
-    // wave-aggregated appends: one atomic per wave and list
+    // Wave-aggregated appends. The three lists (survivors, visibility items, light queries) are reserved by ONE memory instruction: lanes 0-2
+    // each bump one counter, so a batch waits for one atomic round trip instead of three in a row (the words sit on separate 128-byte lines).
     const unsigned long long ballot = __ballot(survive);
-    if (ballot) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(count_out, (uint32_t) __popcll(ballot));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (survive) {
-        const uint32_t j = base + (uint32_t) __popcll(ballot & below);
-        st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
+    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun), bl = __ballot(want_lq);
+    const unsigned long long b2a = kWater ? __ballot(want_amb2) : 0ull, b2s = kWater ? __ballot(want_sun2) : 0ull;
+    const uint32_t ng = (uint32_t) __popcll(bg), na = (uint32_t) __popcll(ba), ns = (uint32_t) __popcll(bn), na2 = (uint32_t) __popcll(b2a);
+    const uint32_t want_count = (lane == 0) ? (uint32_t) __popcll(ballot) : (lane == 1) ? ng + na + ns + na2 + (uint32_t) __popcll(b2s) : (lane == 2) ? (uint32_t) __popcll(bl) : 0u;
+    uint32_t* const want_word = (lane == 0) ? count_out : (lane == 1) ? ctrl + kCtlShadowItems : ctrl + kCtlLightItems;
+    uint32_t reserved = 0;
+    if (want_count) reserved = atomicAdd(want_word, want_count);
+    const uint32_t base_out = __builtin_amdgcn_readlane(reserved, 0), base_shadow = __builtin_amdgcn_readlane(reserved, 1), base_light = __builtin_amdgcn_readlane(reserved, 2);
+    if (survive) {
+      const uint32_t j = base_out + (uint32_t) __popcll(ballot & below);
+      st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
+    }
+    if (want_geo) {
+      const uint32_t j = base_shadow + (uint32_t) __popcll(bg & below);
+      st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
+      st_stream(&sq.dir_out[j], make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i)));
+      st_stream(&sq.ids[j], s_geo_ids);
+    }
+    if (want_amb) {
+      const uint32_t j = base_shadow + ng + (uint32_t) __popcll(ba & below);
+      st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w));
+      st_stream(&sq.dir_out[j], make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i)));
+      st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
+    }
+    if (want_sun) {
+      const uint32_t j = base_shadow + ng + na + (uint32_t) __popcll(bn & below);
+      st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w));
+      st_stream(&sq.dir_out[j], make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i)));
+      st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
+    }
+    if (kWater) {  // second segments beyond the water surface
+      if (want_amb2) {
+        const uint32_t j = base_shadow + ng + na + ns + (uint32_t) __popcll(b2a & below);
+        sq.origin_dist[j] = s_amb2_o;
+        sq.dir_out[j] = make_float4(s_amb2_d.x, s_amb2_d.y, s_amb2_d.z, bitsf(kShadowKindAmbient2 * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
+      }
+      if (want_sun2) {
+        const uint32_t j = base_shadow + ng + na + ns + na2 + (uint32_t) __popcll(b2s & below);
+        sq.origin_dist[j] = s_sun2_o;
+        sq.dir_out[j] = make_float4(s_sun2_d.x, s_sun2_d.y, s_sun2_d.z, bitsf(kShadowKindSun2 * sq.capacity + i));
+        sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
       }
     }
-    const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun);
-    if (bg | ba | bn) {
-      const uint32_t ng = (uint32_t) __popcll(bg), na = (uint32_t) __popcll(ba);
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, ng + na + (uint32_t) __popcll(bn));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (want_geo) {
-        const uint32_t j = base + (uint32_t) __popcll(bg & below);
-        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
-        st_stream(&sq.dir_out[j], make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i)));
-        st_stream(&sq.ids[j], s_geo_ids);
-      }
-      if (want_amb) {
-        const uint32_t j = base + ng + (uint32_t) __popcll(ba & below);
-        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_amb_dir.w));
-        st_stream(&sq.dir_out[j], make_float4(s_amb_dir.x, s_amb_dir.y, s_amb_dir.z, bitsf(2u * sq.capacity + i)));
-        st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
-      }
-      if (want_sun) {
-        const uint32_t j = base + ng + na + (uint32_t) __popcll(bn & below);
-        st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_sun_dir.w));
-        st_stream(&sq.dir_out[j], make_float4(s_sun_dir.x, s_sun_dir.y, s_sun_dir.z, bitsf(3u * sq.capacity + i)));
-        st_stream(&sq.ids[j], make_uint4(0xFFFFFFFFu, 0u, s_geo_ids.z, s_geo_ids.w));
-      }
-    }
-    if (kWater) {
-      const unsigned long long b2a = __ballot(want_amb2), b2s = __ballot(want_sun2);
-      if (b2a | b2s) {
-        const uint32_t na2 = (uint32_t) __popcll(b2a);
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(ctrl + kCtlShadowItems, na2 + (uint32_t) __popcll(b2s));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (want_amb2) {
-          const uint32_t j = base + (uint32_t) __popcll(b2a & below);
-          sq.origin_dist[j] = s_amb2_o;
-          sq.dir_out[j] = make_float4(s_amb2_d.x, s_amb2_d.y, s_amb2_d.z, bitsf(kShadowKindAmbient2 * sq.capacity + i));
-          sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
-        }
-        if (want_sun2) {
-          const uint32_t j = base + na2 + (uint32_t) __popcll(b2s & below);
-          sq.origin_dist[j] = s_sun2_o;
-          sq.dir_out[j] = make_float4(s_sun2_d.x, s_sun2_d.y, s_sun2_d.z, bitsf(kShadowKindSun2 * sq.capacity + i));
-          sq.ids[j] = make_uint4(0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0u);
-        }
-      }
-    }
-    const unsigned long long bl = __ballot(want_lq);
-    if (bl) {
-      uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(ctrl + kCtlLightItems, (uint32_t) __popcll(bl));
-      base = __builtin_amdgcn_readfirstlane(base);
-      if (want_lq) sq.light_items[base + (uint32_t) __popcll(bl & below)] = i;
-    }
+    if (want_lq) sq.light_items[base_light + (uint32_t) __popcll(bl & below)] = i;
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) vertices += __shfl_down(vertices, off);
