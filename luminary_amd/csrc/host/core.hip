@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cfloat>
+#include <queue>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +36,7 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU (lumc_set_bvh_builder)
+  bool top_order_by_area = false; // which nodes count as the top of the tree (staged in LDS): breadth first, or best first by box area (LUM_TOP_ORDER=area; measured: mixed)
   double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
   uint32_t bvh_meshes_by_builder[2] = {0, 0};  // meshes of the last upload built by SAH / by LBVH
   uint32_t lds_nodes = 0;         // nodes of the tree top every ray-kernel workgroup stages in LDS
@@ -413,6 +415,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
   if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : 0;
+  if (const char* o = getenv("LUM_TOP_ORDER")) ctx->top_order_by_area = std::strcmp(o, "area") == 0;
   if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
   if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;
   if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
@@ -845,21 +848,79 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     std::vector<uint32_t> order;
     std::vector<uint8_t> seen(n, 0);
     order.reserve(n);
-    order.push_back(0); seen[0] = 1;
     const size_t top_budget = std::min<size_t>(n, 4096);
-    for (size_t head = 0; head < order.size() && order.size() < top_budget; head++) {
-      const uint32_t id = order[head];
-      const bool top_level = id < sc.tlas_num_nodes;
-      for (int k = 0; k < 4; k++) {
-        const uint32_t c = nodes[id].child[k];
-        if (c == kBvhEmpty) continue;
-        uint32_t next;
-        if (c & kBvhLeafBit) {
-          if (!top_level) continue;
-          next = mesh_root[v->instance_mesh_ids[tlas_order[c & 0x0FFFFFFFu]]];
+    auto next_of = [&](uint32_t id, int k, uint32_t& next) {
+      const uint32_t c = nodes[id].child[k];
+      if (c == kBvhEmpty) return false;
+      if (c & kBvhLeafBit) {
+        if (id >= sc.tlas_num_nodes) return false;
+        next = mesh_root[v->instance_mesh_ids[tlas_order[c & 0x0FFFFFFFu]]];
+      }
+      else next = c;
+      return true;
+    };
+    if (ctx->top_order_by_area) {
+      // best first: a ray that enters a node's box enters a child's with probability area(child) / area(box) (convex boxes, uniformly
+      // distributed lines), so the product of those ratios down from the root estimates how often a node is visited; a child never
+      // outranks its parent, the order stays top-down
+      auto half_area = [](float dx, float dy, float dz) { return (double) dx * dy + (double) dy * dz + (double) dz * dx; };
+      auto child_shares = [&](const Bvh4Node& node, double share[4]) {
+        float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+        for (int k = 0; k < 4; k++) {
+          if (node.child[k] == kBvhEmpty) continue;
+          lo[0] = std::min(lo[0], node.lo_x[k]); lo[1] = std::min(lo[1], node.lo_y[k]); lo[2] = std::min(lo[2], node.lo_z[k]);
+          hi[0] = std::max(hi[0], node.hi_x[k]); hi[1] = std::max(hi[1], node.hi_y[k]); hi[2] = std::max(hi[2], node.hi_z[k]);
         }
-        else next = c;
-        if (!seen[next]) { seen[next] = 1; order.push_back(next); }
+        const double whole = half_area(hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]);
+        for (int k = 0; k < 4; k++)
+          share[k] = (node.child[k] == kBvhEmpty) ? 0.0
+                   : (whole > 0.0) ? std::min(half_area(node.hi_x[k] - node.lo_x[k], node.hi_y[k] - node.lo_y[k], node.hi_z[k] - node.lo_z[k]) / whole, 1.0) : 1.0;
+      };
+      // a mesh is entered through every instance of it: its root's estimate is the sum over the top-level leaves that lead to it
+      std::vector<double> root_estimate(n, 0.0);
+      {
+        std::vector<std::pair<uint32_t, double>> walk{{0u, 1.0}};
+        for (size_t head = 0; head < walk.size() && sc.tlas_num_nodes > 0; head++) {
+          const uint32_t id = walk[head].first;
+          double share[4];
+          child_shares(nodes[id], share);
+          for (int k = 0; k < 4; k++) {
+            const uint32_t c = nodes[id].child[k];
+            if (c == kBvhEmpty) continue;
+            uint32_t next;
+            next_of(id, k, next);
+            if (c & kBvhLeafBit) root_estimate[next] += walk[head].second * share[k];
+            else walk.push_back({next, walk[head].second * share[k]});
+          }
+        }
+      }
+      std::priority_queue<std::pair<double, uint32_t>> open;
+      std::vector<uint8_t> queued(n, 0);
+      open.push({DBL_MAX, 0u}); queued[0] = 1;
+      while (!open.empty() && order.size() < top_budget) {
+        const double p = (open.top().first == DBL_MAX) ? 1.0 : open.top().first;
+        const uint32_t id = open.top().second;
+        open.pop();
+        order.push_back(id); seen[id] = 1;
+        double share[4];
+        child_shares(nodes[id], share);
+        for (int k = 0; k < 4; k++) {
+          uint32_t next;
+          if (!next_of(id, k, next) || queued[next]) continue;
+          queued[next] = 1;
+          const bool enters_mesh = (nodes[id].child[k] & kBvhLeafBit) != 0;
+          open.push({enters_mesh ? root_estimate[next] : p * share[k], next});
+        }
+      }
+    }
+    else {
+      order.push_back(0); seen[0] = 1;
+      for (size_t head = 0; head < order.size() && order.size() < top_budget; head++) {
+        const uint32_t id = order[head];
+        for (int k = 0; k < 4; k++) {
+          uint32_t next;
+          if (next_of(id, k, next) && !seen[next]) { seen[next] = 1; order.push_back(next); }
+        }
       }
     }
     for (uint32_t i = 0; i < n; i++) if (!seen[i]) order.push_back(i);

@@ -7,6 +7,6 @@ except Exception as e:  # noqa: BLE001
     print("no bench line (%s)" % e)
     sys.exit(0)
 k, p = d["config"]["kernel_ms_rank0"], d["config"]["per_ray_rank0"]
-print("%.1f Mrays/s trace %.1f shade %.1f shadow %.1f sort %.1f lq %.1f res %.1f vol %.1f | nodes %.2f/%.2f tris %.2f/%.2f upload %.2fs" % (
+print("%.1f Mrays/s trace %.1f shade %.1f shadow %.1f sort %.1f lq %.1f res %.1f vol %.1f | nodes %.2f/%.2f tris %.2f/%.2f lds %.3f/%.3f upload %.2fs" % (
     d["value"], k["trace"], k["shade"], k["shadow"], k.get("sort", 0.0), k["light_query"], k["resolve"], k.get("volume", 0.0), p["nodes_closest"], p["nodes_shadow"], p["tris_closest"],
-    p["tris_shadow"], d["config"]["scene_upload_s"]))
+    p["tris_shadow"], p.get("lds_hit_rate_closest", 0.0), p.get("lds_hit_rate_shadow", 0.0), d["config"]["scene_upload_s"]))
