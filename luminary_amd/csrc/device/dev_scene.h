@@ -253,6 +253,11 @@ enum CtrlWord : uint32_t {
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 
+#ifndef LUM_LDS_STACK_BYTES
+#define LUM_LDS_STACK_BYTES 65536u  // of a ray workgroup's LDS: bytes that hold the oldest entries of its lanes' traversal stacks instead of tree nodes (0: stacks in scratch)
+#endif
+constexpr uint32_t kRayBlockMax = 1024u;  // the ray kernels' largest workgroup: a lane's share of the LDS stack area is sized for it
+
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow, kCntCount };
 

@@ -139,8 +139,16 @@ template <> struct StackEntry<false> {
   static LUM_DEV bool reachable(E, float) { return true; }
 };
 
-template <bool kOrdered, bool kCull>
-LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+// A lane's traversal stack. Its oldest entries live in the workgroup's LDS behind the staged tree top (LUM_LDS_STACK_BYTES of it, entry i of
+// thread t at word i * blockDim + t: a lane only ever touches its own bank), the rest in scratch: the stacks of the resident lanes do not fit
+// L2 next to the nodes, and with everything in scratch they are a tenth to a fifth of a ray kernel's memory-side traffic.
+template <typename E> struct TraversalStack {
+  E* scratch; E* lds; int lds_entries; uint32_t stride;
+  LUM_DEV void store(int i, E e) { if (i < lds_entries) lds[(uint32_t) i * stride] = e; else scratch[i] = e; }
+  LUM_DEV E load(int i) const { if (i < lds_entries) return lds[(uint32_t) i * stride]; return scratch[i]; }
+};
+template <bool kOrdered, bool kCull, typename S>
+LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, S& stk, int& sp,
                             typename StackEntry<kCull>::E& top, RayStats& st) {
   using SE = StackEntry<kCull>;
   const uint32_t b = cur << 7;
@@ -177,27 +185,27 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
   // ray misses (branch-free pushes store 3 entries per visit, used or not: most of the kernel's L2 requests were those stores).
   if (k1 < inf) {
     if (k2 < inf) {
-      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
-      stk[sp] = top; sp++; top = SE::make(c2, k2);
+      if (k3 < inf) { stk.store(sp, top); sp++; top = SE::make(c3, k3); }
+      stk.store(sp, top); sp++; top = SE::make(c2, k2);
     }
-    stk[sp] = top; sp++; top = SE::make(c1, k1);
+    stk.store(sp, top); sp++; top = SE::make(c1, k1);
   }
 #else
   // Branch-free pushes. The newest entry lives in registers (`top`), older ones in scratch: a push spills the old top to a slot
   // that is only kept if the push is real, so a pop never waits for a scratch load before it can fetch the next node.
   {
     const bool v = k3 < inf;
-    stk[sp] = top; sp += v ? 1 : 0;
+    stk.store(sp, top); sp += v ? 1 : 0;
     top = v ? SE::make(c3, k3) : top;
   }
   {
     const bool v = k2 < inf;
-    stk[sp] = top; sp += v ? 1 : 0;
+    stk.store(sp, top); sp += v ? 1 : 0;
     top = v ? SE::make(c2, k2) : top;
   }
   {
     const bool v = k1 < inf;
-    stk[sp] = top; sp += v ? 1 : 0;
+    stk.store(sp, top); sp += v ? 1 : 0;
     top = v ? SE::make(c1, k1) : top;
   }
 #endif
@@ -210,8 +218,8 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
 // power of two per axis, rounded outwards by the builder (after Ylitie, Karras, Laine 2017, without their octant ordering: the eight entry
 // distances are sorted by a 19-comparator network).
 LUM_DEV float byte_f(uint32_t w, uint32_t k) { return (float) ((w >> (8u * k)) & 0xFFu); }  // v_cvt_f32_ubyte{k}
-template <bool kOrdered, bool kCull>
-LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+template <bool kOrdered, bool kCull, typename S>
+LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, S& stk, int& sp,
                              typename StackEntry<kCull>::E& top, RayStats& st) {
   using SE = StackEntry<kCull>;
   const uint32_t b = cur << 7;
@@ -264,18 +272,18 @@ LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r,
           if (k[4] < inf) {
             if (k[5] < inf) {
               if (k[6] < inf) {
-                if (k[7] < inf) { stk[sp] = top; sp++; top = SE::make(c[7], k[7]); }
-                stk[sp] = top; sp++; top = SE::make(c[6], k[6]);
+                if (k[7] < inf) { stk.store(sp, top); sp++; top = SE::make(c[7], k[7]); }
+                stk.store(sp, top); sp++; top = SE::make(c[6], k[6]);
               }
-              stk[sp] = top; sp++; top = SE::make(c[5], k[5]);
+              stk.store(sp, top); sp++; top = SE::make(c[5], k[5]);
             }
-            stk[sp] = top; sp++; top = SE::make(c[4], k[4]);
+            stk.store(sp, top); sp++; top = SE::make(c[4], k[4]);
           }
-          stk[sp] = top; sp++; top = SE::make(c[3], k[3]);
+          stk.store(sp, top); sp++; top = SE::make(c[3], k[3]);
         }
-        stk[sp] = top; sp++; top = SE::make(c[2], k[2]);
+        stk.store(sp, top); sp++; top = SE::make(c[2], k[2]);
       }
-      stk[sp] = top; sp++; top = SE::make(c[1], k[1]);
+      stk.store(sp, top); sp++; top = SE::make(c[1], k[1]);
     }
     return (k[0] < inf) ? c[0] : kBvhEmpty;
   }
@@ -285,15 +293,15 @@ LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r,
   for (uint32_t j = 0; j < 8; j++) {
     if (k[j] < inf) {
       if (next == kBvhEmpty) next = c[j];
-      else { stk[sp] = top; sp++; top = SE::make(c[j], k[j]); }
+      else { stk.store(sp, top); sp++; top = SE::make(c[j], k[j]); }
     }
   }
   return next;
 }
 
 // ---- 4-wide nodes with quantised child boxes in 64 bytes (Bvh4QNode) ----
-template <bool kOrdered, bool kCull>
-LUM_DEV uint32_t visit_node_q(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk, int& sp,
+template <bool kOrdered, bool kCull, typename S>
+LUM_DEV uint32_t visit_node_q(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, S& stk, int& sp,
                               typename StackEntry<kCull>::E& top, RayStats& st) {
   using SE = StackEntry<kCull>;
   const uint32_t b = cur << 6;
@@ -337,10 +345,10 @@ LUM_DEV uint32_t visit_node_q(const NodeSource& src, uint32_t cur, const TRay& r
   }
   if (k1 < inf) {
     if (k2 < inf) {
-      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
-      stk[sp] = top; sp++; top = SE::make(c2, k2);
+      if (k3 < inf) { stk.store(sp, top); sp++; top = SE::make(c3, k3); }
+      stk.store(sp, top); sp++; top = SE::make(c2, k2);
     }
-    stk[sp] = top; sp++; top = SE::make(c1, k1);
+    stk.store(sp, top); sp++; top = SE::make(c1, k1);
   }
   return (k0 < inf) ? c0 : kBvhEmpty;
 }
@@ -371,8 +379,8 @@ LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, Ra
 // on the hall, 32.6 -> 36.1 on the scan: rays that find an occluder have fetched a node they would never have visited (nodes per ray 15.2 -> 16.2),
 // lanes with and without a second node diverge, and the iteration carries twice the registers. Off. `second` = kBvhEmpty for lanes without such an entry. Every child of the second node
 // that the ray may touch is pushed; of the first node's children the nearest is continued with, as in visit_node.
-template <bool kCull>
-LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t second, const TRay& r, float tmax, typename StackEntry<kCull>::E* __restrict__ stk,
+template <bool kCull, typename S>
+LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t second, const TRay& r, float tmax, S& stk,
                                  int& sp, typename StackEntry<kCull>::E& top, RayStats& st) {
   using SE = StackEntry<kCull>;
   const float inf = __builtin_inff();
@@ -389,10 +397,10 @@ LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t s
       e2 = child_entry(b.nx.z, b.ny.z, b.nz.z, b.fx.z, b.fy.z, b.fz.z, r, tmax);
       e3 = child_entry(b.nx.w, b.ny.w, b.nz.w, b.fx.w, b.fy.w, b.fz.w, r, tmax);
       d0 = b.ch.x; d1 = b.ch.y; d2 = b.ch.z; d3 = b.ch.w;
-      if (e3 < inf) { stk[sp] = top; sp++; top = SE::make(d3, e3); }
-      if (e2 < inf) { stk[sp] = top; sp++; top = SE::make(d2, e2); }
-      if (e1 < inf) { stk[sp] = top; sp++; top = SE::make(d1, e1); }
-      if (e0 < inf) { stk[sp] = top; sp++; top = SE::make(d0, e0); }
+      if (e3 < inf) { stk.store(sp, top); sp++; top = SE::make(d3, e3); }
+      if (e2 < inf) { stk.store(sp, top); sp++; top = SE::make(d2, e2); }
+      if (e1 < inf) { stk.store(sp, top); sp++; top = SE::make(d1, e1); }
+      if (e0 < inf) { stk.store(sp, top); sp++; top = SE::make(d0, e0); }
     }
   }
   float k0 = child_entry(a.nx.x, a.ny.x, a.nz.x, a.fx.x, a.fy.x, a.fz.x, r, tmax);
@@ -403,24 +411,25 @@ LUM_DEV uint32_t visit_two_nodes(const NodeSource& src, uint32_t cur, uint32_t s
   cswap(k0, c0, k1, c1); cswap(k2, c2, k3, c3); cswap(k0, c0, k2, c2); cswap(k1, c1, k3, c3); cswap(k1, c1, k2, c2);
   if (k1 < inf) {
     if (k2 < inf) {
-      if (k3 < inf) { stk[sp] = top; sp++; top = SE::make(c3, k3); }
-      stk[sp] = top; sp++; top = SE::make(c2, k2);
+      if (k3 < inf) { stk.store(sp, top); sp++; top = SE::make(c3, k3); }
+      stk.store(sp, top); sp++; top = SE::make(c2, k2);
     }
-    stk[sp] = top; sp++; top = SE::make(c1, k1);
+    stk.store(sp, top); sp++; top = SE::make(c1, k1);
   }
   return (k0 < inf) ? c0 : kBvhEmpty;
 }
 
 // Pops the newest entry into (node, tnear) and refills the register top from scratch. The bottom of the stack is a sentinel
 // (kTraversalDone) that is never removed.
-LUM_DEV uint2 stack_pop(uint2* __restrict__ stk, int& sp, uint2& top) {
+template <typename S>
+LUM_DEV uint2 stack_pop(const S& stk, int& sp, uint2& top) {
   const uint2 e = top;
-  if (sp > 0) { sp--; top = stk[sp]; }
+  if (sp > 0) { sp--; top = stk.load(sp); }
   else top = make_uint2(kTraversalDone, 0u);
   return e;
 }
-template <typename E>
-LUM_DEV void stack_push(E* __restrict__ stk, int& sp, E& top, E e) { stk[sp] = top; sp++; top = e; }
+template <typename S, typename E>
+LUM_DEV void stack_push(S& stk, int& sp, E& top, E e) { stk.store(sp, top); sp++; top = e; }
 
 LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
 
@@ -463,7 +472,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   // Dual visits (visit_two_nodes) push all four children of the second node, which is not depth-first any more: the guard below allows them only
   // while fewer than kDualLimit entries are stacked, after which single visits need at most 3 more per remaining level (<= 126): 256 entries.
   constexpr int kDualLimit = 120;
-  E stk[(LUM_DUAL_VISIT && Q::kDual) ? 2 * kStackSize : kStackSize];
+  E stack_in_scratch[(LUM_DUAL_VISIT && Q::kDual) ? 2 * kStackSize : kStackSize];
   int sp = 0;
   TRay r;
   V3 wo = v3(0.0f, 0.0f, 0.0f), wd = v3(0.0f, 0.0f, 1.0f);
@@ -481,6 +490,8 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     __syncthreads();
   }
   const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
+  TraversalStack<E> stk{stack_in_scratch, reinterpret_cast<E*>(reinterpret_cast<char*>(lds_top) + lds_count * kNodeBytes) + threadIdx.x,
+                        (int) (LUM_LDS_STACK_BYTES / (kRayBlockMax * (uint32_t) sizeof(E))), blockDim.x};
 #if LUM_PREFETCH
   __shared__ uint32_t prefetch_sink[kPrefetchSinkWords];
   uint32_t* wave_sink = prefetch_sink + (threadIdx.x >> 6) * 64u;
@@ -502,7 +513,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       const bool done = SE::node(e) == kTraversalDone, leave = SE::node(e) == kLeaveInstance;
       // (an unconditional load, with the sentinel kept in memory or selected afterwards, was measured 2-16 % slower: the loaded entry
       // must flow into `top` untouched so that nothing waits for it before the next node's loads are in flight)
-      if (!done) { sp--; top = stk[sp]; }
+      if (!done) { sp--; top = stk.load(sp); }
       left_instance |= leave;
       again = !done && (leave || !SE::reachable(e, tmax));
     } while (again);
@@ -625,7 +636,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
             if (!(t & kBvhLeafBit) && sp < kDualLimit) {  // the newest entry is an inner node (markers and leaves carry the leaf bit): same level as `cur`
               second = t;
               st.nodes++;
-              if (sp > 0) { sp--; top = stk[sp]; }
+              if (sp > 0) { sp--; top = stk.load(sp); }
               else top = SE::make(kTraversalDone, 0.0f);
             }
             cur = visit_two_nodes<Q::kCull>(nodes, cur, second, r, tmax, stk, sp, top, st);
@@ -757,7 +768,8 @@ struct ShadowState {
 // ---- single-level traversal of the light-only BVH (rare: BSDF-sampled light directions) ----
 template <typename LeafFn>
 LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
-  uint2 stk[kStackSize];
+  uint2 stack_in_scratch[kStackSize];
+  TraversalStack<uint2> stk{stack_in_scratch, nullptr, 0, 0u};  // the light tree is shallow: scratch only
   int sp = 0;
   uint2 top = make_uint2(kTraversalDone, 0u);
   TRay r;

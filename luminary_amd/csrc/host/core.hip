@@ -987,10 +987,11 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     const int blocks_per_cu = LUM_TRACE_BLOCKS_PER_CU;  // both flavours launch one workgroup of 768 (3 waves per SIMD) or 1024 (4) threads per CU
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
     lds_bytes = lds_bytes > 16384 ? lds_bytes - 8192 : 0;  // margin: the ray kernels' static LDS (the prefetch experiment's sink) and the runtime's own
+    lds_bytes = lds_bytes > LUM_LDS_STACK_BYTES ? lds_bytes - LUM_LDS_STACK_BYTES : 0;  // the stacks' share (dev_trace.h, TraversalStack)
     ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / kNodeBytes, nodes.size());
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
-    const size_t dyn = (size_t) ctx->lds_nodes * kNodeBytes;
+    const size_t dyn = (size_t) ctx->lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES;
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->set_ray_kernel_lds(dyn));
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->set_ray_kernel_lds(dyn));
   }
@@ -1283,14 +1284,14 @@ static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue
   DeviceScene tree = ctx->scene;
   tree.bvh_nodes = tree.particle_bvh_nodes; tree.blas_tris = tree.particle_tris; tree.tlas_leaves = tree.particle_leaves; tree.tlas_num_nodes = tree.particle_tlas_num_nodes;
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * kNodeBytes, stream, tree, q, ctrl, ctx->particle_lds_nodes);
+  ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES, stream, tree, q, ctrl, ctx->particle_lds_nodes);
 }
 
 // The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
 static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const DeviceScene& sc = ctx->scene;
   const uint32_t max_depth = sc.max_ray_depth;
-  const size_t lds_dyn = (size_t) ctx->lds_nodes * kNodeBytes;
+  const size_t lds_dyn = (size_t) ctx->lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES;
   int cur = 0;
   const WavefrontKernels& wf = *ctx->wf;
   const bool render_volumes = sc.fog_active || sc.ocean_active;  // device_manager.c:478
@@ -2008,7 +2009,7 @@ int lumc_trace_closest(LumContext* ctx, uint32_t n, const float* d_origins, cons
   uint32_t* cursor = ctx->d_ctrl + kCtlStride * (kCtrlRows - 1);
   HIP_TRY(ctx, hipMemsetAsync(cursor, 0, sizeof(uint32_t) * 8, stream));  // up to 8 work cursors (dev_trace.h LUM_XCD_RANGES)
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
-  ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * kNodeBytes, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
+  ctx->wf->trace_rays(grid_persistent(ctx, n), (size_t) ctx->lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES, stream, ctx->scene, n, d_origins, d_dirs, d_ignore, d_out, cursor, ctx->d_counters,
                       ctx->lds_nodes);
   HIP_TRY(ctx, hipGetLastError());
   return 0;
