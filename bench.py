@@ -76,8 +76,10 @@ def build_workload(name, width, height, bounces):
     raise SystemExit("unknown workload " + name)
 
 
-def pmc_record(workload, spp_per_step, flavour):
-    """Per-kernel counter record of this workload from the committed PMC passes (None when there is none for this configuration)."""
+def pmc_record(workload, spp_per_step, flavour, lds_stack_bytes):
+    """Per-kernel counter record of this workload from the committed PMC passes (None when there is none for this configuration).
+    `_ray_traffic_stale`: the passes ran a library with another LDS split of the ray kernels (traversal stacks in scratch instead of LDS):
+    their memory-side bytes of k_trace / k_shadow_rays are not this build's; k_shade's counters are unaffected."""
     try:
         with open(PMC_FILE) as f:
             t = json.load(f)
@@ -85,6 +87,7 @@ def pmc_record(workload, spp_per_step, flavour):
         if int(e["spp_per_step"]) != int(spp_per_step) or e.get("flavour", "exact") != flavour:
             return None
         e = dict(e)
+        e["_ray_traffic_stale"] = int(e.get("lds_stack_bytes", 0)) != int(lds_stack_bytes)
         e["_source"] = "profiles/pmc_counters.json (%s)" % t.get("collected", "rocprofv3 --pmc passes of this command")
         e["_fetch_factor"] = t.get("fetch_size_factor")
         return e
@@ -268,7 +271,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     del fm, sm
 
     # ---- rooflines (rank 0's kernels) ----
-    pmc = pmc_record(name, args.samples_per_pass, core.flavour) if (world == 1 and dist is None) else None
+    pmc = pmc_record(name, args.samples_per_pass, core.flavour, core.lds_stack_bytes()) if (world == 1 and dist is None) else None
     nodes_trace, tris_trace, nodes_shadow, tris_shadow = cnt[CNT_NODES], cnt[CNT_TRIS], cnt[6], cnt[7]
     alg = {"trace": nodes_trace * NODE_BYTES + tris_trace * TRI_BYTES + cnt[CNT_TRACE] * IO_TRACE_BYTES,
            "shadow": nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES}
@@ -281,7 +284,21 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
              "achieved_algorithmic": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "algorithmic_bytes_per_launch": alg[k] / max(n, 1),
              "achieved": None, "frac": None, "traffic": None, "l2": None}
         e = pmc.get(pmc_name[k]) if pmc else None
-        if e and avg_ms > 0:
+        if e and avg_ms > 0 and pmc["_ray_traffic_stale"]:
+            # The committed counters are of a build whose traversal stacks lived in scratch. This build keeps their oldest 64 KB per workgroup
+            # in LDS, which removes most of the stack traffic (all of the old build's writes but the results, and their read-back) and adds
+            # some node fetches (a smaller staged tree top). No counter-based figure is claimed: `traffic` is null, `achieved` / `frac` are a
+            # LOWER bound (old fetched bytes minus old written bytes: as if every stack byte written had also been read back from memory and
+            # none of it remained), the old build's total is given as the upper bound.
+            lower = max(e["fetch_bytes_per_launch"] - e["write_bytes_per_launch"], 0.0)
+            r["achieved"] = lower / (avg_ms * 1e-3) / 1e9
+            r["frac"] = r["achieved"] / HBM_PEAK_GBPS
+            r["frac_upper_bound"] = e["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            r["traffic_stale"] = {"bytes_per_launch": e["bytes_per_launch"], "fetch": e["fetch_bytes_per_launch"], "write": e["write_bytes_per_launch"],
+                                  "lds_stack_bytes_then": int(pmc.get("lds_stack_bytes", 0)), "lds_stack_bytes_now": core.lds_stack_bytes(),
+                                  "note": "counters predate the LDS-resident traversal stacks; frac is a lower bound, frac_upper_bound prices the old traffic at the new time"}
+            r["traffic_source"], r["fetch_size_factor"] = pmc["_source"], pmc["_fetch_factor"]
+        elif e and avg_ms > 0:
             r["traffic"] = e["bytes_per_launch"]
             r["traffic_fetch"], r["traffic_write"] = e["fetch_bytes_per_launch"], e["write_bytes_per_launch"]
             # the PMC passes ran the same passes (same sample ids) as this run's steps: bytes per launch carry over, time is this run's
@@ -315,7 +332,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     total_ms = sum(v[0] for v in times.values()) or 1.0
     out = {
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "ray_sorting": core.ray_sorting,
+        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "lds_stack_bytes": core.lds_stack_bytes(), "ray_sorting": core.ray_sorting,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if dist is not None else "single GPU",
                    "frame_reduce": None if dist is None else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,

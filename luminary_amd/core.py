@@ -329,6 +329,12 @@ class Core:
         """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
         self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1}[name]))
 
+    def lds_stack_bytes(self):
+        """Bytes of a ray workgroup's LDS that hold traversal stack entries (build-time constant of the library)."""
+        fn = self._lib.lumc_lds_stack_bytes
+        fn.restype = C.c_uint
+        return int(fn())
+
     def bvh_build_seconds(self):
         fn = self._lib.lumc_bvh_build_seconds
         fn.restype = C.c_double

@@ -2269,6 +2269,8 @@ int lumc_set_flavour(LumContext* ctx, int flavour) {
 }
 int lumc_get_flavour(const LumContext* ctx) { return (ctx && ctx->wf == wavefront_kernels_exact()) ? LUMC_FLAVOUR_EXACT : LUMC_FLAVOUR_FAST; }
 
+unsigned int lumc_lds_stack_bytes(void) { return LUM_LDS_STACK_BYTES; }
+
 int lumc_set_bvh_builder(LumContext* ctx, int builder) {
   if (!ctx || builder < 0 || builder > 1) { if (ctx) ctx->error = "lumc_set_bvh_builder: 0 (SAH, host) or 1 (LBVH, GPU)"; return 1; }
   ctx->bvh_builder = builder;

@@ -142,13 +142,16 @@ def main():
                 merged[k]["_launches"] = n
                 for c, x in v.items():
                     merged[k][c] = x / n
-        flavour = args.flavour
+        flavour, lds_stack_bytes = args.flavour, 0
         try:
             line = [l for l in open(os.path.join(args.out_dir, "%s_fetch.log" % wkey)) if l.startswith("{")][-1]
-            flavour = json.loads(line)["config"].get("flavour", flavour)
+            config = json.loads(line)["config"]
+            flavour = config.get("flavour", flavour)
+            lds_stack_bytes = int(config.get("lds_stack_bytes", 0))
         except (OSError, IndexError, ValueError, KeyError):
             pass
-        rec = {"spp_per_step": args.spp, "flavour": flavour or "exact"}
+        # the build the counters belong to: bench.py only prices the ray kernels with them when its library has the same LDS split
+        rec = {"spp_per_step": args.spp, "flavour": flavour or "exact", "lds_stack_bytes": lds_stack_bytes}
         for key, v in sorted(merged.items()):
             n = v.get("_launches", 1)
             fetch, write = v.get("FETCH_SIZE", 0.0) * 1024.0 * factor, v.get("WRITE_SIZE", 0.0) * 1024.0
