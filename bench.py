@@ -18,16 +18,21 @@ N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak 
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
 Prints ONE JSON line on rank 0.
 
-roofline: for the dominant ray kernel
+roofline: the block of the kernel that took most of the timed region, chosen over ALL kernels; the three big kernels are also
+reported by name (roofline_trace, roofline_shadow, roofline_shade). For a ray kernel
   achieved_algorithmic = (nodes*112 + triangles*48 + rays*40) / kernel time   SURVEY §8d's formula, counted in the kernel. Most of these
                          bytes are served by LDS/L1/L2, so this is NOT an HBM rate and no fraction of the HBM peak is derived from it.
   traffic              = memory-side bytes per launch of that kernel from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
                          same command and workload (profiles/pmc_counters.json, written by tools/pmc_collect.py; the factor applied to
                          FETCH_SIZE for this access pattern is calibrated by tools/microbench/fetch_calib.hip and stored in the file)
-  achieved, frac       = traffic / average launch time, and that over the 8 TB/s HBM peak: the HBM-side figure. null without a PMC
-                         record for the workload.
+  achieved, frac       = traffic / average launch time, and that over the 8 TB/s HBM peak: the memory-side figure ("memory_side" says what
+                         serves it: the hall's tree and triangles fit the 256 MiB Infinity Cache and FETCH_SIZE counts its hits, so there it
+                         is a fabric rate; the 10 M-triangle scan is an HBM rate). null - never an inferred bound - unless the committed
+                         counters were collected from this very source tree (source_hash) and workload.
+  frac_of_dependent_gather_ceiling = memory-side line rate of the kernel over what tools/microbench/gather.hip reaches with chains of dependent
+                         divergent 7 x 16-byte line gathers at the same occupancy and table size (profiles/gather_ceiling.json)
   l2                   = L2 request bytes per launch (TCP_TCC_READ_REQ x 64 B... see the file) over the aggregate L2 bandwidth
-and "valu" for k_shade (the longest kernel): wave-level VALU instructions per launch / time against the chip's VALU issue peak.
+and bound "valu" for k_shade: wave-level VALU instructions per launch / time against the chip's VALU issue peak (its memory-side bytes are given too).
 """
 import argparse
 import json
@@ -76,10 +81,38 @@ def build_workload(name, width, height, bounces):
     raise SystemExit("unknown workload " + name)
 
 
+def source_hash():
+    """Identity of the device code a counter file belongs to: SHA-1 over the kernel sources, the core that launches them, the BVH builders and
+    the build flags. tools/pmc_collect.py stores it with the counters; a bench run of another source tree reports no counter-based figure."""
+    import hashlib
+    from luminary_amd import build as b
+    h = hashlib.sha1()
+    csrc = os.path.join(ROOT, "luminary_amd", "csrc")
+    files = sorted(os.path.join("device", f) for f in os.listdir(os.path.join(csrc, "device"))) + ["host/core.hip", "host/bvh_build.cpp", "host/lbvh.hip"]
+    for f in files:
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(f.encode() + b"\0" + fh.read())
+    h.update(b._flags_identity().encode())
+    return h.hexdigest()[:16]
+
+
+def gather_ceiling(table_bytes, active_lanes=32):
+    """Line rate (128-byte lines per second) tools/microbench/gather.hip measured for dependent divergent 7 x 16-byte gathers at 16 waves per CU with
+    `active_lanes` of 64 lanes holding a ray, from the table size nearest to `table_bytes` (profiles/gather_ceiling.json); None without the file."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "gather_ceiling.json")) as f:
+            rows = [r for r in json.load(f)["rows"] if r["loads"] == 7 and r["group"] == 1 and r["dep"] == 1 and r["active_per_wave"] == active_lanes and r["waves_per_cu"] == 16]
+        if not rows:
+            return None
+        r = min(rows, key=lambda r: abs(np.log(max(r["table_mib"] * 1048576.0, 1.0) / max(table_bytes, 1.0))))
+        return {"lines_per_s": r["gvisits_per_s"] * 1e9, "table_mib": r["table_mib"], "line_tb_s": r["line_tb_s"]}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_record(workload, spp_per_step, flavour, lds_stack_bytes):
     """Per-kernel counter record of this workload from the committed PMC passes (None when there is none for this configuration).
-    `_ray_traffic_stale`: the passes ran a library with another LDS split of the ray kernels (traversal stacks in scratch instead of LDS):
-    their memory-side bytes of k_trace / k_shadow_rays are not this build's; k_shade's counters are unaffected."""
+    `_stale`: the passes ran another source tree (or another LDS split of the ray kernels): no counter-based figure is derived from them."""
     try:
         with open(PMC_FILE) as f:
             t = json.load(f)
@@ -87,7 +120,7 @@ def pmc_record(workload, spp_per_step, flavour, lds_stack_bytes):
         if int(e["spp_per_step"]) != int(spp_per_step) or e.get("flavour", "exact") != flavour:
             return None
         e = dict(e)
-        e["_ray_traffic_stale"] = int(e.get("lds_stack_bytes", 0)) != int(lds_stack_bytes)
+        e["_stale"] = int(e.get("lds_stack_bytes", 0)) != int(lds_stack_bytes) or e.get("source_hash") != source_hash()
         e["_source"] = "profiles/pmc_counters.json (%s)" % t.get("collected", "rocprofv3 --pmc passes of this command")
         e["_fetch_factor"] = t.get("fetch_size_factor")
         return e
@@ -277,6 +310,27 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
            "shadow": nodes_shadow * NODE_BYTES + tris_shadow * TRI_BYTES + cnt[CNT_SHADOW] * IO_SHADOW_BYTES}
     pmc_name = {"trace": "k_trace", "shadow": "k_shadow_rays", "shade": "k_shade"}
 
+    bvh = core.bvh_stats()  # BLAS nodes, BLAS triangles, TLAS nodes, light nodes
+    working_set = (bvh[0] + bvh[2]) * 128.0 + bvh[1] * 48.0
+    memory_side = ("fabric: the tree and triangles (%.0f MB) fit the 256 MiB Infinity Cache, whose hits FETCH_SIZE counts" if working_set < 240e6 else
+                   "hbm: the tree and triangles (%.0f MB) exceed the 256 MiB Infinity Cache") % (working_set / 1e6)
+
+    def add_traffic(r, e, avg_ms):
+        """memory-side bytes per launch from the counter record `e` of the same source tree; stale records only say that they are stale"""
+        if not e or avg_ms <= 0:
+            return
+        if pmc["_stale"]:
+            r["traffic_stale"] = {"note": "profiles/pmc_counters.json was collected from another source tree or LDS split: no counter-based figure for this build",
+                                  "source_hash_then": pmc.get("source_hash"), "source_hash_now": source_hash()}
+            return
+        r["traffic"] = e["bytes_per_launch"]
+        r["traffic_fetch"], r["traffic_write"] = e["fetch_bytes_per_launch"], e["write_bytes_per_launch"]
+        r["memory_side"] = memory_side
+        r["traffic_source"], r["fetch_size_factor"], r["source_hash"] = pmc["_source"], pmc["_fetch_factor"], pmc.get("source_hash")
+        if e.get("l2_read_bytes_per_launch"):
+            l2 = e["l2_read_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            r["l2"] = {"achieved": l2, "peak": L2_PEAK_GBPS, "frac": l2 / L2_PEAK_GBPS, "hit_rate": e.get("l2_hit_rate"), "unit": "GB/s"}
+
     def ray_roofline(k):
         ms, n = times[k]
         avg_ms = ms / max(n, 1)
@@ -284,55 +338,43 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
              "achieved_algorithmic": alg[k] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0, "algorithmic_bytes_per_launch": alg[k] / max(n, 1),
              "achieved": None, "frac": None, "traffic": None, "l2": None}
         e = pmc.get(pmc_name[k]) if pmc else None
-        if e and avg_ms > 0 and pmc["_ray_traffic_stale"]:
-            # The committed counters are of a build whose traversal stacks lived in scratch. This build keeps their oldest 64 KB per workgroup
-            # in LDS, which removes most of the stack traffic (all of the old build's writes but the results, and their read-back) and adds
-            # some node fetches (a smaller staged tree top). No counter-based figure is claimed: `traffic` is null, `achieved` / `frac` are a
-            # LOWER bound (old fetched bytes minus old written bytes: as if every stack byte written had also been read back from memory and
-            # none of it remained), the old build's total is given as the upper bound.
-            lower = max(e["fetch_bytes_per_launch"] - e["write_bytes_per_launch"], 0.0)
-            r["achieved"] = lower / (avg_ms * 1e-3) / 1e9
-            r["frac"] = r["achieved"] / HBM_PEAK_GBPS
-            r["frac_upper_bound"] = e["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
-            r["traffic_stale"] = {"bytes_per_launch": e["bytes_per_launch"], "fetch": e["fetch_bytes_per_launch"], "write": e["write_bytes_per_launch"],
-                                  "lds_stack_bytes_then": int(pmc.get("lds_stack_bytes", 0)), "lds_stack_bytes_now": core.lds_stack_bytes(),
-                                  "note": "counters predate the LDS-resident traversal stacks; frac is a lower bound, frac_upper_bound prices the old traffic at the new time"}
-            r["traffic_source"], r["fetch_size_factor"] = pmc["_source"], pmc["_fetch_factor"]
-        elif e and avg_ms > 0:
-            r["traffic"] = e["bytes_per_launch"]
-            r["traffic_fetch"], r["traffic_write"] = e["fetch_bytes_per_launch"], e["write_bytes_per_launch"]
+        add_traffic(r, e, avg_ms)
+        if r["traffic"] is not None:
             # the PMC passes ran the same passes (same sample ids) as this run's steps: bytes per launch carry over, time is this run's
-            r["achieved"] = e["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+            r["achieved"] = r["traffic"] / (avg_ms * 1e-3) / 1e9
             r["frac"] = r["achieved"] / HBM_PEAK_GBPS
-            if e.get("l2_read_bytes_per_launch"):
-                l2 = e["l2_read_bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
-                r["l2"] = {"achieved": l2, "peak": L2_PEAK_GBPS, "frac": l2 / L2_PEAK_GBPS, "hit_rate": e.get("l2_hit_rate"), "unit": "GB/s"}
-            r["traffic_source"], r["fetch_size_factor"] = pmc["_source"], pmc["_fetch_factor"]
+            r["lane_utilisation"], r["wait_fraction"] = e.get("valu_lane_utilisation"), e.get("wait_fraction")
+            ceil = gather_ceiling(working_set)
+            if ceil:
+                lines_per_s = r["traffic_fetch"] / 128.0 / (avg_ms * 1e-3)
+                r["frac_of_dependent_gather_ceiling"] = lines_per_s / ceil["lines_per_s"]
+                r["dependent_gather_ceiling"] = dict(ceil, note="tools/microbench/gather.hip: dependent 7 x 16 B gathers of random 128-B lines, 16 waves per CU, "
+                                                     "32 of 64 lanes active, every visit a miss; the kernel's figure counts only the lines that reach the memory side")
         return r
 
     def valu_roofline(k):
         ms, n = times[k]
         avg_ms = ms / max(n, 1)
         r = {"bound": "valu", "kernel": pmc_name[k], "launches": n, "avg_launch_ms": avg_ms, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
-             "achieved": None, "frac": None, "vertices_per_launch": cnt[CNT_VERTICES] / max(n, 1)}
+             "achieved": None, "frac": None, "traffic": None, "vertices_per_launch": cnt[CNT_VERTICES] / max(n, 1)}
         e = pmc.get(pmc_name[k]) if pmc else None
-        if e and e.get("valu_insts_per_launch") and avg_ms > 0:
+        add_traffic(r, e, avg_ms)
+        if r["traffic"] is not None and e.get("valu_insts_per_launch"):
             r["achieved"] = e["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
             r["frac"] = r["achieved"] / VALU_PEAK_GINST
             r["valu_insts_per_launch"] = e["valu_insts_per_launch"]
-            r["lane_utilisation"] = e.get("valu_lane_utilisation")
+            r["lane_utilisation"], r["wait_fraction"] = e.get("valu_lane_utilisation"), e.get("wait_fraction")
             r["valu_insts_per_vertex_lane"] = e["valu_insts_per_launch"] * 64.0 * (e.get("valu_lane_utilisation") or 0.0) / max(r["vertices_per_launch"], 1.0)
-            r["traffic_source"] = pmc["_source"]
+            r["memory_side_GBps"] = r["traffic"] / (avg_ms * 1e-3) / 1e9
         return r
 
-    dominant_ray = "trace" if times["trace"][0] >= times["shadow"][0] else "shadow"
-    roofline = ray_roofline(dominant_ray)
-    other = ray_roofline("shadow" if dominant_ray == "trace" else "trace")
-    shade = valu_roofline("shade")
+    blocks = {"trace": ray_roofline("trace"), "shadow": ray_roofline("shadow"), "shade": valu_roofline("shade")}
+    dominant = max(blocks, key=lambda k: times[k][0])  # over ALL kernels: nothing outside these three comes close (kernel_share_rank0)
+    roofline = dict(blocks[dominant], dominant_of="all kernels of the timed region by total time")
     total_ms = sum(v[0] for v in times.values()) or 1.0
     out = {
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
-        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "lds_stack_bytes": core.lds_stack_bytes(), "ray_sorting": core.ray_sorting,
+        "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "lds_stack_bytes": core.lds_stack_bytes(), "source_hash": source_hash(), "ray_sorting": core.ray_sorting,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if dist is not None else "single GPU",
                    "frame_reduce": None if dist is None else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
@@ -343,7 +385,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                    "kernel_ms_rank0": {k: round(v[0], 3) for k, v in times.items()},
                    "kernel_share_rank0": {k: round(v[0] / total_ms, 3) for k, v in times.items() if v[0] > 0},
                    "output_chain_rank0": output_chain, "scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2)},
-        "roofline": roofline, "roofline_other_ray_kernel": other, "roofline_shade": shade,
+        "roofline": roofline, "roofline_trace": blocks["trace"], "roofline_shadow": blocks["shadow"], "roofline_shade": blocks["shade"],
     }
     return out, view
 
@@ -423,7 +465,8 @@ def main():
         return
     out = {"metric": "Mrays/s at 1920x1080, 8 bounces", "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": head["config"], "roofline": head["roofline"], "roofline_other_ray_kernel": head["roofline_other_ray_kernel"], "roofline_shade": head["roofline_shade"],
+           "config": head["config"], "roofline": head["roofline"], "roofline_trace": head["roofline_trace"], "roofline_shadow": head["roofline_shadow"],
+           "roofline_shade": head["roofline_shade"],
            "cpu_baseline": cpu, "secondary": secondary or None}
     print(json.dumps(out))
 

@@ -11,7 +11,8 @@ import os
 from . import build as _build
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libluminary_amd.so")
+# LUM_LIB: an experiment variant built here with `python -m luminary_amd.build --variant NAME` (luminary_amd/lib/variants/NAME/), for A/B runs on the GPU box
+LIB_PATH = os.environ.get("LUM_LIB") or os.path.join(_HERE, "lib", "libluminary_amd.so")
 
 
 class LuminaryError(RuntimeError):

@@ -61,7 +61,13 @@ def _run(cmd):
     return r.stdout
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variant=None):
+    """variant: an experiment build (LUM_CXXFLAGS / LUM_FAST_FLAGS of the calling environment) into lib/variants/<variant>/ next to the default
+    library, compiled here and selected on the GPU box with LUM_LIB=<path>: an A/B run then costs no compile time there."""
+    global LIB, OBJ_DIR, STAMP
+    if variant:
+        vdir = os.path.join(LIB_DIR, "variants", variant)
+        LIB, OBJ_DIR, STAMP = os.path.join(vdir, "libluminary_amd.so"), os.path.join(vdir, "obj"), os.path.join(vdir, "build_flags.txt")
     # the effective flag list is part of the build's identity: a library left behind by a diagnostic build (LUM_CXXFLAGS=-DLUM_PHASE_STATS,
     # an ablation ...) is rebuilt instead of being silently reused
     stamp_ok = os.path.exists(STAMP) and open(STAMP).read() == _flags_identity()
@@ -106,4 +112,5 @@ def build(force=False, verbose=False):
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    variant = sys.argv[sys.argv.index("--variant") + 1] if "--variant" in sys.argv else None
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv, variant=variant))

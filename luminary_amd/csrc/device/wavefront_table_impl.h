@@ -101,6 +101,15 @@ static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock
 }  // namespace table
 LUM_NS_END
 
+#if defined(LUM_PHASE_STATS) && LUM_FAST
+// the fast flavour's own counter block (dev_math.h); the exact flavour's is read by lumc_debug_phase_stats (core.hip)
+extern "C" int lumc_debug_phase_stats_fast(uint64_t out[16], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_phase), sizeof(uint64_t) * 16) != hipSuccess) return 1;
+  if (reset) { const uint64_t zero[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase), zero, sizeof(zero)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
 namespace lum {
 #if LUM_FAST
 const WavefrontKernels* wavefront_kernels_fast() { return &fast::table::kTable; }

@@ -278,6 +278,8 @@ LuminaryResult luminary_host_create(LuminaryHost** host, LuminaryHostCreateInfo 
 }
 
 namespace {
+LuminaryResult render_locked(LuminaryHost* host, uint32_t num_samples, uint32_t samples_per_pass);
+uint32_t pass_size(LuminaryHost* h);
 void stop_worker(LuminaryHost* h, bool join) {
   {
     std::lock_guard<std::mutex> l(h->worker_mutex);
@@ -291,7 +293,7 @@ void stop_worker(LuminaryHost* h, bool join) {
 
 // The "Device" worker: one iteration = the next sample allocations of the running accumulation (luminary_ext_render, which also rebuilds
 // the scene after an edit and produces the outputs that are due). Small chunks first, so that the first images of a new accumulation
-// appear quickly, then 8 sample ids per wavefront pass.
+// appear quickly, then whole wavefront passes of pass_size() sample ids.
 void worker_main(LuminaryHost* h) {
   for (;;) {
     {
@@ -300,17 +302,31 @@ void worker_main(LuminaryHost* h) {
       if (h->worker_stop) break;
     }
     while (h->api_waiting.load() > 0) std::this_thread::yield();  // edits first
-    uint32_t accumulated;
-    bool scene_ready;
-    { ApiLock lock(h); accumulated = h->accumulated_samples; scene_ready = h->core_scene_valid; }
-    if (accumulated >= (1u << 20)) {  // every sample id is used up (MAX_NUM_GLOBAL_SAMPLES, device_utils.h:39): idle until the next edit
+    LuminaryResult r = LUMINARY_SUCCESS;
+    bool idle = false;
+    {
+      // One lock from the decision to the last kernel of the iteration: the flag is looked at again under the host's mutex (a stop that set it
+      // and then took and released this mutex has been seen by now, so nothing renders after luminary_ext_stop_render returned), and the
+      // first sample id is computed under the same lock the passes run under (no start / edit / synchronous render can slip in between).
+      ApiLock lock(h);
+      bool active;
+      { std::lock_guard<std::mutex> l(h->worker_mutex); active = h->async_active && !h->async_failed && !h->worker_stop; }
+      if (!active) continue;
+      const uint32_t accumulated = h->accumulated_samples;
+      if (accumulated >= (1u << 20)) idle = true;  // every sample id is used up (MAX_NUM_GLOBAL_SAMPLES, device_utils.h:39): idle until the next edit
+      else {
+        thread_status_start(h->status_device, h->core_scene_valid ? "Rendering" : "Updating scene");
+        // small allocations first so that the first images of a new accumulation appear quickly, then whole passes (pass_size)
+        const uint32_t cap = pass_size(h);
+        const uint32_t chunk = accumulated < 1u ? 1u : (accumulated < cap ? accumulated : cap);
+        r = render_locked(h, chunk, cap);
+      }
+    }
+    if (idle) {
       std::unique_lock<std::mutex> l(h->worker_mutex);
       h->worker_cv.wait_for(l, std::chrono::milliseconds(50));
       continue;
     }
-    thread_status_start(h->status_device, scene_ready ? "Rendering" : "Updating scene");
-    const uint32_t chunk = accumulated < 1u ? 1u : (accumulated < 8u ? accumulated : 8u);
-    const LuminaryResult r = luminary_ext_render(h, chunk);
     thread_status_stop(h->status_device);
     if (r != LUMINARY_SUCCESS) {
       std::fprintf(stderr, "[luminary_amd] render worker: %s; waiting for the next scene edit or luminary_host_start_new_render\n", luminary_result_to_string(r));
@@ -822,10 +838,21 @@ LuminaryResult produce_outputs(LuminaryHost* h, PreviewState preview = PreviewSt
 }
 }  // namespace
 
-LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
-                                           uint32_t samples_per_pass) {
-  CHECK_NULL(host);
-  ApiLock lock(host);
+namespace {
+// Sample ids per wavefront pass of the render loop. Deep bounces keep few paths alive, so many ids share a pass to keep 256 CUs busy (hall +5 %,
+// Example-class +26 %, scan +35 % from 8 to 32, profiles/r02_ab_experiments.txt) - but a pass is also the latency of the next image, so a frame
+// that is being watched (recurring outputs) keeps 8. Bounded by the work buffers: at most 64 M paths (about 32 GB of queues) per pass.
+uint32_t pass_size(LuminaryHost* h) {
+  const uint32_t want = h->outputs.properties().enabled ? 8u : 32u;
+  const LuminaryRendererSettings& st = h->scene.settings;
+  const uint64_t pixels = std::max<uint64_t>((uint64_t) (st.width << st.supersampling) * (st.height << st.supersampling), 1u);
+  const uint64_t fit = std::max<uint64_t>((64ull << 20) / pixels, 1u);
+  return (uint32_t) std::min<uint64_t>(want, fit);
+}
+
+// luminary_ext_render_samples with the host's mutex held by the caller
+LuminaryResult render_samples_locked(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
+                                     uint32_t samples_per_pass) {
   std::vector<LumContext*> cores;
   LuminaryResult r = ensure_partition_cores(host, &cores);
   if (r) return r;
@@ -883,6 +910,14 @@ LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* p
   }
   return LUMINARY_SUCCESS;
 }
+}  // namespace
+
+LuminaryResult luminary_ext_render_samples(LuminaryHost* host, const uint32_t* pixels, uint32_t num_pixels, uint32_t first_sample, uint32_t num_samples,
+                                           uint32_t samples_per_pass) {
+  CHECK_NULL(host);
+  ApiLock lock(host);
+  return render_samples_locked(host, pixels, num_pixels, first_sample, num_samples, samples_per_pass);
+}
 // The frame's first sample as the undersampling preview: every iteration renders one pixel per block, then the outputs are produced
 // from the coarse image; the last iteration completes sample 0 of every pixel. Returns through *ran whether the preview applied.
 static LuminaryResult render_first_sample_as_preview(LuminaryHost* host, bool* ran) {
@@ -904,17 +939,14 @@ static LuminaryResult render_first_sample_as_preview(LuminaryHost* host, bool* r
   return LUMINARY_SUCCESS;
 }
 
-// The reference's render loop for `num_samples` more sample allocations of the whole frame (device_renderer.c:488-575): with
-// settings.enable_adaptive_sampling the stage schedule of the adaptive sampler, otherwise one sample id per pixel and allocation.
-LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
-  CHECK_NULL(host);
-  LuminaryRendererSettings settings;
-  { ApiLock lock(host); settings = host->scene.settings; }
+namespace {
+// luminary_ext_render with the host's mutex held by the caller (the render worker and the API call share it): the first sample id of the
+// allocation is read under the same lock the passes run under.
+LuminaryResult render_locked(LuminaryHost* host, uint32_t num_samples, uint32_t samples_per_pass) {
+  const LuminaryRendererSettings settings = host->scene.settings;
   if (!settings.enable_adaptive_sampling) {
-    uint32_t first;
-    { ApiLock lock(host); first = host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0; }
+    uint32_t first = host->pixels_all && !host->adaptive_active ? host->accumulated_samples : 0;
     if (first == 0 && num_samples > 0) {  // a new accumulation: its first sample may be due as the undersampling preview
-      ApiLock lock(host);
       const LuminaryResult r = ensure_core(host);
       if (r) return r;
       if (!preview_schedule(host).empty()) {
@@ -932,9 +964,8 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
         if (ran) { first = 1; num_samples--; }
       }
     }
-    return luminary_ext_render_samples(host, nullptr, 0, first, num_samples, 8);
+    return render_samples_locked(host, nullptr, 0, first, num_samples, samples_per_pass);
   }
-  ApiLock lock(host);
   LuminaryResult r = ensure_core(host);
   if (r) return r;
   if (!host->adaptive_active) {
@@ -981,6 +1012,15 @@ LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
     if (r) return r;
   }
   return LUMINARY_SUCCESS;
+}
+}  // namespace
+
+// The reference's render loop for `num_samples` more sample allocations of the whole frame (device_renderer.c:488-575): with
+// settings.enable_adaptive_sampling the stage schedule of the adaptive sampler, otherwise one sample id per pixel and allocation.
+LuminaryResult luminary_ext_render(LuminaryHost* host, uint32_t num_samples) {
+  CHECK_NULL(host);
+  ApiLock lock(host);
+  return render_locked(host, num_samples, 8);
 }
 LuminaryResult luminary_ext_get_accumulators(LuminaryHost* host, float* first_moment, float* second_moment, uint32_t* num_pixels) {
   CHECK_NULL(host);

@@ -12,22 +12,23 @@ import luminary_amd  # noqa: E402
 from luminary_amd.core import Core  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "example"
-host, label = bench.build_workload(name, 1920, 1080, 8)
+host, label = bench.build_workload(name, 1920, 1080, 8), bench.WORKLOADS[name]
 core = Core(0)
 core.upload(host.device_scene())
 core.set_pixels(None)
 lib = luminary_amd._lib()
+stats_fn = lib.lumc_debug_phase_stats_fast if core.flavour == "fast" else lib.lumc_debug_phase_stats  # one counter block per flavour
 out = (C.c_uint64 * 16)()
-core.render(0, 8, samples_per_pass=8)
-lib.lumc_debug_phase_stats(out, 1)
+core.render(0, 32, samples_per_pass=32)
+stats_fn(out, 1)
 core.reset_counters()
-core.render(8, 8, samples_per_pass=8)
-lib.lumc_debug_phase_stats(out, 1)
+core.render(32, 32, samples_per_pass=32)
+stats_fn(out, 1)
 cnt = core.counters()
 node_it, inst_it, inst_l, tri_it, tri_l, outer, pop_it, pop_l = [int(x) for x in out][:8]
 sh = [int(x) for x in out][8:]
 nodes = int(cnt[4] + cnt[6]); tris = int(cnt[5] + cnt[7]); rays = int(cnt[0] + cnt[1])
-print(label)
+print(label, "- flavour", core.flavour)
 print("rays %d  node visits %d  triangle tests %d" % (rays, nodes, tris))
 print("node phase:     %10d wave iterations, lane occupancy %.3f" % (node_it, nodes / (64.0 * max(node_it, 1))))
 print("pop:            %10d wave iterations, lane occupancy %.3f" % (pop_it, pop_l / (64.0 * max(pop_it, 1))))

@@ -31,6 +31,9 @@ PASSES = [
     ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum"]),
     ("ea", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum"]),
     ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS"]),
+    ("ta", ["TA_BUSY_avr", "TA_BUSY_max", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "GRBM_GUI_ACTIVE"]),
+    ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
+             "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_GATE_EN1_sum", "TCP_TCC_READ_REQ_sum"]),
     ("sq2", ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM"]),
 ]
 
@@ -142,16 +145,17 @@ def main():
                 merged[k]["_launches"] = n
                 for c, x in v.items():
                     merged[k][c] = x / n
-        flavour, lds_stack_bytes = args.flavour, 0
+        flavour, lds_stack_bytes, source_hash = args.flavour, 0, None
         try:
             line = [l for l in open(os.path.join(args.out_dir, "%s_fetch.log" % wkey)) if l.startswith("{")][-1]
             config = json.loads(line)["config"]
             flavour = config.get("flavour", flavour)
             lds_stack_bytes = int(config.get("lds_stack_bytes", 0))
+            source_hash = config.get("source_hash")
         except (OSError, IndexError, ValueError, KeyError):
             pass
         # the build the counters belong to: bench.py only prices the ray kernels with them when its library has the same LDS split
-        rec = {"spp_per_step": args.spp, "flavour": flavour or "exact", "lds_stack_bytes": lds_stack_bytes}
+        rec = {"spp_per_step": args.spp, "flavour": flavour or "exact", "lds_stack_bytes": lds_stack_bytes, "source_hash": source_hash}
         for key, v in sorted(merged.items()):
             n = v.get("_launches", 1)
             fetch, write = v.get("FETCH_SIZE", 0.0) * 1024.0 * factor, v.get("WRITE_SIZE", 0.0) * 1024.0
@@ -177,6 +181,22 @@ def main():
                 for c in ("SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"):
                     if v.get(c) is not None:
                         e[c.lower().replace("sq_", "") + "_per_launch"] = v[c]
+            if v.get("GRBM_GUI_ACTIVE"):
+                # the vector-memory address unit: one divergent 16-byte lane load per cycle and CU (tools/microbench/gather.hip), so its busy share says how
+                # close a ray kernel is to the rate at which its lanes can ask for nodes and triangles at all
+                e["ta_busy_frac_avg"], e["ta_busy_frac_max"] = v.get("TA_BUSY_avr", 0.0) / v["GRBM_GUI_ACTIVE"], v.get("TA_BUSY_max", 0.0) / v["GRBM_GUI_ACTIVE"]
+                e["gui_active_cycles_per_launch"] = v["GRBM_GUI_ACTIVE"]
+                e["ta_addr_stalled_by_tc_cycles_per_launch"] = v.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0.0)
+                e["ta_data_stalled_by_tc_cycles_per_launch"] = v.get("TA_DATA_STALLED_BY_TC_CYCLES_sum", 0.0)
+                e["ta_flat_read_wavefronts_per_launch"] = v.get("TA_FLAT_READ_WAVEFRONTS_sum", 0.0)
+            if v.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+                e["l1_cache_accesses_per_launch"] = v["TCP_TOTAL_CACHE_ACCESSES_sum"]
+                e["l1_ta_data_stall_cycles_per_launch"] = v.get("TCP_TCP_TA_DATA_STALL_CYCLES_sum", 0.0)
+                e["l1_pending_stall_cycles_per_launch"] = v.get("TCP_PENDING_STALL_CYCLES_sum", 0.0)
+                e["l1_read_tagconflict_stall_cycles_per_launch"] = v.get("TCP_READ_TAGCONFLICT_STALL_CYCLES_sum", 0.0)
+                e["l1_busy_cycles_per_launch"] = v.get("TCP_GATE_EN1_sum", 0.0)
+                if v.get("TCP_TCC_READ_REQ_sum"):
+                    e["l1_to_l2_read_latency_cycles"] = v.get("TCP_TCC_READ_REQ_LATENCY_sum", 0.0) / v["TCP_TCC_READ_REQ_sum"]
             rec[key] = e
         if args.extra:
             rec["bench_args"] = args.extra
