@@ -71,31 +71,62 @@ LUM_DEV float child_importance(const Ctx& g, const ChildBlock& b, uint32_t power
 
 struct TreeWork { uint32_t cont[kLightTreeOutputs]; float root_sum; };  // cont: is_light | index << 1 | probability(20 bit) << 9
 
+// The root's children as the kernels read them: dequantised once at scene upload (core.hip: mean = byte * 2^e + base, sigma = byte * 2^e_sigma, power
+// = the 16-bit integer, all exact in binary32, so these are the numbers the device used to derive per vertex), eight floats per child
+// {mean.xyz, sigma, power, 0, 0, 0}. The table is the same for every lane of every wave: it is read through the constant address space, i.e. with
+// scalar loads into SGPRs, and costs the vector unit nothing.
+typedef const float __attribute__((address_space(4)))* RootTable;
+typedef const uint32_t __attribute__((address_space(4)))* RootHeader;
+typedef float f2 __attribute__((ext_vector_type(2)));  // two binary32 numbers in a register pair: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 work on both at once
+
+// tree_importance for two children at a time. The generic form evaluates them one after the other; the surface vertex's form (the hot one: k_shade)
+// runs the same operations in the same order on register pairs, so both give the bits of tree_importance().
+template <class Ctx>
+LUM_DEV f2 tree_importance_pair(const Ctx& g, f2 power, f2 mx, f2 my, f2 mz, f2 sd) {
+  return f2{tree_importance(g, power.x, v3(mx.x, my.x, mz.x), sd.x), tree_importance(g, power.y, v3(mx.y, my.y, mz.y), sd.y)};
+}
+LUM_DEV f2 tree_importance_pair(const GeoContext& g, f2 power, f2 mx, f2 my, f2 mz, f2 sd) {
+  const f2 px = mx - g.position.x, py = my - g.position.y, pz = mz - g.position.z;
+  const f2 dist_sq = px * px + py * py + pz * pz;
+  const f2 variance = sd * sd;
+  const f2 denom = dist_sq + variance;
+  const f2 inv = f2{1.0f / denom.x, 1.0f / denom.y};
+  const f2 r = power * inv;
+  if ((g.params.flags & kMatSubstrateMask) == kMatTranslucent) return r;
+  const f2 t = variance * inv;
+  const f2 d = px * g.normal.x + py * g.normal.y + pz * g.normal.z;
+  const f2 ndl = d * f2{sqrtf(inv.x), sqrtf(inv.y)};
+  const f2 NdotL = f2{saturate(ndl.x), saturate(ndl.y)};
+  return r * (NdotL * (1.0f - t) + t);
+}
+
 // Root pass (light_tree.cuh:191-255): one scan over <= 128 children feeds 8 independent resampling lanes.
+// Two thirds of the pass are the eight reservoirs' updates (ris.cuh:138-148, per child and lane: accept = r < p; r = clamp(accept ? r / p : (r - p) / (1 - p))).
+// Both quotients are formed for two lanes at a time with packed multiplies - they do not depend on the comparison - and the comparison only selects:
+// the same operations on the same operands as the one-lane-at-a-time form, in 5.5 instead of 8 instructions per child and lane.
 template <class Ctx>
 LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler& smp) {
-  const uint4 h = sc.light_tree_root[0];
-  const uint32_t num_root_lights = h.y >> 16, num_sections = (h.z >> 16) & 0xFFu;
-  const V3 base = v3(bfloat_unpack(h.x), bfloat_unpack(h.x >> 16), bfloat_unpack(h.y));
-  const V3 ex = v3(exp2i((int8_t) (h.w & 0xFF)), exp2i((int8_t) ((h.w >> 8) & 0xFF)), exp2i((int8_t) ((h.w >> 16) & 0xFF)));
-  const float exp_v = exp2i((int8_t) (h.w >> 24));
-  float lane_random[kLightTreeOutputs], lane_target[kLightTreeOutputs];
+  const RootHeader hp = (RootHeader) sc.light_tree_root;
+  const uint4 h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
+  const uint32_t num_root_lights = h.y >> 16, num_children = ((h.z >> 16) & 0xFFu) * 8u;
+  const RootTable table = (RootTable) sc.light_root_children;
+  f2 lane_random[kLightTreeOutputs / 2];
+  float lane_target[kLightTreeOutputs];
   uint32_t lane_pick[kLightTreeOutputs];
 #pragma unroll
   for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
-    lane_random[l] = smp.next1(TreeTargets<Ctx>::kPrepass + l);
+    lane_random[l >> 1][l & 1] = smp.next1(TreeTargets<Ctx>::kPrepass + l);
     lane_target[l] = 0.0f;
     lane_pick[l] = 0;
   }
   float total = 0.0f, sum = 0.0f;
-  for (uint32_t s = 0; s < num_sections; s++) {
-    const uint4 q0 = sc.light_tree_root[1 + 3 * s], q1 = sc.light_tree_root[2 + 3 * s], q2 = sc.light_tree_root[3 + 3 * s];
-    const ChildBlock blk{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
-    const uint32_t pw[4] = {q2.x, q2.y, q2.z, q2.w};
+  for (uint32_t c = 0; c < num_children; c += 2) {
+    const RootTable e = table + 8u * c;
+    const f2 power = f2{e[4], e[12]};
+    const f2 imp = tree_importance_pair(g, power, f2{e[0], e[8]}, f2{e[1], e[9]}, f2{e[2], e[10]}, f2{e[3], e[11]});
 #pragma unroll
-    for (uint32_t c = 0; c < 8; c++) {
-      const uint32_t power_q = (pw[c >> 1] >> ((c & 1) * 16)) & 0xFFFFu;
-      const float target = child_importance(g, blk, power_q, base, ex, exp_v, c);
+    for (uint32_t k = 0; k < 2; k++) {
+      const float target = (power[k] == 0.0f) ? 0.0f : fmaxf(imp[k], 0.0f);
       total += target;
       const float prob = (target > 0.0f) ? target / total : 0.0f;
       if (prob == 0.0f) continue;
@@ -106,13 +137,18 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler
       // keep them two divisions: without the barrier the compiler rewrites `accept ? 1/p : 1/(1-p)` as `1 / (accept ? p : 1-p)` in
       // each of the eight lanes (same bits, eight correctly rounded divisions of 11 instructions instead of two)
       asm volatile("" : "+v"(inv_accept), "+v"(inv_reject));
+      const f2 ia = f2{inv_accept, inv_accept}, ir = f2{inv_reject, inv_reject}, p2 = f2{prob, prob};
 #pragma unroll
-      for (uint32_t l = 0; l < ((LUM_ABLATE_LIGHT & 4) ? 1u : kLightTreeOutputs); l++) {
-        const bool accept = lane_random[l] < prob;
-        lane_target[l] = accept ? target : lane_target[l];
-        const float shifted = accept ? lane_random[l] : lane_random[l] - prob;
-        lane_random[l] = clamp_random(shifted * (accept ? inv_accept : inv_reject));
-        if (accept) lane_pick[l] = s * 8 + c;
+      for (uint32_t q = 0; q < ((LUM_ABLATE_LIGHT & 4) ? 1u : kLightTreeOutputs / 2); q++) {
+        const f2 if_accepted = lane_random[q] * ia, if_rejected = (lane_random[q] - p2) * ir;
+#pragma unroll
+        for (uint32_t hlf = 0; hlf < 2; hlf++) {
+          const uint32_t l = 2 * q + hlf;
+          const bool accept = lane_random[q][hlf] < prob;
+          lane_target[l] = accept ? target : lane_target[l];
+          lane_pick[l] = accept ? c + k : lane_pick[l];
+          lane_random[q][hlf] = clamp_random(accept ? if_accepted[hlf] : if_rejected[hlf]);
+        }
       }
     }
   }
@@ -187,6 +223,19 @@ LUM_DEV TriLight load_tri_light(const DeviceScene& sc, uint32_t inst, uint32_t t
   t.scene_tri = sc.mesh_tri_offset[mesh] + tri;
   t.material_id = sc.tri_tex[t.scene_tri].w & 0xFFFFu;
   t.bidirectional = (sc.materials[2 * t.material_id].x & kDMatBidirectionalEmission) != 0;
+  return t;
+}
+// The same triangle from the per-light table k_light_table writes at scene upload (three 16-byte words per light: vertex | material id and the
+// bidirectional flag, edge1 | scene triangle, edge2): one round trip of three parallel loads instead of the chain handle -> mesh -> triangle offset
+// -> vertices / transform / material word, and none of the instance transform's arithmetic per candidate. The table holds what load_tri_light
+// returns in the exact flavour, bit for bit.
+LUM_DEV TriLight load_tri_light_table(const DeviceScene& sc, uint32_t light_id) {
+  const float4 a = sc.light_tri_table[3u * light_id], b = sc.light_tri_table[3u * light_id + 1u], c = sc.light_tri_table[3u * light_id + 2u];
+  TriLight t;
+  t.vertex = v3(a.x, a.y, a.z); t.edge1 = v3(b.x, b.y, b.z); t.edge2 = v3(c.x, c.y, c.z);
+  t.material_id = fbits(a.w) & 0xFFFFu;
+  t.bidirectional = (fbits(a.w) >> 16) != 0u;
+  t.scene_tri = fbits(b.w);
   return t;
 }
 LUM_DEV float tri_light_solid_angle(const TriLight& t, V3 origin) {  // light_triangle.cuh:94-108
@@ -330,8 +379,8 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
     const uint2 handle = sc.light_tri_handles[pick.light_id];
+    const TriLight tl = load_tri_light_table(sc, pick.light_id);
     if (handle.x == g.instance_id && handle.y == g.tri_id) continue;
-    const TriLight tl = load_tri_light(sc, handle.x, handle.y);
     V3 ray; float sa;
     if (!sample_tri_solid_angle(g.position, tl, smp.next2(kRndLightGeoRay + lane), ray, sa)) continue;
     F2 uv;

@@ -33,6 +33,13 @@
 #define g_phase g_phase_fast  // one counter block per flavour (two translation units in one library)
 #endif
 __device__ unsigned long long g_phase[16];
+#if LUM_FAST
+#define g_phase_time g_phase_time_fast
+#endif
+// wave-level cycles (s_memtime) per kind of iteration of the ray kernels' phase loop, and how many there were:
+//   0/1 node iterations that touch memory   2/3 node iterations on staged nodes only   4/5 triangle iterations   6/7 instance-entry iterations
+//   8/9 refills (ray fetch)   10/11 whole kernel per wave
+__device__ unsigned long long g_phase_time[16];
 #define LUM_STAT(k_iter, k_lanes) do { const unsigned long long act_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(act_)) { \
   atomicAdd(&g_phase[k_iter], 1ull); atomicAdd(&g_phase[k_lanes], (unsigned long long) __popcll(act_)); } } while (0)
 #else

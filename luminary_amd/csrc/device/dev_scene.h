@@ -65,6 +65,10 @@ constexpr uint32_t kBvhLeafMaxTri = 4;
 struct BvhTri { float p0[3]; uint32_t id; float e1[3]; uint32_t scene_index; float e2[3]; uint32_t albedo_tex; };  // albedo_tex: texture id of the
 // triangle's material or kBvhTriNoTexture: the ray queries consult the texture's alpha without touching the material first
 constexpr uint32_t kBvhTriNoTexture = 0xFFFFFFFFu;
+// ... and this value marks a triangle whose material has no albedo texture and alpha 1: a visibility ray that crosses it is blocked, which the any-hit
+// test then knows from the triangle's own 48 bytes (k_tri_opacity writes it at scene upload; without it every crossing costs two more dependent
+// fetches - the triangle's material id, then the material - before the ray may stop)
+constexpr uint32_t kBvhTriOpaque = 0xFFFFFFFEu;
 static_assert(sizeof(BvhTri) == 48, "48 bytes per triangle");
 
 struct DeviceScene {
@@ -77,8 +81,10 @@ struct DeviceScene {
   const uint4* materials;             // 2 x uint4 per material
   // light tree
   const uint4* light_tree_root;   // header, then 3 x 16 B per section; nullptr without lights
+  const float* light_root_children;  // the root's children dequantised (8 floats each: mean.xyz, sigma, power, 0, 0, 0), read with scalar loads (dev_light.h)
   const uint4* light_tree_nodes;  // 4 x 16 B per node
   const uint2* light_tri_handles;
+  const float4* light_tri_table;     // 3 x 16 B per light: world-space vertex | material id, bidirectional << 16; edge1 | scene triangle; edge2 (k_light_table)
   // sampler and LUTs
   const uint32_t* bluenoise_2d;
   const uint16_t* lut_conductor;
@@ -96,7 +102,7 @@ struct DeviceScene {
   const Bvh4Node* light_nodes;     // leaves index light_tris
   const BvhTri* light_tris;        // world space, id = light id
   uint32_t num_meshes, num_instances, num_materials, num_lights, num_textures;
-  uint32_t tlas_num_nodes, light_num_nodes;
+  uint32_t tlas_num_nodes, light_num_nodes, tlas_num_leaves;
   // settings / camera / sky (device_structs.h:8-124)
   uint32_t width, height, max_ray_depth, shading_mode;
   float cam_pos[3];
@@ -155,7 +161,7 @@ struct DeviceScene {
   const Bvh4Node* particle_bvh_nodes;
   const BvhTri* particle_tris;
   const float4* particle_leaves;
-  uint32_t particle_tlas_num_nodes;
+  uint32_t particle_tlas_num_nodes, particle_num_leaves;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).

@@ -23,6 +23,18 @@
 
 LUM_NS_BEGIN
 
+#ifndef LUM_TRACE_BLOCK_FAST
+#define LUM_TRACE_BLOCK_FAST 1024  // the fast flavour's ray kernels need 128 VGPRs: 4 waves per SIMD in one 1024-thread workgroup per CU (measured against 768: visibility kernel -16 %, closest-hit kernel -9 % on the hall)
+#endif
+#if LUM_FAST && !defined(LUM_TRACE_BLOCK)
+#define LUM_TRACE_BLOCK LUM_TRACE_BLOCK_FAST
+#endif
+#ifndef LUM_TRACE_BLOCK
+#define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
+                             // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)
+#endif
+constexpr int kTraceBlock = LUM_TRACE_BLOCK;
+
 constexpr uint32_t kHitSky        = 0xFFFFFFFEu;  // cuda/utils.cuh:50-64
 constexpr uint32_t kLeaveInstance = 0xFFFFFFFDu;  // stack marker: back from a bottom-level BVH to the top level
 constexpr uint32_t kTraversalDone = 0xFFFFFFFCu;
@@ -41,6 +53,16 @@ constexpr int kStackSize = 128;
 #define LUM_REFILL 40  // persistent waves refill their idle lanes when fewer than this many lanes are still traversing
 #endif
 
+#ifndef LUM_LDS_INSTANCES
+#define LUM_LDS_INSTANCES 64  // top-level leaf records (64 bytes each) a ray workgroup keeps in LDS next to the staged tree top
+#endif
+#ifndef LUM_LDS_TURN
+#define LUM_LDS_TURN 0   // lanes on staged nodes get wave iterations of their own while at least this many of them exist (0: off); see the phase vote
+#endif
+#ifndef LUM_LDS_FIRST
+#define LUM_LDS_FIRST 1  // such iterations come before triangle and instance-entry phases (0: only where the node phase would have run anyway)
+#endif
+
 #ifndef LUM_DUAL_VISIT
 #define LUM_DUAL_VISIT 0  // experiment, measured negative (visibility kernel +18 % on the hall): see visit_two_nodes
 #endif
@@ -56,6 +78,13 @@ constexpr uint32_t kPrefetchSinkWords = 64u * 16u;  // one dword per lane for up
 #else
 #define LUM_PHASE(k) do {} while (0)
 #define LUM_PHASE_LANES(k) do {} while (0)
+#endif
+#ifdef LUM_PHASE_STATS
+#define LUM_TIME_BEGIN() const unsigned long long t_begin_ = __builtin_readcyclecounter()
+#define LUM_TIME_END(k) do { ptime_[k] += __builtin_readcyclecounter() - t_begin_; ptime_[(k) + 1]++; } while (0)
+#else
+#define LUM_TIME_BEGIN() do {} while (0)
+#define LUM_TIME_END(k) do {} while (0)
 #endif  // lds_nodes: node visits served from the LDS-staged top of the tree
 
 // Reciprocal for the box test only (v_rcp_f32, 1 ulp): like the min/max below it decides what gets visited, never a result; the
@@ -142,10 +171,28 @@ template <> struct StackEntry<false> {
 // A lane's traversal stack. Its oldest entries live in the workgroup's LDS behind the staged tree top (LUM_LDS_STACK_BYTES of it, entry i of
 // thread t at word i * blockDim + t: a lane only ever touches its own bank), the rest in scratch: the stacks of the resident lanes do not fit
 // L2 next to the nodes, and with everything in scratch they are a tenth to a fifth of a ray kernel's memory-side traffic.
+// how an entry is kept in memory: a plain machine word (the HIP vector classes have no assignment through an address-space-qualified pointer)
+template <typename E> struct StackWord;
+template <> struct StackWord<uint32_t> {
+  typedef uint32_t W;
+  static LUM_DEV W pack(uint32_t e) { return e; }
+  static LUM_DEV uint32_t unpack(W w) { return w; }
+};
+template <> struct StackWord<uint2> {
+  typedef unsigned long long W;
+  static LUM_DEV W pack(uint2 e) { return (W) e.x | ((W) e.y << 32); }
+  static LUM_DEV uint2 unpack(W w) { return make_uint2((uint32_t) w, (uint32_t) (w >> 32)); }
+};
 template <typename E> struct TraversalStack {
-  E* scratch; E* lds; int lds_entries; uint32_t stride;
-  LUM_DEV void store(int i, E e) { if (i < lds_entries) lds[(uint32_t) i * stride] = e; else scratch[i] = e; }
-  LUM_DEV E load(int i) const { if (i < lds_entries) return lds[(uint32_t) i * stride]; return scratch[i]; }
+  // Typed address spaces on purpose: with generic pointers the compiler merges the two branches of load() into one flat_load through a selected
+  // pointer - every pop then went through the vector-memory address unit, whether its entry sat in LDS or not, and (flat loads count on both
+  // counters) the wave waited for it at once. The LDS entries are kTraceBlock entries apart (a compile-time shift or multiply, not blockDim.x).
+  typedef typename StackWord<E>::W W;
+  typedef __attribute__((address_space(5))) W* ScratchPtr;
+  typedef __attribute__((address_space(3))) W* LdsPtr;
+  ScratchPtr scratch; LdsPtr lds; int lds_entries;
+  LUM_DEV void store(int i, E e) { if (i < lds_entries) lds[(uint32_t) i * (uint32_t) kTraceBlock] = StackWord<E>::pack(e); else scratch[i] = StackWord<E>::pack(e); }
+  LUM_DEV E load(int i) const { if (i < lds_entries) return StackWord<E>::unpack(lds[(uint32_t) i * (uint32_t) kTraceBlock]); return StackWord<E>::unpack(scratch[i]); }
 };
 template <bool kOrdered, bool kCull, typename S>
 LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, S& stk, int& sp,
@@ -434,12 +481,16 @@ LUM_DEV void stack_push(S& stk, int& sp, E& top, E e) { stk.store(sp, top); sp++
 LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
 
 // All triangles of a leaf are fetched before the first test, so a leaf costs one memory round trip instead of one per triangle.
+// The twelve loads are unconditional - slots beyond the leaf's count re-read its last triangle (same cache lines, nothing new is fetched): with a
+// branch per slot the compiler parked the slots in other registers behind `s_waitcnt`s of their own, and a four-triangle leaf waited for memory
+// up to four times in a row (measured: 9.5 us per triangle phase of a wave against 2 us per node phase).
 struct LeafTris {
   float4 a[kBvhLeafMaxTri], b[kBvhLeafMaxTri], c[kBvhLeafMaxTri];
   LUM_DEV void load(const BvhTri* __restrict__ tris, uint32_t first, uint32_t count) {
 #pragma unroll
     for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
-      if (j < count) { a[j] = tri_f4(tris, first + j, 0); b[j] = tri_f4(tris, first + j, 1); c[j] = tri_f4(tris, first + j, 2); }
+      const uint32_t t = first + min(j, count - 1u);
+      a[j] = tri_f4(tris, t, 0); b[j] = tri_f4(tris, t, 1); c[j] = tri_f4(tris, t, 2);
     }
   }
 };
@@ -489,9 +540,18 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     for (uint32_t i = threadIdx.x; i < lds_count * (kNodeBytes / 16u); i += blockDim.x) lds_top[i] = g[i];
     __syncthreads();
   }
+  // ... and the records of the first top-level leaves (the rows of an instance's world->object matrix): entering one of those instances costs no
+  // memory round trip. A scene of one mesh, like the hall, has one; 72 instances are 4.5 KB.
+  __shared__ float4 lds_leaves[4u * LUM_LDS_INSTANCES];
+  const uint32_t staged_leaves = min(sc.tlas_num_leaves, (uint32_t) LUM_LDS_INSTANCES);
+  for (uint32_t i = threadIdx.x; i < 4u * staged_leaves; i += blockDim.x) lds_leaves[i] = sc.tlas_leaves[i];
+  __syncthreads();
   const NodeSource nodes{sc.bvh_nodes, reinterpret_cast<const char*>(lds_top), lds_count};
-  TraversalStack<E> stk{stack_in_scratch, reinterpret_cast<E*>(reinterpret_cast<char*>(lds_top) + lds_count * kNodeBytes) + threadIdx.x,
-                        (int) (LUM_LDS_STACK_BYTES / (kRayBlockMax * (uint32_t) sizeof(E))), blockDim.x};
+  typedef typename TraversalStack<E>::W StackW;
+  static_assert(sizeof(StackW) == sizeof(E), "a stack entry is one machine word");
+  TraversalStack<E> stk{(typename TraversalStack<E>::ScratchPtr) reinterpret_cast<StackW*>(stack_in_scratch),
+                        (typename TraversalStack<E>::LdsPtr) (reinterpret_cast<StackW*>(reinterpret_cast<char*>(lds_top) + lds_count * kNodeBytes) + threadIdx.x),
+                        (int) (LUM_LDS_STACK_BYTES / (kRayBlockMax * (uint32_t) sizeof(E)))};
 #if LUM_PREFETCH
   __shared__ uint32_t prefetch_sink[kPrefetchSinkWords];
   uint32_t* wave_sink = prefetch_sink + (threadIdx.x >> 6) * 64u;
@@ -500,6 +560,8 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   E top = SE::make(kTraversalDone, 0.0f);
 #ifdef LUM_PHASE_STATS
   uint32_t phase_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long ptime_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const unsigned long long t_kernel_ = __builtin_readcyclecounter();
 #endif
   auto pop = [&]() {
     LUM_PHASE(6); LUM_PHASE_LANES(7);
@@ -541,6 +603,10 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 
   while (true) {
     const unsigned long long idle = __ballot(cur == kTraversalDone);
+#ifdef LUM_PHASE_STATS
+    const unsigned long long t_refill_ = __builtin_readcyclecounter();
+    const bool refilling_ = idle != 0ull && more;
+#endif
     if (idle != 0ull && more) {  // wave-uniform
       if (chunk_next >= chunk_end) {
 #if LUM_XCD_RANGES
@@ -582,6 +648,9 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
         chunk_next += min(want, avail);
       }
     }
+#ifdef LUM_PHASE_STATS
+    if (refilling_) { ptime_[8] += __builtin_readcyclecounter() - t_refill_; ptime_[9]++; }
+#endif
     if (__ballot(cur != kTraversalDone) == 0ull) break;
     LUM_PHASE(5);
 
@@ -596,12 +665,33 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       const uint32_t n_live = (uint32_t) __popcll(__ballot(live)), n_tris = (uint32_t) __popcll(__ballot(want_tris)), n_enter = (uint32_t) __popcll(__ballot(want_enter));
       if (n_live == 0u) break;
       const uint32_t n_nodes = n_live - n_tris - n_enter;
+#if LUM_LDS_TURN
+      // A wave iteration ends when its slowest lane has its data: one lane whose node comes from memory makes all lanes wait a memory round trip
+      // (about 3 us under this kernel's own load), lanes whose node sits in the staged tree top included - and those are 60 % of the node visits.
+      // So while enough lanes stand on staged nodes they get iterations of their own, which issue no vector-memory load at all and take a
+      // quarter of the time; the lanes on other nodes wait those out and are then served together.
+      const bool on_staged = live && ((!at_leaf && cur < lds_count) || (want_enter && (cur & 0x0FFFFFFFu) < staged_leaves));
+      const uint32_t n_staged = (uint32_t) __popcll(__ballot(on_staged));
+      const bool staged_turn = n_staged >= LUM_LDS_TURN && (LUM_LDS_FIRST || n_tris * LUM_VOTE_TRIS < max(n_nodes, n_enter) * LUM_VOTE_NODES) && (LUM_LDS_FIRST || n_enter < n_nodes);
+      const bool run_tris = !staged_turn && n_tris * LUM_VOTE_TRIS >= max(n_nodes, n_enter) * LUM_VOTE_NODES;
+      const bool run_enter = !staged_turn && !run_tris && n_enter >= n_nodes;
+#else
       const bool run_tris = n_tris * LUM_VOTE_TRIS >= max(n_nodes, n_enter) * LUM_VOTE_NODES;
       const bool run_enter = !run_tris && n_enter >= n_nodes;
+#endif
       // Three per-lane conditions of which the vote leaves at most one non-empty. Written as independent divergent ifs on purpose: with
       // wave-uniform if/else-if branches the compiler routed every ray register through a temporary and back at the merge point
       // (about forty v_mov per iteration).
+#if LUM_LDS_TURN
+      const bool do_tris = run_tris && want_tris, do_enter = (run_enter && want_enter) || (staged_turn && want_enter && on_staged),
+                 do_node = !run_tris && !run_enter && live && !at_leaf && (!staged_turn || on_staged);
+#else
       const bool do_tris = run_tris && want_tris, do_enter = run_enter && want_enter, do_node = !run_tris && !run_enter && live && !at_leaf;
+#endif
+      LUM_TIME_BEGIN();
+#ifdef LUM_PHASE_STATS
+      const bool memory_node_ = __ballot(do_node && cur >= lds_count) != 0ull;
+#endif
       {
         if (do_tris) {
           LUM_PHASE(3); LUM_PHASE_LANES(4);
@@ -613,8 +703,10 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       {
         if (do_enter) {
           LUM_PHASE(1); LUM_PHASE_LANES(2);
-          const float4* __restrict__ leaf = sc.tlas_leaves + 4u * (cur & 0x0FFFFFFFu);
-          const float4 r0 = leaf[0], r1 = leaf[1], r2 = leaf[2], meta = leaf[3];
+          const uint32_t leaf_index = cur & 0x0FFFFFFFu;
+          float4 r0, r1, r2, meta;
+          if (leaf_index < staged_leaves) { const float4* leaf = lds_leaves + 4u * leaf_index; r0 = leaf[0]; r1 = leaf[1]; r2 = leaf[2]; meta = leaf[3]; }
+          else { const float4* __restrict__ leaf = sc.tlas_leaves + 4u * leaf_index; r0 = leaf[0]; r1 = leaf[1]; r2 = leaf[2]; meta = leaf[3]; }
           inst = fbits(meta.x);
           const float px = wo.x - r0.w, py = wo.y - r1.w, pz = wo.z - r2.w;
           const V3 oo = v3(mat_row_apply(r0.x, r0.y, r0.z, px, py, pz), mat_row_apply(r1.x, r1.y, r1.z, px, py, pz), mat_row_apply(r2.x, r2.y, r2.z, px, py, pz));
@@ -665,11 +757,20 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           }
         }
       }
+#ifdef LUM_PHASE_STATS
+      {  // a wave iteration ends when every lane's registers are written: make the clock wait for what the phase loaded
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        const int kind = run_tris ? 4 : (run_enter ? 6 : (memory_node_ ? 0 : 2));
+        LUM_TIME_END(kind);
+      }
+#endif
       if (more && n_live < LUM_REFILL) break;
     }
   }
 #ifdef LUM_PHASE_STATS
+  ptime_[10] = __builtin_readcyclecounter() - t_kernel_; ptime_[11] = 1;
   for (int k = 0; k < 8; k++) if (phase_[k]) atomicAdd(&g_phase[k], (unsigned long long) phase_[k]);
+  if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 12; k++) if (ptime_[k]) atomicAdd(&g_phase_time[k], ptime_[k]);
 #endif
 }
 
@@ -698,7 +799,7 @@ struct ClosestState {
       const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && id < best.tri_id)))) {
         // alpha cut-outs: texels with alpha 0 do not exist for the ray (optix_common.cuh:20-46, optix_anyhit.cuh:26-30)
-        if (fbits(c.w) != kBvhTriNoTexture && fbits(c.w) < sc.num_textures &&
+        if (fbits(c.w) < sc.num_textures &&  // kBvhTriNoTexture and kBvhTriOpaque are no texture ids
             texture_load(sc, fbits(c.w), triangle_uv(sc.tri_tex[fbits(b.w)], uv), true, make_float4(0.0f, 0.0f, 0.0f, 1.0f)).w == 0.0f)
           continue;
         best.instance_id = inst; best.tri_id = id; best.t = t; best.scene_tri = fbits(b.w); tmax = t;
@@ -743,6 +844,7 @@ struct ShadowState {
       F2 uv;
       const float t = intersect_triangle(v3(a.x, a.y, a.z), v3(b.x, b.y, b.z), v3(c.x, c.y, c.z), o, d, uv);
       if (!(t > kEps && t < dist)) continue;
+      if (fbits(c.w) == kBvhTriOpaque) { blocked = true; return true; }  // untextured, alpha 1 (k_tri_opacity): what the material fetch below would find
       const uint4 tt = sc.tri_tex[fbits(b.w)];  // b.w = triangle index in the scene arrays
       const Material m = load_material(sc, tt.w & 0xFFFFu);
       Col albedo = m.albedo;
@@ -769,7 +871,7 @@ struct ShadowState {
 template <typename LeafFn>
 LUM_DEV void traverse_lights(const DeviceScene& sc, V3 o, V3 d, float& tmax, RayStats& st, LeafFn&& on_leaf) {
   uint2 stack_in_scratch[kStackSize];
-  TraversalStack<uint2> stk{stack_in_scratch, nullptr, 0, 0u};  // the light tree is shallow: scratch only
+  TraversalStack<uint2> stk{(TraversalStack<uint2>::ScratchPtr) reinterpret_cast<unsigned long long*>(stack_in_scratch), nullptr, 0};  // the light tree is shallow: scratch only
   int sp = 0;
   uint2 top = make_uint2(kTraversalDone, 0u);
   TRay r;

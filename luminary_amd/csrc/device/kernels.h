@@ -23,17 +23,7 @@
 LUM_NS_BEGIN
 
 constexpr int kBlock = 256;
-#ifndef LUM_TRACE_BLOCK_FAST
-#define LUM_TRACE_BLOCK_FAST 1024  // the fast flavour's ray kernels need 128 VGPRs: 4 waves per SIMD in one 1024-thread workgroup per CU (measured against 768: visibility kernel -16 %, closest-hit kernel -9 % on the hall)
-#endif
-#if LUM_FAST && !defined(LUM_TRACE_BLOCK)
-#define LUM_TRACE_BLOCK LUM_TRACE_BLOCK_FAST
-#endif
-#ifndef LUM_TRACE_BLOCK
-#define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
-                             // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)
-#endif
-constexpr int kTraceBlock = LUM_TRACE_BLOCK;
+// kTraceBlock (threads per workgroup of the persistent ray kernels) is defined in dev_trace.h, which lays the lanes' traversal stacks out by it
 #ifndef LUM_TRACE_MIN_WAVES
 #define LUM_TRACE_MIN_WAVES 0  // experiment: register budget of the ray kernels as waves per SIMD (0: whatever one workgroup of kTraceBlock threads per CU allows)
 #endif
@@ -1402,6 +1392,33 @@ __global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene 
 
 // ---- HDRI bake (cuda/sky_hdri.cuh:13-160, device/device_sky.c:283-316): the sky without celestial bodies - and with the clouds, when active - seen from
 // `origin`, as an equirectangular dim x dim image. 32 lanes per texel share its samples; their means go through the reference's trimmed mean. ----
+#if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
+// Marks the traversal triangles a visibility ray cannot pass (kBvhTriOpaque, dev_scene.h): the decision of optix_anyhit.cuh:49-139 for an untextured
+// material with alpha 1, taken once per triangle with the kernels' own material decoding.
+__global__ __launch_bounds__(kBlock) void k_tri_opacity(DeviceScene sc, BvhTri* tris, uint32_t count) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= count) return;
+  const uint32_t tex = tris[i].albedo_tex;
+  if (tex != kBvhTriNoTexture && tex != kBvhTriOpaque) return;  // textured: the texel decides
+  const uint32_t material = sc.tri_tex[tris[i].scene_index].w & 0xFFFFu;
+  if (material >= sc.num_materials) return;
+  const Material m = load_material(sc, material);
+  tris[i].albedo_tex = (m.albedo_tex == kTextureNone && m.alpha == 1.0f) ? kBvhTriOpaque : kBvhTriNoTexture;
+}
+
+// The emissive triangles in world space, one record per light id (load_tri_light_table, dev_light.h): light_triangle_init's result
+// (light_triangle.cuh:37-72) evaluated once per light at scene upload instead of once per candidate and vertex.
+__global__ __launch_bounds__(kBlock) void k_light_table(DeviceScene sc, float4* table) {
+  const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+  if (i >= sc.num_lights) return;
+  const uint2 handle = sc.light_tri_handles[i];
+  const TriLight t = load_tri_light(sc, handle.x, handle.y);
+  table[3u * i] = make_float4(t.vertex.x, t.vertex.y, t.vertex.z, bitsf(t.material_id | (t.bidirectional ? 0x10000u : 0u)));
+  table[3u * i + 1u] = make_float4(t.edge1.x, t.edge1.y, t.edge1.z, bitsf(t.scene_tri));
+  table[3u * i + 2u] = make_float4(t.edge2.x, t.edge2.y, t.edge2.z, 0.0f);
+}
+#endif
+
 #if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
 __global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, float oy, float oz, uint32_t dim, uint32_t sample_count, float4* __restrict__ dst) {
   __shared__ float values[256];

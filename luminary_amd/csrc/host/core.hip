@@ -723,6 +723,7 @@ static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, Dev
   if (upload(ctx, leaves.data(), leaves.size(), &sc.particle_leaves)) return 1;
   if (upload(ctx, (const float4*) v->particle_normals, (size_t) sc.particles_count, &sc.particle_normals)) return 1;
   sc.particle_tlas_num_nodes = (uint32_t) tlas.nodes.size();
+  sc.particle_num_leaves = (uint32_t) (leaves.size() / 4);
   ctx->particle_lds_nodes = (uint32_t) std::min<size_t>(ctx->lds_nodes, nodes.size());
   return 0;
 }
@@ -746,6 +747,28 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   if (v->light_tree_root && v->num_lights) {
     const uint32_t sections = v->light_tree_root[10];
     if (upload(ctx, (const uint4*) v->light_tree_root, (size_t) 1 + 3 * sections, &sc.light_tree_root)) return 1;
+    {
+      // The root's children as floats (dev_light.h tree_prepass): mean = byte * 2^e + base per axis, sigma = byte * 2^e_sigma, power = the 16-bit
+      // integer - the operations the kernels used to perform per vertex (cuda/light_tree.cuh:133-161, :203-205), every one exact or a single
+      // binary32 rounding, so the table holds the same bits (this translation unit is compiled without contraction).
+      const uint32_t* h = (const uint32_t*) v->light_tree_root;
+      auto bf = [](uint32_t v16) { const uint32_t b = (v16 & 0xFFFFu) << 16; float f; std::memcpy(&f, &b, 4); return f; };
+      const float base[3] = {bf(h[0]), bf(h[0] >> 16), bf(h[1])};
+      const float ex[3] = {std::ldexp(1.0f, (int8_t) (h[3] & 0xFF)), std::ldexp(1.0f, (int8_t) ((h[3] >> 8) & 0xFF)), std::ldexp(1.0f, (int8_t) ((h[3] >> 16) & 0xFF))};
+      const float ev = std::ldexp(1.0f, (int8_t) (h[3] >> 24));
+      std::vector<float> table((size_t) sections * 8 * 8 + 16, 0.0f);  // + one pair of zeros: the pass reads two children per step
+      for (uint32_t s = 0; s < sections; s++) {
+        const uint8_t* sec = (const uint8_t*) (h + 4 + 12 * s);  // 8 x rel mean x, y, z, rel std dev, then 8 x u16 power
+        for (uint32_t c = 0; c < 8; c++) {
+          float* e = &table[((size_t) s * 8 + c) * 8];
+          for (int a = 0; a < 3; a++) { const float q = (float) sec[8 * a + c]; const float scaled = q * ex[a]; e[a] = scaled + base[a]; }
+          e[3] = (float) sec[24 + c] * ev;
+          uint16_t pw; std::memcpy(&pw, sec + 32 + 2 * c, 2);
+          e[4] = (float) pw;
+        }
+      }
+      if (upload(ctx, table.data(), table.size(), &sc.light_root_children)) return 1;
+    }
     if (upload(ctx, (const uint4*) v->light_tree_nodes, (size_t) v->num_light_tree_nodes * 4, &sc.light_tree_nodes)) return 1;
     if (upload(ctx, (const uint2*) v->light_tri_handles, v->num_lights, &sc.light_tri_handles)) return 1;
   }
@@ -973,6 +996,7 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       std::memcpy(&leaves[4 * i + 3], words, 16);
     }
     if (upload(ctx, leaves.data(), leaves.size(), &sc.tlas_leaves)) return 1;
+    sc.tlas_num_leaves = (uint32_t) (leaves.size() / 4);  // records that exist (one of padding included): what a workgroup may stage in LDS
   }
   ctx->bvh_stats[0] = nodes.size() - sc.tlas_num_nodes;
   {
@@ -1018,6 +1042,18 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   ctx->bvh_stats[1] = total_tris;
 
   { const uint32_t nt = sc.num_textures; sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights; sc.num_textures = nt; }
+  if (total_tris) {  // which traversal triangles stop a visibility ray on their own (kBvhTriOpaque)
+    hipLaunchKernelGGL(k_tri_opacity, dim3((total_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, const_cast<BvhTri*>(sc.blas_tris), total_tris);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  if (sc.light_tree_root && sc.num_lights) {  // the emissive triangles in world space, one record per light (load_tri_light_table)
+    float4* table = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**) &table, sizeof(float4) * 3 * (size_t) sc.num_lights)); ctx->scene_allocs.push_back(table);
+    hipLaunchKernelGGL(k_light_table, dim3((sc.num_lights + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, table);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    sc.light_tri_table = table;
+  }
   sc.width = v->width; sc.height = v->height; sc.max_ray_depth = v->max_ray_depth; sc.shading_mode = v->shading_mode;
   std::memcpy(sc.cam_pos, v->cam_pos, sizeof(sc.cam_pos));
   std::memcpy(sc.cam_rotation, v->cam_rotation, sizeof(sc.cam_rotation));
@@ -1282,7 +1318,7 @@ int lumc_clear_accumulators(LumContext* ctx) {
 // The particle pass of the closest-hit kernel: the same traversal on the particle tree (the scene copy carries it in place of the surfaces' tree).
 static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue& q, uint32_t* ctrl, uint32_t N) {
   DeviceScene tree = ctx->scene;
-  tree.bvh_nodes = tree.particle_bvh_nodes; tree.blas_tris = tree.particle_tris; tree.tlas_leaves = tree.particle_leaves; tree.tlas_num_nodes = tree.particle_tlas_num_nodes;
+  tree.bvh_nodes = tree.particle_bvh_nodes; tree.blas_tris = tree.particle_tris; tree.tlas_leaves = tree.particle_leaves; tree.tlas_num_nodes = tree.particle_tlas_num_nodes; tree.tlas_num_leaves = tree.particle_num_leaves;
   Launch l(ctx, stream, LUMC_KERNEL_TRACE);
   ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES, stream, tree, q, ctrl, ctx->particle_lds_nodes);
 }

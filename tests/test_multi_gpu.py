@@ -139,14 +139,18 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert "torch" not in sys.modules or not hasattr(sys.modules["torch"], "_lum_gpu_touched")
 
 
-def test_bench_does_not_price_ray_kernels_with_counters_of_another_lds_split():
-    """The committed PMC record names the LDS split (traversal stack bytes) of the library it was collected with; bench.py flags the
-    ray kernels' memory-side bytes as stale when its own library is built differently, and prices them with a lower bound instead."""
+def test_bench_does_not_price_kernels_with_counters_of_another_build(monkeypatch):
+    """The committed PMC record names the source tree (hash of the device code and build flags) and the LDS split of the library it was collected
+    with; bench.py derives counter-based figures only when both match its own - otherwise the record is flagged stale and `traffic` / `frac` stay
+    null (never an inferred bound)."""
     import bench
     recorded = bench.pmc_record("hall", 32, "fast", 0)
     if recorded is None:
         pytest.skip("no counter record for the hall in profiles/pmc_counters.json")
     then = int(recorded.get("lds_stack_bytes", 0))
-    assert bench.pmc_record("hall", 32, "fast", then)["_ray_traffic_stale"] is False
-    assert bench.pmc_record("hall", 32, "fast", then + 4096)["_ray_traffic_stale"] is True
+    monkeypatch.setattr(bench, "source_hash", lambda: recorded.get("source_hash"))
+    assert bench.pmc_record("hall", 32, "fast", then)["_stale"] is False
+    assert bench.pmc_record("hall", 32, "fast", then + 4096)["_stale"] is True
+    monkeypatch.setattr(bench, "source_hash", lambda: "another tree")
+    assert bench.pmc_record("hall", 32, "fast", then)["_stale"] is True
     assert bench.pmc_record("hall", 32, "exact", then) is None or bench.pmc_record("hall", 32, "exact", then).get("flavour") == "exact"

@@ -36,6 +36,16 @@ print("instance entry: %10d wave iterations, lane occupancy %.3f" % (inst_it, in
 print("triangle phase: %10d wave iterations, lane occupancy %.3f, triangle slots used %.3f of 4" % (tri_it, tri_l / (64.0 * max(tri_it, 1)), tris / max(tri_l, 1)))
 print("outer iterations (refill checks): %d" % outer)
 print("per ray: %.2f node, %.2f instance, %.2f leaf visits" % (nodes / rays, inst_l / rays, tri_l / rays))
+if core.flavour == "fast" and hasattr(lib, "lumc_debug_phase_times_fast"):
+    tm = (C.c_uint64 * 16)()
+    lib.lumc_debug_phase_times_fast(tm, 1)
+    tm = [int(x) for x in tm]
+    # s_memtime counts at 100 MHz on this part (constant clock), so one tick = 10 ns
+    names = ["node iterations that touch memory", "node iterations on staged nodes only", "triangle iterations", "instance-entry iterations", "refills", "whole kernel per wave"]
+    for k, nm in enumerate(names):
+        c, n = tm[2 * k], tm[2 * k + 1]
+        if n:
+            print("time: %-40s %12d  avg %8.1f ticks  total %14d ticks" % (nm, n, c / n, c))
 print("shade: light sampling entered by %d waves, lane occupancy %.3f" % (sh[6], sh[7] / (64.0 * max(sh[6], 1))))
 print("shade: candidate loop %d wave iterations, occupancy %.3f; BSDF+MIS part %d wave iterations, occupancy %.3f (%.2f of 8 candidates per vertex)"
       % (sh[0], sh[1] / (64.0 * max(sh[0], 1)), sh[2], sh[3] / (64.0 * max(sh[2], 1)), sh[3] / max(sh[7], 1)))

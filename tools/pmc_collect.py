@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--calib", action="store_true")
     ap.add_argument("--spp", type=int, default=32)
     ap.add_argument("--extra", default="", help="extra bench.py arguments for every workload (e.g. '--clouds'): feature frames instead of the BASELINE ones")
+    ap.add_argument("--passes", default="", help="comma-separated subset of the counter groups (fetch,write,tcc,ea,sq,ta,tcp,sq2); default: all")
     ap.add_argument("--label", default="", help="suffix of the workload keys when --extra is given (e.g. 'clouds' -> 'example+clouds')")
     args = ap.parse_args()
     os.makedirs(args.out_dir, exist_ok=True)
@@ -137,6 +138,8 @@ def main():
         wkey = w + ("+" + args.label if args.label else "")
         merged = defaultdict(dict)  # kernel -> counter -> value PER LAUNCH (every pass launches the same kernels the same number of times)
         for tag, counters in PASSES:
+            if args.passes and tag not in args.passes.split(","):
+                continue
             res = run_pass(args.out_dir, "%s_%s" % (wkey, tag), counters, cmd, kernel_key)
             for k, v in res.items():
                 if not k.startswith("k_"):
