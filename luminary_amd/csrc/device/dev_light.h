@@ -145,7 +145,7 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler
         for (uint32_t hlf = 0; hlf < 2; hlf++) {
           const uint32_t l = 2 * q + hlf;
           const bool accept = lane_random[q][hlf] < prob;
-          lane_target[l] = accept ? target : lane_target[l];
+          lane_target[l] = accept ? target : lane_target[l];  // (evaluating the picked child's importance again after the scan instead costs more in spills than this select)
           lane_pick[l] = accept ? c + k : lane_pick[l];
           lane_random[q][hlf] = clamp_random(accept ? if_accepted[hlf] : if_rejected[hlf]);
         }

@@ -39,8 +39,14 @@ LUM_DEV uint32_t sobol_second_dim(uint32_t v) {
   v ^= v << 16; v ^= (v & 0x00FF00FFu) << 8; v ^= (v & 0x0F0F0F0Fu) << 4; v ^= (v & 0x33333333u) << 2; v ^= (v & 0x55555555u) << 1;
   return v;
 }
+// squares32(key, dimension) for every dimension a path can ask for (target + depth * kRndTargetCount, depth < 64): a random number's dimension is
+// the same in every lane of every wave, so its seed is one scalar load from this table instead of six 32-bit multiplies (quarter-rate instructions) and
+// a dozen other vector instructions per random number and lane - the hash was a twelfth of the shading kernel. Filled per device and flavour by
+// init_sampler_seeds() (wavefront_table_impl.h) with the same integer function.
+constexpr uint32_t kSeedTableSize = 64u * kRndTargetCount;
+__constant__ uint32_t g_sampler_seeds[kSeedTableSize];
 LUM_DEV U2 sobol_owen(uint32_t index, uint32_t dimension) {
-  const uint32_t seed = squares32(0xfcbd6e15u, dimension);
+  const uint32_t seed = g_sampler_seeds[dimension];
   const uint32_t j    = laine_karras(__brev(index), seed);
   return U2{owen_scramble(j, hash_combine(seed, 0)), owen_scramble(sobol_second_dim(j), hash_combine(seed, 1))};
 }

@@ -150,6 +150,31 @@ LUM_DEV bool within(float tnear, float tmax) { return tnear <= __builtin_fmaf(tm
 // workgroup of the persistent ray kernels: a divergent 16-byte LDS read costs a fraction of a divergent L1 access.
 struct NodeSource { const Bvh4Node* global; const char* lds; uint32_t lds_count; };
 
+// Where the sixteen-byte word `i` of the node array sits in the staged copy. A lane reads the same word (say, the near x planes) of whatever node it
+// stands on; unswizzled, that word of every even node lies on the same four LDS banks and of every odd node on four others, so a wave's read of
+// 64 different nodes queued up on eight banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.5-0.6). XOR-ing the word's position inside its node with
+// bits 1-3 of the node index spreads the same word of sixteen consecutive nodes over all 64 banks. Float-box nodes only (LUM_LDS_SWIZZLE).
+// Measured (profiles/r03_ab_experiments.txt, same box): hall 221.1 / 373.6 ms per 3 steps of the closest-hit / visibility kernel without, 222.3 / 374.0 with
+// it; scan 65.1 / 70.7 against 65.9 / 70.5 - the LDS reads are not on the kernels' critical path. Off: it costs nine instructions per staged visit.
+#ifndef LUM_LDS_SWIZZLE
+#define LUM_LDS_SWIZZLE 0
+#endif
+LUM_DEV uint32_t lds_slot_swizzle(uint32_t word_index) {
+#if LUM_LDS_SWIZZLE
+  return word_index ^ ((word_index >> 4) & 7u);  // word_index = node * 8 + slot: bits 1-3 of the node index are bits 4-6 here
+#else
+  return word_index;
+#endif
+}
+LUM_DEV uint32_t lds_node_swizzle_bytes(uint32_t node) {
+#if LUM_LDS_SWIZZLE
+  return ((node >> 1) & 7u) << 4;
+#else
+  (void) node;
+  return 0u;
+#endif
+}
+
 // Traversal stack entry. Closest-hit rays keep the child's entry distance next to its index so that a pop can drop what lies beyond the hit
 // found meanwhile (8 bytes). A visibility ray's segment never shrinks, every stacked child stays within reach, so its entries are the
 // index alone (4 bytes): half the scratch traffic of the kernel that writes most of it (rocprofv3 WRITE_SIZE, C3: 4.9 GB per launch of which
@@ -203,9 +228,10 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
   uint4 ch;
   if (cur < src.lds_count) {
     const char* p = src.lds + b;
-    nx = *reinterpret_cast<const float4*>(p + r.nx); ny = *reinterpret_cast<const float4*>(p + r.ny); nz = *reinterpret_cast<const float4*>(p + r.nz);
-    fx = *reinterpret_cast<const float4*>(p + r.fx); fy = *reinterpret_cast<const float4*>(p + r.fy); fz = *reinterpret_cast<const float4*>(p + r.fz);
-    ch = *reinterpret_cast<const uint4*>(p + 96u);
+    const uint32_t z = lds_node_swizzle_bytes(cur);
+    nx = *reinterpret_cast<const float4*>(p + (r.nx ^ z)); ny = *reinterpret_cast<const float4*>(p + (r.ny ^ z)); nz = *reinterpret_cast<const float4*>(p + (r.nz ^ z));
+    fx = *reinterpret_cast<const float4*>(p + (r.fx ^ z)); fy = *reinterpret_cast<const float4*>(p + (r.fy ^ z)); fz = *reinterpret_cast<const float4*>(p + (r.fz ^ z));
+    ch = *reinterpret_cast<const uint4*>(p + (96u ^ z));
     st.lds_nodes++;
   }
   else {
@@ -406,9 +432,10 @@ LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, Ra
   const uint32_t b = id << 7;
   if (id < src.lds_count) {
     const char* p = src.lds + b;
-    n.nx = *reinterpret_cast<const float4*>(p + r.nx); n.ny = *reinterpret_cast<const float4*>(p + r.ny); n.nz = *reinterpret_cast<const float4*>(p + r.nz);
-    n.fx = *reinterpret_cast<const float4*>(p + r.fx); n.fy = *reinterpret_cast<const float4*>(p + r.fy); n.fz = *reinterpret_cast<const float4*>(p + r.fz);
-    n.ch = *reinterpret_cast<const uint4*>(p + 96u);
+    const uint32_t z = lds_node_swizzle_bytes(id);
+    n.nx = *reinterpret_cast<const float4*>(p + (r.nx ^ z)); n.ny = *reinterpret_cast<const float4*>(p + (r.ny ^ z)); n.nz = *reinterpret_cast<const float4*>(p + (r.nz ^ z));
+    n.fx = *reinterpret_cast<const float4*>(p + (r.fx ^ z)); n.fy = *reinterpret_cast<const float4*>(p + (r.fy ^ z)); n.fz = *reinterpret_cast<const float4*>(p + (r.fz ^ z));
+    n.ch = *reinterpret_cast<const uint4*>(p + (96u ^ z));
     st.lds_nodes++;
   }
   else {
@@ -537,7 +564,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   extern __shared__ float4 lds_top[];
   {
     const float4* __restrict__ g = reinterpret_cast<const float4*>(sc.bvh_nodes);
-    for (uint32_t i = threadIdx.x; i < lds_count * (kNodeBytes / 16u); i += blockDim.x) lds_top[i] = g[i];
+    for (uint32_t i = threadIdx.x; i < lds_count * (kNodeBytes / 16u); i += blockDim.x) lds_top[lds_slot_swizzle(i)] = g[i];
     __syncthreads();
   }
   // ... and the records of the first top-level leaves (the rows of an instance's world->object matrix): entering one of those instances costs no

@@ -15,6 +15,8 @@ struct WavefrontKernels {
   uint32_t trace_block;  // threads per workgroup of the persistent ray kernels (one workgroup per CU)
   // dynamic LDS of the persistent ray kernels (the staged tree top); returns a hipError_t
   int (*set_ray_kernel_lds)(size_t bytes);
+  // fills this flavour's table of sampler seeds on the current device (dev_sampler.h); returns a hipError_t
+  int (*init_sampler_seeds)();
   void (*generate)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count);
   void (*generate_adaptive)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const AdaptiveView& a, const AdaptivePass& pass, const PathQueue& q, float4* results,
                             uint32_t* count);

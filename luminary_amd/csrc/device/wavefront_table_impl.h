@@ -1,6 +1,8 @@
 // Defines this translation unit's WavefrontKernels table (include once, after kernels.h and dev_adaptive.h).
 #pragma once
 
+#include <vector>
+
 #include "dev_adaptive.h"
 #include "wavefront_table.h"
 
@@ -13,6 +15,23 @@ static int set_ray_kernel_lds(size_t bytes) {
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_trace_rays, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
   if (e == hipSuccess) e = hipFuncSetAttribute((const void*) k_trace_particles, hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
   return (int) e;
+}
+static int init_sampler_seeds() {
+  static std::vector<uint32_t> seeds;  // squares32(0xfcbd6e15, dimension), random.cuh:172-194 - the device function's integer arithmetic on the host
+  if (seeds.empty()) {
+    seeds.resize(kSeedTableSize);
+    auto swap_h = [](uint32_t a) { return (a >> 16) | (a << 16); };
+    const uint32_t key = 0xfcbd6e15u;
+    for (uint32_t d = 0; d < kSeedTableSize; d++) {
+      uint32_t x = d * key, y = d * key, z = y + key;
+      x = x * x + y; x = swap_h(x);
+      x = x * x + z; x = swap_h(x);
+      x = x * x + y; x = swap_h(x);
+      x = x * x + z; z = x; x = swap_h(x);
+      seeds[d] = z ^ (x * x + y);
+    }
+  }
+  return (int) hipMemcpyToSymbol(HIP_SYMBOL(g_sampler_seeds), seeds.data(), sizeof(uint32_t) * kSeedTableSize);
 }
 static void generate(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count) {
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, sc, pp, q, results, count);
@@ -95,7 +114,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
-static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
+static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, init_sampler_seeds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
                                         shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
 
 }  // namespace table

@@ -425,6 +425,8 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   HIP_TRY(ctx, hipGetDeviceCount(&count));
   if (device_ordinal < 0 || device_ordinal >= count) { ctx->error = "no such HIP device"; return 1; }
   HIP_TRY(ctx, hipSetDevice(device_ordinal));
+  HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->init_sampler_seeds());  // per device: module globals live on each GPU
+  HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->init_sampler_seeds());
   HIP_TRY(ctx, hipMalloc((void**) &ctx->d_ctrl, sizeof(uint32_t) * kCtlStride * kCtrlRows));
   HIP_TRY(ctx, hipMemset(ctx->d_ctrl, 0, sizeof(uint32_t) * kCtlStride * kCtrlRows));
   HIP_TRY(ctx, hipMalloc((void**) &ctx->d_counters, sizeof(uint64_t) * LUMC_CNT_COUNT));
