@@ -5,6 +5,7 @@ import numpy as np
 
 from . import DeviceSceneView, _lib
 
+DIRTY_CONSTANTS, DIRTY_MATERIALS, DIRTY_INSTANCES, DIRTY_LIGHTS, DIRTY_MESHES, DIRTY_TEXTURES, DIRTY_PARTICLES, DIRTY_ALL = 1, 2, 4, 8, 16, 32, 64, 127
 CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
 KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky", "sort", "volume")
 
@@ -152,6 +153,12 @@ class Core:
     def upload(self, view):
         self._view_keepalive = view
         self._call("lumc_scene_upload", C.byref(view))
+        self.width, self.height = view.width, view.height
+
+    def update(self, view, dirty):
+        """lumc_scene_update: takes over only the parts of `view` named by `dirty` (DIRTY_* below); the accumulation is not touched."""
+        self._view_keepalive = view
+        self._call("lumc_scene_update", C.byref(view), C.c_uint(dirty))
         self.width, self.height = view.width, view.height
 
     def generate_output(self, params, first_moment=None, want_float=False):

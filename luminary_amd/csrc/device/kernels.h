@@ -1393,17 +1393,19 @@ __global__ __launch_bounds__(kBlock, LUM_CLOUD_WAVES) void k_clouds(DeviceScene 
 // ---- HDRI bake (cuda/sky_hdri.cuh:13-160, device/device_sky.c:283-316): the sky without celestial bodies - and with the clouds, when active - seen from
 // `origin`, as an equirectangular dim x dim image. 32 lanes per texel share its samples; their means go through the reference's trimmed mean. ----
 #if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit
-// Marks the traversal triangles a visibility ray cannot pass (kBvhTriOpaque, dev_scene.h): the decision of optix_anyhit.cuh:49-139 for an untextured
-// material with alpha 1, taken once per triangle with the kernels' own material decoding.
+// The material word of the traversal triangles (dev_scene.h): the albedo texture's id, or - untextured - whether a visibility ray cannot pass
+// (kBvhTriOpaque: the decision of optix_anyhit.cuh:49-139 for alpha 1), taken once per triangle with the kernels' own material decoding; run at
+// scene upload and again after a material edit.
 __global__ __launch_bounds__(kBlock) void k_tri_opacity(DeviceScene sc, BvhTri* tris, uint32_t count) {
   const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
   if (i >= count) return;
-  const uint32_t tex = tris[i].albedo_tex;
-  if (tex != kBvhTriNoTexture && tex != kBvhTriOpaque) return;  // textured: the texel decides
   const uint32_t material = sc.tri_tex[tris[i].scene_index].w & 0xFFFFu;
-  if (material >= sc.num_materials) return;
-  const Material m = load_material(sc, material);
-  tris[i].albedo_tex = (m.albedo_tex == kTextureNone && m.alpha == 1.0f) ? kBvhTriOpaque : kBvhTriNoTexture;
+  uint32_t word = kBvhTriNoTexture;
+  if (material < sc.num_materials) {
+    const Material m = load_material(sc, material);
+    word = (m.albedo_tex != kTextureNone) ? m.albedo_tex : ((m.alpha == 1.0f) ? kBvhTriOpaque : kBvhTriNoTexture);  // textured: the texel decides
+  }
+  tris[i].albedo_tex = word;
 }
 
 // The emissive triangles in world space, one record per light id (load_tri_light_table, dev_light.h): light_triangle_init's result

@@ -35,12 +35,18 @@ struct LuminaryPath { std::string value; };
 struct LuminaryHost {
   lum::HostScene scene;
   lum::DeviceSceneBuffers device_scene;
+  // Which parts of the scene edits have touched since the device scene / a device's copy of it was last brought up to date (LUMC_DIRTY_*; the
+  // reference keeps such flags per entity, scene.h:42-63, and its device manager uploads by them, device_manager.c:311-320, :424-450): a camera
+  // move re-encodes and re-uploads nothing but constants, a material edit the material array, an instance edit the top-level tree.
+  uint32_t scene_dirty = LUMC_DIRTY_ALL;  // parts of `device_scene` that are out of date
+  uint32_t core_dirty = LUMC_DIRTY_ALL;   // parts the main device's context has not taken over yet
   bool device_scene_valid = false;
   bool core_scene_valid = false;
+  uint32_t core_width = 0, core_height = 0;  // frame size the main context's pixel set was made for
   LumContext* core = nullptr;        // context of the main device: renders (its tiles) and produces every output
   int device_ordinal = 0;            // HIP ordinal of the main device
   // every visible device (device_manager.c:776-862 creates one Device per masked id); the frame is tiled over the enabled ones
-  struct DeviceSlot { int ordinal = 0; bool enabled = false; LumContext* core = nullptr; bool scene_valid = false; };
+  struct DeviceSlot { int ordinal = 0; bool enabled = false; LumContext* core = nullptr; bool scene_valid = false; uint32_t dirty = LUMC_DIRTY_ALL; };
   std::vector<DeviceSlot> devices;
   uint32_t main_slot = 0;
   uint32_t partition_n = 0;          // devices the current accumulation is tiled over (0 or 1: the main device renders every pixel)
@@ -87,9 +93,10 @@ std::vector<uint32_t> embedded_bluenoise() {
   return v;
 }
 
-void invalidate(LuminaryHost* h) {
+void invalidate(LuminaryHost* h, uint32_t dirty = LUMC_DIRTY_ALL) {
+  h->scene_dirty |= dirty; h->core_dirty |= dirty;
   h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false;
-  for (auto& slot : h->devices) slot.scene_valid = false;
+  for (auto& slot : h->devices) { slot.scene_valid = false; slot.dirty |= dirty; }
   { std::lock_guard<std::mutex> l(h->worker_mutex); h->async_failed = false; }  // the edit may have repaired what failed
   h->worker_cv.notify_all();
 }
@@ -136,8 +143,13 @@ LuminaryResult ensure_device_scene(LuminaryHost* h) {
     h->scene.hdri_origin[0] = p.x; h->scene.hdri_origin[1] = p.y; h->scene.hdri_origin[2] = p.z;
     h->hdri_origin_pending = false;
   }
-  const std::string err = lum::build_device_scene(h->scene, embedded_bluenoise(), &h->device_scene);
-  if (!err.empty()) { h->log.push_back(err); std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); return LUMINARY_ERROR_API_EXCEPTION; }
+  static const std::vector<uint32_t> bluenoise = embedded_bluenoise();
+  const std::string err = lum::update_device_scene(h->scene, bluenoise, h->scene_dirty, &h->device_scene);
+  if (!err.empty()) { h->log.push_back(err); std::fprintf(stderr, "[luminary_amd] %s\n", err.c_str()); h->scene_dirty = h->core_dirty = LUMC_DIRTY_ALL; return LUMINARY_ERROR_API_EXCEPTION; }
+  // what was re-encoded is what the devices have to take over (the encoder may add a part: the texture pool when the sky mode moves the moon in or out)
+  h->core_dirty |= h->device_scene.rebuilt;
+  for (auto& slot : h->devices) slot.dirty |= h->device_scene.rebuilt;
+  h->scene_dirty = 0;
   h->device_scene_valid = true;
   h->core_scene_valid = false;
   return LUMINARY_SUCCESS;
@@ -155,9 +167,15 @@ LuminaryResult ensure_core(LuminaryHost* h) {
   const LuminaryResult r = ensure_device_scene(h);
   if (r) return r;
   if (!h->core_scene_valid) {
-    if (lumc_scene_upload(h->core, &h->device_scene.view)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(h->core)); return LUMINARY_ERROR_CUDA; }
+    if (lumc_scene_update(h->core, &h->device_scene.view, h->core_dirty)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(h->core)); h->core_dirty = LUMC_DIRTY_ALL; return LUMINARY_ERROR_CUDA; }
+    h->core_dirty = 0;
     h->core_scene_valid = true;
-    h->num_pixels = 0;
+    // The accumulation starts over. With the frame size unchanged the pixel sets of the devices stay as they are and only their accumulators
+    // are cleared; a new size makes the render loop set them up again (num_pixels = 0).
+    const LumDeviceSceneView& v = h->device_scene.view;
+    const bool same_frame = h->num_pixels != 0 && h->core_width == v.width && h->core_height == v.height;
+    h->core_width = v.width; h->core_height = v.height;
+    if (!same_frame || h->partition_n > 1 || lumc_clear_accumulators(h->core)) h->num_pixels = 0;
   }
   return LUMINARY_SUCCESS;
 }
@@ -178,7 +196,7 @@ LuminaryResult ensure_partition_cores(LuminaryHost* h, std::vector<LumContext*>*
   if (r) return r;
   cores->clear();
   for (LuminaryHost::DeviceSlot* slot : enabled_slots(h)) {
-    if (slot == &h->devices[h->main_slot]) { slot->core = h->core; slot->scene_valid = true; cores->push_back(h->core); continue; }
+    if (slot == &h->devices[h->main_slot]) { slot->core = h->core; slot->scene_valid = true; slot->dirty = 0; cores->push_back(h->core); continue; }
     if (!slot->core) {
       if (lumc_context_create(slot->ordinal, &slot->core)) {
         std::fprintf(stderr, "[luminary_amd] device %d: %s\n", slot->ordinal, lumc_last_error(slot->core));
@@ -190,9 +208,10 @@ LuminaryResult ensure_partition_cores(LuminaryHost* h, std::vector<LumContext*>*
       slot->scene_valid = false;
     }
     if (!slot->scene_valid) {
-      if (lumc_scene_upload(slot->core, &h->device_scene.view)) { std::fprintf(stderr, "[luminary_amd] device %d: %s\n", slot->ordinal, lumc_last_error(slot->core)); return LUMINARY_ERROR_CUDA; }
+      if (lumc_scene_update(slot->core, &h->device_scene.view, slot->dirty)) { std::fprintf(stderr, "[luminary_amd] device %d: %s\n", slot->ordinal, lumc_last_error(slot->core)); slot->dirty = LUMC_DIRTY_ALL; return LUMINARY_ERROR_CUDA; }
+      slot->dirty = 0;
       slot->scene_valid = true;
-      h->partition_n = 0;  // its pixel set is gone with the old scene
+      h->partition_n = 0;  // the accumulation restarts: the render loop deals the tiles again (which also clears every device's accumulators)
     }
     cores->push_back(slot->core);
   }
@@ -422,11 +441,12 @@ LuminaryResult luminary_host_set_device_enable(LuminaryHost* host, uint32_t devi
     host->device_ordinal = m.ordinal;
     if (m.core) { host->core = m.core; }  // its render context becomes the main context
     host->core_scene_valid = false;
+    host->core_dirty = LUMC_DIRTY_ALL;  // the new main context takes the whole scene again
     host->num_pixels = 0;
   }
   host->partition_n = 0;
   host->comm_ready = false;
-  invalidate(host);  // the integration restarts with the new partition
+  invalidate(host, 0);  // the integration restarts with the new partition; the scene itself did not change
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_host_start_device(LuminaryHost* host, uint32_t index) { return luminary_host_set_device_enable(host, index, true); }
@@ -450,7 +470,7 @@ LuminaryResult luminary_host_load_obj_file(LuminaryHost* host, LuminaryPath* pat
   host->scene.materials.insert(host->scene.materials.end(), mats.begin(), mats.end());
   for (auto& t : textures) host->scene.textures.push_back(std::move(t));
   host->scene.meshes.push_back(std::move(mesh));
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_MESHES | LUMC_DIRTY_INSTANCES | LUMC_DIRTY_MATERIALS | LUMC_DIRTY_TEXTURES | LUMC_DIRTY_LIGHTS);
   return LUMINARY_SUCCESS;
 }
 
@@ -590,7 +610,7 @@ LuminaryResult luminary_ext_add_texture(LuminaryHost* host, const uint8_t* rgba8
   std::memcpy(t.texels.data(), rgba8, t.texels.size() * 4);
   host->scene.textures.push_back(std::move(t));
   *texture_id = (uint16_t) (host->scene.textures.size() - 1);
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_TEXTURES | LUMC_DIRTY_LIGHTS);  // emissive textures weigh the light tree
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_ext_write_png(const char* path, const uint32_t* argb8, uint32_t width, uint32_t height, size_t ld) { return lum::write_png(path, argb8, width, height, ld); }
@@ -599,7 +619,7 @@ LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
   CHECK_NULL(host);
   ApiLock lock(host);
   host->hdri_origin_pending = true;
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_CONSTANTS);
   return LUMINARY_SUCCESS;
 }
 
@@ -618,7 +638,9 @@ LuminaryResult luminary_host_request_sky_hdri_build(LuminaryHost* host) {
       const bool restarts = change_restarts(*in, host->scene.FIELD);                                    \
       host->scene.FIELD = *in;                                                                          \
       if (std::is_same<TYPE, LuminarySky>::value) host->hdri_origin_pending = true; /* sky.c:45: every sky change dirties the panorama */ \
-      if (restarts) invalidate(host); /* else: only the outputs change; the accumulated frame stays (SCENE_DIRTY_FLAG_OUTPUT) */ \
+      /* these entities reach the kernels as constants (and tables derived from them): no mesh, instance or material array is touched */ \
+      if (restarts) invalidate(host, LUMC_DIRTY_CONSTANTS | (std::is_same<TYPE, LuminaryParticles>::value ? LUMC_DIRTY_PARTICLES : 0u)); \
+      /* else: only the outputs change; the accumulated frame stays (SCENE_DIRTY_FLAG_OUTPUT) */ \
     }                                                                                                   \
     return LUMINARY_SUCCESS;                                                                            \
   }
@@ -643,7 +665,7 @@ LuminaryResult luminary_host_set_material(LuminaryHost* host, uint16_t id, const
   if (id >= host->scene.materials.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   host->scene.materials[id] = *material;
   host->scene.materials[id].id = id;
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_MATERIALS | LUMC_DIRTY_LIGHTS);  // geometry and acceleration structures stay; emission feeds the light tree
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_host_get_instance(LuminaryHost* host, uint32_t id, LuminaryInstance* instance) {
@@ -660,7 +682,7 @@ LuminaryResult luminary_host_set_instance(LuminaryHost* host, const LuminaryInst
   if (instance->id >= host->scene.instances.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   lum::HostInstance& i = host->scene.instances[instance->id];
   i.mesh_id = instance->mesh_id; i.translation = instance->position; i.rotation = instance->rotation; i.scale = instance->scale; i.active = true;
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_INSTANCES | LUMC_DIRTY_LIGHTS);  // top-level tree and light tree; the per-mesh trees are reused
   return LUMINARY_SUCCESS;
 }
 // host.c:902-930: writes defaults and the new id back to the caller
@@ -672,7 +694,7 @@ LuminaryResult luminary_host_new_instance(LuminaryHost* host, LuminaryInstance* 
   host->scene.instances.push_back(i);
   instance->id = (uint32_t) host->scene.instances.size() - 1; instance->mesh_id = i.mesh_id;
   instance->position = i.translation; instance->rotation = i.rotation; instance->scale = i.scale;
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_INSTANCES | LUMC_DIRTY_LIGHTS);
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_host_get_num_meshes(LuminaryHost* host, uint32_t* n) { CHECK_NULL(host); CHECK_NULL(n); *n = (uint32_t) host->scene.meshes.size(); return LUMINARY_SUCCESS; }
@@ -702,7 +724,7 @@ LuminaryResult luminary_ext_add_mesh(LuminaryHost* host, const float* positions,
   }
   host->scene.meshes.push_back(std::move(m));
   if (mesh_id) *mesh_id = (uint32_t) host->scene.meshes.size() - 1;
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_MESHES | LUMC_DIRTY_INSTANCES | LUMC_DIRTY_LIGHTS);
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id) {
@@ -712,7 +734,7 @@ LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMater
   host->scene.materials.push_back(*material);
   host->scene.materials.back().id = (uint32_t) host->scene.materials.size() - 1;
   if (material_id) *material_id = (uint16_t) (host->scene.materials.size() - 1);
-  invalidate(host);
+  invalidate(host, LUMC_DIRTY_MATERIALS | LUMC_DIRTY_LIGHTS);
   return LUMINARY_SUCCESS;
 }
 LuminaryResult luminary_ext_build_device_scene(LuminaryHost* host, const LumDeviceSceneView** view) {

@@ -31,7 +31,15 @@ struct LumContext {
   int device = 0;
   std::string error;
   const WavefrontKernels* wf = wavefront_kernels_fast();  // flavour of the wavefront kernels (lumc_set_flavour; LUM_FLAVOUR=exact|fast overrides the default)
-  std::vector<void*> scene_allocs;
+  // device allocations of the scene by the part of it they belong to (lumc_scene_update frees and rebuilds a part at a time)
+  enum AllocGroup { kGrpMesh = 0, kGrpInst, kGrpMat, kGrpLight, kGrpTex, kGrpConst, kGrpPart, kGrpOnce, kGrpCount };
+  std::vector<void*> scene_allocs[kGrpCount];
+  int alloc_group = kGrpOnce;
+  // what a partial update needs again: the per-mesh trees (node indices relative to the mesh, leaf ranges relative to its first triangle) and boxes
+  std::vector<Bvh4> mesh_bvh;
+  std::vector<Aabb> mesh_box;
+  std::vector<uint32_t> sky_lut_key;  // the sky parameters the two sky tables were generated from
+  float4* d_sky_lut[2] = {nullptr, nullptr};
   DeviceScene scene{};
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
@@ -139,16 +147,22 @@ int upload(LumContext* ctx, const T* host, size_t count, const T** out, bool sce
   if (count == 0 || host == nullptr) return 0;
   void* d = nullptr;
   HIP_TRY(ctx, hipMalloc(&d, sizeof(T) * count));
-  if (scene_owned) ctx->scene_allocs.push_back(d);
+  if (scene_owned) ctx->scene_allocs[ctx->alloc_group].push_back(d);
   HIP_TRY(ctx, hipMemcpy(d, host, sizeof(T) * count, hipMemcpyHostToDevice));
   *out = (const T*) d;
   return 0;
 }
 
+void free_group(LumContext* ctx, int group) {
+  for (void* p : ctx->scene_allocs[group]) (void) hipFree(p);
+  ctx->scene_allocs[group].clear();
+}
 void free_scene(LumContext* ctx) {
-  for (void* p : ctx->scene_allocs) (void) hipFree(p);
-  ctx->scene_allocs.clear();
+  for (int g = 0; g < LumContext::kGrpCount; g++) free_group(ctx, g);
   for (int i = 0; i < 4; i++) { if (ctx->d_luts[i]) (void) hipFree(ctx->d_luts[i]); ctx->d_luts[i] = nullptr; }
+  for (int i = 0; i < 2; i++) { if (ctx->d_sky_lut[i]) (void) hipFree(ctx->d_sky_lut[i]); ctx->d_sky_lut[i] = nullptr; }
+  ctx->sky_lut_key.clear();
+  ctx->mesh_bvh.clear(); ctx->mesh_box.clear();
   ctx->has_scene = false;
 }
 
@@ -730,23 +744,39 @@ static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, Dev
   return 0;
 }
 
-int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
-  if (!ctx || !v) return 1;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
-  free_scene(ctx);
+// The scene on the device, part by part (lumc_scene_update). Every part frees what it allocated before; parts that are not dirty keep their device
+// arrays and the fields of ctx->scene that point at them.
+static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned dirty) {
   DeviceScene& sc = ctx->scene;
-  std::memset(&sc, 0, sizeof(sc));
   if (!v->bluenoise_2d) { ctx->error = "scene has no blue-noise mask"; return 1; }
   if (v->max_ray_depth > 63) { ctx->error = "max_ray_depth exceeds 63 (6-bit field, device_structs.h:9)"; return 1; }
   const uint32_t total_tris = v->num_meshes ? v->mesh_tri_offset[v->num_meshes] : 0;
+  if (dirty & LUMC_DIRTY_MESHES) dirty |= LUMC_DIRTY_INSTANCES;  // the assembled node array holds the per-mesh trees
+  if (dirty & LUMC_DIRTY_PARTICLES) dirty |= LUMC_DIRTY_CONSTANTS;
+  const bool dirty_meshes = (dirty & LUMC_DIRTY_MESHES) != 0, dirty_instances = (dirty & LUMC_DIRTY_INSTANCES) != 0, dirty_lights = (dirty & LUMC_DIRTY_LIGHTS) != 0;
+  ctx->has_scene = false;  // until this update has gone through
 
-  if (upload(ctx, v->mesh_tri_offset, (size_t) v->num_meshes + 1, &sc.mesh_tri_offset)) return 1;
-  if (upload(ctx, (const float4*) v->vertices, (size_t) total_tris * 3, &sc.vertices)) return 1;
-  if (upload(ctx, (const uint4*) v->tri_tex, (size_t) total_tris, &sc.tri_tex)) return 1;
-  if (upload(ctx, v->instance_mesh_ids, v->num_instances, &sc.instance_mesh_ids)) return 1;
-  if (upload(ctx, (const float4*) v->instance_transforms, (size_t) v->num_instances * 2, &sc.instance_transforms)) return 1;
-  if (upload(ctx, (const uint4*) v->materials, (size_t) v->num_materials * 2, &sc.materials)) return 1;
-  if (v->light_tree_root && v->num_lights) {
+  if (dirty_meshes) {
+    free_group(ctx, LumContext::kGrpMesh); ctx->alloc_group = LumContext::kGrpMesh;
+    if (upload(ctx, v->mesh_tri_offset, (size_t) v->num_meshes + 1, &sc.mesh_tri_offset)) return 1;
+    if (upload(ctx, (const float4*) v->vertices, (size_t) total_tris * 3, &sc.vertices)) return 1;
+    if (upload(ctx, (const uint4*) v->tri_tex, (size_t) total_tris, &sc.tri_tex)) return 1;
+  }
+  if (dirty_instances) {
+    free_group(ctx, LumContext::kGrpInst); ctx->alloc_group = LumContext::kGrpInst;
+    if (upload(ctx, v->instance_mesh_ids, v->num_instances, &sc.instance_mesh_ids)) return 1;
+    if (upload(ctx, (const float4*) v->instance_transforms, (size_t) v->num_instances * 2, &sc.instance_transforms)) return 1;
+  }
+  if (dirty & LUMC_DIRTY_MATERIALS) {
+    free_group(ctx, LumContext::kGrpMat); ctx->alloc_group = LumContext::kGrpMat;
+    if (upload(ctx, (const uint4*) v->materials, (size_t) v->num_materials * 2, &sc.materials)) return 1;
+  }
+  if (dirty_lights) {
+    free_group(ctx, LumContext::kGrpLight); ctx->alloc_group = LumContext::kGrpLight;
+    sc.light_tree_root = nullptr; sc.light_root_children = nullptr; sc.light_tree_nodes = nullptr; sc.light_tri_handles = nullptr; sc.light_tri_table = nullptr;
+    sc.light_nodes = nullptr; sc.light_tris = nullptr; sc.light_num_nodes = 0;
+  }
+  if (dirty_lights && v->light_tree_root && v->num_lights) {
     const uint32_t sections = v->light_tree_root[10];
     if (upload(ctx, (const uint4*) v->light_tree_root, (size_t) 1 + 3 * sections, &sc.light_tree_root)) return 1;
     {
@@ -774,9 +804,12 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     if (upload(ctx, (const uint4*) v->light_tree_nodes, (size_t) v->num_light_tree_nodes * 4, &sc.light_tree_nodes)) return 1;
     if (upload(ctx, (const uint2*) v->light_tri_handles, v->num_lights, &sc.light_tri_handles)) return 1;
   }
-  if (upload(ctx, v->bluenoise_2d, 65536, &sc.bluenoise_2d)) return 1;
-  sc.num_textures = 0;
-  if (v->num_textures && v->texture_table && v->texels) {
+  if (!sc.bluenoise_2d) { ctx->alloc_group = LumContext::kGrpOnce; if (upload(ctx, v->bluenoise_2d, 65536, &sc.bluenoise_2d)) return 1; }
+  if (dirty & LUMC_DIRTY_TEXTURES) {
+    free_group(ctx, LumContext::kGrpTex); ctx->alloc_group = LumContext::kGrpTex;
+    sc.num_textures = 0; sc.texture_table = nullptr; sc.texels = nullptr;
+  }
+  if ((dirty & LUMC_DIRTY_TEXTURES) && v->num_textures && v->texture_table && v->texels) {
     size_t texel_count = 0;
     for (uint32_t t = 0; t < v->num_textures; t++)
       texel_count = std::max(texel_count, (size_t) v->texture_table[4 * t] + (size_t) v->texture_table[4 * t + 1] * v->texture_table[4 * t + 2]);
@@ -787,9 +820,12 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
 
   // ---- top-level BVH over the instances' world boxes + one bottom-level BVH per mesh, in ONE node array with absolute indices ----
   // Depth caps keep the traversal stack bounded (dev_trace.h kStackSize): top level <= 16, bottom levels <= 26 BVH4 levels.
-  std::vector<Aabb> mesh_box(v->num_meshes);
+  if (dirty_instances) {
+  std::vector<Aabb>& mesh_box = ctx->mesh_box;
   std::vector<std::vector<Aabb>> tri_boxes(v->num_meshes);
-  for (uint32_t m = 0; m < v->num_meshes; m++) {
+  if (dirty_meshes) mesh_box.assign(v->num_meshes, Aabb{});
+  if (mesh_box.size() != v->num_meshes || (!dirty_meshes && ctx->mesh_bvh.size() != v->num_meshes)) { ctx->error = "lumc_scene_update: the meshes changed but LUMC_DIRTY_MESHES is not set"; return 1; }
+  for (uint32_t m = 0; dirty_meshes && m < v->num_meshes; m++) {
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
     tri_boxes[m].resize(nt);
     Aabb mb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
@@ -828,20 +864,27 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     sc.tlas_num_nodes = (uint32_t) tlas.nodes.size();
     ctx->bvh_stats[2] = tlas.nodes.size();
   }
-  ctx->bvh_build_seconds = 0.0;
-  ctx->bvh_meshes_by_builder[0] = ctx->bvh_meshes_by_builder[1] = 0;
-  std::vector<BvhTri> blas_tris((size_t) total_tris + 1);
-  std::memset(blas_tris.data(), 0, sizeof(BvhTri) * blas_tris.size());
+  if (dirty_meshes) {
+    ctx->bvh_build_seconds = 0.0;
+    ctx->bvh_meshes_by_builder[0] = ctx->bvh_meshes_by_builder[1] = 0;
+    ctx->mesh_bvh.assign(v->num_meshes, Bvh4{});
+  }
+  std::vector<BvhTri> blas_tris(dirty_meshes ? (size_t) total_tris + 1 : 0);
+  if (dirty_meshes) std::memset(blas_tris.data(), 0, sizeof(BvhTri) * blas_tris.size());
   std::vector<uint32_t> mesh_root(v->num_meshes + 1, 0);
   for (uint32_t m = 0; m < v->num_meshes; m++) {
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
-    const auto t_build = std::chrono::steady_clock::now();
-    Bvh4 bvh;
-    if (ctx->bvh_builder == 1) bvh = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
-    if (!bvh.nodes.empty()) ctx->bvh_meshes_by_builder[1]++;
-    else { bvh = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26); ctx->bvh_meshes_by_builder[0]++; }  // default, and fallback for too deep LBVH trees
-    ctx->bvh_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
-    if (bvh.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
+    if (dirty_meshes) {  // the only part of an upload that takes long: an instance edit reuses the trees
+      const auto t_build = std::chrono::steady_clock::now();
+      Bvh4 built;
+      if (ctx->bvh_builder == 1) built = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+      if (!built.nodes.empty()) ctx->bvh_meshes_by_builder[1]++;
+      else { built = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26); ctx->bvh_meshes_by_builder[0]++; }  // default, and fallback for too deep LBVH trees
+      ctx->bvh_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
+      if (built.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
+      ctx->mesh_bvh[m] = std::move(built);
+    }
+    const Bvh4& bvh = ctx->mesh_bvh[m];
     const uint32_t base = (uint32_t) nodes.size();
     mesh_root[m] = base;
     for (Bvh4Node n : bvh.nodes) {
@@ -852,19 +895,15 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       }
       nodes.push_back(n);
     }
-    for (uint32_t i = 0; i < nt; i++) {
+    for (uint32_t i = 0; dirty_meshes && i < nt; i++) {
       const uint32_t t = bvh.prims[i];
       const float* p = v->vertices + (size_t) (t0 + t) * 12;
       BvhTri& bt = blas_tris[(size_t) t0 + i];
       for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
       bt.id = t; bt.scene_index = t0 + t;
-      {
-        const uint32_t material = v->tri_tex[(size_t) (t0 + t) * 4 + 3] & 0xFFFFu;
-        const uint16_t albedo_tex = (material < v->num_materials) ? v->materials[(size_t) material * 16 + 12] : (uint16_t) 0xFFFF;
-        bt.albedo_tex = (albedo_tex == 0xFFFF) ? kBvhTriNoTexture : albedo_tex;
-      }
+      bt.albedo_tex = kBvhTriNoTexture;  // k_tri_opacity writes the word from the triangle's material (below; again after a material edit)
     }
-    tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit();
+    if (dirty_meshes) { tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit(); }
   }
   // ---- renumber: the top of the tree first, in breadth-first order across both levels (top-level leaves continue into the root of
   // their mesh), so that "node index < K" selects the K most visited nodes; the ray kernels stage those in LDS ----
@@ -987,8 +1026,9 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
 #if LUM_BVH4Q
   quantise_bvh4(nodes);
 #endif
+  ctx->alloc_group = LumContext::kGrpInst;
   if (upload(ctx, nodes.data(), nodes.size(), &sc.bvh_nodes)) return 1;
-  if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1;
+  if (dirty_meshes) { ctx->alloc_group = LumContext::kGrpMesh; if (upload(ctx, blas_tris.data(), blas_tris.size(), &sc.blas_tris)) return 1; ctx->alloc_group = LumContext::kGrpInst; }
   {
     std::vector<float4> leaves(4 * tlas_order.size() + 4);
     for (size_t i = 0; i < tlas_order.size(); i++) {
@@ -1021,8 +1061,10 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->set_ray_kernel_lds(dyn));
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->set_ray_kernel_lds(dyn));
   }
+  }  // dirty_instances
   // ---- light-only BVH (world-space triangles; reference: optix_bvh.c:382-478) ----
-  {
+  if (dirty_lights) {
+    ctx->alloc_group = LumContext::kGrpLight;
     const uint32_t nl = (v->light_tree_root && v->light_bvh_tris) ? v->num_lights : 0;
     std::vector<Aabb> boxes(nl);
     for (uint32_t l = 0; l < nl; l++) { const float* p = v->light_bvh_tris + (size_t) l * 12; boxes[l] = tri_box(p, p + 4, p + 8); }
@@ -1044,18 +1086,21 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   ctx->bvh_stats[1] = total_tris;
 
   { const uint32_t nt = sc.num_textures; sc.num_meshes = v->num_meshes; sc.num_instances = v->num_instances; sc.num_materials = v->num_materials; sc.num_lights = v->num_lights; sc.num_textures = nt; }
-  if (total_tris) {  // which traversal triangles stop a visibility ray on their own (kBvhTriOpaque)
+  if (total_tris && (dirty_meshes || (dirty & LUMC_DIRTY_MATERIALS))) {  // the triangles' material words: texture id, or whether they stop a visibility ray on their own
     hipLaunchKernelGGL(k_tri_opacity, dim3((total_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, const_cast<BvhTri*>(sc.blas_tris), total_tris);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (sc.light_tree_root && sc.num_lights) {  // the emissive triangles in world space, one record per light (load_tri_light_table)
+  if (dirty_lights && sc.light_tree_root && sc.num_lights) {  // the emissive triangles in world space, one record per light (load_tri_light_table)
     float4* table = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**) &table, sizeof(float4) * 3 * (size_t) sc.num_lights)); ctx->scene_allocs.push_back(table);
+    HIP_TRY(ctx, hipMalloc((void**) &table, sizeof(float4) * 3 * (size_t) sc.num_lights)); ctx->scene_allocs[LumContext::kGrpLight].push_back(table);
     hipLaunchKernelGGL(k_light_table, dim3((sc.num_lights + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, table);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipDeviceSynchronize());
     sc.light_tri_table = table;
   }
+  if (dirty & (LUMC_DIRTY_CONSTANTS | LUMC_DIRTY_PARTICLES)) {
+  if (dirty & LUMC_DIRTY_CONSTANTS) { free_group(ctx, LumContext::kGrpConst); }
+  ctx->alloc_group = LumContext::kGrpConst;
   sc.width = v->width; sc.height = v->height; sc.max_ray_depth = v->max_ray_depth; sc.shading_mode = v->shading_mode;
   std::memcpy(sc.cam_pos, v->cam_pos, sizeof(sc.cam_pos));
   std::memcpy(sc.cam_rotation, v->cam_rotation, sizeof(sc.cam_rotation));
@@ -1147,30 +1192,50 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
   std::memcpy(sc.particles_albedo, v->particles_albedo, sizeof(sc.particles_albedo));
   std::memcpy(sc.particles_direction, v->particles_direction, sizeof(sc.particles_direction));
   std::memcpy(sc.particles_phase, v->particles_phase, sizeof(sc.particles_phase));
-  if (build_particle_tree(ctx, v, sc)) return 1;
+  if (dirty & LUMC_DIRTY_PARTICLES) {
+    free_group(ctx, LumContext::kGrpPart); ctx->alloc_group = LumContext::kGrpPart;
+    if (build_particle_tree(ctx, v, sc)) return 1;
+    ctx->alloc_group = LumContext::kGrpConst;
+  }
   if (sc.sky_mode != kSkyConstantColor) {  // HDRI mode bakes from them and samples the sun through them
     const size_t tm_texels = 2 * (size_t) kSkyTmWidth * kSkyTmHeight, ms_texels = 2 * (size_t) kSkyMsSize * kSkyMsSize;
     if (v->sky_lut_transmittance && v->sky_lut_multiscattering) {
       if (upload(ctx, (const float4*) v->sky_lut_transmittance, tm_texels, &sc.sky_lut_transmittance)) return 1;
       if (upload(ctx, (const float4*) v->sky_lut_multiscattering, ms_texels, &sc.sky_lut_multiscattering)) return 1;
+      ctx->sky_lut_key.clear();
     }
     else {
-      float4* tm = nullptr; float4* ms = nullptr;
-      HIP_TRY(ctx, hipMalloc((void**) &tm, sizeof(float4) * tm_texels)); ctx->scene_allocs.push_back(tm);
-      HIP_TRY(ctx, hipMalloc((void**) &ms, sizeof(float4) * ms_texels)); ctx->scene_allocs.push_back(ms);
-      hipLaunchKernelGGL(k_sky_transmittance_lut, dim3((kSkyTmWidth * kSkyTmHeight + 63) / 64), dim3(64), 0, 0, sc, tm);
-      sc.sky_lut_transmittance = tm;  // the multiscattering integration reads the finished transmittance table
-      hipLaunchKernelGGL(k_sky_multiscattering_lut, dim3(kSkyMsSize, kSkyMsSize), dim3(kSkyMsIter), 0, 0, sc, ms);
-      sc.sky_lut_multiscattering = ms;
-      HIP_TRY(ctx, hipGetLastError());
-      HIP_TRY(ctx, hipDeviceSynchronize());
+      // the two tables are functions of the atmosphere's parameters alone (sky.cuh:110-176, :186-332): a camera move or a sun move keeps them
+      std::vector<uint32_t> key;
+      auto put = [&](const void* p, size_t bytes) { const size_t at = key.size(); key.resize(at + (bytes + 3) / 4, 0u); std::memcpy(key.data() + at, p, bytes); };
+      put(&sc.sky_ozone_absorption, sizeof(sc.sky_ozone_absorption));
+      const float params[] = {sc.sky_base_density, sc.sky_rayleigh_density, sc.sky_mie_density, sc.sky_ozone_density, sc.sky_rayleigh_falloff, sc.sky_mie_falloff,
+                              sc.sky_ground_visibility, sc.sky_ozone_layer_thickness, sc.sky_multiscattering_factor, sc.sky_sun_strength};
+      put(params, sizeof(params)); put(sc.sky_mie_phase, sizeof(sc.sky_mie_phase)); put(sc.sky_sun_pos, sizeof(sc.sky_sun_pos)); put(sc.sky_geometry_offset, sizeof(sc.sky_geometry_offset));
+      if (!ctx->d_sky_lut[0]) {
+        HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sky_lut[0], sizeof(float4) * tm_texels));
+        HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sky_lut[1], sizeof(float4) * ms_texels));
+        ctx->sky_lut_key.clear();
+      }
+      if (key != ctx->sky_lut_key) {
+        hipLaunchKernelGGL(k_sky_transmittance_lut, dim3((kSkyTmWidth * kSkyTmHeight + 63) / 64), dim3(64), 0, 0, sc, ctx->d_sky_lut[0]);
+        sc.sky_lut_transmittance = ctx->d_sky_lut[0];  // the multiscattering integration reads the finished transmittance table
+        hipLaunchKernelGGL(k_sky_multiscattering_lut, dim3(kSkyMsSize, kSkyMsSize), dim3(kSkyMsIter), 0, 0, sc, ctx->d_sky_lut[1]);
+        HIP_TRY(ctx, hipGetLastError());
+        HIP_TRY(ctx, hipDeviceSynchronize());
+        ctx->sky_lut_key = key;
+      }
+      sc.sky_lut_transmittance = ctx->d_sky_lut[0];
+      sc.sky_lut_multiscattering = ctx->d_sky_lut[1];
     }
   }
   // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
   const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
   const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
-  for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_luts[t], sizeof(uint16_t) * lut_count[t]));
-  if (host_luts[0] && host_luts[1] && host_luts[2] && host_luts[3]) {
+  const bool have_luts = ctx->d_luts[0] != nullptr;
+  for (int t = 0; t < 4 && !have_luts; t++) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_luts[t], sizeof(uint16_t) * lut_count[t]));
+  if (have_luts && dirty != LUMC_DIRTY_ALL) { /* a partial update keeps the tables the context renders with */ }
+  else if (host_luts[0] && host_luts[1] && host_luts[2] && host_luts[3]) {
     for (int t = 0; t < 4; t++) HIP_TRY(ctx, hipMemcpy(ctx->d_luts[t], host_luts[t], sizeof(uint16_t) * lut_count[t], hipMemcpyHostToDevice));
   }
   else {
@@ -1216,7 +1281,25 @@ int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
       if (lumc_sky_hdri_build(ctx, v->sky_hdri_origin, v->sky_hdri_dim, v->sky_hdri_samples ? v->sky_hdri_samples : 1u)) { ctx->has_scene = false; return 1; }
     }
   }
+  }  // constants
   ctx->has_scene = true;
+  return 0;
+}
+
+int lumc_scene_upload(LumContext* ctx, const LumDeviceSceneView* v) {
+  if (!ctx || !v) return 1;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  free_scene(ctx);
+  std::memset(&ctx->scene, 0, sizeof(ctx->scene));
+  return scene_update(ctx, v, LUMC_DIRTY_ALL);
+}
+
+int lumc_scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned int dirty) {
+  if (!ctx || !v) return 1;
+  if (!ctx->has_scene || (dirty & LUMC_DIRTY_ALL) == LUMC_DIRTY_ALL) return lumc_scene_upload(ctx, v);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipDeviceSynchronize());  // nothing renders from the arrays that are about to be freed
+  if (scene_update(ctx, v, dirty & LUMC_DIRTY_ALL)) { free_scene(ctx); return 1; }  // a failed partial update leaves no half-updated scene behind
   return 0;
 }
 

@@ -908,7 +908,9 @@ void generate_particles(const LuminaryParticles& p, std::vector<float>* vertices
   }
 }
 
-std::string build_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, DeviceSceneBuffers* out) {
+// Which parts of the device scene an edit touched (scene.h:42-63 keeps such flags per entity; device_manager.c:311-320, :424-450 re-uploads by
+// them). LUMC_DIRTY_* of include/lum_core.h, shared with the core's lumc_scene_update.
+std::string update_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, uint32_t dirty, DeviceSceneBuffers* out) {
   if (bluenoise.size() != 65536) return "blue-noise mask must hold 65536 texels";
   const LuminaryRendererSettings& st = scene.settings;
   if (st.supersampling > 3) return "supersampling exceeds its 2-bit field";
@@ -918,7 +920,8 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   if (scene.materials.size() > 0xFFFF) return "too many materials";
 
   DeviceSceneBuffers& b = *out;
-  b.bluenoise = bluenoise;
+  if (b.bluenoise.size() != 65536) { b.bluenoise = bluenoise; dirty = LUMC_DIRTY_ALL; }  // first build
+  if (dirty & LUMC_DIRTY_MESHES) {
   b.mesh_tri_offset.assign(scene.meshes.size() + 1, 0);
   size_t total = 0;
   for (size_t m = 0; m < scene.meshes.size(); m++) { b.mesh_tri_offset[m] = (uint32_t) total; total += scene.meshes[m].triangle_count(); }
@@ -941,6 +944,8 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
       tt[3] = mesh.material_ids[t];
     }
   }
+  }
+  if (dirty & (LUMC_DIRTY_INSTANCES | LUMC_DIRTY_MESHES)) {
   // inactive instances keep their slot (ids are stable) but point at no mesh
   b.instance_mesh_ids.resize(scene.instances.size());
   b.instance_transforms.resize(scene.instances.size() * 8);
@@ -949,17 +954,28 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
     b.instance_mesh_ids[i] = (inst.active && inst.mesh_id < scene.meshes.size()) ? inst.mesh_id : 0xFFFFFFFFu;
     encode_transform(inst, b.instance_transforms.data() + 8 * i);
   }
-  b.materials.resize(scene.materials.size() * 16);
-  for (size_t i = 0; i < scene.materials.size(); i++) encode_material(scene.materials[i], b.materials.data() + 16 * i);
-
-  LightTreeOutput lt;
-  build_light_tree(scene, &lt);
-  b.light_tree_root = lt.root; b.light_tree_nodes = lt.nodes; b.light_tri_handles = lt.tri_handles; b.light_bvh_tris = lt.bvh_tris;
+  }
+  if (dirty & LUMC_DIRTY_MATERIALS) {
+    b.materials.resize(scene.materials.size() * 16);
+    for (size_t i = 0; i < scene.materials.size(); i++) encode_material(scene.materials[i], b.materials.data() + 16 * i);
+  }
+  if (dirty & LUMC_DIRTY_LIGHTS) {  // the tree depends on the emissive materials, the instances and the meshes (device_manager.c:439-450: rebuilt when its build id changes)
+    LightTreeOutput lt;
+    build_light_tree(scene, &lt);
+    b.light_tree_root = lt.root; b.light_tree_nodes = lt.nodes; b.light_tri_handles = lt.tri_handles; b.light_bvh_tris = lt.bvh_tris;
+  }
 
   LumDeviceSceneView& v = b.view;
   std::memset(&v, 0, sizeof(v));
   v.num_meshes = (uint32_t) scene.meshes.size(); v.num_instances = (uint32_t) scene.instances.size();
-  v.num_materials = (uint32_t) scene.materials.size(); v.num_lights = (uint32_t) (lt.tri_handles.size() / 2);
+  v.num_materials = (uint32_t) scene.materials.size(); v.num_lights = (uint32_t) (b.light_tri_handles.size() / 2);
+  // the texture pool: the scene's textures, then the embedded moon textures while the procedural sky is on (a change of the sky mode moves them in or out)
+  const bool moon_in_pool = (scene.sky.mode & 3u) == LUMINARY_SKY_MODE_DEFAULT;
+  if (b.moon_in_pool != moon_in_pool) dirty |= LUMC_DIRTY_TEXTURES;
+  b.rebuilt = dirty;
+  if (dirty & LUMC_DIRTY_TEXTURES) {
+  b.moon_in_pool = moon_in_pool;
+  b.moon_albedo_tex = b.moon_normal_tex = 0xFFFFFFFFu;
   b.texture_table.clear(); b.texels.clear();
   for (const HostTexture& t : scene.textures) {
     float g = t.gamma;
@@ -968,9 +984,8 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
     b.texture_table.push_back((uint32_t) b.texels.size()); b.texture_table.push_back(t.width); b.texture_table.push_back(t.height); b.texture_table.push_back(gbits);
     b.texels.insert(b.texels.end(), t.texels.begin(), t.texels.end());
   }
-  v.num_textures = (uint32_t) scene.textures.size();
-  v.sky_moon_albedo_tex = v.sky_moon_normal_tex = 0xFFFFFFFFu;
-  if ((scene.sky.mode & 3u) == LUMINARY_SKY_MODE_DEFAULT) {
+  b.num_textures = (uint32_t) scene.textures.size();
+  if (moon_in_pool) {
     // the embedded moon textures join the pool behind the scene's own (device_embedded_data.c:62-92)
     const HostTexture* moon[2];
     if (moon_textures(moon)) {
@@ -982,15 +997,17 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
         b.texture_table.push_back(gbits);
         b.texels.insert(b.texels.end(), moon[k]->texels.begin(), moon[k]->texels.end());
       }
-      v.sky_moon_albedo_tex = v.num_textures; v.sky_moon_normal_tex = v.num_textures + 1;
-      v.num_textures += 2;
+      b.moon_albedo_tex = b.num_textures; b.moon_normal_tex = b.num_textures + 1;
+      b.num_textures += 2;
     }
   }
+  }
+  v.num_textures = b.num_textures; v.sky_moon_albedo_tex = b.moon_albedo_tex; v.sky_moon_normal_tex = b.moon_normal_tex;
   v.texture_table = b.texture_table.empty() ? nullptr : b.texture_table.data();
   v.texels = b.texels.empty() ? nullptr : b.texels.data();
   v.mesh_tri_offset = b.mesh_tri_offset.data(); v.vertices = b.vertices.data(); v.tri_tex = b.tri_tex.data();
   v.instance_mesh_ids = b.instance_mesh_ids.data(); v.instance_transforms = b.instance_transforms.data(); v.materials = b.materials.data();
-  v.light_tree_root = lt.root.empty() ? nullptr : b.light_tree_root.data();
+  v.light_tree_root = b.light_tree_root.empty() ? nullptr : b.light_tree_root.data();
   v.light_tree_nodes = b.light_tree_nodes.empty() ? nullptr : b.light_tree_nodes.data();
   v.light_tri_handles = b.light_tri_handles.empty() ? nullptr : b.light_tri_handles.data();
   v.light_bvh_tris = b.light_bvh_tris.empty() ? nullptr : b.light_bvh_tris.data();
@@ -1061,11 +1078,13 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   v.particles_direction[1] = std::sin(pt.direction_altitude);
   v.particles_direction[2] = std::sin(pt.direction_azimuth) * std::cos(pt.direction_altitude);
   jendersie_eon_parameters(pt.phase_diameter, v.particles_phase);
-  b.particle_vertices.clear(); b.particle_normals.clear();
-  if (v.particles_active) {
-    if (pt.count > (1u << 22)) return "particles: more than 4 M particles";
-    if (!(pt.scale > 0.0f)) return "particles: scale must be positive";
-    generate_particles(pt, &b.particle_vertices, &b.particle_normals);
+  if (dirty & LUMC_DIRTY_PARTICLES) {
+    b.particle_vertices.clear(); b.particle_normals.clear();
+    if (v.particles_active) {
+      if (pt.count > (1u << 22)) return "particles: more than 4 M particles";
+      if (!(pt.scale > 0.0f)) return "particles: scale must be positive";
+      generate_particles(pt, &b.particle_vertices, &b.particle_normals);
+    }
   }
   v.particle_vertices = b.particle_vertices.empty() ? nullptr : b.particle_vertices.data();
   v.particle_normals = b.particle_normals.empty() ? nullptr : b.particle_normals.data();
@@ -1102,6 +1121,10 @@ std::string build_device_scene(const HostScene& scene, const std::vector<uint32_
   }
   v.cloud_noise_shape = nullptr; v.cloud_noise_detail = nullptr; v.cloud_noise_weather = nullptr;
   return std::string();
+}
+
+std::string build_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, DeviceSceneBuffers* out) {
+  return update_device_scene(scene, bluenoise, LUMC_DIRTY_ALL, out);
 }
 
 }  // namespace lum

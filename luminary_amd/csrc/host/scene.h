@@ -83,9 +83,16 @@ struct DeviceSceneBuffers {
   std::vector<uint32_t> sky_stars_offsets; // 64 x 32 + 1
   std::vector<float> particle_vertices;    // 24 floats per particle
   std::vector<float> particle_normals;     // 4 floats per particle
+  // texture pool bookkeeping that outlives a partial update
+  uint32_t num_textures = 0, moon_albedo_tex = 0xFFFFFFFFu, moon_normal_tex = 0xFFFFFFFFu;
+  bool moon_in_pool = false;
+  uint32_t rebuilt = 0;  // LUMC_DIRTY_* parts the last update_device_scene rebuilt (what the core has to take over)
 };
 
 // Fills `out` from the scene. `bluenoise` must hold 65536 texels. Returns an empty string or an error message.
+// update_device_scene re-encodes only the parts named by `dirty` (LUMC_DIRTY_*, include/lum_core.h) and refreshes the scalar fields; everything
+// else in `out` must be what an earlier call built from the same scene.
+std::string update_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, uint32_t dirty, DeviceSceneBuffers* out);
 std::string build_device_scene(const HostScene& scene, const std::vector<uint32_t>& bluenoise, DeviceSceneBuffers* out);
 
 // Light tree build (device_light.c:2236-2265). Exposed for tests.

@@ -1,0 +1,165 @@
+"""Partial scene updates behind the host API (include/lum_core.h lumc_scene_update, LUMC_DIRTY_*).
+
+The reference keeps dirty flags per scene entity (src/luminary/scene.h:42-63) and its device manager re-uploads by them: camera / settings /
+sky as constants (device/device_manager.c:311-320), acceleration structures only for mesh or instance changes (:424-430), the light tree when
+its build id changes (:439-450). Here: an edit marks the parts it touched, the encoder re-encodes those, every device takes over those. The
+tests edit a scene that has already been rendered and compare the next frames, bit for bit (exact flavour), with a host that was given the
+edited scene from the start - and check that no per-mesh tree was rebuilt for edits that do not touch a mesh."""
+import time
+
+import numpy as np
+import pytest
+
+import luminary_amd
+from luminary_amd import scenes
+from luminary_amd.core import DIRTY_ALL, DIRTY_CONSTANTS, Core
+
+
+def test_the_c_abi_exports_the_partial_update():
+    lib = luminary_amd._lib()
+    assert hasattr(lib, "lumc_scene_update") and hasattr(lib, "lumc_scene_upload")
+    assert DIRTY_ALL == 127 and DIRTY_CONSTANTS == 1
+
+
+def _frame(host, spp=2):
+    host.render_samples(0, spp, samples_per_pass=spp)
+    fm, sm = host.accumulators()
+    return fm.copy(), sm.copy()
+
+
+def _build_seconds(host):
+    import ctypes as C
+    lib = luminary_amd._lib()
+    lib.lumc_bvh_build_seconds.restype = C.c_double
+    return float(lib.lumc_bvh_build_seconds(C.c_void_p(host.core_context())))
+
+
+def _edits():
+    """name -> function applying the edit to a host"""
+    def camera(h):
+        c = h.get_camera()
+        c.pos.x += 0.7; c.pos.y += 0.2; c.rotation.y += 0.3
+        h.set_camera(c)
+
+    def depth(h):
+        s = h.get_settings()
+        s.max_ray_depth = 3
+        h.set_settings(s)
+
+    def sky_colour(h):
+        k = h.get_sky()
+        k.constant_color.r, k.constant_color.g, k.constant_color.b = 0.2, 0.9, 0.4
+        h.set_sky(k)
+
+    def material_albedo(h):
+        m = h.get_material(1)
+        m.albedo.r, m.albedo.g, m.albedo.b = 0.1, 0.8, 0.3
+        m.roughness = 0.4
+        h.set_material(1, m)
+
+    def material_emission(h):  # a new emitter: the light tree changes, no geometry does
+        m = h.get_material(2)
+        m.emission_active = True
+        m.emission.r, m.emission.g, m.emission.b = 3.0, 2.0, 1.0
+        h.set_material(2, m)
+
+    def material_transparency(h):  # alpha below one: the traversal triangles' opacity words change
+        m = h.get_material(3)
+        m.albedo.a = 0.35
+        h.set_material(3, m)
+
+    def instance_move(h):
+        i = h.get_instance(1)
+        i.position.x += 0.9; i.position.y += 0.4; i.rotation.z += 0.5; i.scale.x *= 1.3
+        h.set_instance(i)
+
+    return {"camera": camera, "depth": depth, "sky_colour": sky_colour, "material_albedo": material_albedo, "material_emission": material_emission,
+            "material_transparency": material_transparency, "instance_move": instance_move}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("edit", sorted(_edits()))
+def test_an_edit_after_rendering_equals_a_fresh_scene(edit):
+    """zoo scene (instances, transparency, emitters, more lights than the tree's root holds): render, edit, render == edit, render."""
+    apply = _edits()[edit]
+    a = scenes.zoo_scene(64, 48, 6)
+    _frame(a)                       # the scene is on the device
+    t_before = _build_seconds(a)
+    apply(a)
+    got = _frame(a)
+    t_after = _build_seconds(a)
+    b = scenes.zoo_scene(64, 48, 6)
+    apply(b)
+    want = _frame(b)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1]), "partial update differs from a fresh upload after '%s'" % edit
+    assert t_after == t_before, "no per-mesh tree may be rebuilt for '%s' (lumc_bvh_build_seconds changed: %g -> %g)" % (edit, t_before, t_after)
+    assert not np.array_equal(got[0], _frame(scenes.zoo_scene(64, 48, 6))[0]), "the edit '%s' must change the image (otherwise the test proves nothing)" % edit
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_a_sequence_of_edits_and_a_new_mesh():
+    """All edits one after the other on one host, then a mesh is added (the one edit that rebuilds trees): still equal to a fresh host."""
+    a = scenes.zoo_scene(64, 48, 6)
+    b = scenes.zoo_scene(64, 48, 6)
+    _frame(a)
+    for name in sorted(_edits()):
+        _edits()[name](a)
+        _edits()[name](b)
+        _frame(a, 1)  # every intermediate state reaches the device
+    quad = np.array([[-1, 0.5, -1, 1, 0.5, -1, 1, 0.5, 1], [-1, 0.5, -1, 1, 0.5, 1, -1, 0.5, 1]], dtype=np.float32).reshape(-1)
+    for h in (a, b):
+        mesh = h.add_mesh(quad, np.array([1, 1], dtype=np.uint16))
+        h.new_instance(mesh, position=(0.3, 0.2, 0.1))
+    got, want = _frame(a), _frame(b)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_core_level_update_of_constants_only():
+    """lumc_scene_update(CONSTANTS) on the C ABI itself: a moved camera without touching any array."""
+    host = scenes.zoo_scene(64, 48, 6)
+    view = host.device_scene()
+    core = Core(0)
+    core.upload(view)
+    core.set_pixels(None)
+    core.render(0, 2, samples_per_pass=2)
+    t0 = core.bvh_build_seconds()
+    c = host.get_camera()
+    c.pos.z -= 0.5
+    host.set_camera(c)
+    view2 = host.device_scene()
+    core.update(view2, DIRTY_CONSTANTS)
+    assert core.bvh_build_seconds() == t0
+    core.set_pixels(None)
+    core.render(0, 2, samples_per_pass=2)
+    got = core.accumulators()[0]
+    fresh = Core(0)
+    fresh.upload(view2)
+    fresh.set_pixels(None)
+    fresh.render(0, 2, samples_per_pass=2)
+    assert np.array_equal(got, fresh.accumulators()[0])
+    core.close(); fresh.close(); host.close()
+
+
+@pytest.mark.gpu
+def test_camera_move_on_the_hall_is_a_matter_of_milliseconds():
+    """The north-star scene (1.43 M triangles): after luminary_host_set_camera the first new sample is there within 20 ms plus the sample's own
+    render time, and no tree is rebuilt (a full upload builds for 0.4 s and uploads for 0.3 s)."""
+    host = scenes.hall_scene(480, 270, 8)  # a small frame: the render time of the sample itself stays out of the way
+    host.render_samples(0, 1, samples_per_pass=1)
+    t_build = _build_seconds(host)
+    host.render_samples(1, 1, samples_per_pass=1)  # a sample without any edit: the baseline
+    t0 = time.perf_counter()
+    host.render_samples(2, 1, samples_per_pass=1)
+    plain = time.perf_counter() - t0
+    c = host.get_camera()
+    c.pos.x += 0.25
+    t0 = time.perf_counter()
+    host.set_camera(c)
+    host.render_samples(0, 1, samples_per_pass=1)
+    moved = time.perf_counter() - t0
+    assert _build_seconds(host) == t_build
+    assert moved - plain < 0.020, "camera move: %.1f ms over a plain sample's %.1f ms" % (1e3 * (moved - plain), 1e3 * plain)
+    host.close()
