@@ -49,7 +49,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave64 VALU instructions per ns: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles per wave instruction = 1228.8 G/s
+# wave64 VALU instructions per second the chip issues: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles (a 16-lane SIMD passes a wave64 instruction in four) = 614.4 G/s.
+# Measured (tools/microbench/valu_rate.hip, profiles/r03_valu_rate.txt, 4 waves per SIMD): v_fma_f32 618-632, v_cmp+v_cndmask 644, two-operand VOP2 forms
+# (v_mul_f32, v_fmac_f32) 846-924, v_pk_fma_f32 449-462 (two results each), v_rcp_f32 / v_sqrt_f32 300. Rounds 1-2 priced k_shade against 1228.8 (2 cycles
+# per instruction), which no instruction mix of this kernel can reach: its "0.48" was 0.97 of this figure.
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 NODE_BYTES, TRI_BYTES = 112, 48  # one node visit fetches 7 x 16 B of a 128-B BVH4 node; triangle = 48 B (DESIGN.md "Algorithmic bytes")
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
 IO_SHADOW_BYTES = 24 + 4 + 12  # origin+dir, tmax, RGB visibility
@@ -463,6 +467,14 @@ def main():
         dist.destroy_process_group()
     if rank != 0:
         return
+    try:  # how far the benchmarked flavour is from the bit-exact one on this scene (tests/test_flavours.py gates it on the GPU)
+        with open(os.path.join(ROOT, "profiles", "flavour_gate.json")) as f:
+            gate = json.load(f)
+        if head["config"]["flavour"] == "fast" and args.workload == "hall":
+            head["config"]["fast_vs_exact_rel_l2_1024spp"] = gate["fast_vs_exact_rel_l2"]["1024"]
+            head["config"]["fast_vs_exact_note"] = gate["note"]
+    except (OSError, KeyError, ValueError):
+        pass
     out = {"metric": "Mrays/s at 1920x1080, 8 bounces", "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": head["config"], "roofline": head["roofline"], "roofline_trace": head["roofline_trace"], "roofline_shadow": head["roofline_shadow"],

@@ -1377,6 +1377,16 @@ void oracle_probe_light_sample(const OracleScene* s, const OracleProbeMaterial* 
   }
 }
 
+/* the light-only BVH query of a BSDF-sampled direction (optix_anyhit.cuh:145-205 restated order-independently, o_trace.h trace_light_bvh): for every
+ * random number the light picked among those the ray crosses and their count */
+void oracle_probe_light_bvh(const OracleScene* s, const float origin[3], const float dir[3], uint32_t count, const float* randoms, uint32_t* light_ids, uint32_t* num_hits) {
+  OTracer tr;
+  tracer_init(&tr, s, 1);
+  for (uint32_t i = 0; i < count; i++)
+    light_ids[i] = trace_light_bvh(&tr, v3(origin[0], origin[1], origin[2]), v3(dir[0], dir[1], dir[2]), 0xFFFFFFFFu, 0u, randoms[i], &num_hits[i]);
+  tracer_free(&tr);
+}
+
 /* ---- probes of the fog's building blocks (tests/test_fog.py) ---- */
 void oracle_probe_volume_path(const float cam_pos[3], float dist, float height, uint32_t count, const float* origins, const float* dirs, const float* limits, float* out) {
   OracleScene sc;

@@ -100,22 +100,61 @@ def test_fast_flavour_is_the_same_estimator_on_the_material_zoo():
 
 
 @pytest.mark.gpu
-def test_fast_flavour_on_the_north_star_scene():
-    """1 M-triangle hall at 1920x1080, 8 bounces, 8 spp: image sum within 1e-3 of exact and ray counters within 0.1 %, per-pixel relative
-    L2 within the Monte-Carlo-free arithmetic noise expected at 8 spp (< 2e-2)."""
+def test_fast_flavour_on_the_north_star_scene_at_1024_spp():
+    """The benchmarked flavour on the scene the north-star target is quoted on, at the target's own sample count: 1 M-triangle hall, 1920x1080,
+    8 bounces, 256 and 1024 spp, identical sample ids.
+
+    Measured (profiles/r03_flavour_hall.txt, gpurun_out/r03j/flavour_diag_hall.txt): relative L2 against the exact flavour 4.77e-3 at 64 spp,
+    2.38e-3 at 256, 1.22e-3 at 1024 - halving with every fourfold sample count - with an image-sum difference of -1.8e-6. That is Monte-Carlo
+    noise of paths that have decorrelated, not an arithmetic error: a last-bit difference that crosses one of the path state's truncating
+    quantisers (21-bit throughput records, 16-bit ray packing, 8/10-bit material parameters per vertex) replaces the rest of the path, and it does
+    so whichever part of the fast arithmetic is left in - contraction alone, hardware reciprocals alone, v_rsq alone or the fast transcendentals
+    alone each give the same 2.1-2.4e-3 at 256 spp as all of them together. No implementation that is not bit-identical to the one it is compared
+    with gets below this on this scene - the reference's own --use_fast_math build included - so the gate is: (a) rel-L2 < 1.5e-3 at 1024 spp
+    (the north star's 1e-3 is met from about 1500 spp on, and at any spp by the exact flavour, which equals the CPU oracle bit for bit);
+    (b) no drift: image sums within 1e-4; (c) the 1 / sqrt(spp) law between 256 and 1024 spp (a bias would flatten it); (d) ray counters within 0.1 %."""
     host = scenes.hall_scene(1920, 1080, 8)
     view = oracle_lib.with_luts(host.device_scene())
     core = Core(0)
     try:
         core.upload(view)
-        exact, cnt_exact = _render(core, view, "exact", 8, 8)
-        fast, cnt_fast = _render(core, view, "fast", 8, 8)
+        out = {}
+        for spp in (256, 1024):
+            exact, cnt_exact = _render(core, view, "exact", spp, 32)
+            fast, cnt_fast = _render(core, view, "fast", spp, 32)
+            assert np.isfinite(fast).all()
+            _counters_close(cnt_fast, cnt_exact)
+            bias = float(fast.astype(np.float64).sum() / exact.astype(np.float64).sum()) - 1.0
+            assert abs(bias) < 1e-4, "image-sum drift of the fast flavour at %d spp: %g" % (spp, bias)
+            out[spp] = _rel_l2(fast, exact)
     finally:
         core.close()
-    assert np.isfinite(fast).all()
-    assert abs(float(fast.astype(np.float64).sum() / exact.astype(np.float64).sum()) - 1.0) < 1e-3
-    _counters_close(cnt_fast, cnt_exact)
-    assert _rel_l2(fast, exact) < 2e-2
+    assert out[1024] < 1.5e-3, "relative L2 of the fast flavour against exact at 1024 spp on the hall: %g" % out[1024]
+    assert 1.7 < out[256] / out[1024] < 2.3, "the difference must fall like 1 / sqrt(spp): %g at 256 spp, %g at 1024" % (out[256], out[1024])
+
+
+@pytest.mark.gpu
+def test_fast_flavour_against_the_oracle_on_the_north_star_scene():
+    """The same flavour against the CPU oracle itself (not against the exact flavour, which equals it): 2123 strided pixels of the hall at 64 spp.
+    Expected from the figure above: 1.22e-3 x sqrt(1024 / 64) = 4.9e-3 on the full frame; a strided subset of 0.1 % of the pixels scatters
+    around that, bound 8e-3; sums within 2e-3 (the subset's own noise)."""
+    host = scenes.hall_scene(1920, 1080, 8)
+    view = oracle_lib.with_luts(host.device_scene())
+    pixels = np.arange(0, 1920 * 1080, 977, dtype=np.uint32)
+    ofm, _, _ = oracle_lib.render(view, 0, 64, pixels=pixels)
+    core = Core(0)
+    try:
+        core.upload(view)
+        core.set_flavour("fast")
+        core.set_pixels(pixels)
+        core.render(0, 64, samples_per_pass=64)
+        fm, _ = core.accumulators()
+    finally:
+        core.close()
+    assert np.isfinite(fm).all()
+    err = _rel_l2(fm, ofm)
+    assert err < 8e-3, "fast flavour vs oracle on %d pixels at 64 spp: %g" % (pixels.size, err)
+    assert abs(float(fm.astype(np.float64).sum() / ofm.astype(np.float64).sum()) - 1.0) < 2e-3
 
 
 @pytest.mark.gpu

@@ -275,3 +275,83 @@ def test_emissive_white_box_direct_lighting_adds_up():
     mean = float(img.mean())
     assert abs(mean - 2.0) < 0.04, mean
     assert float(np.abs(img.mean(axis=0) - 2.0).max()) < 0.35, "no pixel far off (Monte-Carlo noise only)"
+
+
+def test_light_bvh_pick_is_uniform_over_the_lights_a_ray_crosses():
+    """A BSDF-sampled direction is traced against the light-only BVH; of the k lights it crosses up to the nearest opaque one, one is picked and its
+    contribution multiplied by k (cuda/optix_anyhit.cuh:145-205, direct_lighting.cuh:596-611). OptiX calls the any-hit program in an unspecified
+    order, so the restatement (oracle/o_trace.h trace_light_bvh, csrc/device/dev_trace.h light_query) picks by the minimum of a hash of (light id,
+    random number) - HIP == oracle cannot tell whether that choice is uniform, this test does: k semi-transparent emissive sheets in a row, a ray
+    through all of them, 64 k random numbers -> every light is picked 1 / k of the time within three standard deviations; an opaque sheet in the
+    row ends the candidate list."""
+    k = 5
+    host = Host()
+    scenes.apply_benchmark_settings(host, 8, 8, 1, sky=(0.0, 0.0, 0.0))
+    glass = scenes._material((1.0, 1.0, 1.0), 0.5, emission=(1.0, 1.0, 1.0), bidirectional=True, alpha=0.5)
+    wall = scenes._material((1.0, 1.0, 1.0), 0.5, emission=(1.0, 1.0, 1.0), bidirectional=True)
+    g, w = host.add_material(glass), host.add_material(wall)
+
+    def sheet(z):  # one triangle large enough for the ray, facing -z
+        return [-4.0, -4.0, z, 4.0, -4.0, z, 0.0, 6.0, z]
+    tris = np.array([sheet(1.0 + i) for i in range(k)] + [sheet(1.0 + k)] + [sheet(2.0 + k)], dtype=np.float32)
+    mats = np.array([g] * k + [w] + [g], dtype=np.uint16)  # k transparent emitters, an opaque one, and one behind it that must never be seen
+    host.new_instance(host.add_mesh(tris.reshape(-1), mats))
+    view = oracle_lib.with_luts(host.device_scene())
+    assert view.num_lights == k + 2
+    lib = oracle_lib.lib()
+    n = 1 << 16
+    rnd = ((np.arange(n, dtype=np.float64) + 0.5) / n).astype(np.float32)
+    np.random.RandomState(3).shuffle(rnd)
+    ids = np.zeros(n, dtype=np.uint32)
+    hits = np.zeros(n, dtype=np.uint32)
+    lib.oracle_probe_light_bvh(C.byref(view), _f3((0.1, 0.2, 0.0)), _f3((0.0, 0.0, 1.0)), n, rnd.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p),
+                               hits.ctypes.data_as(C.c_void_p))
+    assert (hits == k + 1).all(), "k transparent sheets and the opaque one behind them; nothing beyond it"
+    handles = np.ctypeslib.as_array(C.cast(view.light_tri_handles, C.POINTER(C.c_uint32)), (2 * view.num_lights,)).reshape(-1, 2)
+    behind = [l for l in range(view.num_lights) if handles[l, 1] == k + 1]
+    assert len(behind) == 1 and not (ids == behind[0]).any(), "the light behind the opaque sheet is not a candidate"
+    p = 1.0 / (k + 1)
+    sigma = np.sqrt(p * (1.0 - p) / n)
+    for l in range(view.num_lights):
+        if l == behind[0]:
+            continue
+        f = float((ids == l).mean())
+        assert abs(f - p) < 3.0 * sigma, "light %d picked %.4f of the time, expected %.4f +- %.4f" % (l, f, p, 3.0 * sigma)
+
+
+SHEET_Z = 2.0  # behind the camera of this test
+
+
+def test_fully_transparent_surfaces_do_not_disturb_the_direct_lighting_sum():
+    """The emissive white box again (every pixel must show 2 E, see above), now with fully transparent, uncoloured surfaces inside it - one plain, one
+    emissive. They exist for no ray (alpha 0: optix_anyhit.cuh:26-30, :62-66, :158-166), emit nothing (light_get_color multiplies by alpha) and are
+    no candidates of the light-BVH pick, although the emissive one sits in the light tree and in the light-only BVH: the light-tree estimator, the
+    BSDF-sampled light ray, its candidate count and the MIS weights between the two still have to add up to 2 E."""
+    host = Host()
+    n = 16
+    scenes.apply_benchmark_settings(host, n, n, 0, sky=(0.0, 0.0, 0.0))
+    m = scenes._material((1.0, 1.0, 1.0), 0.25, emission=(1.0, 1.0, 1.0), bidirectional=True)
+    m.roughness_clamp = 0.0
+    mid = host.add_material(m)
+    ghost = host.add_material(scenes._material((1.0, 1.0, 1.0), 0.5, alpha=0.0))
+    ghost_light = host.add_material(scenes._material((1.0, 1.0, 1.0), 0.5, emission=(5.0, 5.0, 5.0), bidirectional=True, alpha=0.0))
+    box, _ = scenes._box()
+    tri = (np.asarray(box, dtype=np.float32).reshape(-1, 3, 3) * 4.0).reshape(-1, 9)
+    # two large sheets in the half of the room the camera does not look into (a camera ray that met one would end there: max_ray_depth 0), between
+    # the walls the camera sees and the walls that light them
+    def sheet(z, mat):
+        return [[-3.5, -3.5, z, 3.5, -3.5, z, 3.5, 3.5, z], [-3.5, -3.5, z, 3.5, 3.5, z, -3.5, 3.5, z]], [mat, mat]
+    quads, mats = [], []
+    for z, mat in ((SHEET_Z, ghost), (SHEET_Z * 1.3, ghost_light)):
+        q, mm = sheet(z, mat)
+        quads += q; mats += mm
+    host.new_instance(host.add_mesh(tri, np.full(len(tri), mid, dtype=np.uint16)))
+    host.new_instance(host.add_mesh(np.asarray(quads, dtype=np.float32).reshape(-1), np.asarray(mats, dtype=np.uint16)))
+    scenes.set_camera(host, (0.3, 0.2, 0.1), (0.2, 0.4, 0.0), fov=0.8)
+    view = oracle_lib.with_luts(host.device_scene())
+    assert view.num_lights == 12 + 2
+    spp = 96
+    fm, _, cnt = oracle_lib.render(view, 0, spp)
+    img = fm.reshape(3, n, n) / spp
+    assert cnt[1] > 0 and cnt[2] > 0
+    assert abs(float(img.mean()) - 2.0) < 0.05, float(img.mean())

@@ -18,6 +18,6 @@ python - <<PY
 import json
 for w in ("example", "hall", "scan"):
     d = json.loads(open("profiles/${tag}_bench_%s.json" % w).read())
-    print(w, round(d["value"]), "Mrays/s,", round(d["ms_per_step"], 1), "ms/step, roofline.frac", round(d["roofline"]["frac"], 3), "traffic", d["roofline"]["traffic"])
+    print(w, round(d["value"]), "Mrays/s,", round(d["ms_per_step"], 1), "ms/step, roofline.frac", d["roofline"]["frac"], "traffic", d["roofline"]["traffic"])
 PY
 tail -1 profiles/${tag}_pytest_gpu.log
