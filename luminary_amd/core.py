@@ -336,6 +336,12 @@ class Core:
         """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
         self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1}[name]))
 
+    def comm_count(self):
+        """Ranks of the RCCL communicator this context belongs to (ncclCommCount; 1 without one)."""
+        fn = self._lib.lumc_comm_count
+        fn.restype = C.c_int
+        return int(fn(self._ctx))
+
     def lds_stack_bytes(self):
         """Bytes of a ray workgroup's LDS that hold traversal stack entries (build-time constant of the library)."""
         fn = self._lib.lumc_lds_stack_bytes

@@ -51,6 +51,7 @@ struct LuminaryHost {
   uint32_t main_slot = 0;
   uint32_t partition_n = 0;          // devices the current accumulation is tiled over (0 or 1: the main device renders every pixel)
   bool comm_ready = false;           // the slots of the current partition share an RCCL communicator
+  bool handoff_preview = false;      // the frame's first sample sits on the main device (undersampling preview): the tiles take it over when they are dealt
   std::vector<uint32_t> pixels;  // pixel set of the current accumulation
   bool pixels_all = true;
   uint32_t num_pixels = 0;
@@ -777,7 +778,7 @@ std::vector<PreviewState> preview_schedule(LuminaryHost* h) {
   std::vector<PreviewState> out;
   const LuminaryRendererSettings& st = h->scene.settings;
   if (!h->outputs.properties().enabled || !(st.region_width >= 1.0f && st.region_height >= 1.0f)) return out;
-  if (enabled_slots(h).size() > 1) return out;  // a tiled render has no coarse first sample: every device starts on its tiles at once
+  // (with several devices the main device renders the coarse-to-fine first sample alone; the tiles then take its sums over: lumc_accumulators_from_frame)
   for (uint32_t stage = st.undersampling & 31u; stage > 0; stage--)
     for (uint32_t it = (stage == (st.undersampling & 31u)) ? 4u : 3u; it-- > 0;) { PreviewState ps; ps.stage = stage; ps.iteration = it; out.push_back(ps); }
   return out;
@@ -886,6 +887,10 @@ LuminaryResult render_samples_locked(LuminaryHost* host, const uint32_t* pixels,
   if (host->adaptive_active) same = false;  // leaving adaptive mode restarts the accumulation
   if (!same) {
     const LumDeviceSceneView& v = host->device_scene.view;
+    // the first sample of this frame was rendered on the main device as the preview: its sums go to whoever owns the pixels from now on
+    const bool handoff = host->handoff_preview && all && first_sample == 1 && host->accumulated_samples == 1 && host->pixels_all && host->num_pixels == v.width * v.height;
+    host->handoff_preview = false;
+    if (handoff && lumc_frame_assemble(host->core, v.width * v.height, 0, nullptr, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
     if (want_n > 1) {
       std::vector<uint32_t> tiles;
       for (uint32_t k = 0; k < want_n; k++) {
@@ -910,7 +915,12 @@ LuminaryResult render_samples_locked(LuminaryHost* host, const uint32_t* pixels,
     if (!all) host->pixels.assign(pixels, pixels + num_pixels);
     host->num_pixels = all ? v.width * v.height : num_pixels;
     host->accumulated_samples = 0;
-    host->render_seconds = 0.0;
+    if (handoff) {
+      for (uint32_t k = 0; k < want_n; k++)
+        if (lumc_accumulators_from_frame(cores[k], host->core)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(cores[k])); return LUMINARY_ERROR_CUDA; }
+      host->accumulated_samples = 1;
+    }
+    else host->render_seconds = 0.0;
   }
   // stop at every sample count a pending request is keyed to (device_output.c:160-168), produce the outputs due there, go on
   uint32_t done = 0;
@@ -983,49 +993,96 @@ LuminaryResult render_locked(LuminaryHost* host, uint32_t num_samples, uint32_t 
         bool ran = false;
         const LuminaryResult rp = render_first_sample_as_preview(host, &ran);
         if (rp) return rp;
-        if (ran) { first = 1; num_samples--; }
+        if (ran) { first = 1; num_samples--; host->handoff_preview = enabled_slots(host).size() > 1; }
       }
     }
+    if (num_samples == 0 && !host->handoff_preview) return LUMINARY_SUCCESS;
     return render_samples_locked(host, nullptr, 0, first, num_samples, samples_per_pass);
   }
-  LuminaryResult r = ensure_core(host);
+  // Adaptive sampling over the enabled devices: the reference's main device computes the rates for all devices (device_adaptive_sampler.c:60-74,
+  // :205-213; device_manager.c:452-469). Here every device owns the 4x4 blocks of its 32x32 tiles (lumc_adaptive_set_partition), renders their
+  // tasks and, when a stage is due, contributes their variances to ONE all-reduce of 4 bytes per block (lumc_adaptive_exchange_all), after which every
+  // device derives the same rates: rates, variances and frame equal the single-device run bit for bit.
+  std::vector<LumContext*> cores;
+  LuminaryResult r = ensure_partition_cores(host, &cores);
   if (r) return r;
-  if (!host->adaptive_active) {
+  const uint32_t n = (uint32_t) cores.size();
+  auto fail = [&](LumContext* c) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(c)); return LUMINARY_ERROR_CUDA; };
+  if (!host->adaptive_active || host->partition_n != n) {
+    const LumDeviceSceneView& v = host->device_scene.view;
     lumc_use_assembled_frame(host->core, 0);
-    if (lumc_set_pixels(host->core, nullptr, 0)) return LUMINARY_ERROR_CUDA;
-    host->partition_n = 1;  // adaptive sampling runs on the main device
-    host->pixels_all = true;
-    host->num_pixels = host->device_scene.view.width * host->device_scene.view.height;
-    host->accumulated_samples = 0;
-    host->render_seconds = 0.0;
     LumAdaptiveParams ap;
     std::memset(&ap, 0, sizeof(ap));
     ap.max_sampling_rate = settings.adaptive_sampling_max_sampling_rate;
     ap.avg_sampling_rate = settings.adaptive_sampling_avg_sampling_rate;
     ap.update_interval = settings.adaptive_sampling_update_interval;
-    ap.tone = output_params(host, host->device_scene.view.width, host->device_scene.view.height);
+    ap.tone = output_params(host, v.width, v.height);
     ap.exposure = settings.adaptive_sampling_exposure_aware ? ap.tone.exposure : 0.0f;
-    if (lumc_adaptive_begin(host->core, &ap)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+    const uint32_t blocks_x = (v.width + 3) / 4, blocks_y = (v.height + 3) / 4, tiles_x = (v.width + 31) / 32;
+    std::vector<uint8_t> mask((size_t) blocks_x * blocks_y);
+    for (uint32_t k = 0; k < n; k++) {
+      if (lumc_set_pixels(cores[k], nullptr, 0) || lumc_adaptive_begin(cores[k], &ap)) return fail(cores[k]);
+      if (n > 1) {  // the blocks of tile t belong to device t % n, like the pixels of a uniform tiled render (lumc_tile_pixels)
+        for (uint32_t by = 0; by < blocks_y; by++)
+          for (uint32_t bx = 0; bx < blocks_x; bx++) mask[(size_t) by * blocks_x + bx] = (((by / 8) * tiles_x + bx / 8) % n == k) ? 1 : 0;
+        if (lumc_adaptive_set_partition(cores[k], mask.data())) return fail(cores[k]);
+      }
+    }
+    if (n > 1 && !host->comm_ready) {
+      if (lumc_comm_init_all(cores.data(), (int) n) == 0) host->comm_ready = true;
+      else std::fprintf(stderr, "[luminary_amd] no RCCL communicator (%s): block variances and frames go through the host / peer copies\n", lumc_last_error(cores[0]));
+    }
+    host->partition_n = n;
+    host->pixels_all = true;
+    host->num_pixels = v.width * v.height;
+    host->accumulated_samples = 0;
+    host->render_seconds = 0.0;
+    host->handoff_preview = false;
     host->adaptive_active = true;
   }
   uint32_t done = 0;
   if (host->accumulated_samples == 0 && num_samples > 0) {  // execution 0 of stage 0 as the undersampling preview, when one is due
     bool ran = false;
+    const uint32_t partition = host->partition_n;
+    host->partition_n = 1;  // the preview's images come from the main device's own accumulators
     r = render_first_sample_as_preview(host, &ran);
+    host->partition_n = partition;
     if (r) return r;
     if (ran) {
-      if (lumc_adaptive_note_first_sample(host->core, nullptr)) { std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core)); return LUMINARY_ERROR_CUDA; }
+      if (n > 1) {  // every device takes over the first sample of the blocks it owns
+        if (lumc_frame_assemble(host->core, host->num_pixels, 0, nullptr, nullptr)) return fail(host->core);
+        for (uint32_t k = 0; k < n; k++) if (lumc_accumulators_from_frame(cores[k], host->core)) return fail(cores[k]);
+      }
+      for (uint32_t k = 0; k < n; k++) if (lumc_adaptive_note_first_sample(cores[k], nullptr)) return fail(cores[k]);
       done = 1;
     }
   }
+  auto executions_done = [&](LumContext* c, uint32_t* pending) {
+    LumAdaptiveInfo info;
+    std::memset(&info, 0, sizeof(info));
+    lumc_adaptive_info(c, &info);
+    uint32_t total = 0;
+    for (uint32_t e : info.executions) total += e;
+    if (pending) *pending = info.build_pending;
+    return total;
+  };
+  // a stage may be due right away (the preview was its last execution)
+  { uint32_t pending = 0; executions_done(cores[0], &pending); if (n > 1 && pending && lumc_adaptive_exchange_all(cores.data(), (int) n)) return fail(cores[0]); }
   while (done < num_samples) {
     uint32_t chunk = num_samples - done;
     for (const LuminaryOutputRequestProperties& req : host->outputs.pending_requests())
       if (req.sample_count > host->accumulated_samples && req.sample_count - host->accumulated_samples < chunk) chunk = req.sample_count - host->accumulated_samples;
     const auto t0 = std::chrono::steady_clock::now();
-    if (lumc_adaptive_render(host->core, chunk, nullptr) || lumc_synchronize(host->core)) {
-      std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(host->core));
-      return LUMINARY_ERROR_CUDA;
+    uint32_t left = chunk;
+    while (left > 0) {  // a partitioned context stops where a stage is due: exchange, go on
+      const uint32_t before = executions_done(cores[0], nullptr);
+      for (uint32_t k = 0; k < n; k++) if (lumc_adaptive_render(cores[k], left, nullptr)) return fail(cores[k]);
+      for (uint32_t k = 0; k < n; k++) if (lumc_synchronize(cores[k])) return fail(cores[k]);
+      uint32_t pending = 0;
+      const uint32_t ran_now = executions_done(cores[0], &pending) - before;
+      if (pending && lumc_adaptive_exchange_all(cores.data(), (int) n)) return fail(cores[0]);
+      if (ran_now == 0 && !pending) { std::fprintf(stderr, "[luminary_amd] adaptive rendering made no progress\n"); return LUMINARY_ERROR_API_EXCEPTION; }
+      left -= std::min(left, ran_now);
     }
     { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); host->render_seconds += dt; host->last_sample_ms = 1e3 * dt / (chunk ? chunk : 1u); }
     host->accumulated_samples += chunk;
@@ -1065,6 +1122,7 @@ LuminaryResult luminary_ext_get_radiance(LuminaryHost* host, float* rgb, uint32_
   const LumDeviceSceneView& v = host->device_scene.view;
   if (width != v.width || height != v.height) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
   if (host->adaptive_active) {  // every pixel has its own sample count: the beauty result image is the radiance
+    if (host->partition_n > 1) { const LuminaryResult ra = assemble_partition(host); if (ra) return ra; }
     std::vector<float> planes(3 * (size_t) host->num_pixels);
     if (lumc_generate_result_host(host->core, 0, 0, 0, 1.0f, nullptr, planes.data())) return LUMINARY_ERROR_CUDA;
     for (size_t p = 0; p < host->num_pixels; p++)

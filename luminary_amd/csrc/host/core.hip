@@ -2348,6 +2348,98 @@ int lumc_frame_assemble_all(LumContext** ctxs, int n, uint32_t frame_pixels, int
   return 0;
 }
 
+// ---- one process, several GPUs: what the tiled render loop of the host API needs beyond the frame assembly ----
+namespace {
+// this context's accumulators <- the frame's values at its pixels; with an adaptive partition only inside the blocks it owns
+__global__ __launch_bounds__(256) void k_accumulators_from_frame(const float* __restrict__ frame, uint32_t frame_pixels, const uint32_t* __restrict__ pixels, uint32_t n,
+                                                                 const uint8_t* __restrict__ block_mask, uint32_t width, uint32_t blocks_x, float* __restrict__ fm, float* __restrict__ sm) {
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < n; p += gridDim.x * 256u) {
+    const uint32_t index = pixels ? pixels[p] : p;
+    bool mine = index < frame_pixels;
+    if (mine && block_mask) { const uint32_t y = index / width, x = index - y * width; mine = block_mask[(y >> 2) * blocks_x + (x >> 2)] != 0; }
+    fm[p] = mine ? frame[index] : 0.0f; fm[n + p] = mine ? frame[frame_pixels + index] : 0.0f; fm[2u * n + p] = mine ? frame[2u * frame_pixels + index] : 0.0f;
+    sm[p] = mine ? frame[3u * frame_pixels + index] : 0.0f;
+  }
+}
+}  // namespace
+
+// The accumulators of `dst` (whatever its pixel set: a tile list, or the full frame with an adaptive partition) take the values the frame buffer of
+// `src` holds at dst's pixels (lumc_frame_assemble on src first: its own full-frame accumulators, scattered). This is how the first sample of a
+// frame, rendered coarse to fine on the main device alone (the undersampling preview, device.c:392-420), is handed to the devices that go on with
+// the frame's tiles: every pixel's sums continue where the preview left them, so the tiled frame equals the single-device frame bit for bit.
+int lumc_accumulators_from_frame(LumContext* dst, LumContext* src) {
+  if (!dst || !src || !src->d_frame || !dst->d_first_moment || dst->num_pixels == 0) { if (dst) dst->error = "lumc_accumulators_from_frame: no frame on the source or no accumulators on the destination"; return 1; }
+  const uint32_t frame_pixels = src->frame_capacity;
+  const float* frame = src->d_frame;
+  float* staging = nullptr;
+  HIP_TRY(dst, hipSetDevice(src->device));
+  HIP_TRY(dst, hipDeviceSynchronize());
+  HIP_TRY(dst, hipSetDevice(dst->device));
+  if (dst != src) {  // another context (another GPU, or the same one in test set-ups): a copy of the frame on dst's device
+    const size_t bytes = sizeof(float) * 4 * (size_t) frame_pixels;
+    HIP_TRY(dst, hipMalloc((void**) &staging, bytes));
+    HIP_TRY(dst, hipMemcpyPeer(staging, dst->device, src->d_frame, src->device, bytes));
+    frame = staging;
+  }
+  const LumContext::Adaptive& a = dst->adaptive;
+  hipLaunchKernelGGL(k_accumulators_from_frame, dim3(grid_for(dst->num_pixels)), dim3(256), 0, 0, frame, frame_pixels, (const uint32_t*) dst->d_pixels, dst->num_pixels,
+                     a.active ? (const uint8_t*) a.d_block_mask : nullptr, dst->scene.width, a.active ? a.blocks_x : 0u, dst->d_first_moment, dst->d_second_moment);
+  HIP_TRY(dst, hipGetLastError());
+  HIP_TRY(dst, hipDeviceSynchronize());
+  if (staging) (void) hipFree(staging);
+  return 0;
+}
+
+// A stage build of adaptive rendering tiled over the contexts of one process (lumc_adaptive_set_partition on each): every context computes the
+// variances of its blocks, ONE all-reduce of 4 bytes per block makes the array complete everywhere (every block has one owner: the sum is a gather and
+// exact), every context derives the same rates. Grouped ncclAllReduce when the contexts share a communicator (lumc_comm_init_all); otherwise - two
+// contexts on one device in tests, or no RCCL - the arrays are summed on the host in context order.
+int lumc_adaptive_exchange_all(LumContext** ctxs, int n) {
+  if (!ctxs || n < 1) return 1;
+  bool rccl = n > 1;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i] || !ctxs[i]->adaptive.active) { if (ctxs[0]) ctxs[0]->error = "lumc_adaptive_exchange_all: adaptive mode is not active on every context"; return 1; }
+    if (ctxs[i]->adaptive.num_blocks != ctxs[0]->adaptive.num_blocks) { ctxs[0]->error = "lumc_adaptive_exchange_all: contexts of different frames"; return 1; }
+    HIP_TRY(ctxs[0], hipSetDevice(ctxs[i]->device));
+    if (adaptive_compute_variance(ctxs[i], (hipStream_t) 0)) { ctxs[0]->error = ctxs[i]->error; return 1; }
+    rccl = rccl && ctxs[i]->comm && ctxs[i]->comm_world == n && ctxs[i]->comm_rank == i;
+  }
+  const uint32_t nb = ctxs[0]->adaptive.num_blocks;
+  if (rccl) {
+    NCCL_TRY(ctxs[0], ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+      (void) hipSetDevice(ctxs[i]->device);
+      const ncclResult_t e = ncclAllReduce(ctxs[i]->adaptive.d_block_variance, ctxs[i]->adaptive.d_block_variance, nb, ncclFloat, ncclSum, ctxs[i]->comm, (hipStream_t) 0);
+      if (e != ncclSuccess) { (void) ncclGroupEnd(); ctxs[0]->error = std::string("ncclAllReduce failed: ") + ncclGetErrorString(e); return 1; }
+    }
+    NCCL_TRY(ctxs[0], ncclGroupEnd());
+  }
+  else if (n > 1) {
+    std::vector<float> sum(nb, 0.0f), part(nb);
+    for (int i = 0; i < n; i++) {
+      HIP_TRY(ctxs[0], hipSetDevice(ctxs[i]->device));
+      HIP_TRY(ctxs[0], hipMemcpy(part.data(), ctxs[i]->adaptive.d_block_variance, sizeof(float) * nb, hipMemcpyDeviceToHost));
+      for (uint32_t b = 0; b < nb; b++) sum[b] += part[b];
+    }
+    for (int i = 0; i < n; i++) {
+      HIP_TRY(ctxs[0], hipSetDevice(ctxs[i]->device));
+      HIP_TRY(ctxs[0], hipMemcpy(ctxs[i]->adaptive.d_block_variance, sum.data(), sizeof(float) * nb, hipMemcpyHostToDevice));
+    }
+  }
+  for (int i = 0; i < n; i++) {
+    HIP_TRY(ctxs[0], hipSetDevice(ctxs[i]->device));
+    if (ctxs[i]->adaptive.stage_id >= kAdaptiveStages) { ctxs[0]->error = "lumc_adaptive_exchange_all: the last stage is already running"; return 1; }
+    if (adaptive_finish_build(ctxs[i], (hipStream_t) 0)) { ctxs[0]->error = ctxs[i]->error; return 1; }
+  }
+  return 0;
+}
+// Ranks of the communicator this context belongs to (1 without one): what a launcher prints to show that RCCL saw every GPU.
+int lumc_comm_count(const LumContext* ctx) {
+  if (!ctx || !ctx->comm) return 1;
+  int count = 1;
+  return ncclCommCount(ctx->comm, &count) == ncclSuccess ? count : 1;
+}
+
 // The assembled frame of this context (valid on the root after lumc_frame_assemble*): planar first moment [3][frame_pixels] and second moment.
 int lumc_frame_download(LumContext* ctx, uint32_t frame_pixels, float* first_moment, float* second_moment) {
   if (!ctx || !ctx->d_frame || frame_pixels > ctx->frame_capacity) { if (ctx) ctx->error = "lumc_frame_download: no assembled frame"; return 1; }

@@ -96,3 +96,38 @@ def test_four_rank_adaptive_rendering_uneven(tmp_path):
     result = os.path.join(str(tmp_path), "result_adaptive4.txt")
     mp.spawn(_adaptive_worker, args=(4, port, str(tmp_path), result, 42, 27, 8), nprocs=4, join=True)
     assert open(result).read() == "ok"
+
+
+def _frame_worker(rank, world, port, result_file, width, height):
+    """The partition and the one exchange step of BASELINE config 4 (4K frame over 8 ranks) without the rendering in between: every rank fills
+    the accumulators of its own pixels with a function of the pixel index; the assembled frame must hold that function everywhere."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from luminary_amd.distributed import assemble_frame, tile_pixels
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    px = tile_pixels(width, height, rank, world)  # 32 x 32 tiles, round robin
+    value = lambda p, c: ((p.astype(np.int64) * 2654435761 + c * 40503) % 1000003).astype(np.float32)
+    fm = np.stack([value(px, c) for c in range(3)]).reshape(-1)
+    sm = value(px, 3)
+    counts = torch.tensor([px.size], dtype=torch.int64)
+    dist.all_reduce(counts)
+    full = assemble_frame(torch.from_numpy(fm), torch.from_numpy(sm), px, width * height, dist, 0)
+    if rank == 0:
+        p = np.arange(width * height, dtype=np.int64)
+        ok = int(counts[0]) == width * height and all(np.array_equal(full[c].numpy(), value(p, c)) for c in range(4))
+        open(result_file, "w").write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_tile_deal_and_reduce_of_the_4k_frame(tmp_path):
+    """BASELINE config 4's frame, 3840 x 2160 over 8 ranks: 120 x 67.5 tiles of 32 pixels (a ragged bottom row of 16-pixel-high tiles), 8 100 tiles
+    dealt round robin, every pixel owned once, one reduce of 4 x 8.3 M floats per rank assembles the frame on rank 0."""
+    import torch.multiprocessing as mp
+    port = 37500 + (os.getpid() % 2000)
+    result = os.path.join(str(tmp_path), "result_4k.txt")
+    mp.spawn(_frame_worker, args=(8, port, result, 3840, 2160), nprocs=8, join=True)
+    assert open(result).read() == "ok"

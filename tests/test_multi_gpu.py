@@ -154,3 +154,59 @@ def test_bench_does_not_price_kernels_with_counters_of_another_build(monkeypatch
     monkeypatch.setattr(bench, "source_hash", lambda: "another tree")
     assert bench.pmc_record("hall", 32, "fast", then)["_stale"] is True
     assert bench.pmc_record("hall", 32, "exact", then) is None or bench.pmc_record("hall", 32, "exact", then).get("flavour") == "exact"
+
+
+def _adaptive_rates(host):
+    """stage counts and block variances of the host's main context (lumc_adaptive_download on Host.core_context())"""
+    import ctypes as C
+    lib = luminary_amd._lib()
+    blocks = ((host.get_settings().width + 3) // 4) * ((host.get_settings().height + 3) // 4)
+    counts = np.zeros(blocks, dtype=np.uint32)
+    var = np.zeros(blocks, dtype=np.float32)
+    assert lib.lumc_adaptive_download(C.c_void_p(host.core_context()), counts.ctypes.data_as(C.c_void_p), var.ctypes.data_as(C.c_void_p)) == 0
+    return counts, var
+
+
+def _configure(host, w, h, adaptive, undersampling):
+    s = host.get_settings()
+    s.undersampling, s.supersampling, s.enable_adaptive_sampling = undersampling, 0, adaptive
+    s.adaptive_sampling_max_sampling_rate, s.adaptive_sampling_avg_sampling_rate, s.adaptive_sampling_update_interval = 8, 2, 2
+    s.adaptive_sampling_exposure_aware = True
+    host.set_settings(s)
+    host.set_output_properties(w, h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive,undersampling", [(True, 0), (False, 2), (True, 2)])
+def test_host_tiles_adaptive_sampling_and_keeps_the_preview(tmp_path, monkeypatch, adaptive, undersampling):
+    """Default-settings frontends on several GPUs (the reference: device_adaptive_sampler.c:205-213, device_manager.c:452-469 - adaptive sampling is
+    its default mode): with three device slots the host tiles adaptive rendering too (every device owns the blocks of its tiles, one exchange of
+    block variances per stage) and renders the frame's first sample as the undersampling preview on the main device, whose sums the tiles then take
+    over. Accumulators, rates, block variances, the recurring ARGB8 output and the ray counters equal the single-device run bit for bit."""
+    w, h = 100, 70
+    frames = {}
+    for name, fake in (("one", None), ("three", "3")):
+        if fake:
+            monkeypatch.setenv("LUM_FAKE_DEVICES", fake)
+            monkeypatch.setenv("LUM_MAX_DEVICES", "8")
+        host = scenes.cornell_host(str(tmp_path / name), w, h, 3)
+        assert host.get_device_count() == (3 if fake else 1)
+        _configure(host, w, h, adaptive, undersampling)
+        host.render(1)                      # the preview (if any) alone: its coarse images are what is on display
+        img_first, n_first, _ = host.get_image(host.acquire_output())
+        host.render(9)                      # through two stage builds at update interval 2 (2 + 4 executions)
+        fm, sm = host.accumulators()
+        img, n, _ = host.get_image(host.acquire_output())
+        rates = _adaptive_rates(host) if adaptive else None
+        frames[name] = (fm, sm, img, n, img_first, n_first, rates, host.ray_counters()[:4])
+        host.close()
+    a, b = frames["one"], frames["three"]
+    assert a[3] == b[3] == 10 and a[5] == b[5] == 1
+    assert np.array_equal(a[4], b[4]), "the image after the first allocation (preview)"
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "accumulators"
+    assert np.array_equal(a[2], b[2]), "ARGB8 output"
+    assert a[7] == b[7], "ray counters add up over the devices"
+    if adaptive:
+        assert np.array_equal(a[6][0], b[6][0]), "per-block rates"
+        assert np.array_equal(a[6][1], b[6][1]), "block variances of the last build"
+        assert len(np.unique(a[6][0])) > 1, "the rates differ over the frame (otherwise the test proves little)"
