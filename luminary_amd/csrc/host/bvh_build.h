@@ -24,6 +24,14 @@ struct Bvh4 {
 // splits; if that is still too deep the result is empty (nodes.empty()).
 Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri, uint32_t max_depth = 20);
 
+// The same tree with spatial splits (Stich, Friedrich, Dietrich: "Spatial Splits in Bounding Volume Hierarchies", HPG 2009): where the best object
+// split leaves the children's boxes overlapping, the set is also tried cut by a plane, triangles that straddle it referenced on both sides with their
+// boxes clipped to each side. `vertices` = 3 x float4 per triangle (the device scene's layout); `splittable[i] == 0` keeps triangle i in one leaf (a
+// visibility ray multiplies the transparency of every triangle reference it crosses, so only opaque triangles may be referenced twice - for those,
+// and for closest hits, a second reference changes nothing: same distance, same ids). prims then holds one entry per REFERENCE (prims.size() >= count).
+// Opt-in (LUM_BVH_SPATIAL=1): the benchmark meshes are evenly tessellated and gain nothing (tools/bvh_quality.cpp), long thin triangles do.
+Bvh4 build_bvh4_triangles(const float* vertices, const Aabb* boxes, const uint8_t* splittable, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri, uint32_t max_depth = 20);
+
 // Same contract, built on the current HIP device (lbvh.hip): Morton-ordered binary radix tree collapsed to 4-wide nodes. Much faster to
 // build, somewhat slower to trace. Returns an empty result when the tree is deeper than `max_depth` or a HIP call fails; the caller
 // then falls back to build_bvh4.

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../../include/lum_core.h"
@@ -140,6 +141,19 @@ namespace {
       return 1;                                                                                                     \
     }                                                                                                               \
   } while (0)
+
+// [0, n) in contiguous chunks over the host's cores (per-triangle loops of the scene upload: 10 M triangles are 100 ms each on one core)
+template <class F>
+void host_parallel_for(size_t n, F&& fn) {
+  const unsigned hc = std::thread::hardware_concurrency();
+  const unsigned threads = (unsigned) std::min<size_t>(std::min(std::max(hc, 1u), 32u), std::max<size_t>(n / 65536, 1));
+  if (threads <= 1) { fn((size_t) 0, n); return; }
+  const size_t chunk = (n + threads - 1) / threads;
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < threads; t++) pool.emplace_back([&, t] { const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk); if (b < e) fn(b, e); });
+  fn((size_t) 0, std::min(n, chunk));
+  for (auto& th : pool) th.join();
+}
 
 template <typename T>
 int upload(LumContext* ctx, const T* host, size_t count, const T** out, bool scene_owned = true) {
@@ -370,7 +384,7 @@ __global__ __launch_bounds__(256) void k_ray_sort_keys(const float4* __restrict_
                                                        SortGrid g, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
   const uint32_t n = min(*count, capacity);
   for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < capacity; i += gridDim.x * 256u) {
-    uint32_t key = 0x1FFFFFu;  // beyond the live items: sorts to the end
+    uint32_t key = 0x200000u;  // beyond the live items: above every live key (21 bits), so they sort to the end whether or not the sort is stable
     if (i < n) {
       const float4 o = origin[i], d = dir[i];
       const uint32_t cx = (uint32_t) fminf(fmaxf((o.x - g.lo[0]) * g.scale[0], 0.0f), 63.0f), cy = (uint32_t) fminf(fmaxf((o.y - g.lo[1]) * g.scale[1], 0.0f), 63.0f),
@@ -398,7 +412,7 @@ int ensure_sort(LumContext* ctx, uint32_t items) {
     HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sort_vals[k], sizeof(uint32_t) * (size_t) items));
   }
   hipcub::DoubleBuffer<uint32_t> keys(ctx->d_sort_keys[0], ctx->d_sort_keys[1]), vals(ctx->d_sort_vals[0], ctx->d_sort_vals[1]);
-  HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, ctx->sort_temp_bytes, keys, vals, (int) items, 0, 21, (hipStream_t) 0));
+  HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, ctx->sort_temp_bytes, keys, vals, (int) items, 0, 22, (hipStream_t) 0));
   HIP_TRY(ctx, hipMalloc(&ctx->d_sort_temp, std::max<size_t>(ctx->sort_temp_bytes, 16)));
   ctx->sort_capacity = items;
   return 0;
@@ -415,7 +429,7 @@ const uint32_t* sort_rays(LumContext* ctx, hipStream_t stream, const float4* ori
   hipLaunchKernelGGL(k_ray_sort_keys, dim3(blocks ? blocks : 1), dim3(256), 0, stream, origin, dir, count, capacity, g, ctx->d_sort_keys[0], ctx->d_sort_vals[0]);
   hipcub::DoubleBuffer<uint32_t> keys(ctx->d_sort_keys[0], ctx->d_sort_keys[1]), vals(ctx->d_sort_vals[0], ctx->d_sort_vals[1]);
   size_t bytes = ctx->sort_temp_bytes;
-  if (hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_temp, bytes, keys, vals, (int) capacity, 0, 21, stream) != hipSuccess) return nullptr;
+  if (hipcub::DeviceRadixSort::SortPairs(ctx->d_sort_temp, bytes, keys, vals, (int) capacity, 0, 22, stream) != hipSuccess) return nullptr;
   return vals.Current();
 }
 
@@ -829,11 +843,17 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
     tri_boxes[m].resize(nt);
     Aabb mb{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
-    for (uint32_t t = 0; t < nt; t++) {
-      const float* p = v->vertices + (size_t) (t0 + t) * 12;
-      tri_boxes[m][t] = tri_box(p, p + 4, p + 8);
-      for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], tri_boxes[m][t].lo[k]); mb.hi[k] = std::max(mb.hi[k], tri_boxes[m][t].hi[k]); }
-    }
+    std::mutex mb_mutex;
+    host_parallel_for(nt, [&](size_t b, size_t e) {
+      Aabb part{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+      for (size_t t = b; t < e; t++) {
+        const float* p = v->vertices + ((size_t) t0 + t) * 12;
+        tri_boxes[m][t] = tri_box(p, p + 4, p + 8);
+        for (int k = 0; k < 3; k++) { part.lo[k] = std::min(part.lo[k], tri_boxes[m][t].lo[k]); part.hi[k] = std::max(part.hi[k], tri_boxes[m][t].hi[k]); }
+      }
+      std::lock_guard<std::mutex> lock(mb_mutex);
+      for (int k = 0; k < 3; k++) { mb.lo[k] = std::min(mb.lo[k], part.lo[k]); mb.hi[k] = std::max(mb.hi[k], part.hi[k]); }
+    });
     mesh_box[m] = mb;
   }
   std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
@@ -895,14 +915,16 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
       }
       nodes.push_back(n);
     }
-    for (uint32_t i = 0; dirty_meshes && i < nt; i++) {
-      const uint32_t t = bvh.prims[i];
-      const float* p = v->vertices + (size_t) (t0 + t) * 12;
-      BvhTri& bt = blas_tris[(size_t) t0 + i];
-      for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
-      bt.id = t; bt.scene_index = t0 + t;
-      bt.albedo_tex = kBvhTriNoTexture;  // k_tri_opacity writes the word from the triangle's material (below; again after a material edit)
-    }
+    if (dirty_meshes) host_parallel_for(nt, [&](size_t b, size_t e) {
+      for (size_t i = b; i < e; i++) {
+        const uint32_t t = bvh.prims[i];
+        const float* p = v->vertices + (size_t) (t0 + t) * 12;
+        BvhTri& bt = blas_tris[(size_t) t0 + i];
+        for (int k = 0; k < 3; k++) { bt.p0[k] = p[k]; bt.e1[k] = p[4 + k] - p[k]; bt.e2[k] = p[8 + k] - p[k]; }
+        bt.id = t; bt.scene_index = t0 + t;
+        bt.albedo_tex = kBvhTriNoTexture;  // k_tri_opacity writes the word from the triangle's material (below; again after a material edit)
+      }
+    });
     if (dirty_meshes) { tri_boxes[m].clear(); tri_boxes[m].shrink_to_fit(); }
   }
   // ---- renumber: the top of the tree first, in breadth-first order across both levels (top-level leaves continue into the root of
@@ -1057,7 +1079,9 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / kNodeBytes, nodes.size());
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
-    const size_t dyn = (size_t) ctx->lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES;
+    // The attribute is a property of the kernel, not of a context: it is set to what the largest scene may ask for (the whole budget computed
+    // above), never to this scene's need - a second context with a small scene must not lower the cap a first one launches with.
+    const size_t dyn = lds_bytes + LUM_LDS_STACK_BYTES;
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_exact()->set_ray_kernel_lds(dyn));
     HIP_TRY(ctx, (hipError_t) wavefront_kernels_fast()->set_ray_kernel_lds(dyn));
   }
