@@ -826,7 +826,7 @@ struct ParticleQuery {
   }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
     LeafTris lt;
-    lt.load(sc.blas_tris, first, count);
+    lt.load<false>(sc.blas_tris, first, count);
 #pragma unroll
     for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
       if (j >= count) break;

@@ -31,11 +31,18 @@ PASSES = [
     ("tcc", ["TCC_HIT_sum", "TCC_MISS_sum", "TCC_REQ_sum", "TCP_TCC_READ_REQ_sum"]),
     ("ea", ["TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_DRAM_sum", "TCC_EA0_WRREQ_sum"]),
     ("sq", ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES", "SQ_INSTS_LDS"]),
-    ("ta", ["TA_BUSY_avr", "TA_BUSY_max", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum", "TA_FLAT_READ_WAVEFRONTS_sum", "GRBM_GUI_ACTIVE"]),
-    ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TCP_READ_TAGCONFLICT_STALL_CYCLES_sum",
-             "TCP_TCC_READ_REQ_LATENCY_sum", "TCP_GATE_EN1_sum", "TCP_TCC_READ_REQ_sum"]),
+    # the address unit and the L1: few hardware counters per block instance, so small groups (six TA counters in one pass: "Request exceeds the
+    # capabilities of the hardware to collect", and rocprofv3 then hangs in its signal handler - every pass runs under a time limit)
+    ("ta", ["TA_BUSY_avr", "GRBM_GUI_ACTIVE"]),
+    ("ta2", ["TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum"]),
+    ("ta3", ["TA_FLAT_READ_WAVEFRONTS_sum", "TA_BUSY_max"]),
+    ("tcp", ["TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_TCP_TA_DATA_STALL_CYCLES_sum", "TCP_PENDING_STALL_CYCLES_sum"]),
+    ("tcp2", ["TCP_TCC_READ_REQ_LATENCY_sum", "TCP_TCC_READ_REQ_sum", "TCP_GATE_EN1_sum"]),
     ("sq2", ["SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SALU", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY", "SQ_INSTS_SMEM"]),
 ]
+
+
+PASS_TIMEOUT_S = 420
 
 
 def kernel_key(name):
@@ -56,7 +63,14 @@ def run_pass(out_dir, tag, counters, cmd, key_fn):
     full = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--"] + cmd
     t = time.time()
     with open(os.path.join(out_dir, tag + ".log"), "w") as log:
-        rc = subprocess.call(full, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT)
+        proc = subprocess.Popen(full, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT, start_new_session=True)  # its own process group: the one thing killed on a time-out
+        try:
+            rc = proc.wait(timeout=PASS_TIMEOUT_S)
+        except subprocess.TimeoutExpired:
+            import signal
+            os.killpg(proc.pid, signal.SIGKILL)
+            proc.wait()
+            rc = -9
     print("pass %-28s rc %d  %.0f s" % (tag, rc, time.time() - t), flush=True)
     files = sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     tot, disp = defaultdict(lambda: defaultdict(float)), defaultdict(set)
