@@ -163,3 +163,54 @@ def test_camera_move_on_the_hall_is_a_matter_of_milliseconds():
     assert _build_seconds(host) == t_build
     assert moved - plain < 0.020, "camera move: %.1f ms over a plain sample's %.1f ms" % (1e3 * (moved - plain), 1e3 * plain)
     host.close()
+
+
+def _view_bytes(view):
+    """every array a device scene view points at, as bytes (sizes from the view's own counts), plus the scalar part of the struct"""
+    import ctypes as C
+    n_tris = int(np.ctypeslib.as_array(C.cast(view.mesh_tri_offset, C.POINTER(C.c_uint32)), (view.num_meshes + 1,))[-1]) if view.num_meshes else 0
+    def arr(ptr, ctype, count):
+        if not ptr or count == 0:
+            return b""
+        return bytes(np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), (count,)))
+    sections = 0
+    if view.light_tree_root:
+        sections = int(np.ctypeslib.as_array(C.cast(view.light_tree_root, C.POINTER(C.c_uint8)), (16,))[10])
+    out = {
+        "mesh_tri_offset": arr(view.mesh_tri_offset, C.c_uint32, view.num_meshes + 1), "vertices": arr(view.vertices, C.c_uint32, n_tris * 12),
+        "tri_tex": arr(view.tri_tex, C.c_uint32, n_tris * 4), "instance_mesh_ids": arr(view.instance_mesh_ids, C.c_uint32, view.num_instances),
+        "instance_transforms": arr(view.instance_transforms, C.c_uint32, view.num_instances * 8), "materials": arr(view.materials, C.c_uint16, view.num_materials * 16),
+        "light_tree_root": arr(view.light_tree_root, C.c_uint8, 16 + 48 * sections if view.light_tree_root else 0),
+        "light_tree_nodes": arr(view.light_tree_nodes, C.c_uint8, view.num_light_tree_nodes * 64), "light_tri_handles": arr(view.light_tri_handles, C.c_uint32, view.num_lights * 2),
+        "light_bvh_tris": arr(view.light_bvh_tris, C.c_uint32, view.num_lights * 12),
+    }
+    scalars = {}
+    for name, typ in view._fields_:
+        if typ is C.c_void_p or (isinstance(typ, type) and issubclass(typ, C._Pointer)):
+            continue  # addresses differ between two hosts; what they point at is compared above
+        v = getattr(view, name)
+        if isinstance(v, (int, float)):
+            scalars[name] = v
+        elif hasattr(v, "_length_") and not hasattr(v, "contents"):
+            scalars[name] = bytes(v)
+    out["scalars"] = scalars
+    return out
+
+
+@pytest.mark.parametrize("edit", sorted(_edits()))
+def test_the_encoder_re_encodes_only_what_an_edit_touched_and_gets_the_same_scene(edit):
+    """CPU half of the partial updates: after an edit, the device scene the host layer hands to the core (update_device_scene with the edit's dirty
+    parts) equals, array by array and field by field, the scene a fresh host encodes from scratch with the same edit applied."""
+    apply = _edits()[edit]
+    a = scenes.zoo_scene(64, 48, 6)
+    a.device_scene()  # encoded once: the edit below is then a partial update
+    apply(a)
+    got = _view_bytes(a.device_scene())
+    b = scenes.zoo_scene(64, 48, 6)
+    apply(b)
+    want = _view_bytes(b.device_scene())
+    # the panorama's origin is the camera position at the time the sky last changed (device_sky.c:249-266): history, not a function of the scene
+    got["scalars"].pop("sky_hdri_origin"); want["scalars"].pop("sky_hdri_origin")
+    for key in want:
+        assert got[key] == want[key], "'%s' differs after the partial update '%s'" % (key, edit)
+    a.close(); b.close()
