@@ -225,18 +225,25 @@ LUM_DEV TriLight load_tri_light(const DeviceScene& sc, uint32_t inst, uint32_t t
   t.bidirectional = (sc.materials[2 * t.material_id].x & kDMatBidirectionalEmission) != 0;
   return t;
 }
-// The same triangle from the per-light table k_light_table writes at scene upload (three 16-byte words per light: vertex | material id and the
-// bidirectional flag, edge1 | scene triangle, edge2): one round trip of three parallel loads instead of the chain handle -> mesh -> triangle offset
-// -> vertices / transform / material word, and none of the instance transform's arithmetic per candidate. The table holds what load_tri_light
-// returns in the exact flavour, bit for bit.
-LUM_DEV TriLight load_tri_light_table(const DeviceScene& sc, uint32_t light_id) {
-  const float4 a = sc.light_tri_table[3u * light_id], b = sc.light_tri_table[3u * light_id + 1u], c = sc.light_tri_table[3u * light_id + 2u];
-  TriLight t;
+// The same triangle from the per-light table k_light_table writes at scene upload (four 16-byte words per light, one 64-byte line: vertex | material
+// id and the bidirectional flag, edge1 | scene triangle, edge2 | area, emitted colour | whether it needs the textures): one round trip of four parallel
+// loads instead of the chain handle -> mesh -> triangle offset -> vertices / transform / material word -> material, and neither the instance
+// transform's arithmetic nor the area (a cross product and a square root) nor the material's decoding per candidate. The table holds what
+// load_tri_light, tri_light_area and - for an emitter without emission or albedo texture - tri_light_color return in the exact flavour, bit for bit.
+struct TableLight { TriLight tri; float area; Col color; bool textured; };
+LUM_DEV TableLight load_tri_light_table(const DeviceScene& sc, uint32_t light_id) {
+  const float4 a = sc.light_tri_table[4u * light_id], b = sc.light_tri_table[4u * light_id + 1u], c = sc.light_tri_table[4u * light_id + 2u],
+               d = sc.light_tri_table[4u * light_id + 3u];
+  TableLight e;
+  TriLight& t = e.tri;
   t.vertex = v3(a.x, a.y, a.z); t.edge1 = v3(b.x, b.y, b.z); t.edge2 = v3(c.x, c.y, c.z);
   t.material_id = fbits(a.w) & 0xFFFFu;
   t.bidirectional = (fbits(a.w) >> 16) != 0u;
   t.scene_tri = fbits(b.w);
-  return t;
+  e.area = c.w;
+  e.color = col(d.x, d.y, d.z);
+  e.textured = fbits(d.w) != 0u;
+  return e;
 }
 LUM_DEV float tri_light_solid_angle(const TriLight& t, V3 origin) {  // light_triangle.cuh:94-108
   const V3 a = normalize(t.vertex - origin), b = normalize((t.vertex + t.edge1) - origin), c = normalize((t.vertex + t.edge2) - origin);
@@ -353,23 +360,42 @@ LUM_DEV float mis_for_bsdf_ray(V3 origin, const TriLight& t, Col color, float di
   const float area = tri_light_area(t), sa = tri_light_solid_angle(t, origin);
   return mis_base(gi_pdf, sa, importance(color) * area, dist * dist, root_sum);
 }
-LUM_DEV float mis_for_light_sample(const GeoContext& g, V3 L, const TriLight& t, Col color, float dist, float solid_angle, float root_sum) {
-  const float power = importance(color) * tri_light_area(t);
+LUM_DEV float mis_for_light_sample(const GeoContext& g, V3 L, float area, Col color, float dist, float solid_angle, float root_sum) {
+  const float power = importance(color) * area;
   return 1.0f - mis_base(light_direction_probability(g, L), solid_angle, power, dist * dist, root_sum);
 }
+#if LUM_FAST
+// The fast flavour's form inside the candidate loop: the probability from the direction terms the BSDF evaluation has just formed in world space (the
+// products N.V, N.H, H.V, H.L do not depend on the frame they are taken in) instead of a second analysis of the same pair of directions rotated
+// into the shading frame - a rotation, a normalisation and a half vector less per candidate. `Vl` = the view direction in that frame (per vertex).
+LUM_DEV float light_direction_probability_terms(const MatParams& p, V3 Vl, const RayTerms& c) {
+  const bool with_refraction = (p.flags & kMatSubstrateMask) == kMatTranslucent;
+  const float refr_prob = with_refraction ? 0.5f : 0.0f;
+  const float roughness = p.roughness();
+  const float sr = light_dir_roughness(roughness);
+  float prob;
+  if (c.is_refraction) prob = refr_prob * pdf_refraction(sr, c.NdotH, c.NdotV, c.HdotV, c.HdotL, p.ior());
+  else prob = (1.0f - refr_prob) * pdf_vndf_bounded(Vl, sr, c.NdotH, c.NdotV);
+  return prob * light_dir_rr(roughness);
+}
+#endif
 
 // ---- light sampling (light.cuh:84-159) ----
 struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum; };
 
-LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp) {
+LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, ShadeClock& clock) {
   LUM_STAT(14, 15);
   const TreeWork work = tree_prepass(sc, g, smp);
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));
+  LUM_LAP(clock, 1);
   LightSample out;
   out.light_id = kLightIdInvalid; out.ray = v3(0.0f, 0.0f, 0.0f); out.color = splat(0.0f); out.dist = 0.0f;
   Reservoir rv;
   rv.random = smp.next1(kRndLightGeoResampling);
   rv.reset();
+#if LUM_FAST
+  const V3 view_local = normalize(qapply(rotation_to_z(g.normal), g.V));  // light_direction_probability's Vl
+#endif
 #ifndef LUM_ABLATE_LANES
 #define LUM_ABLATE_LANES kLightTreeOutputs  // measurement only: fewer resampling lanes evaluated (results are wrong)
 #endif
@@ -379,7 +405,8 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
     const uint2 handle = sc.light_tri_handles[pick.light_id];
-    const TriLight tl = load_tri_light_table(sc, pick.light_id);
+    const TableLight entry = load_tri_light_table(sc, pick.light_id);
+    const TriLight& tl = entry.tri;
     if (handle.x == g.instance_id && handle.y == g.tri_id) continue;
     V3 ray; float sa;
     if (!sample_tri_solid_angle(g.position, tl, smp.next2(kRndLightGeoRay + lane), ray, sa)) continue;
@@ -387,7 +414,8 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     const float dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, g.position, ray, uv);
     if (dist == kFltMax) continue;
     LUM_STAT(10, 11);
-    Col lc = tri_light_color(sc, tl, uv);
+    LUM_LAP(clock, 10);
+    Col lc = entry.textured ? tri_light_color(sc, tl, uv) : entry.color;
     bool is_refraction;
 #ifndef LUM_ABLATE_LIGHT_DEFINED_BELOW
 #define LUM_ABLATE_LIGHT_DEFINED_BELOW
@@ -395,11 +423,22 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
 #if 0
 #define LUM_ABLATE_LIGHT 0  // measurement only: 1 no BSDF evaluation, 2 no MIS weight, 4 one resampling lane in the root pass (results are wrong)
 #endif
+#if LUM_FAST
+    const RayTerms terms = analyze_direction(g.params, g.normal, g.V, ray);
+    is_refraction = terms.is_refraction;
+    const Col bw = (LUM_ABLATE_LIGHT & 1) ? splat(0.5f) : eval_with_face_normal(energy, g.params, terms, kHintGeneral, ray, normal_unpack(g.face_normal_packed), 1.0f);
+    LUM_LAP(clock, 11);
+    const float mis = (LUM_ABLATE_LIGHT & 2) ? 0.5f : 1.0f - mis_base(light_direction_probability_terms(g.params, view_local, terms), sa, importance(lc) * entry.area, dist * dist, work.root_sum);
+#else
     const Col bw = (LUM_ABLATE_LIGHT & 1) ? splat(0.5f) : eval_bsdf(energy, g, ray, kHintGeneral, is_refraction, 1.0f);
-    const float mis = (LUM_ABLATE_LIGHT & 2) ? 0.5f : mis_for_light_sample(g, ray, tl, lc, dist, sa, work.root_sum);
+    LUM_LAP(clock, 11);
+    const float mis = (LUM_ABLATE_LIGHT & 2) ? 0.5f : mis_for_light_sample(g, ray, entry.area, lc, dist, sa, work.root_sum);
+#endif
     lc = (lc * bw) * mis;
     if (rv.add(importance(lc), pick.weight * sa)) { out.light_id = pick.light_id; out.ray = ray; out.color = lc; out.dist = dist; }
+    LUM_LAP(clock, 12);
   }
+  LUM_LAP(clock, 2);
   out.color = out.color * rv.sampling_weight();
   out.root_sum = work.root_sum;
   return out;

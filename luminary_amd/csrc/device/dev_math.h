@@ -40,10 +40,28 @@ __device__ unsigned long long g_phase[16];
 //   0/1 node iterations that touch memory   2/3 node iterations on staged nodes only   4/5 triangle iterations   6/7 instance-entry iterations
 //   8/9 refills (ray fetch)   10/11 whole kernel per wave
 __device__ unsigned long long g_phase_time[16];
+#if LUM_FAST
+#define g_shade_time g_shade_time_fast
+#endif
+// wave-level cycles of k_shade's parts (per batch of 64 vertices):
+//   0 queue words + surface context + local frame   1 light-tree root pass + energy terms   2 the resampling candidates   3 BSDF-driven light direction
+//   4 bounce + ambient record   5 sun   6 NEE stores, classification, roulette   7 appends   8 collecting hits (input rounds)   9 batches   10 candidate: pick + triangle sample
+//   11 candidate: colour + BSDF   12 candidate: MIS + reservoir
+__device__ unsigned long long g_shade_time[16];
+struct ShadeClock {
+  unsigned long long t[16];
+  unsigned long long last;
+  LUM_DEV void start() { for (int k = 0; k < 16; k++) t[k] = 0; last = __builtin_readcyclecounter(); }
+  LUM_DEV void lap(int k) { const unsigned long long now = __builtin_readcyclecounter(); t[k] += now - last; last = now; if (k == 8) t[9]++; }
+  LUM_DEV void flush() { if ((threadIdx.x & 63u) == 0u) for (int k = 0; k < 16; k++) if (t[k]) atomicAdd(&g_shade_time[k], t[k]); }
+};
+#define LUM_LAP(clock, k) (clock).lap(k)
 #define LUM_STAT(k_iter, k_lanes) do { const unsigned long long act_ = __ballot(true); if ((threadIdx.x & 63u) == (uint32_t) __builtin_ctzll(act_)) { \
   atomicAdd(&g_phase[k_iter], 1ull); atomicAdd(&g_phase[k_lanes], (unsigned long long) __popcll(act_)); } } while (0)
 #else
 #define LUM_STAT(k_iter, k_lanes) do {} while (0)
+struct ShadeClock { LUM_DEV void start() {} LUM_DEV void lap(int) {} LUM_DEV void flush() {} };
+#define LUM_LAP(clock, k) do {} while (0)
 #endif
 
 LUM_NS_BEGIN

@@ -84,7 +84,7 @@ struct DeviceScene {
   const float* light_root_children;  // the root's children dequantised (8 floats each: mean.xyz, sigma, power, 0, 0, 0), read with scalar loads (dev_light.h)
   const uint4* light_tree_nodes;  // 4 x 16 B per node
   const uint2* light_tri_handles;
-  const float4* light_tri_table;     // 3 x 16 B per light: world-space vertex | material id, bidirectional << 16; edge1 | scene triangle; edge2 (k_light_table)
+  const float4* light_tri_table;     // 4 x 16 B per light: world-space vertex | material id, bidirectional << 16; edge1 | scene triangle; edge2 | area; colour | textured (k_light_table)
   // sampler and LUTs
   const uint32_t* bluenoise_2d;
   const uint16_t* lut_conductor;

@@ -274,6 +274,8 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
   __shared__ uint32_t pending_hits[kBlock / 64][128];
   uint32_t* pending = pending_hits[threadIdx.x >> 6];
   uint32_t num_pending = 0;  // wave-uniform
+  ShadeClock clock;
+  clock.start();
   for (uint32_t round = 0;; round++) {
     const bool input_done = round >= rounds;
     if (!input_done) {
@@ -310,6 +312,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
       continue;
     }
     __builtin_amdgcn_wave_barrier();
+    LUM_LAP(clock, 8);
     const uint32_t take = min(num_pending, 64u);
     num_pending -= take;
     const bool valid = lane < take;
@@ -338,6 +341,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);
         const LocalFrame lf = local_frame(sc, g);
+        LUM_LAP(clock, 0);
         float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
         float4 bs_rp = make_float4(0.0f, 0.0f, 1.0f, 0.0f), bs_ws = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         s_origin = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, 0.0f);
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         if (geo_allowed) {
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
-          else ls = sample_light(sc, g, smp);
+          else ls = sample_light(sc, g, smp, clock);
           if (top_volume != kVolumeNone) ls.color = ls.color * volume_transmittance(sc, top_volume, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
           if (ls.light_id != kLightIdInvalid) {
@@ -365,6 +369,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
             want_lq = true;
             bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, ls.root_sum);
           }
+          LUM_LAP(clock, 3);
         }
         BounceSample bounce;
         if (LUM_ABLATE & 4) { bounce.ray = g.normal; bounce.weight = splat(0.5f); bounce.transparent_pass = false; bounce.microfacet_based = false; }
@@ -397,6 +402,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
             }
           }
         }
+        LUM_LAP(clock, 4);
         if (kSkyMode != kSkyConstantColor) {  // the sun: its own record and the fourth kind of visibility ray
           uint4 sun = make_uint4(0u, 0u, 0u, 0u);
           Col sun_light; V3 sun_dir;
@@ -426,6 +432,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
             }
           }
           st_stream(&nee.sun[i], sun);
+          LUM_LAP(clock, 5);
         }
         st_stream(&nee.geo_color_light[i], geo_cl);
         st_stream(&nee.bsdf_ray_prob[i], bs_rp); st_stream(&nee.bsdf_weight_sum[i], bs_ws);
@@ -479,6 +486,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         }
       }
     }
+    LUM_LAP(clock, 6);
     // Wave-aggregated appends. The three lists (survivors, visibility items, light queries) are reserved by ONE memory instruction: lanes 0-2
     // each bump one counter, so a batch waits for one atomic round trip instead of three in a row (the words sit on separate 128-byte lines).
     const unsigned long long ballot = __ballot(survive);
@@ -527,7 +535,9 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
       }
     }
     if (want_lq) sq.light_items[base_light + (uint32_t) __popcll(bl & below)] = i;
+    LUM_LAP(clock, 7);
   }
+  clock.flush();
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) vertices += __shfl_down(vertices, off);
   if ((threadIdx.x & 63) == 0 && vertices) atomicAdd((unsigned long long*) &counters[kCntVertices], (unsigned long long) vertices);
@@ -1415,9 +1425,13 @@ __global__ __launch_bounds__(kBlock) void k_light_table(DeviceScene sc, float4* 
   if (i >= sc.num_lights) return;
   const uint2 handle = sc.light_tri_handles[i];
   const TriLight t = load_tri_light(sc, handle.x, handle.y);
-  table[3u * i] = make_float4(t.vertex.x, t.vertex.y, t.vertex.z, bitsf(t.material_id | (t.bidirectional ? 0x10000u : 0u)));
-  table[3u * i + 1u] = make_float4(t.edge1.x, t.edge1.y, t.edge1.z, bitsf(t.scene_tri));
-  table[3u * i + 2u] = make_float4(t.edge2.x, t.edge2.y, t.edge2.z, 0.0f);
+  const Material m = load_material(sc, t.material_id);
+  const bool textured = m.luminance_tex != kTextureNone || m.albedo_tex != kTextureNone;
+  const Col color = textured ? splat(0.0f) : tri_light_color(sc, t, F2{0.0f, 0.0f});  // without textures the colour does not depend on the point
+  table[4u * i] = make_float4(t.vertex.x, t.vertex.y, t.vertex.z, bitsf(t.material_id | (t.bidirectional ? 0x10000u : 0u)));
+  table[4u * i + 1u] = make_float4(t.edge1.x, t.edge1.y, t.edge1.z, bitsf(t.scene_tri));
+  table[4u * i + 2u] = make_float4(t.edge2.x, t.edge2.y, t.edge2.z, tri_light_area(t));
+  table[4u * i + 3u] = make_float4(color.r, color.g, color.b, bitsf(textured ? 1u : 0u));
 }
 #endif
 

@@ -1114,9 +1114,9 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     hipLaunchKernelGGL(k_tri_opacity, dim3((total_tris + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, const_cast<BvhTri*>(sc.blas_tris), total_tris);
     HIP_TRY(ctx, hipGetLastError());
   }
-  if (dirty_lights && sc.light_tree_root && sc.num_lights) {  // the emissive triangles in world space, one record per light (load_tri_light_table)
-    float4* table = nullptr;
-    HIP_TRY(ctx, hipMalloc((void**) &table, sizeof(float4) * 3 * (size_t) sc.num_lights)); ctx->scene_allocs[LumContext::kGrpLight].push_back(table);
+  if ((dirty_lights || ((dirty & (LUMC_DIRTY_MATERIALS | LUMC_DIRTY_INSTANCES | LUMC_DIRTY_MESHES)) && sc.light_tri_table)) && sc.light_tree_root && sc.num_lights) {  // the emissive triangles in world space with what their material says, one record per light (load_tri_light_table)
+    float4* table = const_cast<float4*>(sc.light_tri_table);  // a material edit alone refills the table in place (same lights)
+    if (dirty_lights) { HIP_TRY(ctx, hipMalloc((void**) &table, sizeof(float4) * 4 * (size_t) sc.num_lights)); ctx->scene_allocs[LumContext::kGrpLight].push_back(table); }
     hipLaunchKernelGGL(k_light_table, dim3((sc.num_lights + kBlock - 1) / kBlock), dim3(kBlock), 0, 0, sc, table);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipDeviceSynchronize());

@@ -50,3 +50,14 @@ print("shade: light sampling entered by %d waves, lane occupancy %.3f" % (sh[6],
 print("shade: candidate loop %d wave iterations, occupancy %.3f; BSDF+MIS part %d wave iterations, occupancy %.3f (%.2f of 8 candidates per vertex)"
       % (sh[0], sh[1] / (64.0 * max(sh[0], 1)), sh[2], sh[3] / (64.0 * max(sh[2], 1)), sh[3] / max(sh[7], 1)))
 print("shade: light-tree descent %d wave iterations, occupancy %.3f" % (sh[4], sh[5] / (64.0 * max(sh[4], 1))))
+if core.flavour == "fast" and hasattr(lib, "lumc_debug_shade_times_fast"):
+    tm = (C.c_uint64 * 16)()
+    lib.lumc_debug_shade_times_fast(tm, 1)
+    tm = [int(x) for x in tm]
+    names = {0: "queue words, surface context, local frame", 1: "light-tree root pass + energy terms", 10: "candidate: pick + triangle sample", 11: "candidate: colour + BSDF",
+             12: "candidate: MIS + reservoir", 2: "candidate loop remainder", 3: "BSDF-driven light direction", 4: "bounce + ambient record", 5: "sun", 6: "NEE stores, classification, roulette",
+             7: "appends", 8: "collecting hits (input rounds)"}
+    total = sum(tm[k] for k in names)
+    print("shade time (s_memtime ticks per wave, %d batches of 64 vertices; shares of %d ticks):" % (tm[9], total))
+    for k, nm in names.items():
+        print("  %-45s %6.1f %%   %8.1f ticks per batch" % (nm, 100.0 * tm[k] / max(total, 1), tm[k] / max(tm[9], 1)))
