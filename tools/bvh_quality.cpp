@@ -3,7 +3,9 @@
 // The ray kernels' time follows the node visits (profiles/r03_ab_experiments.txt: +10 % visits = +28 % time on the hall), so builder changes can be judged
 // here before they go to the GPU.
 //   g++ -O2 -std=c++17 -fopenmp -I luminary_amd/csrc/host -o /tmp/bvh_quality tools/bvh_quality.cpp luminary_amd/csrc/host/bvh_build.cpp
-//   /tmp/bvh_quality vertices.f32 [rays]       vertices.f32 = the mesh as the device scene holds it: 3 x float4 per triangle (tools/dump_mesh.py)
+//   /tmp/bvh_quality vertices.f32 [rays] [sah|lbvh|ploc] [radius]     vertices.f32 = the mesh as the device scene holds it: 3 x float4 per triangle
+//   lbvh / ploc: CPU models of the GPU builders (lbvh.hip) - the Morton-ordered radix tree, and parallel locally-ordered clustering (Meister, Bittner 2018)
+//   over the same order - collapsed to 4-wide nodes by the rule k_lbvh_collapse uses; to judge a builder's trees before it is written for the GPU.
 // Rays: origins on random triangles (pushed off the surface), cosine-distributed directions about the normal - what a path tracer's bounces look like.
 #include <chrono>
 #ifdef _OPENMP
@@ -14,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "bvh_build.h"
@@ -96,6 +99,143 @@ static void walk(const Bvh4& bvh, const std::vector<float>& verts, V o, V d, flo
   if (best < tmax) st.hits++;
 }
 
+// ---- CPU models of the GPU builders ----
+#include <algorithm>
+#include <functional>
+#include <numeric>
+struct BinTree { std::vector<int> left, right; std::vector<Aabb> box; std::vector<uint32_t> count; int root = -1; uint32_t leaves = 0; };  // node k < leaves: primitive order[k]
+static Aabb merge(const Aabb& a, const Aabb& b) { Aabb r; for (int k = 0; k < 3; k++) { r.lo[k] = std::min(a.lo[k], b.lo[k]); r.hi[k] = std::max(a.hi[k], b.hi[k]); } return r; }
+static float half_area(const Aabb& b) { const float x = b.hi[0] - b.lo[0], y = b.hi[1] - b.lo[1], z = b.hi[2] - b.lo[2]; return x * y + y * z + z * x; }
+static uint64_t spread21(uint64_t v) { v &= 0x1FFFFF; v = (v | v << 32) & 0x1F00000000FFFFull; v = (v | v << 16) & 0x1F0000FF0000FFull; v = (v | v << 8) & 0x100F00F00F00F00Full; v = (v | v << 4) & 0x10C30C30C30C30C3ull; v = (v | v << 2) & 0x1249249249249249ull; return v; }
+static std::vector<uint32_t> morton_order(const std::vector<Aabb>& boxes, std::vector<uint64_t>& codes) {
+  Aabb all = boxes[0];
+  for (const Aabb& b : boxes) all = merge(all, b);
+  const size_t n = boxes.size();
+  codes.resize(n);
+  std::vector<uint32_t> order(n);
+  for (size_t i = 0; i < n; i++) {
+    uint64_t q[3];
+    for (int k = 0; k < 3; k++) { const float c = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]), e = std::max(all.hi[k] - all.lo[k], 1e-30f); q[k] = (uint64_t) std::min(std::max((c - all.lo[k]) / e * 2097152.0f, 0.0f), 2097151.0f); }
+    codes[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+    order[i] = (uint32_t) i;
+  }
+  std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] != codes[b] ? codes[a] < codes[b] : a < b; });
+  return order;
+}
+static BinTree build_lbvh_model(const std::vector<Aabb>& boxes, std::vector<uint32_t>& order) {
+  std::vector<uint64_t> codes;
+  order = morton_order(boxes, codes);
+  const uint32_t n = (uint32_t) boxes.size();
+  BinTree t; t.leaves = n;
+  t.left.assign(n, -1); t.right.assign(n, -1); t.box.resize(n); t.count.assign(n, 1);
+  for (uint32_t k = 0; k < n; k++) t.box[k] = boxes[order[k]];
+  std::function<int(uint32_t, uint32_t)> rec = [&](uint32_t a, uint32_t b) -> int {  // [a, b]
+    if (a == b) return (int) a;
+    const uint64_t ca = codes[order[a]], cb = codes[order[b]];
+    uint32_t split;
+    if (ca == cb) split = (a + b) / 2;
+    else {
+      const int bit = 63 - __builtin_clzll(ca ^ cb);
+      uint32_t lo = a, hi = b;  // last index whose bit is 0
+      while (lo < hi) { const uint32_t m = (lo + hi + 1) / 2; if ((codes[order[m]] >> bit) & 1) hi = m - 1; else lo = m; }
+      split = lo;
+    }
+    const int l = rec(a, split), r = rec(split + 1, b);
+    t.left.push_back(l); t.right.push_back(r); t.box.push_back(merge(t.box[l], t.box[r])); t.count.push_back(t.count[l] + t.count[r]);
+    return (int) t.left.size() - 1;
+  };
+  t.root = rec(0, n - 1);
+  return t;
+}
+static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint32_t>& order, int radius) {
+  std::vector<uint64_t> codes;
+  order = morton_order(boxes, codes);
+  const uint32_t n = (uint32_t) boxes.size();
+  BinTree t; t.leaves = n;
+  t.left.assign(n, -1); t.right.assign(n, -1); t.box.resize(n); t.count.assign(n, 1);
+  for (uint32_t k = 0; k < n; k++) t.box[k] = boxes[order[k]];
+  std::vector<int> cur(n), next;
+  std::iota(cur.begin(), cur.end(), 0);
+  std::vector<int> nn;
+  int iterations = 0;
+  while (cur.size() > 1) {
+    const int m = (int) cur.size();
+    nn.assign(m, -1);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; i++) {
+      float best = INFINITY; int bj = -1;
+      for (int j = std::max(0, i - radius); j <= std::min(m - 1, i + radius); j++) {
+        if (j == i) continue;
+        const float a = half_area(merge(t.box[cur[i]], t.box[cur[j]]));
+        if (a < best) { best = a; bj = j; }  // ties: the lower index, on both sides of the pair
+      }
+      nn[i] = bj;
+    }
+    next.clear();
+    for (int i = 0; i < m; i++) {
+      const int j = nn[i];
+      if (nn[j] == i) {
+        if (i < j) {
+          const int l = cur[i], r = cur[j];
+          t.left.push_back(l); t.right.push_back(r); t.box.push_back(merge(t.box[l], t.box[r])); t.count.push_back(t.count[l] + t.count[r]);
+          next.push_back((int) t.left.size() - 1);
+        }
+      }
+      else next.push_back(cur[i]);
+    }
+    cur.swap(next);
+    iterations++;
+  }
+  t.root = cur[0];
+  std::printf("ploc: radius %d, %d iterations\n", radius, iterations);
+  return t;
+}
+// k_lbvh_collapse's rule: open the child with the largest box until there are four; a subtree of at most max_leaf primitives is a leaf.
+static Bvh4 collapse_model(const BinTree& t, const std::vector<uint32_t>& order, uint32_t max_leaf) {
+  Bvh4 out;
+  // primitive order: depth-first over the binary tree, so that every subtree is a contiguous range
+  std::vector<uint32_t> first(t.left.size(), 0);
+  {
+    std::vector<std::pair<int, uint32_t>> stack{{t.root, 0u}};
+    out.prims.resize(t.leaves);
+    while (!stack.empty()) {
+      auto [b, off] = stack.back(); stack.pop_back();
+      first[b] = off;
+      if (t.left[b] < 0) { out.prims[off] = order[b]; continue; }
+      stack.push_back({t.left[b], off});
+      stack.push_back({t.right[b], off + t.count[t.left[b]]});
+    }
+  }
+  struct Item { int bin; uint32_t node4; uint32_t depth; };
+  std::vector<Item> queue{{t.root, 0u, 1u}};
+  out.nodes.resize(1);
+  for (size_t q = 0; q < queue.size(); q++) {
+    const Item item = queue[q];
+    out.max_depth = std::max(out.max_depth, item.depth);
+    auto is_leaf = [&](int b) { return t.count[b] <= max_leaf; };
+    int kids[4]; int nk = 0;
+    if (is_leaf(item.bin)) kids[nk++] = item.bin;
+    else { kids[nk++] = t.left[item.bin]; kids[nk++] = t.right[item.bin]; }
+    while (nk < 4) {
+      int pick = -1; float best = -1.0f;
+      for (int k = 0; k < nk; k++) { if (is_leaf(kids[k])) continue; const float a = half_area(t.box[kids[k]]); if (a > best) { best = a; pick = k; } }
+      if (pick < 0) break;
+      const int b = kids[pick];
+      kids[pick] = t.left[b]; kids[nk++] = t.right[b];
+    }
+    Bvh4Node node;
+    for (int k = 0; k < 4; k++) { node.child[k] = kBvhEmpty; node.pad[k] = 0; node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = 3.4e38f; node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -3.4e38f; }
+    for (int k = 0; k < nk; k++) {
+      const Aabb& b = t.box[kids[k]];
+      node.lo_x[k] = b.lo[0]; node.lo_y[k] = b.lo[1]; node.lo_z[k] = b.lo[2]; node.hi_x[k] = b.hi[0]; node.hi_y[k] = b.hi[1]; node.hi_z[k] = b.hi[2];
+      if (is_leaf(kids[k])) node.child[k] = kBvhLeafBit | ((t.count[kids[k]] - 1u) << 28) | first[kids[k]];
+      else { node.child[k] = (uint32_t) out.nodes.size(); queue.push_back({kids[k], (uint32_t) out.nodes.size(), item.depth + 1}); out.nodes.emplace_back(); }
+    }
+    out.nodes[item.node4] = node;
+  }
+  return out;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: bvh_quality vertices.f32 [rays]\n"); return 1; }
   FILE* f = std::fopen(argv[1], "rb");
@@ -115,11 +255,14 @@ int main(int argc, char** argv) {
     boxes[t] = b;
   }
   const auto t0 = std::chrono::steady_clock::now();
-#ifdef LUM_BVH_HAS_TRIANGLE_BUILD
-  const Bvh4 bvh = build_bvh4_triangles(verts.data(), boxes.data(), nullptr, nt, kBvhLeafMaxTri, 26);
-#else
-  const Bvh4 bvh = build_bvh4(boxes.data(), nt, kBvhLeafMaxTri, 26);
-#endif
+  const std::string builder = argc > 3 ? argv[3] : "sah";
+  Bvh4 bvh;
+  if (builder == "sah") bvh = build_bvh4(boxes.data(), nt, kBvhLeafMaxTri, 26);
+  else {
+    std::vector<uint32_t> order;
+    const BinTree t = builder == "lbvh" ? build_lbvh_model(boxes, order) : build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 16);
+    bvh = collapse_model(t, order, kBvhLeafMaxTri);
+  }
   const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (bvh.nodes.empty()) { std::printf("build failed (too deep)\n"); return 1; }
   size_t kids = 0, leaf_refs = 0, leaf_count = 0;

@@ -9,7 +9,7 @@ import bench  # noqa: E402
 from luminary_amd.core import Core  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "hall"
-host, label = bench.build_workload(name, 1920, 1080, 8)
+host, label = bench.build_workload(name, 1920, 1080, 8), bench.WORKLOADS[name]
 view = host.device_scene()
 print(label)
 for builder in ("sah", "lbvh", "lbvh"):
