@@ -811,6 +811,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
 struct ParticleQuery {
   static constexpr bool kDual = false;
   static constexpr bool kOrdered = true;
+  static constexpr int kFarFirst = 0;
   static constexpr bool kCull = true;
   PathQueue q;
   float best_t;

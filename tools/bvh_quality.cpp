@@ -73,10 +73,10 @@ static void walk(const Bvh4& bvh, const std::vector<float>& verts, V o, V d, flo
     else {
       st.nodes++;
       const Bvh4Node& n = bvh.nodes[cur];
-      float k[4]; uint32_t c[4];
+      float k[4], kf[4]; uint32_t c[4];
       for (int j = 0; j < 4; j++) {
         c[j] = n.child[j];
-        k[j] = INFINITY;
+        k[j] = INFINITY; kf[j] = INFINITY;
         if (c[j] == kBvhEmpty) continue;
         const float lo[3] = {n.lo_x[j], n.lo_y[j], n.lo_z[j]}, hi[3] = {n.hi_x[j], n.hi_y[j], n.hi_z[j]};
         float tn = 0.0f, tf = best;
@@ -85,10 +85,36 @@ static void walk(const Bvh4& bvh, const std::vector<float>& verts, V o, V d, flo
           if (t0 > t1) std::swap(t0, t1);
           tn = std::max(tn, t0); tf = std::min(tf, t1);
         }
-        if (tn <= tf) k[j] = tn;
+        if (tn <= tf) { k[j] = tn; kf[j] = tf; }
       }
+      if (!(any_hit && (std::getenv("BQ_ANYHIT_UNSORTED") || std::getenv("BQ_ANYHIT_ORDER")))) {
+      static const int tie = std::getenv("BQ_TIE") ? std::atoi(std::getenv("BQ_TIE")) : 0;  // ties of the entry distance (origin inside both boxes): 1 longer stay first, 2 shorter stay first
       for (int a = 0; a < 4; a++)  // sort by entry distance (4 entries)
-        for (int b = a + 1; b < 4; b++) if (k[b] < k[a]) { std::swap(k[a], k[b]); std::swap(c[a], c[b]); }
+        for (int b = a + 1; b < 4; b++) {
+          bool sw = k[b] < k[a];
+          if (tie && k[b] == k[a] && k[a] < INFINITY) sw = tie == 1 ? kf[b] > kf[a] : kf[b] < kf[a];
+          if (sw) { std::swap(k[a], k[b]); std::swap(kf[a], kf[b]); std::swap(c[a], c[b]); }
+        }
+      }
+      if (any_hit && std::getenv("BQ_ANYHIT_ORDER")) {  // 1 farthest first, 2 largest box first
+        const int mode = std::atoi(std::getenv("BQ_ANYHIT_ORDER"));
+        float key[4];
+        for (int a = 0; a < 4; a++) {
+          key[a] = INFINITY;
+          if (k[a] == INFINITY) continue;
+          int j = 0; for (; j < 4; j++) if (n.child[j] == c[a]) break;
+          const float dx = n.hi_x[j] - n.lo_x[j], dy = n.hi_y[j] - n.lo_y[j], dz = n.hi_z[j] - n.lo_z[j];
+          key[a] = mode == 1 ? -k[a] : mode == 2 ? -(dx * dy + dy * dz + dz * dx) : mode == 3 ? -kf[j] : mode == 4 ? -(kf[j] - k[a]) : -(kf[j] - k[a]) * (dx * dy + dy * dz + dz * dx);
+        }
+        for (int a = 0; a < 4; a++)
+          for (int b = a + 1; b < 4; b++) if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(k[a], k[b]); std::swap(c[a], c[b]); }
+      }
+      if (any_hit && std::getenv("BQ_ANYHIT_UNSORTED")) {  // stored order, misses moved to the end
+        int w = 0; float k2[4]; uint32_t c2[4];
+        for (int a = 0; a < 4; a++) if (k[a] < INFINITY) { k2[w] = k[a]; c2[w] = c[a]; w++; }
+        for (int a = w; a < 4; a++) { k2[a] = INFINITY; c2[a] = kBvhEmpty; }
+        for (int a = 0; a < 4; a++) { k[a] = k2[a]; c[a] = c2[a]; }
+      }
       for (int j = 3; j >= 1; j--) if (k[j] < INFINITY) stack[sp++] = {c[j], k[j]};
       if (k[0] < INFINITY) { cur = c[0]; continue; }
     }
