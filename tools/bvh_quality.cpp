@@ -104,7 +104,7 @@ static void walk(const Bvh4& bvh, const std::vector<float>& verts, V o, V d, flo
           if (k[a] == INFINITY) continue;
           int j = 0; for (; j < 4; j++) if (n.child[j] == c[a]) break;
           const float dx = n.hi_x[j] - n.lo_x[j], dy = n.hi_y[j] - n.lo_y[j], dz = n.hi_z[j] - n.lo_z[j];
-          key[a] = mode == 1 ? -k[a] : mode == 2 ? -(dx * dy + dy * dz + dz * dx) : mode == 3 ? -kf[j] : mode == 4 ? -(kf[j] - k[a]) : -(kf[j] - k[a]) * (dx * dy + dy * dz + dz * dx);
+          key[a] = mode == 1 ? -k[a] : mode == 6 ? (cur < 4096u ? -k[a] : k[a]) : mode == 7 ? (cur < 4096u ? k[a] : -k[a]) : mode == 8 ? (cur < 65536u ? -k[a] : k[a]) : mode == 2 ? -(dx * dy + dy * dz + dz * dx) : mode == 3 ? -kf[j] : mode == 4 ? -(kf[j] - k[a]) : -(kf[j] - k[a]) * (dx * dy + dy * dz + dz * dx);
         }
         for (int a = 0; a < 4; a++)
           for (int b = a + 1; b < 4; b++) if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(k[a], k[b]); std::swap(c[a], c[b]); }
