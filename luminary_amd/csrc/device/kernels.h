@@ -340,7 +340,6 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
 
         // NEE work (geometry.cuh:31-74; direct_lighting.cuh:352-443)
         const bool geo_allowed = lights_present && ((state & kStVolumeScattered) == 0);
-        const LocalFrame lf = local_frame(sc, g);
         LUM_LAP(clock, 0);
         float4 geo_cl = make_float4(0.0f, 0.0f, 0.0f, bitsf(kLightIdInvalid));
         float4 bs_rp = make_float4(0.0f, 0.0f, 1.0f, 0.0f), bs_ws = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -349,25 +348,31 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
 #ifndef LUM_ABLATE
 #define LUM_ABLATE 0  // measurement only: 1 skips light sampling, 2 the BSDF light direction, 4 the bounce (results are wrong)
 #endif
+        float light_root_sum = 0.0f;
         if (geo_allowed) {
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
           else ls = sample_light(sc, g, smp, clock);
           if (top_volume != kVolumeNone) ls.color = ls.color * volume_transmittance(sc, top_volume, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
+          light_root_sum = ls.root_sum;
           if (ls.light_id != kLightIdInvalid) {
             want_geo = true;
             const uint2 target = sc.light_tri_handles[ls.light_id];
             s_geo_dir = make_float4(ls.ray.x, ls.ray.y, ls.ray.z, ls.dist);
             s_geo_ids.x = target.x; s_geo_ids.y = target.y;
           }
+        }
+        // the shading frame is formed after the light sampling: its thirteen registers need not live through the candidate loop
+        const LocalFrame lf = local_frame(sc, g);
+        if (geo_allowed) {
           LightDirSample lb;
           if (LUM_ABLATE & 2) { lb.ray = v3(0.0f, 0.0f, 1.0f); lb.weight = splat(0.0f); lb.probability = 0.0f; }
           else lb = sample_light_direction(lf, g, smp);
           bs_rp = make_float4(lb.ray.x, lb.ray.y, lb.ray.z, lb.probability);
           if (lb.probability != 0.0f) {
             want_lq = true;
-            bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, ls.root_sum);
+            bs_ws = make_float4(lb.weight.r, lb.weight.g, lb.weight.b, light_root_sum);
           }
           LUM_LAP(clock, 3);
         }
