@@ -411,7 +411,7 @@ def main():
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
-    ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too")
+    ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2, 3], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too, 3 path queue physically reordered")
     ap.add_argument("--clouds", action="store_true", help="procedural sky with the three cloud layers active (not a BASELINE configuration)")
     ap.add_argument("--ocean", type=float, default=None, help="height of an ocean surface put into the scene (default: none, the BASELINE configurations)")
     ap.add_argument("--fog", type=float, default=0.0, help="density of the fog volume the scene is put in (0 = none, the BASELINE configurations)")

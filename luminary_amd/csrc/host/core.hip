@@ -107,7 +107,10 @@ struct LumContext {
   uint32_t frame_result_pixels = 0;
   // ray ordering (N1): keys + permutation, double-buffered for hipcub's radix sort; sized for the visibility items (4 per path)
   bool sync_debug = false;
-  int sort_mode = 0;              // 0 queue order, 1 closest-hit rays of depth >= 1 sorted, 2 visibility rays too (lumc_set_ray_sorting, LUM_SORT)
+  int sort_mode = 0;              // 0 queue order, 1 closest-hit rays of depth >= 1 traced through a sorted permutation, 2 visibility rays too, 3 the path queue physically reordered (lumc_set_ray_sorting, LUM_SORT)
+  PathQueue sort_queue{};         // mode 3: the four state planes the reorder pass writes; swapped with the queue's own afterwards
+  void* sort_planes[4] = {nullptr, nullptr, nullptr, nullptr};  // what was allocated for them (after swaps sort_queue may point into the work block)
+  uint32_t sort_queue_capacity = 0;
   int sort_key = 0;               // 0 position-major (Morton cell | direction octant), 1 direction-major
   uint32_t* d_sort_keys[2] = {nullptr, nullptr};
   uint32_t* d_sort_vals[2] = {nullptr, nullptr};
@@ -193,6 +196,9 @@ void free_work(LumContext* ctx) {
   ctx->capacity = 0;
   ctx->work_shadow_kinds = 0;
   ctx->cloud = CloudQueue{};
+  // the reorder pass's planes (ray-sorting mode 3) trade places with the queues' own: they go with them
+  for (int k = 0; k < 4; k++) { if (ctx->sort_planes[k]) (void) hipFree(ctx->sort_planes[k]); ctx->sort_planes[k] = nullptr; }
+  ctx->sort_queue = PathQueue{}; ctx->sort_queue_capacity = 0;
 }
 
 int ensure_work(LumContext* ctx, uint32_t paths) {
@@ -415,6 +421,29 @@ int ensure_sort(LumContext* ctx, uint32_t items) {
   HIP_TRY(ctx, hipcub::DeviceRadixSort::SortPairs(nullptr, ctx->sort_temp_bytes, keys, vals, (int) items, 0, 22, (hipStream_t) 0));
   HIP_TRY(ctx, hipMalloc(&ctx->d_sort_temp, std::max<size_t>(ctx->sort_temp_bytes, 16)));
   ctx->sort_capacity = items;
+  return 0;
+}
+
+// Mode 3: the path state of the live paths gathered through the sorted permutation into a second set of planes, written in order - the pass every
+// later kernel of the depth then reads coherently (trace, shade, and through the order of the appends the visibility rays and the next depth).
+__global__ __launch_bounds__(256) void k_permute_queue(PathQueue src, PathQueue dst, const uint32_t* __restrict__ order, const uint32_t* __restrict__ count, uint32_t capacity) {
+  const uint32_t n = min(*count, capacity);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+    const uint32_t j = order[i];
+    const float4 o = src.origin_t[j], d = src.dir_slot[j];
+    const uint4 a = src.aux[j], h = src.hit_id[j];
+    dst.origin_t[i] = o; dst.dir_slot[i] = d; dst.aux[i] = a; dst.hit_id[i] = h;
+  }
+}
+
+int ensure_sort_queue(LumContext* ctx, uint32_t items) {
+  if (items == ctx->sort_queue_capacity) return 0;
+  for (int k = 0; k < 4; k++) { if (ctx->sort_planes[k]) (void) hipFree(ctx->sort_planes[k]); ctx->sort_planes[k] = nullptr; }
+  ctx->sort_queue = PathQueue{}; ctx->sort_queue_capacity = 0;
+  for (int k = 0; k < 4; k++) HIP_TRY(ctx, hipMalloc(&ctx->sort_planes[k], 16 * (size_t) items));
+  ctx->sort_queue.origin_t = (float4*) ctx->sort_planes[0]; ctx->sort_queue.dir_slot = (float4*) ctx->sort_planes[1];
+  ctx->sort_queue.aux = (uint4*) ctx->sort_planes[2]; ctx->sort_queue.hit_id = (uint4*) ctx->sort_planes[3];
+  ctx->sort_queue_capacity = items;
   return 0;
 }
 
@@ -1471,6 +1500,15 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     if (ctx->sort_mode >= 1 && depth >= 1) {
       order = sort_rays(ctx, stream, ctx->queue[cur].origin_t, ctx->queue[cur].dir_slot, ctrl + kCtlPaths, N);
       if (!order) { ctx->error = "ray sorting failed"; return 1; }
+      if (ctx->sort_mode == 3) {  // physical reorder: the planes change places, the permutation is spent
+        if (ensure_sort_queue(ctx, ctx->capacity)) return 1;
+        Launch l(ctx, stream, LUMC_KERNEL_SORT);
+        PathQueue& q = ctx->queue[cur];
+        hipLaunchKernelGGL(k_permute_queue, dim3(std::min<uint32_t>((N + 255u) / 256u, 65536u)), dim3(256), 0, stream, q, ctx->sort_queue, order, ctrl + kCtlPaths, N);
+        std::swap(q.origin_t, ctx->sort_queue.origin_t); std::swap(q.dir_slot, ctx->sort_queue.dir_slot);
+        std::swap(q.aux, ctx->sort_queue.aux); std::swap(q.hit_id, ctx->sort_queue.hit_id);
+        order = nullptr;
+      }
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
@@ -1527,7 +1565,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
     }
     const uint32_t* shadow_order = nullptr;
-    if (ctx->sort_mode >= 2) {
+    if (ctx->sort_mode == 2) {
       shadow_order = sort_rays(ctx, stream, ctx->shadow.origin_dist, ctx->shadow.dir_out, ctrl + kCtlShadowItems,
                                (sc.ocean_active ? kSurfaceShadowKindsWater : 4u) * (ctx->shadow.capacity < N ? ctx->shadow.capacity : N));
       if (!shadow_order) { ctx->error = "ray sorting failed"; return 1; }
@@ -2493,7 +2531,7 @@ int lumc_device_name(int ordinal, char* out, size_t size) {
 }
 
 int lumc_set_ray_sorting(LumContext* ctx, int mode) {
-  if (!ctx || mode < 0 || mode > 2) { if (ctx) ctx->error = "lumc_set_ray_sorting: 0 (queue order), 1 (closest-hit rays sorted), 2 (visibility rays too)"; return 1; }
+  if (!ctx || mode < 0 || mode > 3) { if (ctx) ctx->error = "lumc_set_ray_sorting: 0 (queue order), 1 (closest-hit rays sorted), 2 (visibility rays too), 3 (path queue physically reordered)"; return 1; }
   ctx->sort_mode = mode;
   return 0;
 }

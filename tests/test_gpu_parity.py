@@ -277,14 +277,15 @@ def test_debug_shading_modes_match_the_oracle(core, mode):
 
 def test_ray_sorting_does_not_change_results(core):
     """Ray ordering (lumc_set_ray_sorting): tracing the closest-hit rays of depth >= 1 (mode 1) and the visibility rays (mode 2) in the order
-    of a sort by origin cell and direction octant gives bit-identical moments and counters - every path owns its slots."""
+    of a sort by origin cell and direction octant, or physically reordering the path queue by it at every depth (mode 3), gives bit-identical
+    moments and counters - every path owns its slots."""
     host = scenes.example_scene(256, 144, 8, sphere_segments=10, ground_res=24, num_objects=32, num_lights=8)
     view = oracle_lib.with_luts(host.device_scene())
     core.upload(view)
     core.set_pixels(None)
     ref = None
     try:
-        for mode in (0, 1, 2):
+        for mode in (0, 1, 2, 3):
             core.set_ray_sorting(mode)
             core.clear()
             core.reset_counters()
