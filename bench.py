@@ -231,6 +231,11 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     core.upload(view)  # builds the BVHs, generates the BSDF tables on the GPU
     upload_s = time.time() - t_up
     pixels = tile_pixels(view.width, view.height, rank, world) if dist is not None else None
+    if pixels is None and args.pixel_tile:  # experiment: the frame's pixels dealt to the paths in t x t tiles instead of rows (the moments then come back in that order)
+        import numpy as np
+        t = args.pixel_tile
+        ys, xs = np.divmod(np.arange(view.width * view.height, dtype=np.int64), view.width)
+        pixels = np.lexsort((xs, ys, xs // t, ys // t)).astype(np.uint32)
     core.set_pixels(pixels)
     P = core.num_pixels
     frame_pixels = view.width * view.height
@@ -412,6 +417,7 @@ def main():
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2, 3], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too, 3 path queue physically reordered")
+    ap.add_argument("--pixel-tile", type=int, default=0, help="experiment: order the paths by t x t pixel tiles instead of pixel rows (N = 1)")
     ap.add_argument("--clouds", action="store_true", help="procedural sky with the three cloud layers active (not a BASELINE configuration)")
     ap.add_argument("--ocean", type=float, default=None, help="height of an ocean surface put into the scene (default: none, the BASELINE configurations)")
     ap.add_argument("--fog", type=float, default=0.0, help="density of the fog volume the scene is put in (0 = none, the BASELINE configurations)")
