@@ -87,6 +87,27 @@ static void walk(const Bvh4& bvh, const std::vector<float>& verts, V o, V d, flo
         }
         if (tn <= tf) { k[j] = tn; kf[j] = tf; }
       }
+      static const int axis_order = std::getenv("BQ_AXIS_ORDER") ? std::atoi(std::getenv("BQ_AXIS_ORDER")) : 0;
+      if (axis_order && !any_hit) {  // closest-hit rays: children ordered by their centres along the node's longest axis (1) / the ray's dominant axis (2), by the direction's sign - no distances
+        float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int j = 0; j < 4; j++) {
+          if (n.child[j] == kBvhEmpty) continue;
+          lo[0] = std::min(lo[0], n.lo_x[j]); lo[1] = std::min(lo[1], n.lo_y[j]); lo[2] = std::min(lo[2], n.lo_z[j]);
+          hi[0] = std::max(hi[0], n.hi_x[j]); hi[1] = std::max(hi[1], n.hi_y[j]); hi[2] = std::max(hi[2], n.hi_z[j]);
+        }
+        int ax = 0;
+        if (axis_order == 1) { for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[ax] - lo[ax]) ax = a; }
+        else { const float dd[3] = {std::fabs(d.x), std::fabs(d.y), std::fabs(d.z)}; for (int a = 1; a < 3; a++) if (dd[a] > dd[ax]) ax = a; }
+        const float sgn = (ax == 0 ? d.x : ax == 1 ? d.y : d.z) < 0 ? -1.0f : 1.0f;
+        float key[4];
+        for (int j = 0; j < 4; j++) {
+          const float c0 = ax == 0 ? n.lo_x[j] + n.hi_x[j] : ax == 1 ? n.lo_y[j] + n.hi_y[j] : n.lo_z[j] + n.hi_z[j];
+          key[j] = k[j] < INFINITY ? sgn * c0 : INFINITY;
+        }
+        for (int a = 0; a < 4; a++)
+          for (int b = a + 1; b < 4; b++) if (key[b] < key[a]) { std::swap(key[a], key[b]); std::swap(k[a], k[b]); std::swap(kf[a], kf[b]); std::swap(c[a], c[b]); }
+      }
+      else
       if (!(any_hit && (std::getenv("BQ_ANYHIT_UNSORTED") || std::getenv("BQ_ANYHIT_ORDER")))) {
       static const int tie = std::getenv("BQ_TIE") ? std::atoi(std::getenv("BQ_TIE")) : 0;  // ties of the entry distance (origin inside both boxes): 1 longer stay first, 2 shorter stay first
       for (int a = 0; a < 4; a++)  // sort by entry distance (4 entries)
