@@ -334,7 +334,7 @@ class Core:
 
     def set_bvh_builder(self, name):
         """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
-        self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1}[name]))
+        self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1, "ploc": 2}[name]))
 
     def comm_count(self):
         """Ranks of the RCCL communicator this context belongs to (ncclCommCount; 1 without one)."""

@@ -88,10 +88,11 @@ __global__ void k_lbvh_hierarchy(const uint64_t* __restrict__ codes, int n, int2
 }
 
 __global__ void k_lbvh_fit(const BinBox* __restrict__ boxes, const uint32_t* __restrict__ ids, int n, const int2* __restrict__ children, const int* __restrict__ parent,
-                           BinBox* __restrict__ node_box, uint32_t* __restrict__ arrivals) {
+                           BinBox* __restrict__ node_box, uint32_t* __restrict__ arrivals, int2* __restrict__ ranges) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   node_box[(n - 1) + k] = boxes[ids[k]];
+  ranges[(n - 1) + k] = make_int2(k, k);
   __threadfence();
   int node = parent[(n - 1) + k];
   while (node >= 0) {
@@ -126,7 +127,7 @@ __global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const 
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= in_count) return;
   const CollapseItem item = in[q];
-  auto prim_count = [&](int b) -> uint32_t { return (b >= n - 1) ? 1u : (uint32_t) (ranges[b].y - ranges[b].x + 1); };
+  auto prim_count = [&](int b) -> uint32_t { return (uint32_t) (ranges[b].y - ranges[b].x + 1); };  // ranges cover the leaves too (2n - 1 entries)
   auto is_leaf = [&](int b) -> bool { return prim_count(b) <= max_leaf; };
   int kids[4];
   int nk = 0;
@@ -166,7 +167,7 @@ __global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const 
     node.lo_x[k] = lo[0]; node.lo_y[k] = lo[1]; node.lo_z[k] = lo[2];
     node.hi_x[k] = hi[0]; node.hi_y[k] = hi[1]; node.hi_z[k] = hi[2];
     if (is_leaf(kids[k])) {
-      const uint32_t first = (kids[k] >= n - 1) ? (uint32_t) (kids[k] - (n - 1)) : (uint32_t) ranges[kids[k]].x;
+      const uint32_t first = (uint32_t) ranges[kids[k]].x;
       node.child[k] = kBvhLeafBit | ((prim_count(kids[k]) - 1u) << 28) | first;
     }
     else {
@@ -178,11 +179,101 @@ __global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const 
   nodes[item.node4] = node;
 }
 
+
+// ---- parallel locally-ordered clustering (Meister, Bittner: "Parallel Locally-Ordered Clustering for Bounding Volume Hierarchy Construction", TVCG
+// 2018) over the same Morton order: bottom-up, every cluster looks `radius` places to either side for the neighbour whose union with it has the
+// smallest box, mutual choices merge, the array is compacted, until one cluster is left. The tree is no longer tied to the Morton code's bit
+// boundaries: on architectural meshes the closest-hit rays visit 13 % fewer nodes than in the radix tree (tools/bvh_quality.cpp models both), at
+// two to three times its build time. Node numbering as above (inner nodes [0, n-1), leaf k = n-1+k, root 0): merge number q creates node n-2-q.
+constexpr int kPlocRadius = 8;
+constexpr int kPlocBlock = 256;
+
+__global__ void k_ploc_init(const BinBox* __restrict__ boxes, const uint32_t* __restrict__ ids, int n, BinBox* __restrict__ node_box, uint32_t* __restrict__ count,
+                            int* __restrict__ clusters, int* __restrict__ parent) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  node_box[(n - 1) + k] = boxes[ids[k]];
+  count[(n - 1) + k] = 1u;
+  clusters[k] = (n - 1) + k;
+  if (k == 0) parent[0] = -1;
+}
+
+__global__ __launch_bounds__(kPlocBlock) void k_ploc_nearest(const int* __restrict__ clusters, int m, const BinBox* __restrict__ node_box, int* __restrict__ nearest) {
+  __shared__ BinBox tile[kPlocBlock + 2 * kPlocRadius];
+  const int base = blockIdx.x * kPlocBlock - kPlocRadius;
+  for (int t = threadIdx.x; t < kPlocBlock + 2 * kPlocRadius; t += kPlocBlock) {
+    const int j = base + t;
+    if (j >= 0 && j < m) tile[t] = node_box[clusters[j]];
+  }
+  __syncthreads();
+  const int i = blockIdx.x * kPlocBlock + threadIdx.x;
+  if (i >= m) return;
+  const BinBox a = tile[threadIdx.x + kPlocRadius];
+  float best = FLT_MAX;
+  int pick = -1;
+  for (int d = -kPlocRadius; d <= kPlocRadius; d++) {  // ascending j: of equal areas the lower index wins, on both sides of a pair
+    const int j = i + d;
+    if (d == 0 || j < 0 || j >= m) continue;
+    const BinBox b = tile[threadIdx.x + kPlocRadius + d];
+    BinBox u;
+    for (int x = 0; x < 3; x++) { u.lo[x] = fminf(a.lo[x], b.lo[x]); u.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    const float area = half_area(u);
+    if (area < best) { best = area; pick = j; }
+  }
+  nearest[i] = pick;
+}
+
+// x = this place opens a merged cluster (the lower index of a mutual pair), y = this place stays in the array (everything but the pair's upper index)
+__global__ void k_ploc_flags(const int* __restrict__ nearest, int m, uint2* __restrict__ flags) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nearest[i];
+  const bool mutual = j >= 0 && nearest[j] == i;
+  flags[i] = make_uint2((mutual && i < j) ? 1u : 0u, (mutual && i > j) ? 0u : 1u);
+}
+struct AddPair { __host__ __device__ uint2 operator()(const uint2& a, const uint2& b) const { return make_uint2(a.x + b.x, a.y + b.y); } };
+
+__global__ void k_ploc_merge(const int* __restrict__ clusters, const int* __restrict__ nearest, const uint2* __restrict__ flags, const uint2* __restrict__ offsets, int m, int n,
+                             uint32_t merges_before, int2* __restrict__ children, int* __restrict__ parent, BinBox* __restrict__ node_box, uint32_t* __restrict__ count,
+                             int* __restrict__ clusters_out, uint2* __restrict__ totals) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint2 f = flags[i], o = offsets[i];
+  if (i == m - 1) *totals = make_uint2(o.x + f.x, o.y + f.y);
+  if (!f.y) return;
+  int id = clusters[i];
+  if (f.x) {
+    const int left = id, right = clusters[nearest[i]];
+    id = (n - 2) - (int) (merges_before + o.x);
+    const BinBox a = node_box[left], b = node_box[right];
+    BinBox u;
+    for (int x = 0; x < 3; x++) { u.lo[x] = fminf(a.lo[x], b.lo[x]); u.hi[x] = fmaxf(a.hi[x], b.hi[x]); }
+    node_box[id] = u;
+    count[id] = count[left] + count[right];
+    children[id] = make_int2(left, right);
+    parent[left] = id; parent[right] = id;
+  }
+  clusters_out[o.y] = id;
+}
+
+// Every subtree's primitives as one range of the output order: a node starts where the subtrees to the left of its path from the root end.
+__global__ void k_ploc_ranges(int n, const int2* __restrict__ children, const int* __restrict__ parent, const uint32_t* __restrict__ count, const uint32_t* __restrict__ ids,
+                              int2* __restrict__ ranges, uint32_t* __restrict__ prims) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= 2 * n - 1) return;
+  uint32_t first = 0;
+  for (int x = b, p = parent[b]; p >= 0; x = p, p = parent[p])
+    if (children[p].y == x) first += count[children[p].x];
+  ranges[b] = make_int2((int) first, (int) (first + count[b] - 1u));
+  if (b >= n - 1) prims[first] = ids[b - (n - 1)];
+}
+
 #define LBVH_TRY(expr) do { if ((expr) != hipSuccess) { ok = false; goto done; } } while (0)
 
 }  // namespace
 
-Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) {
+namespace {
+Bvh4 build_on_device(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth, bool ploc) {
   static_assert(sizeof(Aabb) == sizeof(BinBox), "box layouts must match");
   Bvh4 result;
   if (count < 2) return build_bvh4(boxes, count, max_leaf, max_depth);  // nothing to sort
@@ -198,6 +289,9 @@ Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
   uint64_t* d_codes = nullptr; uint64_t* d_codes_sorted = nullptr;
   uint32_t* d_ids = nullptr; uint32_t* d_ids_sorted = nullptr; uint32_t* d_arrivals = nullptr; uint32_t* d_counters = nullptr;
   int2* d_children = nullptr; int2* d_ranges = nullptr; int* d_parent = nullptr;
+  uint32_t* d_count = nullptr; uint32_t* d_prims = nullptr; int* d_clusters[2] = {nullptr, nullptr}; int* d_nearest = nullptr;
+  uint2* d_flags = nullptr; uint2* d_offsets = nullptr; uint2* d_totals = nullptr; void* d_scan_temp = nullptr;
+  size_t scan_bytes = 0;
   CollapseItem* d_queue[2] = {nullptr, nullptr};
   Bvh4Node* d_nodes = nullptr;
   void* d_temp = nullptr;
@@ -215,7 +309,7 @@ Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
   LBVH_TRY(hipMalloc((void**) &d_arrivals, sizeof(uint32_t) * count));
   LBVH_TRY(hipMalloc((void**) &d_counters, sizeof(uint32_t) * 4));
   LBVH_TRY(hipMalloc((void**) &d_children, sizeof(int2) * count));
-  LBVH_TRY(hipMalloc((void**) &d_ranges, sizeof(int2) * count));
+  LBVH_TRY(hipMalloc((void**) &d_ranges, sizeof(int2) * (2 * (size_t) count - 1)));
   LBVH_TRY(hipMalloc((void**) &d_parent, sizeof(int) * (2 * (size_t) count - 1)));
   LBVH_TRY(hipMalloc((void**) &d_queue[0], sizeof(CollapseItem) * count));
   LBVH_TRY(hipMalloc((void**) &d_queue[1], sizeof(CollapseItem) * count));
@@ -226,10 +320,47 @@ Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
   LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_codes, d_codes_sorted, d_ids, d_ids_sorted, n, 0, 63));
   LBVH_TRY(hipMalloc(&d_temp, temp_bytes ? temp_bytes : 16));
   LBVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_codes, d_codes_sorted, d_ids, d_ids_sorted, n, 0, 63));
-  hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const uint64_t*) d_codes_sorted, n, d_children, d_ranges, d_parent);
-  hipLaunchKernelGGL(k_lbvh_fit, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const BinBox*) d_boxes, (const uint32_t*) d_ids_sorted, n,
-                     (const int2*) d_children, (const int*) d_parent, d_node_box, d_arrivals);
-  LBVH_TRY(hipGetLastError());
+  if (!ploc) {
+    hipLaunchKernelGGL(k_lbvh_hierarchy, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const uint64_t*) d_codes_sorted, n, d_children, d_ranges, d_parent);
+    hipLaunchKernelGGL(k_lbvh_fit, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const BinBox*) d_boxes, (const uint32_t*) d_ids_sorted, n,
+                       (const int2*) d_children, (const int*) d_parent, d_node_box, d_arrivals, d_ranges);
+    LBVH_TRY(hipGetLastError());
+  }
+  else {
+    LBVH_TRY(hipMalloc((void**) &d_count, sizeof(uint32_t) * (2 * (size_t) count - 1)));
+    LBVH_TRY(hipMalloc((void**) &d_prims, sizeof(uint32_t) * count));
+    LBVH_TRY(hipMalloc((void**) &d_clusters[0], sizeof(int) * count));
+    LBVH_TRY(hipMalloc((void**) &d_clusters[1], sizeof(int) * count));
+    LBVH_TRY(hipMalloc((void**) &d_nearest, sizeof(int) * count));
+    LBVH_TRY(hipMalloc((void**) &d_flags, sizeof(uint2) * count));
+    LBVH_TRY(hipMalloc((void**) &d_offsets, sizeof(uint2) * count));
+    LBVH_TRY(hipMalloc((void**) &d_totals, sizeof(uint2)));
+    LBVH_TRY(hipcub::DeviceScan::ExclusiveScan(nullptr, scan_bytes, d_flags, d_offsets, AddPair(), make_uint2(0u, 0u), n));
+    LBVH_TRY(hipMalloc(&d_scan_temp, scan_bytes ? scan_bytes : 16));
+    hipLaunchKernelGGL(k_ploc_init, dim3((count + threads - 1) / threads), dim3(threads), 0, 0, (const BinBox*) d_boxes, (const uint32_t*) d_ids_sorted, n, d_node_box, d_count,
+                       d_clusters[0], d_parent);
+    int m = n, cur = 0;
+    uint32_t merges = 0;
+    while (m > 1) {
+      const uint32_t blocks = (uint32_t) (m + threads - 1) / threads;
+      hipLaunchKernelGGL(k_ploc_nearest, dim3((m + kPlocBlock - 1) / kPlocBlock), dim3(kPlocBlock), 0, 0, (const int*) d_clusters[cur], m, (const BinBox*) d_node_box, d_nearest);
+      hipLaunchKernelGGL(k_ploc_flags, dim3(blocks), dim3(threads), 0, 0, (const int*) d_nearest, m, d_flags);
+      size_t bytes = scan_bytes;
+      LBVH_TRY(hipcub::DeviceScan::ExclusiveScan(d_scan_temp, bytes, d_flags, d_offsets, AddPair(), make_uint2(0u, 0u), m));
+      hipLaunchKernelGGL(k_ploc_merge, dim3(blocks), dim3(threads), 0, 0, (const int*) d_clusters[cur], (const int*) d_nearest, (const uint2*) d_flags, (const uint2*) d_offsets, m, n,
+                         merges, d_children, d_parent, d_node_box, d_count, d_clusters[cur ^ 1], d_totals);
+      uint2 totals;
+      LBVH_TRY(hipMemcpy(&totals, d_totals, sizeof(totals), hipMemcpyDeviceToHost));
+      if (totals.x == 0u || (int) totals.y >= m) { ok = false; goto done; }  // cannot happen: the pair with the smallest union is always mutual
+      merges += totals.x;
+      m = (int) totals.y;
+      cur ^= 1;
+    }
+    if (merges != count - 1u) { ok = false; goto done; }
+    hipLaunchKernelGGL(k_ploc_ranges, dim3((2 * count - 1 + threads - 1) / threads), dim3(threads), 0, 0, n, (const int2*) d_children, (const int*) d_parent, (const uint32_t*) d_count,
+                       (const uint32_t*) d_ids_sorted, d_ranges, d_prims);
+    LBVH_TRY(hipGetLastError());
+  }
   {
     const CollapseItem root{0, 0u};
     LBVH_TRY(hipMemcpy(d_queue[0], &root, sizeof(root), hipMemcpyHostToDevice));
@@ -251,15 +382,20 @@ Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
   result.nodes.resize(node_count);
   result.prims.resize(count);
   LBVH_TRY(hipMemcpy(result.nodes.data(), d_nodes, sizeof(Bvh4Node) * node_count, hipMemcpyDeviceToHost));
-  LBVH_TRY(hipMemcpy(result.prims.data(), d_ids_sorted, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+  LBVH_TRY(hipMemcpy(result.prims.data(), ploc ? d_prims : d_ids_sorted, sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
   result.max_depth = depth;
 done:
   {
-    void* bufs[] = {d_boxes, d_node_box, d_codes, d_codes_sorted, d_ids, d_ids_sorted, d_arrivals, d_counters, d_children, d_ranges, d_parent, d_queue[0], d_queue[1], d_nodes, d_temp};
+    void* bufs[] = {d_boxes, d_node_box, d_codes, d_codes_sorted, d_ids, d_ids_sorted, d_arrivals, d_counters, d_children, d_ranges, d_parent, d_queue[0], d_queue[1], d_nodes, d_temp,
+                    d_count, d_prims, d_clusters[0], d_clusters[1], d_nearest, d_flags, d_offsets, d_totals, d_scan_temp};
     for (void* b : bufs) if (b) (void) hipFree(b);
   }
   if (!ok) return Bvh4();
   return result;
 }
+}  // namespace
+
+Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) { return build_on_device(boxes, count, max_leaf, max_depth, false); }
+Bvh4 build_bvh4_ploc(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) { return build_on_device(boxes, count, max_leaf, max_depth, true); }
 
 }  // namespace lum

@@ -308,7 +308,7 @@ int main(int argc, char** argv) {
   else {
     std::vector<uint32_t> order;
     const BinTree t = builder == "lbvh" ? build_lbvh_model(boxes, order) : build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 16);
-    bvh = collapse_model(t, order, kBvhLeafMaxTri);
+    bvh = collapse_model(t, order, std::getenv("BQ_MAX_LEAF") ? (uint32_t) std::atoi(std::getenv("BQ_MAX_LEAF")) : kBvhLeafMaxTri);
   }
   const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (bvh.nodes.empty()) { std::printf("build failed (too deep)\n"); return 1; }
