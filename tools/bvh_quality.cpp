@@ -194,7 +194,7 @@ static BinTree build_lbvh_model(const std::vector<Aabb>& boxes, std::vector<uint
   t.root = rec(0, n - 1);
   return t;
 }
-static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint32_t>& order, int radius) {
+static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint32_t>& order, int radius, size_t stop_at = 1, std::vector<int>* roots = nullptr) {
   std::vector<uint64_t> codes;
   order = morton_order(boxes, codes);
   const uint32_t n = (uint32_t) boxes.size();
@@ -205,7 +205,7 @@ static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint
   std::iota(cur.begin(), cur.end(), 0);
   std::vector<int> nn;
   int iterations = 0;
-  while (cur.size() > 1) {
+  while (cur.size() > stop_at) {
     const int m = (int) cur.size();
     nn.assign(m, -1);
 #pragma omp parallel for schedule(static)
@@ -234,7 +234,8 @@ static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint
     iterations++;
   }
   t.root = cur[0];
-  std::printf("ploc: radius %d, %d iterations\n", radius, iterations);
+  if (roots) *roots = cur;
+  std::printf("ploc: radius %d, %d iterations, %zu clusters left\n", radius, iterations, cur.size());
   return t;
 }
 // k_lbvh_collapse's rule: open the child with the largest box until there are four; a subtree of at most max_leaf primitives is a leaf.
@@ -283,6 +284,68 @@ static Bvh4 collapse_model(const BinTree& t, const std::vector<uint32_t>& order,
   return out;
 }
 
+// Top of the tree by the host's SAH builder over the boxes of the clusters PLOC stopped at, the clusters' subtrees collapsed below it.
+static Bvh4 hybrid_model(const BinTree& t, const std::vector<uint32_t>& order, const std::vector<int>& roots, uint32_t max_leaf) {
+  std::vector<Aabb> cb(roots.size());
+  for (size_t k = 0; k < roots.size(); k++) cb[k] = t.box[roots[k]];
+  const Bvh4 top = build_bvh4(cb.data(), (uint32_t) cb.size(), 1, 26);
+  Bvh4 out;
+  out.nodes = top.nodes;
+  out.max_depth = top.max_depth;
+  // primitive order: cluster after cluster (in the top tree's leaf order), depth-first inside
+  std::vector<uint32_t> first(t.left.size(), 0);
+  out.prims.resize(t.leaves);
+  uint32_t base = 0;
+  std::vector<uint32_t> cluster_first(roots.size());
+  for (uint32_t c : top.prims) {
+    cluster_first[c] = base;
+    std::vector<std::pair<int, uint32_t>> stack{{roots[c], base}};
+    while (!stack.empty()) {
+      auto [b, off] = stack.back(); stack.pop_back();
+      first[b] = off;
+      if (t.left[b] < 0) { out.prims[off] = order[b]; continue; }
+      stack.push_back({t.left[b], off});
+      stack.push_back({t.right[b], off + t.count[t.left[b]]});
+    }
+    base += t.count[roots[c]];
+  }
+  struct Item { int bin; uint32_t node4; uint32_t depth; };
+  std::vector<Item> queue;
+  auto is_leaf = [&](int b) { return t.count[b] <= max_leaf; };
+  for (Bvh4Node& n : out.nodes)
+    for (int k = 0; k < 4; k++) {
+      if (n.child[k] == kBvhEmpty || !(n.child[k] & kBvhLeafBit)) continue;
+      const uint32_t c = top.prims[n.child[k] & 0x0FFFFFFFu];  // one cluster per top-level leaf
+      const int b = roots[c];
+      if (is_leaf(b)) n.child[k] = kBvhLeafBit | ((t.count[b] - 1u) << 28) | first[b];
+      else { n.child[k] = (uint32_t) (out.nodes.size() + queue.size()); queue.push_back({b, n.child[k], top.max_depth + 1}); }
+    }
+  out.nodes.resize(out.nodes.size() + queue.size());
+  for (size_t q = 0; q < queue.size(); q++) {
+    const Item item = queue[q];
+    out.max_depth = std::max(out.max_depth, item.depth);
+    int kids[4]; int nk = 0;
+    kids[nk++] = t.left[item.bin]; kids[nk++] = t.right[item.bin];
+    while (nk < 4) {
+      int pick = -1; float best = -1.0f;
+      for (int k = 0; k < nk; k++) { if (is_leaf(kids[k])) continue; const float a = half_area(t.box[kids[k]]); if (a > best) { best = a; pick = k; } }
+      if (pick < 0) break;
+      const int b = kids[pick];
+      kids[pick] = t.left[b]; kids[nk++] = t.right[b];
+    }
+    Bvh4Node node;
+    for (int k = 0; k < 4; k++) { node.child[k] = kBvhEmpty; node.pad[k] = 0; node.lo_x[k] = node.lo_y[k] = node.lo_z[k] = 3.4e38f; node.hi_x[k] = node.hi_y[k] = node.hi_z[k] = -3.4e38f; }
+    for (int k = 0; k < nk; k++) {
+      const Aabb& b = t.box[kids[k]];
+      node.lo_x[k] = b.lo[0]; node.lo_y[k] = b.lo[1]; node.lo_z[k] = b.lo[2]; node.hi_x[k] = b.hi[0]; node.hi_y[k] = b.hi[1]; node.hi_z[k] = b.hi[2];
+      if (is_leaf(kids[k])) node.child[k] = kBvhLeafBit | ((t.count[kids[k]] - 1u) << 28) | first[kids[k]];
+      else { node.child[k] = (uint32_t) out.nodes.size(); queue.push_back({kids[k], (uint32_t) out.nodes.size(), item.depth + 1}); out.nodes.emplace_back(); }
+    }
+    out.nodes[item.node4] = node;
+  }
+  return out;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: bvh_quality vertices.f32 [rays]\n"); return 1; }
   FILE* f = std::fopen(argv[1], "rb");
@@ -307,8 +370,15 @@ int main(int argc, char** argv) {
   if (builder == "sah") bvh = build_bvh4(boxes.data(), nt, kBvhLeafMaxTri, 26);
   else {
     std::vector<uint32_t> order;
+    if (builder == "hybrid") {  // bvh_quality verts rays hybrid radius clusters
+      std::vector<int> roots;
+      const BinTree t = build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 8, argc > 5 ? (size_t) std::atoi(argv[5]) : 4096, &roots);
+      bvh = hybrid_model(t, order, roots, kBvhLeafMaxTri);
+    }
+    else {
     const BinTree t = builder == "lbvh" ? build_lbvh_model(boxes, order) : build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 16);
     bvh = collapse_model(t, order, std::getenv("BQ_MAX_LEAF") ? (uint32_t) std::atoi(std::getenv("BQ_MAX_LEAF")) : kBvhLeafMaxTri);
+    }
   }
   const double build_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (bvh.nodes.empty()) { std::printf("build failed (too deep)\n"); return 1; }
