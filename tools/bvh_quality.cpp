@@ -164,6 +164,19 @@ static std::vector<uint32_t> morton_order(const std::vector<Aabb>& boxes, std::v
     uint64_t q[3];
     for (int k = 0; k < 3; k++) { const float c = 0.5f * (boxes[i].lo[k] + boxes[i].hi[k]), e = std::max(all.hi[k] - all.lo[k], 1e-30f); q[k] = (uint64_t) std::min(std::max((c - all.lo[k]) / e * 2097152.0f, 0.0f), 2097151.0f); }
     codes[i] = spread21(q[0]) << 2 | spread21(q[1]) << 1 | spread21(q[2]);
+    if (std::getenv("BQ_EMC")) {  // extended Morton code (Vinkler et al. 2017): a size bit after every BQ_EMC position bits, large primitives separate early
+      const int every = std::atoi(std::getenv("BQ_EMC"));
+      float diag = 0, ext = 0;
+      for (int k = 0; k < 3; k++) { const float e = boxes[i].hi[k] - boxes[i].lo[k]; diag += e * e; const float a = all.hi[k] - all.lo[k]; ext += a * a; }
+      const uint64_t sz = (uint64_t) std::min(std::max(std::sqrt(diag / std::max(ext, 1e-30f)) * 1048576.0f, 0.0f), 1048575.0f);  // 20 bits
+      const uint64_t pos = codes[i];
+      uint64_t out = 0; int ob = 63, pb = 62, sb = 19, run = 0;
+      while (ob >= 0 && pb >= 0) {
+        if (run == every && sb >= 0) { out |= ((sz >> sb) & 1ull) << ob; sb--; ob--; run = 0; continue; }
+        out |= ((pos >> pb) & 1ull) << ob; pb--; ob--; run++;
+      }
+      codes[i] = out;
+    }
     order[i] = (uint32_t) i;
   }
   std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return codes[a] != codes[b] ? codes[a] < codes[b] : a < b; });
@@ -213,7 +226,10 @@ static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint
       float best = INFINITY; int bj = -1;
       for (int j = std::max(0, i - radius); j <= std::min(m - 1, i + radius); j++) {
         if (j == i) continue;
-        const float a = half_area(merge(t.box[cur[i]], t.box[cur[j]]));
+        float a = half_area(merge(t.box[cur[i]], t.box[cur[j]]));
+        static const int crit = std::getenv("BQ_PLOC_CRIT") ? std::atoi(std::getenv("BQ_PLOC_CRIT")) : 0;
+        if (crit == 1) a *= (float) (t.count[cur[i]] + t.count[cur[j]]);
+        else if (crit == 2) a -= half_area(t.box[cur[i]]) + half_area(t.box[cur[j]]);
         if (a < best) { best = a; bj = j; }  // ties: the lower index, on both sides of the pair
       }
       nn[i] = bj;
