@@ -48,6 +48,11 @@ __device__ unsigned long long g_phase_time[16];
 //   4 bounce + ambient record   5 sun   6 NEE stores, classification, roulette   7 appends   8 collecting hits (input rounds)   9 batches   10 candidate: pick + triangle sample
 //   11 candidate: colour + BSDF   12 candidate: MIS + reservoir
 __device__ unsigned long long g_shade_time[16];
+#if LUM_FAST
+#define g_vis_stat g_vis_stat_fast
+#endif
+// visibility rays by kind (0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun): [2k] rays, [2k+1] of them blocked by an opaque surface
+__device__ unsigned long long g_vis_stat[8];
 struct ShadeClock {
   unsigned long long t[16];
   unsigned long long last;

@@ -730,6 +730,9 @@ struct ShadowQuery : ShadowState {
   }
   LUM_DEV void finish(const DeviceScene&, uint32_t j) {
     const Col v = result();
+#ifdef LUM_PHASE_STATS
+    { const uint32_t kind = min(out / sq.capacity, 3u); atomicAdd(&g_vis_stat[2u * kind], 1ull); if (blocked) atomicAdd(&g_vis_stat[2u * kind + 1u], 1ull); }
+#endif
 #ifdef LUM_EXPERIMENT_VIS_IN_ITEM_ORDER
     sq.vis[j] = make_float4(v.r, v.g, v.b, 0.0f);
 #else

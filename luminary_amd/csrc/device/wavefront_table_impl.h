@@ -132,6 +132,11 @@ extern "C" int lumc_debug_phase_times_fast(uint64_t out[16], int reset) {
   if (reset) { const uint64_t zero[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_phase_time), zero, sizeof(zero)) != hipSuccess) return 1; }
   return 0;
 }
+extern "C" int lumc_debug_vis_stats_fast(uint64_t out[8], int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_vis_stat), sizeof(uint64_t) * 8) != hipSuccess) return 1;
+  if (reset) { const uint64_t zero[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_vis_stat), zero, sizeof(zero)) != hipSuccess) return 1; }
+  return 0;
+}
 extern "C" int lumc_debug_shade_times_fast(uint64_t out[16], int reset) {
   if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_shade_time), sizeof(uint64_t) * 16) != hipSuccess) return 1;
   if (reset) { const uint64_t zero[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_shade_time), zero, sizeof(zero)) != hipSuccess) return 1; }

@@ -61,3 +61,10 @@ if core.flavour == "fast" and hasattr(lib, "lumc_debug_shade_times_fast"):
     print("shade time (s_memtime ticks per wave, %d batches of 64 vertices; shares of %d ticks):" % (tm[9], total))
     for k, nm in names.items():
         print("  %-45s %6.1f %%   %8.1f ticks per batch" % (nm, 100.0 * tm[k] / max(total, 1), tm[k] / max(tm[9], 1)))
+if core.flavour == "fast" and hasattr(lib, "lumc_debug_vis_stats_fast"):
+    vs = (C.c_uint64 * 8)()
+    lib.lumc_debug_vis_stats_fast(vs, 1)
+    vs = [int(x) for x in vs]
+    for k, nm in enumerate(["sampled light (segment)", "BSDF-sampled light (segment)", "ambient (no end point)", "sun (no end point)"]):
+        if vs[2 * k]:
+            print("visibility rays, %-30s %12d, blocked by an opaque surface %.3f" % (nm, vs[2 * k], vs[2 * k + 1] / vs[2 * k]))
