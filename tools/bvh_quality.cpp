@@ -2,11 +2,18 @@
 // (dev_trace.h: nearest child first, far children stacked, closest-hit rays cull by the hit distance, visibility rays stop at the first hit).
 // The ray kernels' time follows the node visits (profiles/r03_ab_experiments.txt: +10 % visits = +28 % time on the hall), so builder changes can be judged
 // here before they go to the GPU.
-//   g++ -O2 -std=c++17 -fopenmp -I luminary_amd/csrc/host -o /tmp/bvh_quality tools/bvh_quality.cpp luminary_amd/csrc/host/bvh_build.cpp
+//   g++ -O2 -std=c++17 -fopenmp -I luminary_amd/csrc/host -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ -o /tmp/bvh_quality tools/bvh_quality.cpp luminary_amd/csrc/host/bvh_build.cpp -lpthread
 //   /tmp/bvh_quality vertices.f32 [rays] [sah|lbvh|ploc] [radius]     vertices.f32 = the mesh as the device scene holds it: 3 x float4 per triangle
 //   lbvh / ploc: CPU models of the GPU builders (lbvh.hip) - the Morton-ordered radix tree, and parallel locally-ordered clustering (Meister, Bittner 2018)
 //   over the same order - collapsed to 4-wide nodes by the rule k_lbvh_collapse uses; to judge a builder's trees before it is written for the GPU.
+//   hybrid: the SAH builder's tree over the boxes of the last K clusters of the clustering, the clusters' subtrees below it (argv: radius K).
 // Rays: origins on random triangles (pushed off the surface), cosine-distributed directions about the normal - what a path tracer's bounces look like.
+// Environment knobs (each a question that was asked of the model before anything was written for the GPU; answers in profiles/r03_ab_experiments.txt):
+//   BQ_ANYHIT_ORDER=1..8   child order of any-hit rays: 1 farthest entry first (what the visibility kernel does since), 2 largest box, 3 farthest exit, 4 longest overlap,
+//                          5 overlap x area, 6 / 8 farthest first in the first 4096 / 65536 nodes only, 7 everywhere but there;  BQ_ANYHIT_UNSORTED=1 stored order
+//   BQ_AXIS_ORDER=1|2      closest-hit rays: children ordered without distances, along the node's longest axis / the ray's dominant axis
+//   BQ_TIE=1|2             closest-hit rays: equal entry distances broken by the longer / shorter stay in the box
+//   BQ_MAX_LEAF=n          leaf size of the lbvh / ploc models;  BQ_PLOC_CRIT=1|2 merge criterion;  BQ_EMC=n extended Morton codes with a size bit every n position bits
 #include <chrono>
 #ifdef _OPENMP
 #include <omp.h>
