@@ -369,6 +369,82 @@ static Bvh4 hybrid_model(const BinTree& t, const std::vector<uint32_t>& order, c
   return out;
 }
 
+// ---- 8-wide model: the 4-wide tree's nodes widened by opening their largest inner children until there are eight; walked nearest first (exact
+// entry distances) or in the order of the children's centres along the ray's octant diagonal (what a node with children stored in octant order gives
+// without computing or sorting any distance) ----
+struct Wide { float lo[8][3], hi[8][3]; uint32_t child[8]; int n; };
+static std::vector<Wide> widen(const Bvh4& b) {
+  std::vector<Wide> out;
+  struct Item { uint32_t node4; uint32_t wide; };
+  std::vector<Item> queue{{0u, 0u}};
+  out.emplace_back();
+  for (size_t q = 0; q < queue.size(); q++) {
+    struct Kid { Aabb box; uint32_t ref; };
+    std::vector<Kid> kids;
+    auto add_children = [&](uint32_t n4) {
+      const Bvh4Node& n = b.nodes[n4];
+      for (int k = 0; k < 4; k++) if (n.child[k] != kBvhEmpty) kids.push_back({Aabb{{n.lo_x[k], n.lo_y[k], n.lo_z[k]}, {n.hi_x[k], n.hi_y[k], n.hi_z[k]}}, n.child[k]});
+    };
+    add_children(queue[q].node4);
+    while (true) {
+      int pick = -1; float best = -1.0f;
+      for (size_t k = 0; k < kids.size(); k++) {
+        if (kids[k].ref & kBvhLeafBit) continue;
+        const Bvh4Node& c = b.nodes[kids[k].ref];
+        int cn = 0; for (int j = 0; j < 4; j++) cn += c.child[j] != kBvhEmpty;
+        if (kids.size() - 1 + cn > 8) continue;
+        const float a = half_area(kids[k].box);
+        if (a > best) { best = a; pick = (int) k; }
+      }
+      if (pick < 0) break;
+      const uint32_t open = kids[pick].ref;
+      kids.erase(kids.begin() + pick);
+      add_children(open);
+    }
+    Wide w; w.n = (int) kids.size();
+    for (int k = 0; k < w.n; k++) {
+      for (int a = 0; a < 3; a++) { w.lo[k][a] = kids[k].box.lo[a]; w.hi[k][a] = kids[k].box.hi[a]; }
+      if (kids[k].ref & kBvhLeafBit) w.child[k] = kids[k].ref;
+      else { w.child[k] = (uint32_t) out.size(); queue.push_back({kids[k].ref, (uint32_t) out.size()}); out.emplace_back(); }
+    }
+    out[queue[q].wide] = w;
+  }
+  return out;
+}
+static void walk_wide(const std::vector<Wide>& nodes, const Bvh4& bvh, const std::vector<float>& verts, V o, V d, bool octant_order, Stats& st) {
+  const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, oo[3] = {o.x, o.y, o.z}, sg[3] = {d.x < 0 ? -1.0f : 1.0f, d.y < 0 ? -1.0f : 1.0f, d.z < 0 ? -1.0f : 1.0f};
+  struct E { uint32_t node; float t; };
+  E stack[512]; int sp = 0; uint32_t cur = 0; float best = INFINITY;
+  st.rays++;
+  while (true) {
+    if (cur & kBvhLeafBit) {
+      const uint32_t first = cur & 0x0FFFFFFFu, count = ((cur >> 28) & 7u) + 1u;
+      st.leaves++;
+      for (uint32_t j = 0; j < count; j++) { st.tris++; const float t = hit_tri(&verts[(size_t) bvh.prims[first + j] * 12], o, d); if (t < best) best = t; }
+    }
+    else {
+      st.nodes++;
+      const Wide& n = nodes[cur];
+      float k[8], key[8]; uint32_t c[8]; int m = 0;
+      for (int j = 0; j < n.n; j++) {
+        float tn = 0.0f, tf = best;
+        for (int a = 0; a < 3; a++) { float t0 = (n.lo[j][a] - oo[a]) * inv[a], t1 = (n.hi[j][a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+        if (tn > tf) continue;
+        k[m] = tn; c[m] = n.child[j];
+        key[m] = octant_order ? sg[0] * (n.lo[j][0] + n.hi[j][0]) + sg[1] * (n.lo[j][1] + n.hi[j][1]) + sg[2] * (n.lo[j][2] + n.hi[j][2]) : tn;
+        m++;
+      }
+      for (int a = 0; a < m; a++) for (int b2 = a + 1; b2 < m; b2++) if (key[b2] < key[a]) { std::swap(key[a], key[b2]); std::swap(k[a], k[b2]); std::swap(c[a], c[b2]); }
+      for (int j = m - 1; j >= 1; j--) stack[sp++] = {c[j], k[j]};
+      if (m > 0) { cur = c[0]; continue; }
+    }
+    bool found = false;
+    while (sp > 0) { const E e = stack[--sp]; if (e.t <= best) { cur = e.node; found = true; break; } }
+    if (!found) break;
+  }
+  if (best < INFINITY) st.hits++;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: bvh_quality vertices.f32 [rays]\n"); return 1; }
   FILE* f = std::fopen(argv[1], "rb");
@@ -442,6 +518,38 @@ int main(int argc, char** argv) {
     {
       closest.nodes += c.nodes; closest.leaves += c.leaves; closest.tris += c.tris; closest.rays += c.rays; closest.hits += c.hits;
       shadow.nodes += s.nodes; shadow.leaves += s.leaves; shadow.tris += s.tris; shadow.rays += s.rays; shadow.hits += s.hits;
+    }
+  }
+  if (std::getenv("BQ_WIDE")) {
+    const std::vector<Wide> wide = widen(bvh);
+    double kids8 = 0; for (const Wide& w : wide) kids8 += w.n;
+    for (int mode = 0; mode < 2; mode++) {
+      Stats ws;
+#pragma omp parallel
+      {
+        Stats c;
+        std::mt19937 rng(1234u + 977u * (unsigned) omp_get_thread_num());
+        std::uniform_real_distribution<float> U(0.0f, 1.0f);
+#pragma omp for schedule(static)
+        for (int64_t i = 0; i < (int64_t) nrays; i++) {
+          const uint32_t t = (uint32_t) (U(rng) * nt) % nt;
+          const float* p = &verts[(size_t) t * 12];
+          const V p0{p[0], p[1], p[2]}, e1 = sub(V{p[4], p[5], p[6]}, p0), e2 = sub(V{p[8], p[9], p[10]}, p0);
+          float u = U(rng), v = U(rng);
+          if (u + v > 1) { u = 1 - u; v = 1 - v; }
+          V n = norm(cross(e1, e2));
+          if (U(rng) < 0.5f) n = mul(n, -1.0f);
+          const V o = add(add(p0, add(mul(e1, u), mul(e2, v))), mul(n, 1e-3f));
+          const float r1 = U(rng), r2 = U(rng), phi = 6.2831853f * r1, sr = std::sqrt(r2);
+          const V tan = norm(std::fabs(n.x) < 0.9f ? cross(n, V{1, 0, 0}) : cross(n, V{0, 1, 0})), bit = cross(n, tan);
+          const V d = norm(add(add(mul(tan, sr * std::cos(phi)), mul(bit, sr * std::sin(phi))), mul(n, std::sqrt(1 - r2))));
+          walk_wide(wide, bvh, verts, o, d, mode == 1, c);
+        }
+#pragma omp critical
+        { ws.nodes += c.nodes; ws.leaves += c.leaves; ws.tris += c.tris; ws.rays += c.rays; ws.hits += c.hits; }
+      }
+      std::printf("8-wide (%zu nodes, %.2f children per node), %s: nodes %.2f  leaves %.2f  triangles %.2f per closest-hit ray\n", wide.size(), kids8 / wide.size(),
+                  mode ? "children in octant-diagonal order (no distances)" : "nearest first", ws.nodes / ws.rays, ws.leaves / ws.rays, ws.tris / ws.rays);
     }
   }
   std::printf("closest: nodes %.2f  leaves %.2f  triangles %.2f per ray (hit %.2f)\n", closest.nodes / closest.rays, closest.leaves / closest.rays, closest.tris / closest.rays, closest.hits / closest.rays);
