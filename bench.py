@@ -16,7 +16,9 @@ Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x108
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
-Prints ONE JSON line on rank 0.
+Prints ONE JSON line on rank 0, as the LAST line of stdout, at most 4 KB (`headline`): the contract's fields, the dominant kernel's roofline, the three
+big kernels in brief, value_exact (the bit-exact flavour on the same scene), the CPU baseline, the secondaries' values. Everything else - prose, ceilings,
+L2 figures, per-ray counts, the secondaries' own blocks - goes to profiles/bench_detail.json (written by the same run) and to stderr.
 
 roofline: the block of the kernel that took most of the timed region, chosen over ALL kernels; the three big kernels are also
 reported by name (roofline_trace, roofline_shadow, roofline_shade). For a ray kernel
@@ -49,11 +51,12 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 L2_PEAK_GBPS = 34500.0   # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate
-# wave64 VALU instructions per second the chip issues: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles (a 16-lane SIMD passes a wave64 instruction in four) = 614.4 G/s.
-# Measured (tools/microbench/valu_rate.hip, profiles/r03_valu_rate.txt, 4 waves per SIMD): v_fma_f32 618-632, v_cmp+v_cndmask 644, two-operand VOP2 forms
-# (v_mul_f32, v_fmac_f32) 846-924, v_pk_fma_f32 449-462 (two results each), v_rcp_f32 / v_sqrt_f32 300. Rounds 1-2 priced k_shade against 1228.8 (2 cycles
-# per instruction), which no instruction mix of this kernel can reach: its "0.48" was 0.97 of this figure.
-VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
+# wave64 VALU instructions per second. The guide's vector peak (157.3 TFLOP/s f32) is one wave64 FMA per 2 cycles and SIMD: 256 CUs x 4 SIMDs x 2.4 GHz / 2
+# = 1228.8 G/s; k_shade's `frac` is priced against that. tools/microbench/valu_rate.hip (profiles/r03_valu_rate.txt, 4 waves per SIMD) measures what single
+# instruction kinds reach: v_fma_f32 (VOP3) 618-632 G/s, v_cmp+v_cndmask 644, two-operand VOP2 forms (v_mul_f32, v_fmac_f32) 846-924, v_pk_fma_f32 449-462 (two results
+# each), v_rcp_f32 / v_sqrt_f32 300: one instruction's rate is not a peak, so the 614.4 figure is only quoted beside it (frac_of_measured_fma_rate).
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0          # MI355X_MICROARCH.md (157.3 TF vector f32 = 2 flops x 64 lanes x this): 1228.8 G wave64 instructions/s - the peak `frac` is priced against
+VALU_MEASURED_FMA_GINST = 256 * 4 * 2.4 / 4.0  # what tools/microbench/valu_rate.hip measures for v_fma_f32 (VOP3): 614.4 G/s - reported as frac_of_measured_fma_rate, not as a peak
 NODE_BYTES, TRI_BYTES = 112, 48  # one node visit fetches 7 x 16 B of a 128-B BVH4 node; triangle = 48 B (DESIGN.md "Algorithmic bytes")
 IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
 IO_SHADOW_BYTES = 24 + 4 + 12  # origin+dir, tmax, RGB visibility
@@ -175,6 +178,7 @@ def cpu_baseline(view, budget_s):
     except OSError:
         pass
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port", "cpu": model,
+            "sample_short": "oracle/ (scalar C restatement, OpenMP) on %d pixels x %d spp of the same frame, 9 depth passes: %.3g rays in %.1f s" % (npx, spp, rays, dt),
             "note": "unoptimised test oracle (scalar C restatement written for bit-exact checking, not for speed): a reported baseline, not a target",
             "sample": "oracle/ (CPU restatement, OpenMP over pixels, %d threads) on %d pixels x %d spp of the same frame, all 9 depth passes: "
                       "%.0f rays in %.1f s (its %.1f s BVH build excluded)" % (cores, npx, spp, rays, dt, t_build)}
@@ -193,7 +197,7 @@ def spawn_distributed(n):
     return subprocess.call(cmd, env=env)
 
 
-def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output_chain):
+def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output_chain, exact_steps=0):
     """Uploads workload `name`, times `steps` passes after `warmup` untimed ones (barrier + synchronize on both sides, max over ranks) and
     returns (json dict, device scene view)."""
     import torch
@@ -301,6 +305,25 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
             per = out_ms / out_n
             output_chain = {"ms_per_frame": round(per, 4), "GB/s": round(40.0 * view.width * view.height / (per * 1e-3) / 1e9, 1),
                             "frac_of_hbm_peak": round(40.0 * view.width * view.height / (per * 1e-3) / 1e9 / HBM_PEAK_GBPS, 3)}
+    # the bit-exact flavour (what every parity test runs) on the same uploaded scene: a driver-timed number for the path that is identical to the oracle
+    exact = None
+    if exact_steps > 0 and dist is None and core.flavour != "exact":
+        was = core.flavour
+        core.set_flavour("exact")
+        step(0)
+        torch.cuda.synchronize()
+        core.synchronize()
+        core.reset_counters()
+        te = time.time()
+        for i in range(exact_steps):
+            step(1 + i)
+        torch.cuda.synchronize()
+        core.synchronize()
+        te = time.time() - te
+        ce = core.counters()
+        exact = {"value": (ce[CNT_TRACE] + ce[CNT_SHADOW] + ce[CNT_LIGHT_BVH]) / te / 1e6, "unit": "Mrays/s", "flavour": "exact", "steps": exact_steps, "warmup": 1,
+                 "ms_per_step": te / exact_steps * 1e3, "samples_per_s": view.width * view.height * spp_step * exact_steps / te}
+        core.set_flavour(was)
     rays_local = cnt[CNT_TRACE] + cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]
     stats = torch.tensor([float(rays_local), float(cnt[CNT_TRACE]), float(cnt[CNT_SHADOW]), float(cnt[CNT_LIGHT_BVH]), elapsed], dtype=torch.float64,
                          device="cuda")
@@ -371,6 +394,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         if r["traffic"] is not None and e.get("valu_insts_per_launch"):
             r["achieved"] = e["valu_insts_per_launch"] / (avg_ms * 1e-3) / 1e9
             r["frac"] = r["achieved"] / VALU_PEAK_GINST
+            r["frac_of_measured_fma_rate"] = r["achieved"] / VALU_MEASURED_FMA_GINST
             r["valu_insts_per_launch"] = e["valu_insts_per_launch"]
             r["lane_utilisation"], r["wait_fraction"] = e.get("valu_lane_utilisation"), e.get("wait_fraction")
             r["valu_insts_per_vertex_lane"] = e["valu_insts_per_launch"] * 64.0 * (e.get("valu_lane_utilisation") or 0.0) / max(r["vertices_per_launch"], 1.0)
@@ -388,6 +412,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                    "frame_reduce": None if dist is None else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
                    "rccl_ranks": None if dist is None else (core.comm_count() if cabi else dist.get_world_size()),  # ncclCommCount of the library's own communicator
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
+                   "seconds_to_1024spp": 1024.0 / (spp_step * steps / elapsed),
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2),
@@ -397,6 +422,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                    "output_chain_rank0": output_chain, "scene_build_s": round(build_s, 2), "scene_upload_s": round(upload_s, 2)},
         "roofline": roofline, "roofline_trace": blocks["trace"], "roofline_shadow": blocks["shadow"], "roofline_shade": blocks["shade"],
     }
+    out["value_exact"] = exact
     return out, view
 
 
@@ -408,6 +434,7 @@ def main():
     ap.add_argument("--workload", default="hall", choices=sorted(WORKLOADS))
     ap.add_argument("--secondary", default="example,scan", help="workloads timed after the headline at N = 1 and reported under 'secondary' ('none' skips them)")
     ap.add_argument("--secondary-steps", type=int, default=4)
+    ap.add_argument("--exact-steps", type=int, default=4, help="N = 1: steps of the headline workload timed once more in the bit-exact flavour (value_exact; 0 skips)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
@@ -456,18 +483,27 @@ def main():
             dist.broadcast_object_list(ids, src=0)
             core.comm_init_rank(world, rank, ids[0])
             ok = torch.ones(1, device="cuda")
-        except Exception as e:  # noqa: BLE001 - any failure here falls back to torch's reduce, on every rank
-            sys.stderr.write("rank %d: C-ABI communicator failed (%s); torch.distributed reduces instead\n" % (rank, e))
+        except Exception as e:  # noqa: BLE001 - reported by every rank, then the run ends non-zero: `--reduce torch` is the way to ask for torch's reduce
+            sys.stderr.write("rank %d: C-ABI communicator failed (%s)\n" % (rank, e))
             ok = torch.zeros(1, device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         core._bench_comm = bool(ok.item() > 0)
-    head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True)
+        if not core._bench_comm:
+            dist.destroy_process_group()
+            raise SystemExit("bench.py: the library's RCCL communicator (lumc_comm_init_rank) could not be created on every rank; "
+                             "run with --reduce torch to reduce through torch.distributed instead")
+        if core.comm_count() != world:
+            dist.destroy_process_group()
+            raise SystemExit("bench.py: the library's communicator reports %d ranks, the job has %d" % (core.comm_count(), world))
+    head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True, exact_steps=args.exact_steps)
+    exact = head.pop("value_exact", None)
     # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
     cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and dist is None and args.sky == "constant" and rank == 0) else None
     secondary = {}
     if dist is None and args.secondary != "none":
         for name in [s for s in args.secondary.split(",") if s and s != args.workload]:
             sec, _ = run_workload(core, name, args, rank, world, None, args.secondary_steps, 1, False)
+            sec.pop("value_exact", None)
             secondary[name] = sec
     if dist is not None:
         dist.barrier()
@@ -482,12 +518,76 @@ def main():
             head["config"]["fast_vs_exact_note"] = gate["note"]
     except (OSError, KeyError, ValueError):
         pass
-    out = {"metric": "Mrays/s at 1920x1080, 8 bounces", "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-           "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-           "config": head["config"], "roofline": head["roofline"], "roofline_trace": head["roofline_trace"], "roofline_shadow": head["roofline_shadow"],
-           "roofline_shade": head["roofline_shade"],
-           "cpu_baseline": cpu, "secondary": secondary or None}
-    print(json.dumps(out))
+    detail = {"metric": METRIC, "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": head["config"], "roofline": head["roofline"], "roofline_trace": head["roofline_trace"], "roofline_shadow": head["roofline_shadow"],
+              "roofline_shade": head["roofline_shade"], "value_exact": exact, "cpu_baseline": cpu, "secondary": secondary or None}
+    # Everything goes to the sidecar (and to stderr); stdout's LAST line is the headline alone, a few KB: the driver keeps the tail of stdout only.
+    detail_path = os.path.join(ROOT, "profiles", "bench_detail.json")
+    try:
+        with open(detail_path, "w") as f:
+            json.dump(detail, f, indent=1)
+            f.write("\n")
+    except OSError as e:
+        sys.stderr.write("bench.py: could not write %s (%s)\n" % (detail_path, e))
+    sys.stderr.write("bench detail: " + json.dumps(detail) + "\n")
+    sys.stderr.flush()
+    line = json.dumps(headline(detail))
+    assert len(line) <= 4096, "headline grew to %d bytes" % len(line)
+    print(line)
+    sys.stdout.flush()
+
+
+METRIC = "Mrays/s at 1920x1080, 8 bounces"
+
+
+def _r(x, digits=5):
+    """numbers of the headline carry `digits` significant digits"""
+    if isinstance(x, float):
+        return float("%.*g" % (digits, x))
+    return x
+
+
+def headline(d):
+    """The one JSON line the driver parses: the contract's fields, the dominant kernel's roofline in full, the three big kernels in brief, the CPU
+    baseline, the secondaries' values. Prose, ceilings, L2 figures, per-ray counts and the secondaries' blocks live in profiles/bench_detail.json."""
+    c = d["config"]
+    cfg_keys = ["workload", "width", "height", "max_ray_depth", "flavour", "spp_per_step", "paths_per_gpu_per_step", "partition", "frame_reduce", "rccl_ranks",
+                "samples_per_s", "seconds_to_1024spp", "rays", "rays_answered_without_trace", "mrays_per_s_answered", "ambient_reuse", "bvh", "source_hash",
+                "fast_vs_exact_rel_l2_1024spp", "kernel_share_rank0"]
+    cfg = {k: c[k] for k in cfg_keys if c.get(k) is not None}
+
+    def brief(r, full=False):
+        keys = ["kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches"] if full else ["kernel", "bound", "frac", "traffic", "avg_launch_ms"]
+        out = {k: r.get(k) for k in keys}
+        for k in ("frac_of_measured_fma_rate", "frac_of_dependent_gather_ceiling", "lane_utilisation", "wait_fraction"):
+            if r.get(k) is not None:
+                out[k] = r[k]
+        if r.get("traffic") is None and r.get("traffic_stale"):
+            out["traffic_stale"] = "counters in profiles/pmc_counters.json are of source %s, this build is %s" % (r["traffic_stale"].get("source_hash_then"), r["traffic_stale"].get("source_hash_now"))
+        return out
+
+    h = {k: d[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    h["config"] = cfg
+    h["roofline"] = brief(d["roofline"], True)
+    for k in ("roofline_trace", "roofline_shadow", "roofline_shade"):
+        h[k] = brief(d[k])
+    if d.get("value_exact"):
+        h["value_exact"] = d["value_exact"]
+    if d.get("cpu_baseline"):
+        b = d["cpu_baseline"]
+        h["cpu_baseline"] = {"value": b["value"], "unit": b["unit"], "cores": b["cores"], "kind": b["kind"], "cpu": b.get("cpu"), "sample": b.get("sample_short", b.get("sample", ""))[:160]}
+    if d.get("secondary"):
+        h["secondary"] = {n: {"value": s["value"], "ms_per_step": s["ms_per_step"], "steps": s["steps"], "samples_per_s": s["config"].get("samples_per_s")} for n, s in d["secondary"].items()}
+    h["detail"] = "profiles/bench_detail.json"
+
+    def rnd(o):
+        if isinstance(o, dict):
+            return {k: rnd(v) for k, v in o.items()}
+        if isinstance(o, list):
+            return [rnd(v) for v in o]
+        return _r(o)
+    return rnd(h)
 
 
 if __name__ == "__main__":
