@@ -96,6 +96,10 @@ std::vector<uint32_t> embedded_bluenoise() {
 
 void invalidate(LuminaryHost* h, uint32_t dirty = LUMC_DIRTY_ALL) {
   h->scene_dirty |= dirty; h->core_dirty |= dirty;
+  // An adaptive accumulation ends with the edit. The context leaves adaptive mode in lumc_set_pixels only, and an unchanged frame size would keep the
+  // pixel set (ensure_core): without this, a uniform render after `enable_adaptive_sampling = false` ran on a context whose result image still
+  // normalised by the stale per-block sample counts.
+  if (h->adaptive_active) h->num_pixels = 0;
   h->device_scene_valid = false; h->core_scene_valid = false; h->accumulated_samples = 0; h->adaptive_active = false;
   for (auto& slot : h->devices) { slot.scene_valid = false; slot.dirty |= dirty; }
   { std::lock_guard<std::mutex> l(h->worker_mutex); h->async_failed = false; }  // the edit may have repaired what failed

@@ -40,6 +40,8 @@ struct LumContext {
   std::vector<Bvh4> mesh_bvh;
   std::vector<Aabb> mesh_box;
   std::vector<uint32_t> sky_lut_key;  // the sky parameters the two sky tables were generated from
+  float* d_bridge_lut = nullptr;      // the bridge sampler's vertex-count table (context-owned: scene.bridge_lut points here while bridges are possible)
+  std::vector<float> bridge_lut_host; // its content, to notice a caller that hands over another table
   float4* d_sky_lut[2] = {nullptr, nullptr};
   DeviceScene scene{};
   bool has_scene = false;
@@ -179,6 +181,8 @@ void free_scene(LumContext* ctx) {
   for (int i = 0; i < 4; i++) { if (ctx->d_luts[i]) (void) hipFree(ctx->d_luts[i]); ctx->d_luts[i] = nullptr; }
   for (int i = 0; i < 2; i++) { if (ctx->d_sky_lut[i]) (void) hipFree(ctx->d_sky_lut[i]); ctx->d_sky_lut[i] = nullptr; }
   ctx->sky_lut_key.clear();
+  if (ctx->d_bridge_lut) (void) hipFree(ctx->d_bridge_lut);
+  ctx->d_bridge_lut = nullptr; ctx->bridge_lut_host.clear();
   ctx->mesh_bvh.clear(); ctx->mesh_box.clear();
   ctx->has_scene = false;
 }
@@ -1189,15 +1193,7 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   sc.fog_density = v->fog_density; sc.fog_dist = v->fog_dist; sc.fog_height = v->fog_height;
   std::memcpy(sc.fog_phase, v->fog_phase, sizeof(sc.fog_phase));
   sc.bridge_max_num_vertices = v->bridge_max_num_vertices;
-  sc.bridge_lut = nullptr;
-  if (sc.fog_active) {
-    if (!(sc.fog_density > 0.0f)) { ctx->error = "lumc_scene_upload: fog needs a positive density"; return 1; }
-    if (sc.num_lights > 0) {  // bridges to the emissive triangles need the vertex-count table and at least one vertex
-      if (!v->bridge_lut) { ctx->error = "lumc_scene_upload: fog with emissive triangles needs bridge_lut"; return 1; }
-      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
-      if (upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
-    }
-  }
+  if (sc.fog_active && !(sc.fog_density > 0.0f)) { ctx->error = "lumc_scene_upload: fog needs a positive density"; return 1; }
   // ---- ocean ----
   sc.ocean_active = v->ocean_active ? 1u : 0u;
   sc.ocean_height = v->ocean_height; sc.ocean_amplitude = v->ocean_amplitude; sc.ocean_frequency = v->ocean_frequency;
@@ -1212,11 +1208,6 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   sc.ocean_triangle_light_contribution = v->ocean_triangle_light_contribution ? 1u : 0u;
   if (sc.ocean_active) {
     if (!(sc.ocean_refractive_index >= 1.0f)) { ctx->error = "lumc_scene_upload: the ocean needs a refractive index of at least 1"; return 1; }
-    if (sc.ocean_triangle_light_contribution && sc.num_lights > 0) {  // bridges in the water
-      if (!v->bridge_lut) { ctx->error = "lumc_scene_upload: an ocean lit by emissive triangles needs bridge_lut"; return 1; }
-      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
-      if (!sc.bridge_lut && upload(ctx, v->bridge_lut, (size_t) 64 * 21, &sc.bridge_lut)) return 1;
-    }
   }
   // ---- clouds ----
   sc.cloud_active = v->cloud_active ? 1u : 0u;
@@ -1283,6 +1274,26 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
       sc.sky_lut_multiscattering = ctx->d_sky_lut[1];
     }
   }
+  // ---- bridges to emissive triangles (fog, or an ocean with triangle_light_contribution): the vertex-count table. Decided after EVERY update, not
+  // only when the constants are dirty: a material that becomes emissive (MATERIALS | LIGHTS) gives a fogged scene its first light, and
+  // bridges_vertex_count_importance reads the table without a check. The table lives in the context (5 KB, uploaded once per content). ----
+  {
+    const bool need_bridges = (sc.fog_active || (sc.ocean_active && sc.ocean_triangle_light_contribution)) && sc.num_lights > 0 && sc.light_tree_root;
+    sc.bridge_lut = nullptr;
+    if (need_bridges) {
+      if (!v->bridge_lut) { ctx->error = sc.fog_active ? "lumc_scene_upload: fog with emissive triangles needs bridge_lut" : "lumc_scene_upload: an ocean lit by emissive triangles needs bridge_lut"; return 1; }
+      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
+      const size_t n = (size_t) 64 * 21;
+      if (!ctx->d_bridge_lut || ctx->bridge_lut_host.size() != n || std::memcmp(ctx->bridge_lut_host.data(), v->bridge_lut, n * sizeof(float)) != 0) {
+        if (!ctx->d_bridge_lut) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_bridge_lut, n * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bridge_lut, v->bridge_lut, n * sizeof(float), hipMemcpyHostToDevice));
+        ctx->bridge_lut_host.assign(v->bridge_lut, v->bridge_lut + n);
+      }
+      sc.bridge_lut = ctx->d_bridge_lut;
+    }
+  }
+  // the moon's texture ids follow the texture pool (the host layer appends the two moon textures behind the scene's own): an added texture moves them
+  sc.sky_moon_albedo_tex = v->sky_moon_albedo_tex; sc.sky_moon_normal_tex = v->sky_moon_normal_tex;
   // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
   const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
   const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};

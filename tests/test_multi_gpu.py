@@ -210,3 +210,34 @@ def test_host_tiles_adaptive_sampling_and_keeps_the_preview(tmp_path, monkeypatc
         assert np.array_equal(a[6][0], b[6][0]), "per-block rates"
         assert np.array_equal(a[6][1], b[6][1]), "block variances of the last build"
         assert len(np.unique(a[6][0])) > 1, "the rates differ over the frame (otherwise the test proves little)"
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_reduces_through_the_c_abi():
+    """The command line the driver's multi-GPU bench uses, with one rank (what a one-GPU box offers): `python -m torch.distributed.run --nproc-per-node 1
+    bench.py --gpus 1 ...` must take the distributed path - tile deal, the library's own RCCL communicator made from rank 0's id, lumc_frame_assemble -
+    and say so in its line; a communicator failure ends the run non-zero (bench.py), so rc 0 here means RCCL took the frame."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.pop("LUM_FLAVOUR", None)  # the bench's own default
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--workload", "cornell", "--width", "256", "--height", "192", "--steps", "1", "--warmup", "1",
+           "--samples-per-pass", "4", "--cpu-budget", "0", "--secondary", "none"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    assert len(line) <= 4096
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["config"]["frame_reduce"].startswith("C ABI"), out["config"]["frame_reduce"]
+    assert out["config"]["rccl_ranks"] == 1
+    assert out["config"]["partition"].startswith("32x32")

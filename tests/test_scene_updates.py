@@ -214,3 +214,89 @@ def test_the_encoder_re_encodes_only_what_an_edit_touched_and_gets_the_same_scen
     for key in want:
         assert got[key] == want[key], "'%s' differs after the partial update '%s'" % (key, edit)
     a.close(); b.close()
+
+
+# ---- round 4: the three partial-update paths the advisor found untested ----
+
+@pytest.mark.gpu
+def test_first_emitter_in_a_fogged_scene_arrives_by_a_material_edit():
+    """Fog, no emissive triangle at the first upload; then a material becomes emissive (MATERIALS | LIGHTS, no CONSTANTS): the bridge sampler's
+    vertex-count table has to reach the device with the first light (it used to be uploaded with the constants only: a GPU memory fault)."""
+    def fogged():
+        h = scenes.edge_scene("no_lights", 48, 32, 4)
+        fog = h.get_fog()
+        fog.active, fog.density = True, 40.0
+        h.set_fog(fog)
+        return h
+
+    def glow(h):
+        m = h.get_material(1)
+        m.emission_active = True
+        m.emission.r, m.emission.g, m.emission.b = 6.0, 5.0, 4.0
+        h.set_material(1, m)
+
+    a = fogged()
+    dark = _frame(a)
+    glow(a)
+    got = _frame(a)
+    b = fogged()
+    glow(b)
+    want = _frame(b)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert not np.array_equal(got[0], dark[0])
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_a_texture_added_after_rendering_moves_the_moon_textures():
+    """Procedural sky: the host layer appends the moon's two textures behind the scene's own, so luminary_ext_add_texture after a render shifts their
+    ids (TEXTURES | LIGHTS, no CONSTANTS); the context has to follow or the moon is shaded with the new texture."""
+    from test_sky import _night_scene  # the example scene at night through a long lens, the moon on the optical axis
+
+    def night():
+        return _night_scene()[0]
+
+    tex = (np.arange(16 * 16 * 4, dtype=np.uint32) * 37 % 251).astype(np.uint8).reshape(16, 16, 4)
+    a = night()
+    _frame(a)
+    a.add_texture(tex)
+    got = _frame(a)
+    b = night()
+    b.add_texture(tex)
+    want = _frame(b)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_switching_adaptive_sampling_off_leaves_adaptive_mode(tmp_path):
+    """Adaptive render, then `enable_adaptive_sampling = false` with the frame size unchanged: the next (uniform) render and its result image equal a
+    host that never was adaptive (the context used to stay in adaptive mode and normalise by the stale per-block sample counts)."""
+    def settings(h, adaptive):
+        s = h.get_settings()
+        s.enable_adaptive_sampling = adaptive
+        s.adaptive_sampling_max_sampling_rate, s.adaptive_sampling_avg_sampling_rate, s.adaptive_sampling_update_interval = 8, 2, 2
+        h.set_settings(s)
+
+    def image(h, samples):
+        promise = h.request_output(samples, 48, 48)
+        h.render(samples)
+        handle = h.try_await_output(promise)
+        assert handle is not None
+        img, count, _ = h.get_image(handle)
+        h.release_output(handle)
+        return img.copy(), count
+
+    a = scenes.cornell_host(str(tmp_path / "a"), 48, 48, 3)
+    settings(a, True)
+    image(a, 7)
+    settings(a, False)
+    got, n_got = image(a, 4)
+    b = scenes.cornell_host(str(tmp_path / "b"), 48, 48, 3)
+    settings(b, False)
+    want, n_want = image(b, 4)
+    assert n_got == n_want == 4
+    assert np.array_equal(got, want)
+    fa, fb = a.accumulators(), b.accumulators()
+    assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
+    a.close(); b.close()
