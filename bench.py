@@ -201,7 +201,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     """Uploads workload `name`, times `steps` passes after `warmup` untimed ones (barrier + synchronize on both sides, max over ranks) and
     returns (json dict, device scene view)."""
     import torch
-    from luminary_amd.core import CNT_LIGHT_BVH, CNT_NODES, CNT_SHADOW, CNT_TRACE, CNT_TRIS, CNT_VERTICES
+    from luminary_amd.core import CNT_AMBIENT_DEFERRED, CNT_AMBIENT_FALLBACK, CNT_LIGHT_BVH, CNT_NODES, CNT_SHADOW, CNT_TRACE, CNT_TRIS, CNT_VERTICES
     t_build = time.time()
     host = build_workload(name, args.width, args.height, args.bounces)
     label = WORKLOADS[name]
@@ -325,14 +325,15 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                  "ms_per_step": te / exact_steps * 1e3, "samples_per_s": view.width * view.height * spp_step * exact_steps / te}
         core.set_flavour(was)
     rays_local = cnt[CNT_TRACE] + cnt[CNT_SHADOW] + cnt[CNT_LIGHT_BVH]
-    stats = torch.tensor([float(rays_local), float(cnt[CNT_TRACE]), float(cnt[CNT_SHADOW]), float(cnt[CNT_LIGHT_BVH]), elapsed], dtype=torch.float64,
-                         device="cuda")
+    stats = torch.tensor([float(rays_local), float(cnt[CNT_TRACE]), float(cnt[CNT_SHADOW]), float(cnt[CNT_LIGHT_BVH]), elapsed,
+                          float(cnt[CNT_AMBIENT_DEFERRED] - cnt[CNT_AMBIENT_FALLBACK])], dtype=torch.float64, device="cuda")
     if dist is not None:
         mx = stats.clone()
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         elapsed = float(mx[4])
     rays_total = float(stats[0])
+    answered = float(stats[5])  # ambient samples answered by the next closest-hit ray: visibility queries that cost no traversal (not in `value`)
     del fm, sm
 
     # ---- rooflines (rank 0's kernels) ----
@@ -414,6 +415,9 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "seconds_to_1024spp": 1024.0 / (spp_step * steps / elapsed),
                    "rays": {"closest": float(stats[1]), "shadow": float(stats[2]), "light_bvh": float(stats[3])},
+                   # `value` counts executed rays only (SURVEY 8d's rule). Ambient samples whose visibility the path's next closest-hit ray answered cost no
+                   # traversal and are not in it; the reference would have traced each of them: value + these = the rate in the reference's own ray count.
+                   "ambient_reuse": core.ambient_reuse, "rays_answered_without_trace": answered, "mrays_per_s_answered": (rays_total + answered) / elapsed / 1e6,
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2),
                                      "lds_hit_rate_closest": round(cnt[10] / max(nodes_trace, 1), 3), "lds_hit_rate_shadow": round(cnt[11] / max(nodes_shadow, 1), 3)},
@@ -443,6 +447,8 @@ def main():
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
                     help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
+    ap.add_argument("--ambient-reuse", default="auto", choices=["auto", "on", "off"],
+                    help="ambient samples answered by the next closest-hit ray instead of a visibility ray (lumc_set_ambient_reuse; auto = the flavour's default: fast on, exact off)")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2, 3], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too, 3 path queue physically reordered")
     ap.add_argument("--pixel-tile", type=int, default=0, help="experiment: order the paths by t x t pixel tiles instead of pixel rows (N = 1)")
     ap.add_argument("--clouds", action="store_true", help="procedural sky with the three cloud layers active (not a BASELINE configuration)")
@@ -476,6 +482,7 @@ def main():
         core.set_flavour(args.flavour)
     if args.sort is not None:
         core.set_ray_sorting(args.sort)
+    core.set_ambient_reuse({"auto": -1, "on": 1, "off": 0}[args.ambient_reuse])
     if dist is not None and args.reduce == "cabi":
         # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes to the other ranks
         try:

@@ -6,7 +6,8 @@ import numpy as np
 from . import DeviceSceneView, _lib
 
 DIRTY_CONSTANTS, DIRTY_MATERIALS, DIRTY_INSTANCES, DIRTY_LIGHTS, DIRTY_MESHES, DIRTY_TEXTURES, DIRTY_PARTICLES, DIRTY_ALL = 1, 2, 4, 8, 16, 32, 64, 127
-CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW = range(12)
+CNT_TRACE, CNT_SHADOW, CNT_LIGHT_BVH, CNT_VERTICES, CNT_NODES, CNT_TRIS, CNT_NODES_SHADOW, CNT_TRIS_SHADOW, CNT_NODES_LIGHT, CNT_TRIS_LIGHT, CNT_NODES_LDS, CNT_NODES_LDS_SHADOW, CNT_AMBIENT_DEFERRED, CNT_AMBIENT_FALLBACK = range(14)
+CNT_COUNT = 16  # LUMC_CNT_COUNT
 KERNELS = ("generate", "trace", "shade", "shadow", "accumulate", "light_query", "resolve", "output", "sky", "sort", "volume")
 
 
@@ -130,6 +131,17 @@ class Core:
         """0 queue order, 1 closest-hit rays of depth >= 1 sorted by (origin cell, direction octant), 2 visibility rays too."""
         self._call("lumc_set_ray_sorting", C.c_int(mode))
 
+    def set_ambient_reuse(self, mode):
+        """-1 by flavour (fast: on, exact: off), 0 off, 1 on (lumc_set_ambient_reuse)"""
+        self._call("lumc_set_ambient_reuse", C.c_int(mode))
+
+    @property
+    def ambient_reuse(self):
+        """does the next render answer ambient samples from the closest-hit rays (lumc_get_ambient_reuse: by mode, flavour and scene)?"""
+        fn = self._lib.lumc_get_ambient_reuse
+        fn.restype = C.c_int
+        return bool(fn(self._ctx))
+
     def set_flavour(self, name):
         self._call("lumc_set_flavour", C.c_int({"exact": 0, "fast": 1}[name]))
 
@@ -238,7 +250,7 @@ class Core:
         return fm.reshape(3, -1), sm
 
     def counters(self):
-        out = (C.c_uint64 * 12)()
+        out = (C.c_uint64 * CNT_COUNT)()
         self._call("lumc_counters", out)
         return [int(x) for x in out]
 

@@ -265,6 +265,9 @@ static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second ha
 constexpr uint32_t kRayBlockMax = 1024u;  // the ray kernels' largest workgroup: a lane's share of the LDS stack area is sized for it
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
-                         kCntNodesLdsShadow, kCntCount };
+                         kCntNodesLdsShadow,
+                         kCntAmbientDeferred,  // ambient samples whose visibility ray was not queued: the path's next closest-hit ray answers (k_shade)
+                         kCntAmbientFallback,  // ... of which the closest hit could not decide: traced by the second visibility pass (counted in kCntShadow too)
+                         kCntSpare0, kCntSpare1, kCntCount };
 
 }  // namespace lum

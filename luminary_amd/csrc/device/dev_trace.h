@@ -830,10 +830,15 @@ struct ClosestState {
   static constexpr bool kOrdered = true;
   static constexpr int kFarFirst = 0;
   static constexpr bool kCull = true;  // stack entries carry the entry distance: a pop drops children beyond the nearest hit so far
-  bool use_ignore;
+  // Two facts ride along for the ambient-visibility reuse (TraceQuery, kernels.h) without a vector register of their own: bit 31 of best.scene_tri says
+  // that the nearest hit so far is an untextured alpha-1 triangle (kBvhTriOpaque: it would stop a visibility ray on its own), `cutout` (a lane mask in
+  // scalar registers, like use_ignore) that an alpha cut-out was skipped on the way (a visibility ray may have to multiply such a texel's colour in).
+  // result() hands out the clean triangle index.
+  static constexpr uint32_t kOpaqueBit = 0x80000000u;
+  bool use_ignore, cutout;
   uint32_t ign_inst, ign_tri;
   Hit best;
-  LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax, 0u}; }
+  LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; cutout = false; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax, 0u}; }
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
     LeafTris lt;
     lt.load<false>(sc.blas_tris, first, count);
@@ -849,14 +854,23 @@ struct ClosestState {
       if (t < best.t || (t == best.t && t != kFltMax && (inst < best.instance_id || (inst == best.instance_id && id < best.tri_id)))) {
         // alpha cut-outs: texels with alpha 0 do not exist for the ray (optix_common.cuh:20-46, optix_anyhit.cuh:26-30)
         if (fbits(c.w) < sc.num_textures &&  // kBvhTriNoTexture and kBvhTriOpaque are no texture ids
-            texture_load(sc, fbits(c.w), triangle_uv(sc.tri_tex[fbits(b.w)], uv), true, make_float4(0.0f, 0.0f, 0.0f, 1.0f)).w == 0.0f)
+            texture_load(sc, fbits(c.w), triangle_uv(sc.tri_tex[fbits(b.w)], uv), true, make_float4(0.0f, 0.0f, 0.0f, 1.0f)).w == 0.0f) {
+          cutout = true;
           continue;
-        best.instance_id = inst; best.tri_id = id; best.t = t; best.scene_tri = fbits(b.w); tmax = t;
+        }
+        best.instance_id = inst; best.tri_id = id; best.t = t; best.scene_tri = fbits(b.w) | (fbits(c.w) == kBvhTriOpaque ? kOpaqueBit : 0u); tmax = t;
       }
     }
     return false;
   }
-  LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax, 0u} : best; }
+  LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax, 0u} : Hit{best.instance_id, best.tri_id, best.t, best.scene_tri & ~kOpaqueBit}; }
+  // What a visibility ray along the same ray over (eps, FLT_MAX) with the same ignored triangle would report, where that follows from this query alone:
+  // 1 = nothing in the way (no hit, no cut-out skipped), 0 = blocked (the nearest hit lies beyond eps and is opaque on its own), -1 = unknown (the nearest
+  // surface is transparent or textured, or closer than eps, or a cut-out was skipped: the visibility ray has to be traced).
+  LUM_DEV int visibility_along() const {
+    if (best.t == kFltMax) return cutout ? -1 : 1;
+    return (best.t > kEps && (best.scene_tri & kOpaqueBit)) ? 0 : -1;
+  }
 };
 
 // Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light

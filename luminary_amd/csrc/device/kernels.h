@@ -137,6 +137,18 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams 
 // ---- closest-hit pass (replaces optix/optix_kernel_raytrace.cu:147-183) ----
 // `order` (optional): the queue is traced in the order of a sort by ray origin cell and direction octant (k_ray_sort_keys, core.hip), so
 // that the lanes of a wave and the waves of a CU walk the same part of the tree; the queue itself is not moved.
+// Ambient-visibility reuse (fast flavour, plain scenes - lumc_set_ambient_reuse, core.hip). In a constant-colour or panorama sky the ambient sample of a
+// vertex runs along its bounce direction (direct_lighting.cuh:388-405): the closest-hit ray of the NEXT depth walks the same line. Where that ray's
+// nearest hit is opaque, or it hits nothing, the ambient visibility is known without a second traversal (94 % of the hall's ambient rays end at an opaque
+// surface). k_shade then queues no visibility ray for a surviving path but notes the path's new queue index in the vertex's ambient record; the
+// closest-hit pass leaves two flag bits next to the hit's triangle index (below); k_resolve of the vertex's depth runs AFTER that pass and reads the
+// answer from the path's hit. What the nearest hit cannot decide (transparent or textured first hit, a hit closer than eps, a skipped cut-out) is listed,
+// traced by a small second visibility pass and resolved by k_resolve_listed. The reference traces the ambient ray along the direction after its
+// 2 x 32-bit octahedral packing (ray_unpack(ray_pack(bounce))), a last-bit difference from the bounce ray: the exact flavour therefore keeps tracing it
+// (bit-identity with the oracle), the fast flavour does not promise the last bit anyway.
+constexpr uint32_t kNoAmbientPath = 0xFFFFFFFFu;
+constexpr uint32_t kHitTriOpaque = 0x80000000u, kHitTriCutout = 0x40000000u, kHitTriMask = 0x3FFFFFFFu;  // hit_scene_tri: flag bits above the triangle index
+
 struct TraceQuery : ClosestState {
   PathQueue q;
   const uint32_t* order;
@@ -156,7 +168,8 @@ struct TraceQuery : ClosestState {
     const Hit h = result();
     reinterpret_cast<float*>(&q.origin_t[i])[3] = h.t;
     *reinterpret_cast<uint2*>(&q.hit_id[i]) = make_uint2(h.instance_id, h.tri_id);
-    q.hit_scene_tri[i] = h.scene_tri;
+    static_assert(kOpaqueBit == kHitTriOpaque, "the opaque bit is stored where ClosestState keeps it");
+    q.hit_scene_tri[i] = ((best.t == kFltMax) ? 0u : best.scene_tri) | (cutout ? kHitTriCutout : 0u);
   }
 };
 
@@ -259,9 +272,12 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 // ambient samples get a second visibility segment beyond it (dev_water.h); without an ocean none of that code exists in the kernel.
 template <uint32_t kSkyMode, bool kWater>
 __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
-                                                                    uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
+                                                                    uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  // ambient_reuse (see AmbientReuse above): the ambient visibility of a surviving path comes from its next closest-hit ray; never with an ocean (the ambient
+  // ray then ends at the water surface) or under the procedural sky (no ambient sample)
+  const bool reuse_ambient = ambient_reuse != 0u && !kWater && kSkyMode != kSkyDefault;
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
@@ -333,7 +349,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
         const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
-        const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i], aux.z);
+        const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i] & kHitTriMask, aux.z);
         // the volume the vertex is in: without an ocean the stack holds the fog or nothing for the whole path
         const uint32_t top_volume = kWater ? volume_stack_peek(hid.w, false) : (sc.fog_active ? (uint32_t) kVolumeFog : (uint32_t) kVolumeNone);
         const uint32_t second_volume = kWater ? volume_stack_peek(hid.w, true) : (uint32_t) kVolumeNone;
@@ -441,7 +457,8 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         }
         st_stream(&nee.geo_color_light[i], geo_cl);
         st_stream(&nee.bsdf_ray_prob[i], bs_rp); st_stream(&nee.bsdf_weight_sum[i], bs_ws);
-        st_stream(&nee.ambient[i], amb);
+        if (reuse_ambient) reinterpret_cast<uint2*>(&nee.ambient[i])[0] = make_uint2(amb.x, amb.y);  // the other half after the appends: the path's next queue index
+        else st_stream(&nee.ambient[i], amb);
 
         // delta-path classification (geometry.cuh:80-101)
         const float roughness = g.params.roughness();
@@ -491,6 +508,8 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         }
       }
     }
+    const bool amb_deferred = reuse_ambient && want_amb && survive;  // answered by the path's next closest-hit ray
+    if (amb_deferred) { want_amb = false; vertices += 1u << 16; }   // counted in the upper half of the lane's vertex counter (a lane shades a few hundred vertices per launch)
     LUM_LAP(clock, 6);
     // Wave-aggregated appends. The three lists (survivors, visibility items, light queries) are reserved by ONE memory instruction: lanes 0-2
     // each bump one counter, so a batch waits for one atomic round trip instead of three in a row (the words sit on separate 128-byte lines).
@@ -506,6 +525,8 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
     if (survive) {
       const uint32_t j = base_out + (uint32_t) __popcll(ballot & below);
       st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
+      // the vertex's ambient record: colour xy | the path's index in the next queue (the packed ray is only read with fog, which excludes the reuse)
+      if (reuse_ambient) reinterpret_cast<uint2*>(&nee.ambient[i])[1] = make_uint2(amb_deferred ? j : kNoAmbientPath, 0u);
     }
     if (want_geo) {
       const uint32_t j = base_shadow + (uint32_t) __popcll(bg & below);
@@ -543,9 +564,12 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
     LUM_LAP(clock, 7);
   }
   clock.flush();
+  uint32_t deferred = vertices >> 16;
+  vertices &= 0xFFFFu;
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) vertices += __shfl_down(vertices, off);
+  for (int off = 32; off > 0; off >>= 1) { vertices += __shfl_down(vertices, off); deferred += __shfl_down(deferred, off); }
   if ((threadIdx.x & 63) == 0 && vertices) atomicAdd((unsigned long long*) &counters[kCntVertices], (unsigned long long) vertices);
+  if ((threadIdx.x & 63) == 0 && deferred) atomicAdd((unsigned long long*) &counters[kCntAmbientDeferred], (unsigned long long) deferred);
 }
 
 // ---- debug shading modes (settings.shading_mode != DEFAULT): one closest-hit pass, then a colour per hit (geometry_process_tasks_debug,
@@ -599,7 +623,7 @@ __global__ __launch_bounds__(kBlock) void k_shade_debug(DeviceScene sc, PathQueu
         result = col(((float) (v & 0x7FFu)) / 0x7FF, ((float) ((v >> 10) & 0x7FFu)) / 0x7FF, ((float) ((v >> 20) & 0x7FFu)) / 0x7FF);
       }
       else if (sc.shading_mode == 1u || sc.shading_mode == 3u || sc.shading_mode == 5u) {
-        const GeoContext g = build_context(sc, hit_origin, ray, aux.w, hid.x, hid.y, in.hit_scene_tri[i], aux.z);
+        const GeoContext g = build_context(sc, hit_origin, ray, aux.w, hid.x, hid.y, in.hit_scene_tri[i] & kHitTriMask, aux.z);
         if (sc.shading_mode == 1u) result = g.params.albedo() + g.params.emission();                    // ALBEDO
         else if (sc.shading_mode == 3u) result = col(saturate(g.normal.x), saturate(g.normal.y), saturate(g.normal.z));  // NORMAL
         else result = g.params.albedo() * 0.025f + g.params.emission();                                   // LIGHTS
@@ -752,63 +776,133 @@ __global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, c
 }
 
 // ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
+// kAmbientKnown: the ambient sample's visibility is `ambient_vis` (from the path's next closest hit) instead of the visibility pass's word.
+template <bool kAmbientKnown>
+LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis) {
+  const uint4 aux = in.aux[i];
+  const uint32_t slot = fbits(in.dir_slot[i].w);
+  const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
+  Col acc = splat(0.0f);
+  {  // sampled light (direct_lighting.cuh:445-464)
+    const float4 cl = ld_stream(&nee.geo_color_light[i]);
+    Col vis = splat(0.0f);
+    if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = ld_stream(&sq.vis[i]); vis = col(v.x, v.y, v.z); }
+    acc = acc + col(cl.x, cl.y, cl.z) * vis;
+  }
+  {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
+    const float4 lc = ld_stream(&nee.bsdf_weight_sum[i]);
+    Col vis = splat(0.0f);
+    if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
+    Col seen = col(lc.x, lc.y, lc.z) * vis;
+    if (lc.w != 0.0f && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
+    acc = acc + seen;
+  }
+  if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
+    const uint4 sun = nee.sun[i];
+    Col vis = splat(0.0f);
+    if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+    if (sc.ocean_active && (sun.x != 0 || sun.y != 0)) {
+      const float4 w = nee.sun_water[i];
+      Col vis2 = splat(1.0f);
+      if ((fbits(w.w) & kSkyRaySecond) && !(fbits(w.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindSun2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+      acc = acc + combine_sun_ray(record_unpack(U2{sun.x, sun.y}), vis, w.x, fbits(w.w), vis2);
+    }
+    else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
+  }
+  {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
+    const uint4 amb = ld_stream(&nee.ambient[i]);
+    Col vis = splat(0.0f);
+    if (kAmbientKnown) vis = splat(ambient_vis);
+    else if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
+    Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
+    if (sc.ocean_active) {
+      if (amb.x != 0 || amb.y != 0) {
+        const float4 t1 = nee.amb_t1[i], t2 = nee.amb_t2[i];
+        Col vis2 = splat(1.0f);
+        if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindAmbient2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+        seen = combine_ambient_ray(record_unpack(U2{amb.x, amb.y}), vis, col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2);
+      }
+    }
+    else if (sc.fog_active) {  // direct_lighting.cuh:561-563
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      seen = seen * volume_transmittance(sc, kVolumeFog, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
+    }
+    acc = acc + seen;
+  }
+  add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
+}
+
+LUM_DEV bool resolves_here(uint32_t hit_type) {  // sky, and with volumes: scattering events and ended paths have nothing to resolve
+  return !(hit_type > kHitTriangleLimit && !particle_is_hit(hit_type) && hit_type != kHitOcean);
+}
+
 __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, float4* results, const uint32_t* ctrl) {
   const uint32_t n = ctrl[kCtlPaths];
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
-    const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
-    if (hid.x > kHitTriangleLimit && !particle_is_hit(hid.x) && hid.x != kHitOcean) continue;  // sky, and with volumes: scattering events and ended paths
-    const uint4 aux = in.aux[i];
-    const uint32_t slot = fbits(in.dir_slot[i].w);
-    const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
-    Col acc = splat(0.0f);
-    {  // sampled light (direct_lighting.cuh:445-464)
-      const float4 cl = ld_stream(&nee.geo_color_light[i]);
-      Col vis = splat(0.0f);
-      if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = ld_stream(&sq.vis[i]); vis = col(v.x, v.y, v.z); }
-      acc = acc + col(cl.x, cl.y, cl.z) * vis;
-    }
-    {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
-      const float4 lc = ld_stream(&nee.bsdf_weight_sum[i]);
-      Col vis = splat(0.0f);
-      if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
-      Col seen = col(lc.x, lc.y, lc.z) * vis;
-      if (lc.w != 0.0f && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
-      acc = acc + seen;
-    }
-    if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
-      const uint4 sun = nee.sun[i];
-      Col vis = splat(0.0f);
-      if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
-      if (sc.ocean_active && (sun.x != 0 || sun.y != 0)) {
-        const float4 w = nee.sun_water[i];
-        Col vis2 = splat(1.0f);
-        if ((fbits(w.w) & kSkyRaySecond) && !(fbits(w.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindSun2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
-        acc = acc + combine_sun_ray(record_unpack(U2{sun.x, sun.y}), vis, w.x, fbits(w.w), vis2);
-      }
-      else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
-    }
-    {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
-      const uint4 amb = ld_stream(&nee.ambient[i]);
-      Col vis = splat(0.0f);
-      if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
-      Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
-      if (sc.ocean_active) {
-        if (amb.x != 0 || amb.y != 0) {
-          const float4 t1 = nee.amb_t1[i], t2 = nee.amb_t2[i];
-          Col vis2 = splat(1.0f);
-          if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindAmbient2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
-          seen = combine_ambient_ray(record_unpack(U2{amb.x, amb.y}), vis, col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2);
+    if (!resolves_here(in.hit_id[i].x)) continue;
+    resolve_vertex<false>(sc, in, nee, sq, results, i, lights_present, 0.0f);
+  }
+}
+
+// The resolve of a depth whose ambient samples were left to the next depth's closest-hit pass (ambient-visibility reuse, above TraceQuery): `next` is the
+// queue that pass has just traced. A deferred sample reads its answer from the path's hit: nothing hit (and no cut-out skipped) = visible, an opaque
+// nearest hit beyond eps = blocked - what a visibility ray over (eps, FLT_MAX) that ignores the vertex's own triangle reports. Undecided vertices are not
+// resolved here: their ambient ray is queued (items from index 0: the depth's own items are spent) and their index listed for k_resolve_listed.
+__global__ __launch_bounds__(kBlock) void k_resolve_reuse(DeviceScene sc, PathQueue in, PathQueue next, NeeQueue nee, ShadowQueue sq, float4* results, uint32_t* ctrl, uint64_t* counters) {
+  const uint32_t n = ctrl[kCtlPaths];
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  const uint32_t lane = threadIdx.x & 63u;
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  for (uint32_t round = 0; round < rounds; round++) {
+    const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+    bool undecided = false;
+    uint32_t j = kNoAmbientPath;
+    uint2 self = make_uint2(0u, 0u);
+    if (i < n) {
+      const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
+      if (resolves_here(hid.x)) {
+        const uint4 amb = nee.ambient[i];
+        j = ((amb.x != 0 || amb.y != 0)) ? amb.z : kNoAmbientPath;
+        if (j == kNoAmbientPath) resolve_vertex<false>(sc, in, nee, sq, results, i, lights_present, 0.0f);  // no ambient sample, or its visibility ray was traced (the path ended here)
+        else {
+          const float t = next.origin_t[j].w;
+          const uint32_t word = next.hit_scene_tri[j];
+          int v;
+          if (t == kFltMax) v = (word & kHitTriCutout) ? -1 : 1;
+          else v = (t > kEps && (word & kHitTriOpaque)) ? 0 : -1;
+          if (v >= 0) resolve_vertex<true>(sc, in, nee, sq, results, i, lights_present, (float) v);
+          else { undecided = true; self = hid; }
         }
       }
-      else if (sc.fog_active) {  // direct_lighting.cuh:561-563
-        const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
-        seen = seen * volume_transmittance(sc, kVolumeFog, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
-      }
-      acc = acc + seen;
     }
-    add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
+    const unsigned long long bu = __ballot(undecided);
+    if (bu) {
+      uint32_t base = 0;
+      if (lane == (uint32_t) __builtin_ctzll(bu)) {
+        base = atomicAdd(ctrl + kCtlVolumeShadowItems, (uint32_t) __popcll(bu));
+        atomicAdd((unsigned long long*) &counters[kCntAmbientFallback], (unsigned long long) __popcll(bu));
+      }
+      base = __shfl(base, __builtin_ctzll(bu));
+      if (undecided) {
+        const uint32_t k = base + (uint32_t) __popcll(bu & below);
+        const float4 o4 = next.origin_t[j], d4 = next.dir_slot[j];
+        sq.origin_dist[k] = make_float4(o4.x, o4.y, o4.z, kFltMax);
+        sq.dir_out[k] = make_float4(d4.x, d4.y, d4.z, bitsf(2u * sq.capacity + i));
+        sq.ids[k] = make_uint4(0xFFFFFFFFu, 0u, self.x, self.y);
+        sq.light_items[k] = i;
+      }
+    }
   }
+}
+
+// ... and the vertices k_resolve_reuse listed, after the second visibility pass has traced their ambient rays.
+__global__ __launch_bounds__(kBlock) void k_resolve_listed(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, float4* results, const uint32_t* ctrl) {
+  const uint32_t n = ctrl[kCtlVolumeShadowItems];
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock)
+    resolve_vertex<false>(sc, in, nee, sq, results, sq.light_items[k], lights_present, 0.0f);
 }
 
 

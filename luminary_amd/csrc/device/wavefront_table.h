@@ -24,7 +24,7 @@ struct WavefrontKernels {
                 uint32_t lds_nodes);
   void (*sky_inscattering)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
-                uint32_t* ctrl, uint32_t depth_const, uint64_t* counters);
+                uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse);
   void (*shade_debug)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl);
   void (*sky)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*light_query)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl, uint32_t depth_const,
@@ -32,6 +32,10 @@ struct WavefrontKernels {
   void (*shadow_rays)(uint32_t grid, size_t lds, hipStream_t s, const DeviceScene& sc, const ShadowQueue& sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters,
                       uint32_t lds_nodes);
   void (*resolve)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
+  // ambient-visibility reuse (kernels.h, above TraceQuery): the resolve of a depth after the NEXT depth's closest-hit pass over `next`, and of the vertices it listed
+  void (*resolve_reuse)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& next, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
+                        uint32_t* ctrl, uint64_t* counters);
+  void (*resolve_listed)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
   // fog (dev_volume.h): light scattered into the rays of a depth, its summation, the scattering events and their bounce
   void (*volume_inscatter)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
                            uint32_t depth_const);

@@ -48,10 +48,10 @@ static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc
   hipLaunchKernelGGL(k_sky_inscattering, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
 }
 static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
-                  uint32_t* ctrl, uint32_t depth_const, uint64_t* counters) {
+                  uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
   auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false> : k_shade<kSkyConstantColor, false>;
   if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true> : k_shade<kSkyConstantColor, true>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
 }
 static void shade_debug(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_shade_debug, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl);
@@ -69,6 +69,13 @@ static void shadow_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSc
 }
 static void resolve(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_resolve, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);
+}
+static void resolve_reuse(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& next, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
+                          uint32_t* ctrl, uint64_t* counters) {
+  hipLaunchKernelGGL(k_resolve_reuse, dim3(grid), dim3(kBlock), 0, s, sc, in, next, nee, sq, results, ctrl, counters);
+}
+static void resolve_listed(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
+  hipLaunchKernelGGL(k_resolve_listed, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);
 }
 static void volume_inscatter(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
                              uint32_t depth_const) {
@@ -115,7 +122,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, init_sampler_seeds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve,           volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve, resolve_reuse, resolve_listed, volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
 
 }  // namespace table
 LUM_NS_END

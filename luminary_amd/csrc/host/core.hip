@@ -46,6 +46,7 @@ struct LumContext {
   DeviceScene scene{};
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
+  int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
   int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU, 2 PLOC on the GPU (lumc_set_bvh_builder)
   bool top_order_by_area = false; // which nodes count as the top of the tree (staged in LDS): breadth first, or best first by box area (LUM_TOP_ORDER=area; measured: mixed)
   double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
@@ -480,6 +481,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
   if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;
   if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
+  if (const char* e = getenv("LUM_AMBIENT_REUSE")) ctx->ambient_reuse = atoi(e) != 0 ? 1 : 0;
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -1473,6 +1475,16 @@ static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue
   ctx->wf->trace_particles(grid_persistent(ctx, N), (size_t) ctx->particle_lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES, stream, tree, q, ctrl, ctx->particle_lds_nodes);
 }
 
+// Does the next pass reuse the closest-hit rays for the ambient visibility (lumc_set_ambient_reuse)? Plain scenes only: with fog the vertex's ambient term
+// is dimmed along the packed direction, an ocean ends the ambient ray at the water surface, particles and the ocean replace closest hits after the
+// pass that would answer, clouds and the procedural sky have no ambient sample; the reorder of sort mode 3 does not move hit_scene_tri.
+static bool ambient_reuse_active(const LumContext* ctx) {
+  const DeviceScene& sc = ctx->scene;
+  const bool wanted = ctx->ambient_reuse < 0 ? (ctx->wf == wavefront_kernels_fast()) : ctx->ambient_reuse != 0;
+  return wanted && ctx->has_scene && sc.sky_mode != kSkyDefault && !sc.fog_active && !sc.ocean_active && !sc.particles_active && !sc.cloud_active &&
+         !sc.sky_aerial_perspective && ctx->sort_mode == 0 && sc.shading_mode == 0u;
+}
+
 // The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
 static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   const DeviceScene& sc = ctx->scene;
@@ -1503,6 +1515,11 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     wf.shade_debug(grid_for(N), stream, sc, ctx->queue[0], ctx->d_results, (const uint32_t*) ctx->d_ctrl);
     return 0;
   }
+  // Ambient-visibility reuse (lumc_set_ambient_reuse; AmbientReuse in kernels.h): the vertices of depth d leave their ambient sample to the closest-hit
+  // pass of depth d + 1, which is followed by a second, small visibility pass (what the closest hit could not decide) and only then by the resolve of
+  // depth d - still before k_shade of depth d + 1 touches the result slots, so the order of the sums is the usual one.
+  const bool reuse = ambient_reuse_active(ctx);
+  bool resolve_pending = false;  // the previous depth's resolve waits for this depth's closest-hit pass
   for (uint32_t depth = 0; depth <= max_depth; depth++) {
     // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
     const uint32_t depth_const = (depth == max_depth && depth > 0) ? depth - 1 : depth;
@@ -1525,6 +1542,20 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
+    }
+    if (resolve_pending) {  // the previous depth's resolve: ambient samples answered by the pass above; what it cannot answer is traced (the control words of the fog's visibility pass: no fog here) and resolved after
+      uint32_t* prev = ctrl - kCtlStride;
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+        wf.resolve_reuse(grid_for(N), stream, sc, ctx->queue[cur ^ 1], ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, prev, ctx->d_counters);
+      }
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
+        wf.shadow_rays(ctx->trace_blocks, lds_dyn, stream, sc, ctx->shadow, nullptr, prev + kCtlVolumeShift, ctx->d_counters, ctx->lds_nodes);
+      }
+      Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+      wf.resolve_listed(std::min<uint32_t>(grid_for(N), 1024u), stream, sc, ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) prev);
+      resolve_pending = false;
     }
     if (sc.particles_active) trace_particles(ctx, stream, ctx->queue[cur], ctrl, N);  // optix_kernel_raytrace.cu:171
     if (sc.ocean_active) {  // optix_kernel_raytrace.cu:134-144, :172
@@ -1558,7 +1589,8 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters);
+      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
+               (reuse && depth < max_depth) ? 1u : 0u);
     }
     if (sc.particles_active) {  // device_renderer.c:99-103
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
@@ -1586,7 +1618,8 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
       wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, shadow_order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
-    {
+    if (reuse && depth < max_depth) resolve_pending = true;
+    else {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
       wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
     }
@@ -2554,6 +2587,12 @@ int lumc_set_flavour(LumContext* ctx, int flavour) {
   ctx->wf = flavour == LUMC_FLAVOUR_FAST ? wavefront_kernels_fast() : wavefront_kernels_exact();
   return 0;
 }
+int lumc_set_ambient_reuse(LumContext* ctx, int mode) {
+  if (!ctx || mode < -1 || mode > 1) { if (ctx) ctx->error = "lumc_set_ambient_reuse: -1 (by flavour), 0 (off) or 1 (on)"; return 1; }
+  ctx->ambient_reuse = mode;
+  return 0;
+}
+int lumc_get_ambient_reuse(const LumContext* ctx) { return (ctx && ambient_reuse_active(ctx)) ? 1 : 0; }
 int lumc_get_flavour(const LumContext* ctx) { return (ctx && ctx->wf == wavefront_kernels_exact()) ? LUMC_FLAVOUR_EXACT : LUMC_FLAVOUR_FAST; }
 
 unsigned int lumc_lds_stack_bytes(void) { return LUM_LDS_STACK_BYTES; }

@@ -1,0 +1,137 @@
+"""Ambient-visibility reuse (include/lum_core.h lumc_set_ambient_reuse; kernels.h above TraceQuery; the depth loop in core.hip).
+
+Under a constant-colour or panorama sky the ambient sample of a vertex runs along its bounce direction (cuda/direct_lighting.cuh:388-405), i.e. along the
+closest-hit ray the path traces at the next depth anyway. Where that ray's nearest hit is opaque, or it leaves the scene, the visibility is known and no
+visibility ray is traced; a transparent or textured nearest hit, a skipped alpha cut-out, and paths that end at the vertex still trace theirs.
+The reference's ambient ray uses the direction after its 2 x 32-bit packing, a last-bit difference from the bounce ray, so the exact flavour (bit-identical
+to the oracle) keeps tracing by default and the fast flavour reuses. Forced on in the EXACT flavour, the only difference to the traced result is that
+last bit of the direction: the images must agree in all but a handful of pixels, and the ray counters must add up exactly."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from luminary_amd import scenes
+from luminary_amd.core import CNT_AMBIENT_DEFERRED, CNT_AMBIENT_FALLBACK, CNT_LIGHT_BVH, CNT_SHADOW, CNT_TRACE, CNT_VERTICES, Core
+
+
+def test_the_c_abi_exports_the_switch():
+    from luminary_amd import _lib
+    lib = _lib()
+    assert hasattr(lib, "lumc_set_ambient_reuse") and hasattr(lib, "lumc_get_ambient_reuse")
+
+
+def _render(core, mode, spp=8, batch=4):
+    core.set_ambient_reuse(mode)
+    core.set_pixels(None)
+    core.reset_counters()
+    core.render(0, spp, samples_per_pass=batch)
+    fm, sm = core.accumulators()
+    return fm.copy(), sm.copy(), core.counters()
+
+
+def _scene(name, tmp):
+    if name == "cornell":
+        return scenes.cornell_host(str(tmp), 96, 96, 6)
+    if name == "zoo":            # glass, coloured transparency, metals, hundreds of emitters: transparent first hits -> the fallback pass
+        return scenes.zoo_scene(96, 64, 8)
+    if name == "textured":       # alpha cut-outs and texture-driven transparency: the cut-out flag -> the fallback pass
+        return scenes.textured_scene(96, 64, 6)
+    if name == "example":
+        return scenes.example_scene(160, 96, 6, sphere_segments=8, ground_res=12, num_objects=16, num_lights=4)
+    if name == "no_lights":
+        return scenes.edge_scene("no_lights", 64, 48, 4)
+    raise ValueError(name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cornell", "zoo", "textured", "example", "no_lights"])
+def test_reuse_in_the_exact_flavour_equals_tracing_up_to_the_direction_rounding(name, tmp_path):
+    host = _scene(name, tmp_path)
+    view = oracle_lib.with_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.set_flavour("exact")
+        core.upload(view)
+        core.set_ambient_reuse(-1)
+        assert not core.ambient_reuse, "the exact flavour keeps tracing by default (bit-identity with the oracle)"
+        fm0, sm0, c0 = _render(core, 0)
+        core.set_ambient_reuse(1)
+        assert core.ambient_reuse
+        fm1, sm1, c1 = _render(core, 1)
+        fm2, _, _ = _render(core, 0)
+    finally:
+        core.close()
+    assert np.array_equal(fm0, fm2), "switching back and forth must not change the traced result"
+    assert c0[CNT_AMBIENT_DEFERRED] == 0 and c0[CNT_AMBIENT_FALLBACK] == 0
+    # the paths are the same paths: closest-hit rays, light queries and vertices do not change; every ambient query is either traced or answered
+    for k in (CNT_TRACE, CNT_LIGHT_BVH, CNT_VERTICES):
+        assert c1[k] == c0[k]
+    assert c1[CNT_AMBIENT_DEFERRED] > 0, "nothing was deferred: the reuse did not run"
+    assert c1[CNT_SHADOW] + c1[CNT_AMBIENT_DEFERRED] - c1[CNT_AMBIENT_FALLBACK] == c0[CNT_SHADOW]
+    if name in ("zoo", "textured"):
+        assert c1[CNT_AMBIENT_FALLBACK] > 0, "this scene has transparent / cut-out first hits: the fallback pass must have traced some"
+    if name in ("cornell", "no_lights"):
+        assert c1[CNT_AMBIENT_FALLBACK] <= c1[CNT_AMBIENT_DEFERRED] // 1000, "opaque scene: (almost) every deferred sample is answered by the closest hit"
+    # the images: identical except where the last bit of the direction decides whether a ray grazes an edge
+    differing = int((np.abs(fm1 - fm0).max(axis=0) > 0).sum())
+    assert differing <= max(4, fm0.shape[1] // 500), "%d of %d pixels differ" % (differing, fm0.shape[1])
+    assert abs(float(fm1.sum()) - float(fm0.sum())) <= 1e-4 * float(fm0.sum())
+    assert np.isfinite(fm1).all() and np.isfinite(sm1).all()
+
+
+@pytest.mark.gpu
+def test_default_by_flavour_and_scene(tmp_path):
+    """fast: on for plain scenes; off with fog / under the procedural sky / with ray sorting; exact: off."""
+    from luminary_amd import SKY_MODE_DEFAULT
+    host = scenes.cornell_host(str(tmp_path), 32, 32, 2)
+    core = Core(0)
+    try:
+        core.set_flavour("fast")
+        core.upload(oracle_lib.with_luts(host.device_scene()))
+        assert core.ambient_reuse
+        core.set_ray_sorting(1)
+        assert not core.ambient_reuse
+        core.set_ray_sorting(0)
+        core.set_flavour("exact")
+        assert not core.ambient_reuse
+        core.set_flavour("fast")
+        fog = host.get_fog()
+        fog.active, fog.density = True, 10.0
+        host.set_fog(fog)
+        core.upload(oracle_lib.with_luts(host.device_scene()))
+        assert not core.ambient_reuse
+        fog.active = False
+        host.set_fog(fog)
+        sky = host.get_sky()
+        sky.mode = SKY_MODE_DEFAULT
+        host.set_sky(sky)
+        core.upload(oracle_lib.with_luts(host.device_scene()))
+        assert not core.ambient_reuse
+    finally:
+        core.close()
+
+
+@pytest.mark.gpu
+def test_fast_flavour_with_and_without_reuse(tmp_path):
+    """The benchmarked configuration: fast flavour, reuse on (its default) against reuse off - same paths, same counters but the visibility rays, images within
+    the handful of edge pixels; under the panorama sky (HDRI mode) as well."""
+    from luminary_amd import SKY_MODE_HDRI
+    for hdri in (False, True):
+        host = scenes.example_scene(160, 96, 6, sphere_segments=8, ground_res=12, num_objects=16, num_lights=4)
+        if hdri:
+            sky = host.get_sky()
+            sky.mode = SKY_MODE_HDRI
+            host.set_sky(sky)
+        core = Core(0)
+        try:
+            core.set_flavour("fast")
+            core.upload(oracle_lib.with_luts(host.device_scene()))
+            fm0, _, c0 = _render(core, 0)
+            fm1, _, c1 = _render(core, -1)
+        finally:
+            core.close()
+        assert c1[CNT_AMBIENT_DEFERRED] > 0 and c0[CNT_AMBIENT_DEFERRED] == 0
+        assert c1[CNT_TRACE] == c0[CNT_TRACE] and c1[CNT_VERTICES] == c0[CNT_VERTICES]
+        assert c1[CNT_SHADOW] + c1[CNT_AMBIENT_DEFERRED] - c1[CNT_AMBIENT_FALLBACK] == c0[CNT_SHADOW]
+        differing = int((np.abs(fm1 - fm0).max(axis=0) > 0).sum())
+        assert differing <= max(4, fm0.shape[1] // 500), "%d of %d pixels differ (hdri=%s)" % (differing, fm0.shape[1], hdri)

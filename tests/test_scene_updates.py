@@ -230,10 +230,10 @@ def test_first_emitter_in_a_fogged_scene_arrives_by_a_material_edit():
         return h
 
     def glow(h):
-        m = h.get_material(1)
+        m = h.get_material(0)  # the grey material of every triangle of this scene
         m.emission_active = True
         m.emission.r, m.emission.g, m.emission.b = 6.0, 5.0, 4.0
-        h.set_material(1, m)
+        h.set_material(0, m)
 
     a = fogged()
     dark = _frame(a)
