@@ -15,7 +15,8 @@ Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x108
          256 CUs busy: 4 / 8 / 16 / 32 ids per pass give 2610 / 2769 / 2861 / 2907 Mrays/s on the hall (profiles/r02_ab_experiments.txt).
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
-         rendering); each rank accumulates its own pixels and one RCCL reduce to rank 0 at the end assembles the frame moments.
+         rendering); each rank accumulates its own pixels and ONE RCCL collective at the end assembles the frame moments on rank 0: a gather of
+         the ranks' own tiles behind the C ABI (lumc_frame_gather; --reduce cabi-reduce: the reduce of zero-padded full frames it replaced).
 Prints ONE JSON line on rank 0, as the LAST line of stdout, at most 4 KB (`headline`): the contract's fields, the dominant kernel's roofline, the three
 big kernels in brief, value_exact (the bit-exact flavour on the same scene), the CPU baseline, the secondaries' values. Everything else - prose, ceilings,
 L2 figures, per-ray counts, the secondaries' own blocks - goes to profiles/bench_detail.json (written by the same run) and to stderr.
@@ -253,7 +254,10 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
             core.render(i * spp_step, spp_step, spp_step, 0, 0, stream)
 
         def assemble():
-            core.frame_assemble(frame_pixels, 0, stream)
+            if args.reduce == "cabi-reduce":
+                core.frame_assemble(frame_pixels, 0, stream)   # every rank's zero-padded full frame, ncclReduce(SUM)
+            else:
+                core.frame_gather(view.width, view.height, 0, stream)  # the ranks' own pixels, one ncclGather (1 / N of the bytes)
     else:
         fm = torch.zeros(3 * P, dtype=torch.float32, device="cuda")
         sm = torch.zeros(P, dtype=torch.float32, device="cuda")
@@ -410,7 +414,8 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "lds_stack_bytes": core.lds_stack_bytes(), "source_hash": source_hash(), "ray_sorting": core.ray_sorting,
                    "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if dist is not None else "single GPU",
-                   "frame_reduce": None if dist is None else ("C ABI: lumc_frame_assemble (RCCL ncclReduce)" if cabi else "torch.distributed.reduce (RCCL)"),
+                   "frame_reduce": None if dist is None else (("C ABI: lumc_frame_assemble (RCCL ncclReduce of full frames)" if args.reduce == "cabi-reduce" else
+                                                               "C ABI: lumc_frame_gather (RCCL ncclGather of the ranks' own tiles)") if cabi else "torch.distributed.reduce (RCCL)"),
                    "rccl_ranks": None if dist is None else (core.comm_count() if cabi else dist.get_world_size()),  # ncclCommCount of the library's own communicator
                    "samples_per_s": view.width * view.height * spp_step * steps / elapsed,
                    "seconds_to_1024spp": 1024.0 / (spp_step * steps / elapsed),
@@ -445,8 +450,9 @@ def main():
     ap.add_argument("--samples-per-pass", type=int, default=32, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
-    ap.add_argument("--reduce", default="cabi", choices=["cabi", "torch"],
-                    help="N > 1: who assembles the frame on rank 0 - the library's own RCCL reduce behind the C ABI (lumc_frame_assemble) or torch.distributed's")
+    ap.add_argument("--reduce", default="cabi", choices=["cabi", "cabi-reduce", "torch"],
+                    help="N > 1: who assembles the frame on rank 0 - the library behind the C ABI with one ncclGather of the ranks' own tiles (lumc_frame_gather, default) or "
+                         "with an ncclReduce of zero-padded full frames (lumc_frame_assemble), or torch.distributed's reduce")
     ap.add_argument("--ambient-reuse", default="auto", choices=["auto", "on", "off"],
                     help="ambient samples answered by the next closest-hit ray instead of a visibility ray (lumc_set_ambient_reuse; auto = the flavour's default: fast on, exact off)")
     ap.add_argument("--sort", type=int, default=None, choices=[0, 1, 2, 3], help="ray ordering between bounces: 0 queue order, 1 closest-hit rays sorted, 2 visibility rays too, 3 path queue physically reordered")
@@ -483,7 +489,7 @@ def main():
     if args.sort is not None:
         core.set_ray_sorting(args.sort)
     core.set_ambient_reuse({"auto": -1, "on": 1, "off": 0}[args.ambient_reuse])
-    if dist is not None and args.reduce == "cabi":
+    if dist is not None and args.reduce != "torch":
         # the library's own RCCL communicator: rank 0 makes the id, torch.distributed only carries its 128 bytes to the other ranks
         try:
             ids = [Core.comm_unique_id() if rank == 0 else None]

@@ -115,6 +115,13 @@ class Core:
         self._call("lumc_frame_assemble", C.c_uint32(frame_pixels), C.c_int(root), C.c_void_p(stream), C.byref(ptr))
         return ptr.value
 
+    def frame_gather(self, width, height, root=0, stream=0):
+        """The frame by a gather of the ranks' own pixels (this context holds its share of the 32x32 tile deal): pack, ONE ncclGather to `root`, scatter there.
+        Returns the device pointer of the assembled frame on root, None elsewhere (lumc_frame_gather)."""
+        ptr = C.c_void_p()
+        self._call("lumc_frame_gather", C.c_uint32(width), C.c_uint32(height), C.c_int(root), C.c_void_p(stream), C.byref(ptr))
+        return ptr.value
+
     def frame_download(self, frame_pixels):
         fm = np.zeros(3 * frame_pixels, dtype=np.float32)
         sm = np.zeros(frame_pixels, dtype=np.float32)

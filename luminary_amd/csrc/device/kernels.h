@@ -522,12 +522,14 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
     uint32_t reserved = 0;
     if (want_count) reserved = atomicAdd(want_word, want_count);
     const uint32_t base_out = __builtin_amdgcn_readlane(reserved, 0), base_shadow = __builtin_amdgcn_readlane(reserved, 1), base_light = __builtin_amdgcn_readlane(reserved, 2);
+    uint32_t amb_path = kNoAmbientPath;
     if (survive) {
       const uint32_t j = base_out + (uint32_t) __popcll(ballot & below);
       st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
-      // the vertex's ambient record: colour xy | the path's index in the next queue (the packed ray is only read with fog, which excludes the reuse)
-      if (reuse_ambient) reinterpret_cast<uint2*>(&nee.ambient[i])[1] = make_uint2(amb_deferred ? j : kNoAmbientPath, 0u);
+      amb_path = amb_deferred ? j : kNoAmbientPath;
     }
+    // the second half of the vertex's ambient record: the path's index in the next queue, or none (the packed ray is only read with fog, which excludes the reuse)
+    if (reuse_ambient && valid) reinterpret_cast<uint2*>(&nee.ambient[i])[1] = make_uint2(amb_path, 0u);
     if (want_geo) {
       const uint32_t j = base_shadow + (uint32_t) __popcll(bg & below);
       st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));

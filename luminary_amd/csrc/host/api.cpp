@@ -826,7 +826,10 @@ LuminaryResult assemble_partition(LuminaryHost* h) {
   for (LuminaryHost::DeviceSlot* slot : enabled_slots(h)) if (slot->core) cores.push_back(slot->core);
   if (cores.size() != h->partition_n || cores[0] != h->core) return LUMINARY_ERROR_API_EXCEPTION;
   const LumDeviceSceneView& v = h->device_scene.view;
-  if (lumc_frame_assemble_all(cores.data(), (int) cores.size(), v.width * v.height, 0, nullptr) || lumc_use_assembled_frame(h->core, 1)) {
+  // uniform tiled rendering: the devices hold the shares of the 32x32 tile deal, so the frame is a gather of their own pixels (1 / n of a reduce's bytes);
+  // adaptive rendering keeps full-frame accumulators with a block mask per device: those frames are summed
+  const bool gathered = !h->adaptive_active && lumc_frame_gather_all(cores.data(), (int) cores.size(), v.width, v.height, 0, nullptr) == 0;
+  if ((!gathered && lumc_frame_assemble_all(cores.data(), (int) cores.size(), v.width * v.height, 0, nullptr)) || lumc_use_assembled_frame(h->core, 1)) {
     std::fprintf(stderr, "[luminary_amd] %s\n", lumc_last_error(h->core));
     return LUMINARY_ERROR_CUDA;
   }

@@ -268,6 +268,99 @@ struct Builder {
   }
 };
 
+// ---- insertion-based optimisation of the finished binary tree (Bittner, Hapala, Havran: "Fast Insertion-Based Optimization of Bounding Volume
+// Hierarchies", CGF 2013) ----
+// A top-down builder decides every split with what it sees at that node; the result is locally good and globally improvable. One step takes a subtree
+// out (its parent node is removed, the sibling moves up, the ancestors' boxes shrink), looks - branch and bound over the whole tree, cheapest
+// enlargement first - for the place where putting it back enlarges the tree's boxes least, and inserts it there with the freed parent node. The cost
+// that falls is the sum of the inner nodes' surface areas, which is what the expected number of node visits of a random ray is proportional to.
+// Leaves (sets of at most max_leaf primitives) are moved whole: the primitive order, and with it the leaf ranges, stay as built.
+struct Reinserter {
+  std::vector<BinNode>& nodes;
+  std::vector<uint32_t> parent;
+  explicit Reinserter(std::vector<BinNode>& n) : nodes(n), parent(n.size(), 0xFFFFFFFFu) {
+    for (uint32_t i = 0; i < nodes.size(); i++) if (nodes[i].count == 0) { parent[nodes[i].left] = i; parent[nodes[i].right] = i; }
+  }
+  static Aabb join(const Aabb& a, const Aabb& b) { Aabb r = a; grow(r, b); return r; }
+  bool leaf(uint32_t i) const { return nodes[i].count > 0; }
+  void refit_up(uint32_t i) {
+    while (i != 0xFFFFFFFFu) {
+      const Aabb b = join(nodes[nodes[i].left].box, nodes[nodes[i].right].box);
+      if (std::memcmp(&b, &nodes[i].box, sizeof(Aabb)) == 0) break;
+      nodes[i].box = b;
+      i = parent[i];
+    }
+  }
+  double inner_area() const { double a = 0; for (const BinNode& n : nodes) if (n.count == 0) a += half_area(n.box); return a; }
+
+  // Takes `n` out and puts it back where the tree grows least. Returns true when the tree changed.
+  bool reinsert(uint32_t n, std::vector<std::pair<float, uint32_t>>& heap) {
+    const uint32_t p = parent[n];
+    if (p == 0xFFFFFFFFu || p == 0u) return false;  // the root and its children stay (the root keeps index 0)
+    const uint32_t g = parent[p];
+    const uint32_t s = nodes[p].left == n ? nodes[p].right : nodes[p].left;
+    // remove: s takes p's place
+    (nodes[g].left == p ? nodes[g].left : nodes[g].right) = s;
+    parent[s] = g;
+    refit_up(g);
+    // search
+    const Aabb nb = nodes[n].box;
+    const float na = half_area(nb);
+    float best_cost = FLT_MAX;
+    uint32_t best = s;
+    heap.clear();
+    heap.emplace_back(0.0f, 0u);
+    auto cmp = [](const std::pair<float, uint32_t>& a, const std::pair<float, uint32_t>& b) { return a.first > b.first; };  // min-heap on the induced cost
+    while (!heap.empty()) {
+      std::pop_heap(heap.begin(), heap.end(), cmp);
+      const float induced = heap.back().first;
+      const uint32_t x = heap.back().second;
+      heap.pop_back();
+      if (induced + na >= best_cost) break;
+      const float direct = half_area(join(nodes[x].box, nb));
+      const float total = induced + direct;
+      if (total < best_cost) { best_cost = total; best = x; }
+      if (!leaf(x)) {
+        const float child_induced = total - half_area(nodes[x].box);
+        if (child_induced + na < best_cost) {
+          heap.emplace_back(child_induced, nodes[x].left); std::push_heap(heap.begin(), heap.end(), cmp);
+          heap.emplace_back(child_induced, nodes[x].right); std::push_heap(heap.begin(), heap.end(), cmp);
+        }
+      }
+    }
+    // insert: p becomes the parent of (best, n) where best was
+    const uint32_t bp = parent[best];
+    if (bp == 0xFFFFFFFFu) {  // best is the root: keep index 0 as the root by moving the root's content into p... simpler: insert below the root's nearer child instead
+      // (cannot happen for a subtree that was not a child of the root unless it is huge; fall back to the old place)
+      best = s;
+    }
+    const uint32_t bp2 = parent[best];
+    (nodes[bp2].left == best ? nodes[bp2].left : nodes[bp2].right) = p;
+    parent[p] = bp2;
+    nodes[p].left = best; nodes[p].right = n; nodes[p].count = 0;
+    parent[best] = p; parent[n] = p;
+    nodes[p].box = join(nodes[best].box, nb);
+    refit_up(bp2);
+    return best != s;
+  }
+
+  void run(int passes, float fraction) {
+    std::vector<std::pair<float, uint32_t>> heap;
+    std::vector<uint32_t> order(nodes.size());
+    for (int pass = 0; pass < passes; pass++) {
+      std::iota(order.begin(), order.end(), 0u);
+      std::vector<float> key(nodes.size());
+      for (uint32_t i = 0; i < nodes.size(); i++) key[i] = half_area(nodes[i].box);
+      std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] > key[b] || (key[a] == key[b] && a < b); });
+      const size_t take = (size_t) (fraction * order.size());
+      size_t moved = 0;
+      const double before = inner_area();
+      for (size_t k = 0; k < take; k++) moved += reinsert(order[k], heap) ? 1 : 0;
+      if (env_int("LUM_BVH_TIMING", 0)) std::fprintf(stderr, "[bvh] reinsertion pass %d: %zu of %zu subtrees moved, inner area %.6g -> %.6g\n", pass, moved, take, before, inner_area());
+    }
+  }
+};
+
 // ---- builder with spatial splits (bvh_build.h build_bvh4_triangles) ----
 struct Ref { uint32_t prim; Aabb box; };
 
@@ -563,6 +656,10 @@ Bvh4 build_bvh4(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t m
     for (uint32_t i = 0; i < count; i++) { std::memcpy(b.items[i].lo, boxes[i].lo, 12); std::memcpy(b.items[i].hi, boxes[i].hi, 12); b.items[i].prim = i; }
     const auto t0 = std::chrono::steady_clock::now();
     b.build(count);
+    if (max_leaf > 1 && attempt == 0) {
+      const int passes = env_int("LUM_BVH_REINSERT", 0);
+      if (passes > 0) { Reinserter r(b.nodes); r.run(passes, env_float("LUM_BVH_REINSERT_FRACTION", 1.0f)); }
+    }
     const auto t1 = std::chrono::steady_clock::now();
     Bvh4 out = collapse(b);
     if (env_int("LUM_BVH_TIMING", 0))

@@ -126,6 +126,13 @@ struct LumContext {
   int comm_rank = 0, comm_world = 1;
   float* d_frame = nullptr;
   uint32_t frame_capacity = 0;
+  // tile gather (lumc_frame_gather*): this rank's padded [4][gather_stride] send buffer; on the root the [world][4][gather_stride] receive buffer and every
+  // rank's pixel list [world][gather_stride] (0xFFFFFFFF = padding), keyed by (width, height, world)
+  float* d_gather_send = nullptr;
+  float* d_gather_recv = nullptr;
+  uint32_t* d_gather_pixels = nullptr;
+  uint32_t gather_stride = 0, gather_key[3] = {0, 0, 0};
+  size_t gather_recv_floats = 0;
   bool use_frame = false;         // the result / output entry points read the assembled frame instead of this context's own accumulators
   uint32_t* d_ctrl = nullptr;     // kCtlStride control words per depth (+1 row), zeroed per pass; last row: cursor of lumc_trace_closest
   uint64_t* d_counters = nullptr;
@@ -517,6 +524,9 @@ void lumc_context_destroy(LumContext* ctx) {
   if (ctx->d_argb8) (void) hipFree(ctx->d_argb8);
   if (ctx->d_counters) (void) hipFree(ctx->d_counters);
   if (ctx->d_frame_result) (void) hipFree(ctx->d_frame_result);
+  if (ctx->d_gather_send) (void) hipFree(ctx->d_gather_send);
+  if (ctx->d_gather_recv) (void) hipFree(ctx->d_gather_recv);
+  if (ctx->d_gather_pixels) (void) hipFree(ctx->d_gather_pixels);
   if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
   for (uint32_t*& t : ctx->d_cloud_noise) { if (t) (void) hipFree(t); t = nullptr; }
   if (ctx->d_undersampling_pixels) (void) hipFree(ctx->d_undersampling_pixels);
@@ -1276,26 +1286,6 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
       sc.sky_lut_multiscattering = ctx->d_sky_lut[1];
     }
   }
-  // ---- bridges to emissive triangles (fog, or an ocean with triangle_light_contribution): the vertex-count table. Decided after EVERY update, not
-  // only when the constants are dirty: a material that becomes emissive (MATERIALS | LIGHTS) gives a fogged scene its first light, and
-  // bridges_vertex_count_importance reads the table without a check. The table lives in the context (5 KB, uploaded once per content). ----
-  {
-    const bool need_bridges = (sc.fog_active || (sc.ocean_active && sc.ocean_triangle_light_contribution)) && sc.num_lights > 0 && sc.light_tree_root;
-    sc.bridge_lut = nullptr;
-    if (need_bridges) {
-      if (!v->bridge_lut) { ctx->error = sc.fog_active ? "lumc_scene_upload: fog with emissive triangles needs bridge_lut" : "lumc_scene_upload: an ocean lit by emissive triangles needs bridge_lut"; return 1; }
-      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
-      const size_t n = (size_t) 64 * 21;
-      if (!ctx->d_bridge_lut || ctx->bridge_lut_host.size() != n || std::memcmp(ctx->bridge_lut_host.data(), v->bridge_lut, n * sizeof(float)) != 0) {
-        if (!ctx->d_bridge_lut) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_bridge_lut, n * sizeof(float)));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_bridge_lut, v->bridge_lut, n * sizeof(float), hipMemcpyHostToDevice));
-        ctx->bridge_lut_host.assign(v->bridge_lut, v->bridge_lut + n);
-      }
-      sc.bridge_lut = ctx->d_bridge_lut;
-    }
-  }
-  // the moon's texture ids follow the texture pool (the host layer appends the two moon textures behind the scene's own): an added texture moves them
-  sc.sky_moon_albedo_tex = v->sky_moon_albedo_tex; sc.sky_moon_normal_tex = v->sky_moon_normal_tex;
   // ---- BSDF energy tables: taken from the caller or generated here (device/device_bsdf.c:64-130) ----
   const uint16_t* host_luts[4] = {v->lut_conductor, v->lut_glossy, v->lut_dielectric, v->lut_dielectric_inv};
   const uint32_t lut_count[4] = {1024, 1024, 32768, 32768};
@@ -1349,6 +1339,26 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     }
   }
   }  // constants
+  // ---- bridges to emissive triangles (fog, or an ocean with triangle_light_contribution): the vertex-count table. Decided after EVERY update, not
+  // only when the constants are dirty: a material that becomes emissive (MATERIALS | LIGHTS) gives a fogged scene its first light, and
+  // bridges_vertex_count_importance reads the table without a check. The table lives in the context (5 KB, uploaded once per content). ----
+  {
+    const bool need_bridges = (sc.fog_active || (sc.ocean_active && sc.ocean_triangle_light_contribution)) && sc.num_lights > 0 && sc.light_tree_root;
+    sc.bridge_lut = nullptr;
+    if (need_bridges) {
+      if (!v->bridge_lut) { ctx->error = sc.fog_active ? "lumc_scene_upload: fog with emissive triangles needs bridge_lut" : "lumc_scene_upload: an ocean lit by emissive triangles needs bridge_lut"; return 1; }
+      if (sc.bridge_max_num_vertices == 0) { ctx->error = "lumc_scene_upload: bridge_max_num_vertices must be at least 1"; return 1; }
+      const size_t n = (size_t) 64 * 21;
+      if (!ctx->d_bridge_lut || ctx->bridge_lut_host.size() != n || std::memcmp(ctx->bridge_lut_host.data(), v->bridge_lut, n * sizeof(float)) != 0) {
+        if (!ctx->d_bridge_lut) HIP_TRY(ctx, hipMalloc((void**) &ctx->d_bridge_lut, n * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_bridge_lut, v->bridge_lut, n * sizeof(float), hipMemcpyHostToDevice));
+        ctx->bridge_lut_host.assign(v->bridge_lut, v->bridge_lut + n);
+      }
+      sc.bridge_lut = ctx->d_bridge_lut;
+    }
+  }
+  // the moon's texture ids follow the texture pool (the host layer appends the two moon textures behind the scene's own): an added texture moves them
+  sc.sky_moon_albedo_tex = v->sky_moon_albedo_tex; sc.sky_moon_normal_tex = v->sky_moon_normal_tex;
   ctx->has_scene = true;
   return 0;
 }
@@ -1420,7 +1430,10 @@ int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, ui
   }
   ctx->sky_hdri_key.clear();
   if (ctx->sky_hdri_dim != dim) {
-    if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
+    if (ctx->d_gather_send) (void) hipFree(ctx->d_gather_send);
+  if (ctx->d_gather_recv) (void) hipFree(ctx->d_gather_recv);
+  if (ctx->d_gather_pixels) (void) hipFree(ctx->d_gather_pixels);
+  if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
     ctx->d_sky_hdri = nullptr; ctx->sky_hdri_dim = 0;
     HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sky_hdri, sizeof(float4) * (size_t) dim * dim));
     ctx->sky_hdri_dim = dim;
@@ -2451,6 +2464,150 @@ int lumc_frame_assemble_all(LumContext** ctxs, int n, uint32_t frame_pixels, int
     HIP_TRY(r, hipDeviceSynchronize());
     (void) hipFree(staging);
   }
+  if (d_frame_root) *d_frame_root = r->d_frame;
+  return 0;
+}
+
+// ---- tile gather: the frame assembled from the ranks' own pixels instead of a reduce over whole frames ----
+// Every pixel has one owner, so summing the ranks' zero-padded full frames (lumc_frame_assemble: 16 bytes per FRAME pixel from every rank, 133 MB per
+// rank at 4K) moves `world` times what is needed: a rank's contribution is the 16 bytes of each pixel it OWNS. Where the ranks' pixel sets are the tile
+// deal of lumc_tile_pixels (32 x 32 tiles dealt round-robin - what bench.py and the host API's tiled render loop use), every rank can compute every other
+// rank's pixel list, so nothing but the sums travels: each rank packs its [3][P] + [P] accumulators into a [4][M] buffer (M = the largest tile share,
+// zero padded: the deal is even to within one tile), ONE ncclGather brings the `world` buffers to the root, and a scatter kernel on the root puts every
+// value at its pixel. Reference: device_result_interface.c:107-299 (sample partition, sums staged through pinned host memory).
+namespace {
+__global__ __launch_bounds__(256) void k_gather_pack(const float* __restrict__ fm, const float* __restrict__ sm, uint32_t n, uint32_t stride, float* __restrict__ send) {
+  for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < stride; p += gridDim.x * 256u) {
+    const bool in = p < n;
+    send[p] = in ? fm[p] : 0.0f; send[stride + p] = in ? fm[n + p] : 0.0f; send[2u * stride + p] = in ? fm[2u * n + p] : 0.0f; send[3u * stride + p] = in ? sm[p] : 0.0f;
+  }
+}
+__global__ __launch_bounds__(256) void k_gather_unpack(const float* __restrict__ recv, const uint32_t* __restrict__ pixels, uint32_t world, uint32_t stride, uint32_t frame_pixels,
+                                                       float* __restrict__ frame) {
+  const uint32_t total = world * stride;
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const uint32_t index = pixels[i];
+    if (index >= frame_pixels) continue;  // padding
+    const uint32_t r = i / stride, p = i - r * stride;
+    const float* src = recv + (size_t) r * 4u * stride;
+    frame[index] = src[p]; frame[frame_pixels + index] = src[stride + p]; frame[2u * frame_pixels + index] = src[2u * stride + p]; frame[3u * frame_pixels + index] = src[3u * stride + p];
+  }
+}
+
+constexpr uint32_t kGatherTile = 32u;  // the deal bench.py, luminary_amd/distributed.py and the host API use
+
+// Sizes this context's gather buffers for (width, height, world): the send buffer on every rank, the receive buffer and the pixel lists on the root.
+// Fails when this context's pixel count is not its share of the deal (the gather is only for the standard deal; anything else reduces).
+int gather_prepare(LumContext* ctx, uint32_t width, uint32_t height, int world, int rank, bool is_root) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint32_t share = 0, stride = 0;
+  for (int r = 0; r < world; r++) {
+    uint32_t c = 0;
+    if (lumc_tile_pixels(width, height, (uint32_t) r, (uint32_t) world, kGatherTile, nullptr, &c)) { ctx->error = "lumc_frame_gather: bad deal"; return 1; }
+    if (r == rank) share = c;
+    stride = std::max(stride, c);
+  }
+  if (!ctx->d_first_moment || ctx->num_pixels != share || (world > 1 && !ctx->d_pixels)) {
+    ctx->error = "lumc_frame_gather: this context's pixel set is not its share of the 32x32 tile deal (use lumc_frame_assemble for other partitions)";
+    return 1;
+  }
+  stride = (stride + 3u) & ~3u;
+  const bool same = ctx->gather_key[0] == width && ctx->gather_key[1] == height && ctx->gather_key[2] == (uint32_t) world && ctx->gather_stride == stride && ctx->d_gather_send;
+  if (!same) {
+    if (ctx->d_gather_send) (void) hipFree(ctx->d_gather_send);
+    if (ctx->d_gather_pixels) (void) hipFree(ctx->d_gather_pixels);
+    ctx->d_gather_send = nullptr; ctx->d_gather_pixels = nullptr;
+    HIP_TRY(ctx, hipMalloc((void**) &ctx->d_gather_send, sizeof(float) * 4 * (size_t) stride));
+    ctx->gather_stride = stride; ctx->gather_key[0] = width; ctx->gather_key[1] = height; ctx->gather_key[2] = (uint32_t) world;
+  }
+  if (is_root) {
+    const size_t need = (size_t) world * 4 * stride;
+    if (ctx->gather_recv_floats < need) {
+      if (ctx->d_gather_recv) (void) hipFree(ctx->d_gather_recv);
+      ctx->d_gather_recv = nullptr; ctx->gather_recv_floats = 0;
+      HIP_TRY(ctx, hipMalloc((void**) &ctx->d_gather_recv, sizeof(float) * need));
+      ctx->gather_recv_floats = need;
+    }
+    if (!ctx->d_gather_pixels) {
+      std::vector<uint32_t> lists((size_t) world * stride, 0xFFFFFFFFu);
+      for (int r = 0; r < world; r++) { uint32_t c = 0; (void) lumc_tile_pixels(width, height, (uint32_t) r, (uint32_t) world, kGatherTile, lists.data() + (size_t) r * stride, &c); }
+      HIP_TRY(ctx, hipMalloc((void**) &ctx->d_gather_pixels, sizeof(uint32_t) * lists.size()));
+      HIP_TRY(ctx, hipMemcpy(ctx->d_gather_pixels, lists.data(), sizeof(uint32_t) * lists.size(), hipMemcpyHostToDevice));
+    }
+    const uint32_t frame_pixels = width * height;
+    if (ctx->frame_capacity != frame_pixels) {
+      if (ctx->d_frame) (void) hipFree(ctx->d_frame);
+      ctx->d_frame = nullptr; ctx->frame_capacity = 0;
+      HIP_TRY(ctx, hipMalloc((void**) &ctx->d_frame, sizeof(float) * 4 * (size_t) frame_pixels));
+      ctx->frame_capacity = frame_pixels;
+    }
+  }
+  return 0;
+}
+int gather_pack(LumContext* ctx, hipStream_t stream) {
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(k_gather_pack, dim3(grid_for(ctx->gather_stride)), dim3(256), 0, stream, (const float*) ctx->d_first_moment, (const float*) ctx->d_second_moment, ctx->num_pixels,
+                     ctx->gather_stride, ctx->d_gather_send);
+  HIP_TRY(ctx, hipGetLastError());
+  return 0;
+}
+int gather_unpack(LumContext* root, int world, hipStream_t stream) {
+  HIP_TRY(root, hipSetDevice(root->device));
+  hipLaunchKernelGGL(k_gather_unpack, dim3(grid_for((uint32_t) world * root->gather_stride)), dim3(256), 0, stream, (const float*) root->d_gather_recv, (const uint32_t*) root->d_gather_pixels,
+                     (uint32_t) world, root->gather_stride, root->frame_capacity, root->d_frame);
+  HIP_TRY(root, hipGetLastError());
+  return 0;
+}
+}  // namespace
+
+// One process per GPU (lumc_comm_init_rank): pack, one ncclGather to `root`, scatter on the root. Without a communicator (one rank) the pack is copied.
+int lumc_frame_gather(LumContext* ctx, uint32_t width, uint32_t height, int root, void* stream_, float** d_frame_out) {
+  if (!ctx) return 1;
+  hipStream_t stream = (hipStream_t) stream_;
+  const int world = ctx->comm ? ctx->comm_world : 1, rank = ctx->comm ? ctx->comm_rank : 0;
+  if (root < 0 || root >= world) { ctx->error = "lumc_frame_gather: bad root"; return 1; }
+  if (gather_prepare(ctx, width, height, world, rank, rank == root)) return 1;
+  if (gather_pack(ctx, stream)) return 1;
+  const size_t count = 4 * (size_t) ctx->gather_stride;
+  if (ctx->comm) NCCL_TRY(ctx, ncclGather(ctx->d_gather_send, rank == root ? ctx->d_gather_recv : nullptr, count, ncclFloat, root, ctx->comm, stream));
+  else HIP_TRY(ctx, hipMemcpyAsync(ctx->d_gather_recv, ctx->d_gather_send, sizeof(float) * count, hipMemcpyDeviceToDevice, stream));
+  if (rank == root && gather_unpack(ctx, world, stream)) return 1;
+  if (d_frame_out) *d_frame_out = rank == root ? ctx->d_frame : nullptr;
+  return 0;
+}
+
+// One process, several GPUs (ctxs[i] holds share i of the deal over n): a grouped ncclGather when the contexts share a communicator
+// (lumc_comm_init_all), peer copies of the packed buffers into the root's receive buffer otherwise.
+int lumc_frame_gather_all(LumContext** ctxs, int n, uint32_t width, uint32_t height, int root, float** d_frame_root) {
+  if (!ctxs || n < 1 || root < 0 || root >= n) return 1;
+  bool rccl = n > 1;
+  for (int i = 0; i < n; i++) {
+    if (!ctxs[i]) return 1;
+    if (gather_prepare(ctxs[i], width, height, n, i, i == root) || gather_pack(ctxs[i], (hipStream_t) 0)) { if (i) ctxs[0]->error = ctxs[i]->error; return 1; }
+    rccl = rccl && ctxs[i]->comm && ctxs[i]->comm_world == n && ctxs[i]->comm_rank == i;
+  }
+  LumContext* r = ctxs[root];
+  const size_t count = 4 * (size_t) r->gather_stride;
+  if (rccl) {
+    NCCL_TRY(r, ncclGroupStart());
+    for (int i = 0; i < n; i++) {
+      (void) hipSetDevice(ctxs[i]->device);
+      const ncclResult_t e = ncclGather(ctxs[i]->d_gather_send, i == root ? r->d_gather_recv : nullptr, count, ncclFloat, root, ctxs[i]->comm, (hipStream_t) 0);
+      if (e != ncclSuccess) { (void) ncclGroupEnd(); r->error = std::string("ncclGather failed: ") + ncclGetErrorString(e); return 1; }
+    }
+    NCCL_TRY(r, ncclGroupEnd());
+    for (int i = 0; i < n; i++) { HIP_TRY(r, hipSetDevice(ctxs[i]->device)); HIP_TRY(r, hipDeviceSynchronize()); }
+  }
+  else {
+    for (int i = 0; i < n; i++) {
+      HIP_TRY(r, hipSetDevice(ctxs[i]->device));
+      HIP_TRY(r, hipDeviceSynchronize());
+      HIP_TRY(r, hipSetDevice(r->device));
+      HIP_TRY(r, hipMemcpyPeer(r->d_gather_recv + (size_t) i * count, r->device, ctxs[i]->d_gather_send, ctxs[i]->device, sizeof(float) * count));
+    }
+  }
+  if (gather_unpack(r, n, (hipStream_t) 0)) return 1;
+  HIP_TRY(r, hipDeviceSynchronize());
   if (d_frame_root) *d_frame_root = r->d_frame;
   return 0;
 }

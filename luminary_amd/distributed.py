@@ -34,6 +34,36 @@ def assemble_frame(first_moment, second_moment, pixels, num_frame_pixels, dist=N
     return full
 
 
+def gather_frame(first_moment, second_moment, width, height, rank, world, dist=None, dst=0, tile=32):
+    """The same frame by a GATHER of the ranks' own pixels (what lumc_frame_gather does behind the C ABI with one ncclGather): every rank packs its planar
+    accumulators into a zero-padded [4, M] buffer (M = the largest share of the tile deal, a function of (width, height, world) every rank computes),
+    `dst` receives the `world` buffers and scatters each through that rank's pixel list, which it derives from the deal itself. 16 bytes per OWNED pixel
+    travel instead of 16 bytes per frame pixel from every rank. Returns the [4, W*H] frame on `dst`, None elsewhere."""
+    import torch
+    shares = [tile_pixels(width, height, r, world, tile) for r in range(world)] if (dist is None or rank == dst) else None
+    counts = [int(s.size) for s in shares] if shares is not None else None
+    if counts is None:  # the share sizes follow from the deal alone
+        counts = [int(tile_pixels(width, height, r, world, tile).size) for r in range(world)]
+    stride = (max(counts) + 3) & ~3
+    p = counts[rank]
+    assert first_moment.numel() == 3 * p and second_moment.numel() == p, "this rank's accumulators are not its share of the deal"
+    send = torch.zeros(4, stride, dtype=torch.float32, device=first_moment.device)
+    send[0:3, :p] = first_moment.view(3, p)
+    send[3, :p] = second_moment
+    if dist is None:
+        received = [send]
+    else:
+        received = [torch.zeros_like(send) for _ in range(world)] if rank == dst else None
+        dist.gather(send, received, dst=dst)
+        if rank != dst:
+            return None
+    full = torch.zeros(4, width * height, dtype=torch.float32, device=first_moment.device)
+    for r in range(world):
+        idx = torch.from_numpy(np.ascontiguousarray(shares[r]).astype(np.int64)).to(full.device)
+        full.index_copy_(1, idx, received[r][:, :counts[r]])
+    return full
+
+
 def block_mask(width, height, rank, world, tile=32):
     """Adaptive-sampling blocks (4x4 pixels, row-major over ceil(w/4) x ceil(h/4)) owned by `rank` under the same tile deal as
     tile_pixels: a block belongs to the rank of the tile it lies in (tiles are whole blocks: tile % 4 == 0)."""

@@ -30,8 +30,12 @@ def _render(core, mode, spp=8, batch=4):
 
 
 def _scene(name, tmp):
-    if name == "cornell":
-        return scenes.cornell_host(str(tmp), 96, 96, 6)
+    if name == "cornell":        # the generated box has a black sky (no ambient sample at all): give it one, the box is open at the front
+        host = scenes.cornell_host(str(tmp), 96, 96, 6)
+        sky = host.get_sky()
+        sky.constant_color.r, sky.constant_color.g, sky.constant_color.b = 0.5, 0.6, 0.8
+        host.set_sky(sky)
+        return host
     if name == "zoo":            # glass, coloured transparency, metals, hundreds of emitters: transparent first hits -> the fallback pass
         return scenes.zoo_scene(96, 64, 8)
     if name == "textured":       # alpha cut-outs and texture-driven transparency: the cut-out flag -> the fallback pass

@@ -15,7 +15,7 @@ def _worker(rank, world, port, tmp, result_file, width=48, height=32, tile=8):
     import torch.distributed as dist
     import oracle_lib
     from luminary_amd import scenes
-    from luminary_amd.distributed import assemble_frame, tile_pixels
+    from luminary_amd.distributed import assemble_frame, gather_frame, tile_pixels
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,10 +23,15 @@ def _worker(rank, world, port, tmp, result_file, width=48, height=32, tile=8):
     px = tile_pixels(view.width, view.height, rank, world, tile=tile)
     fm, sm, _ = oracle_lib.render(view, 0, 2, pixels=px, threads=2)
     full = assemble_frame(torch.from_numpy(fm.reshape(-1)), torch.from_numpy(sm), px, view.width * view.height, dist, 0)
+    # ... and the same frame by a gather of the ranks' own pixels (lumc_frame_gather's scheme: padded shares, the root derives every rank's pixel list)
+    gathered = gather_frame(torch.from_numpy(fm.reshape(-1)), torch.from_numpy(sm), view.width, view.height, rank, world, dist, 0, tile=tile)
     if rank == 0:
         ref_fm, ref_sm, _ = oracle_lib.render(view, 0, 2, threads=2)
         ok = np.array_equal(full[:3].numpy(), ref_fm) and np.array_equal(full[3].numpy(), ref_sm)
+        ok = ok and gathered is not None and np.array_equal(gathered.numpy(), full.numpy())
         open(result_file, "w").write("ok" if ok else "mismatch")
+    else:
+        assert gathered is None
     dist.barrier()
     dist.destroy_process_group()
 

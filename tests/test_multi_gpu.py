@@ -238,6 +238,68 @@ def test_bench_under_torchrun_reduces_through_the_c_abi():
     assert len(line) <= 4096
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0
-    assert out["config"]["frame_reduce"].startswith("C ABI"), out["config"]["frame_reduce"]
+    assert out["config"]["frame_reduce"].startswith("C ABI: lumc_frame_gather"), out["config"]["frame_reduce"]
     assert out["config"]["rccl_ranks"] == 1
     assert out["config"]["partition"].startswith("32x32")
+
+
+@pytest.mark.gpu
+def test_rccl_tile_gather_with_a_one_rank_communicator():
+    """lumc_frame_gather on the box's one GPU: the context holds share 0 of 1 of the tile deal (the whole frame, in tile order), packs it, ncclGather with a
+    one-rank communicator, the scatter by the deal's pixel list - the frame must hold every pixel's sums at its place. A pixel set that is not a share of the
+    deal is refused (those reduce)."""
+    w, h = 100, 70
+    host = scenes.example_scene(w, h, 3, sphere_segments=8, ground_res=12, num_objects=16, num_lights=4)
+    view = oracle_lib.with_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.upload(view)
+        px = Core.tile_pixels(w, h, 0, 1)
+        core.set_pixels(px)
+        core.render(0, 2, samples_per_pass=2)
+        fm, sm = core.accumulators()
+        core.comm_init_rank(1, 0, Core.comm_unique_id())
+        assert core.frame_gather(w, h, 0)
+        ffm, fsm = core.frame_download(w * h)
+        core.set_pixels(px[: px.size // 2])
+        from luminary_amd.core import CoreError
+        with pytest.raises(CoreError):
+            core.frame_gather(w, h, 0)
+    finally:
+        core.close()
+    want = np.zeros((3, w * h), dtype=np.float32)
+    want[:, px] = fm
+    want_sm = np.zeros(w * h, dtype=np.float32)
+    want_sm[px] = sm
+    assert np.array_equal(ffm, want) and np.array_equal(fsm, want_sm)
+    ofm, osm, _ = oracle_lib.render(view, 0, 2)
+    assert np.array_equal(ffm, ofm) and np.array_equal(fsm, osm)
+
+
+@pytest.mark.gpu
+def test_tile_gather_over_three_contexts_equals_the_reduce_and_the_single_render():
+    """lumc_frame_gather_all with three contexts (all on device 0: RCCL refuses that, so the packed buffers travel by peer copy - the pack, the padding of
+    uneven shares and the root's scatter through the other ranks' pixel lists are what is under test) against lumc_frame_assemble_all and a full-frame render."""
+    import ctypes as C
+    w, h = 100, 70  # 4 x 3 tiles of 32: shares of 4 / 4 / 4 tiles with ragged right and bottom edges
+    host = scenes.example_scene(w, h, 3, sphere_segments=8, ground_res=12, num_objects=16, num_lights=4)
+    view = oracle_lib.with_luts(host.device_scene())
+    cores = [Core(0) for _ in range(3)]
+    try:
+        for r, c in enumerate(cores):
+            c.upload(view)
+            c.set_pixels(Core.tile_pixels(w, h, r, 3))
+            c.render(0, 2, samples_per_pass=2)
+        lib = luminary_amd._lib()
+        arr = (C.c_void_p * 3)(*[c._ctx for c in cores])
+        out = C.c_void_p()
+        assert lib.lumc_frame_gather_all(arr, 3, C.c_uint32(w), C.c_uint32(h), 0, C.byref(out)) == 0
+        gfm, gsm = cores[0].frame_download(w * h)
+        assert lib.lumc_frame_assemble_all(arr, 3, C.c_uint32(w * h), 0, C.byref(out)) == 0
+        rfm, rsm = cores[0].frame_download(w * h)
+    finally:
+        for c in cores:
+            c.close()
+    assert np.array_equal(gfm, rfm) and np.array_equal(gsm, rsm), "gather == reduce"
+    ofm, osm, _ = oracle_lib.render(view, 0, 2)
+    assert np.array_equal(gfm, ofm) and np.array_equal(gsm, osm), "... == the frame rendered in one piece"

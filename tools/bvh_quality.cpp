@@ -261,6 +261,58 @@ static BinTree build_ploc_model(const std::vector<Aabb>& boxes, std::vector<uint
   std::printf("ploc: radius %d, %d iterations, %zu clusters left\n", radius, iterations, cur.size());
   return t;
 }
+// Insertion-based optimisation (Bittner et al. 2013; bvh_build.cpp Reinserter) on the model trees: BQ_REINSERT=<passes>. What would a clustered tree gain from it?
+static void reinsert_model(BinTree& t, int passes) {
+  const size_t n = t.left.size();
+  std::vector<int> parent(n, -1);
+  for (size_t i = 0; i < n; i++) if (t.left[i] >= 0) { parent[t.left[i]] = (int) i; parent[t.right[i]] = (int) i; }
+  auto refit_up = [&](int i) { while (i >= 0) { t.box[i] = merge(t.box[t.left[i]], t.box[t.right[i]]); i = parent[i]; } };
+  std::vector<std::pair<float, int>> heap;
+  auto cmp = [](const std::pair<float, int>& a, const std::pair<float, int>& b) { return a.first > b.first; };
+  for (int pass = 0; pass < passes; pass++) {
+    std::vector<int> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::vector<float> key(n);
+    for (size_t i = 0; i < n; i++) key[i] = half_area(t.box[i]);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return key[a] > key[b] || (key[a] == key[b] && a < b); });
+    double before = 0; for (size_t i = 0; i < n; i++) if (t.left[i] >= 0) before += half_area(t.box[i]);
+    size_t moved = 0;
+    for (int nd : order) {
+      const int p = parent[nd];
+      if (p < 0 || p == t.root) continue;
+      const int g = parent[p], s = t.left[p] == nd ? t.right[p] : t.left[p];
+      (t.left[g] == p ? t.left[g] : t.right[g]) = s; parent[s] = g; refit_up(g);
+      const Aabb nb = t.box[nd]; const float na = half_area(nb);
+      float best_cost = INFINITY; int best = s;
+      heap.clear(); heap.emplace_back(0.0f, t.root);
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const float induced = heap.back().first; const int x = heap.back().second; heap.pop_back();
+        if (induced + na >= best_cost) break;
+        const float total = induced + half_area(merge(t.box[x], nb));
+        if (total < best_cost) { best_cost = total; best = x; }
+        if (t.left[x] >= 0) {
+          const float ci = total - half_area(t.box[x]);
+          if (ci + na < best_cost) { heap.emplace_back(ci, t.left[x]); std::push_heap(heap.begin(), heap.end(), cmp); heap.emplace_back(ci, t.right[x]); std::push_heap(heap.begin(), heap.end(), cmp); }
+        }
+      }
+      if (parent[best] < 0) best = s;
+      const int bp = parent[best];
+      (t.left[bp] == best ? t.left[bp] : t.right[bp]) = p; parent[p] = bp;
+      t.left[p] = best; t.right[p] = nd; parent[best] = p; parent[nd] = p;
+      refit_up(p);
+      moved += best != s;
+    }
+    double after = 0; for (size_t i = 0; i < n; i++) if (t.left[i] >= 0) after += half_area(t.box[i]);
+    std::printf("reinsertion pass %d: %zu subtrees moved, inner area %.6g -> %.6g\n", pass, moved, before, after);
+  }
+  // subtree sizes
+  std::function<uint32_t(int)> cnt = [&](int b) -> uint32_t { if (t.left[b] < 0) return t.count[b] = 1; return t.count[b] = cnt(t.left[b]) + cnt(t.right[b]); };
+  std::vector<int> stack{t.root}, post;
+  while (!stack.empty()) { const int b = stack.back(); stack.pop_back(); post.push_back(b); if (t.left[b] >= 0) { stack.push_back(t.left[b]); stack.push_back(t.right[b]); } }
+  for (size_t k = post.size(); k-- > 0;) { const int b = post[k]; t.count[b] = t.left[b] < 0 ? 1u : t.count[t.left[b]] + t.count[t.right[b]]; }
+}
+
 // k_lbvh_collapse's rule: open the child with the largest box until there are four; a subtree of at most max_leaf primitives is a leaf.
 static Bvh4 collapse_model(const BinTree& t, const std::vector<uint32_t>& order, uint32_t max_leaf) {
   Bvh4 out;
@@ -475,7 +527,8 @@ int main(int argc, char** argv) {
       bvh = hybrid_model(t, order, roots, kBvhLeafMaxTri);
     }
     else {
-    const BinTree t = builder == "lbvh" ? build_lbvh_model(boxes, order) : build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 16);
+    BinTree t = builder == "lbvh" ? build_lbvh_model(boxes, order) : build_ploc_model(boxes, order, argc > 4 ? std::atoi(argv[4]) : 16);
+    if (std::getenv("BQ_REINSERT")) reinsert_model(t, std::atoi(std::getenv("BQ_REINSERT")));
     bvh = collapse_model(t, order, std::getenv("BQ_MAX_LEAF") ? (uint32_t) std::atoi(std::getenv("BQ_MAX_LEAF")) : kBvhLeafMaxTri);
     }
   }
