@@ -39,6 +39,29 @@ struct alignas(128) Bvh8Node {
 };
 static_assert(sizeof(Bvh8Node) == 128, "BVH8 node must be one cache line");
 
+// 8-wide node with its children in OCTANT SLOTS (LUM_BVH8O; after Ylitie, Karras, Laine: "Efficient Incoherent Ray Traversal on GPUs Through Compressed
+// Wide BVHs", HPG 2017 - the format of the reference's own, unused software traversal: node src/luminary/utils.h:123-138, slot assignment bvh.c:1093-1145,
+// traversal order cuda/bvh.cuh:82-106). The builder puts the child whose centre lies towards octant direction s (bit a set: the +a side of the node's
+// centre) into slot s; a ray whose direction signs are `oct` (bit a set: d_a < 0) meets the slots roughly front to back in the order s ^ oct = 0 ... 7, so
+// a visit needs no distances, no sort and ONE stack entry (the group of children still to be walked) instead of up to seven. 80 bytes of a 128-byte slot:
+//   16 B  origin xyz | biased exponents of the per-axis scale x, y, z | imask (bit s: slot s holds an inner node)
+//   16 B  child_base (the inner children are consecutive nodes, in slot order) | leaf_base | meta[8]: leaf slot s = offset (5 bits) | count - 1 (2 bits):
+//         its primitives are leaf_base + offset ... (the builder reorders the triangles / top-level leaf records node by node); other slots 0
+//   48 B  lo_x[8] lo_y[8] | lo_z[8] hi_x[8] | hi_y[8] hi_z[8]: one byte per slot, child box = origin + q * 2^(e - 127), rounded outwards; empty slots hold
+//         inverted boxes (lo 255, hi 0) and are never entered
+#ifndef LUM_BVH8O
+#define LUM_BVH8O 0
+#endif
+struct alignas(128) Bvh8oNode {
+  float origin[3];
+  uint8_t exp[3], imask;
+  uint32_t child_base, leaf_base;
+  uint8_t meta[8];
+  uint8_t lo_x[8], lo_y[8], lo_z[8], hi_x[8], hi_y[8], hi_z[8];
+  uint32_t pad[12];
+};
+static_assert(sizeof(Bvh8oNode) == 128, "one slot");
+
 // 4-wide node with quantised child boxes in half a cache line (LUM_BVH4Q): same tree, same node indices, same child words as Bvh4Node; child j's box =
 // origin + q * 2^(e - 127) per axis, lower corners rounded down, upper up (the boxes only grow). A visit fetches 64 instead of 112 bytes and the LDS
 // holds twice the nodes; it pays with 24 byte->float conversions. Scene and particle trees; the light tree keeps float boxes.
@@ -180,6 +203,7 @@ struct NeeQueue {
   float4* bsdf_weight_sum;  // shade: bsdf weight rgb | light-tree root sum; after the light query: light colour rgb | valid flag
   uint4* ambient;           // packed colour (record format) xy | packed ray zw
   uint4* sun;               // same for the sun sample (written and read unless the sky is a constant colour)
+  uint32_t* amb_path;       // ambient-visibility reuse (kernels.h): the surviving path's index in the next queue - its closest hit answers the ambient sample - or none
   // only with an active ocean (dev_water.h): what lies between the two visibility segments of a sun / ambient sample taken under water
   float4* sun_water;        // 1 - Fresnel reflection at the surface | - | - | flags (uint bits: second segment, total reflection)
   float4* amb_t1;           // transmittance of the vertex's volume up to the surface rgb | 1 - Fresnel reflection

@@ -8,15 +8,23 @@
 // Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
 // the candidate set only (see light_query).
 //
-// Execution model (gfx950): the ray kernels are chains of dependent memory round trips at 3 waves per SIMD; no unit is saturated
-// (VALU issue ~60 %, L1 address path 30-60 %, L2 ~40 %, HBM < 30 %), so both the instructions and the round trips per wave iteration
-// count:
+// Execution model (gfx950; counters of round 3, profiles/pmc_counters.json): one ray per lane, persistent waves, 4 waves per SIMD in
+// the fast flavour (128 VGPRs), 3 in the exact one. The kernels are bound by two units at once - the vector ALU issues 63-72 % of the time (of the
+// measured v_fma rate) at a lane utilisation of 0.46-0.54, and the vector-memory address unit is busy 70-81 % of the cycles (a divergent 16-byte lane
+// load costs it one cycle per lane: 7 per node visit that misses the staged top, 12 per leaf) - not by memory bandwidth (0.37-0.51 of 8 TB/s) and not
+// by latency as such (an L1->L2 read returns after ~400 cycles, a tenth of a wave iteration). So both the instructions and the lane loads per wave
+// iteration count:
 //   * one node visit = 7 x 16-byte loads (near/far planes picked by the ray's direction signs, so no per-axis min/max),
-//     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and branch-free pushes;
+//     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and conditional pushes: ~110 vector instructions;
 //   * every wave iteration runs ONE phase - node visit, instance entry or triangle tests - chosen by a vote over its lanes, so a
 //     lane that holds a leaf does not wait for the slowest lane of the wave to find one (plain while-while: 0.33-0.41 lane occupancy);
 //   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing;
-//   * the first nodes of the array (breadth-first across both levels) are staged in LDS by every workgroup.
+//   * the first nodes of the array (breadth-first across both levels) are staged in LDS by every workgroup, the oldest stack entries of every lane
+//     live there too.
+// Structural alternatives that were built and measured, and lost (profiles/r0*_ab_experiments.txt): 8-wide quantised nodes with a sorting network (twice),
+// 64-byte quantised 4-wide nodes, dual-node visits, speculative traversal past a leaf (LUM_SPECULATE, round 4: +7 % node visits, +16-19 % time),
+// physical ray reordering between bounces, per-XCD work ranges, LDS-DMA prefetch. The 8-wide octant-order node (no sort, one group entry per visit) was
+// prototyped as a visit routine and a CPU walk before a rewrite (tools/microbench/node_visit.hip, tools/bvh_quality.cpp BQ_WIDE): see DESIGN.md section 4.
 #pragma once
 
 #include "dev_light.h"
@@ -66,6 +74,14 @@ constexpr int kStackSize = 128;
 #define LUM_LDS_FIRST 1  // such iterations come before triangle and instance-entry phases (0: only where the node phase would have run anyway)
 #endif
 
+// Speculative traversal (after Aila, Laine: "Understanding the Efficiency of Ray Traversal on GPUs", HPG 2009): a lane that reaches a triangle leaf while
+// the wave goes on visiting nodes does not sit the node phases out. It sets the leaf aside (`postponed`, one register) and takes on the newest stack
+// entry when that is an inner node it may still have to visit; the leaf is tested when the wave's triangle phase comes. Results do not depend on the
+// order in which leaves and nodes are met (closest hits are a minimum, visibility a product / any blocker); what it can cost is visits that the
+// postponed leaf's hit would have culled. 1: closest-hit rays, 2: visibility rays, 3: both.
+#ifndef LUM_SPECULATE
+#define LUM_SPECULATE 0
+#endif
 #ifndef LUM_DUAL_VISIT
 #define LUM_DUAL_VISIT 0  // experiment, measured negative (visibility kernel +18 % on the hall): see visit_two_nodes
 #endif
@@ -106,10 +122,12 @@ LUM_DEV float vmin2(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=
 struct TRay {
   V3 o, d, inv, noi;  // noi = -(o * inv)
   uint32_t nx, ny, nz, fx, fy, fz;
+  uint32_t oct;       // direction signs, bit a set: inv_a < 0 (the octant-slot nodes of LUM_BVH8O are walked in the order slot ^ oct)
   LUM_DEV void set(V3 origin, V3 dir) {
     o = origin; d = dir;
     inv = v3(safe_inv(dir.x), safe_inv(dir.y), safe_inv(dir.z));
     noi = v3(-(origin.x * inv.x), -(origin.y * inv.y), -(origin.z * inv.z));
+    oct = (inv.x < 0.0f ? 1u : 0u) | (inv.y < 0.0f ? 2u : 0u) | (inv.z < 0.0f ? 4u : 0u);
     nx = (inv.x < 0.0f) ? 48u : 0u;  fx = 48u - nx;    // lo_x at 0, hi_x at 48
     ny = (inv.y < 0.0f) ? 64u : 16u; fy = 80u - ny;    // lo_y at 16, hi_y at 64
     nz = (inv.z < 0.0f) ? 80u : 32u; fz = 112u - nz;   // lo_z at 32, hi_z at 80
@@ -293,10 +311,10 @@ LUM_DEV uint32_t visit_node(const NodeSource& src, uint32_t cur, const TRay& r, 
 }
 
 // ---- 8-wide nodes with quantised child boxes (Bvh8Node): the scene's and the particles' trees ----
-// A ray kernel's time is the chain of dependent node fetches (VALU issue 0.25): eight children per 128-byte line instead of
-// four shorten that chain by a third to a half for the same bytes per visit; the boxes are 8-bit offsets from the node's corner in units of a
+// Eight children per 128-byte line instead of four: 22 % fewer node visits on the hall, the boxes 8-bit offsets from the node's corner in units of a
 // power of two per axis, rounded outwards by the builder (after Ylitie, Karras, Laine 2017, without their octant ordering: the eight entry
-// distances are sorted by a 19-comparator network).
+// distances are sorted by a 19-comparator network). Measured twice (rounds 1 and 2): a visit costs 215 instead of 110 vector instructions - 48
+// byte->float conversions and the network's 95 - and the kernels are issue-bound (section 4): closest-hit +9 %, visibility +10 % time. Off.
 LUM_DEV float byte_f(uint32_t w, uint32_t k) { return (float) ((w >> (8u * k)) & 0xFFu); }  // v_cvt_f32_ubyte{k}
 template <bool kOrdered, bool kCull, typename S>
 LUM_DEV uint32_t visit_node8(const NodeSource& src, uint32_t cur, const TRay& r, float tmax, S& stk, int& sp,
@@ -455,8 +473,8 @@ LUM_DEV NodeData load_node(const NodeSource& src, uint32_t id, const TRay& r, Ra
 }
 
 // Visibility rays visit every stacked node anyway (their segment never shrinks), so a lane whose newest stack entry is an inner node of the same
-// level takes it along: both nodes' lines are requested before either is tested, which halves the dependent round trips of a ray - the kernels
-// are bound by those, not by arithmetic (VALU issue 0.25). Measured (LUM_DUAL_VISIT=1): NOT faster - visibility kernel 121.9 -> 144.4 ms per 3 steps
+// level takes it along: both nodes' lines are requested before either is tested, which halves the dependent round trips of a ray (the idea of
+// round 2, when the kernels were thought to be bound by those; the counters of round 3 say issue rate and address unit). Measured (LUM_DUAL_VISIT=1): NOT faster - visibility kernel 121.9 -> 144.4 ms per 3 steps
 // on the hall, 32.6 -> 36.1 on the scan: rays that find an occluder have fetched a node they would never have visited (nodes per ray 15.2 -> 16.2),
 // lanes with and without a second node diverge, and the iteration carries twice the registers. Off. `second` = kBvhEmpty for lanes without such an entry. Every child of the second node
 // that the ray may touch is pushed; of the first node's children the nearest is continued with, as in visit_node.
@@ -569,6 +587,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
   V3 wo = v3(0.0f, 0.0f, 0.0f), wd = v3(0.0f, 0.0f, 1.0f);
   float tmax = 0.0f;
   uint32_t cur = kTraversalDone, inst = kNoInstance, idx = 0;
+  uint32_t postponed = kBvhEmpty;  // Q::kSpeculate: a leaf of the current instance set aside for the wave's next triangle phase
   r.set(wo, wd);
   bool more = true;
   // Experiment (LUM_DEFER_FINISH): results are stores, and on this part a store counts on the same in-order counter as the loads (vmcnt): written where
@@ -706,8 +725,18 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
     // (and the other way round), instead of waiting until every lane has found a leaf: measured lane occupancy of the node phase
     // was 0.33-0.41 with the plain while-while loop.
     while (true) {
+      if (Q::kSpeculate) {
+        // a lane on a leaf of an instance, nothing set aside yet, whose newest stack entry is an inner node within reach (markers, leaves and the
+        // sentinel carry the leaf bit): the leaf waits, the lane walks on. Such an entry always has something below it (the sentinel at least).
+        const uint32_t t = SE::node(top);
+        if (cur != kTraversalDone && (cur & kBvhLeafBit) && inst != kNoInstance && postponed == kBvhEmpty && !(t & kBvhLeafBit) && SE::reachable(top, tmax)) {
+          postponed = cur; cur = t; sp--; top = stk.load(sp);
+        }
+      }
       const bool live = cur != kTraversalDone;
       const bool at_leaf = live && (cur & kBvhLeafBit);
+      // (with speculation: a lane counts for the triangle vote when it cannot go on without the triangle phase; lanes that hold a postponed leaf and a
+      // node take part in both phases)
       const bool want_tris = at_leaf && inst != kNoInstance, want_enter = at_leaf && inst == kNoInstance;
       const uint32_t n_live = (uint32_t) __popcll(__ballot(live)), n_tris = (uint32_t) __popcll(__ballot(want_tris)), n_enter = (uint32_t) __popcll(__ballot(want_enter));
       if (n_live == 0u) break;
@@ -733,7 +762,7 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       const bool do_tris = run_tris && want_tris, do_enter = (run_enter && want_enter) || (staged_turn && want_enter && on_staged),
                  do_node = !run_tris && !run_enter && live && !at_leaf && (!staged_turn || on_staged);
 #else
-      const bool do_tris = run_tris && want_tris, do_enter = run_enter && want_enter, do_node = !run_tris && !run_enter && live && !at_leaf;
+      const bool do_tris = run_tris && (want_tris || (Q::kSpeculate && postponed != kBvhEmpty)), do_enter = run_enter && want_enter, do_node = !run_tris && !run_enter && live && !at_leaf;
 #endif
       LUM_TIME_BEGIN();
 #ifdef LUM_PHASE_STATS
@@ -742,7 +771,12 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
       {
         if (do_tris) {
           LUM_PHASE(3); LUM_PHASE_LANES(4);
-          if (q.on_tris(sc, inst, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
+          if (Q::kSpeculate && postponed != kBvhEmpty) {  // the leaf set aside first; the lane's place in the traversal (cur, a node or another leaf) stays
+            const uint32_t leaf = postponed;
+            postponed = kBvhEmpty;
+            if (q.on_tris(sc, inst, leaf & 0x0FFFFFFFu, ((leaf >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
+          }
+          else if (q.on_tris(sc, inst, cur & 0x0FFFFFFFu, ((cur >> 28) & 0x7u) + 1u, r.o, r.d, tmax, st)) cur = kTraversalDone;
           else pop();
           if (cur == kTraversalDone) { if (LUM_DEFER_FINISH) unwritten = true; else q.finish(sc, idx); }
         }
@@ -799,8 +833,12 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
           }
 #endif
           if (cur == kBvhEmpty) {
-            pop();
-            if (cur == kTraversalDone) { if (LUM_DEFER_FINISH) unwritten = true; else q.finish(sc, idx); }
+            // (with a leaf set aside nothing is popped: the next entry might be the way out of the instance the leaf belongs to)
+            if (Q::kSpeculate && postponed != kBvhEmpty) { cur = postponed; postponed = kBvhEmpty; }
+            else {
+              pop();
+              if (cur == kTraversalDone) { if (LUM_DEFER_FINISH) unwritten = true; else q.finish(sc, idx); }
+            }
           }
         }
       }
@@ -822,18 +860,30 @@ LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict
 #endif
 }
 
+LUM_NS_END
+#if LUM_BVH8O
+#include "dev_trace8.h"
+#define LUM_TRACE_ITEMS trace_items8
+#else
+#define LUM_TRACE_ITEMS trace_items
+#endif
+LUM_NS_BEGIN
+
 struct Hit { uint32_t instance_id, tri_id; float t; uint32_t scene_tri; };
 
 // Nearest hit in [0, FLT_MAX); optionally ignoring the triangle the path is leaving (STATE_FLAG_USE_IGNORE_HANDLE).
 struct ClosestState {
   static constexpr bool kDual = false;
+  static constexpr bool kSpeculate = (LUM_SPECULATE & 1) != 0;
   static constexpr bool kOrdered = true;
   static constexpr int kFarFirst = 0;
   static constexpr bool kCull = true;  // stack entries carry the entry distance: a pop drops children beyond the nearest hit so far
-  // Two facts ride along for the ambient-visibility reuse (TraceQuery, kernels.h) without a vector register of their own: bit 31 of best.scene_tri says
-  // that the nearest hit so far is an untextured alpha-1 triangle (kBvhTriOpaque: it would stop a visibility ray on its own), `cutout` (a lane mask in
-  // scalar registers, like use_ignore) that an alpha cut-out was skipped on the way (a visibility ray may have to multiply such a texel's colour in).
-  // result() hands out the clean triangle index.
+  // Two facts ride along for the ambient-visibility reuse (TraceQuery / k_resolve_reuse, kernels.h) without a vector register of their own: bit 31 of
+  // best.scene_tri says that the nearest hit so far is an untextured alpha-1 triangle (kBvhTriOpaque: it would stop a visibility ray on its own), `cutout`
+  // (a lane mask in scalar registers, like use_ignore) that an alpha cut-out was skipped on the way (a visibility ray may have to multiply such a
+  // texel's colour in). A visibility ray along the same ray over (eps, FLT_MAX) that ignores the same triangle reports 1 where nothing was hit and no
+  // cut-out skipped, 0 where the nearest hit lies beyond eps and is opaque on its own; everything else has to be traced. result() hands out the clean
+  // triangle index.
   static constexpr uint32_t kOpaqueBit = 0x80000000u;
   bool use_ignore, cutout;
   uint32_t ign_inst, ign_tri;
@@ -864,13 +914,6 @@ struct ClosestState {
     return false;
   }
   LUM_DEV Hit result() const { return (best.t == kFltMax) ? Hit{kHitSky, 0u, kFltMax, 0u} : Hit{best.instance_id, best.tri_id, best.t, best.scene_tri & ~kOpaqueBit}; }
-  // What a visibility ray along the same ray over (eps, FLT_MAX) with the same ignored triangle would report, where that follows from this query alone:
-  // 1 = nothing in the way (no hit, no cut-out skipped), 0 = blocked (the nearest hit lies beyond eps and is opaque on its own), -1 = unknown (the nearest
-  // surface is transparent or textured, or closer than eps, or a cut-out was skipped: the visibility ray has to be traced).
-  LUM_DEV int visibility_along() const {
-    if (best.t == kFltMax) return cutout ? -1 : 1;
-    return (best.t > kEps && (best.scene_tri & kOpaqueBit)) ? 0 : -1;
-  }
 };
 
 // Transparency along (eps, dist): product over crossed surfaces, zero as soon as one is opaque. Skips the sampled light
@@ -894,6 +937,7 @@ struct ShadowState {
 #endif
   static constexpr bool kCull = LUM_SHADOW_CULL != 0;  // the segment never shrinks: 4-byte stack entries (StackEntry<false>)
   static constexpr bool kDual = true;                  // two nodes per visit where the stack offers a second one (visit_two_nodes)
+  static constexpr bool kSpeculate = (LUM_SPECULATE & 2) != 0;
   uint32_t tgt_inst, tgt_tri, self_inst, self_tri;
   float dist;
 #if LUM_FAST

@@ -140,14 +140,16 @@ __global__ __launch_bounds__(kBlock) void k_generate(DeviceScene sc, PassParams 
 // Ambient-visibility reuse (fast flavour, plain scenes - lumc_set_ambient_reuse, core.hip). In a constant-colour or panorama sky the ambient sample of a
 // vertex runs along its bounce direction (direct_lighting.cuh:388-405): the closest-hit ray of the NEXT depth walks the same line. Where that ray's
 // nearest hit is opaque, or it hits nothing, the ambient visibility is known without a second traversal (94 % of the hall's ambient rays end at an opaque
-// surface). k_shade then queues no visibility ray for a surviving path but notes the path's new queue index in the vertex's ambient record; the
+// surface). k_shade then queues no visibility ray for a surviving path but notes the path's new queue index next to the vertex (nee.amb_path); the
 // closest-hit pass leaves two flag bits next to the hit's triangle index (below); k_resolve of the vertex's depth runs AFTER that pass and reads the
 // answer from the path's hit. What the nearest hit cannot decide (transparent or textured first hit, a hit closer than eps, a skipped cut-out) is listed,
-// traced by a small second visibility pass and resolved by k_resolve_listed. The reference traces the ambient ray along the direction after its
+// traced by a small second visibility pass - the very ray k_shade would have queued - and resolved by k_resolve_listed. The reference traces the ambient ray along the direction after its
 // 2 x 32-bit octahedral packing (ray_unpack(ray_pack(bounce))), a last-bit difference from the bounce ray: the exact flavour therefore keeps tracing it
 // (bit-identity with the oracle), the fast flavour does not promise the last bit anyway.
 constexpr uint32_t kNoAmbientPath = 0xFFFFFFFFu;
-constexpr uint32_t kHitTriOpaque = 0x80000000u, kHitTriCutout = 0x40000000u, kHitTriMask = 0x3FFFFFFFu;  // hit_scene_tri: flag bits above the triangle index
+// hit_scene_tri: flag bits above the triangle index (28 bits, like the leaf ranges): the hit is opaque on its own | a cut-out was skipped | the hit lies beyond
+// eps | something was hit - everything k_resolve_reuse needs to know about the path's closest hit, in the one word it reads
+constexpr uint32_t kHitTriOpaque = 0x80000000u, kHitTriCutout = 0x40000000u, kHitTriBeyondEps = 0x20000000u, kHitTriHit = 0x10000000u, kHitTriMask = 0x0FFFFFFFu;
 
 struct TraceQuery : ClosestState {
   PathQueue q;
@@ -169,7 +171,7 @@ struct TraceQuery : ClosestState {
     reinterpret_cast<float*>(&q.origin_t[i])[3] = h.t;
     *reinterpret_cast<uint2*>(&q.hit_id[i]) = make_uint2(h.instance_id, h.tri_id);
     static_assert(kOpaqueBit == kHitTriOpaque, "the opaque bit is stored where ClosestState keeps it");
-    q.hit_scene_tri[i] = ((best.t == kFltMax) ? 0u : best.scene_tri) | (cutout ? kHitTriCutout : 0u);
+    q.hit_scene_tri[i] = ((best.t == kFltMax) ? 0u : (best.scene_tri | kHitTriHit | (best.t > kEps ? kHitTriBeyondEps : 0u))) | (cutout ? kHitTriCutout : 0u);
   }
 };
 
@@ -180,7 +182,7 @@ __global__ LUM_TRACE_BOUNDS void k_trace(DeviceScene sc, PathQueue q, const uint
   tq.q = q;
   tq.order = order;
   tq.item = 0;
-  trace_items(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
+  LUM_TRACE_ITEMS(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
@@ -457,8 +459,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         }
         st_stream(&nee.geo_color_light[i], geo_cl);
         st_stream(&nee.bsdf_ray_prob[i], bs_rp); st_stream(&nee.bsdf_weight_sum[i], bs_ws);
-        if (reuse_ambient) reinterpret_cast<uint2*>(&nee.ambient[i])[0] = make_uint2(amb.x, amb.y);  // the other half after the appends: the path's next queue index
-        else st_stream(&nee.ambient[i], amb);
+        st_stream(&nee.ambient[i], amb);
 
         // delta-path classification (geometry.cuh:80-101)
         const float roughness = g.params.roughness();
@@ -528,8 +529,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
       st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
       amb_path = amb_deferred ? j : kNoAmbientPath;
     }
-    // the second half of the vertex's ambient record: the path's index in the next queue, or none (the packed ray is only read with fog, which excludes the reuse)
-    if (reuse_ambient && valid) reinterpret_cast<uint2*>(&nee.ambient[i])[1] = make_uint2(amb_path, 0u);
+    if (reuse_ambient && valid) nee.amb_path[i] = amb_path;  // every vertex of the depth: k_resolve_reuse reads it for each of them
     if (want_geo) {
       const uint32_t j = base_shadow + (uint32_t) __popcll(bg & below);
       st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
@@ -773,7 +773,7 @@ __global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, c
   ShadowQuery q;
   q.sq = sq;
   q.order = order;
-  trace_items(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
+  LUM_TRACE_ITEMS(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow, kCntNodesLdsShadow);
 }
 
@@ -865,17 +865,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve_reuse(DeviceScene sc, PathQu
     if (i < n) {
       const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
       if (resolves_here(hid.x)) {
-        const uint4 amb = nee.ambient[i];
-        j = ((amb.x != 0 || amb.y != 0)) ? amb.z : kNoAmbientPath;
+        j = nee.amb_path[i];
         if (j == kNoAmbientPath) resolve_vertex<false>(sc, in, nee, sq, results, i, lights_present, 0.0f);  // no ambient sample, or its visibility ray was traced (the path ended here)
         else {
-          const float t = next.origin_t[j].w;
           const uint32_t word = next.hit_scene_tri[j];
           int v;
-          if (t == kFltMax) v = (word & kHitTriCutout) ? -1 : 1;
-          else v = (t > kEps && (word & kHitTriOpaque)) ? 0 : -1;
+          if (!(word & kHitTriHit)) v = (word & kHitTriCutout) ? -1 : 1;
+          else v = ((word & (kHitTriBeyondEps | kHitTriOpaque)) == (kHitTriBeyondEps | kHitTriOpaque)) ? 0 : -1;
           if (v >= 0) resolve_vertex<true>(sc, in, nee, sq, results, i, lights_present, (float) v);
-          else { undecided = true; self = hid; }
+          else { undecided = true; self = hid; }  // (j is not needed any more: the ray below is the vertex's own ambient ray)
         }
       }
     }
@@ -889,9 +887,13 @@ __global__ __launch_bounds__(kBlock) void k_resolve_reuse(DeviceScene sc, PathQu
       base = __shfl(base, __builtin_ctzll(bu));
       if (undecided) {
         const uint32_t k = base + (uint32_t) __popcll(bu & below);
-        const float4 o4 = next.origin_t[j], d4 = next.dir_slot[j];
-        sq.origin_dist[k] = make_float4(o4.x, o4.y, o4.z, kFltMax);
-        sq.dir_out[k] = make_float4(d4.x, d4.y, d4.z, bitsf(2u * sq.capacity + i));
+        // exactly the item k_shade would have queued: from the hit point along the ambient record's packed direction (direct_lighting.cuh:388-405)
+        const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+        const V3 hit_origin = v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w;
+        const uint4 amb = nee.ambient[i];
+        const V3 ar = ray_unpack(U2{amb.z, amb.w});
+        sq.origin_dist[k] = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, kFltMax);
+        sq.dir_out[k] = make_float4(ar.x, ar.y, ar.z, bitsf(2u * sq.capacity + i));
         sq.ids[k] = make_uint4(0xFFFFFFFFu, 0u, self.x, self.y);
         sq.light_items[k] = i;
       }
@@ -914,6 +916,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_listed(DeviceScene sc, PathQ
 // same traversal on the particle tree (the scene argument carries that tree in place of the surfaces').
 struct ParticleQuery {
   static constexpr bool kDual = false;
+  static constexpr bool kSpeculate = false;
   static constexpr bool kOrdered = true;
   static constexpr int kFarFirst = 0;
   static constexpr bool kCull = true;
@@ -975,7 +978,7 @@ __global__ LUM_TRACE_BOUNDS void k_trace_particles(DeviceScene particle_tree, Pa
   pq.particles_scale = particle_tree.particles_scale; pq.particles_speed = particle_tree.particles_speed;
   pq.direction = v3(particle_tree.particles_direction[0], particle_tree.particles_direction[1], particle_tree.particles_direction[2]);
   pq.bluenoise = particle_tree.bluenoise_2d;
-  trace_items(particle_tree, ctrl[kCtlPaths], ctrl + kCtlParticleCursor, pq, st, rays, lds_nodes);
+  LUM_TRACE_ITEMS(particle_tree, ctrl[kCtlPaths], ctrl + kCtlParticleCursor, pq, st, rays, lds_nodes);
 }
 
 // particle_process_tasks (particle.cuh:7-108): light sample, sun, phase-function bounce whose direction doubles as the ambient sample. The
@@ -1972,7 +1975,7 @@ __global__ LUM_TRACE_BOUNDS void k_trace_rays(DeviceScene sc, uint32_t n, const 
   uint32_t rays = 0;
   RaysQuery q;
   q.origins = origins; q.dirs = dirs; q.ignore = ignore; q.out = out;
-  trace_items(sc, n, cursor, q, st, rays, lds_nodes);
+  LUM_TRACE_ITEMS(sc, n, cursor, q, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 

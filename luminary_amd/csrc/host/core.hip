@@ -223,10 +223,10 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   if (paths <= ctx->capacity && kinds <= ctx->work_shadow_kinds && (!clouds || ctx->cloud.items)) return 0;
   if (paths < ctx->capacity) paths = ctx->capacity;
   free_work(ctx);
-  // per path: 2 queues x 68 B + NEE 80 B + result 16 B + up to `kinds` visibility rays x (48 B + 16 B result) + 4 B light-query index
+  // per path: 2 queues x 68 B + NEE 84 B + result 16 B + up to `kinds` visibility rays x (48 B + 16 B result) + 4 B light-query index
   // (+ the volumes' 96 B of in-scattering records, 4 B scattering-event index and 48 B of water-surface factors of the surface vertices)
   const size_t n = paths;
-  const size_t bytes = n * (2 * 68 + 80 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 100 + 48 : 0) + (clouds ? 3 * (4 + 16 + 4) : 0)) + 56 * 256;
+  const size_t bytes = n * (2 * 68 + 84 + 16 + (size_t) kinds * 64 + 4 + (kinds > 4u ? 100 + 48 : 0) + (clouds ? 3 * (4 + 16 + 4) : 0)) + 56 * 256;
   HIP_TRY(ctx, hipMalloc(&ctx->work_block, bytes));
   char* p = (char*) ctx->work_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };  // keeps every array 256-byte aligned
@@ -242,6 +242,7 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   ctx->nee.bsdf_weight_sum = (float4*) take(n * 16);
   ctx->nee.ambient         = (uint4*) take(n * 16);
   ctx->nee.sun             = (uint4*) take(n * 16);
+  ctx->nee.amb_path        = (uint32_t*) take(n * 4);
   ctx->d_results           = (float4*) take(n * 16);
   ctx->shadow.origin_dist  = (float4*) take(kinds * n * 16);
   ctx->shadow.dir_out      = (float4*) take(kinds * n * 16);
@@ -645,6 +646,130 @@ static bool widen_to_bvh8(const std::vector<Bvh4Node>& in, const std::vector<uin
   return true;
 }
 
+// ---- 8-wide nodes with children in octant slots (Bvh8oNode, dev_scene.h) from a finished 4-wide tree ----
+// Widening as above (a node absorbs its largest inner children while at most eight result). Then, per node: the children take octant slots (greedy:
+// the (child, slot) pair with the largest projection of the child's offset from the node's centre onto the slot's diagonal first, as the reference's
+// bvh.c:1093-1145), the inner children become consecutive nodes in slot order (nodes are numbered in the order the widening queue meets them: the top
+// of the tree first), and the leaf slots' primitives become one consecutive run per node: `leaf_order` is the new order of the leaf items (triangles of
+// the bottom level / records of the top level) as indices into the old one. `is_top[i]`: node i belongs to the top level (its leaves are instance
+// records). Returns false when a node's leaves do not fit the 5-bit offsets (cannot happen with <= 4 primitives per leaf: 8 x 4 = 32).
+struct Bvh8oResult {
+  std::vector<Bvh8oNode> nodes;
+  std::vector<uint32_t> old_to_new;        // for the `keep` roots (others: 0xFFFFFFFF when absorbed)
+  std::vector<uint32_t> tri_order, top_leaf_order;
+  std::vector<uint32_t> levels;            // per keep root
+  uint32_t top_nodes = 0;
+};
+static bool build_bvh8o(const std::vector<Bvh4Node>& in, const std::vector<uint8_t>& is_top, const std::vector<uint32_t>& keep, size_t num_tris, size_t num_top_leaves, Bvh8oResult& out) {
+  const size_t n = in.size();
+  std::vector<std::vector<WideChild>> wide(n);
+  std::vector<uint8_t> survives(n, 0);
+  std::vector<uint32_t> level(n, 0), root_of(n, 0), queue;
+  out.old_to_new.assign(n, 0xFFFFFFFFu);
+  for (size_t r = 0; r < keep.size(); r++) if (keep[r] < n && !survives[keep[r]]) { survives[keep[r]] = 1; level[keep[r]] = 1; root_of[keep[r]] = (uint32_t) r; out.old_to_new[keep[r]] = (uint32_t) queue.size(); queue.push_back(keep[r]); }
+  out.levels.assign(keep.size(), 0);
+  out.tri_order.clear(); out.top_leaf_order.clear();
+  out.tri_order.reserve(num_tris); out.top_leaf_order.reserve(num_top_leaves);
+  out.nodes.clear();
+  out.top_nodes = 0;
+  for (size_t head = 0; head < queue.size(); head++) {
+    const uint32_t i = queue[head];
+    out.levels[root_of[i]] = std::max(out.levels[root_of[i]], level[i]);
+    WideChild list[8];
+    uint32_t m = node_children(in[i], list);
+    for (;;) {
+      int best = -1;
+      float best_area = -1.0f;
+      for (uint32_t k = 0; k < m; k++) {
+        const uint32_t ref = list[k].ref;
+        if (ref & kBvhLeafBit) continue;
+        uint32_t cm = 0;
+        for (int j = 0; j < 4; j++) if (in[ref].child[j] != kBvhEmpty) cm++;
+        if (cm == 0 || m - 1 + cm > 8) continue;
+        const float a = box_area(list[k]);
+        if (a > best_area) { best_area = a; best = (int) k; }
+      }
+      if (best < 0) break;
+      WideChild sub[4];
+      const uint32_t cm = node_children(in[list[best].ref], sub);
+      list[best] = sub[0];
+      for (uint32_t j = 1; j < cm; j++) list[m++] = sub[j];
+    }
+    // the node's box, slots
+    float lo[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, hi[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t k = 0; k < m; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], list[k].lo[a]); hi[a] = std::max(hi[a], list[k].hi[a]); }
+    if (m == 0) for (int a = 0; a < 3; a++) { lo[a] = 0.0f; hi[a] = 0.0f; }
+    int slot_of[8];
+    {
+      float cost[8][8];
+      for (uint32_t k = 0; k < m; k++)
+        for (int sl = 0; sl < 8; sl++) {
+          float c = 0.0f;
+          for (int a = 0; a < 3; a++) c += (((sl >> a) & 1) ? 1.0f : -1.0f) * (0.5f * (list[k].lo[a] + list[k].hi[a]) - 0.5f * (lo[a] + hi[a]));
+          cost[k][sl] = c;
+        }
+      bool used_k[8] = {false, false, false, false, false, false, false, false}, used_s[8] = {false, false, false, false, false, false, false, false};
+      for (uint32_t it = 0; it < m; it++) {
+        int bk = -1, bs = -1;
+        float best = -FLT_MAX;
+        for (uint32_t k = 0; k < m; k++) if (!used_k[k]) for (int sl = 0; sl < 8; sl++) if (!used_s[sl] && (bk < 0 || cost[k][sl] > best)) { best = cost[k][sl]; bk = (int) k; bs = sl; }
+        used_k[bk] = used_s[bs] = true;
+        slot_of[bk] = bs;
+      }
+    }
+    int child_in_slot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+    for (uint32_t k = 0; k < m; k++) child_in_slot[slot_of[k]] = (int) k;
+    Bvh8oNode o;
+    std::memset(&o, 0, sizeof(o));
+    float scale[3];
+    for (int a = 0; a < 3; a++) {
+      o.origin[a] = lo[a];
+      const float extent = hi[a] - lo[a];
+      int e = -126;
+      if (extent > 0.0f && std::isfinite(extent)) {
+        int ex;
+        std::frexp(extent / 255.0f, &ex);
+        e = std::max(-126, std::min(127, ex));
+      }
+      while (e < 127 && std::ceil((hi[a] - lo[a]) / std::ldexp(1.0f, e)) > 255.0f) e++;  // the quotient must stay below 256 after the subtraction's rounding
+      o.exp[a] = (uint8_t) (e + 127);
+      scale[a] = std::ldexp(1.0f, e);
+    }
+    uint8_t* qlo[3] = {o.lo_x, o.lo_y, o.lo_z};
+    uint8_t* qhi[3] = {o.hi_x, o.hi_y, o.hi_z};
+    const bool top = is_top[i] != 0;
+    if (top) out.top_nodes++;
+    std::vector<uint32_t>& leaf_order = top ? out.top_leaf_order : out.tri_order;
+    o.leaf_base = (uint32_t) leaf_order.size();
+    o.child_base = (uint32_t) queue.size();  // where this node's first inner child is about to be numbered
+    for (int sl = 0; sl < 8; sl++) {
+      const int k = child_in_slot[sl];
+      if (k < 0) { for (int a = 0; a < 3; a++) { qlo[a][sl] = 255; qhi[a][sl] = 0; } continue; }
+      const WideChild& c = list[k];
+      for (int a = 0; a < 3; a++) {
+        const float l = std::floor((c.lo[a] - lo[a]) / scale[a]), h = std::ceil((c.hi[a] - lo[a]) / scale[a]);
+        qlo[a][sl] = (uint8_t) std::max(0.0f, std::min(255.0f, l));
+        qhi[a][sl] = (uint8_t) std::max(0.0f, std::min(255.0f, h));
+      }
+      if (c.ref & kBvhLeafBit) {
+        const uint32_t first = c.ref & 0x0FFFFFFFu, count = ((c.ref >> 28) & 7u) + 1u;
+        const uint32_t offset = (uint32_t) leaf_order.size() - o.leaf_base;
+        if (offset > 31u || count > 4u) return false;
+        o.meta[sl] = (uint8_t) (offset | ((count - 1u) << 5));
+        for (uint32_t j = 0; j < count; j++) leaf_order.push_back(first + j);
+      }
+      else {
+        o.imask |= (uint8_t) (1u << sl);
+        survives[c.ref] = 1; level[c.ref] = level[i] + 1; root_of[c.ref] = root_of[i];
+        out.old_to_new[c.ref] = (uint32_t) queue.size();
+        queue.push_back(c.ref);
+      }
+    }
+    out.nodes.push_back(o);
+  }
+  return out.tri_order.size() == num_tris && out.top_leaf_order.size() == num_top_leaves;
+}
+
 // ---- 64-byte quantised nodes (Bvh4QNode, dev_scene.h) from a finished 4-wide tree: node for node, same indices ----
 static void quantise_bvh4(std::vector<Bvh4Node>& nodes) {
   std::vector<Bvh4QNode> out(nodes.size());
@@ -790,6 +915,29 @@ static int build_particle_tree(LumContext* ctx, const LumDeviceSceneView* v, Dev
     for (size_t i = 0; i < tlas.prims.size(); i++) { const uint32_t words[4] = {tlas.prims[i], mesh_root_index, 0u, 0u}; std::memcpy(&leaves[4 * i + 3], words, 16); }
   }
 #endif
+#if LUM_BVH8O
+  {
+    std::vector<uint8_t> is_top(nodes.size(), 0);
+    for (uint32_t i = 0; i < base; i++) is_top[i] = 1;
+    Bvh8oResult r8;
+    if (!build_bvh8o(nodes, is_top, {0u, base}, nt, tlas.prims.size(), r8)) { ctx->error = "8-wide conversion of the particle tree failed"; return 1; }
+    if (r8.levels[0] + r8.levels[1] + 8u > (uint32_t) kStackSize) { ctx->error = "particle BVH too deep for the traversal stack"; return 1; }
+    mesh_root_index = r8.old_to_new[base];
+    std::vector<BvhTri> reordered(tris.size());
+    std::memset(reordered.data(), 0, sizeof(BvhTri) * reordered.size());
+    for (size_t i = 0; i < r8.tri_order.size(); i++) reordered[i] = tris[r8.tri_order[i]];
+    tris.swap(reordered);
+    std::vector<float4> moved(leaves.size());
+    for (size_t i = 0; i < r8.top_leaf_order.size(); i++) {
+      for (int k = 0; k < 3; k++) moved[4 * i + k] = leaves[4 * (size_t) r8.top_leaf_order[i] + k];
+      const uint32_t words[4] = {tlas.prims[r8.top_leaf_order[i]], mesh_root_index, 0u, 0u};
+      std::memcpy(&moved[4 * i + 3], words, 16);
+    }
+    leaves.swap(moved);
+    nodes.resize(r8.nodes.size());
+    std::memcpy(nodes.data(), r8.nodes.data(), r8.nodes.size() * sizeof(Bvh8oNode));
+  }
+#endif
 #if LUM_BVH4Q
   quantise_bvh4(nodes);
 #endif
@@ -811,6 +959,9 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   if (v->max_ray_depth > 63) { ctx->error = "max_ray_depth exceeds 63 (6-bit field, device_structs.h:9)"; return 1; }
   const uint32_t total_tris = v->num_meshes ? v->mesh_tri_offset[v->num_meshes] : 0;
   if (dirty & LUMC_DIRTY_MESHES) dirty |= LUMC_DIRTY_INSTANCES;  // the assembled node array holds the per-mesh trees
+#if LUM_BVH8O
+  if (dirty & LUMC_DIRTY_INSTANCES) dirty |= LUMC_DIRTY_MESHES;  // (experiment) the 8-wide conversion reorders the triangles by the assembled tree: an instance edit rebuilds all of it
+#endif
   if (dirty & LUMC_DIRTY_PARTICLES) dirty |= LUMC_DIRTY_CONSTANTS;
   const bool dirty_meshes = (dirty & LUMC_DIRTY_MESHES) != 0, dirty_instances = (dirty & LUMC_DIRTY_INSTANCES) != 0, dirty_lights = (dirty & LUMC_DIRTY_LIGHTS) != 0;
   ctx->has_scene = false;  // until this update has gone through
@@ -975,6 +1126,7 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   }
   // ---- renumber: the top of the tree first, in breadth-first order across both levels (top-level leaves continue into the root of
   // their mesh), so that "node index < K" selects the K most visited nodes; the ray kernels stage those in LDS ----
+  std::vector<uint8_t> node_is_top;  // after the renumbering: the node belongs to the top level (LUM_BVH8O)
   {
     const size_t n = nodes.size();
     std::vector<uint32_t> order;
@@ -1067,6 +1219,8 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     }
     nodes.swap(renum);
     for (uint32_t m = 0; m < v->num_meshes; m++) mesh_root[m] = new_index[mesh_root[m]];
+    node_is_top.resize(n);
+    for (uint32_t i = 0; i < n; i++) node_is_top[i] = order[i] < sc.tlas_num_nodes ? 1 : 0;
   }
   if (total_tris >= (1u << 28) || nodes.size() >= (1u << 25)) { ctx->error = "scene too large for 28-bit leaf ranges / 32-bit node offsets"; return 1; }
 #if LUM_BVH8
@@ -1089,6 +1243,33 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     nodes.resize(wide.size());
     std::memcpy(nodes.data(), wide.data(), wide.size() * sizeof(Bvh8Node));
     ctx->bvh_stats[2] = new_tlas_nodes;
+  }
+#endif
+#if LUM_BVH8O
+  {
+    std::vector<uint32_t> keep;
+    keep.push_back(0u);
+    for (uint32_t m = 0; m < v->num_meshes; m++) if (v->mesh_tri_offset[m + 1] > v->mesh_tri_offset[m]) keep.push_back(mesh_root[m]);
+    Bvh8oResult r8;
+    if (!build_bvh8o(nodes, node_is_top, keep, total_tris, tlas_order.size(), r8)) { ctx->error = "8-wide conversion failed (leaf offsets / unreferenced leaves)"; return 1; }
+    uint32_t deepest_mesh = 0;
+    for (size_t r = 1; r < r8.levels.size(); r++) deepest_mesh = std::max(deepest_mesh, r8.levels[r]);
+    if (r8.levels[0] + deepest_mesh + 8u > (uint32_t) kStackSize) { ctx->error = "BVH too deep for the traversal stack (8-wide nodes)"; return 1; }  // one group entry per level + an instance's two
+    {  // the triangles and the top-level leaf records in the order the nodes refer to them
+      std::vector<BvhTri> reordered(blas_tris.size());
+      std::memset(reordered.data(), 0, sizeof(BvhTri) * reordered.size());
+      for (size_t i = 0; i < r8.tri_order.size(); i++) reordered[i] = blas_tris[r8.tri_order[i]];
+      blas_tris.swap(reordered);
+      std::vector<uint32_t> tl(tlas_order.size());
+      for (size_t i = 0; i < tl.size(); i++) tl[i] = tlas_order[r8.top_leaf_order[i]];
+      tlas_order.swap(tl);
+    }
+    for (uint32_t m = 0; m < v->num_meshes; m++) if (v->mesh_tri_offset[m + 1] > v->mesh_tri_offset[m]) mesh_root[m] = r8.old_to_new[mesh_root[m]];
+    sc.tlas_num_nodes = r8.top_nodes;
+    ctx->bvh_stats[2] = r8.top_nodes;
+    static_assert(sizeof(Bvh8oNode) == sizeof(Bvh4Node), "same 128-byte slot");
+    nodes.resize(r8.nodes.size());
+    std::memcpy(nodes.data(), r8.nodes.data(), r8.nodes.size() * sizeof(Bvh8oNode));
   }
 #endif
 #if LUM_BVH4Q

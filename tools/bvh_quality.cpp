@@ -497,6 +497,72 @@ static void walk_wide(const std::vector<Wide>& nodes, const Bvh4& bvh, const std
   if (best < INFINITY) st.hits++;
 }
 
+// Mode 2 of the 8-wide model - what a compressed wide BVH really does (Ylitie, Karras, Laine 2017; the reference's dead software path: slot assignment
+// bvh.c:1093-1145, traversal order cuda/bvh.cuh:82-106): every child sits in one of eight octant slots chosen at build time (greedy: the (child, slot) pair
+// with the largest projection of the child's offset from the node's centre onto the slot's diagonal first), a ray meets the slots in the order
+// slot ^ octant, and the stack holds GROUPS (node, slots left) without distances: a group popped later is walked even when the hit found meanwhile lies
+// in front of it (every child is still tested against the current hit distance when it is visited). Quantised boxes are not modelled.
+static void assign_slots(std::vector<Wide>& nodes) {
+  for (Wide& w : nodes) {
+    float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = 0; k < w.n; k++) for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], w.lo[k][a]); hi[a] = std::max(hi[a], w.hi[k][a]); }
+    float cost[8][8];
+    for (int k = 0; k < w.n; k++)
+      for (int sl = 0; sl < 8; sl++) {
+        float c = 0;
+        for (int a = 0; a < 3; a++) c += (((sl >> a) & 1) ? 1.0f : -1.0f) * (0.5f * (w.lo[k][a] + w.hi[k][a]) - 0.5f * (lo[a] + hi[a]));
+        cost[k][sl] = c;
+      }
+    int slot_of[8]; bool used_k[8] = {false}, used_s[8] = {false};
+    for (int it = 0; it < w.n; it++) {
+      int bk = -1, bs = -1; float best = -INFINITY;
+      for (int k = 0; k < w.n; k++) if (!used_k[k]) for (int sl = 0; sl < 8; sl++) if (!used_s[sl] && cost[k][sl] > best) { best = cost[k][sl]; bk = k; bs = sl; }
+      used_k[bk] = used_s[bs] = true; slot_of[bk] = bs;
+    }
+    Wide out = w;
+    for (int sl = 0; sl < 8; sl++) out.child[sl] = kBvhEmpty;
+    for (int k = 0; k < w.n; k++) { const int sl = slot_of[k]; out.child[sl] = w.child[k]; for (int a = 0; a < 3; a++) { out.lo[sl][a] = w.lo[k][a]; out.hi[sl][a] = w.hi[k][a]; } }
+    out.n = 8;
+    w = out;
+  }
+}
+static void walk_groups(const std::vector<Wide>& nodes, const Bvh4& bvh, const std::vector<float>& verts, V o, V d, Stats& st) {
+  const float inv[3] = {1.0f / d.x, 1.0f / d.y, 1.0f / d.z}, oo[3] = {o.x, o.y, o.z};
+  const int oct = (d.x < 0 ? 1 : 0) | (d.y < 0 ? 2 : 0) | (d.z < 0 ? 4 : 0);
+  struct G { uint32_t node; uint32_t mask; };  // mask in priority order: bit r = slot r ^ oct
+  G stack[512]; int sp = 0; float best = INFINITY;
+  st.rays++;
+  auto visit = [&](uint32_t node) -> uint32_t {
+    st.nodes++;
+    const Wide& n = nodes[node];
+    uint32_t mask = 0;
+    for (int sl = 0; sl < 8; sl++) {
+      if (n.child[sl] == kBvhEmpty) continue;
+      float tn = 0.0f, tf = best;
+      for (int a = 0; a < 3; a++) { float t0 = (n.lo[sl][a] - oo[a]) * inv[a], t1 = (n.hi[sl][a] - oo[a]) * inv[a]; if (t0 > t1) std::swap(t0, t1); tn = std::max(tn, t0); tf = std::min(tf, t1); }
+      if (tn <= tf) mask |= 1u << (sl ^ oct);
+    }
+    return mask;
+  };
+  G g{0u, visit(0u)};
+  while (true) {
+    if (g.mask == 0) { if (sp == 0) break; g = stack[--sp]; continue; }
+    const int r = __builtin_ctz(g.mask);
+    g.mask &= g.mask - 1;
+    const uint32_t child = nodes[g.node].child[r ^ oct];
+    if (child & kBvhLeafBit) {
+      const uint32_t first = child & 0x0FFFFFFFu, count = ((child >> 28) & 7u) + 1u;
+      st.leaves++;
+      for (uint32_t j = 0; j < count; j++) { st.tris++; const float t = hit_tri(&verts[(size_t) bvh.prims[first + j] * 12], o, d); if (t < best) best = t; }
+    }
+    else {
+      if (g.mask) stack[sp++] = g;
+      g = G{child, visit(child)};
+    }
+  }
+  if (best < INFINITY) st.hits++;
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) { std::fprintf(stderr, "usage: bvh_quality vertices.f32 [rays]\n"); return 1; }
   FILE* f = std::fopen(argv[1], "rb");
@@ -576,7 +642,9 @@ int main(int argc, char** argv) {
   if (std::getenv("BQ_WIDE")) {
     const std::vector<Wide> wide = widen(bvh);
     double kids8 = 0; for (const Wide& w : wide) kids8 += w.n;
-    for (int mode = 0; mode < 2; mode++) {
+    std::vector<Wide> slotted = wide;
+    assign_slots(slotted);
+    for (int mode = 0; mode < 3; mode++) {
       Stats ws;
 #pragma omp parallel
       {
@@ -596,13 +664,14 @@ int main(int argc, char** argv) {
           const float r1 = U(rng), r2 = U(rng), phi = 6.2831853f * r1, sr = std::sqrt(r2);
           const V tan = norm(std::fabs(n.x) < 0.9f ? cross(n, V{1, 0, 0}) : cross(n, V{0, 1, 0})), bit = cross(n, tan);
           const V d = norm(add(add(mul(tan, sr * std::cos(phi)), mul(bit, sr * std::sin(phi))), mul(n, std::sqrt(1 - r2))));
-          walk_wide(wide, bvh, verts, o, d, mode == 1, c);
+          if (mode == 2) walk_groups(slotted, bvh, verts, o, d, c);
+          else walk_wide(wide, bvh, verts, o, d, mode == 1, c);
         }
 #pragma omp critical
         { ws.nodes += c.nodes; ws.leaves += c.leaves; ws.tris += c.tris; ws.rays += c.rays; ws.hits += c.hits; }
       }
       std::printf("8-wide (%zu nodes, %.2f children per node), %s: nodes %.2f  leaves %.2f  triangles %.2f per closest-hit ray\n", wide.size(), kids8 / wide.size(),
-                  mode ? "children in octant-diagonal order (no distances)" : "nearest first", ws.nodes / ws.rays, ws.leaves / ws.rays, ws.tris / ws.rays);
+                  mode == 2 ? "static octant slots, group stack, no distance cull at a pop" : mode ? "children in octant-diagonal order (no distances)" : "nearest first", ws.nodes / ws.rays, ws.leaves / ws.rays, ws.tris / ws.rays);
     }
   }
   std::printf("closest: nodes %.2f  leaves %.2f  triangles %.2f per ray (hit %.2f)\n", closest.nodes / closest.rays, closest.leaves / closest.rays, closest.tris / closest.rays, closest.hits / closest.rays);

@@ -10,12 +10,20 @@
 #define REP4(x) x x x x
 #define REP16(x) REP4(REP4(x))
 
+// The clock the run reached, measured inside the kernel: the shader-clock counter (s_memtime) over the constant 100 MHz counter (s_memrealtime), both
+// read by one wave at the start and at the end of its loop. (Round 3 divided by an assumed 2.4 GHz.)
+__device__ unsigned long long g_clock_samples[4];
+__device__ __forceinline__ unsigned long long real_time() { unsigned long long t; asm volatile("s_memrealtime %0\n s_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
+
 template <int KIND>
 __global__ __launch_bounds__(256) void k_rate(float* out, int iters, float seed) {
+  const bool sampler = blockIdx.x == 0 && threadIdx.x == 0;
+  unsigned long long c0 = 0, r0 = 0;
+  if (sampler) { c0 = __builtin_readcyclecounter(); r0 = real_time(); }
   float a0 = seed, a1 = seed + 1, a2 = seed + 2, a3 = seed + 3, a4 = seed + 4, a5 = seed + 5, a6 = seed + 6, a7 = seed + 7;
   float b0 = seed * 2, b1 = seed * 3, b2 = seed * 4, b3 = seed * 5, b4 = seed * 6, b5 = seed * 7, b6 = seed * 8, b7 = seed * 9;
   const float m = 0.999f, c = 0.001f;
-  for (int i = 0; i < iters; i++) {
+  for (int i = 0; i < (KIND == 11 ? 0 : iters); i++) {
     if (KIND == 0) {  // v_fma_f32, 16 independent chains
       REP4(asm volatile("v_fma_f32 %0, %0, %16, %17\n v_fma_f32 %1, %1, %16, %17\n v_fma_f32 %2, %2, %16, %17\n v_fma_f32 %3, %3, %16, %17\n"
                         "v_fma_f32 %4, %4, %16, %17\n v_fma_f32 %5, %5, %16, %17\n v_fma_f32 %6, %6, %16, %17\n v_fma_f32 %7, %7, %16, %17\n"
@@ -86,6 +94,17 @@ __global__ __launch_bounds__(256) void k_rate(float* out, int iters, float seed)
                              : "v"(m), "v"(c));))
     }
   }
+  if (KIND == 11) {  // v_mul_lo_u32: the sampler's hash rounds (dev_sampler.h laine_karras) are made of these
+    uint32_t u0 = __float_as_uint(a0), u1 = __float_as_uint(a1), u2 = __float_as_uint(a2), u3 = __float_as_uint(a3), u4 = __float_as_uint(a4), u5 = __float_as_uint(a5), u6 = __float_as_uint(a6), u7 = __float_as_uint(a7);
+    const uint32_t k = 0x6c50b47cu;
+    for (int i = 0; i < iters; i++) {
+      REP4(REP4(asm volatile("v_mul_lo_u32 %0, %0, %8\n v_mul_lo_u32 %1, %1, %8\n v_mul_lo_u32 %2, %2, %8\n v_mul_lo_u32 %3, %3, %8\n"
+                             : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7)
+                             : "v"(k));))
+    }
+    a0 = __uint_as_float(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+  }
+  if (sampler) { g_clock_samples[0] = __builtin_readcyclecounter() - c0; g_clock_samples[1] = real_time() - r0; }
   const float s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + b0 + b1 + b2 + b3 + b4 + b5 + b6 + b7;
   if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
@@ -105,8 +124,14 @@ static void run(const char* name, int waves_per_simd, float* out, int cus) {
   (void) hipEventElapsedTime(&ms, a, b);
   const double insts = (double) grid.x * 4.0 * iters * 64.0;  // wave-instructions
   const double per_simd_per_s = insts / (cus * 4.0) / (ms * 1e-3);
-  printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"g_wave_insts_per_s\": %.1f, \"cycles_per_wave_inst_per_simd_at_2.4GHz\": %.2f}\n", name, waves_per_simd, ms, insts / (ms * 1e-3) / 1e9,
-         2.4e9 / per_simd_per_s);
+  unsigned long long samples[4] = {0, 0, 0, 0};
+  (void) hipMemcpyFromSymbol(samples, HIP_SYMBOL(g_clock_samples), sizeof(samples));
+  // s_memtime counts shader-clock cycles where the part exposes them; where it runs at the constant 100 MHz as well the ratio is 1 and says nothing
+  const double ratio = samples[1] ? (double) samples[0] / (double) samples[1] : 0.0;
+  const double clock_hz = ratio > 1.5 ? ratio * 100e6 : 0.0;
+  printf("{\"kind\": \"%s\", \"waves_per_simd\": %d, \"ms\": %.3f, \"g_wave_insts_per_s\": %.1f, \"cycles_per_wave_inst_per_simd_at_2.4GHz\": %.2f, \"measured_clock_ghz\": %.3f, "
+         "\"cycles_per_wave_inst_per_simd_at_measured_clock\": %.2f, \"memtime_ticks\": %llu, \"memrealtime_ticks\": %llu}\n", name, waves_per_simd, ms, insts / (ms * 1e-3) / 1e9,
+         2.4e9 / per_simd_per_s, clock_hz / 1e9, clock_hz > 0.0 ? clock_hz / per_simd_per_s : 0.0, samples[0], samples[1]);
   fflush(stdout);
 }
 
@@ -129,6 +154,7 @@ int main() {
     run<8>("v_fmac_f32", w, out, cus);
     run<9>("v_med3_f32 (one vector operand)", w, out, cus);
     run<10>("v_sqrt_f32", w, out, cus);
+    run<11>("v_mul_lo_u32", w, out, cus);
   }
   (void) hipDeviceSynchronize();
   return 0;
