@@ -423,6 +423,8 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
                    # `value` counts executed rays only (SURVEY 8d's rule). Ambient samples whose visibility the path's next closest-hit ray answered cost no
                    # traversal and are not in it; the reference would have traced each of them: value + these = the rate in the reference's own ray count.
                    "ambient_reuse": core.ambient_reuse, "rays_answered_without_trace": answered, "mrays_per_s_answered": (rays_total + answered) / elapsed / 1e6,
+                   "value_note": ("executed rays only; %.3g ambient visibility queries were answered by the paths' next closest-hit rays and are not in it "
+                                  "(rounds 1-3 traced them): in the reference's ray count the rate is mrays_per_s_answered" % answered) if answered > 0 else None,
                    "per_ray_rank0": {"nodes_closest": round(nodes_trace / max(cnt[CNT_TRACE], 1), 2), "tris_closest": round(tris_trace / max(cnt[CNT_TRACE], 1), 2),
                                      "nodes_shadow": round(nodes_shadow / max(cnt[CNT_SHADOW], 1), 2), "tris_shadow": round(tris_shadow / max(cnt[CNT_SHADOW], 1), 2),
                                      "lds_hit_rate_closest": round(cnt[10] / max(nodes_trace, 1), 3), "lds_hit_rate_shadow": round(cnt[11] / max(nodes_shadow, 1), 3)},
@@ -566,7 +568,7 @@ def headline(d):
     baseline, the secondaries' values. Prose, ceilings, L2 figures, per-ray counts and the secondaries' blocks live in profiles/bench_detail.json."""
     c = d["config"]
     cfg_keys = ["workload", "width", "height", "max_ray_depth", "flavour", "spp_per_step", "paths_per_gpu_per_step", "partition", "frame_reduce", "rccl_ranks",
-                "samples_per_s", "seconds_to_1024spp", "rays", "rays_answered_without_trace", "mrays_per_s_answered", "ambient_reuse", "bvh", "source_hash",
+                "samples_per_s", "seconds_to_1024spp", "rays", "rays_answered_without_trace", "mrays_per_s_answered", "ambient_reuse", "value_note", "bvh", "source_hash",
                 "fast_vs_exact_rel_l2_1024spp", "kernel_share_rank0"]
     cfg = {k: c[k] for k in cfg_keys if c.get(k) is not None}
 
