@@ -445,7 +445,7 @@ def main():
     ap.add_argument("--workload", default="hall", choices=sorted(WORKLOADS))
     ap.add_argument("--secondary", default="example,scan", help="workloads timed after the headline at N = 1 and reported under 'secondary' ('none' skips them)")
     ap.add_argument("--secondary-steps", type=int, default=4)
-    ap.add_argument("--exact-steps", type=int, default=4, help="N = 1: steps of the headline workload timed once more in the bit-exact flavour (value_exact; 0 skips)")
+    ap.add_argument("--exact-steps", type=int, default=4, help="N = 1: steps of the headline workload timed once more in the bit-exact flavour (value_exact; 0 or --secondary none skip it)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
@@ -510,7 +510,8 @@ def main():
         if core.comm_count() != world:
             dist.destroy_process_group()
             raise SystemExit("bench.py: the library's communicator reports %d ranks, the job has %d" % (core.comm_count(), world))
-    head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True, exact_steps=args.exact_steps)
+    # value_exact belongs to the full report, like the secondaries: `--secondary none` (profiling passes, A/B tools) times the headline flavour alone
+    head, view = run_workload(core, args.workload, args, rank, world, dist, args.steps, args.warmup, True, exact_steps=args.exact_steps if args.secondary != "none" else 0)
     exact = head.pop("value_exact", None)
     # reported at N=1 only; the oracle needs the sky tables for the procedural sky, which the bench does not generate on the CPU
     cpu = cpu_baseline(view, args.cpu_budget) if (args.cpu_budget > 0 and dist is None and args.sky == "constant" and rank == 0) else None
