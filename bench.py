@@ -568,7 +568,7 @@ def headline(d):
     """The one JSON line the driver parses: the contract's fields, the dominant kernel's roofline in full, the three big kernels in brief, the CPU
     baseline, the secondaries' values. Prose, ceilings, L2 figures, per-ray counts and the secondaries' blocks live in profiles/bench_detail.json."""
     c = d["config"]
-    cfg_keys = ["workload", "width", "height", "max_ray_depth", "flavour", "spp_per_step", "paths_per_gpu_per_step", "partition", "frame_reduce", "rccl_ranks",
+    cfg_keys = ["workload", "width", "height", "max_ray_depth", "flavour", "lds_stack_bytes", "spp_per_step", "paths_per_gpu_per_step", "partition", "frame_reduce", "rccl_ranks",
                 "samples_per_s", "seconds_to_1024spp", "rays", "rays_answered_without_trace", "mrays_per_s_answered", "ambient_reuse", "value_note", "bvh", "source_hash",
                 "fast_vs_exact_rel_l2_1024spp", "kernel_share_rank0"]
     cfg = {k: c[k] for k in cfg_keys if c.get(k) is not None}

@@ -352,8 +352,8 @@ class Core:
         self._call("lumc_adaptive_note_first_sample", C.c_void_p(0))
 
     def set_bvh_builder(self, name):
-        """'sah' (host, default) or 'lbvh' (GPU) for the next upload."""
-        self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1, "ploc": 2}[name]))
+        """'sah' (host, default), 'lbvh', 'ploc' or 'sah_gpu' (the GPU builders) for the next upload."""
+        self._call("lumc_set_bvh_builder", C.c_int({"sah": 0, "lbvh": 1, "ploc": 2, "sah_gpu": 3}[name]))
 
     def comm_count(self):
         """Ranks of the RCCL communicator this context belongs to (ncclCommCount; 1 without one)."""

@@ -40,4 +40,8 @@ Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvh
 // tree: two to three times the LBVH's build time, trees between its quality and the SAH builder's.
 Bvh4 build_bvh4_ploc(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri, uint32_t max_depth = 20);
 
+// The host builder's binned SAH, level by level on the device (lbvh.hip): for meshes without degenerate sets the same binary tree and leaf order as
+// build_bvh4, in tens of milliseconds. Empty result when the tree is deeper than `max_depth` 4-wide levels or a HIP call fails (the caller falls back).
+Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf = kBvhLeafMaxTri, uint32_t max_depth = 20);
+
 }  // namespace lum

@@ -47,7 +47,7 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
-  int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU, 2 PLOC on the GPU (lumc_set_bvh_builder)
+  int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU, 2 PLOC on the GPU, 3 binned SAH on the GPU (lumc_set_bvh_builder)
   bool top_order_by_area = false; // which nodes count as the top of the tree (staged in LDS): breadth first, or best first by box area (LUM_TOP_ORDER=area; measured: mixed)
   double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
   uint32_t bvh_meshes_by_builder[2] = {0, 0};  // meshes of the last upload built by SAH / by LBVH
@@ -484,7 +484,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   *out = nullptr;
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
-  if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : (std::strcmp(b, "ploc") == 0) ? 2 : 0;
+  if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : (std::strcmp(b, "ploc") == 0) ? 2 : (std::strcmp(b, "sah_gpu") == 0) ? 3 : 0;
   if (const char* o = getenv("LUM_TOP_ORDER")) ctx->top_order_by_area = std::strcmp(o, "area") == 0;
   if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
   if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;
@@ -1095,6 +1095,7 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
       Bvh4 built;
       if (ctx->bvh_builder == 1) built = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
       else if (ctx->bvh_builder == 2) built = build_bvh4_ploc(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+      else if (ctx->bvh_builder == 3) built = build_bvh4_sah_gpu(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
       if (!built.nodes.empty()) ctx->bvh_meshes_by_builder[1]++;
       else { built = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26); ctx->bvh_meshes_by_builder[0]++; }  // default, and fallback for too deep LBVH trees
       ctx->bvh_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
@@ -2936,7 +2937,7 @@ int lumc_get_flavour(const LumContext* ctx) { return (ctx && ctx->wf == wavefron
 unsigned int lumc_lds_stack_bytes(void) { return LUM_LDS_STACK_BYTES; }
 
 int lumc_set_bvh_builder(LumContext* ctx, int builder) {
-  if (!ctx || builder < 0 || builder > 2) { if (ctx) ctx->error = "lumc_set_bvh_builder: 0 (SAH, host), 1 (LBVH, GPU) or 2 (PLOC, GPU)"; return 1; }
+  if (!ctx || builder < 0 || builder > 3) { if (ctx) ctx->error = "lumc_set_bvh_builder: 0 (SAH, host), 1 (LBVH, GPU), 2 (PLOC, GPU) or 3 (SAH, GPU)"; return 1; }
   ctx->bvh_builder = builder;
   return 0;
 }

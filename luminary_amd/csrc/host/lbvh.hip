@@ -17,6 +17,8 @@
 
 #include <cfloat>
 #include <cstring>
+#include <vector>
+#include <algorithm>
 
 #include "bvh_build.h"
 
@@ -394,6 +396,341 @@ done:
   return result;
 }
 }  // namespace
+
+// ---- binned SAH on the device: the host builder's trees (bvh_build.cpp Builder), built breadth first ----
+// The host builder decides every split from 16 bins per axis over the centroid bounds of the node's primitives; nothing in that needs a serial order.
+// Here every level of the binary tree is one round of four kernels over ALL primitives: (1) bin - every primitive of a node that is still to be split
+// grows the boxes and counts of its three bins (atomics on order-preserving integer images of the floats: min / max are exact, so the bins hold the
+// bits the host's loop produces; a block whose primitives all belong to one node - the top levels - gathers in LDS first and flushes 336 words); (2)
+// split - one thread per node sweeps the bins with the host's own expressions (same operand order, no contraction: this file is compiled with the exact
+// flavour's flags) and allocates the two children; (3) a prefix sum of "goes left" over the whole array and a scatter make every node's partition
+// stable, as the host's; (4) bounds - the children's boxes and centroid bounds, again by atomics. One small download per level (how many nodes are
+// left to split). The binary tree then goes through the LBVH's collapse kernel. For meshes without degenerate sets (all centroids of a set equal: the
+// host falls back to a median split by nth_element, this builder halves the set by position) the tree, and the leaf order, are the host builder's.
+namespace {
+
+constexpr int kSahBins = 16, kSahBinWords = 7;          // per bin: box (6 ordered words) | count
+constexpr int kSahNodeBinWords = 3 * kSahBins * kSahBinWords;
+
+__host__ __device__ __forceinline__ uint32_t ord_enc(float f) { uint32_t b; std::memcpy(&b, &f, 4); return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u); }
+__host__ __device__ __forceinline__ float ord_dec(uint32_t k) { const uint32_t b = k ^ ((k >> 31) ? 0x80000000u : 0xFFFFFFFFu); float f; std::memcpy(&f, &b, 4); return f; }
+
+struct SahNode {
+  uint32_t first, count;
+  uint32_t box[6];    // lo xyz, hi xyz as ordered words (atomics)
+  uint32_t cbox[6];   // centroid bounds
+  int active_rank;    // index into this level's bins, or -1
+  int split_axis, split_bin;  // chosen this level (split_axis -1: halve by position)
+  uint32_t left_count;
+  int left, right;
+};
+
+__device__ __forceinline__ float sah_centre(const BinBox& b, int a) { return 0.5f * (b.lo[a] + b.hi[a]); }
+__device__ __forceinline__ int sah_bin_of(const BinBox& b, int a, float clo, float chi) {
+  const float ext = chi - clo;
+  const float scale = ext > 0.0f ? (float) kSahBins / ext : 0.0f;
+  int bin = (int) ((sah_centre(b, a) - clo) * scale);
+  return min(max(bin, 0), kSahBins - 1);
+}
+
+// box and centroid bounds of the nodes created this level (`fresh` marks them), from the primitives in their new order
+__global__ __launch_bounds__(256) void k_sah_bounds(const BinBox* __restrict__ boxes, const int* __restrict__ owner, uint32_t n, SahNode* __restrict__ nodes, const uint8_t* __restrict__ fresh) {
+  __shared__ uint32_t acc[12];
+  __shared__ int uniform_node;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lo_i = blockIdx.x * 256u, hi_i = min(lo_i + 255u, n - 1u);
+  if (threadIdx.x == 0) uniform_node = (owner[lo_i] == owner[hi_i]) ? owner[lo_i] : -1;  // positions of a node are contiguous: equal ends = one node
+  if (threadIdx.x < 12) acc[threadIdx.x] = threadIdx.x % 6 < 3 ? ord_enc(FLT_MAX) : ord_enc(-FLT_MAX);
+  __syncthreads();
+  const int un = uniform_node;
+  if (i < n) {
+    const int node = owner[i];
+    if (fresh[node]) {
+      const BinBox b = boxes[i];
+      uint32_t* box = un >= 0 ? acc : nodes[node].box;
+      uint32_t* cbox = un >= 0 ? acc + 6 : nodes[node].cbox;
+      for (int a = 0; a < 3; a++) {
+        const uint32_t c = ord_enc(sah_centre(b, a));
+        atomicMin(&box[a], ord_enc(b.lo[a])); atomicMax(&box[3 + a], ord_enc(b.hi[a]));
+        atomicMin(&cbox[a], c); atomicMax(&cbox[3 + a], c);
+      }
+    }
+  }
+  __syncthreads();
+  if (un >= 0 && fresh[un] && threadIdx.x < 12) {
+    uint32_t* dst = threadIdx.x < 6 ? &nodes[un].box[threadIdx.x] : &nodes[un].cbox[threadIdx.x - 6];
+    if (threadIdx.x % 6 < 3) atomicMin(dst, acc[threadIdx.x]); else atomicMax(dst, acc[threadIdx.x]);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_sah_bin(const BinBox* __restrict__ boxes, const int* __restrict__ owner, uint32_t n, const SahNode* __restrict__ nodes, uint32_t* __restrict__ bins) {
+  __shared__ uint32_t acc[kSahNodeBinWords];
+  __shared__ int uniform_node;
+  const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t lo_i = blockIdx.x * 256u, hi_i = min(lo_i + 255u, n - 1u);
+  if (threadIdx.x == 0) uniform_node = (owner[lo_i] == owner[hi_i]) ? owner[lo_i] : -1;
+  __syncthreads();
+  const int un = uniform_node;
+  const bool local = un >= 0 && nodes[un].active_rank >= 0;
+  if (local) for (int w = threadIdx.x; w < kSahNodeBinWords; w += 256) { const int f = w % kSahBinWords; acc[w] = f < 3 ? ord_enc(FLT_MAX) : f < 6 ? ord_enc(-FLT_MAX) : 0u; }
+  __syncthreads();
+  if (i < n) {
+    const int node = owner[i];
+    const int rank = nodes[node].active_rank;
+    if (rank >= 0) {
+      const BinBox b = boxes[i];
+      uint32_t* base = local ? acc : bins + (size_t) rank * kSahNodeBinWords;
+      for (int a = 0; a < 3; a++) {
+        const float clo = ord_dec(nodes[node].cbox[a]), chi = ord_dec(nodes[node].cbox[3 + a]);
+        if (!(chi - clo > 0.0f)) continue;  // the host skips an axis without extent (scale 0)
+        uint32_t* w = base + (a * kSahBins + sah_bin_of(b, a, clo, chi)) * kSahBinWords;
+        for (int k = 0; k < 3; k++) { atomicMin(&w[k], ord_enc(b.lo[k])); atomicMax(&w[3 + k], ord_enc(b.hi[k])); }
+        atomicAdd(&w[6], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (local) {
+    uint32_t* dst = bins + (size_t) nodes[un].active_rank * kSahNodeBinWords;
+    for (int w = threadIdx.x; w < kSahNodeBinWords; w += 256) {
+      const int f = w % kSahBinWords;
+      if (f < 3) atomicMin(&dst[w], acc[w]); else if (f < 6) atomicMax(&dst[w], acc[w]); else if (acc[w]) atomicAdd(&dst[w], acc[w]);
+    }
+  }
+}
+
+__device__ __forceinline__ void bin_grow(BinBox& a, const uint32_t* w) {
+  for (int k = 0; k < 3; k++) { a.lo[k] = fminf(a.lo[k], ord_dec(w[k])); a.hi[k] = fmaxf(a.hi[k], ord_dec(w[3 + k])); }
+}
+__device__ __forceinline__ float sah_half_area(const BinBox& b) {
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  if (dx < 0.0f) return 0.0f;
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// One thread per node to be split: the host's sweep over its bins (bvh_build.cpp Builder::split), the children, who of them is split next level.
+__global__ void k_sah_split(const int* __restrict__ active, uint32_t num_active, const uint32_t* __restrict__ bins, SahNode* __restrict__ nodes, uint32_t max_leaf,
+                            uint32_t* __restrict__ counters /* [0] nodes allocated, [1] next level's active count */, int* __restrict__ next_active, uint8_t* __restrict__ fresh,
+                            int2* __restrict__ children, int2* __restrict__ ranges) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= num_active) return;
+  const int id = active[q];
+  SahNode nd = nodes[id];
+  const uint32_t* my = bins + (size_t) q * kSahNodeBinWords;
+  float best_cost = FLT_MAX;
+  int best_axis = -1, best_bin = -1;
+  uint32_t best_left = 0;
+  for (int a = 0; a < 3; a++) {
+    const float clo = ord_dec(nd.cbox[a]), chi = ord_dec(nd.cbox[3 + a]);
+    if (!(chi - clo > 0.0f)) continue;
+    float right_area[kSahBins];
+    uint32_t right_cnt[kSahBins];
+    BinBox acc{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}};
+    uint32_t c = 0;
+    for (int b = kSahBins - 1; b > 0; b--) { const uint32_t* w = my + (a * kSahBins + b) * kSahBinWords; bin_grow(acc, w); c += w[6]; right_area[b] = sah_half_area(acc); right_cnt[b] = c; }
+    acc = BinBox{{FLT_MAX, FLT_MAX, FLT_MAX}, {-FLT_MAX, -FLT_MAX, -FLT_MAX}}; c = 0;
+    for (int b = 0; b < kSahBins - 1; b++) {
+      const uint32_t* w = my + (a * kSahBins + b) * kSahBinWords;
+      bin_grow(acc, w); c += w[6];
+      if (c == 0 || right_cnt[b + 1] == 0) continue;
+      const float cost = sah_half_area(acc) * c + right_area[b + 1] * right_cnt[b + 1];
+      if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; best_left = c; }
+    }
+  }
+  if (best_axis < 0) { best_bin = -1; best_left = nd.count / 2; }  // no axis separates the centroids: halve the set where it stands
+  const int l = (int) atomicAdd(&counters[0], 2u), r = l + 1;
+  nd.split_axis = best_axis; nd.split_bin = best_bin; nd.left_count = best_left; nd.left = l; nd.right = r;
+  nodes[id] = nd;
+  children[id] = make_int2(l, r);
+  for (int side = 0; side < 2; side++) {
+    SahNode ch;
+    ch.first = side == 0 ? nd.first : nd.first + best_left;
+    ch.count = side == 0 ? best_left : nd.count - best_left;
+    for (int k = 0; k < 3; k++) { ch.box[k] = ch.cbox[k] = ord_enc(FLT_MAX); ch.box[3 + k] = ch.cbox[3 + k] = ord_enc(-FLT_MAX); }
+    ch.split_axis = -1; ch.split_bin = -1; ch.left_count = 0; ch.left = ch.right = -1;
+    ch.active_rank = -1;
+    const int cid = side == 0 ? l : r;
+    if (ch.count > max_leaf) { ch.active_rank = (int) atomicAdd(&counters[1], 1u); next_active[ch.active_rank] = cid; }
+    nodes[cid] = ch;
+    fresh[cid] = 1;
+    ranges[cid] = make_int2((int) ch.first, (int) (ch.first + ch.count - 1u));
+  }
+}
+
+__global__ void k_sah_flags(const BinBox* __restrict__ boxes, const int* __restrict__ owner, uint32_t n, const SahNode* __restrict__ nodes, uint32_t* __restrict__ flags) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const SahNode& nd = nodes[owner[i]];
+  uint32_t f = 0;
+  if (nd.left >= 0) {  // split this level
+    if (nd.split_axis < 0) f = (i - nd.first) < nd.left_count ? 1u : 0u;
+    else f = sah_bin_of(boxes[i], nd.split_axis, ord_dec(nd.cbox[nd.split_axis]), ord_dec(nd.cbox[3 + nd.split_axis])) <= nd.split_bin ? 1u : 0u;
+  }
+  flags[i] = f;
+}
+__global__ void k_sah_scatter(const BinBox* __restrict__ boxes, const uint32_t* __restrict__ ids, const int* __restrict__ owner, uint32_t n, const SahNode* __restrict__ nodes,
+                              const uint32_t* __restrict__ flags, const uint32_t* __restrict__ offsets, BinBox* __restrict__ boxes_out, uint32_t* __restrict__ ids_out,
+                              int* __restrict__ owner_out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int node = owner[i];
+  const SahNode& nd = nodes[node];
+  uint32_t pos = i;
+  int own = node;
+  if (nd.left >= 0) {
+    const uint32_t lefts_before = offsets[i] - offsets[nd.first];  // exclusive prefix of "goes left" inside the node
+    if (flags[i]) { pos = nd.first + lefts_before; own = nd.left; }
+    else { pos = nd.first + nd.left_count + ((i - nd.first) - lefts_before); own = nd.right; }
+  }
+  boxes_out[pos] = boxes[i]; ids_out[pos] = ids[i]; owner_out[pos] = own;
+}
+// what was split this level is done with; the collapse kernel wants the boxes as floats
+__global__ void k_sah_finish_level(const int* __restrict__ active, uint32_t num_active, SahNode* __restrict__ nodes) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < num_active) { SahNode& nd = nodes[active[q]]; nd.active_rank = -1; nd.left = -1; }
+}
+__global__ void k_sah_export(const SahNode* __restrict__ nodes, uint32_t count, BinBox* __restrict__ node_box) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= count) return;
+  BinBox b;
+  for (int k = 0; k < 3; k++) { b.lo[k] = ord_dec(nodes[i].box[k]); b.hi[k] = ord_dec(nodes[i].box[3 + k]); }
+  node_box[i] = b;
+}
+
+}  // namespace
+
+Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) {
+  Bvh4 result;
+  if (count < 2) return build_bvh4(boxes, count, max_leaf, max_depth);
+  max_leaf = max_leaf < 1 ? 1 : (max_leaf > kBvhLeafMaxTri ? kBvhLeafMaxTri : max_leaf);
+  const uint32_t n = count;
+  const size_t max_nodes2 = 2 * (size_t) count + 2;  // binary nodes
+  const size_t max_active = (size_t) count / (max_leaf + 1u) + 2;
+  BinBox* d_boxes[2] = {nullptr, nullptr}; uint32_t* d_ids[2] = {nullptr, nullptr}; int* d_owner[2] = {nullptr, nullptr};
+  SahNode* d_nodes2 = nullptr; uint32_t* d_bins = nullptr; int* d_active[2] = {nullptr, nullptr}; uint8_t* d_fresh = nullptr;
+  uint32_t* d_flags = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_counters = nullptr; void* d_scan_temp = nullptr;
+  int2* d_children = nullptr; int2* d_ranges = nullptr; BinBox* d_node_box = nullptr;
+  CollapseItem* d_queue[2] = {nullptr, nullptr}; Bvh4Node* d_nodes = nullptr;
+  size_t scan_bytes = 0;
+  bool ok = true;
+  const int threads = 256;
+  const uint32_t blocks_n = (n + threads - 1) / threads;
+  uint32_t num_active = 1, nodes_allocated = 1, levels = 0;
+  int cur = 0, acur = 0;
+  uint32_t node_count = 1, level_count = 1, depth = 0;
+  const uint32_t max_nodes4 = count;
+  for (int k = 0; k < 2; k++) {
+    LBVH_TRY(hipMalloc((void**) &d_boxes[k], sizeof(BinBox) * n));
+    LBVH_TRY(hipMalloc((void**) &d_ids[k], sizeof(uint32_t) * n));
+    LBVH_TRY(hipMalloc((void**) &d_owner[k], sizeof(int) * n));
+    LBVH_TRY(hipMalloc((void**) &d_active[k], sizeof(int) * max_active));
+    LBVH_TRY(hipMalloc((void**) &d_queue[k], sizeof(CollapseItem) * count));
+  }
+  LBVH_TRY(hipMalloc((void**) &d_nodes2, sizeof(SahNode) * max_nodes2));
+  LBVH_TRY(hipMalloc((void**) &d_bins, sizeof(uint32_t) * kSahNodeBinWords * max_active));
+  LBVH_TRY(hipMalloc((void**) &d_fresh, max_nodes2));
+  LBVH_TRY(hipMalloc((void**) &d_flags, sizeof(uint32_t) * n));
+  LBVH_TRY(hipMalloc((void**) &d_offsets, sizeof(uint32_t) * n));
+  LBVH_TRY(hipMalloc((void**) &d_counters, sizeof(uint32_t) * 4));
+  LBVH_TRY(hipMalloc((void**) &d_children, sizeof(int2) * max_nodes2));
+  LBVH_TRY(hipMalloc((void**) &d_ranges, sizeof(int2) * max_nodes2));
+  LBVH_TRY(hipMalloc((void**) &d_node_box, sizeof(BinBox) * max_nodes2));
+  LBVH_TRY(hipMalloc((void**) &d_nodes, sizeof(Bvh4Node) * max_nodes4));
+  LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_offsets, (int) n));
+  LBVH_TRY(hipMalloc(&d_scan_temp, scan_bytes ? scan_bytes : 16));
+  LBVH_TRY(hipMemcpy(d_boxes[0], boxes, sizeof(BinBox) * n, hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> ids(n);
+    for (uint32_t i = 0; i < n; i++) ids[i] = i;
+    LBVH_TRY(hipMemcpy(d_ids[0], ids.data(), sizeof(uint32_t) * n, hipMemcpyHostToDevice));
+    LBVH_TRY(hipMemset(d_owner[0], 0, sizeof(int) * n));
+    SahNode root;
+    root.first = 0; root.count = n;
+    for (int k = 0; k < 3; k++) { root.box[k] = root.cbox[k] = ord_enc(FLT_MAX); root.box[3 + k] = root.cbox[3 + k] = ord_enc(-FLT_MAX); }
+    root.active_rank = n > max_leaf ? 0 : -1; root.split_axis = -1; root.split_bin = -1; root.left_count = 0; root.left = root.right = -1;
+    LBVH_TRY(hipMemcpy(d_nodes2, &root, sizeof(root), hipMemcpyHostToDevice));
+    const int2 r0 = make_int2(0, (int) n - 1);
+    LBVH_TRY(hipMemcpy(d_ranges, &r0, sizeof(r0), hipMemcpyHostToDevice));
+    const int zero = 0;
+    LBVH_TRY(hipMemcpy(d_active[0], &zero, sizeof(int), hipMemcpyHostToDevice));
+    LBVH_TRY(hipMemset(d_fresh, 0, max_nodes2));
+    const uint8_t one = 1;
+    LBVH_TRY(hipMemcpy(d_fresh, &one, 1, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_sah_bounds, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[0], (const int*) d_owner[0], n, d_nodes2, (const uint8_t*) d_fresh);
+    LBVH_TRY(hipMemset(d_fresh, 0, 1));
+    num_active = n > max_leaf ? 1u : 0u;
+  }
+  while (num_active > 0) {
+    if (++levels > 96u) { ok = false; goto done; }
+    {  // empty bins for this level's nodes: lo = +max, hi = -max, count 0
+      std::vector<uint32_t> one(kSahNodeBinWords);
+      for (int w = 0; w < kSahNodeBinWords; w++) { const int f = w % kSahBinWords; one[w] = f < 3 ? ord_enc(FLT_MAX) : f < 6 ? ord_enc(-FLT_MAX) : 0u; }
+      // (a fill kernel would do; the pattern is 7 words long, so: upload once, replicate by doubling copies)
+      LBVH_TRY(hipMemcpy(d_bins, one.data(), sizeof(uint32_t) * kSahNodeBinWords, hipMemcpyHostToDevice));
+      for (size_t have = 1; have < num_active; have *= 2) {
+        const size_t add = std::min(have, (size_t) num_active - have);
+        LBVH_TRY(hipMemcpy(d_bins + have * kSahNodeBinWords, d_bins, sizeof(uint32_t) * kSahNodeBinWords * add, hipMemcpyDeviceToDevice));
+      }
+    }
+    hipLaunchKernelGGL(k_sah_bin, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, (const SahNode*) d_nodes2, d_bins);
+    {
+      const uint32_t init[2] = {nodes_allocated, 0u};
+      LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
+    }
+    hipLaunchKernelGGL(k_sah_split, dim3((num_active + threads - 1) / threads), dim3(threads), 0, 0, (const int*) d_active[acur], num_active, (const uint32_t*) d_bins, d_nodes2, max_leaf,
+                       d_counters, d_active[acur ^ 1], d_fresh, d_children, d_ranges);
+    hipLaunchKernelGGL(k_sah_flags, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, (const SahNode*) d_nodes2, d_flags);
+    {
+      size_t bytes = scan_bytes;
+      LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, bytes, d_flags, d_offsets, (int) n));
+    }
+    hipLaunchKernelGGL(k_sah_scatter, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const uint32_t*) d_ids[cur], (const int*) d_owner[cur], n,
+                       (const SahNode*) d_nodes2, (const uint32_t*) d_flags, (const uint32_t*) d_offsets, d_boxes[cur ^ 1], d_ids[cur ^ 1], d_owner[cur ^ 1]);
+    hipLaunchKernelGGL(k_sah_finish_level, dim3((num_active + threads - 1) / threads), dim3(threads), 0, 0, (const int*) d_active[acur], num_active, d_nodes2);
+    cur ^= 1;
+    hipLaunchKernelGGL(k_sah_bounds, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, d_nodes2, (const uint8_t*) d_fresh);
+    uint32_t host_counters[2];
+    LBVH_TRY(hipMemcpy(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost));
+    LBVH_TRY(hipMemset(d_fresh + nodes_allocated, 0, host_counters[0] - nodes_allocated));
+    nodes_allocated = host_counters[0];
+    num_active = host_counters[1];
+    acur ^= 1;
+    if (nodes_allocated + 2u > max_nodes2 || num_active > max_active) { ok = false; goto done; }
+  }
+  LBVH_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_sah_export, dim3((nodes_allocated + threads - 1) / threads), dim3(threads), 0, 0, (const SahNode*) d_nodes2, nodes_allocated, d_node_box);
+  {
+    const CollapseItem root{0, 0u};
+    LBVH_TRY(hipMemcpy(d_queue[0], &root, sizeof(root), hipMemcpyHostToDevice));
+    const uint32_t init[4] = {0u, 1u, 0u, 0u};
+    LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
+  }
+  for (int q = 0; level_count > 0; q ^= 1) {
+    depth++;
+    if (depth > max_depth) { ok = false; goto done; }
+    hipLaunchKernelGGL(k_lbvh_collapse, dim3((level_count + threads - 1) / threads), dim3(threads), 0, 0, (int) n, (const int2*) d_children, (const int2*) d_ranges,
+                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[q], level_count, d_queue[q ^ 1], d_counters, d_counters + 1, d_nodes);
+    uint32_t host_counters[2];
+    LBVH_TRY(hipMemcpy(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost));
+    level_count = host_counters[0];
+    node_count = host_counters[1];
+    if (node_count > max_nodes4) { ok = false; goto done; }
+    LBVH_TRY(hipMemset(d_counters, 0, sizeof(uint32_t)));
+  }
+  result.nodes.resize(node_count);
+  result.prims.resize(count);
+  LBVH_TRY(hipMemcpy(result.nodes.data(), d_nodes, sizeof(Bvh4Node) * node_count, hipMemcpyDeviceToHost));
+  LBVH_TRY(hipMemcpy(result.prims.data(), d_ids[cur], sizeof(uint32_t) * count, hipMemcpyDeviceToHost));
+  result.max_depth = depth;
+done:
+  {
+    void* bufs[] = {d_boxes[0], d_boxes[1], d_ids[0], d_ids[1], d_owner[0], d_owner[1], d_active[0], d_active[1], d_queue[0], d_queue[1], d_nodes2, d_bins, d_fresh, d_flags,
+                    d_offsets, d_counters, d_children, d_ranges, d_node_box, d_nodes, d_scan_temp};
+    for (void* b : bufs) if (b) (void) hipFree(b);
+  }
+  if (!ok) return Bvh4();
+  return result;
+}
 
 Bvh4 build_bvh4_lbvh(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) { return build_on_device(boxes, count, max_leaf, max_depth, false); }
 Bvh4 build_bvh4_ploc(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint32_t max_depth) { return build_on_device(boxes, count, max_leaf, max_depth, true); }

@@ -12,7 +12,7 @@ name = sys.argv[1] if len(sys.argv) > 1 else "hall"
 host, label = bench.build_workload(name, 1920, 1080, 8), bench.WORKLOADS[name]
 view = host.device_scene()
 print(label)
-for builder in ("sah", "lbvh", "ploc", "ploc"):
+for builder in ("sah", "lbvh", "ploc", "sah_gpu", "sah_gpu"):
     core = Core(0)
     core.set_bvh_builder(builder)
     t = time.time()
