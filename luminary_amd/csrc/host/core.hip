@@ -47,7 +47,7 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
-  int bvh_builder = 0;            // 0 binned SAH on the host (default), 1 LBVH on the GPU, 2 PLOC on the GPU, 3 binned SAH on the GPU (lumc_set_bvh_builder)
+  int bvh_builder = 3;            // 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU, 3 binned SAH on the GPU (default since round 4: the host builder's trees in a fifth of its time; a mesh it cannot take falls back to 0) (lumc_set_bvh_builder)
   bool top_order_by_area = false; // which nodes count as the top of the tree (staged in LDS): breadth first, or best first by box area (LUM_TOP_ORDER=area; measured: mixed)
   double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
   uint32_t bvh_meshes_by_builder[2] = {0, 0};  // meshes of the last upload built by SAH / by LBVH
@@ -484,7 +484,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   *out = nullptr;
   LumContext* ctx = new LumContext();
   ctx->device = device_ordinal;
-  if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : (std::strcmp(b, "ploc") == 0) ? 2 : (std::strcmp(b, "sah_gpu") == 0) ? 3 : 0;
+  if (const char* b = getenv("LUM_BVH_BUILDER")) ctx->bvh_builder = (std::strcmp(b, "lbvh") == 0) ? 1 : (std::strcmp(b, "ploc") == 0) ? 2 : (std::strcmp(b, "sah") == 0 || std::strcmp(b, "host") == 0) ? 0 : 3;
   if (const char* o = getenv("LUM_TOP_ORDER")) ctx->top_order_by_area = std::strcmp(o, "area") == 0;
   if (const char* e = getenv("LUM_SORT")) ctx->sort_mode = atoi(e);
   if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;

@@ -463,6 +463,13 @@ __global__ __launch_bounds__(256) void k_sah_bounds(const BinBox* __restrict__ b
   }
 }
 
+__global__ void k_sah_clear_bins(uint32_t* __restrict__ bins, size_t words) {
+  for (size_t w = blockIdx.x * (size_t) blockDim.x + threadIdx.x; w < words; w += (size_t) gridDim.x * blockDim.x) {
+    const int f = (int) (w % kSahBinWords);
+    bins[w] = f < 3 ? ord_enc(FLT_MAX) : f < 6 ? ord_enc(-FLT_MAX) : 0u;
+  }
+}
+
 __global__ __launch_bounds__(256) void k_sah_bin(const BinBox* __restrict__ boxes, const int* __restrict__ owner, uint32_t n, const SahNode* __restrict__ nodes, uint32_t* __restrict__ bins) {
   __shared__ uint32_t acc[kSahNodeBinWords];
   __shared__ int uniform_node;
@@ -663,14 +670,8 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
   while (num_active > 0) {
     if (++levels > 96u) { ok = false; goto done; }
     {  // empty bins for this level's nodes: lo = +max, hi = -max, count 0
-      std::vector<uint32_t> one(kSahNodeBinWords);
-      for (int w = 0; w < kSahNodeBinWords; w++) { const int f = w % kSahBinWords; one[w] = f < 3 ? ord_enc(FLT_MAX) : f < 6 ? ord_enc(-FLT_MAX) : 0u; }
-      // (a fill kernel would do; the pattern is 7 words long, so: upload once, replicate by doubling copies)
-      LBVH_TRY(hipMemcpy(d_bins, one.data(), sizeof(uint32_t) * kSahNodeBinWords, hipMemcpyHostToDevice));
-      for (size_t have = 1; have < num_active; have *= 2) {
-        const size_t add = std::min(have, (size_t) num_active - have);
-        LBVH_TRY(hipMemcpy(d_bins + have * kSahNodeBinWords, d_bins, sizeof(uint32_t) * kSahNodeBinWords * add, hipMemcpyDeviceToDevice));
-      }
+      const size_t words = (size_t) num_active * kSahNodeBinWords;
+      hipLaunchKernelGGL(k_sah_clear_bins, dim3((uint32_t) std::min<size_t>((words + 255) / 256, 65535)), dim3(256), 0, 0, d_bins, words);
     }
     hipLaunchKernelGGL(k_sah_bin, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, (const SahNode*) d_nodes2, d_bins);
     {
