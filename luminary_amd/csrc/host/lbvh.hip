@@ -463,6 +463,7 @@ __global__ __launch_bounds__(256) void k_sah_bounds(const BinBox* __restrict__ b
   }
 }
 
+__global__ void k_sah_set_counters(uint32_t* counters, uint32_t a, uint32_t b) { counters[0] = a; counters[1] = b; }
 __global__ void k_sah_clear_bins(uint32_t* __restrict__ bins, size_t words) {
   for (size_t w = blockIdx.x * (size_t) blockDim.x + threadIdx.x; w < words; w += (size_t) gridDim.x * blockDim.x) {
     const int f = (int) (w % kSahBinWords);
@@ -618,6 +619,7 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
   uint32_t* d_flags = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_counters = nullptr; void* d_scan_temp = nullptr;
   int2* d_children = nullptr; int2* d_ranges = nullptr; BinBox* d_node_box = nullptr;
   CollapseItem* d_queue[2] = {nullptr, nullptr}; Bvh4Node* d_nodes = nullptr;
+  char* d_pool = nullptr;
   size_t scan_bytes = 0;
   bool ok = true;
   const int threads = 256;
@@ -626,25 +628,27 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
   int cur = 0, acur = 0;
   uint32_t node_count = 1, level_count = 1, depth = 0;
   const uint32_t max_nodes4 = count;
-  for (int k = 0; k < 2; k++) {
-    LBVH_TRY(hipMalloc((void**) &d_boxes[k], sizeof(BinBox) * n));
-    LBVH_TRY(hipMalloc((void**) &d_ids[k], sizeof(uint32_t) * n));
-    LBVH_TRY(hipMalloc((void**) &d_owner[k], sizeof(int) * n));
-    LBVH_TRY(hipMalloc((void**) &d_active[k], sizeof(int) * max_active));
-    LBVH_TRY(hipMalloc((void**) &d_queue[k], sizeof(CollapseItem) * count));
+  {  // one allocation for everything (a dozen hipMallocs of hundreds of megabytes cost more than a level of the build)
+    LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_offsets, (int) n));
+    size_t total = 0;
+    auto reserve = [&](size_t bytes) { const size_t at = total; total += (bytes + 255) & ~(size_t) 255; return at; };
+    const size_t o_boxes[2] = {reserve(sizeof(BinBox) * n), reserve(sizeof(BinBox) * n)}, o_ids[2] = {reserve(sizeof(uint32_t) * n), reserve(sizeof(uint32_t) * n)};
+    const size_t o_owner[2] = {reserve(sizeof(int) * n), reserve(sizeof(int) * n)}, o_active[2] = {reserve(sizeof(int) * max_active), reserve(sizeof(int) * max_active)};
+    const size_t o_queue[2] = {reserve(sizeof(CollapseItem) * count), reserve(sizeof(CollapseItem) * count)};
+    const size_t o_nodes2 = reserve(sizeof(SahNode) * max_nodes2), o_bins = reserve(sizeof(uint32_t) * kSahNodeBinWords * max_active), o_fresh = reserve(max_nodes2);
+    const size_t o_flags = reserve(sizeof(uint32_t) * n), o_offsets = reserve(sizeof(uint32_t) * n), o_counters = reserve(sizeof(uint32_t) * 4);
+    const size_t o_children = reserve(sizeof(int2) * max_nodes2), o_ranges = reserve(sizeof(int2) * max_nodes2), o_node_box = reserve(sizeof(BinBox) * max_nodes2);
+    const size_t o_nodes = reserve(sizeof(Bvh4Node) * max_nodes4), o_scan = reserve(scan_bytes ? scan_bytes : 16);
+    LBVH_TRY(hipMalloc((void**) &d_pool, total));
+    for (int k = 0; k < 2; k++) {
+      d_boxes[k] = (BinBox*) (d_pool + o_boxes[k]); d_ids[k] = (uint32_t*) (d_pool + o_ids[k]); d_owner[k] = (int*) (d_pool + o_owner[k]);
+      d_active[k] = (int*) (d_pool + o_active[k]); d_queue[k] = (CollapseItem*) (d_pool + o_queue[k]);
+    }
+    d_nodes2 = (SahNode*) (d_pool + o_nodes2); d_bins = (uint32_t*) (d_pool + o_bins); d_fresh = (uint8_t*) (d_pool + o_fresh);
+    d_flags = (uint32_t*) (d_pool + o_flags); d_offsets = (uint32_t*) (d_pool + o_offsets); d_counters = (uint32_t*) (d_pool + o_counters);
+    d_children = (int2*) (d_pool + o_children); d_ranges = (int2*) (d_pool + o_ranges); d_node_box = (BinBox*) (d_pool + o_node_box);
+    d_nodes = (Bvh4Node*) (d_pool + o_nodes); d_scan_temp = (void*) (d_pool + o_scan);
   }
-  LBVH_TRY(hipMalloc((void**) &d_nodes2, sizeof(SahNode) * max_nodes2));
-  LBVH_TRY(hipMalloc((void**) &d_bins, sizeof(uint32_t) * kSahNodeBinWords * max_active));
-  LBVH_TRY(hipMalloc((void**) &d_fresh, max_nodes2));
-  LBVH_TRY(hipMalloc((void**) &d_flags, sizeof(uint32_t) * n));
-  LBVH_TRY(hipMalloc((void**) &d_offsets, sizeof(uint32_t) * n));
-  LBVH_TRY(hipMalloc((void**) &d_counters, sizeof(uint32_t) * 4));
-  LBVH_TRY(hipMalloc((void**) &d_children, sizeof(int2) * max_nodes2));
-  LBVH_TRY(hipMalloc((void**) &d_ranges, sizeof(int2) * max_nodes2));
-  LBVH_TRY(hipMalloc((void**) &d_node_box, sizeof(BinBox) * max_nodes2));
-  LBVH_TRY(hipMalloc((void**) &d_nodes, sizeof(Bvh4Node) * max_nodes4));
-  LBVH_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_flags, d_offsets, (int) n));
-  LBVH_TRY(hipMalloc(&d_scan_temp, scan_bytes ? scan_bytes : 16));
   LBVH_TRY(hipMemcpy(d_boxes[0], boxes, sizeof(BinBox) * n, hipMemcpyHostToDevice));
   {
     std::vector<uint32_t> ids(n);
@@ -674,10 +678,7 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
       hipLaunchKernelGGL(k_sah_clear_bins, dim3((uint32_t) std::min<size_t>((words + 255) / 256, 65535)), dim3(256), 0, 0, d_bins, words);
     }
     hipLaunchKernelGGL(k_sah_bin, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, (const SahNode*) d_nodes2, d_bins);
-    {
-      const uint32_t init[2] = {nodes_allocated, 0u};
-      LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
-    }
+    hipLaunchKernelGGL(k_sah_set_counters, dim3(1), dim3(1), 0, 0, d_counters, nodes_allocated, 0u);
     hipLaunchKernelGGL(k_sah_split, dim3((num_active + threads - 1) / threads), dim3(threads), 0, 0, (const int*) d_active[acur], num_active, (const uint32_t*) d_bins, d_nodes2, max_leaf,
                        d_counters, d_active[acur ^ 1], d_fresh, d_children, d_ranges);
     hipLaunchKernelGGL(k_sah_flags, dim3(blocks_n), dim3(threads), 0, 0, (const BinBox*) d_boxes[cur], (const int*) d_owner[cur], n, (const SahNode*) d_nodes2, d_flags);
@@ -725,9 +726,7 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
   result.max_depth = depth;
 done:
   {
-    void* bufs[] = {d_boxes[0], d_boxes[1], d_ids[0], d_ids[1], d_owner[0], d_owner[1], d_active[0], d_active[1], d_queue[0], d_queue[1], d_nodes2, d_bins, d_fresh, d_flags,
-                    d_offsets, d_counters, d_children, d_ranges, d_node_box, d_nodes, d_scan_temp};
-    for (void* b : bufs) if (b) (void) hipFree(b);
+    if (d_pool) (void) hipFree(d_pool);
   }
   if (!ok) return Bvh4();
   return result;
