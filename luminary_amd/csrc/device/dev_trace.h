@@ -576,6 +576,7 @@ LUM_DEV void prefetch_line(const void* p, uint32_t* wave_sink) {
 // matrix (an affine map preserves distances along the ray, so tmax and the stacked entry distances stay valid across levels).
 template <class Q>
 LUM_DEV void trace_items(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays, uint32_t lds_count) {
+  if (n == 0u) return;  // wave-uniform (a kernel argument read from the control words): an empty launch - the ambient reuse's fallback list on an opaque scene - stages nothing
   using SE = StackEntry<Q::kCull>;
   using E = typename SE::E;
   // Dual visits (visit_two_nodes) push all four children of the second node, which is not depth-first any more: the guard below allows them only

@@ -77,6 +77,7 @@ LUM_DEV uint32_t test_node8(const Node8Words& n, const TRay& r, float tmax) {
 
 template <class Q>
 LUM_DEV void trace_items8(const DeviceScene& sc, uint32_t n, uint32_t* __restrict__ cursor, Q& q, RayStats& st, uint32_t& rays, uint32_t lds_count) {
+  if (n == 0u) return;
   typedef uint2 E;
   E stack_in_scratch[kStackSize];
   int sp = 0;

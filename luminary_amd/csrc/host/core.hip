@@ -58,6 +58,7 @@ struct LumContext {
   // pixels and accumulators
   uint32_t* d_pixels = nullptr;
   uint32_t num_pixels = 0;
+  uint64_t pixels_hash = 0;       // of the pixel list in its order (lumc_set_pixels): the tile gather checks that the set IS the share of the deal it assumes
   float* d_first_moment = nullptr;
   float* d_second_moment = nullptr;
   // work buffers (sized for capacity paths)
@@ -1636,6 +1637,13 @@ int lumc_sky_hdri_download(LumContext* ctx, float* rgba, uint32_t* dim) {
   return 0;
 }
 
+// FNV-1a over a pixel list (null: 0, 1, 2 ... n - 1): the identity of a context's pixel set and of its ORDER
+static uint64_t pixel_list_hash(const uint32_t* pixels, uint32_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (uint32_t i = 0; i < n; i++) { h ^= pixels ? pixels[i] : i; h *= 1099511628211ull; }
+  return h;
+}
+
 int lumc_set_pixels(LumContext* ctx, const uint32_t* pixels, uint32_t num_pixels) {
   if (!ctx || !ctx->has_scene) { if (ctx) ctx->error = "lumc_set_pixels: no scene"; return 1; }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1645,6 +1653,7 @@ int lumc_set_pixels(LumContext* ctx, const uint32_t* pixels, uint32_t num_pixels
   if (ctx->d_first_moment) { (void) hipFree(ctx->d_first_moment); ctx->d_first_moment = nullptr; }
   if (ctx->d_second_moment) { (void) hipFree(ctx->d_second_moment); ctx->d_second_moment = nullptr; }
   ctx->num_pixels = num_pixels;
+  ctx->pixels_hash = pixel_list_hash(pixels, num_pixels);  // what lumc_frame_gather checks the set against (a null list = the frame in row-major order)
   if (num_pixels == 0) return 0;
   if (pixels) {
     HIP_TRY(ctx, hipMalloc((void**) &ctx->d_pixels, sizeof(uint32_t) * num_pixels));
@@ -2689,8 +2698,15 @@ int gather_prepare(LumContext* ctx, uint32_t width, uint32_t height, int world, 
     if (r == rank) share = c;
     stride = std::max(stride, c);
   }
-  if (!ctx->d_first_moment || ctx->num_pixels != share || (world > 1 && !ctx->d_pixels)) {
-    ctx->error = "lumc_frame_gather: this context's pixel set is not its share of the 32x32 tile deal (use lumc_frame_assemble for other partitions)";
+  bool is_share = ctx->d_first_moment && ctx->num_pixels == share;
+  if (is_share) {  // ... and the same pixels in the same order: the root scatters the rank's sums through the list IT derives from the deal
+    std::vector<uint32_t> mine(share ? share : 1);
+    uint32_t c = 0;
+    (void) lumc_tile_pixels(width, height, (uint32_t) rank, (uint32_t) world, kGatherTile, mine.data(), &c);
+    is_share = pixel_list_hash(mine.data(), share) == ctx->pixels_hash;
+  }
+  if (!is_share) {
+    ctx->error = "lumc_frame_gather: this context's pixel set is not its share of the 32x32 tile deal, in the deal's order (use lumc_frame_assemble for other partitions)";
     return 1;
   }
   stride = (stride + 3u) & ~3u;

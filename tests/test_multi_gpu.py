@@ -265,6 +265,12 @@ def test_rccl_tile_gather_with_a_one_rank_communicator():
         from luminary_amd.core import CoreError
         with pytest.raises(CoreError):
             core.frame_gather(w, h, 0)
+        core.set_pixels(None)  # every pixel, but in row-major order: not the deal's order either (the root would scatter the sums to the wrong pixels)
+        with pytest.raises(CoreError):
+            core.frame_gather(w, h, 0)
+        core.set_pixels(px[::-1].copy())  # the right pixels in another order
+        with pytest.raises(CoreError):
+            core.frame_gather(w, h, 0)
     finally:
         core.close()
     want = np.zeros((3, w * h), dtype=np.float32)
