@@ -120,3 +120,39 @@ def test_the_gpu_sah_builder_builds_the_host_builders_trees():
         assert seen["sah"][0] == seen["sah_gpu"][0], "%s: node counts %d vs %d" % (name, seen["sah"][0], seen["sah_gpu"][0])
         assert seen["sah"][1] == seen["sah_gpu"][1], "%s: rays, node visits and triangle tests %s vs %s" % (name, seen["sah"][1], seen["sah_gpu"][1])
         assert np.array_equal(seen["sah"][2], seen["sah_gpu"][2])
+
+
+@pytest.mark.parametrize("builder", ["sah_gpu", "ploc"])
+def test_gpu_builders_on_triangle_soups(builder):
+    """Random triangle soups the level-synchronous builders have to get through: a handful of triangles, many exact duplicates (sets whose centroids all coincide:
+    no axis separates them, the GPU SAH builder halves such a set by position), tiny and huge coordinates, long thin triangles. Closest hits against the
+    oracle's brute force (no tree at all)."""
+    from luminary_amd import Host
+    rng = np.random.RandomState(11)
+    cases = []
+    for n, scale, dup in ((5, 1.0, 0), (17, 1e-3, 0), (300, 1e3, 0), (4000, 1.0, 0), (600, 1.0, 40), (64, 1.0, 64)):
+        c = rng.uniform(-1.0, 1.0, (n, 1, 3)) * 10.0
+        t = c + rng.normal(size=(n, 3, 3)) * rng.choice([0.05, 0.5, 4.0], size=(n, 1, 1))
+        if dup:
+            t[-dup:] = t[0]  # `dup` exact copies of one triangle
+        cases.append((t * scale).astype(np.float32))
+    for tris in cases:
+        host = Host()
+        scenes.apply_benchmark_settings(host, 16, 16, 2, sky=(0.5, 0.5, 0.5))
+        mat = host.add_material(scenes._material((0.6, 0.6, 0.6), 0.6))
+        host.new_instance(host.add_mesh(tris.reshape(len(tris), 9), np.full(len(tris), mat, dtype=np.uint16)))
+        scenes.set_camera(host, (0.0, 0.0, 30.0), (0.0, 0.0, 0.0))
+        view = oracle_lib.with_luts(host.device_scene())
+        span = float(np.abs(tris).max())
+        o, d = _rays(20000, 3, -1.5 * span, 1.5 * span)
+        ign = np.full((o.shape[0], 2), 0xFFFFFFFF, dtype=np.uint32)
+        core = Core(0)
+        try:
+            core.set_bvh_builder(builder)
+            core.upload(view)
+            got = core.trace_closest_host(o, d, ign)
+        finally:
+            core.close()
+        want = oracle_lib.trace_closest(view, o, d, ign, use_bvh=False)
+        assert np.array_equal(got, want), "%s: %d triangles, extent %g" % (builder, len(tris), span)
+        host.close()
