@@ -139,7 +139,7 @@ class Core:
         self._call("lumc_set_ray_sorting", C.c_int(mode))
 
     def set_ambient_reuse(self, mode):
-        """-1 by flavour (fast: on, exact: off), 0 off, 1 on (lumc_set_ambient_reuse)"""
+        """-1 by flavour (fast: on, exact: off), 0 off, 1 on - in the exact flavour the reuse then only takes what it can prove and stays bit-identical (lumc_set_ambient_reuse)"""
         self._call("lumc_set_ambient_reuse", C.c_int(mode))
 
     @property
@@ -260,6 +260,13 @@ class Core:
         out = (C.c_uint64 * CNT_COUNT)()
         self._call("lumc_counters", out)
         return [int(x) for x in out]
+
+    def query_counters(self):
+        """counters() with the visibility entry as QUERIES answered - rays traced plus the ambient samples the closest-hit rays answered (minus those traced
+        after all): what a renderer that traces every visibility ray counts, e.g. the oracle."""
+        c = self.counters()
+        c[CNT_SHADOW] += c[CNT_AMBIENT_DEFERRED] - c[CNT_AMBIENT_FALLBACK]
+        return c
 
     def reset_counters(self):
         self._call("lumc_reset_counters")

@@ -101,6 +101,7 @@ struct DeviceScene {
   const uint4* tri_tex;
   const uint32_t* instance_mesh_ids;
   const float4* instance_transforms;  // 2 x float4 per instance
+  const float4* instance_rows;        // 3 x float4 per instance: the rows of its world->object matrix, translation in .w - what the top-level leaf records hold, by instance id
   const uint4* materials;             // 2 x uint4 per material
   // light tree
   const uint4* light_tree_root;   // header, then 3 x 16 B per section; nullptr without lights

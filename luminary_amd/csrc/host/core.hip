@@ -1055,6 +1055,7 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   }
   std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
   for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
+  if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_rows)) return 1;  // by instance id: the exact flavour's ambient reuse re-tests a ray against a hit's triangle (k_resolve_reuse)
 
   std::vector<Bvh4Node> nodes;
   std::vector<uint32_t> tlas_order;  // instance id of every top-level leaf
@@ -1684,6 +1685,9 @@ static void trace_particles(LumContext* ctx, hipStream_t stream, const PathQueue
 // pass that would answer, clouds and the procedural sky have no ambient sample; the reorder of sort mode 3 does not move hit_scene_tri.
 static bool ambient_reuse_active(const LumContext* ctx) {
   const DeviceScene& sc = ctx->scene;
+  // -1: by flavour. The fast flavour: on. The exact flavour: off - asked for (1), it takes only the answers it can prove for the ambient ray itself
+  // (k_resolve_reuse re-tests that ray against the hit's triangle) and stays bit-identical to the oracle, but the proof's gathers cost more than the
+  // cheap rays they save (hall: visibility kernel -29 ms, resolve +61 ms per step), so it is not its default.
   const bool wanted = ctx->ambient_reuse < 0 ? (ctx->wf == wavefront_kernels_fast()) : ctx->ambient_reuse != 0;
   return wanted && ctx->has_scene && sc.sky_mode != kSkyDefault && !sc.fog_active && !sc.ocean_active && !sc.particles_active && !sc.cloud_active &&
          !sc.sky_aerial_perspective && ctx->sort_mode == 0 && sc.shading_mode == 0u;

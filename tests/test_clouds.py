@@ -168,7 +168,7 @@ def _parity(host, samples=2, spp_pass=2, counters=4, view=None):
         assert np.isfinite(ofm).all()
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:counters] == [int(x) for x in ocnt[:counters]], (core.counters()[:4], list(ocnt[:4]))
+        assert core.query_counters()[:counters] == [int(x) for x in ocnt[:counters]], (core.query_counters()[:4], list(ocnt[:4]))
         return ofm
     finally:
         core.close()
@@ -276,7 +276,7 @@ def test_clouds_baked_into_the_panorama_match_the_oracle():
         fm, sm = core.accumulators()
         ofm, osm, ocnt = oracle_lib.render(oracle_view, 0, 3)
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
-        assert np.array_equal(sm, osm) and core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert np.array_equal(sm, osm) and core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     finally:
         core.close()
 

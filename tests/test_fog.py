@@ -245,7 +245,7 @@ def _parity(host, samples=3, first=0, spp_pass=2):
         assert np.isfinite(ofm).all()
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:4] == [int(x) for x in ocnt[:4]], (core.counters()[:4], list(ocnt[:4]))
+        assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]], (core.query_counters()[:4], list(ocnt[:4]))
         return ofm, ocnt
     finally:
         core.close()

@@ -92,7 +92,7 @@ def test_render_parity_cornell(core, tmp_path_factory, bounces, spp):
     ofm, osm, ocnt = oracle_lib.render(view, 0, spp)
     _assert_same(fm, ofm, "first moment")
     _assert_same(sm, osm, "second moment")
-    cnt = core.counters()
+    cnt = core.query_counters()  # visibility QUERIES: rays traced + ambient samples answered by the next closest hit (the oracle traces every one)
     assert cnt[0] == ocnt[0] and cnt[1] == ocnt[1] and cnt[2] == ocnt[2] and cnt[3] == ocnt[3], (cnt, ocnt)
     assert fm.max() > 0.0
 
@@ -159,7 +159,7 @@ def test_render_parity_material_zoo(core, sky_mode, aperture, blades):
     ofm, osm, ocnt = oracle_lib.render(view, 5, 3)
     _assert_same(fm, ofm, "first moment (material zoo)")
     _assert_same(sm, osm, "second moment (material zoo)")
-    cnt = core.counters()
+    cnt = core.query_counters()
     assert cnt[:4] == [int(x) for x in ocnt[:4]], (cnt, ocnt)
     assert np.isfinite(fm).all() and fm.max() > 0.0
 
@@ -200,7 +200,7 @@ def _full_size_frame_properties(core, host, min_triangles, width=1920, height=10
     core.render(0, 2, samples_per_pass=2)
     sub, sub_sm = core.accumulators()
     _assert_same(sub, ofm, "strided pixels rendered alone vs oracle")
-    assert core.counters()[:4] == [int(x) for x in ocnt[:4]], "ray counters of the strided pixels"
+    assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]], "ray counters of the strided pixels"
 
     core.set_pixels(None)
     core.render(0, 1, samples_per_pass=1)
@@ -284,6 +284,7 @@ def test_ray_sorting_does_not_change_results(core):
     core.upload(view)
     core.set_pixels(None)
     ref = None
+    core.set_ambient_reuse(0)  # the reuse is off whenever rays are sorted: compare like with like (node visits and visibility rays are among the counters)
     try:
         for mode in (0, 1, 2, 3):
             core.set_ray_sorting(mode)
@@ -302,6 +303,7 @@ def test_ray_sorting_does_not_change_results(core):
                 assert cnt == ref[2], "counters, sort mode %d" % mode
     finally:
         core.set_ray_sorting(0)
+        core.set_ambient_reuse(-1)
 
 
 def test_render_parity_emission_textures(core):
@@ -318,7 +320,7 @@ def test_render_parity_emission_textures(core):
     ofm, osm, ocnt = oracle_lib.render(view, 0, 6)
     _assert_same(fm, ofm, "first moment (emission textures)")
     _assert_same(sm, osm, "second moment (emission textures)")
-    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
 
 
 def test_render_parity_textured_scene(core):
@@ -335,7 +337,7 @@ def test_render_parity_textured_scene(core):
     ofm, osm, ocnt = oracle_lib.render(view, 2, 3)
     _assert_same(fm, ofm, "first moment (textured scene)")
     _assert_same(sm, osm, "second moment (textured scene)")
-    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     # closest hits through the cut-outs agree with brute force as well
     o, d = _random_rays(30000, 21, -9.0, 9.0)
     o[:, 1] = np.abs(o[:, 1]) * 0.3 + 0.1
@@ -357,7 +359,7 @@ def test_render_parity_edge_scenes(core, kind):
     ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
     _assert_same(fm, ofm, "first moment (%s)" % kind)
     _assert_same(sm, osm, "second moment (%s)" % kind)
-    assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+    assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     if kind == "empty":
         assert np.allclose(fm / 3.0, np.array([[0.4], [0.5], [0.7]], dtype=np.float32), rtol=1e-6)  # the constant sky, nothing else
 

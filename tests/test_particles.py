@@ -138,7 +138,7 @@ def _parity(host, samples=3, spp_pass=2, counters=4):
         assert np.isfinite(ofm).all()
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:counters] == [int(x) for x in ocnt[:counters]], (core.counters()[:4], list(ocnt[:4]))
+        assert core.query_counters()[:counters] == [int(x) for x in ocnt[:counters]], (core.query_counters()[:4], list(ocnt[:4]))
         return ofm
     finally:
         core.close()

@@ -92,7 +92,7 @@ def test_render_parity_with_the_procedural_sky(altitude):
         ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
         assert fm.reshape(3, H, W)[:, :4].mean() > 0.0, "the top rows see the sky"
     finally:
         core.close()
@@ -148,7 +148,7 @@ def test_sky_variants_match_the_oracle(variant):
         ofm, osm, ocnt = oracle_lib.render(view, 1, 2)
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     finally:
         core.close()
 
@@ -329,7 +329,7 @@ def test_render_parity_in_hdri_mode(case):
         ofm, osm, ocnt = oracle_lib.render(oracle_view, 0, 3)
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     finally:
         core.close()
 
@@ -409,6 +409,6 @@ def test_aerial_perspective_matches_the_oracle(mode):
         ofm, osm, ocnt = oracle_lib.render(view, 0, 3)
         assert np.array_equal(fm, ofm), "first moment: %d of %d differ, max %g" % ((fm != ofm).sum(), fm.size, np.abs(fm - ofm).max())
         assert np.array_equal(sm, osm)
-        assert core.counters()[:4] == [int(x) for x in ocnt[:4]]
+        assert core.query_counters()[:4] == [int(x) for x in ocnt[:4]]
     finally:
         core.close()

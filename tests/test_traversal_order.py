@@ -16,6 +16,7 @@ def test_visibility_rays_need_fewer_node_visits_than_closest_hit_rays():
     core = Core(0)
     try:
         core.upload(host.device_scene())
+        core.set_ambient_reuse(0)  # every visibility ray traced: the visiting order of ALL of them is what is measured
         core.set_pixels(None)
         core.reset_counters()
         core.render(0, 4, samples_per_pass=4)
