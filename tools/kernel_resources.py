@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Table of registers / scratch / LDS per kernel from the last build (luminary_amd/lib/obj/kernel_resource_usage.txt)."""
+"""Table of registers / scratch / LDS per kernel from the last build (luminary_amd/lib/obj/kernel_resource_usage.txt; --variant NAME: of that variant's build)."""
 import os, re, subprocess, sys
 p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "luminary_amd", "lib", "obj", "kernel_resource_usage.txt")
+if len(sys.argv) > 2 and sys.argv[1] == "--variant":
+    p = os.path.join(os.path.dirname(os.path.dirname(p)), "variants", sys.argv[2], "obj", "kernel_resource_usage.txt")
+    del sys.argv[1:3]
 rows, cur = [], None
 for line in open(p):
     m = re.search(r"Function Name: (\S+)", line)
