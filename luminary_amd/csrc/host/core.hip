@@ -12,9 +12,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <vector>
 
 #include "../../../include/lum_core.h"
@@ -28,6 +31,11 @@
 
 using namespace lum;
 
+// A mesh's bottom-level tree (node indices relative to the mesh, leaf ranges relative to its first triangle). The contexts of one process share them: a host
+// with several devices hands every context the same meshes, the first one builds a mesh's tree, the others - and a later upload of the same mesh - take it
+// from find_mesh_tree (below), and it is released with the last context that holds it.
+struct MeshTree { Bvh4 bvh; bool built_on_gpu = false; };
+
 struct LumContext {
   int device = 0;
   std::string error;
@@ -37,7 +45,7 @@ struct LumContext {
   std::vector<void*> scene_allocs[kGrpCount];
   int alloc_group = kGrpOnce;
   // what a partial update needs again: the per-mesh trees (node indices relative to the mesh, leaf ranges relative to its first triangle) and boxes
-  std::vector<Bvh4> mesh_bvh;
+  std::vector<std::shared_ptr<const MeshTree>> mesh_bvh;
   std::vector<Aabb> mesh_box;
   std::vector<uint32_t> sky_lut_key;  // the sky parameters the two sky tables were generated from
   float* d_bridge_lut = nullptr;      // the bridge sampler's vertex-count table (context-owned: scene.bridge_lut points here while bridges are possible)
@@ -167,6 +175,55 @@ void host_parallel_for(size_t n, F&& fn) {
   for (unsigned t = 1; t < threads; t++) pool.emplace_back([&, t] { const size_t b = std::min(n, t * chunk), e = std::min(n, b + chunk); if (b < e) fn(b, e); });
   fn((size_t) 0, std::min(n, chunk));
   for (auto& th : pool) th.join();
+}
+
+// ---- the process's bottom-level trees by what they were built from: the mesh's triangles (two 64-bit hashes of the vertex words, chunk by chunk so that the
+// value does not depend on the number of threads), the builder asked for and every LUM_* variable of the environment (the builders' knobs) ----
+struct MeshTreeKey {
+  uint64_t h0, h1, env;
+  uint32_t tris; int builder;
+  bool operator<(const MeshTreeKey& o) const { return std::tie(h0, h1, env, tris, builder) < std::tie(o.h0, o.h1, o.env, o.tris, o.builder); }
+};
+static std::mutex g_mesh_tree_mutex;
+static std::map<MeshTreeKey, std::weak_ptr<const MeshTree>> g_mesh_trees;
+extern "C" char** environ;
+
+static MeshTreeKey mesh_tree_key(const float* tri_vertices, uint32_t tris, int builder) {
+  constexpr size_t kChunk = 65536;  // triangles (12 floats each)
+  const size_t chunks = ((size_t) tris + kChunk - 1) / kChunk;
+  std::vector<uint64_t> part(2 * chunks);
+  host_parallel_for(chunks, [&](size_t b, size_t e) {
+    for (size_t c = b; c < e; c++) {
+      const size_t first = c * kChunk, last = std::min<size_t>((size_t) tris, first + kChunk);
+      uint64_t a = 0x9E3779B97F4A7C15ull ^ c, z = 0xC2B2AE3D27D4EB4Full + c;
+      for (size_t w = first * 6; w < last * 6; w++) {
+        uint64_t x;
+        std::memcpy(&x, reinterpret_cast<const char*>(tri_vertices) + w * 8, 8);
+        a = (a ^ x) * 0x100000001B3ull; a ^= a >> 29;
+        z = (z + x) * 0xFF51AFD7ED558CCDull; z ^= z >> 32;
+      }
+      part[2 * c] = a; part[2 * c + 1] = z;
+    }
+  });
+  MeshTreeKey k{0xCBF29CE484222325ull, 0x84222325CBF29CE4ull, 0xCBF29CE484222325ull, tris, builder};
+  for (size_t c = 0; c < chunks; c++) { k.h0 = (k.h0 ^ part[2 * c]) * 0x100000001B3ull; k.h1 = (k.h1 + part[2 * c + 1]) * 0xFF51AFD7ED558CCDull; k.h1 ^= k.h1 >> 32; }
+  for (char** e = environ; e && *e; e++)
+    if (std::strncmp(*e, "LUM_", 4) == 0) for (const char* p = *e; *p; p++) k.env = (k.env ^ (uint8_t) *p) * 0x100000001B3ull;
+  return k;
+}
+static std::shared_ptr<const MeshTree> find_mesh_tree(const MeshTreeKey& k) {
+  if (const char* e = getenv("LUM_BVH_SHARE")) if (atoi(e) == 0) return nullptr;  // every upload builds (tools/lbvh_bench.py times the builders this way)
+  std::lock_guard<std::mutex> lock(g_mesh_tree_mutex);
+  auto it = g_mesh_trees.find(k);
+  if (it == g_mesh_trees.end()) return nullptr;
+  std::shared_ptr<const MeshTree> t = it->second.lock();
+  if (!t) g_mesh_trees.erase(it);
+  return t;
+}
+static void keep_mesh_tree(const MeshTreeKey& k, const std::shared_ptr<const MeshTree>& t) {
+  std::lock_guard<std::mutex> lock(g_mesh_tree_mutex);
+  for (auto it = g_mesh_trees.begin(); it != g_mesh_trees.end();) it = it->second.expired() ? g_mesh_trees.erase(it) : std::next(it);
+  g_mesh_trees[k] = t;
 }
 
 template <typename T>
@@ -1085,26 +1142,33 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   if (dirty_meshes) {
     ctx->bvh_build_seconds = 0.0;
     ctx->bvh_meshes_by_builder[0] = ctx->bvh_meshes_by_builder[1] = 0;
-    ctx->mesh_bvh.assign(v->num_meshes, Bvh4{});
+    ctx->mesh_bvh.assign(v->num_meshes, nullptr);
   }
   std::vector<BvhTri> blas_tris(dirty_meshes ? (size_t) total_tris + 1 : 0);
   if (dirty_meshes) std::memset(blas_tris.data(), 0, sizeof(BvhTri) * blas_tris.size());
   std::vector<uint32_t> mesh_root(v->num_meshes + 1, 0);
   for (uint32_t m = 0; m < v->num_meshes; m++) {
     const uint32_t t0 = v->mesh_tri_offset[m], nt = v->mesh_tri_offset[m + 1] - t0;
-    if (dirty_meshes) {  // the only part of an upload that takes long: an instance edit reuses the trees
+    if (dirty_meshes) {  // the only part of an upload that takes long: an instance edit reuses the trees, another device of the host the first one's
       const auto t_build = std::chrono::steady_clock::now();
-      Bvh4 built;
-      if (ctx->bvh_builder == 1) built = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
-      else if (ctx->bvh_builder == 2) built = build_bvh4_ploc(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
-      else if (ctx->bvh_builder == 3) built = build_bvh4_sah_gpu(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
-      if (!built.nodes.empty()) ctx->bvh_meshes_by_builder[1]++;
-      else { built = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26); ctx->bvh_meshes_by_builder[0]++; }  // default, and fallback for too deep LBVH trees
+      const MeshTreeKey key = mesh_tree_key(v->vertices + (size_t) t0 * 12, nt, ctx->bvh_builder);
+      std::shared_ptr<const MeshTree> tree = find_mesh_tree(key);
+      if (!tree) {
+        auto built = std::make_shared<MeshTree>();
+        if (ctx->bvh_builder == 1) built->bvh = build_bvh4_lbvh(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+        else if (ctx->bvh_builder == 2) built->bvh = build_bvh4_ploc(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+        else if (ctx->bvh_builder == 3) built->bvh = build_bvh4_sah_gpu(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);
+        built->built_on_gpu = !built->bvh.nodes.empty();
+        if (!built->built_on_gpu) built->bvh = build_bvh4(tri_boxes[m].data(), nt, kBvhLeafMaxTri, 26);  // the host builder: asked for, or the fallback for a mesh the GPU builders cannot take
+        if (built->bvh.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
+        tree = built;
+        keep_mesh_tree(key, tree);
+      }
+      ctx->bvh_meshes_by_builder[tree->built_on_gpu ? 1 : 0]++;
       ctx->bvh_build_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_build).count();
-      if (built.nodes.empty()) { ctx->error = "mesh BVH exceeds 26 levels"; return 1; }
-      ctx->mesh_bvh[m] = std::move(built);
+      ctx->mesh_bvh[m] = std::move(tree);
     }
-    const Bvh4& bvh = ctx->mesh_bvh[m];
+    const Bvh4& bvh = ctx->mesh_bvh[m]->bvh;
     const uint32_t base = (uint32_t) nodes.size();
     mesh_root[m] = base;
     for (Bvh4Node n : bvh.nodes) {

@@ -1,5 +1,7 @@
 """GPU builders (lbvh.hip: the Morton-ordered radix tree, and parallel locally-ordered clustering over the same order): the trees they build give
 the same hits and the same image as the oracle (and therefore as the host SAH builder): results never depend on the acceleration structure."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -156,3 +158,34 @@ def test_gpu_builders_on_triangle_soups(builder):
         want = oracle_lib.trace_closest(view, o, d, ign, use_bvh=False)
         assert np.array_equal(got, want), "%s: %d triangles, extent %g" % (builder, len(tris), span)
         host.close()
+
+
+def test_the_contexts_of_a_process_share_a_meshs_tree(monkeypatch):
+    """A host with several devices uploads the same meshes to every context: the first context builds a mesh's tree, the others take it (core.hip
+    find_mesh_tree: keyed by the triangles' words, the builder and the builders' environment) - same nodes, same image, a fraction of the time; a mesh
+    that differs in one coordinate is built, and with the last context that holds it a tree is released (the next upload builds again)."""
+    monkeypatch.delenv("LUM_BVH_SHARE", raising=False)
+    view = scenes.hall_scene(160, 90, 3, target_triangles=200_000).device_scene()
+
+    def upload(v):
+        core = Core(0)
+        core.set_bvh_builder("sah")  # the slowest builder: the difference between building and taking is the largest
+        core.upload(v)
+        core.set_pixels(None)
+        core.render(0, 2, samples_per_pass=2)
+        return core, core.bvh_build_seconds(), core.bvh_stats()[0], core.accumulators()[0].copy(), core.bvh_meshes_by_builder()
+
+    first, t_first, nodes_first, frame_first, by_first = upload(view)
+    second, t_second, nodes_second, frame_second, by_second = upload(view)
+    assert nodes_second == nodes_first and np.array_equal(frame_second, frame_first) and by_second == by_first
+    assert t_second < 0.25 * t_first, "the second context built its own tree: %.3f s after %.3f s" % (t_second, t_first)
+    moved = scenes.hall_scene(160, 90, 3, target_triangles=200_000).device_scene()
+    ctypes.cast(moved.vertices, ctypes.POINTER(ctypes.c_float))[5] += 0.25  # one coordinate of one triangle: another mesh
+    third, t_third, _, _, _ = upload(moved)
+    assert t_third > 0.5 * t_first, "a different mesh was served from the cache (%.3f s against %.3f s)" % (t_third, t_first)
+    for c in (first, second, third):
+        c.close()
+    again, t_again, nodes_again, frame_again, _ = upload(view)
+    assert t_again > 0.5 * t_first, "the tree outlived its contexts (%.3f s against %.3f s)" % (t_again, t_first)
+    assert nodes_again == nodes_first and np.array_equal(frame_again, frame_first)
+    again.close()

@@ -4,6 +4,7 @@ import os
 import sys
 import time
 
+os.environ["LUM_BVH_SHARE"] = "0"  # time every build: no tree taken from another context of the process
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from luminary_amd.core import Core  # noqa: E402
