@@ -276,8 +276,21 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 // sampled (not CONSTANT).
 // kWater (the scene has an ocean): a path's volume is read from its stack, a vertex under water takes the sun through the surface and its sun and
 // ambient samples get a second visibility segment beyond it (dev_water.h); without an ocean none of that code exists in the kernel.
-template <uint32_t kSkyMode, bool kWater>
-__global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
+// kStage (experiment, LUM_SHADE_STAGED): 0 = the whole vertex in one kernel (the product); 1 = the light sampling alone - context, root pass, the eight
+// candidates, the chosen light's visibility item, the light record and the root sum (parked in the fourth word of the BSDF-direction record) - and
+// 2 = everything else, with the root sum read back: the split the reference's geometry kernel suggests (cuda/geometry.cuh:11-180 calls the light
+// sampling as one block) so that each stage gets its own register budget.
+#ifndef LUM_SHADE_STAGED
+#define LUM_SHADE_STAGED 0
+#endif
+#ifndef LUM_SHADE_STAGE1_WAVES
+#define LUM_SHADE_STAGE1_WAVES 3
+#endif
+#ifndef LUM_SHADE_STAGE2_WAVES
+#define LUM_SHADE_STAGE2_WAVES 4
+#endif
+template <uint32_t kSkyMode, bool kWater, int kStage = 0>
+__global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kStage == 2 ? LUM_SHADE_STAGE2_WAVES : (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
@@ -307,7 +320,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
         const uint32_t hit_type = in.hit_id[i].x;
         if (hit_type == kHitSky) {
           const uint4 aux = in.aux[i];
-          if (aux.w & kStAllowAmbient) {
+          if (kStage != 1 && (aux.w & kStAllowAmbient)) {
             if (kSkyMode == kSkyDefault) is_sky = true;  // the atmosphere is ray-marched by k_sky
             else if (kSkyMode == kSkyHdri) {
               const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
       const uint32_t slot = fbits(d4.w), state = aux.w;
       const Col record_in = record_unpack(U2{aux.x, aux.y});
       {
-        vertices++;
+        if (kStage != 1) vertices++;
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
         const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
@@ -371,7 +384,8 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
 #define LUM_ABLATE 0  // measurement only: 1 skips light sampling, 2 the BSDF light direction, 4 the bounce (results are wrong)
 #endif
         float light_root_sum = 0.0f;
-        if (geo_allowed) {
+        if (kStage == 2) { if (geo_allowed) light_root_sum = reinterpret_cast<const float*>(&nee.bsdf_weight_sum[i])[3]; }
+        else if (geo_allowed) {
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
           else ls = sample_light(sc, g, smp, clock);
@@ -385,6 +399,11 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
             s_geo_ids.x = target.x; s_geo_ids.y = target.y;
           }
         }
+        if (kStage == 1) {
+          st_stream(&nee.geo_color_light[i], geo_cl);
+          if (geo_allowed) reinterpret_cast<float*>(&nee.bsdf_weight_sum[i])[3] = light_root_sum;
+        }
+        else {
         // the shading frame is formed after the light sampling: its thirteen registers need not live through the candidate loop
         const LocalFrame lf = local_frame(sc, g);
         if (geo_allowed) {
@@ -461,7 +480,7 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
           st_stream(&nee.sun[i], sun);
           LUM_LAP(clock, 5);
         }
-        st_stream(&nee.geo_color_light[i], geo_cl);
+        if (kStage == 0) st_stream(&nee.geo_color_light[i], geo_cl);
         st_stream(&nee.bsdf_ray_prob[i], bs_rp); st_stream(&nee.bsdf_weight_sum[i], bs_ws);
         st_stream(&nee.ambient[i], amb);
 
@@ -511,7 +530,23 @@ __global__ __launch_bounds__(kBlock, (kSkyMode == kSkyConstantColor && !kWater) 
           n_aux = make_uint4(rp.x, rp.y, medium, new_state);
           n_hid = make_uint4(g.instance_id, g.tri_id, hid.z, hid.w);
         }
+        }  // kStage != 1
       }
+    }
+    if (kStage == 1) {  // the one list this stage appends to
+      const unsigned long long bg = __ballot(want_geo);
+      if (bg) {
+        uint32_t base = 0;
+        if (lane == (uint32_t) __builtin_ctzll(bg)) base = atomicAdd(ctrl + kCtlShadowItems, (uint32_t) __popcll(bg));
+        base = __shfl(base, __builtin_ctzll(bg));
+        if (want_geo) {
+          const uint32_t j = base + (uint32_t) __popcll(bg & below);
+          st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
+          st_stream(&sq.dir_out[j], make_float4(s_geo_dir.x, s_geo_dir.y, s_geo_dir.z, bitsf(i)));
+          st_stream(&sq.ids[j], s_geo_ids);
+        }
+      }
+      continue;
     }
     const bool amb_deferred = reuse_ambient && want_amb && survive;  // answered by the path's next closest-hit ray
     if (amb_deferred) { want_amb = false; vertices += 1u << 16; }   // counted in the upper half of the lane's vertex counter (a lane shades a few hundred vertices per launch)

@@ -49,9 +49,20 @@ static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc
 }
 static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
                   uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
+#if LUM_SHADE_STAGED
+  auto* k1 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false, 1> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false, 1> : k_shade<kSkyConstantColor, false, 1>;
+  auto* k2 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false, 2> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false, 2> : k_shade<kSkyConstantColor, false, 2>;
+  if (sc.ocean_active) {
+    k1 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true, 1> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true, 1> : k_shade<kSkyConstantColor, true, 1>;
+    k2 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true, 2> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true, 2> : k_shade<kSkyConstantColor, true, 2>;
+  }
+  hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
+  hipLaunchKernelGGL(k2, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
+#else
   auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false> : k_shade<kSkyConstantColor, false>;
   if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true> : k_shade<kSkyConstantColor, true>;
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
+#endif
 }
 static void shade_debug(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_shade_debug, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl);
