@@ -818,24 +818,50 @@ __global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, c
 
 // ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
 // kAmbientKnown: the ambient sample's visibility is `ambient_vis` (from the path's next closest hit) instead of the visibility pass's word.
-template <bool kAmbientKnown>
-LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis) {
-  const uint4 aux = in.aux[i];
-  const uint32_t slot = fbits(in.dir_slot[i].w);
+// The loads come in two batches, each issued as a block before anything waits for it: the vertex's own records (state, slot, the four NEE records),
+// then what those call for (the visibility words that matter, the path's result slot). Written branch by branch, as the reference's kernel reads, a lane
+// made five dependent round trips; the kernel is a stream of 160 bytes per vertex with no arithmetic to speak of, so its time was those round trips.
+// The sums are formed in the reference's order (sampled light, BSDF-sampled light, sun, ambient; then the path's weight).
+struct ResolveRecords { uint4 aux; uint32_t slot; float4 cl, lc; uint4 amb; };
+LUM_DEV ResolveRecords load_resolve_records(const PathQueue& in, const NeeQueue& nee, uint32_t i) {
+  ResolveRecords r;
+  r.aux = ld_stream(&in.aux[i]);
+  r.slot = fbits(reinterpret_cast<const float*>(&in.dir_slot[i])[3]);
+  r.cl = ld_stream(&nee.geo_color_light[i]);
+  r.lc = ld_stream(&nee.bsdf_weight_sum[i]);
+  r.amb = ld_stream(&nee.ambient[i]);
+  return r;
+}
+// kAmbient: 0 = the ambient sample's visibility is the visibility pass's word; 1 = it is `ambient_vis` (decided by the caller from the path's next closest
+// hit); 2 = the fast flavour's reuse: it comes from `*hit_word` (next.hit_scene_tri of the deferred sample's path), loaded HERE with the second batch and
+// decoded afterwards - false is returned, and nothing written, when that hit does not decide the sample (the caller queues its ray).
+template <int kAmbient>
+LUM_DEV bool resolve_records(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis,
+                             const ResolveRecords& r, const uint32_t* hit_word = nullptr) {
+  const uint4 aux = r.aux;
+  const uint32_t slot = r.slot;
   const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
-  Col acc = splat(0.0f);
-  {  // sampled light (direct_lighting.cuh:445-464)
-    const float4 cl = ld_stream(&nee.geo_color_light[i]);
-    Col vis = splat(0.0f);
-    if (fbits(cl.w) != kLightIdInvalid && geo_allowed) { const float4 v = ld_stream(&sq.vis[i]); vis = col(v.x, v.y, v.z); }
-    acc = acc + col(cl.x, cl.y, cl.z) * vis;
+  const float4 cl = r.cl, lc = r.lc;
+  const uint4 amb = r.amb;
+  const bool deferred = kAmbient == 2 && hit_word != nullptr;
+  const bool need_geo = fbits(cl.w) != kLightIdInvalid && geo_allowed, need_bsdf = lc.w != 0.0f, need_amb = kAmbient != 1 && !deferred && (amb.x != 0 || amb.y != 0);
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 vg = zero, vb = zero, va = zero;
+  uint32_t word = 0u;
+  if (deferred) word = *hit_word;
+  if (need_geo) vg = ld_stream(&sq.vis[i]);
+  if (need_bsdf) vb = ld_stream(&sq.vis[sq.capacity + i]);
+  if (need_amb) va = ld_stream(&sq.vis[2u * sq.capacity + i]);
+  const float4 before = results[slot];
+  if (deferred) {  // nothing hit (and no cut-out skipped) = visible; an opaque nearest hit beyond eps = blocked; anything else is not decided here
+    if (!(word & kHitTriHit)) { if (word & kHitTriCutout) return false; ambient_vis = 1.0f; }
+    else { if ((word & (kHitTriBeyondEps | kHitTriOpaque)) != (kHitTriBeyondEps | kHitTriOpaque)) return false; ambient_vis = 0.0f; }
   }
+  Col acc = splat(0.0f);
+  acc = acc + col(cl.x, cl.y, cl.z) * col(vg.x, vg.y, vg.z);  // sampled light (direct_lighting.cuh:445-464)
   {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
-    const float4 lc = ld_stream(&nee.bsdf_weight_sum[i]);
-    Col vis = splat(0.0f);
-    if (lc.w != 0.0f) { const float4 v = ld_stream(&sq.vis[sq.capacity + i]); vis = col(v.x, v.y, v.z); }
-    Col seen = col(lc.x, lc.y, lc.z) * vis;
-    if (lc.w != 0.0f && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
+    Col seen = col(lc.x, lc.y, lc.z) * col(vb.x, vb.y, vb.z);
+    if (need_bsdf && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
     acc = acc + seen;
   }
   if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
@@ -851,10 +877,7 @@ LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const Ne
     else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
   }
   {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
-    const uint4 amb = ld_stream(&nee.ambient[i]);
-    Col vis = splat(0.0f);
-    if (kAmbientKnown) vis = splat(ambient_vis);
-    else if (amb.x != 0 || amb.y != 0) { const float4 v = ld_stream(&sq.vis[2u * sq.capacity + i]); vis = col(v.x, v.y, v.z); }
+    const Col vis = (kAmbient == 1 || deferred) ? splat(ambient_vis) : col(va.x, va.y, va.z);
     Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
     if (sc.ocean_active) {
       if (amb.x != 0 || amb.y != 0) {
@@ -870,7 +893,13 @@ LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const Ne
     }
     acc = acc + seen;
   }
-  add_to_result(results, slot, acc * record_unpack(U2{aux.x, aux.y}));
+  const Col v = acc * record_unpack(U2{aux.x, aux.y});  // write_beauty_buffer, cuda/memory.cuh:359-368 (add_to_result with the slot already read)
+  if (any_positive(v)) results[slot] = make_float4(before.x + v.r, before.y + v.g, before.z + v.b, before.w);
+  return true;
+}
+template <bool kAmbientKnown>
+LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis) {
+  resolve_records<kAmbientKnown ? 1 : 0>(sc, in, nee, sq, results, i, lights_present, ambient_vis, load_resolve_records(in, nee, i));
 }
 
 LUM_DEV bool resolves_here(uint32_t hit_type) {  // sky, and with volumes: scattering events and ended paths have nothing to resolve
@@ -903,9 +932,14 @@ __global__ __launch_bounds__(kBlock) void k_resolve_reuse(DeviceScene sc, PathQu
     uint2 self = make_uint2(0u, 0u);
     if (i < n) {
       const uint2 hid = *reinterpret_cast<const uint2*>(&in.hit_id[i]);
-      if (resolves_here(hid.x)) {
-        j = nee.amb_path[i];
-        if (j == kNoAmbientPath) resolve_vertex<false>(sc, in, nee, sq, results, i, lights_present, 0.0f);  // no ambient sample, or its visibility ray was traced (the path ended here)
+      j = nee.amb_path[i];  // (stale for an entry that was not shaded: only read below when the entry resolves)
+      if (!resolves_here(hid.x)) j = kNoAmbientPath;
+      else {
+        const ResolveRecords rec = load_resolve_records(in, nee, i);
+        if (!kReuseProves) {  // one call either way: the hit word of a deferred sample travels with the visibility words and the result slot
+          if (!resolve_records<2>(sc, in, nee, sq, results, i, lights_present, 0.0f, rec, (j == kNoAmbientPath) ? nullptr : &next.hit_scene_tri[j])) { undecided = true; self = hid; }
+        }
+        else if (j == kNoAmbientPath) resolve_records<0>(sc, in, nee, sq, results, i, lights_present, 0.0f, rec);  // no ambient sample, or its visibility ray was traced (the path ended here)
         else {
           const uint32_t word = next.hit_scene_tri[j];
           int v;
@@ -936,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void k_resolve_reuse(DeviceScene sc, PathQu
             }
             else if (v == 1) v = -1;
           }
-          if (v >= 0) resolve_vertex<true>(sc, in, nee, sq, results, i, lights_present, (float) v);
+          if (v >= 0) resolve_records<1>(sc, in, nee, sq, results, i, lights_present, (float) v, rec);
           else { undecided = true; self = hid; }  // (j is not needed any more: the ray below is the vertex's own ambient ray)
         }
       }
