@@ -740,12 +740,13 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
       Col lc = splat(0.0f);
       if (light_id != kLightIdInvalid) {
         handle = sc.light_tri_handles[light_id];
-        const TriLight tl = load_tri_light(sc, handle.x, handle.y);
+        const TableLight entry = load_tri_light_table(sc, light_id);  // the light's line of the table the candidate loop reads (dev_light.h): no chain handle -> mesh -> vertices / transform / material
+        const TriLight& tl = entry.tri;
         F2 uv;
         dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, hit_origin, ray, uv);
         if (dist != kFltMax) {
-          lc = tri_light_color(sc, tl, uv);
-          const float mis = mis_for_bsdf_ray(hit_origin, tl, lc, dist, rp.w, ws.w);
+          lc = entry.textured ? tri_light_color(sc, tl, uv) : entry.color;
+          const float mis = (ws.w == 0.0f) ? 1.0f : mis_base(rp.w, tri_light_solid_angle(tl, hit_origin), importance(lc) * entry.area, dist * dist, ws.w);  // mis_for_bsdf_ray with the table's area
           lc = lc * (mis * num_hits);
           lc = lc * col(ws.x, ws.y, ws.z);
         }
