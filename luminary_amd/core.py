@@ -138,6 +138,10 @@ class Core:
         """0 queue order, 1 closest-hit rays of depth >= 1 sorted by (origin cell, direction octant), 2 visibility rays too."""
         self._call("lumc_set_ray_sorting", C.c_int(mode))
 
+    def set_fused_resolve(self, on):
+        """Fast flavour with the ambient reuse: the resolve of a depth rides in the next depth's shading kernel (lumc_set_fused_resolve; default on)."""
+        self._call("lumc_set_fused_resolve", C.c_int(1 if on else 0))
+
     def set_ambient_reuse(self, mode):
         """-1 by flavour (fast: on, exact: off), 0 off, 1 on - in the exact flavour the reuse then only takes what it can prove and stays bit-identical (lumc_set_ambient_reuse)"""
         self._call("lumc_set_ambient_reuse", C.c_int(mode))

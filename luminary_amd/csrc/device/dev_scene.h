@@ -195,7 +195,9 @@ struct PathQueue {
   uint4* aux;         // throughput record x,y | medium IOR stack | state flags
   uint4* hit_id;      // hit (or ignore) instance, triangle | pixel x | y << 16 | sample id
   uint32_t* hit_scene_tri;  // index of the hit triangle in the scene arrays (vertices, tri_tex): spares the shade kernel two dependent loads
+  uint32_t* parent;         // fused resolve (kernels.h FusedResolve): index of the vertex this path continues, in the previous depth's queue | kParentDeferred
 };
+constexpr uint32_t kParentDeferred = 0x80000000u, kParentMask = 0x7FFFFFFFu;  // bit 31: that vertex left its ambient sample to this path's closest hit
 
 // Next-event-estimation data of the vertices of one depth, indexed like the path queue they were shaded from.
 struct NeeQueue {
@@ -219,6 +221,14 @@ struct ShadowQueue {
   float4* vis;          // [kinds * capacity]: kind 0 sampled light, 1 BSDF-sampled light, 2 ambient, 3 sun; with an ocean 4 ambient's and 5 sun's second segment
   uint32_t* light_items;  // path indices that need a light-BVH query
   uint32_t capacity;
+};
+
+// Fused resolve (kernels.h, above k_shade): what k_shade of depth d needs to resolve the vertices of depth d - 1.
+struct FusedResolve {
+  PathQueue prev;        // the queue of depth d - 1 (intact: the queues rotate through three buffers)
+  NeeQueue nee_prev;     // its NEE records
+  ShadowQueue fallback;  // item arrays of the undecided samples' rays; vis = the visibility words of depth d - 1, light_items = the list of their vertices
+  uint32_t* ended;       // out: the vertices of depth d that no entry of depth d + 1 continues (counted in kCtlSkyItems: the procedural sky's list does not exist in this mode)
 };
 
 // What the fog scatters into the rays of one depth (k_volume_inscatter -> visibility rays -> k_volume_resolve), indexed like the path queue.

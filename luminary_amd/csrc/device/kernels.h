@@ -268,6 +268,92 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
   results[slot] = r;
 }
 
+// ---- the resolve of a vertex (optix/optix_kernel_shadow.cu:15-100: sampled light, BSDF-sampled light, (sun,) ambient, then the path's weight), used by the
+// resolve kernels further down and - fused - by k_shade for the vertex a path comes from ----
+// The loads come in two batches, each issued as a block before anything waits for it: the vertex's own records (state, slot, the four NEE records),
+// then what those call for (the visibility words that matter, the path's result slot). Written branch by branch, as the reference's kernel reads, a lane
+// made five dependent round trips; the kernel is a stream of 160 bytes per vertex with no arithmetic to speak of, so its time was those round trips.
+// The sums are formed in the reference's order (sampled light, BSDF-sampled light, sun, ambient; then the path's weight).
+struct ResolveRecords { uint4 aux; uint32_t slot; float4 cl, lc; uint4 amb; };
+LUM_DEV ResolveRecords load_resolve_records(const PathQueue& in, const NeeQueue& nee, uint32_t i) {
+  ResolveRecords r;
+  r.aux = ld_stream(&in.aux[i]);
+  r.slot = fbits(reinterpret_cast<const float*>(&in.dir_slot[i])[3]);
+  r.cl = ld_stream(&nee.geo_color_light[i]);
+  r.lc = ld_stream(&nee.bsdf_weight_sum[i]);
+  r.amb = ld_stream(&nee.ambient[i]);
+  return r;
+}
+// kAmbient: 0 = the ambient sample's visibility is the visibility pass's word; 1 = it is `ambient_vis` (decided by the caller from the path's next closest
+// hit); 2 = the fast flavour's reuse: it comes from `*hit_word` (next.hit_scene_tri of the deferred sample's path), loaded HERE with the second batch and
+// decoded afterwards - false is returned, and nothing written, when that hit does not decide the sample (the caller queues its ray).
+template <int kAmbient>
+LUM_DEV bool resolve_records(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis,
+                             const ResolveRecords& r, const uint32_t* hit_word = nullptr) {
+  const uint4 aux = r.aux;
+  const uint32_t slot = r.slot;
+  const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
+  const float4 cl = r.cl, lc = r.lc;
+  const uint4 amb = r.amb;
+  const bool deferred = kAmbient == 2 && hit_word != nullptr;
+  const bool need_geo = fbits(cl.w) != kLightIdInvalid && geo_allowed, need_bsdf = lc.w != 0.0f, need_amb = kAmbient != 1 && !deferred && (amb.x != 0 || amb.y != 0);
+  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+  float4 vg = zero, vb = zero, va = zero;
+  uint32_t word = 0u;
+  if (deferred) word = *hit_word;
+  if (need_geo) vg = ld_stream(&sq.vis[i]);
+  if (need_bsdf) vb = ld_stream(&sq.vis[sq.capacity + i]);
+  if (need_amb) va = ld_stream(&sq.vis[2u * sq.capacity + i]);
+  const float4 before = results[slot];
+  if (deferred) {  // nothing hit (and no cut-out skipped) = visible; an opaque nearest hit beyond eps = blocked; anything else is not decided here
+    if (!(word & kHitTriHit)) { if (word & kHitTriCutout) return false; ambient_vis = 1.0f; }
+    else { if ((word & (kHitTriBeyondEps | kHitTriOpaque)) != (kHitTriBeyondEps | kHitTriOpaque)) return false; ambient_vis = 0.0f; }
+  }
+  Col acc = splat(0.0f);
+  acc = acc + col(cl.x, cl.y, cl.z) * col(vg.x, vg.y, vg.z);  // sampled light (direct_lighting.cuh:445-464)
+  {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
+    Col seen = col(lc.x, lc.y, lc.z) * col(vb.x, vb.y, vb.z);
+    if (need_bsdf && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
+    acc = acc + seen;
+  }
+  if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
+    const uint4 sun = nee.sun[i];
+    Col vis = splat(0.0f);
+    if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
+    if (sc.ocean_active && (sun.x != 0 || sun.y != 0)) {
+      const float4 w = nee.sun_water[i];
+      Col vis2 = splat(1.0f);
+      if ((fbits(w.w) & kSkyRaySecond) && !(fbits(w.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindSun2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+      acc = acc + combine_sun_ray(record_unpack(U2{sun.x, sun.y}), vis, w.x, fbits(w.w), vis2);
+    }
+    else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
+  }
+  {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
+    const Col vis = (kAmbient == 1 || deferred) ? splat(ambient_vis) : col(va.x, va.y, va.z);
+    Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
+    if (sc.ocean_active) {
+      if (amb.x != 0 || amb.y != 0) {
+        const float4 t1 = nee.amb_t1[i], t2 = nee.amb_t2[i];
+        Col vis2 = splat(1.0f);
+        if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindAmbient2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
+        seen = combine_ambient_ray(record_unpack(U2{amb.x, amb.y}), vis, col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2);
+      }
+    }
+    else if (sc.fog_active) {  // direct_lighting.cuh:561-563
+      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
+      seen = seen * volume_transmittance(sc, kVolumeFog, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
+    }
+    acc = acc + seen;
+  }
+  const Col v = acc * record_unpack(U2{aux.x, aux.y});  // write_beauty_buffer, cuda/memory.cuh:359-368 (add_to_result with the slot already read)
+  if (any_positive(v)) results[slot] = make_float4(before.x + v.r, before.y + v.g, before.z + v.b, before.w);
+  return true;
+}
+template <bool kAmbientKnown>
+LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis) {
+  resolve_records<kAmbientKnown ? 1 : 0>(sc, in, nee, sq, results, i, lights_present, ambient_vis, load_resolve_records(in, nee, i));
+}
+
 // ---- shading pass: cuda/geometry.cuh:11-180 (+ miss handling of cuda/sky.cuh:609-633, roulette cuda/directives.cuh:11-32) ----
 // One instantiation per sky mode (kSkyMode == sc.sky_mode, chosen at launch): sun sampling is a third of the kernel's code again, which a
 // constant-colour scene never runs but would pay for in registers and instruction cache. The modes differ in three places
@@ -289,11 +375,25 @@ LUM_DEV void add_to_result(float4* results, uint32_t slot, Col v) {  // write_be
 #ifndef LUM_SHADE_STAGE2_WAVES
 #define LUM_SHADE_STAGE2_WAVES 4
 #endif
+// Fused resolve (fast flavour with the ambient reuse, lumc_set_fused_resolve): k_resolve_reuse is a stream of 160 bytes per vertex with five loads and a
+// dozen multiply-adds - a kernel that waits - while k_shade computes with idle memory pipes. So the resolve of depth d - 1 rides in k_shade of depth d: every
+// path entry knows the vertex it continues (PathQueue::parent, written with the survivor) and, before anything else touches its result slot, forms that
+// vertex's sum from the previous depth's records (`nee_prev`, `prev`: the queues of three and the NEE records of two depths are kept) and its own closest
+// hit's word - the same loads, now under the other waves' candidate loops. The per-path order of the sums is the usual one (vertex d - 1, then emission or sky of
+// depth d). What stays outside: vertices whose path ended (k_resolve_ended after the depth's visibility pass: no entry continues them) and samples the hit
+// cannot decide (`fallback`: their ambient ray is queued into its own item arrays, traced by a small second pass, resolved by k_resolve_listed - for those
+// the vertex's sum lands after the next depth's emission: the fast flavour's rounding, not the exact flavour's, which never runs this).
+// (struct FusedResolve: dev_scene.h)
 template <uint32_t kSkyMode, bool kWater, int kStage = 0>
 __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kStage == 2 ? LUM_SHADE_STAGE2_WAVES : (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
-                                                                    uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
+                                                                    uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse, const FusedResolve* __restrict__ fused_dev,
+                                                                    uint32_t fused_flags) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  // (the fast flavour only: the exact flavour's sums land in the reference's order for every vertex, its kernels do not carry the code)
+  // (its pointers come through memory, read where they are used: as kernel arguments they sat in scalar registers for the whole kernel, and the spills that
+  // caused put 27 more lane reads into every iteration of the candidate loop)
+  const bool resolve_parents = LUM_FAST && kStage == 0 && !kWater && (fused_flags & 1u) != 0u, announce_children = LUM_FAST && kStage == 0 && !kWater && (fused_flags & 2u) != 0u;
   // ambient_reuse (see AmbientReuse above): the ambient visibility of a surviving path comes from its next closest-hit ray; never with an ocean (the ambient
   // ray then ends at the water surface) or under the procedural sky (no ambient sample)
   const bool reuse_ambient = ambient_reuse != 0u && !kWater && kSkyMode != kSkyDefault;
@@ -311,11 +411,86 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   uint32_t num_pending = 0;  // wave-uniform
   ShadeClock clock;
   clock.start();
+  // fused resolve: an entry's parent word and slot are fetched one round ahead (two registers across the batch in between: one dependent round trip less per round)
+  uint32_t parent_ahead = 0u, slot_ahead = 0u;
+  if (resolve_parents) {
+    const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+    if (i0 < n) { parent_ahead = in.parent[i0]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i0])[3]); }
+  }
   for (uint32_t round = 0;; round++) {
     const bool input_done = round >= rounds;
     if (!input_done) {
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
       bool is_hit = false, is_sky = false;
+      if (resolve_parents) {  // the vertex this entry continues: its sum, before the entry's own emission or sky term
+        const FusedResolve& fused = *fused_dev;
+        bool undecided = false;
+        uint32_t ip = 0;
+        uint4 amb = make_uint4(0u, 0u, 0u, 0u);
+        const uint32_t p = parent_ahead, slot = slot_ahead;
+        {
+          const uint32_t i_ahead = ((round + 1u) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+          if (round + 1u < rounds && i_ahead < n) { parent_ahead = in.parent[i_ahead]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i_ahead])[3]); }
+        }
+        if (i < n) {
+          ip = p & kParentMask;
+          // resolve_records<2> for a plain scene (no fog, no ocean: the reuse's condition), written out: the records, then - together - the hit word of a
+          // deferred sample, the visibility words that matter and the result slot; the sums in the reference's order
+          const uint4 paux = ld_stream(&fused.prev.aux[ip]);
+          const float4 cl = ld_stream(&fused.nee_prev.geo_color_light[ip]), lc = ld_stream(&fused.nee_prev.bsdf_weight_sum[ip]);
+          amb = ld_stream(&fused.nee_prev.ambient[ip]);
+          uint4 sun = make_uint4(0u, 0u, 0u, 0u);
+          if (kSkyMode == kSkyHdri) sun = fused.nee_prev.sun[ip];
+          const bool deferred = (p & kParentDeferred) != 0u;
+          const bool need_geo = fbits(cl.w) != kLightIdInvalid && lights_present && ((paux.w & kStVolumeScattered) == 0), need_bsdf = lc.w != 0.0f;
+          const bool need_amb = !deferred && (amb.x != 0 || amb.y != 0), need_sun = kSkyMode == kSkyHdri && (sun.x != 0 || sun.y != 0);
+          const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          float4 vg = zero, vb = zero, va = zero, vs = zero;
+          uint32_t word = 0u;
+          const float4* __restrict__ vis = fused.fallback.vis;  // (the previous depth's visibility words: sq.vis)
+          const uint32_t cap = fused.fallback.capacity;
+          if (deferred) word = in.hit_scene_tri[i];
+          if (need_geo) vg = ld_stream(&vis[ip]);
+          if (need_bsdf) vb = ld_stream(&vis[cap + ip]);
+          if (need_amb) va = ld_stream(&vis[2u * cap + ip]);
+          if (need_sun) vs = vis[3u * cap + ip];
+          const float4 before = results[slot];
+          float ambient_vis = 0.0f;
+          if (deferred) {  // nothing hit (and no cut-out skipped) = visible; an opaque nearest hit beyond eps = blocked; anything else is not decided here
+            if (!(word & kHitTriHit)) { undecided = (word & kHitTriCutout) != 0u; ambient_vis = 1.0f; }
+            else undecided = (word & (kHitTriBeyondEps | kHitTriOpaque)) != (kHitTriBeyondEps | kHitTriOpaque);
+          }
+          if (!undecided) {
+            Col acc = splat(0.0f);
+            acc = acc + col(cl.x, cl.y, cl.z) * col(vg.x, vg.y, vg.z);
+            acc = acc + col(lc.x, lc.y, lc.z) * col(vb.x, vb.y, vb.z);
+            if (kSkyMode == kSkyHdri) acc = acc + record_unpack(U2{sun.x, sun.y}) * col(vs.x, vs.y, vs.z);
+            acc = acc + record_unpack(U2{amb.x, amb.y}) * (deferred ? splat(ambient_vis) : col(va.x, va.y, va.z));
+            const Col v = acc * record_unpack(U2{paux.x, paux.y});
+            if (any_positive(v)) results[slot] = make_float4(before.x + v.r, before.y + v.g, before.z + v.b, before.w);
+          }
+        }
+        const unsigned long long bu = __ballot(undecided);
+        if (bu) {  // rare: the vertex's own ambient ray, from its hit point along the record's packed direction (direct_lighting.cuh:388-405)
+          uint32_t base = 0;
+          if (lane == (uint32_t) __builtin_ctzll(bu)) {
+            base = atomicAdd(ctrl + kCtlVolumeShadowItems, (uint32_t) __popcll(bu));
+            atomicAdd((unsigned long long*) &counters[kCntAmbientFallback], (unsigned long long) __popcll(bu));
+          }
+          base = __shfl(base, __builtin_ctzll(bu));
+          if (undecided) {
+            const uint32_t k = base + (uint32_t) __popcll(bu & below);
+            const float4 o4 = fused.prev.origin_t[ip], d4 = fused.prev.dir_slot[ip];  // the vertex's hit point as its own visibility rays had it (this path starts at the point projected onto the triangle)
+            const V3 hit_origin = v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w;
+            const uint2 self = *reinterpret_cast<const uint2*>(&fused.prev.hit_id[ip]);
+            const V3 ar = ray_unpack(U2{amb.z, amb.w});
+            fused.fallback.origin_dist[k] = make_float4(hit_origin.x, hit_origin.y, hit_origin.z, kFltMax);
+            fused.fallback.dir_out[k] = make_float4(ar.x, ar.y, ar.z, bitsf(2u * sq.capacity + ip));
+            fused.fallback.ids[k] = make_uint4(0xFFFFFFFFu, 0u, self.x, self.y);
+            fused.fallback.light_items[k] = ip;
+          }
+        }
+      }
       if (i < n) {
         const uint32_t hit_type = in.hit_id[i].x;
         if (hit_type == kHitSky) {
@@ -557,8 +732,10 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
     const unsigned long long bg = __ballot(want_geo), ba = __ballot(want_amb), bn = __ballot(want_sun), bl = __ballot(want_lq);
     const unsigned long long b2a = kWater ? __ballot(want_amb2) : 0ull, b2s = kWater ? __ballot(want_sun2) : 0ull;
     const uint32_t ng = (uint32_t) __popcll(bg), na = (uint32_t) __popcll(ba), ns = (uint32_t) __popcll(bn), na2 = (uint32_t) __popcll(b2a);
-    const uint32_t want_count = (lane == 0) ? (uint32_t) __popcll(ballot) : (lane == 1) ? ng + na + ns + na2 + (uint32_t) __popcll(b2s) : (lane == 2) ? (uint32_t) __popcll(bl) : 0u;
-    uint32_t* const want_word = (lane == 0) ? count_out : (lane == 1) ? ctrl + kCtlShadowItems : ctrl + kCtlLightItems;
+    const unsigned long long be = announce_children ? __ballot(valid && !survive) : 0ull;  // fused resolve: vertices no entry will continue, listed for k_resolve_ended (a fourth counter, same instruction)
+    const uint32_t want_count = (lane == 0) ? (uint32_t) __popcll(ballot) : (lane == 1) ? ng + na + ns + na2 + (uint32_t) __popcll(b2s) : (lane == 2) ? (uint32_t) __popcll(bl) :
+                                (lane == 3) ? (uint32_t) __popcll(be) : 0u;
+    uint32_t* const want_word = (lane == 0) ? count_out : (lane == 1) ? ctrl + kCtlShadowItems : (lane == 2) ? ctrl + kCtlLightItems : ctrl + kCtlSkyItems;
     uint32_t reserved = 0;
     if (want_count) reserved = atomicAdd(want_word, want_count);
     const uint32_t base_out = __builtin_amdgcn_readlane(reserved, 0), base_shadow = __builtin_amdgcn_readlane(reserved, 1), base_light = __builtin_amdgcn_readlane(reserved, 2);
@@ -567,8 +744,10 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
       const uint32_t j = base_out + (uint32_t) __popcll(ballot & below);
       st_stream(&out.origin_t[j], n_o); st_stream(&out.dir_slot[j], n_d); st_stream(&out.aux[j], n_aux); st_stream(&out.hit_id[j], n_hid);
       amb_path = amb_deferred ? j : kNoAmbientPath;
+      if (announce_children) out.parent[j] = i | (amb_deferred ? kParentDeferred : 0u);
     }
-    if (reuse_ambient && valid) nee.amb_path[i] = amb_path;  // every vertex of the depth: k_resolve_reuse reads it for each of them
+    if (reuse_ambient && valid && !announce_children) nee.amb_path[i] = amb_path;  // every vertex of the depth: k_resolve_reuse reads it for each of them (the fused resolve has the parent words and the list below instead)
+    if (be != 0ull && valid && !survive) fused_dev->ended[__builtin_amdgcn_readlane(reserved, 3) + (uint32_t) __popcll(be & below)] = i;
     if (want_geo) {
       const uint32_t j = base_shadow + (uint32_t) __popcll(bg & below);
       st_stream(&sq.origin_dist[j], make_float4(s_origin.x, s_origin.y, s_origin.z, s_geo_dir.w));
@@ -819,90 +998,6 @@ __global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, c
 
 // ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
 // kAmbientKnown: the ambient sample's visibility is `ambient_vis` (from the path's next closest hit) instead of the visibility pass's word.
-// The loads come in two batches, each issued as a block before anything waits for it: the vertex's own records (state, slot, the four NEE records),
-// then what those call for (the visibility words that matter, the path's result slot). Written branch by branch, as the reference's kernel reads, a lane
-// made five dependent round trips; the kernel is a stream of 160 bytes per vertex with no arithmetic to speak of, so its time was those round trips.
-// The sums are formed in the reference's order (sampled light, BSDF-sampled light, sun, ambient; then the path's weight).
-struct ResolveRecords { uint4 aux; uint32_t slot; float4 cl, lc; uint4 amb; };
-LUM_DEV ResolveRecords load_resolve_records(const PathQueue& in, const NeeQueue& nee, uint32_t i) {
-  ResolveRecords r;
-  r.aux = ld_stream(&in.aux[i]);
-  r.slot = fbits(reinterpret_cast<const float*>(&in.dir_slot[i])[3]);
-  r.cl = ld_stream(&nee.geo_color_light[i]);
-  r.lc = ld_stream(&nee.bsdf_weight_sum[i]);
-  r.amb = ld_stream(&nee.ambient[i]);
-  return r;
-}
-// kAmbient: 0 = the ambient sample's visibility is the visibility pass's word; 1 = it is `ambient_vis` (decided by the caller from the path's next closest
-// hit); 2 = the fast flavour's reuse: it comes from `*hit_word` (next.hit_scene_tri of the deferred sample's path), loaded HERE with the second batch and
-// decoded afterwards - false is returned, and nothing written, when that hit does not decide the sample (the caller queues its ray).
-template <int kAmbient>
-LUM_DEV bool resolve_records(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis,
-                             const ResolveRecords& r, const uint32_t* hit_word = nullptr) {
-  const uint4 aux = r.aux;
-  const uint32_t slot = r.slot;
-  const bool geo_allowed = lights_present && ((aux.w & kStVolumeScattered) == 0);
-  const float4 cl = r.cl, lc = r.lc;
-  const uint4 amb = r.amb;
-  const bool deferred = kAmbient == 2 && hit_word != nullptr;
-  const bool need_geo = fbits(cl.w) != kLightIdInvalid && geo_allowed, need_bsdf = lc.w != 0.0f, need_amb = kAmbient != 1 && !deferred && (amb.x != 0 || amb.y != 0);
-  const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  float4 vg = zero, vb = zero, va = zero;
-  uint32_t word = 0u;
-  if (deferred) word = *hit_word;
-  if (need_geo) vg = ld_stream(&sq.vis[i]);
-  if (need_bsdf) vb = ld_stream(&sq.vis[sq.capacity + i]);
-  if (need_amb) va = ld_stream(&sq.vis[2u * sq.capacity + i]);
-  const float4 before = results[slot];
-  if (deferred) {  // nothing hit (and no cut-out skipped) = visible; an opaque nearest hit beyond eps = blocked; anything else is not decided here
-    if (!(word & kHitTriHit)) { if (word & kHitTriCutout) return false; ambient_vis = 1.0f; }
-    else { if ((word & (kHitTriBeyondEps | kHitTriOpaque)) != (kHitTriBeyondEps | kHitTriOpaque)) return false; ambient_vis = 0.0f; }
-  }
-  Col acc = splat(0.0f);
-  acc = acc + col(cl.x, cl.y, cl.z) * col(vg.x, vg.y, vg.z);  // sampled light (direct_lighting.cuh:445-464)
-  {  // BSDF-sampled direction (direct_lighting.cuh:586-667)
-    Col seen = col(lc.x, lc.y, lc.z) * col(vb.x, vb.y, vb.z);
-    if (need_bsdf && (sc.fog_active || sc.ocean_active)) { const float4 t = nee.bsdf_ray_prob[i]; seen = seen * col(t.x, t.y, t.z); }
-    acc = acc + seen;
-  }
-  if (sc.sky_mode != kSkyConstantColor) {  // sun (direct_lighting.cuh:466-519)
-    const uint4 sun = nee.sun[i];
-    Col vis = splat(0.0f);
-    if (sun.x != 0 || sun.y != 0) { const float4 v = sq.vis[3u * sq.capacity + i]; vis = col(v.x, v.y, v.z); }
-    if (sc.ocean_active && (sun.x != 0 || sun.y != 0)) {
-      const float4 w = nee.sun_water[i];
-      Col vis2 = splat(1.0f);
-      if ((fbits(w.w) & kSkyRaySecond) && !(fbits(w.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindSun2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
-      acc = acc + combine_sun_ray(record_unpack(U2{sun.x, sun.y}), vis, w.x, fbits(w.w), vis2);
-    }
-    else acc = acc + record_unpack(U2{sun.x, sun.y}) * vis;
-  }
-  {  // ambient (direct_lighting.cuh:521-584); zero in DEFAULT mode
-    const Col vis = (kAmbient == 1 || deferred) ? splat(ambient_vis) : col(va.x, va.y, va.z);
-    Col seen = record_unpack(U2{amb.x, amb.y}) * vis;
-    if (sc.ocean_active) {
-      if (amb.x != 0 || amb.y != 0) {
-        const float4 t1 = nee.amb_t1[i], t2 = nee.amb_t2[i];
-        Col vis2 = splat(1.0f);
-        if ((fbits(t2.w) & kSkyRaySecond) && !(fbits(t2.w) & kSkyRayTotalReflection)) { const float4 v = sq.vis[kShadowKindAmbient2 * sq.capacity + i]; vis2 = col(v.x, v.y, v.z); }
-        seen = combine_ambient_ray(record_unpack(U2{amb.x, amb.y}), vis, col(t1.x, t1.y, t1.z), t1.w, col(t2.x, t2.y, t2.z), fbits(t2.w), vis2);
-      }
-    }
-    else if (sc.fog_active) {  // direct_lighting.cuh:561-563
-      const float4 o4 = in.origin_t[i], d4 = in.dir_slot[i];
-      seen = seen * volume_transmittance(sc, kVolumeFog, v3(o4.x, o4.y, o4.z) + v3(d4.x, d4.y, d4.z) * o4.w, ray_unpack(U2{amb.z, amb.w}), kFltMax);
-    }
-    acc = acc + seen;
-  }
-  const Col v = acc * record_unpack(U2{aux.x, aux.y});  // write_beauty_buffer, cuda/memory.cuh:359-368 (add_to_result with the slot already read)
-  if (any_positive(v)) results[slot] = make_float4(before.x + v.r, before.y + v.g, before.z + v.b, before.w);
-  return true;
-}
-template <bool kAmbientKnown>
-LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, uint32_t i, bool lights_present, float ambient_vis) {
-  resolve_records<kAmbientKnown ? 1 : 0>(sc, in, nee, sq, results, i, lights_present, ambient_vis, load_resolve_records(in, nee, i));
-}
-
 LUM_DEV bool resolves_here(uint32_t hit_type) {  // sky, and with volumes: scattering events and ended paths have nothing to resolve
   return !(hit_type > kHitTriangleLimit && !particle_is_hit(hit_type) && hit_type != kHitOcean);
 }
@@ -914,6 +1009,15 @@ __global__ __launch_bounds__(kBlock) void k_resolve(DeviceScene sc, PathQueue in
     if (!resolves_here(in.hit_id[i].x)) continue;
     resolve_vertex<false>(sc, in, nee, sq, results, i, lights_present, 0.0f);
   }
+}
+
+// Fused resolve (FusedResolve, above k_shade): the vertices of a depth that no entry of the next depth continues - the path ended there, its ambient ray was
+// traced with the depth's visibility rays - are resolved here, after that pass; the others by the entries that continue them.
+__global__ __launch_bounds__(kBlock) void k_resolve_ended(DeviceScene sc, PathQueue in, NeeQueue nee, ShadowQueue sq, float4* results, const uint32_t* ctrl, const uint32_t* list) {
+  const uint32_t n = ctrl[kCtlSkyItems];
+  const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
+  for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < n; k += gridDim.x * kBlock)
+    resolve_vertex<false>(sc, in, nee, sq, results, list[k], lights_present, 0.0f);
 }
 
 // The resolve of a depth whose ambient samples were left to the next depth's closest-hit pass (ambient-visibility reuse, above TraceQuery): `next` is the

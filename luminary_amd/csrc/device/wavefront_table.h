@@ -24,7 +24,7 @@ struct WavefrontKernels {
                 uint32_t lds_nodes);
   void (*sky_inscattering)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*shade)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
-                uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse);
+                uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse, const FusedResolve* fused_dev, uint32_t fused_flags);  // fused_dev: device memory; flags: 1 resolve the entries' parents, 2 announce the survivors' entries
   void (*shade_debug)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl);
   void (*sky)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const ShadowQueue& sq, float4* results, const uint32_t* ctrl, uint32_t depth_const);
   void (*light_query)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, uint32_t* ctrl, uint32_t depth_const,
@@ -36,6 +36,9 @@ struct WavefrontKernels {
   void (*resolve_reuse)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& next, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
                         uint32_t* ctrl, uint64_t* counters);
   void (*resolve_listed)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl);
+  void (*resolve_ended)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl,
+                        const uint32_t* list);
+  bool fused_resolve;  // k_shade resolves the previous depth's vertices itself when asked to (FusedResolve; not in the staged-shade experiment build)
   // fog (dev_volume.h): light scattered into the rays of a depth, its summation, the scattering events and their bounce
   void (*volume_inscatter)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
                            uint32_t depth_const);

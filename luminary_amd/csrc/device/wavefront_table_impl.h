@@ -48,7 +48,7 @@ static void sky_inscattering(uint32_t grid, hipStream_t s, const DeviceScene& sc
   hipLaunchKernelGGL(k_sky_inscattering, dim3(grid), dim3(kBlock), 0, s, sc, in, results, ctrl, depth_const);
 }
 static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const PathQueue& out, const NeeQueue& nee, const ShadowQueue& sq, float4* results,
-                  uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse) {
+                  uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse, const FusedResolve* fused_dev, uint32_t fused_flags) {
 #if LUM_SHADE_STAGED
   auto* k1 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false, 1> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false, 1> : k_shade<kSkyConstantColor, false, 1>;
   auto* k2 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false, 2> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false, 2> : k_shade<kSkyConstantColor, false, 2>;
@@ -56,12 +56,12 @@ static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const Pat
     k1 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true, 1> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true, 1> : k_shade<kSkyConstantColor, true, 1>;
     k2 = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true, 2> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true, 2> : k_shade<kSkyConstantColor, true, 2>;
   }
-  hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
-  hipLaunchKernelGGL(k2, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
+  hipLaunchKernelGGL(k1, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse, fused_dev, fused_flags);
+  hipLaunchKernelGGL(k2, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse, fused_dev, fused_flags);
 #else
   auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false> : k_shade<kSkyConstantColor, false>;
   if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true> : k_shade<kSkyConstantColor, true>;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse, fused_dev, fused_flags);
 #endif
 }
 static void shade_debug(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, float4* results, const uint32_t* ctrl) {
@@ -87,6 +87,10 @@ static void resolve_reuse(uint32_t grid, hipStream_t s, const DeviceScene& sc, c
 }
 static void resolve_listed(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl) {
   hipLaunchKernelGGL(k_resolve_listed, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl);
+}
+static void resolve_ended(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const NeeQueue& nee, const ShadowQueue& sq, float4* results, const uint32_t* ctrl,
+                          const uint32_t* list) {
+  hipLaunchKernelGGL(k_resolve_ended, dim3(grid), dim3(kBlock), 0, s, sc, in, nee, sq, results, ctrl, list);
 }
 static void volume_inscatter(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PathQueue& in, const VolumeQueue& vq, const ShadowQueue& sq, uint32_t* ctrl,
                              uint32_t depth_const) {
@@ -133,7 +137,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
 }
 
 static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, init_sampler_seeds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
-                                        shade_debug,      sky,              light_query,        shadow_rays, resolve, resolve_reuse, resolve_listed, volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
+                                        shade_debug,      sky,              light_query,        shadow_rays, resolve, resolve_reuse, resolve_listed, resolve_ended, LUM_FAST && !LUM_SHADE_STAGED, volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
 
 }  // namespace table
 LUM_NS_END

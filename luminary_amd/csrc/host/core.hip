@@ -55,6 +55,13 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
+  int fused_resolve = 1;          // with the fast flavour's ambient reuse: k_shade resolves the previous depth's vertices itself (lumc_set_fused_resolve; LUM_FUSED_RESOLVE)
+  void* fused_block = nullptr;    // what that needs beyond the usual work buffers: a third path queue, the parent words, a second set of NEE records, the fallback rays' items
+  uint32_t fused_capacity = 0, fused_refused_capacity = 0;  // (the capacity its allocation last failed for: not tried again)
+  uint32_t* d_ended = nullptr;      // a depth's vertices that no entry continues (k_shade lists them, k_resolve_ended resolves them)
+  FusedResolve* d_fused = nullptr;  // six records in device memory: the previous depth's queue (three buffers) and NEE records (two) by depth % 6
+  NeeQueue nee2{};
+  ShadowQueue fallback{};
   int bvh_builder = 3;            // 0 binned SAH on the host, 1 LBVH on the GPU, 2 PLOC on the GPU, 3 binned SAH on the GPU (default since round 4: the host builder's trees in a fifth of its time; a mesh it cannot take falls back to 0) (lumc_set_bvh_builder)
   bool top_order_by_area = false; // which nodes count as the top of the tree (staged in LDS): breadth first, or best first by box area (LUM_TOP_ORDER=area; measured: mixed)
   double bvh_build_seconds = 0.0; // bottom-level builds of the last lumc_scene_upload
@@ -72,7 +79,7 @@ struct LumContext {
   // work buffers (sized for capacity paths)
   uint32_t capacity = 0;
   void* work_block = nullptr;
-  PathQueue queue[2]{};
+  PathQueue queue[3]{};           // [2]: only with the fused resolve (ensure_fused)
   NeeQueue nee{};
   ShadowQueue shadow{};
   uint32_t particle_lds_nodes = 0;
@@ -263,6 +270,10 @@ void free_adaptive(LumContext* ctx) {
 void free_work(LumContext* ctx) {
   if (ctx->work_block) (void) hipFree(ctx->work_block);
   ctx->work_block = nullptr;
+  if (ctx->fused_block) (void) hipFree(ctx->fused_block);
+  ctx->fused_block = nullptr; ctx->fused_capacity = 0; ctx->d_fused = nullptr;
+  ctx->queue[2] = PathQueue{}; ctx->nee2 = NeeQueue{}; ctx->fallback = ShadowQueue{};
+  for (int k = 0; k < 3; k++) ctx->queue[k].parent = nullptr;
   ctx->capacity = 0;
   ctx->work_shadow_kinds = 0;
   ctx->cloud = CloudQueue{};
@@ -331,6 +342,45 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
   }
   ctx->work_shadow_kinds = kinds;
   ctx->capacity = paths;
+  return 0;
+}
+
+// The fused resolve's own buffers (FusedResolve, kernels.h), sized like the work buffers: per path a third queue entry (68 B), three parent words, a second
+// set of NEE records (84 B) and one fallback ray (48 B + its vertex's index).
+int ensure_fused(LumContext* ctx) {
+  if (ctx->fused_block && ctx->fused_capacity == ctx->capacity) return 0;
+  if (ctx->fused_refused_capacity == ctx->capacity) return 1;
+  if (ctx->fused_block) (void) hipFree(ctx->fused_block);
+  ctx->fused_block = nullptr; ctx->fused_capacity = 0;
+  const size_t n = ctx->capacity;
+  const size_t bytes = n * (68 + 3 * 4 + 84 + 48 + 4 + 4) + 26 * 256 + 6 * sizeof(FusedResolve);
+  if (hipMalloc(&ctx->fused_block, bytes) != hipSuccess) { ctx->fused_block = nullptr; ctx->fused_refused_capacity = ctx->capacity; return 1; }
+  char* p = (char*) ctx->fused_block;
+  auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };
+  PathQueue& q = ctx->queue[2];
+  q.origin_t = (float4*) take(n * 16); q.dir_slot = (float4*) take(n * 16); q.aux = (uint4*) take(n * 16); q.hit_id = (uint4*) take(n * 16);
+  q.hit_scene_tri = (uint32_t*) take(n * 4);
+  for (int k = 0; k < 3; k++) ctx->queue[k].parent = (uint32_t*) take(n * 4);
+  NeeQueue& e = ctx->nee2;
+  e = NeeQueue{};
+  e.geo_color_light = (float4*) take(n * 16); e.bsdf_ray_prob = (float4*) take(n * 16); e.bsdf_weight_sum = (float4*) take(n * 16);
+  e.ambient = (uint4*) take(n * 16); e.sun = (uint4*) take(n * 16); e.amb_path = (uint32_t*) take(n * 4);
+  ShadowQueue& f = ctx->fallback;
+  f.origin_dist = (float4*) take(n * 16); f.dir_out = (float4*) take(n * 16); f.ids = (uint4*) take(n * 16);
+  f.light_items = (uint32_t*) take(n * 4);
+  f.vis = ctx->shadow.vis;  // the undecided samples' answers go where the depth's own ambient answers went: kind 2 of the previous depth's words
+  f.capacity = ctx->shadow.capacity;
+  ctx->d_ended = (uint32_t*) take(n * 4);
+  ctx->d_fused = (FusedResolve*) take(6 * sizeof(FusedResolve));
+  FusedResolve by_depth[6];
+  for (int d = 0; d < 6; d++) {  // depth d is shaded from queue d % 3 with the records d & 1: the depth before it lives in queue (d + 2) % 3 and the other record set
+    by_depth[d].prev = ctx->queue[(d + 2) % 3];
+    by_depth[d].nee_prev = (d & 1) ? ctx->nee : ctx->nee2;
+    by_depth[d].fallback = ctx->fallback;
+    by_depth[d].ended = ctx->d_ended;
+  }
+  HIP_TRY(ctx, hipMemcpy(ctx->d_fused, by_depth, sizeof(by_depth), hipMemcpyHostToDevice));
+  ctx->fused_capacity = ctx->capacity;
   return 0;
 }
 
@@ -548,6 +598,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_SYNC_DEBUG")) ctx->sync_debug = atoi(e) != 0;
   if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
   if (const char* e = getenv("LUM_AMBIENT_REUSE")) ctx->ambient_reuse = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("LUM_FUSED_RESOLVE")) ctx->fused_resolve = atoi(e) != 0 ? 1 : 0;
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -1791,6 +1842,16 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   // pass of depth d + 1, which is followed by a second, small visibility pass (what the closest hit could not decide) and only then by the resolve of
   // depth d - still before k_shade of depth d + 1 touches the result slots, so the order of the sums is the usual one.
   const bool reuse = ambient_reuse_active(ctx);
+  // Fused resolve (FusedResolve, kernels.h): with the fast flavour's reuse the resolve of depth d is done by k_shade of depth d + 1 for the vertices an entry
+  // continues, by k_resolve_ended for the others; the queues rotate through three buffers and the NEE records through two, so that depth d is intact while
+  // depth d + 1 is shaded. The exact flavour's (provable) reuse keeps its own kernel: its sums must land in the reference's order.
+  bool fused = reuse && wf.fused_resolve && ctx->fused_resolve != 0 && ctx->wf == wavefront_kernels_fast() && max_depth > 0;
+  if (fused && ensure_fused(ctx)) {  // no room for its buffers (a third of the work buffers again): the separate resolve kernel does the same sums
+    (void) hipGetLastError();
+    ctx->error.clear();
+    fused = false;
+  }
+  // (cur == depth % 3 and the record set == depth & 1 below: what the six device records assume)
   bool resolve_pending = false;  // the previous depth's resolve waits for this depth's closest-hit pass
   for (uint32_t depth = 0; depth <= max_depth; depth++) {
     // the sampler's depth constant is not advanced before the last pass (device_renderer.c:126-130)
@@ -1815,6 +1876,9 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_TRACE);
       wf.trace(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->queue[cur], order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
+    const int next_q = fused ? (cur + 1) % 3 : (cur ^ 1), prev_q = fused ? (cur + 2) % 3 : (cur ^ 1);
+    NeeQueue& nee = (fused && (depth & 1u)) ? ctx->nee2 : ctx->nee;
+    NeeQueue& nee_before = (fused && (depth & 1u)) ? ctx->nee : ctx->nee2;
     if (resolve_pending) {  // the previous depth's resolve: ambient samples answered by the pass above; what it cannot answer is traced (the control words of the fog's visibility pass: no fog here) and resolved after
       uint32_t* prev = ctrl - kCtlStride;
       {
@@ -1861,8 +1925,16 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
-               (reuse && depth < max_depth) ? 1u : 0u);
+      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[next_q], nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
+               (reuse && depth < max_depth) ? 1u : 0u, fused ? ctx->d_fused + depth % 6u : nullptr, fused ? ((depth > 0 ? 1u : 0u) | (depth < max_depth ? 2u : 0u)) : 0u);
+    }
+    if (fused && depth > 0) {  // the samples of depth - 1 their paths' closest hits could not decide: traced now, their vertices resolved (before this depth's visibility pass reuses the words)
+      {
+        Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
+        wf.shadow_rays(ctx->trace_blocks, lds_dyn, stream, sc, ctx->fallback, nullptr, ctrl + kCtlVolumeShift, ctx->d_counters, ctx->lds_nodes);
+      }
+      Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+      wf.resolve_listed(std::min<uint32_t>(grid_for(N), 1024u), stream, sc, ctx->queue[prev_q], nee_before, ctx->fallback, ctx->d_results, (const uint32_t*) ctrl);
     }
     if (sc.particles_active) {  // device_renderer.c:99-103
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
@@ -1878,7 +1950,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
-      wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
+      wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
     }
     const uint32_t* shadow_order = nullptr;
     if (ctx->sort_mode == 2) {
@@ -1890,16 +1962,20 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
       Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
       wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, shadow_order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
-    if (reuse && depth < max_depth) resolve_pending = true;
+    if (fused && depth < max_depth) {  // the vertices no entry of the next depth continues; the others are resolved by those entries, in k_shade
+      Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+      wf.resolve_ended(std::min<uint32_t>(grid_for(N), 4096u), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, ctx->d_ended);
+    }
+    else if (reuse && depth < max_depth) resolve_pending = true;
     else {
       Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
-      wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], ctx->nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
+      wf.resolve(grid_for(N), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl);
     }
     if (render_volumes && depth != max_depth) {  // device_renderer.c:114-118
       Launch l(ctx, stream, LUMC_KERNEL_VOLUME);
       wf.volume_bounce(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[cur ^ 1], ctx->volume, ctrl, depth_const);
     }
-    cur ^= 1;
+    cur = next_q;
   }
   return 0;
 }
@@ -3008,6 +3084,11 @@ int lumc_get_ray_sorting(const LumContext* ctx) { return ctx ? ctx->sort_mode : 
 int lumc_set_flavour(LumContext* ctx, int flavour) {
   if (!ctx || flavour < 0 || flavour > 1) { if (ctx) ctx->error = "lumc_set_flavour: 0 (exact) or 1 (fast)"; return 1; }
   ctx->wf = flavour == LUMC_FLAVOUR_FAST ? wavefront_kernels_fast() : wavefront_kernels_exact();
+  return 0;
+}
+int lumc_set_fused_resolve(LumContext* ctx, int on) {
+  if (!ctx) return 1;
+  ctx->fused_resolve = on != 0 ? 1 : 0;
   return 0;
 }
 int lumc_set_ambient_reuse(LumContext* ctx, int mode) {
