@@ -153,6 +153,44 @@ def test_the_fused_resolve_gives_the_separate_kernels_sums(name, tmp_path):
 
 
 @pytest.mark.gpu
+def test_the_fused_resolve_over_depths_pixel_subsets_and_growing_passes(tmp_path):
+    """The fused resolve's buffers follow the work buffers (a larger pass reallocates both), its queue rotation any maximum depth (0: nothing to fuse; 1: one
+    fused depth; 7), and a pixel subset renders what the full frame renders for those pixels - each time the separate kernels' image, bit for bit (an opaque
+    scene: no undecided samples)."""
+    def host_with_depth(depth):
+        host = scenes.cornell_host(str(tmp_path / ("d%d" % depth)), 64, 48, depth)
+        sky = host.get_sky()
+        sky.constant_color.r, sky.constant_color.g, sky.constant_color.b = 0.5, 0.6, 0.8
+        host.set_sky(sky)
+        return host
+
+    for depth in (0, 1, 2, 7):
+        view = oracle_lib.with_luts(host_with_depth(depth).device_scene())
+        core = Core(0)
+        try:
+            core.set_flavour("fast")
+            core.upload(view)
+            images = {}
+            for fused in (False, True):
+                core.set_fused_resolve(fused)
+                frames = []
+                for pixels, spp, batch in ((np.arange(5, 64 * 48, 7, dtype=np.uint32), 3, 1), (None, 4, 2), (None, 16, 16), (np.arange(0, 64 * 48, 2, dtype=np.uint32), 6, 3)):
+                    core.set_pixels(pixels)   # the third render is the largest pass so far: the buffers grow between renders
+                    core.reset_counters()
+                    core.render(0, spp, samples_per_pass=batch)
+                    frames.append((core.accumulators()[0].copy(), list(core.counters())))
+                images[fused] = frames
+        finally:
+            core.close()
+        for (fm0, c0), (fm1, c1) in zip(images[False], images[True]):
+            assert c0 == c1, "depth %d" % depth
+            assert c1[CNT_AMBIENT_FALLBACK] == 0
+            assert np.array_equal(fm0, fm1), "depth %d" % depth
+        full, sub = images[True][1][0], images[True][0][0]
+        assert full.shape[1] == 64 * 48 and sub.shape[1] == len(range(5, 64 * 48, 7))
+
+
+@pytest.mark.gpu
 def test_default_by_flavour_and_scene(tmp_path):
     """fast: on for plain scenes; off with fog / under the procedural sky / with ray sorting; exact: off unless asked for."""
     from luminary_amd import SKY_MODE_DEFAULT
