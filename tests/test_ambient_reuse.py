@@ -249,3 +249,37 @@ def test_fast_flavour_with_and_without_reuse(tmp_path):
         assert c1[CNT_SHADOW] + c1[CNT_AMBIENT_DEFERRED] - c1[CNT_AMBIENT_FALLBACK] == c0[CNT_SHADOW]
         differing = int((np.abs(fm1 - fm0).max(axis=0) > 0).sum())
         assert differing <= max(4, fm0.shape[1] // 500), "%d of %d pixels differ (hdri=%s)" % (differing, fm0.shape[1], hdri)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_the_fused_resolve_behind_the_host_api_tiled_and_adaptive(tmp_path, monkeypatch, adaptive):
+    """The same comparison one level up: the unchanged host API in the fast flavour (what a Luminary user gets), the frame tiled over three device slots, uniform
+    and adaptive sampling - LUM_FUSED_RESOLVE=1 (default) against 0, identical images and ray counters (an opaque scene: no undecided samples)."""
+    monkeypatch.setenv("LUM_FLAVOUR", "fast")
+    monkeypatch.setenv("LUM_FAKE_DEVICES", "3")
+    monkeypatch.setenv("LUM_MAX_DEVICES", "8")
+
+    def render(tag, fused):
+        monkeypatch.setenv("LUM_FUSED_RESOLVE", "1" if fused else "0")
+        host = scenes.cornell_host(str(tmp_path / tag), 96, 80, 4)
+        sky = host.get_sky()
+        sky.constant_color.r, sky.constant_color.g, sky.constant_color.b = 0.5, 0.6, 0.8
+        host.set_sky(sky)
+        if adaptive:
+            s = host.get_settings()
+            s.enable_adaptive_sampling = True
+            s.adaptive_sampling_max_sampling_rate, s.adaptive_sampling_avg_sampling_rate, s.adaptive_sampling_update_interval = 8, 2, 2
+            host.set_settings(s)
+        assert host.get_device_count() == 3
+        host.set_output_properties(96, 80)
+        host.render(6)
+        fm, sm = host.accumulators()
+        img, n, _ = host.get_image(host.acquire_output())
+        out = (fm.copy(), sm.copy(), img.copy(), n, list(host.ray_counters()[:4]))
+        host.close()
+        return out
+
+    a, b = render("separate", False), render("fused", True)
+    assert a[3] == b[3] and a[4] == b[4]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
