@@ -182,10 +182,10 @@ def test_the_contexts_of_a_process_share_a_meshs_tree(monkeypatch):
     moved = scenes.hall_scene(160, 90, 3, target_triangles=200_000).device_scene()
     ctypes.cast(moved.vertices, ctypes.POINTER(ctypes.c_float))[5] += 0.25  # one coordinate of one triangle: another mesh
     third, t_third, _, _, _ = upload(moved)
-    assert t_third > 0.5 * t_first, "a different mesh was served from the cache (%.3f s against %.3f s)" % (t_third, t_first)
+    assert t_third > 4.0 * t_second, "a different mesh was served from the cache (%.3f s; a taken tree costs %.3f s, a build %.3f s)" % (t_third, t_second, t_first)
     for c in (first, second, third):
         c.close()
     again, t_again, nodes_again, frame_again, _ = upload(view)
-    assert t_again > 0.5 * t_first, "the tree outlived its contexts (%.3f s against %.3f s)" % (t_again, t_first)
+    assert t_again > 4.0 * t_second, "the tree outlived its contexts (%.3f s; a taken tree costs %.3f s, a build %.3f s)" % (t_again, t_second, t_first)  # (the first build also warms the builder's threads: builds differ by 2 x)
     assert nodes_again == nodes_first and np.array_equal(frame_again, frame_first)
     again.close()
