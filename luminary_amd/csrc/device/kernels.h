@@ -33,10 +33,10 @@ constexpr int kBlock = 256;
 #define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
 #endif
 #ifndef LUM_SHADE_WAVES
-#define LUM_SHADE_WAVES 2  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves)
+#define LUM_SHADE_WAVES 3  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves); round 4: 3 for every sky mode, ocean and flavour (2 before: procedural sky -3.6 % / -10 % of the kernel's time fast / exact, ocean scenes -6 %)
 #endif
-// The constant-colour-sky instantiation of the fast flavour is compiled for 3 waves per SIMD: 168 VGPRs with 25 of them spilled to scratch
-// still runs 4 % faster than 196 VGPRs at 2 waves (hall 154.3 -> 148.0 ms per 3 steps); the instantiations with sun sampling would spill 56-63.
+// (Round 2 compiled only the fast flavour's constant-colour-sky instantiation for 3 waves - the instantiations with sun sampling then spilled 56-63 registers.
+// The kernel has shrunk since: now they spill 26-30, 73-112 with an ocean, and every instantiation is faster at 3 waves; profiles/r04_ab_experiments.txt.)
 #ifndef LUM_CLOUD_WAVES
 #define LUM_CLOUD_WAVES 4  // k_clouds: waves per SIMD it is compiled for (2 / 3 / 4 measured: 1602 / 1369 / 1283 ms, profiles/r02_ab_experiments.txt)
 #endif
@@ -50,7 +50,7 @@ constexpr int kBlock = 256;
 #define LUM_FEATURE_WAVES 3  // the shading kernels of particles, ocean surface and volumes (without a bound k_particle_shade took 266 registers: one wave per SIMD)
 #endif
 #ifndef LUM_SHADE_WAVES_CONSTANT_SKY
-#define LUM_SHADE_WAVES_CONSTANT_SKY (LUM_FAST ? 3 : LUM_SHADE_WAVES)
+#define LUM_SHADE_WAVES_CONSTANT_SKY 3  // both flavours (round 4: the exact flavour's kernel at 3 waves - 168 registers, 8 spilled - instead of 2: -11.5 % of its time, +6 % samples/s)
 #endif
 
 LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
