@@ -31,15 +31,11 @@
 
 LUM_NS_BEGIN
 
-#ifndef LUM_TRACE_BLOCK_FAST
-#define LUM_TRACE_BLOCK_FAST 1024  // the fast flavour's ray kernels need 128 VGPRs: 4 waves per SIMD in one 1024-thread workgroup per CU (measured against 768: visibility kernel -16 %, closest-hit kernel -9 % on the hall)
-#endif
-#if LUM_FAST && !defined(LUM_TRACE_BLOCK)
-#define LUM_TRACE_BLOCK LUM_TRACE_BLOCK_FAST
-#endif
 #ifndef LUM_TRACE_BLOCK
-#define LUM_TRACE_BLOCK 768  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 3 waves per SIMD: one LDS copy of the
-                             // tree top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower)
+#define LUM_TRACE_BLOCK 1024  // threads per workgroup of the persistent ray kernels = one workgroup per CU at 4 waves per SIMD (128 VGPRs): one LDS copy of the tree
+                              // top per CU and room for the lanes' traversal stacks (256 x 3 copies measured 1-2 % slower, 512 13 % slower). Fast flavour against 768
+                              // threads / 3 waves: visibility kernel -16 %, closest-hit kernel -9 % (round 2); the exact flavour, which kept 768 until round 4:
+                              // -12 % / -14 % (140 -> 128 VGPRs, 13 spilled), +6.5 % samples/s
 #endif
 constexpr int kTraceBlock = LUM_TRACE_BLOCK;
 
