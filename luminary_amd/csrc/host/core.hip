@@ -1413,11 +1413,11 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, ctx->device));
     size_t lds_bytes = prop.maxSharedMemoryPerMultiProcessor ? prop.maxSharedMemoryPerMultiProcessor : prop.sharedMemPerBlock;
-    // the ray kernels need ~160 VGPRs: 3 waves per SIMD = 12 waves per CU = one workgroup of kTraceBlock = 768 threads
+    // the ray kernels are compiled for 128 VGPRs: 4 waves per SIMD = 16 waves per CU = one workgroup of kTraceBlock = 1024 threads (both flavours since round 4)
 #ifndef LUM_TRACE_BLOCKS_PER_CU
 #define LUM_TRACE_BLOCKS_PER_CU 1  // experiment: more, smaller workgroups per CU (each with its own, smaller LDS copy of the tree top)
 #endif
-    const int blocks_per_cu = LUM_TRACE_BLOCKS_PER_CU;  // both flavours launch one workgroup of 768 (3 waves per SIMD) or 1024 (4) threads per CU
+    const int blocks_per_cu = LUM_TRACE_BLOCKS_PER_CU;  // one workgroup of kTraceBlock threads per CU
     lds_bytes = std::min<size_t>(lds_bytes, 160 * 1024) / blocks_per_cu;
     lds_bytes = lds_bytes > 16384 ? lds_bytes - 8192 : 0;  // margin: the ray kernels' static LDS (the prefetch experiment's sink) and the runtime's own
     lds_bytes = lds_bytes > LUM_LDS_STACK_BYTES ? lds_bytes - LUM_LDS_STACK_BYTES : 0;  // the stacks' share (dev_trace.h, TraversalStack)
