@@ -49,6 +49,9 @@ constexpr int kBlock = 256;
 #ifndef LUM_FEATURE_WAVES
 #define LUM_FEATURE_WAVES 3  // the shading kernels of particles, ocean surface and volumes (without a bound k_particle_shade took 266 registers: one wave per SIMD)
 #endif
+#ifndef LUM_VOLUME_WAVES
+#define LUM_VOLUME_WAVES 4  // k_volume_inscatter (round 4: 128 VGPRs with 67 spilled beat 168 with 21: the fog's kernels -5 %, a fogged scene +3 % samples/s; the ocean's kernels indifferent)
+#endif
 #ifndef LUM_SHADE_WAVES_CONSTANT_SKY
 #define LUM_SHADE_WAVES_CONSTANT_SKY 3  // both flavours (round 4: the exact flavour's kernel at 3 waves - 168 registers, 8 spilled - instead of 2: -11.5 % of its time, +6 % samples/s)
 #endif
@@ -1799,7 +1802,7 @@ __global__ __launch_bounds__(256) void k_sky_hdri(DeviceScene sc, float ox, floa
 // volume_process_inscattering (volume.cuh:31-98): what the fog scatters into the ray between its origin and its end point (the hit, or infinity
 // for a ray that left the scene): a bridge to a sampled emissive triangle on delta paths, the sun and the ambient sample from a vertex on the
 // ray. The visibility rays go through the ShadowQueue (17 kinds per path), k_volume_resolve sums up (optix_kernel_shadow_volume.cu:13-98).
-__global__ __launch_bounds__(kBlock, LUM_FEATURE_WAVES) void k_volume_inscatter(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
+__global__ __launch_bounds__(kBlock, LUM_VOLUME_WAVES) void k_volume_inscatter(DeviceScene sc, PathQueue in, VolumeQueue vq, ShadowQueue sq, uint32_t* ctrl, uint32_t depth_const) {
   const uint32_t n = ctrl[kCtlPaths];
   const uint32_t lane = threadIdx.x & 63;
   const unsigned long long below = (1ull << lane) - 1ull;
