@@ -55,6 +55,7 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
+  uint32_t shade_grid_rounds = 8;  // k_shade's grid as a multiple of its resident set (0: the common 2048-workgroup cap); LUM_SHADE_GRID
   int fused_resolve = 1;          // with the fast flavour's ambient reuse: k_shade resolves the previous depth's vertices itself (lumc_set_fused_resolve; LUM_FUSED_RESOLVE)
   void* fused_block = nullptr;    // what that needs beyond the usual work buffers: a third path queue, the parent words, a second set of NEE records, the fallback rays' items
   uint32_t fused_capacity = 0, fused_refused_capacity = 0;  // (the capacity its allocation last failed for: not tried again)
@@ -391,6 +392,18 @@ inline uint32_t grid_for(uint32_t n) {
   return blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);  // 256 CUs x 8 resident blocks, grid-stride beyond that
 }
 
+// k_shade: its workgroups are grid-stride loops of equal length, three of them resident per CU (3 waves per SIMD). With the common cap of 2048 workgroups that
+// was 2.67 rounds of the 768 resident places, paid as 3; the grid is now a whole number of rounds, and eight of them: the shorter a workgroup, the shorter the
+// kernel's tail (hall, k_shade per 3 steps: 2048 workgroups 380 ms | 1 round 399 | 2: 383 | 3: 376 | 4: 372 | 6: 369 | 8: 368 | 12: 366 | 24: 371; the Example-class
+// scene is best at 6-8). LUM_SHADE_GRID=<rounds> (0: the 2048 cap).
+inline uint32_t shade_grid(const LumContext* ctx, uint32_t n) {
+  const uint32_t blocks = (n + kBlock - 1) / kBlock;
+  const uint32_t resident = ctx->trace_blocks * 3u;  // trace_blocks = the device's CUs (one persistent ray workgroup each)
+  const uint32_t rounds = ctx->shade_grid_rounds;
+  const uint32_t cap = rounds ? resident * rounds : 2048u;
+  return blocks < 1 ? 1 : std::min(blocks, cap);
+}
+
 // Persistent ray kernels: one workgroup per CU (kTraceBlock threads, its own LDS copy of the tree top); waves pull work from a cursor.
 inline uint32_t grid_persistent(const LumContext* ctx, uint32_t n) {
   const uint32_t tb = ctx->wf->trace_block;
@@ -599,6 +612,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_SORT_KEY")) ctx->sort_key = atoi(e);
   if (const char* e = getenv("LUM_AMBIENT_REUSE")) ctx->ambient_reuse = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("LUM_FUSED_RESOLVE")) ctx->fused_resolve = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("LUM_SHADE_GRID")) ctx->shade_grid_rounds = (uint32_t) atoi(e);
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -1925,7 +1939,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
-      wf.shade(grid_for(N), stream, sc, ctx->queue[cur], ctx->queue[next_q], nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
+      wf.shade(shade_grid(ctx, N), stream, sc, ctx->queue[cur], ctx->queue[next_q], nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
                (reuse && depth < max_depth) ? 1u : 0u, fused ? ctx->d_fused + depth % 6u : nullptr, fused ? ((depth > 0 ? 1u : 0u) | (depth < max_depth ? 2u : 0u)) : 0u);
     }
     if (fused && depth > 0) {  // the samples of depth - 1 their paths' closest hits could not decide: traced now, their vertices resolved (before this depth's visibility pass reuses the words)
