@@ -1964,7 +1964,9 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
     }
     {
       Launch l(ctx, stream, LUMC_KERNEL_LIGHT_QUERY);
-      wf.light_query(grid_for(N), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
+      // (one resident round of its workgroups - four per CU: the kernel's workgroups are dear to start (a 1 KB stack per lane in scratch); 2 rounds, the common cap:
+      //  Example-class 4.6 -> 4.0 ms per 3 steps, scan 3.9 -> 3.6, hall equal; 4 / 8 / 16 rounds on the hall: 30.2 / 32.8 / 44.5 ms against 29.9)
+      wf.light_query(std::min<uint32_t>(grid_for(N), ctx->trace_blocks * 4u), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctrl, depth_const, ctx->d_counters);
     }
     const uint32_t* shadow_order = nullptr;
     if (ctx->sort_mode == 2) {
