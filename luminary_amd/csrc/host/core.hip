@@ -399,7 +399,8 @@ inline uint32_t grid_for(uint32_t n) {
 inline uint32_t shade_grid(const LumContext* ctx, uint32_t n) {
   const uint32_t blocks = (n + kBlock - 1) / kBlock;
   const uint32_t resident = ctx->trace_blocks * 3u;  // trace_blocks = the device's CUs (one persistent ray workgroup each)
-  const uint32_t rounds = ctx->shade_grid_rounds;
+  // (not with an ocean: k_shade<.., ocean> keeps a scratch frame and its workgroups cost more to start - Example-class scene with an ocean, 8 rounds: shade +2 %)
+  const uint32_t rounds = ctx->scene.ocean_active ? 0u : ctx->shade_grid_rounds;
   const uint32_t cap = rounds ? resident * rounds : 2048u;
   return blocks < 1 ? 1 : std::min(blocks, cap);
 }
