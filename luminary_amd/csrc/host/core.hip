@@ -58,6 +58,7 @@ struct LumContext {
   uint32_t shade_grid_rounds = 8;  // k_shade's grid as a multiple of its resident set (0: the common 2048-workgroup cap); LUM_SHADE_GRID
   int fused_resolve = 1;          // with the fast flavour's ambient reuse: k_shade resolves the previous depth's vertices itself (lumc_set_fused_resolve; LUM_FUSED_RESOLVE)
   void* fused_block = nullptr;    // what that needs beyond the usual work buffers: a third path queue, the parent words, a second set of NEE records, the fallback rays' items
+  bool fused_records_stale = false;  // a queue's planes changed places (ray-sorting mode 3) since the records were written
   uint32_t fused_capacity = 0, fused_refused_capacity = 0;  // (the capacity its allocation last failed for: not tried again)
   uint32_t* d_ended = nullptr;      // a depth's vertices that no entry continues (k_shade lists them, k_resolve_ended resolves them)
   FusedResolve* d_fused = nullptr;  // six records in device memory: the previous depth's queue (three buffers) and NEE records (two) by depth % 6
@@ -348,8 +349,21 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
 
 // The fused resolve's own buffers (FusedResolve, kernels.h), sized like the work buffers: per path a third queue entry (68 B), three parent words, a second
 // set of NEE records (84 B) and one fallback ray (48 B + its vertex's index).
+// The six records k_shade reads the previous depth through (device memory): rewritten whenever a queue's planes move.
+int upload_fused_records(LumContext* ctx) {
+  FusedResolve by_depth[6];
+  for (int d = 0; d < 6; d++) {  // depth d is shaded from queue d % 3 with the records d & 1: the depth before it lives in queue (d + 2) % 3 and the other record set
+    by_depth[d].prev = ctx->queue[(d + 2) % 3];
+    by_depth[d].nee_prev = (d & 1) ? ctx->nee : ctx->nee2;
+    by_depth[d].fallback = ctx->fallback;
+    by_depth[d].ended = ctx->d_ended;
+  }
+  HIP_TRY(ctx, hipMemcpy(ctx->d_fused, by_depth, sizeof(by_depth), hipMemcpyHostToDevice));
+  ctx->fused_records_stale = false;
+  return 0;
+}
 int ensure_fused(LumContext* ctx) {
-  if (ctx->fused_block && ctx->fused_capacity == ctx->capacity) return 0;
+  if (ctx->fused_block && ctx->fused_capacity == ctx->capacity) return ctx->fused_records_stale ? upload_fused_records(ctx) : 0;
   if (ctx->fused_refused_capacity == ctx->capacity) return 1;
   if (ctx->fused_block) (void) hipFree(ctx->fused_block);
   ctx->fused_block = nullptr; ctx->fused_capacity = 0;
@@ -373,16 +387,8 @@ int ensure_fused(LumContext* ctx) {
   f.capacity = ctx->shadow.capacity;
   ctx->d_ended = (uint32_t*) take(n * 4);
   ctx->d_fused = (FusedResolve*) take(6 * sizeof(FusedResolve));
-  FusedResolve by_depth[6];
-  for (int d = 0; d < 6; d++) {  // depth d is shaded from queue d % 3 with the records d & 1: the depth before it lives in queue (d + 2) % 3 and the other record set
-    by_depth[d].prev = ctx->queue[(d + 2) % 3];
-    by_depth[d].nee_prev = (d & 1) ? ctx->nee : ctx->nee2;
-    by_depth[d].fallback = ctx->fallback;
-    by_depth[d].ended = ctx->d_ended;
-  }
-  HIP_TRY(ctx, hipMemcpy(ctx->d_fused, by_depth, sizeof(by_depth), hipMemcpyHostToDevice));
   ctx->fused_capacity = ctx->capacity;
-  return 0;
+  return upload_fused_records(ctx);
 }
 
 constexpr uint32_t kCtrlRows = 68;  // depths 0..63, one row past the last depth, spare, lumc_trace_closest
@@ -1884,6 +1890,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
         hipLaunchKernelGGL(k_permute_queue, dim3(std::min<uint32_t>((N + 255u) / 256u, 65536u)), dim3(256), 0, stream, q, ctx->sort_queue, order, ctrl + kCtlPaths, N);
         std::swap(q.origin_t, ctx->sort_queue.origin_t); std::swap(q.dir_slot, ctx->sort_queue.dir_slot);
         std::swap(q.aux, ctx->sort_queue.aux); std::swap(q.hit_id, ctx->sort_queue.hit_id);
+        ctx->fused_records_stale = true;  // (the fused resolve does not run with ray sorting; a later pass without it must not read the old planes)
         order = nullptr;
       }
     }
