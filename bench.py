@@ -14,7 +14,7 @@ Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x108
          (weak scaling: the frame gains 32*N samples per step). Deep bounces keep few paths alive, so many sample ids share a pass to keep
          256 CUs busy: 4 / 8 / 16 / 32 ids per pass give 2610 / 2769 / 2861 / 2907 Mrays/s on the hall (profiles/r02_ab_experiments.txt).
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
-N > 1  = the frame is cut into 32x32 tiles dealt round-robin to the ranks (weak data-parallel over pixels, no collective while
+N > 1  = the frame is cut into 32x32 tiles dealt to the ranks by a lattice - tile (x, y) -> rank (x + k y) % N - (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and ONE RCCL collective at the end assembles the frame moments on rank 0: a gather of
          the ranks' own tiles behind the C ABI (lumc_frame_gather; --reduce cabi-reduce: the reduce of zero-padded full frames it replaced).
 Prints ONE JSON line on rank 0, as the LAST line of stdout, at most 4 KB (`headline`): the contract's fields, the dominant kernel's roofline, the three
@@ -63,7 +63,7 @@ IO_TRACE_BYTES = 24 + 4 + 12  # origin+dir, tmax, hit
 IO_SHADOW_BYTES = 24 + 4 + 12  # origin+dir, tmax, RGB visibility
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
-from luminary_amd.distributed import assemble_frame, tile_pixels  # noqa: E402  (numpy only at import time)
+from luminary_amd.distributed import assemble_frame, tile_lattice_step, tile_pixels  # noqa: E402  (numpy only at import time)
 
 WORKLOADS = {
     "example": "C2 Example-class scene (~100k triangles, 72 instances, 16 emissive quads)",
@@ -287,6 +287,7 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         assemble()
     torch.cuda.synchronize()
     core.synchronize()
+    local_elapsed = time.time() - t0  # this rank's own share (root: plus the frame's arrival), before it waits for the others
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -336,6 +337,17 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
         dist.all_reduce(stats, op=dist.ReduceOp.SUM)
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         elapsed = float(mx[4])
+    load_balance = None
+    if dist is not None:  # what the first scaling record needs to explain itself: the deal's balance in rays and in time (efficiency <= mean / max)
+        mine = torch.tensor([float(rays_local), local_elapsed * 1e3 / steps, float(P)], dtype=torch.float64, device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per = torch.stack(every).cpu().numpy()
+        load_balance = {"rays": {"min": float(per[:, 0].min()), "mean": float(per[:, 0].mean()), "max": float(per[:, 0].max())},
+                        "ms_per_step": {"min": float(per[:, 1].min()), "mean": float(per[:, 1].mean()), "max": float(per[:, 1].max())},
+                        "pixels": {"min": int(per[:, 2].min()), "max": int(per[:, 2].max())},
+                        "mean_over_max_rays": float(per[:, 0].mean() / max(per[:, 0].max(), 1.0)), "mean_over_max_ms": float(per[:, 1].mean() / max(per[:, 1].max(), 1e-9)),
+                        "note": "per rank, before the closing barrier; rank 0's time includes the frame's arrival"}
     rays_total = float(stats[0])
     answered = float(stats[5])  # ambient samples answered by the next closest-hit ray: visibility queries that cost no traversal (not in `value`)
     del fm, sm
@@ -413,7 +425,8 @@ def run_workload(core, name, args, rank, world, dist, steps, warmup, want_output
     out = {
         "value": rays_total / elapsed / 1e6, "unit": "Mrays/s", "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3,
         "config": {"workload": label, "width": view.width, "height": view.height, "max_ray_depth": view.max_ray_depth, "flavour": core.flavour, "lds_stack_bytes": core.lds_stack_bytes(), "source_hash": source_hash(), "ray_sorting": core.ray_sorting,
-                   "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles round-robin over ranks" if dist is not None else "single GPU",
+                   "spp_per_step": spp_step, "paths_per_gpu_per_step": P * spp_step, "partition": "32x32 image tiles, tile (x, y) -> rank (x + %d y) %% %d (lumc_tile_owner)" % (tile_lattice_step(world), world) if dist is not None else "single GPU",
+                   "load_balance": load_balance,
                    "frame_reduce": None if dist is None else (("C ABI: lumc_frame_assemble (RCCL ncclReduce of full frames)" if args.reduce == "cabi-reduce" else
                                                                "C ABI: lumc_frame_gather (RCCL ncclGather of the ranks' own tiles)") if cabi else "torch.distributed.reduce (RCCL)"),
                    "rccl_ranks": None if dist is None else (core.comm_count() if cabi else dist.get_world_size()),  # ncclCommCount of the library's own communicator

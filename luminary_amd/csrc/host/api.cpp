@@ -887,7 +887,7 @@ LuminaryResult render_samples_locked(LuminaryHost* host, const uint32_t* pixels,
   LuminaryResult r = ensure_partition_cores(host, &cores);
   if (r) return r;
   const bool all = pixels == nullptr;
-  // the whole frame is tiled over the enabled devices (32x32 tiles dealt round-robin, lumc_tile_pixels); pixel subsets stay on the main device
+  // the whole frame is tiled over the enabled devices (32x32 tiles dealt by lumc_tile_owner's lattice, lumc_tile_pixels); pixel subsets stay on the main device
   const uint32_t want_n = (all && cores.size() > 1) ? (uint32_t) cores.size() : 1u;
   bool same = (host->num_pixels != 0) && (all == host->pixels_all) && (host->partition_n == want_n);
   if (same && !all) same = (host->pixels.size() == num_pixels) && std::memcmp(host->pixels.data(), pixels, sizeof(uint32_t) * num_pixels) == 0;
@@ -1029,9 +1029,9 @@ LuminaryResult render_locked(LuminaryHost* host, uint32_t num_samples, uint32_t 
     std::vector<uint8_t> mask((size_t) blocks_x * blocks_y);
     for (uint32_t k = 0; k < n; k++) {
       if (lumc_set_pixels(cores[k], nullptr, 0) || lumc_adaptive_begin(cores[k], &ap)) return fail(cores[k]);
-      if (n > 1) {  // the blocks of tile t belong to device t % n, like the pixels of a uniform tiled render (lumc_tile_pixels)
+      if (n > 1) {  // the blocks of a tile belong to the tile's device, like the pixels of a uniform tiled render (lumc_tile_owner)
         for (uint32_t by = 0; by < blocks_y; by++)
-          for (uint32_t bx = 0; bx < blocks_x; bx++) mask[(size_t) by * blocks_x + bx] = (((by / 8) * tiles_x + bx / 8) % n == k) ? 1 : 0;
+          for (uint32_t bx = 0; bx < blocks_x; bx++) mask[(size_t) by * blocks_x + bx] = (lumc_tile_owner(bx / 8, by / 8, tiles_x, n) == k) ? 1 : 0;
         if (lumc_adaptive_set_partition(cores[k], mask.data())) return fail(cores[k]);
       }
     }

@@ -274,6 +274,7 @@ void free_work(LumContext* ctx) {
   ctx->work_block = nullptr;
   if (ctx->fused_block) (void) hipFree(ctx->fused_block);
   ctx->fused_block = nullptr; ctx->fused_capacity = 0; ctx->d_fused = nullptr;
+  ctx->fused_refused_capacity = 0;  // memory may have been freed since the refusal: the next pass asks again
   ctx->queue[2] = PathQueue{}; ctx->nee2 = NeeQueue{}; ctx->fallback = ShadowQueue{};
   for (int k = 0; k < 3; k++) ctx->queue[k].parent = nullptr;
   ctx->capacity = 0;
@@ -350,7 +351,7 @@ int ensure_work(LumContext* ctx, uint32_t paths) {
 // The fused resolve's own buffers (FusedResolve, kernels.h), sized like the work buffers: per path a third queue entry (68 B), three parent words, a second
 // set of NEE records (84 B) and one fallback ray (48 B + its vertex's index).
 // The six records k_shade reads the previous depth through (device memory): rewritten whenever a queue's planes move.
-int upload_fused_records(LumContext* ctx) {
+int upload_fused_records(LumContext* ctx, hipStream_t stream) {
   FusedResolve by_depth[6];
   for (int d = 0; d < 6; d++) {  // depth d is shaded from queue d % 3 with the records d & 1: the depth before it lives in queue (d + 2) % 3 and the other record set
     by_depth[d].prev = ctx->queue[(d + 2) % 3];
@@ -358,12 +359,13 @@ int upload_fused_records(LumContext* ctx) {
     by_depth[d].fallback = ctx->fallback;
     by_depth[d].ended = ctx->d_ended;
   }
+  HIP_TRY(ctx, hipStreamSynchronize(stream));  // a pass still reading the old records on a non-blocking stream is not ordered against the null-stream copy below
   HIP_TRY(ctx, hipMemcpy(ctx->d_fused, by_depth, sizeof(by_depth), hipMemcpyHostToDevice));
   ctx->fused_records_stale = false;
   return 0;
 }
-int ensure_fused(LumContext* ctx) {
-  if (ctx->fused_block && ctx->fused_capacity == ctx->capacity) return ctx->fused_records_stale ? upload_fused_records(ctx) : 0;
+int ensure_fused(LumContext* ctx, hipStream_t stream) {
+  if (ctx->fused_block && ctx->fused_capacity == ctx->capacity) return ctx->fused_records_stale ? upload_fused_records(ctx, stream) : 0;
   if (ctx->fused_refused_capacity == ctx->capacity) return 1;
   if (ctx->fused_block) (void) hipFree(ctx->fused_block);
   ctx->fused_block = nullptr; ctx->fused_capacity = 0;
@@ -388,7 +390,7 @@ int ensure_fused(LumContext* ctx) {
   ctx->d_ended = (uint32_t*) take(n * 4);
   ctx->d_fused = (FusedResolve*) take(6 * sizeof(FusedResolve));
   ctx->fused_capacity = ctx->capacity;
-  return upload_fused_records(ctx);
+  return upload_fused_records(ctx, stream);
 }
 
 constexpr uint32_t kCtrlRows = 68;  // depths 0..63, one row past the last depth, spare, lumc_trace_closest
@@ -1184,6 +1186,7 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
   }
   std::vector<float4> inv_rows(3 * (size_t) v->num_instances + 3);
   for (uint32_t i = 0; i < v->num_instances; i++) instance_inverse_rows(v->instance_transforms + (size_t) i * 8, &inv_rows[3 * (size_t) i]);
+  ctx->alloc_group = LumContext::kGrpInst;  // NOT the group of whatever was uploaded before: a TEXTURES / MATERIALS / LIGHTS-only update frees those groups
   if (upload(ctx, inv_rows.data(), inv_rows.size(), &sc.instance_rows)) return 1;  // by instance id: the exact flavour's ambient reuse re-tests a ray against a hit's triangle (k_resolve_reuse)
 
   std::vector<Bvh4Node> nodes;
@@ -1750,10 +1753,7 @@ int lumc_sky_hdri_build(LumContext* ctx, const float origin[3], uint32_t dim, ui
   }
   ctx->sky_hdri_key.clear();
   if (ctx->sky_hdri_dim != dim) {
-    if (ctx->d_gather_send) (void) hipFree(ctx->d_gather_send);
-  if (ctx->d_gather_recv) (void) hipFree(ctx->d_gather_recv);
-  if (ctx->d_gather_pixels) (void) hipFree(ctx->d_gather_pixels);
-  if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
+    if (ctx->d_sky_hdri) (void) hipFree(ctx->d_sky_hdri);
     ctx->d_sky_hdri = nullptr; ctx->sky_hdri_dim = 0;
     HIP_TRY(ctx, hipMalloc((void**) &ctx->d_sky_hdri, sizeof(float4) * (size_t) dim * dim));
     ctx->sky_hdri_dim = dim;
@@ -1867,7 +1867,7 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
   // continues, by k_resolve_ended for the others; the queues rotate through three buffers and the NEE records through two, so that depth d is intact while
   // depth d + 1 is shaded. The exact flavour's (provable) reuse keeps its own kernel: its sums must land in the reference's order.
   bool fused = reuse && wf.fused_resolve && ctx->fused_resolve != 0 && ctx->wf == wavefront_kernels_fast() && max_depth > 0;
-  if (fused && ensure_fused(ctx)) {  // no room for its buffers (a third of the work buffers again): the separate resolve kernel does the same sums
+  if (fused && ensure_fused(ctx, stream)) {  // no room for its buffers (a third of the work buffers again): the separate resolve kernel does the same sums
     (void) hipGetLastError();
     ctx->error.clear();
     fused = false;
@@ -2712,17 +2712,53 @@ int lumc_device_count(void) {
   return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
 }
 
-// Tile t of the row-major grid of `tile` x `tile` pixel tiles belongs to rank t % world (load balance: neighbouring tiles go to different
-// GPUs). Writes the rank's pixel indices (x + y * width) in tile order, rows within a tile; `out` may be NULL to query the count.
+// The tile deal ("block -> GPU by interleaved round-robin for load balance"). Round 5: a rank-1 lattice instead of t % world over the
+// row-major grid. The old deal is periodic in x with period `world` tiles whenever the tile row length is a multiple of `world` - at 3840 px (120 tiles)
+// and 8 ranks every rank owned vertical 32-pixel stripes. Now tile (x, y) belongs to rank (x + k * y) % world, with k chosen so that a rank's tiles form
+// the most isotropic lattice: k maximises the shortest distance between two tiles of one rank (world 8: k = 3, nearest own tiles at (2, 2) and (1, -3);
+// world 4: k = 2; world 2: the checkerboard). Every rank's share is spread over the frame at the scale of 2-3 tiles in every direction, whatever the
+// frame's width. LUM_TILE_DEAL=rowmajor restores t % world (A/B of the load-balance table, profiles/r05_load_balance.json).
+uint32_t lumc_tile_lattice_step(uint32_t world) {
+  if (world < 2) return 0;
+  uint32_t best_k = 1; int64_t best = -1;
+  for (uint32_t k = 1; k < world; k++) {
+    int64_t shortest = INT64_MAX;
+    for (int64_t b = -(int64_t) world; b <= (int64_t) world; b++)
+      for (int64_t a = -(int64_t) world; a <= (int64_t) world; a++) {
+        if ((a == 0 && b == 0) || ((a + (int64_t) k * b) % (int64_t) world) != 0) continue;
+        shortest = std::min(shortest, a * a + b * b);
+      }
+    if (shortest > best) { best = shortest; best_k = k; }
+  }
+  return best_k;
+}
+
+static bool tile_deal_rowmajor() {
+  static const bool v = [] { const char* e = std::getenv("LUM_TILE_DEAL"); return e && std::strcmp(e, "rowmajor") == 0; }();
+  return v;
+}
+
+uint32_t lumc_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t tiles_x, uint32_t world) {
+  if (world < 2) return 0;
+  if (tile_deal_rowmajor()) return (uint32_t) (((uint64_t) tile_y * tiles_x + tile_x) % world);
+  static uint32_t step_of[65] = {0};  // (0 = not computed yet; a step is >= 1)
+  uint32_t k = world <= 64 ? step_of[world] : 0;
+  if (!k) { k = lumc_tile_lattice_step(world); if (world <= 64) step_of[world] = k; }
+  return (uint32_t) (((uint64_t) tile_x + (uint64_t) k * tile_y) % world);
+}
+
+// Writes the rank's pixel indices (x + y * width): its tiles in row-major tile order, rows within a tile; `out` may be NULL to query the count.
 int lumc_tile_pixels(uint32_t width, uint32_t height, uint32_t rank, uint32_t world, uint32_t tile, uint32_t* out, uint32_t* count) {
   if (!count || world == 0 || rank >= world || tile == 0) return 1;
   const uint32_t tx = (width + tile - 1) / tile, ty = (height + tile - 1) / tile;
   uint32_t n = 0;
-  for (uint32_t t = rank; t < tx * ty; t += world) {
-    const uint32_t x0 = (t % tx) * tile, y0 = (t / tx) * tile;
-    for (uint32_t y = y0; y < std::min(y0 + tile, height); y++)
-      for (uint32_t x = x0; x < std::min(x0 + tile, width); x++) { if (out) out[n] = x + y * width; n++; }
-  }
+  for (uint32_t j = 0; j < ty; j++)
+    for (uint32_t i = 0; i < tx; i++) {
+      if (lumc_tile_owner(i, j, tx, world) != rank) continue;
+      const uint32_t x0 = i * tile, y0 = j * tile;
+      for (uint32_t y = y0; y < std::min(y0 + tile, height); y++)
+        for (uint32_t x = x0; x < std::min(x0 + tile, width); x++) { if (out) out[n] = x + y * width; n++; }
+    }
   *count = n;
   return 0;
 }

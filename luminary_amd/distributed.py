@@ -8,16 +8,53 @@ sample is a pure function of (pixel, sample id), any partition reproduces the si
 import numpy as np
 
 
+def tile_lattice_step(world):
+    """The step k of the deal (== lumc_tile_lattice_step): tile (x, y) belongs to rank (x + k*y) % world; k maximises the shortest distance
+    between two tiles of one rank (ties: the smallest k), so a rank's tiles form the most isotropic lattice (8 ranks: k = 3)."""
+    if world < 2:
+        return 0
+    best_k, best = 1, -1
+    r = np.arange(-world, world + 1)
+    a, b = np.meshgrid(r, r, indexing="xy")
+    d2 = a * a + b * b
+    for k in range(1, world):
+        ok = ((a + k * b) % world == 0) & (d2 > 0)
+        shortest = int(d2[ok].min())
+        if shortest > best:
+            best, best_k = shortest, k
+    return best_k
+
+
+def tile_owner(tile_x, tile_y, tiles_x, world):
+    """Rank of tile (tile_x, tile_y) (arrays or ints) == lumc_tile_owner. LUM_TILE_DEAL=rowmajor: round 1-4's t % world (for A/B only)."""
+    import os
+    if world < 2:
+        return np.zeros_like(np.asarray(tile_x) + np.asarray(tile_y))
+    if os.environ.get("LUM_TILE_DEAL") == "rowmajor":
+        return (np.asarray(tile_y, dtype=np.int64) * tiles_x + tile_x) % world
+    return (np.asarray(tile_x, dtype=np.int64) + tile_lattice_step(world) * np.asarray(tile_y, dtype=np.int64)) % world
+
+
 def tile_pixels(width, height, rank, world, tile=32):
-    """Pixel indices (x + y*width) owned by `rank`: tile t of the row-major tile grid belongs to rank t % world."""
+    """Pixel indices (x + y*width) owned by `rank`: its tiles (tile_owner) in row-major tile order, rows within a tile."""
     tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
     ids = np.arange(tx * ty)
-    mine = ids[ids % world == rank]
+    mine = ids[tile_owner(ids % tx, ids // tx, tx, world) == rank]
     ys, xs = np.meshgrid(np.arange(tile), np.arange(tile), indexing="ij")
     px = (mine % tx)[:, None, None] * tile + xs[None]
     py = (mine // tx)[:, None, None] * tile + ys[None]
     ok = (px < width) & (py < height)
     return (px + py * width)[ok].astype(np.uint32)
+
+
+def tile_share_counts(width, height, world, tile=32):
+    """Pixels per rank under the deal (what every rank needs to size the gather's buffers), without building the lists."""
+    tx, ty = (width + tile - 1) // tile, (height + tile - 1) // tile
+    i, j = np.meshgrid(np.arange(tx), np.arange(ty), indexing="xy")
+    w = np.minimum((i + 1) * tile, width) - i * tile
+    h = np.minimum((j + 1) * tile, height) - j * tile
+    owner = tile_owner(i, j, tx, world)
+    return [int((w * h)[owner == r].sum()) for r in range(world)]
 
 
 def assemble_frame(first_moment, second_moment, pixels, num_frame_pixels, dist=None, dst=0):
@@ -40,10 +77,13 @@ def gather_frame(first_moment, second_moment, width, height, rank, world, dist=N
     `dst` receives the `world` buffers and scatters each through that rank's pixel list, which it derives from the deal itself. 16 bytes per OWNED pixel
     travel instead of 16 bytes per frame pixel from every rank. Returns the [4, W*H] frame on `dst`, None elsewhere."""
     import torch
-    shares = [tile_pixels(width, height, r, world, tile) for r in range(world)] if (dist is None or rank == dst) else None
-    counts = [int(s.size) for s in shares] if shares is not None else None
-    if counts is None:  # the share sizes follow from the deal alone
-        counts = [int(tile_pixels(width, height, r, world, tile).size) for r in range(world)]
+    if dist is None and world != 1:
+        raise ValueError("gather_frame: %d ranks need a process group (dist=None assembles a single rank's frame only)" % world)
+    shares = [tile_pixels(width, height, r, world, tile) for r in range(world)] if rank == dst else None
+    if shares is not None:
+        counts = [int(s.size) for s in shares]
+    else:  # the share sizes follow from the deal alone
+        counts = tile_share_counts(width, height, world, tile)
     stride = (max(counts) + 3) & ~3
     p = counts[rank]
     assert first_moment.numel() == 3 * p and second_moment.numel() == p, "this rank's accumulators are not its share of the deal"
@@ -71,8 +111,7 @@ def block_mask(width, height, rank, world, tile=32):
     bx, by = (width + 3) // 4, (height + 3) // 4
     tx = (width + tile - 1) // tile
     ys, xs = np.meshgrid(np.arange(by), np.arange(bx), indexing="ij")
-    tile_id = (xs * 4) // tile + ((ys * 4) // tile) * tx
-    return (tile_id % world == rank).astype(np.uint8).ravel()
+    return (tile_owner((xs * 4) // tile, (ys * 4) // tile, tx, world) == rank).astype(np.uint8).ravel()
 
 
 def adaptive_render(core, executions, dist=None, device=None):

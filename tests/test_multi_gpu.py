@@ -309,3 +309,99 @@ def test_tile_gather_over_three_contexts_equals_the_reduce_and_the_single_render
     assert np.array_equal(gfm, rfm) and np.array_equal(gsm, rsm), "gather == reduce"
     ofm, osm, _ = oracle_lib.render(view, 0, 2)
     assert np.array_equal(gfm, ofm) and np.array_equal(gsm, osm), "... == the frame rendered in one piece"
+
+
+def test_the_deal_is_a_lattice_and_not_column_stripes():
+    """Round 5: tile (x, y) -> rank (x + k*y) % world. Rounds 1-4 dealt t % world over the row-major grid, which at 3840 px (120 tiles per row, 120 % 8 == 0)
+    gave every rank vertical 32-pixel stripes. Under the lattice every row AND every column of tiles of C4's frame holds all 8 ranks, a rank's nearest own
+    tiles are >= 2.8 tiles away in every direction, the shares are equal to 0.5 %, and the step does not depend on the frame."""
+    from luminary_amd.distributed import tile_lattice_step, tile_owner, tile_share_counts
+    lib = luminary_amd._lib()
+    assert [tile_lattice_step(n) for n in (1, 2, 4, 8)] == [0, 1, 2, 3]
+    assert [int(lib.lumc_tile_lattice_step(n)) for n in range(1, 17)] == [tile_lattice_step(n) for n in range(1, 17)]
+    for (w, h) in ((3840, 2160), (1920, 1080)):
+        tx, ty = (w + 31) // 32, (h + 31) // 32
+        i, j = np.meshgrid(np.arange(tx), np.arange(ty), indexing="xy")
+        owner = tile_owner(i, j, tx, 8)
+        for row in owner:
+            for x0 in range(0, tx - 7):
+                assert len(set(row[x0:x0 + 8].tolist())) == 8
+        for col in owner.T:
+            for y0 in range(0, ty - 7):
+                assert len(set(col[y0:y0 + 8].tolist())) == 8
+        ys, xs = np.nonzero(owner == 5)
+        d2 = (xs[:, None] - xs[None]) ** 2 + (ys[:, None] - ys[None]) ** 2
+        assert d2[d2 > 0].min() == 8, "nearest tile of the same rank at (2, 2)"
+        counts = tile_share_counts(w, h, 8)
+        assert sum(counts) == w * h and max(counts) / (w * h / 8) < 1.005
+        assert counts == [Core.tile_pixels(w, h, r, 8).size for r in range(8)]
+
+
+def _eight_slot_host_equals_one_device(make_host, tmp_path, monkeypatch, spp):
+    frames = {}
+    for name, fake in (("one", None), ("eight", "8")):
+        if fake:
+            monkeypatch.setenv("LUM_FAKE_DEVICES", fake)
+            monkeypatch.setenv("LUM_MAX_DEVICES", "8")
+        host = make_host()
+        assert host.get_device_count() == (8 if fake else 1)
+        s = host.get_settings()
+        host.set_output_properties(s.width, s.height)
+        host.render(spp)
+        fm, sm = host.accumulators()
+        img, n, _ = host.get_image(host.acquire_output())
+        frames[name] = (fm, sm, img, n, host.ray_counters()[:4])
+        host.close()
+    a, b = frames["one"], frames["eight"]
+    assert a[3] == b[3] == spp
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), "accumulators of 8 tile shares == one device"
+    assert np.array_equal(a[2], b[2]), "ARGB8 output"
+    assert a[4] == b[4], "ray counters add up over the 8 devices"
+    assert float(a[0].max()) > 0.0
+
+
+@pytest.mark.gpu
+def test_c4_frame_over_eight_device_slots(tmp_path, monkeypatch):
+    """BASELINE config 4's frame (Example-class scene, 3840x2160, 8 bounces) through the host API with EIGHT device slots (device 0 eight times: the host's
+    partition, lumc_frame_gather_all over 8 shares by the peer-copy transport - RCCL refuses two ranks on one GPU -, the root's scatter through eight pixel
+    lists of the lattice deal): accumulators, ARGB8 and ray counters equal the one-device render bit for bit. The N-rank RCCL gather itself first runs in the
+    driver's multi-GPU bench."""
+    _eight_slot_host_equals_one_device(lambda: scenes.example_scene(3840, 2160, 8), tmp_path, monkeypatch, 2)
+
+
+@pytest.mark.gpu
+def test_c5_scan_over_eight_device_slots(tmp_path, monkeypatch):
+    """BASELINE config 5's scene (10 M-triangle scan, 1920x1080, 8 bounces) with eight device slots: eight contexts share the mesh's tree (LUM_BVH_SHARE), every
+    one holds its own replica of the scene arrays (8 x 1.1 GB of 288 GB)."""
+    _eight_slot_host_equals_one_device(lambda: scenes.scan_scene(1920, 1080, 8, triangles=10_000_000), tmp_path, monkeypatch, 2)
+
+
+@pytest.mark.gpu
+def test_an_hdri_bake_of_another_size_leaves_the_gather_buffers_alone():
+    """lumc_sky_hdri_build freed the tile gather's three device buffers when the panorama's size changed and kept their addresses -
+    the next lumc_frame_gather packed into freed memory and lumc_context_destroy freed them a second time. Gather, bake at a new size, gather, destroy."""
+    import test_sky
+    host = test_sky._scene(altitude=0.3)
+    view = test_sky._with_sky_luts(host.device_scene())
+    w, h = view.width, view.height
+    core = Core(0)
+    try:
+        core.upload(view)
+        px = Core.tile_pixels(w, h, 0, 1)
+        core.set_pixels(px)
+        core.render(0, 2, samples_per_pass=2)
+        core.comm_init_rank(1, 0, Core.comm_unique_id())
+        assert core.frame_gather(w, h, 0)
+        first = core.frame_download(w * h)
+        core.sky_hdri_build((1.0, 6.0, 28.0), 16, 4)
+        core.sky_hdri_build((1.0, 6.0, 28.0), 40, 4)   # another size: the old panorama is freed - and only the panorama
+        filler = [Core(0) for _ in range(2)]             # allocations that would land in freed blocks
+        for f in filler:
+            f.upload(view)
+        assert core.frame_gather(w, h, 0)
+        second = core.frame_download(w * h)
+        for f in filler:
+            f.close()
+    finally:
+        core.close()
+    assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])

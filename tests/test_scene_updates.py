@@ -300,3 +300,36 @@ def test_switching_adaptive_sampling_off_leaves_adaptive_mode(tmp_path):
     fa, fb = a.accumulators(), b.accumulators()
     assert np.array_equal(fa[0], fb[0]) and np.array_equal(fa[1], fb[1])
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dirty", ["textures", "materials", "lights"])
+def test_a_partial_update_keeps_the_instance_rows_of_the_exact_reuse(dirty):
+    """the per-instance inverse rows (k_resolve_reuse re-tests an ambient ray against the hit's triangle: exact flavour with
+    lumc_set_ambient_reuse(1)) were allocated in whatever group the upload had open - a TEXTURES-, MATERIALS- or LIGHTS-only update freed them and the next
+    render read freed memory. They belong to the instances' group."""
+    from luminary_amd.core import DIRTY_LIGHTS, DIRTY_MATERIALS, DIRTY_TEXTURES
+    flag = {"textures": DIRTY_TEXTURES, "materials": DIRTY_MATERIALS, "lights": DIRTY_LIGHTS}[dirty]
+    host = scenes.textured_scene(96, 64, 6)
+    view = host.device_scene()
+    core, fresh = Core(0), Core(0)
+    try:
+        for c in (core, fresh):
+            c.set_flavour("exact")
+        core.upload(view)
+        core.set_ambient_reuse(1)
+        core.set_pixels(None)
+        core.render(0, 2, samples_per_pass=2)
+        before = core.accumulators()[0]
+        core.update(view, flag)
+        core.update(view, flag)  # (twice: the freed group's blocks are handed out again)
+        core.clear()
+        core.render(0, 2, samples_per_pass=2)
+        got = core.accumulators()[0]
+        fresh.upload(view)
+        fresh.set_ambient_reuse(1)
+        fresh.set_pixels(None)
+        fresh.render(0, 2, samples_per_pass=2)
+        assert np.array_equal(got, fresh.accumulators()[0]) and np.array_equal(got, before)
+    finally:
+        core.close(); fresh.close(); host.close()
