@@ -372,6 +372,9 @@ LUMINARY_API LuminaryResult luminary_ext_get_log(const char** text, size_t* leng
 LUMINARY_API LuminaryResult luminary_ext_add_mesh(
   LuminaryHost* host, const float* positions, const float* normals, const float* uvs, const uint16_t* material_ids, uint32_t triangle_count, uint32_t* mesh_id);
 LUMINARY_API LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id);
+/* The host-level mesh back (borrowed pointers into the host's store, valid until the mesh list changes): what an independent encoder starts from. */
+LUMINARY_API LuminaryResult luminary_ext_get_mesh(LuminaryHost* host, uint32_t mesh_id, const float** positions, const float** normals, const float** uvs,
+                                                  const uint16_t** material_ids, uint32_t* triangle_count);
 /* Converts the current scene to the device format (device_structs.c conversions + light tree build). The view and everything it points
  * to stay valid until the next call or host destruction. Needs no GPU. */
 /* Whether replacing `old` by `input` restarts the integration (camera.c:80-147, settings.c:45-72) or only changes the outputs.

@@ -454,6 +454,18 @@ class Host:
               C.c_uint32(n), C.byref(mid))
         return mid.value
 
+    def get_mesh(self, mesh_id):
+        """luminary_ext_get_mesh: the host-level mesh (copies): positions [n, 9], normals [n, 9], uvs [n, 6], material ids [n]."""
+        import numpy as np
+        p, nrm, uv, mat = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.POINTER(C.c_uint16)()
+        n = C.c_uint32()
+        _call("luminary_ext_get_mesh", self._h, C.c_uint32(mesh_id), C.byref(p), C.byref(nrm), C.byref(uv), C.byref(mat), C.byref(n))
+        n = n.value
+        if n == 0:
+            return np.zeros((0, 9), np.float32), np.zeros((0, 9), np.float32), np.zeros((0, 6), np.float32), np.zeros(0, np.uint16)
+        return (np.ctypeslib.as_array(p, shape=(n, 9)).copy(), np.ctypeslib.as_array(nrm, shape=(n, 9)).copy(), np.ctypeslib.as_array(uv, shape=(n, 6)).copy(),
+                np.ctypeslib.as_array(mat, shape=(n,)).copy())
+
     def add_texture(self, rgba8, gamma=1.0):
         """rgba8: uint8 array [height, width, 4]; returns the texture id for Material.albedo_tex / roughness_tex / normal_tex."""
         import numpy as np

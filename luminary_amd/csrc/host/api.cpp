@@ -732,6 +732,21 @@ LuminaryResult luminary_ext_add_mesh(LuminaryHost* host, const float* positions,
   invalidate(host, LUMC_DIRTY_MESHES | LUMC_DIRTY_INSTANCES | LUMC_DIRTY_LIGHTS);
   return LUMINARY_SUCCESS;
 }
+// The host-level mesh as the loaders left it (the reference's Mesh / TriangleGeomData, mesh.h:8-14): borrowed pointers, valid until the mesh list changes. What an
+// independent encoder (the test oracle's o_scene.c) starts from.
+LuminaryResult luminary_ext_get_mesh(LuminaryHost* host, uint32_t mesh_id, const float** positions, const float** normals, const float** uvs,
+                                     const uint16_t** material_ids, uint32_t* triangle_count) {
+  CHECK_NULL(host); CHECK_NULL(triangle_count);
+  ApiLock lock(host);
+  if (mesh_id >= host->scene.meshes.size()) return LUMINARY_ERROR_INVALID_API_ARGUMENT;
+  const lum::HostMesh& m = host->scene.meshes[mesh_id];
+  if (positions) *positions = m.positions.data();
+  if (normals) *normals = m.normals.data();
+  if (uvs) *uvs = m.uvs.data();
+  if (material_ids) *material_ids = m.material_ids.data();
+  *triangle_count = m.triangle_count();
+  return LUMINARY_SUCCESS;
+}
 LuminaryResult luminary_ext_add_material(LuminaryHost* host, const LuminaryMaterial* material, uint16_t* material_id) {
   CHECK_NULL(host); CHECK_NULL(material);
   ApiLock lock(host);

@@ -296,6 +296,11 @@ constexpr uint32_t kNull  = 0xFFFFFFFFu;
 
 struct Fragment {  // device_light.h LightTreeFragment
   F3 low, high, middle, v0, v1, v2;
+  // the fourth lane of v0, v1, v2 and of `middle`. The reference's vectors have four lanes and vec128_rotate_quaternion (host_intrinsics.h:221-233) scales q.w along
+  // with q.xyz, so a vertex of a ROTATED instance leaves it with w = 2 q.w dot(q.xyz, a) instead of 0; nothing clears it: the four-lane dot products of the node
+  // variance (device_light.c:538-547) add (w_k - w_mean)^2, and the light BVH's vertex buffer carries it. Found by the independent encoder oracle/o_scene.c in round 5
+  // (rounds 1-4 computed three lanes: the zoo's rotated emitters got 111 nodes instead of the reference's 109).
+  float w0 = 0.0f, w1 = 0.0f, w2 = 0.0f, wm = 0.0f;
   float power;
   uint32_t instance_id, tri_id;
 };
@@ -322,13 +327,22 @@ F3 rotate_q(F3 a, const float q[4]) {
   r = r + cr * (2.0f * q[3]);
   return r;
 }
+// ... and its fourth lane: q.w * (2 dot_qa) + a.w * (...) + cross.w * (...) with a.w = cross.w = +0, then * scale.w (1) + offset.w (0) (device_light.c:2029-2031, :2075-2077)
+float rotate_q_w(F3 a, const float q[4]) {
+  const float dqa = a.x * q[0] + a.y * q[1] + a.z * q[2], dqq = q[0] * q[0] + q[1] * q[1] + q[2] * q[2];
+  float w = q[3] * (2.0f * dqa);
+  w = w + 0.0f * (q[3] * q[3] - dqq);
+  w = w + 0.0f * (2.0f * q[3]);
+  return w * 1.0f + 0.0f;
+}
 
 void fit_bounds(const Fragment* f, uint32_t n, F3* high, F3* low) {
   F3 h = f3(-kMaxValue, -kMaxValue, -kMaxValue), l = f3(kMaxValue, kMaxValue, kMaxValue);
   for (uint32_t i = 0; i < n; i++) { h = fmax3(h, f[i].high); l = fmin3(l, f[i].low); }
   *high = h; *low = l;
 }
-inline float box_area(F3 d) { return d.x * d.y + d.x * d.z + d.y * d.z; }
+// vec128_box_area (host_intrinsics.h:208-216): the products x y, x z, y z, w w (w = 0) through vec128_hsum, i.e. (xy + yz) + (xz + 0) - the order matters in the last bit
+inline float box_area(F3 d) { return (d.x * d.y + d.y * d.z) + (d.x * d.z + 0.0f); }
 
 struct Bin { F3 high, low; int32_t entry; float power; };
 
@@ -454,19 +468,23 @@ void mean_and_variance(const std::vector<Fragment>& frags, const BinaryNode& nod
   }
   const float inv_total = 1.0f / *power;
   F3 p = f3(0.0f, 0.0f, 0.0f);
+  float pw = 0.0f;  // the mean's fourth lane (Fragment::wm)
   for (uint32_t i = 0; i < node.triangle_count; i++) {
     const Fragment& fr = frags[node.triangles_address + i];
     const float w = fr.power * inv_total;
     p = f3(std::fma(fr.middle.x, w, p.x), std::fma(fr.middle.y, w, p.y), std::fma(fr.middle.z, w, p.z));
+    pw = std::fma(fr.wm, w, pw);
   }
+  // vec128_dot = vec128_hsum of the four products: (x x + z z) + (y y + w w) (host_intrinsics.h:107-117, :201-203)
+  auto dot4 = [](F3 d, float dw) { return (d.x * d.x + d.z * d.z) + (d.y * d.y + dw * dw); };
   float var = 0.0f;
   for (uint32_t i = 0; i < node.triangle_count; i++) {
     const Fragment& fr = frags[node.triangles_address + i];
     const float w = (1.0f / 3.0f) * fr.power * inv_total;
     const F3 d0 = fr.v0 - p, d1 = fr.v1 - p, d2 = fr.v2 - p;
-    var += w * dot3(d0, d0);
-    var += w * dot3(d1, d1);
-    var += w * dot3(d2, d2);
+    var += w * dot4(d0, fr.w0 - pw);
+    var += w * dot4(d1, fr.w1 - pw);
+    var += w * dot4(d2, fr.w2 - pw);
   }
   *mean = p; *variance = var;
 }
@@ -755,12 +773,14 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
         const F3 a = rotate_q(f3(p[0], p[1], p[2]), q) * scale + offset, b = rotate_q(f3(p[3], p[4], p[5]), q) * scale + offset,
                  c = rotate_q(f3(p[6], p[7], p[8]), q) * scale + offset;
         const F3 cr = cross3(b - a, c - a);
-        const float area = 0.5f * std::sqrt(dot3(cr, cr));
+        const float area = 0.5f * std::sqrt((cr.x * cr.x + cr.z * cr.z) + (cr.y * cr.y + 0.0f));  // vec128_norm2: sqrt of vec128_hsum = (x + z) + (y + w)
         if (area == 0.0f) continue;
         Fragment f;
         f.low = fmin3(a, fmin3(b, c)); f.high = fmax3(a, fmax3(b, c));
         f.middle = (a + (b + c)) * (1.0f / 3.0f);
         f.v0 = a; f.v1 = b; f.v2 = c;
+        f.w0 = rotate_q_w(f3(p[0], p[1], p[2]), q); f.w1 = rotate_q_w(f3(p[3], p[4], p[5]), q); f.w2 = rotate_q_w(f3(p[6], p[7], p[8]), q);
+        f.wm = (f.w0 + (f.w1 + f.w2)) * (1.0f / 3.0f);
         f.power = intensity * area * average_intensity;
         f.instance_id = inst_id; f.tri_id = t;
         frags.push_back(f);
@@ -850,6 +870,7 @@ void build_light_tree(const HostScene& scene, LightTreeOutput* out) {
     out->tri_handles[2 * id] = f.instance_id; out->tri_handles[2 * id + 1] = f.tri_id;
     float* t = out->bvh_tris.data() + 12 * id;
     t[0] = f.v0.x; t[1] = f.v0.y; t[2] = f.v0.z; t[4] = f.v1.x; t[5] = f.v1.y; t[6] = f.v1.z; t[8] = f.v2.x; t[9] = f.v2.y; t[10] = f.v2.z;
+    t[3] = f.w0; t[7] = f.w1; t[11] = f.w2;  // LightTreeBVHTriangle is three Vec128: the lanes no kernel reads (vertex stride 16, optix_bvh.c:382-478) hold what the arithmetic left
   }
 }
 

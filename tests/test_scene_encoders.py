@@ -1,0 +1,164 @@
+"""The product's scene encoders and light-tree build against an INDEPENDENT second implementation (weak 1b, missing 2, next 1).
+
+luminary_ext_build_device_scene (luminary_amd/csrc/host/scene.cpp) turns the host-level scene into the bits the kernels read - 32-byte materials, vertices with
+packed normals, bf16 texture coordinates, instance transforms with 16-bit quaternions, the quantised 8-wide light tree, its handle map and the light BVH's vertex
+buffer - and BOTH the rendering oracle and the HIP path consume that output, so render parity cannot see an error in it. oracle/o_scene.c restates the same
+reference files a second time, written from the reference's text (device/device_structs.c:251-412, device/device_packing.c:6-85, device/device_light.c:118-1288,
+:1615-2265, host_math.c:6-21, host_intrinsics.h, cuda/light.cuh:191-270) and not from scene.cpp. These tests hand both the same host-level scene (meshes as the
+loaders left them, luminary_ext_get_mesh; the public API's materials and instances; the raw textures) and compare every array byte for byte.
+
+Adjudicated in round 5 (the first time the two were compared): everything agreed except for emitters of ROTATED instances. The reference's four-lane
+vec128_rotate_quaternion scales q.w too, nothing clears that lane, and its four-lane dot products carry (w - w_mean)^2 into the node variances; scene.cpp
+computed three lanes (the zoo's tree had 111 nodes, the reference's arithmetic gives 109), and summed its dot products and box areas as (a + b) + c where
+vec128_hsum sums (a + c) + (b + d). scene.cpp was wrong on both counts and follows the reference now; `test_the_w_lane...` keeps the finding alive."""
+import numpy as np
+import pytest
+
+import oracle_lib
+from luminary_amd import Host, scenes
+
+ARRAYS = ("mesh_tri_offset", "vertices", "tri_tex", "instance_mesh_ids", "instance_transforms", "materials", "light_tree_root", "light_tree_nodes",
+          "light_tri_handles", "light_bvh_tris")
+
+
+def _compare(host, name):
+    view = host.device_scene()
+    want = oracle_lib.encode_scene(host, view)
+    got = oracle_lib.view_arrays(view)
+    assert got["num_lights"] == want["num_lights"], "%s: %d lights, the independent encoder finds %d" % (name, got["num_lights"], want["num_lights"])
+    assert got["num_light_tree_nodes"] == want["num_light_tree_nodes"], "%s: light tree nodes" % name
+    for k in ARRAYS:
+        assert got[k].shape == want[k].shape, "%s: %s has %s words, expected %s" % (name, k, got[k].shape, want[k].shape)
+        if not np.array_equal(got[k], want[k]):
+            bad = np.nonzero(got[k] != want[k])[0]
+            raise AssertionError("%s: %s differs in %d of %d words, first at %d: %#x vs %#x" % (name, k, bad.size, got[k].size, bad[0], int(got[k][bad[0]]), int(want[k][bad[0]])))
+    return want
+
+
+def test_cornell_box_through_the_lum_obj_pipeline(tmp_path):
+    w = _compare(scenes.cornell_host(str(tmp_path), 64, 64, 1), "cornell")
+    assert w["num_lights"] == 2 and w["materials"].size == 16 * 6
+
+
+def test_example_class_scene_with_72_instances():
+    w = _compare(scenes.example_scene(160, 96, 3), "example")
+    assert w["instance_mesh_ids"].size >= 64 and w["num_lights"] == 32
+    assert w["light_tree_root"][10] == 4, "32 root children in 4 sections"
+
+
+def test_material_zoo_with_rotated_scaled_instances_and_an_inner_level():
+    w = _compare(scenes.zoo_scene(96, 64, 8), "zoo")
+    assert w["num_lights"] == 320 and w["num_light_tree_nodes"] > 0, "more lights than the root's 128 children: inner 64-byte nodes exist"
+    assert w["light_tree_root"][10] == 16
+
+
+def test_textured_materials_and_textured_emitters():
+    _compare(scenes.textured_scene(96, 64, 6), "textured")
+    w = _compare(scenes.emissive_texture_scene(72, 48, 4), "emissive textures")
+    # the screen that is black over one triangle contributes ONE light; the dangling texture none (light.cuh:195-196)
+    assert w["num_lights"] == 5
+    assert (w["light_intensities"] > 0).all() and len(np.unique(w["light_intensities"])) > 1
+
+
+def test_the_hall_and_edge_cases():
+    w = _compare(scenes.hall_scene(480, 270, 8), "hall")
+    assert w["vertices"].size == 12 * 1_433_000 or w["vertices"].size > 12 * 1_000_000
+    assert w["num_lights"] == 64
+    for kind in ("empty", "no_lights", "degenerate", "one_triangle"):  # no mesh at all; no emitter; zero-area and sliver triangles; a single emissive triangle (the one-light root)
+        _compare(scenes.edge_scene(kind, 48, 32, 4), "edge " + kind)
+
+
+def _emitter_soup(seed, num_instances, tris_per_mesh, textured):
+    """Random emissive triangle soups under random rotations, non-uniform scales and translations, several emission strengths per mesh (material slots in an
+    order that is not the id order), non-emissive triangles in between, a degenerate triangle, optionally texture-driven emitters: thousands of lights, several
+    levels of 8-wide nodes, near-ties in the binned SAH."""
+    rng = np.random.default_rng(seed)
+    host = Host()
+    scenes.apply_benchmark_settings(host, 64, 48, 4, sky=(0.0, 0.0, 0.0))
+    mats = [host.add_material(scenes._material((0.6, 0.6, 0.6), 0.5))]
+    for k in range(5):
+        e = rng.uniform(0.1, 40.0, 3) * (k + 1)
+        mats.append(host.add_material(scenes._material((0.8, 0.8, 0.8), 0.7, emission=tuple(float(x) for x in e), bidirectional=bool(k & 1))))
+    if textured:
+        img = rng.integers(0, 255, (8, 8, 4)).astype(np.uint8)
+        img[:2, :, :3] = 0
+        tex = host.add_texture(img, gamma=2.2)
+        mt = scenes._material((0.8, 0.8, 0.8), 0.7, emission=(0.2, 0.1, 0.0))
+        mt.luminance_tex, mt.emission_scale = tex, 25.0
+        mats.append(host.add_material(mt))
+    meshes = []
+    for m in range(3):
+        n = tris_per_mesh
+        centre = rng.uniform(-20, 20, (n, 1, 3))
+        pos = (centre + rng.normal(0, rng.uniform(0.05, 1.5, (n, 1, 1)), (n, 3, 3))).astype(np.float32)
+        pos[5, 2] = pos[5, 1]  # a degenerate triangle: area 0, no light (device_light.c:2084)
+        ids = rng.permutation(np.resize(np.array(mats[::-1], dtype=np.uint16), n))  # slot order != id order
+        uv = rng.uniform(-1.5, 2.5, (n, 6)).astype(np.float32)
+        meshes.append(host.add_mesh(pos.reshape(n, 9), ids, uvs=uv))
+    for i in range(num_instances):
+        rot = tuple(float(x) for x in rng.uniform(-3.1, 3.1, 3)) if i % 4 else (0.0, 0.0, 0.0)
+        host.new_instance(meshes[i % 3], position=tuple(float(x) for x in rng.uniform(-50, 50, 3)), rotation=rot, scale=tuple(float(x) for x in rng.uniform(0.2, 3.0, 3)))
+    scenes.set_camera(host, (0.0, 5.0, 90.0), (0.0, 0.0, 0.0))
+    return host
+
+
+@pytest.mark.parametrize("seed,instances,tris,textured", [(1, 9, 60, False), (2, 14, 200, True), (3, 5, 1500, False)])
+def test_soups_of_rotated_emitters(seed, instances, tris, textured):
+    w = _compare(_emitter_soup(seed, instances, tris, textured), "soup %d" % seed)
+    assert w["num_lights"] > 128 and w["num_light_tree_nodes"] > 16
+    # every light once: the handle map is a permutation of the emissive (instance, triangle) pairs
+    h = w["light_tri_handles"].reshape(-1, 2)
+    assert len({(int(a), int(b)) for a, b in h}) == h.shape[0]
+
+
+def test_the_w_lane_of_rotated_emitters_reaches_the_variance(monkeypatch):
+    """The finding itself: for a rotated emissive instance the reference's vertex leaves vec128_rotate_quaternion with w = 2 q.w dot(q.xyz, a) (host_intrinsics.h:
+    221-233), the light BVH's vertex buffer holds it, and the node variances contain it. The independent encoder with that lane cleared (O_SCENE_CLEAR_W, diagnosis
+    switch) gives another tree than the product - which therefore carries the lane like the reference."""
+    host = _emitter_soup(1, 9, 60, False)
+    view = host.device_scene()
+    got = oracle_lib.view_arrays(view)
+    w_lanes = got["light_bvh_tris"].view(np.float32).reshape(-1, 4)[:, 3]
+    assert (w_lanes != 0.0).any(), "rotated instances: the fourth lane is not zero"
+    monkeypatch.setenv("O_SCENE_CLEAR_W", "1")
+    cleared = oracle_lib.encode_scene(host, view)
+    assert not np.array_equal(cleared["light_tree_root"], got["light_tree_root"]) or not np.array_equal(cleared["light_tree_nodes"], got["light_tree_nodes"])
+    unrotated = scenes.example_scene(160, 96, 3)
+    uw = oracle_lib.view_arrays(unrotated.device_scene())["light_bvh_tris"].view(np.float32).reshape(-1, 4)[:, 3]
+    assert (uw == 0.0).all(), "no rotation, no fourth lane"
+
+
+def test_material_encoder_on_random_materials():
+    """device_struct_material_convert on values that stress every rounding: u16 normalised albedo and roughness, the 8-bit roughness clamp, (ior - 1) / 2, the
+    emission normalised by max + 1 with its 8.8-bit scale, flags."""
+    rng = np.random.default_rng(11)
+    host = Host()
+    for k in range(200):
+        m = scenes._material(tuple(float(x) for x in rng.uniform(0, 1, 3)), float(rng.uniform(0, 1)), metallic=bool(rng.integers(2)), alpha=float(rng.uniform(0, 1)),
+                             emission=tuple(float(x) for x in rng.uniform(0, 10.0 ** rng.uniform(-3, 5), 3)) if k % 3 else None, bidirectional=bool(rng.integers(2)))
+        m.roughness_clamp = float(rng.uniform(0, 1))
+        m.refraction_index = float(rng.uniform(1.0, 3.0))
+        m.emission_scale = float(10.0 ** rng.uniform(-3, 4))
+        m.thin_walled, m.colored_transparency, m.roughness_as_smoothness, m.normal_map_is_compressed = (bool(rng.integers(2)) for _ in range(4))
+        m.base_substrate = int(rng.integers(2))
+        host.add_material(m)
+    tri = np.array([[0, 0, 0, 1, 0, 0, 0, 1, 0]], dtype=np.float32)
+    host.new_instance(host.add_mesh(tri, np.array([3], dtype=np.uint16)))
+    _compare(host, "random materials")
+
+
+def test_vertex_uv_and_transform_encoders_on_random_values():
+    """device_pack_normal (double arithmetic, two rounded u16), device_pack_uv (truncated bf16 pairs), the inverse-rotation Quaternion16."""
+    rng = np.random.default_rng(12)
+    host = Host()
+    n = 4000
+    pos = rng.normal(0, 30, (n, 9)).astype(np.float32)
+    nrm = rng.normal(0, 1, (n, 3, 3))
+    nrm[::7] = np.eye(3)[rng.integers(0, 3, (nrm[::7].shape[0], 3))] * rng.choice([-1.0, 1.0], (nrm[::7].shape[0], 3, 1))  # axis-aligned normals: the octahedron's corners
+    nrm /= np.linalg.norm(nrm, axis=2, keepdims=True)
+    uv = (rng.normal(0, 1, (n, 6)) * 10.0 ** rng.uniform(-4, 3, (n, 1))).astype(np.float32)
+    mesh = host.add_mesh(pos, np.zeros(n, dtype=np.uint16), normals=nrm.reshape(n, 9).astype(np.float32), uvs=uv)
+    for i in range(64):
+        host.new_instance(mesh, position=tuple(float(x) for x in rng.normal(0, 100, 3)), rotation=tuple(float(x) for x in rng.uniform(-7, 7, 3)),
+                          scale=tuple(float(x) for x in 10.0 ** rng.uniform(-2, 2, 3)))
+    _compare(host, "random vertices and transforms")
