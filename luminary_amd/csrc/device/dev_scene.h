@@ -186,6 +186,10 @@ struct DeviceScene {
   const BvhTri* particle_tris;
   const float4* particle_leaves;
   uint32_t particle_tlas_num_nodes, particle_num_leaves;
+  // LUM_PHASE_QUEUES (dev_trace_pool.h): per workgroup of the persistent ray kernels and per pool slot, what does not fit LDS - 4 x 16 bytes of query state, the stack
+  // entries beyond the LDS ones. Null in other builds.
+  uint4* pool_state;
+  unsigned long long* pool_stack;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).
@@ -294,6 +298,22 @@ enum CtrlWord : uint32_t {
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 
+#ifndef LUM_PHASE_QUEUES
+#define LUM_PHASE_QUEUES 0  // 1: k_trace / k_shadow_rays keep their rays in per-wave LDS pools and regroup them by phase (dev_trace_pool.h)
+#endif
+#if LUM_PHASE_QUEUES
+#ifndef LUM_TRACE_BLOCK
+#define LUM_TRACE_BLOCK 1024
+#endif
+#ifndef LUM_POOL_SLOTS
+#define LUM_POOL_SLOTS 128  // rays per wave (<= 256: list entries are bytes)
+#endif
+#ifndef LUM_POOL_STACK_ENTRIES
+#define LUM_POOL_STACK_ENTRIES 2  // 8-byte stack entries per slot kept in LDS
+#endif
+// per slot: the LDS part of its stack, three 16-byte state words, one byte in each of the wave's four lists
+#define LUM_LDS_STACK_BYTES ((LUM_POOL_STACK_ENTRIES * 8u + 48u + 4u) * LUM_POOL_SLOTS * (LUM_TRACE_BLOCK / 64u))
+#endif
 #ifndef LUM_LDS_STACK_BYTES
 #define LUM_LDS_STACK_BYTES 65536u  // of a ray workgroup's LDS: bytes that hold the oldest entries of its lanes' traversal stacks instead of tree nodes (0: stacks in scratch)
 #endif

@@ -14,6 +14,9 @@
 #pragma once
 
 #include "dev_trace.h"
+#if LUM_PHASE_QUEUES
+#include "dev_trace_pool.h"
+#endif
 #include "dev_sky.h"
 #include "dev_volume.h"
 #include "dev_particle.h"
@@ -172,6 +175,16 @@ struct TraceQuery : ClosestState {
     o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = kFltMax;
     return true;
   }
+  // LUM_PHASE_QUEUES (dev_trace_pool.h): the state a pool slot keeps outside LDS, and the world-space ray again
+  static constexpr uint32_t kMutableVecs = 1;
+  LUM_DEV void save_mutable(uint4* m) const { m[0] = make_uint4(best.instance_id, best.tri_id, best.scene_tri, cutout ? 1u : 0u); }
+  LUM_DEV void load_mutable(const uint4* m, float tmax) { best = Hit{m[0].x, m[0].y, tmax, m[0].z}; cutout = m[0].w != 0u; }
+  LUM_DEV void save_const(uint4& c) const { c = make_uint4(use_ignore ? 1u : 0u, ign_inst, ign_tri, 0u); }
+  LUM_DEV void load_const(uint4 c) { use_ignore = c.x != 0u; ign_inst = c.y; ign_tri = c.z; }
+  LUM_DEV void world_ray(const DeviceScene&, uint32_t i, V3& o, V3& d) const {
+    const float4 o4 = q.origin_t[i], d4 = q.dir_slot[i];
+    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z);
+  }
   LUM_DEV void finish(const DeviceScene&, uint32_t) {
     const uint32_t i = item;
     const Hit h = result();
@@ -189,7 +202,11 @@ __global__ LUM_TRACE_BOUNDS void k_trace(DeviceScene sc, PathQueue q, const uint
   tq.q = q;
   tq.order = order;
   tq.item = 0;
+#if LUM_PHASE_QUEUES
+  trace_items_pool(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
+#else
   LUM_TRACE_ITEMS(sc, ctrl[kCtlPaths], ctrl + kCtlTraceCursor, tq, st, rays, lds_nodes);
+#endif
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
 }
 
@@ -968,8 +985,34 @@ struct ShadowQuery : ShadowState {
   ShadowQueue sq;
   const uint32_t* order;
   uint32_t out;
+  uint32_t item;  // LUM_PHASE_QUEUES: the queue entry load() read
+#if LUM_FAST
+  static constexpr uint32_t kMutableVecs = 1;
+  LUM_DEV void save_mutable(uint4* m) const { m[0] = make_uint4(fbits(tr), fbits(tg), fbits(tb), out); }
+  LUM_DEV void load_mutable(const uint4* m, float tmax) { tr = bitsf(m[0].x); tg = bitsf(m[0].y); tb = bitsf(m[0].z); out = m[0].w; dist = tmax; blocked = false; }
+#else
+  static constexpr uint32_t kMutableVecs = 2;
+  LUM_DEV void save_mutable(uint4* m) const {
+    const unsigned long long r = (unsigned long long) __double_as_longlong(tr), g = (unsigned long long) __double_as_longlong(tg), b = (unsigned long long) __double_as_longlong(tb);
+    m[0] = make_uint4((uint32_t) r, (uint32_t) (r >> 32), (uint32_t) g, (uint32_t) (g >> 32));
+    m[1] = make_uint4((uint32_t) b, (uint32_t) (b >> 32), out, 0u);
+  }
+  LUM_DEV void load_mutable(const uint4* m, float tmax) {
+    tr = __longlong_as_double((long long) ((unsigned long long) m[0].x | ((unsigned long long) m[0].y << 32)));
+    tg = __longlong_as_double((long long) ((unsigned long long) m[0].z | ((unsigned long long) m[0].w << 32)));
+    tb = __longlong_as_double((long long) ((unsigned long long) m[1].x | ((unsigned long long) m[1].y << 32)));
+    out = m[1].z; dist = tmax; blocked = false;
+  }
+#endif
+  LUM_DEV void save_const(uint4& c) const { c = make_uint4(tgt_inst, tgt_tri, self_inst, self_tri); }
+  LUM_DEV void load_const(uint4 c) { tgt_inst = c.x; tgt_tri = c.y; self_inst = c.z; self_tri = c.w; }
+  LUM_DEV void world_ray(const DeviceScene&, uint32_t j, V3& o, V3& d) const {
+    const float4 o4 = sq.origin_dist[j], d4 = sq.dir_out[j];
+    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z);
+  }
   LUM_DEV bool load(const DeviceScene&, uint32_t slot, V3& o, V3& d, float& tmax) {
     const uint32_t j = order ? order[slot] : slot;
+    item = j;
     const float4 o4 = ld_stream(&sq.origin_dist[j]), d4 = ld_stream(&sq.dir_out[j]);
     begin(ld_stream(&sq.ids[j]), o4.w);
     out = fbits(d4.w);
@@ -995,7 +1038,11 @@ __global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, c
   ShadowQuery q;
   q.sq = sq;
   q.order = order;
+#if LUM_PHASE_QUEUES
+  trace_items_pool(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
+#else
   LUM_TRACE_ITEMS(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
+#endif
   flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow, kCntNodesLdsShadow);
 }
 

@@ -1448,6 +1448,18 @@ static int scene_update(LumContext* ctx, const LumDeviceSceneView* v, unsigned d
     ctx->lds_nodes = (uint32_t) std::min<size_t>(lds_bytes / kNodeBytes, nodes.size());
     if (const char* e = getenv("LUM_LDS_NODES")) ctx->lds_nodes = std::min<uint32_t>((uint32_t) atoi(e), ctx->lds_nodes);
     ctx->trace_blocks = (uint32_t) prop.multiProcessorCount * blocks_per_cu;
+#if LUM_PHASE_QUEUES
+    // dev_trace_pool.h: per persistent workgroup and pool slot 4 x 16 bytes of query state and the stack entries beyond the LDS ones (once per context)
+    if (!sc.pool_state) {
+      const size_t slots = (size_t) ctx->trace_blocks * LUM_POOL_SLOTS * (LUM_TRACE_BLOCK / 64u);
+      void* a = nullptr; void* b = nullptr;
+      HIP_TRY(ctx, hipMalloc(&a, slots * 4u * sizeof(uint4)));
+      ctx->scene_allocs[LumContext::kGrpOnce].push_back(a);
+      HIP_TRY(ctx, hipMalloc(&b, slots * (size_t) kStackSize * sizeof(unsigned long long)));
+      ctx->scene_allocs[LumContext::kGrpOnce].push_back(b);
+      sc.pool_state = (uint4*) a; sc.pool_stack = (unsigned long long*) b;
+    }
+#endif
     // The attribute is a property of the kernel, not of a context: it is set to what the largest scene may ask for (the whole budget computed
     // above), never to this scene's need - a second context with a small scene must not lower the cap a first one launches with.
     const size_t dyn = lds_bytes + LUM_LDS_STACK_BYTES;
