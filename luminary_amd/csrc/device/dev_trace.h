@@ -8,22 +8,27 @@
 // Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
 // the candidate set only (see light_query).
 //
-// Execution model (gfx950; counters of round 3, profiles/pmc_counters.json): one ray per lane, persistent waves, 4 waves per SIMD in
-// the fast flavour (128 VGPRs), 3 in the exact one. The kernels are bound by two units at once - the vector ALU issues 63-72 % of the time (of the
-// measured v_fma rate) at a lane utilisation of 0.46-0.54, and the vector-memory address unit is busy 70-81 % of the cycles (a divergent 16-byte lane
-// load costs it one cycle per lane: 7 per node visit that misses the staged top, 12 per leaf) - not by memory bandwidth (0.37-0.51 of 8 TB/s) and not
-// by latency as such (an L1->L2 read returns after ~400 cycles, a tenth of a wave iteration). So both the instructions and the lane loads per wave
-// iteration count:
+// Execution model (gfx950; counters of rounds 4-5, profiles/pmc_counters.json, profiles/r05_ab_experiments.txt, DESIGN.md sections 0 and 4): one ray per lane,
+// persistent waves, one workgroup of 1024 threads = 16 waves per CU = 4 waves per SIMD (128 VGPRs) in BOTH flavours since round 4. On the hall a closest-hit
+// launch runs at a VALU lane utilisation of 0.45 (visibility: 0.53), its waves wait 0.56 (0.61) of their cycles, and the vector-memory address unit is busy 0.71
+// of the launch: a divergent 16-byte lane load costs it one cycle per LANE (7 per node visit that misses the staged top, 3 per triangle), whatever the number of
+// wave instructions that carry them. The kernels sit between the two: every variant that removed lane loads added instructions and became issue-bound (64-byte
+// and 8-wide quantised nodes), every variant that removed instructions per ray or filled the waves left the lane loads in place and gained nothing - round 5's
+// LDS phase queues (dev_trace_pool.h, LUM_PHASE_QUEUES) raise the lane utilisation to 0.68 / 0.76 with a third fewer vector-memory instructions at the SAME number
+// of vector instructions and run 25-80 % slower, because twice the rays per CU halve each ray's share of LDS (stack bottoms, staged nodes). Memory bandwidth is
+// not the limit (0.52 / 0.38 of 8 TB/s memory-side), latency as such neither (an L1->L2 read returns after ~400 cycles, a tenth of a wave iteration).
+// What an iteration costs:
 //   * one node visit = 7 x 16-byte loads (near/far planes picked by the ray's direction signs, so no per-axis min/max),
 //     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and conditional pushes: ~110 vector instructions;
 //   * every wave iteration runs ONE phase - node visit, instance entry or triangle tests - chosen by a vote over its lanes, so a
 //     lane that holds a leaf does not wait for the slowest lane of the wave to find one (plain while-while: 0.33-0.41 lane occupancy);
 //   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing;
-//   * the first nodes of the array (breadth-first across both levels) are staged in LDS by every workgroup, the oldest stack entries of every lane
-//     live there too.
+//   * the first nodes of the array (breadth-first across both levels; 704 of them beside 64 KB of stack bottoms) are staged in LDS by every workgroup, the
+//     oldest 8 stack entries of every lane live there too: LDS hit rate of the node visits 0.62 / 0.72.
 // Structural alternatives that were built and measured, and lost (profiles/r0*_ab_experiments.txt): 8-wide quantised nodes with a sorting network (twice),
 // 64-byte quantised 4-wide nodes, dual-node visits, speculative traversal past a leaf (LUM_SPECULATE, round 4: +7 % node visits, +16-19 % time),
-// physical ray reordering between bounces, per-XCD work ranges, LDS-DMA prefetch. The 8-wide octant-order node (no sort, one group entry per visit) was
+// physical ray reordering between bounces, per-XCD work ranges, LDS-DMA prefetch, rays regrouped by phase through LDS (round 5, above), an MFMA slab test for packets
+// (tools/microbench/mfma_slab.hip: 0.62 x the vector path). The 8-wide octant-order node (no sort, one group entry per visit) was
 // prototyped as a visit routine and a CPU walk before a rewrite (tools/microbench/node_visit.hip, tools/bvh_quality.cpp BQ_WIDE): see DESIGN.md section 4.
 #pragma once
 

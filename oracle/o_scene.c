@@ -673,6 +673,87 @@ static float sc_triangle_intensity(const OracleScene* ts, uint32_t tex, const ui
   return best;
 }
 
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * The scalar conversions and the derived parameters
+ * ---------------------------------------------------------------------------------------------------------------------------------- */
+
+/* cuda/math.cuh:1189-1232 (the reference evaluates this on the device per ray; the product once per scene) */
+static void sc_jendersie_eon(float d, float out[4]) {
+  float g_hg = 0.0f, g_d = 0.0f, alpha = 0.0f, w_d = 0.0f; /* beyond 50 micrometres the reference leaves its struct unset */
+  if (d >= 5.0f && d <= 50.0f) {
+    g_hg = expf(-0.0990567f / (d - 1.67154f));
+    g_d = expf(-(2.20679f / (d + 3.91029f)) - 0.428934f);
+    alpha = expf(3.62489f - (8.29288f / (d + 5.52825f)));
+    w_d = expf(-(0.599085f / (d - 0.641583f)) - 0.665888f);
+  }
+  else if (d >= 1.5f && d < 5.0f) {
+    g_hg = 0.0604931f * logf(logf(d)) + 0.940256f;
+    g_d = 0.500411f - (0.081287f / (-2.0f * logf(d) + tanf(logf(d)) + 1.27551f));
+    alpha = 7.30354f * logf(d) + 6.31675f;
+    w_d = 0.026914f * (logf(d) - cosf(5.68947f * (logf(logf(d)) - 0.0292149f))) + 0.376475f;
+  }
+  else if (d >= 0.1f && d < 1.5f) {
+    g_hg = 0.862f - 0.143f * logf(d) * logf(d);
+    g_d = 0.379685f * cosf(1.19692f * cosf(((logf(d) - 0.238604f) * (logf(d) + 1.00667f)) / (0.507522f - 0.15677f * logf(d))) + 1.37932f * logf(d) + 0.0625835f) + 0.344213f;
+    alpha = 250.0f;
+    w_d = 0.146209f * cosf(3.38707f * logf(d) + 2.11193f) + 0.316072f + 0.0778917f * logf(d);
+  }
+  else if (d < 0.1f) {
+    g_hg = 13.8f * d * d;
+    g_d = 1.1456f * d * sinf(9.29044f * d);
+    alpha = 250.0f;
+    w_d = 0.252977f - 312.983f * powf(d, 4.3f);
+  }
+  out[0] = g_hg; out[1] = g_d; out[2] = alpha; out[3] = w_d;
+}
+
+/* device_structs.c:131-171: direction from (azimuth, altitude) in double, scaled to the body's distance, seen from the point sky.geometry_offset above the
+ * earth's centre (sky_defines.h:4-8) */
+static void sc_body_position(float azimuth, float altitude, double distance, const float offset[3], float out[3]) {
+  double x = cos(azimuth) * cos(altitude);
+  double y = sin(altitude);
+  double z = sin(azimuth) * cos(altitude);
+  const double scale = 1.0 / (sqrt(x * x + y * y + z * z));
+  x *= scale * distance;
+  y *= scale * distance;
+  z *= scale * distance;
+  y -= 6371.0f;
+  x -= offset[0];
+  y -= offset[1];
+  z -= offset[2];
+  out[0] = (float) x; out[1] = (float) y; out[2] = (float) z;
+}
+
+void oracle_scene_constants(const OSceneEntities* in, OSceneConstants* out) {
+  memset(out, 0, sizeof(*out));
+  out->width = in->width << in->supersampling;
+  out->height = in->height << in->supersampling;
+  const SQuat q = sc_euler_to_quaternion(in->cam_rotation);
+  out->cam_rotation[0] = q.x; out->cam_rotation[1] = q.y; out->cam_rotation[2] = q.z; out->cam_rotation[3] = q.w;
+  sc_body_position(in->sky_azimuth, in->sky_altitude, 149597870.0f, in->sky_geometry_offset, out->sky_sun_pos);
+  sc_body_position(in->sky_moon_azimuth, in->sky_moon_altitude, 384399.0f, in->sky_geometry_offset, out->sky_moon_pos);
+  sc_jendersie_eon(in->sky_mie_diameter, out->sky_mie_phase);
+  sc_jendersie_eon(in->fog_droplet_diameter, out->fog_phase);
+  sc_jendersie_eon(in->particles_phase_diameter, out->particles_phase);
+  sc_jendersie_eon(in->cloud_droplet_diameter, out->cloud_phase);
+  out->particles_direction[0] = cosf(in->particles_direction_azimuth) * cosf(in->particles_direction_altitude); /* math.cuh:781-788 */
+  out->particles_direction[1] = sinf(in->particles_direction_altitude);
+  out->particles_direction[2] = sinf(in->particles_direction_azimuth) * cosf(in->particles_direction_altitude);
+  /* cuda/ocean_utils.cuh:300-385: Jerlov water types I, IA, IB, II, III, 1C, 3C, 5C, 7C, 9C (structs.h:212-221) */
+  static const float scat[10][3] = {{0.001f, 0.002f, 0.004f}, {0.002f, 0.004f, 0.007f}, {0.045f, 0.054f, 0.07f}, {0.27f, 0.365f, 0.516f}, {0.737f, 0.998f, 1.413f},
+                                    {0.274f, 0.372f, 0.526f}, {0.904f, 1.071f, 1.532f}, {3.589f, 1.382f, 1.857f}, {1.772f, 2.394f, 3.376f}, {2.347f, 3.18f, 4.496f}};
+  static const float absb[10][3] = {{0.309f, 0.053f, 0.009f}, {0.309f, 0.054f, 0.014f}, {0.309f, 0.054f, 0.015f}, {0.31f, 0.054f, 0.016f}, {0.31f, 0.056f, 0.031f},
+                                    {0.316f, 0.067f, 0.105f}, {0.508f, 0.052f, 0.161f}, {4.638f, 0.222f, 0.216f}, {0.351f, 0.188f, 0.574f}, {0.398f, 0.349f, 0.995f}};
+  static const float molw[10] = {0.93f, 0.44f, 0.06f, 0.007f, 0.003f, 0.005f, 0.003f, 0.001f, 0.0f, 0.0f};
+  if (in->ocean_water_type < 10u) {
+    memcpy(out->ocean_scattering, scat[in->ocean_water_type], 12);
+    memcpy(out->ocean_absorption, absb[in->ocean_water_type], 12);
+    out->ocean_molecular_weight = molw[in->ocean_water_type];
+  }
+  out->ocean_caustics_ris_sample_count = (in->ocean_caustics_ris_sample_count > 1u ? in->ocean_caustics_ris_sample_count : 1u) - 1u;
+  for (int l = 0; l < 3; l++) { out->cloud_wind[l][0] = cosf(in->cloud_wind_angle[l]); out->cloud_wind[l][1] = sinf(in->cloud_wind_angle[l]); }
+}
+
 /* ------------------------------------------------------------------------------------------------------------------------------------ */
 int oracle_scene_encode(const OSceneInput* in, OSceneOutput* out) {
   memset(out, 0, sizeof(*out));

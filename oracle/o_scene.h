@@ -75,6 +75,31 @@ typedef struct OSceneOutput {
   float* light_intensities;     /* per light: the average_intensity the fragment was weighted with (diagnosis) */
 } OSceneOutput;
 
+/* ---- the scalar half of the conversion (device_structs.c:11-250) and the parameters the product derives on the host where the reference derives them per ray ---- */
+typedef struct OSceneEntities {
+  /* settings.c / camera.c / sky.c / fog.c / particles.c / ocean.c / cloud.c values as the public API returns them */
+  uint32_t width, height, supersampling;
+  float cam_rotation[3];                        /* euler angles */
+  float sky_azimuth, sky_altitude, sky_moon_azimuth, sky_moon_altitude, sky_geometry_offset[3], sky_mie_diameter;
+  float fog_droplet_diameter;
+  float particles_direction_altitude, particles_direction_azimuth, particles_phase_diameter;
+  uint32_t ocean_water_type, ocean_caustics_ris_sample_count;
+  float cloud_droplet_diameter, cloud_wind_angle[3]; /* low, mid, top */
+} OSceneEntities;
+
+typedef struct OSceneConstants {
+  uint32_t width, height;                       /* internal resolution: << supersampling (device_structs.c:21-22) */
+  float cam_rotation[4];                        /* quaternion x, y, z, w (device_structs.c:76, host_math.c:6-21) */
+  float sky_sun_pos[3], sky_moon_pos[3];        /* device_structs.c:131-171, in double */
+  float sky_mie_phase[4], fog_phase[4], particles_phase[4], cloud_phase[4]; /* jendersie_eon_phase_parameters, cuda/math.cuh:1189-1232 */
+  float particles_direction[3];                 /* angles_to_direction, cuda/math.cuh:781-788 */
+  float ocean_scattering[3], ocean_absorption[3], ocean_molecular_weight; /* cuda/ocean_utils.cuh:300-385 */
+  uint32_t ocean_caustics_ris_sample_count;     /* max(n, 1) - 1 (device_structs.c:94) */
+  float cloud_wind[3][2];                       /* cos, sin of the layers' wind angles (device_structs.c:184-185) */
+} OSceneConstants;
+
+void oracle_scene_constants(const OSceneEntities* in, OSceneConstants* out);
+
 int oracle_scene_encode(const OSceneInput* in, OSceneOutput* out);
 void oracle_scene_free(OSceneOutput* out);
 

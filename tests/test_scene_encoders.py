@@ -162,3 +162,55 @@ def test_vertex_uv_and_transform_encoders_on_random_values():
         host.new_instance(mesh, position=tuple(float(x) for x in rng.normal(0, 100, 3)), rotation=tuple(float(x) for x in rng.uniform(-7, 7, 3)),
                           scale=tuple(float(x) for x in 10.0 ** rng.uniform(-2, 2, 3)))
     _compare(host, "random vertices and transforms")
+
+
+def _bits(x):
+    return np.asarray(list(x), dtype=np.float32).view(np.uint32).tolist()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_scalar_conversions_and_derived_parameters(seed):
+    """The other half of row a18: the entities' conversions (device_structs.c:11-250 - internal resolution, the camera's quaternion, sun and moon positions in
+    double, the ris count, the cloud layers' wind cos / sin) and the parameters the product derives once per scene where the reference derives them per ray
+    (Jendersie-Eon phase parameters of four droplet diameters over all four branches of cuda/math.cuh:1189-1232, the particles' direction, the Jerlov water type's
+    coefficients), from a second implementation, bit for bit."""
+    rng = np.random.default_rng(100 + seed)
+    host = Host()
+    st = host.get_settings()
+    st.width, st.height, st.supersampling = int(rng.integers(8, 300)), int(rng.integers(8, 200)), int(seed & 1)
+    host.set_settings(st)
+    cam = host.get_camera()
+    cam.rotation.x, cam.rotation.y, cam.rotation.z = (float(x) for x in rng.uniform(-4, 4, 3))
+    host.set_camera(cam)
+    sky = host.get_sky()
+    sky.azimuth, sky.altitude, sky.moon_azimuth, sky.moon_altitude = (float(x) for x in rng.uniform(-3.2, 3.2, 4))
+    sky.geometry_offset.x, sky.geometry_offset.y, sky.geometry_offset.z = (float(x) for x in rng.uniform(-50, 50, 3))
+    diameters = [0.05, 0.7, 3.0, 20.0, 60.0, float(rng.uniform(0.01, 55.0))]  # every branch, and beyond the fit's range
+    sky.mie_diameter = diameters[seed % 6]
+    host.set_sky(sky)
+    fog = host.get_fog()
+    fog.droplet_diameter = diameters[(seed + 1) % 6]
+    host.set_fog(fog)
+    pt = host.get_particles()
+    pt.direction_altitude, pt.direction_azimuth, pt.phase_diameter = float(rng.uniform(-1.5, 1.5)), float(rng.uniform(-3, 3)), diameters[(seed + 2) % 6]
+    host.set_particles(pt)
+    oc = host.get_ocean()
+    oc.water_type, oc.caustics_ris_sample_count = (seed * 3) % 10, seed  # 0: max(n, 1) - 1 = 0
+    host.set_ocean(oc)
+    cl = host.get_cloud()
+    cl.droplet_diameter = diameters[(seed + 3) % 6]
+    cl.low.wind_angle, cl.mid.wind_angle, cl.top.wind_angle = (float(x) for x in rng.uniform(-7, 7, 3))
+    host.set_cloud(cl)
+    v = host.device_scene()
+    c = oracle_lib.scene_constants(host)
+    assert (v.width, v.height) == (c.width, c.height)
+    assert _bits(v.cam_rotation) == _bits(c.cam_rotation)
+    assert _bits(v.sky_sun_pos) == _bits(c.sky_sun_pos) and _bits(v.sky_moon_pos) == _bits(c.sky_moon_pos)
+    assert _bits(v.sky_mie_phase) == _bits(c.sky_mie_phase) and _bits(v.fog_phase) == _bits(c.fog_phase)
+    assert _bits(v.particles_phase) == _bits(c.particles_phase) and _bits(v.cloud_phase) == _bits(c.cloud_phase)
+    assert _bits(v.particles_direction) == _bits(c.particles_direction)
+    assert _bits(v.ocean_scattering) == _bits(c.ocean_scattering) and _bits(v.ocean_absorption) == _bits(c.ocean_absorption)
+    assert _bits([v.ocean_molecular_weight]) == _bits([c.ocean_molecular_weight])
+    assert v.ocean_caustics_ris_sample_count == c.ocean_caustics_ris_sample_count
+    for layer in range(3):
+        assert _bits(list(v.cloud_layers[layer])[8:10]) == _bits(c.cloud_wind[layer])
