@@ -545,6 +545,9 @@ def main():
         if head["config"]["flavour"] == "fast" and args.workload == "hall":
             head["config"]["fast_vs_exact_rel_l2_1024spp"] = gate["fast_vs_exact_rel_l2"]["1024"]
             head["config"]["fast_vs_exact_note"] = gate["note"]
+            conv = gate.get("against_converged_render")
+            if conv:  # the like-for-like check against an exact render of 16384 spp (tools/flavour_gate.py, tests/test_flavours.py)
+                head["config"]["flavour_gate"] = {k: conv[k] for k in ("truth_spp", "spp", "e_fast", "e_exact", "e_independent_exact", "e_fast_over_e_exact")}
     except (OSError, KeyError, ValueError):
         pass
     detail = {"metric": METRIC, "value": head["value"], "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -245,6 +245,42 @@ LUM_DEV TableLight load_tri_light_table(const DeviceScene& sc, uint32_t light_id
   e.textured = fbits(d.w) != 0u;
   return e;
 }
+// The first LUM_LDS_LIGHTS lights' table lines and handles, staged in LDS by every workgroup of k_shade (round 5): the candidate loop reads a line of 64 bytes
+// and a handle per candidate through an index it has just computed - five dependent 16-byte gathers, eight times per vertex, from a table of a few KB that every
+// lane of every wave reads. From LDS they cost the address unit nothing and return in a quarter of an L1 hit's time. Lights beyond the staged ones are read from
+// memory as before (one branch per candidate); the values are the same words either way.
+#ifndef LUM_LDS_LIGHTS
+#define LUM_LDS_LIGHTS 256
+#endif
+typedef float LdsF4 __attribute__((ext_vector_type(4)));
+struct StagedLights {
+  const __attribute__((address_space(3))) LdsF4* table;
+  const __attribute__((address_space(3))) unsigned long long* handles;
+  uint32_t count;
+};
+LUM_DEV TableLight load_tri_light_table(const DeviceScene& sc, const StagedLights& sl, uint32_t light_id, uint2& handle) {
+  float4 a, b, c, d;
+  if (light_id < sl.count) {
+    const LdsF4 va = sl.table[4u * light_id], vb = sl.table[4u * light_id + 1u], vc = sl.table[4u * light_id + 2u], vd = sl.table[4u * light_id + 3u];
+    const unsigned long long h = sl.handles[light_id];
+    a = make_float4(va.x, va.y, va.z, va.w); b = make_float4(vb.x, vb.y, vb.z, vb.w); c = make_float4(vc.x, vc.y, vc.z, vc.w); d = make_float4(vd.x, vd.y, vd.z, vd.w);
+    handle = make_uint2((uint32_t) h, (uint32_t) (h >> 32));
+  }
+  else {
+    a = sc.light_tri_table[4u * light_id]; b = sc.light_tri_table[4u * light_id + 1u]; c = sc.light_tri_table[4u * light_id + 2u]; d = sc.light_tri_table[4u * light_id + 3u];
+    handle = sc.light_tri_handles[light_id];
+  }
+  TableLight e;
+  TriLight& t = e.tri;
+  t.vertex = v3(a.x, a.y, a.z); t.edge1 = v3(b.x, b.y, b.z); t.edge2 = v3(c.x, c.y, c.z);
+  t.material_id = fbits(a.w) & 0xFFFFu;
+  t.bidirectional = (fbits(a.w) >> 16) != 0u;
+  t.scene_tri = fbits(b.w);
+  e.area = c.w;
+  e.color = col(d.x, d.y, d.z);
+  e.textured = fbits(d.w) != 0u;
+  return e;
+}
 LUM_DEV float tri_light_solid_angle(const TriLight& t, V3 origin) {  // light_triangle.cuh:94-108
   const V3 a = normalize(t.vertex - origin), b = normalize((t.vertex + t.edge1) - origin), c = normalize((t.vertex + t.edge2) - origin);
   const float G0 = fabsf(dot(cross(a, b), c)), G1 = dot(a, c) + dot(b, c), G2 = 1.0f + dot(a, b);
@@ -383,7 +419,7 @@ LUM_DEV float light_direction_probability_terms(const MatParams& p, V3 Vl, const
 // ---- light sampling (light.cuh:84-159) ----
 struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum; };
 
-LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, ShadeClock& clock) {
+LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, ShadeClock& clock, const StagedLights& staged) {
   LUM_STAT(14, 15);
   const TreeWork work = tree_prepass(sc, g, smp);
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));
@@ -404,8 +440,13 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     LUM_STAT(8, 9);
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
+#if LUM_LDS_LIGHTS
+    uint2 handle;
+    const TableLight entry = load_tri_light_table(sc, staged, pick.light_id, handle);
+#else
     const uint2 handle = sc.light_tri_handles[pick.light_id];
     const TableLight entry = load_tri_light_table(sc, pick.light_id);
+#endif
     const TriLight& tl = entry.tri;
     if (handle.x == g.instance_id && handle.y == g.tri_id) continue;
     V3 ray; float sa;

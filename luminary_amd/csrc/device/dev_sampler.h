@@ -53,14 +53,40 @@ LUM_DEV U2 sobol_owen(uint32_t index, uint32_t dimension) {
 LUM_DEV float unit_float(uint32_t v) { return bitsf(0x3F800000u | (v >> 9)) - 1.0f; }
 LUM_DEV float clamp_random(float r) { return fminf(fmaxf(r, 0.0f), bitsf(0x3F7FFFFFu)); }
 
+// LUM_SCALAR_SOBOL (round 5): the Sobol / Owen part of a random number - three Laine-Karras hashes, twelve 32-bit multiplies at a quarter of the vector rate
+// - depends on (sample id, dimension) only, and the dimension is the same in every lane. The queues stay nearly sorted by sample id through the depths
+// (k_generate writes sample-major, the kernels walk and append in queue order), so the lanes of a wave mostly hold ONE sample id: then the whole hash is
+// wave-uniform and runs on the scalar unit (s_mul_i32, s_brev_b32 ...), which k_shade leaves five sixths idle (SQ_INSTS_SALU = 0.17 x SQ_INSTS_VALU). A wave
+// whose lanes differ takes the vector form. Same integer function either way: the random numbers do not change by a bit.
+#ifndef LUM_SCALAR_SOBOL
+#define LUM_SCALAR_SOBOL 0  // measured (profiles/r05_ab_experiments.txt): k_shade +0.5 ... +3 % - off
+#endif
 struct Sampler {
   const uint32_t* bluenoise;
   uint32_t px, py, sample_id, depth;
+  bool uniform = false;  // every active lane of the wave holds this sample id (detect_uniform(); wave-uniform)
+  LUM_DEV void detect_uniform() {
+#if LUM_SCALAR_SOBOL
+    uniform = __ballot(sample_id != (uint32_t) __builtin_amdgcn_readfirstlane((int) sample_id)) == 0ull;
+#endif
+  }
 
   LUM_DEV U2 raw2(uint32_t target) const { return raw2_at(target, px, py, depth); }
   LUM_DEV U2 raw2_at(uint32_t target, uint32_t x, uint32_t y, uint32_t d) const {
     const uint32_t dim = target + d * kRndTargetCount;
-    U2 q = sobol_owen(sample_id, dim);
+    U2 q;
+#if LUM_SCALAR_SOBOL
+    if (uniform) {
+      // the asm statement pins the index in a scalar register: without it the compiler folds the two branches into one vector hash of
+      // `uniform ? first lane's id : own id`
+      uint32_t sid = (uint32_t) __builtin_amdgcn_readfirstlane((int) sample_id);
+      asm volatile("" : "+s"(sid));
+      q = sobol_owen(sid, (uint32_t) __builtin_amdgcn_readfirstlane((int) dim));  // (the dimension is wave-uniform by construction; say so where a loop counter hides it)
+      asm volatile("" : "+s"(q.x), "+s"(q.y));  // ... and the result: the hash between the two statements can only be scalar code
+    }
+    else
+#endif
+      q = sobol_owen(sample_id, dim);
     const uint32_t ox = (1u + dim) * 3242174889u, oy = (1u + dim) * 2447445413u;
     const uint32_t texel = bluenoise[((x + (ox >> 24)) & 0xFFu) + ((y + (oy >> 24)) & 0xFFu) * 256u];
     q.x += texel & 0xFFFF0000u;

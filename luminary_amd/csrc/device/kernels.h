@@ -429,6 +429,21 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   __shared__ uint32_t pending_hits[kBlock / 64][128];
   uint32_t* pending = pending_hits[threadIdx.x >> 6];
   uint32_t num_pending = 0;  // wave-uniform
+  // the candidate loop's table lines and handles of the first lights, in LDS (dev_light.h StagedLights)
+  StagedLights staged_lights{nullptr, nullptr, 0u};
+#if LUM_LDS_LIGHTS
+  if (kStage != 2) {
+    __shared__ LdsF4 lds_light_table[4u * LUM_LDS_LIGHTS];
+    __shared__ unsigned long long lds_light_handles[LUM_LDS_LIGHTS];
+    const uint32_t staged = lights_present ? min(sc.num_lights, (uint32_t) LUM_LDS_LIGHTS) : 0u;
+    for (uint32_t k = threadIdx.x; k < 4u * staged; k += kBlock) { const float4 v = sc.light_tri_table[k]; const LdsF4 t = {v.x, v.y, v.z, v.w}; lds_light_table[k] = t; }
+    for (uint32_t k = threadIdx.x; k < staged; k += kBlock) { const uint2 h = sc.light_tri_handles[k]; lds_light_handles[k] = (unsigned long long) h.x | ((unsigned long long) h.y << 32); }
+    __syncthreads();
+    staged_lights.table = (const __attribute__((address_space(3))) LdsF4*) lds_light_table;
+    staged_lights.handles = (const __attribute__((address_space(3))) unsigned long long*) lds_light_handles;
+    staged_lights.count = staged;
+  }
+#endif
   ShadeClock clock;
   clock.start();
   // fused resolve: an entry's parent word and slot are fetched one round ahead (two registers across the batch in between: one dependent round trip less per round)
@@ -562,7 +577,8 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         if (kStage != 1) vertices++;
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
-        const Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+        Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+        smp.detect_uniform();
         const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i] & kHitTriMask, aux.z);
         // the volume the vertex is in: without an ocean the stack holds the fog or nothing for the whole path
         const uint32_t top_volume = kWater ? volume_stack_peek(hid.w, false) : (sc.fog_active ? (uint32_t) kVolumeFog : (uint32_t) kVolumeNone);
@@ -583,7 +599,7 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         else if (geo_allowed) {
           LightSample ls;
           if (LUM_ABLATE & 1) { ls.light_id = kLightIdInvalid; ls.root_sum = 1.0f; ls.color = splat(0.0f); ls.ray = v3(0.0f, 0.0f, 1.0f); ls.dist = 1.0f; }
-          else ls = sample_light(sc, g, smp, clock);
+          else ls = sample_light(sc, g, smp, clock, staged_lights);
           if (top_volume != kVolumeNone) ls.color = ls.color * volume_transmittance(sc, top_volume, g.position, ls.ray, ls.dist);  // direct_lighting.cuh:329-337
           geo_cl = make_float4(ls.color.r, ls.color.g, ls.color.b, bitsf(ls.light_id));
           light_root_sum = ls.root_sum;
