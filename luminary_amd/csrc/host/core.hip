@@ -2753,9 +2753,10 @@ static bool tile_deal_rowmajor() {
 uint32_t lumc_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t tiles_x, uint32_t world) {
   if (world < 2) return 0;
   if (tile_deal_rowmajor()) return (uint32_t) (((uint64_t) tile_y * tiles_x + tile_x) % world);
-  static uint32_t step_of[65] = {0};  // (0 = not computed yet; a step is >= 1)
-  uint32_t k = world <= 64 ? step_of[world] : 0;
-  if (!k) { k = lumc_tile_lattice_step(world); if (world <= 64) step_of[world] = k; }
+  static uint32_t step_of[65];
+  static std::once_flag once;
+  std::call_once(once, [] { for (uint32_t w = 0; w <= 64; w++) step_of[w] = lumc_tile_lattice_step(w); });  // (the host's render threads call this concurrently)
+  const uint32_t k = world <= 64 ? step_of[world] : lumc_tile_lattice_step(world);
   return (uint32_t) (((uint64_t) tile_x + (uint64_t) k * tile_y) % world);
 }
 
