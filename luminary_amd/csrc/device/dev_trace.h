@@ -1062,4 +1062,30 @@ LUM_DEV uint32_t light_query(const DeviceScene& sc, V3 origin, V3 dir, uint32_t 
   return best_id;
 }
 
+// ---- what every translation unit with a persistent ray kernel needs (kernels.h, kernel_shadow.h) ----
+// kTraceBlock (threads per workgroup of the persistent ray kernels) is defined in dev_trace.h, which lays the lanes' traversal stacks out by it
+#ifndef LUM_TRACE_MIN_WAVES
+#define LUM_TRACE_MIN_WAVES 0  // experiment: register budget of the ray kernels as waves per SIMD (0: whatever one workgroup of kTraceBlock threads per CU allows)
+#endif
+#if LUM_TRACE_MIN_WAVES
+#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock, LUM_TRACE_MIN_WAVES)
+#else
+#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
+#endif
+
+LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
+                         uint32_t lds_counter = kCntCount) {
+  // one atomic per wave and counter
+  uint32_t n = st.nodes, t = st.tris, r = rays, l = st.lds_nodes;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off); t += __shfl_down(t, off); r += __shfl_down(r, off); l += __shfl_down(l, off); }
+  if ((threadIdx.x & 63) == 0) {
+    if (l && lds_counter != kCntCount) atomicAdd((unsigned long long*) &counters[lds_counter], (unsigned long long) l);
+    if (n) atomicAdd((unsigned long long*) &counters[node_counter], (unsigned long long) n);
+    if (t) atomicAdd((unsigned long long*) &counters[tri_counter], (unsigned long long) t);
+    if (r) atomicAdd((unsigned long long*) &counters[ray_counter], (unsigned long long) r);
+  }
+}
+
+
 LUM_NS_END

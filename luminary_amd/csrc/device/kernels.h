@@ -13,10 +13,7 @@
 // Reference schedule: device/device_renderer.c:53-134; per-kernel restatements cite their sources below.
 #pragma once
 
-#include "dev_trace.h"
-#if LUM_PHASE_QUEUES
-#include "dev_trace_pool.h"
-#endif
+#include "kernel_shadow.h"  // dev_trace.h (+ dev_trace_pool.h), ShadowQuery, k_shadow_rays
 #include "dev_sky.h"
 #include "dev_volume.h"
 #include "dev_particle.h"
@@ -26,15 +23,6 @@
 LUM_NS_BEGIN
 
 constexpr int kBlock = 256;
-// kTraceBlock (threads per workgroup of the persistent ray kernels) is defined in dev_trace.h, which lays the lanes' traversal stacks out by it
-#ifndef LUM_TRACE_MIN_WAVES
-#define LUM_TRACE_MIN_WAVES 0  // experiment: register budget of the ray kernels as waves per SIMD (0: whatever one workgroup of kTraceBlock threads per CU allows)
-#endif
-#if LUM_TRACE_MIN_WAVES
-#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock, LUM_TRACE_MIN_WAVES)
-#else
-#define LUM_TRACE_BOUNDS __launch_bounds__(kTraceBlock)
-#endif
 #ifndef LUM_SHADE_WAVES
 #define LUM_SHADE_WAVES 3  // minimum waves per SIMD the shade kernel is compiled for (register budget 512 / waves); round 4: 3 for every sky mode, ocean and flavour (2 before: procedural sky -3.6 % / -10 % of the kernel's time fast / exact, ocean scenes -6 %)
 #endif
@@ -58,20 +46,6 @@ constexpr int kBlock = 256;
 #ifndef LUM_SHADE_WAVES_CONSTANT_SKY
 #define LUM_SHADE_WAVES_CONSTANT_SKY 3  // both flavours (round 4: the exact flavour's kernel at 3 waves - 168 registers, 8 spilled - instead of 2: -11.5 % of its time, +6 % samples/s)
 #endif
-
-LUM_DEV void flush_stats(uint64_t* counters, const RayStats& st, uint32_t rays, uint32_t ray_counter, uint32_t node_counter, uint32_t tri_counter,
-                         uint32_t lds_counter = kCntCount) {
-  // one atomic per wave and counter
-  uint32_t n = st.nodes, t = st.tris, r = rays, l = st.lds_nodes;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) { n += __shfl_down(n, off); t += __shfl_down(t, off); r += __shfl_down(r, off); l += __shfl_down(l, off); }
-  if ((threadIdx.x & 63) == 0) {
-    if (l && lds_counter != kCntCount) atomicAdd((unsigned long long*) &counters[lds_counter], (unsigned long long) l);
-    if (n) atomicAdd((unsigned long long*) &counters[node_counter], (unsigned long long) n);
-    if (t) atomicAdd((unsigned long long*) &counters[tri_counter], (unsigned long long) t);
-    if (r) atomicAdd((unsigned long long*) &counters[ray_counter], (unsigned long long) r);
-  }
-}
 
 // ---- tasks_create (cuda/kernels.cuh:45-193) + thin-lens camera (cuda/camera_thin_lens.cuh:8-86, cuda/camera.cuh:29-35) ----
 LUM_DEV void camera_ray(const DeviceScene& sc, const Sampler& smp, V3& origin, V3& ray) {
@@ -996,72 +970,7 @@ __global__ __launch_bounds__(kBlock) void k_light_query(DeviceScene sc, PathQueu
   flush_stats(counters, st, 0, kCntLightBvh, kCntNodesLight, kCntTrisLight);
 }
 
-// ---- visibility rays (optix/optix_kernel_shadow.cu:15-100, cuda/optix_anyhit.cuh:49-139) ----
-struct ShadowQuery : ShadowState {
-  ShadowQueue sq;
-  const uint32_t* order;
-  uint32_t out;
-  uint32_t item;  // LUM_PHASE_QUEUES: the queue entry load() read
-#if LUM_FAST
-  static constexpr uint32_t kMutableVecs = 1;
-  LUM_DEV void save_mutable(uint4* m) const { m[0] = make_uint4(fbits(tr), fbits(tg), fbits(tb), out); }
-  LUM_DEV void load_mutable(const uint4* m, float tmax) { tr = bitsf(m[0].x); tg = bitsf(m[0].y); tb = bitsf(m[0].z); out = m[0].w; dist = tmax; blocked = false; }
-#else
-  static constexpr uint32_t kMutableVecs = 2;
-  LUM_DEV void save_mutable(uint4* m) const {
-    const unsigned long long r = (unsigned long long) __double_as_longlong(tr), g = (unsigned long long) __double_as_longlong(tg), b = (unsigned long long) __double_as_longlong(tb);
-    m[0] = make_uint4((uint32_t) r, (uint32_t) (r >> 32), (uint32_t) g, (uint32_t) (g >> 32));
-    m[1] = make_uint4((uint32_t) b, (uint32_t) (b >> 32), out, 0u);
-  }
-  LUM_DEV void load_mutable(const uint4* m, float tmax) {
-    tr = __longlong_as_double((long long) ((unsigned long long) m[0].x | ((unsigned long long) m[0].y << 32)));
-    tg = __longlong_as_double((long long) ((unsigned long long) m[0].z | ((unsigned long long) m[0].w << 32)));
-    tb = __longlong_as_double((long long) ((unsigned long long) m[1].x | ((unsigned long long) m[1].y << 32)));
-    out = m[1].z; dist = tmax; blocked = false;
-  }
-#endif
-  LUM_DEV void save_const(uint4& c) const { c = make_uint4(tgt_inst, tgt_tri, self_inst, self_tri); }
-  LUM_DEV void load_const(uint4 c) { tgt_inst = c.x; tgt_tri = c.y; self_inst = c.z; self_tri = c.w; }
-  LUM_DEV void world_ray(const DeviceScene&, uint32_t j, V3& o, V3& d) const {
-    const float4 o4 = sq.origin_dist[j], d4 = sq.dir_out[j];
-    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z);
-  }
-  LUM_DEV bool load(const DeviceScene&, uint32_t slot, V3& o, V3& d, float& tmax) {
-    const uint32_t j = order ? order[slot] : slot;
-    item = j;
-    const float4 o4 = ld_stream(&sq.origin_dist[j]), d4 = ld_stream(&sq.dir_out[j]);
-    begin(ld_stream(&sq.ids[j]), o4.w);
-    out = fbits(d4.w);
-    o = v3(o4.x, o4.y, o4.z); d = v3(d4.x, d4.y, d4.z); tmax = o4.w;
-    return true;
-  }
-  LUM_DEV void finish(const DeviceScene&, uint32_t j) {
-    const Col v = result();
-#ifdef LUM_PHASE_STATS
-    { const uint32_t kind = min(out / sq.capacity, 3u); atomicAdd(&g_vis_stat[2u * kind], 1ull); if (blocked) atomicAdd(&g_vis_stat[2u * kind + 1u], 1ull); }
-#endif
-#ifdef LUM_EXPERIMENT_VIS_IN_ITEM_ORDER
-    sq.vis[j] = make_float4(v.r, v.g, v.b, 0.0f);
-#else
-    st_stream(&sq.vis[out], make_float4(v.r, v.g, v.b, 0.0f));
-#endif
-  }
-};
-
-__global__ LUM_TRACE_BOUNDS void k_shadow_rays(DeviceScene sc, ShadowQueue sq, const uint32_t* order, uint32_t* ctrl, uint64_t* counters, uint32_t lds_nodes) {
-  RayStats st{0, 0, 0};
-  uint32_t rays = 0;
-  ShadowQuery q;
-  q.sq = sq;
-  q.order = order;
-#if LUM_PHASE_QUEUES
-  trace_items_pool(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
-#else
-  LUM_TRACE_ITEMS(sc, ctrl[kCtlShadowItems], ctrl + kCtlShadowCursor, q, st, rays, lds_nodes);
-#endif
-  flush_stats(counters, st, rays, kCntShadow, kCntNodesShadow, kCntTrisShadow, kCntNodesLdsShadow);
-}
-
+// ---- visibility rays: kernel_shadow.h (its own translation unit in the fast flavour, see there) ----
 // ---- resolve: optix/optix_kernel_shadow.cu:15-100 sums sampled light, BSDF-sampled light, (sun,) ambient, then weights ----
 // kAmbientKnown: the ambient sample's visibility is `ambient_vis` (from the path's next closest hit) instead of the visibility pass's word.
 LUM_DEV bool resolves_here(uint32_t hit_type) {  // sky, and with volumes: scattering events and ended paths have nothing to resolve
