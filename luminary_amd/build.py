@@ -19,6 +19,11 @@ HIPCC = os.path.join(ROCM, "bin", "hipcc")
 HOST_SOURCES = ["host/scene.cpp", "host/bvh_build.cpp", "host/loaders.cpp", "host/api.cpp", "host/utils_api.cpp", "host/output.cpp"]
 EXTRA = os.environ.get("LUM_CXXFLAGS", "").split()
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# The HIP sources are compiled with -Os. Measured (profiles/r05_ab_experiments.txt, three interleaved repeats): 1.3 % off k_trace, 0.7 % off k_shade, 1.5 % off
+# k_shadow_rays = +1.0 % samples/s on the hall (scan +0.6 %, Example-class +0.8 %); -O2 half of that, -Oz loses 7 % in k_shade. Not an instruction-cache effect
+# (SQC_ICACHE_MISSES / SQC_ICACHE_REQ = 0.0000 for all three kernels under -O3): -Os simply emits fewer instructions on the executed paths (less speculation and
+# duplication of code around branches). It comes after -O3 on the command line and wins.
+HIP_OPT = os.environ.get("LUM_HIP_OPT", "-Os").split()
 EXACT = ["-ffp-contract=off", "-fno-fast-math"]  # the numerics contract of the exact flavour and of all host code
 # the fast flavour of the wavefront kernels (csrc/device/flavour.h): contraction, hardware reciprocal / sqrt, reciprocal-multiply for x / y.
 # -fapprox-func: without it 28 divisions of k_shade stay correctly rounded (v_div_scale / v_div_fmas / v_div_fixup with two denormal-mode
@@ -39,7 +44,7 @@ STAMP = os.path.join(LIB_DIR, "build_flags.txt")
 
 
 def _flags_identity():
-    return "\n".join(["common " + " ".join(COMMON), "exact " + " ".join(EXACT), "fast " + " ".join(FAST), "shadow " + " ".join(SHADOW_FLAGS), "extra " + " ".join(EXTRA)]) + "\n"
+    return "\n".join(["common " + " ".join(COMMON), "hip " + " ".join(HIP_OPT), "exact " + " ".join(EXACT), "fast " + " ".join(FAST), "shadow " + " ".join(SHADOW_FLAGS), "extra " + " ".join(EXTRA)]) + "\n"
 
 
 def _newer(target, sources):
@@ -99,7 +104,7 @@ def build(force=False, verbose=False, variant=None):
     def compile_hip(item):
         src, flags = item
         o = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
-        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, *flags, "-fno-slp-vectorize", *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", o])
+        out = _run([HIPCC, "--offload-arch=gfx950", *COMMON, *HIP_OPT, *flags, "-fno-slp-vectorize", *EXTRA, "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(CSRC, src), "-o", o])
         return o, out
 
     with ThreadPoolExecutor(max_workers=len(HIP_SOURCES)) as pool:
