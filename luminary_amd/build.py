@@ -34,12 +34,12 @@ if os.environ.get("LUM_FAST_FLAGS") is not None:  # diagnosis only (tools/flavou
     FAST = ["-DLUM_FAST=1"] + os.environ["LUM_FAST_FLAGS"].split()
 # -fno-slp-vectorize: the SLP vectoriser packs neighbouring f32 multiplies/adds into v_pk_* and pays for it with register
 # moves (19 of the 61 instructions of a triangle test); same arithmetic, measured 2 % faster without it
-# the fast flavour's visibility-ray kernel is a translation unit of its own: the max-ILP scheduler takes 3-4 % off it and costs the other kernels 1-2 %
+# each flavour's visibility-ray kernel is a translation unit of its own: the max-ILP scheduler takes 3-4 % off it and costs the other kernels 1-2 %
 # (csrc/device/kernel_shadow.h, profiles/r05_ab_experiments.txt); LUM_FAST_SHADOW_SCHED= (empty) in the environment builds it with the default scheduler
 SHADOW_SCHED = os.environ.get("LUM_FAST_SHADOW_SCHED", "max-ilp")
 SHADOW_FLAGS = (["-mllvm", "-amdgpu-sched-strategy=" + SHADOW_SCHED] if SHADOW_SCHED else [])
-HIP_SOURCES = [("host/core.hip", EXACT), ("host/lbvh.hip", EXACT), ("device/wavefront_fast.hip", FAST + ["-DLUM_SHADOW_KERNEL_EXTERN=1"]),
-               ("device/wavefront_fast_shadow.hip", FAST + SHADOW_FLAGS)]
+HIP_SOURCES = [("host/core.hip", EXACT + ["-DLUM_SHADOW_KERNEL_EXTERN=1"]), ("host/lbvh.hip", EXACT), ("device/wavefront_fast.hip", FAST + ["-DLUM_SHADOW_KERNEL_EXTERN=1"]),
+               ("device/wavefront_fast_shadow.hip", FAST + SHADOW_FLAGS), ("device/wavefront_exact_shadow.hip", EXACT + SHADOW_FLAGS)]
 STAMP = os.path.join(LIB_DIR, "build_flags.txt")
 
 

@@ -2,9 +2,9 @@
 // fast flavour compiles the kernel in ITS OWN translation unit (csrc/device/wavefront_fast_shadow.hip) with another instruction scheduler:
 // `-mllvm -amdgpu-sched-strategy=max-ilp` takes 3-4 % off k_shadow_rays (hall 180.2 -> 172.4 ms per 3 steps, scan 40.9 -> 39.8, Example-class 26.65 -> 25.8)
 // and ADDS 2.4 % to k_shade and 0.8 % to k_trace when applied to the whole flavour (profiles/r05_ab_experiments.txt) - the option is per translation unit.
-// LUM_SHADOW_KERNEL_EXTERN=1 (the fast flavour's main unit): the kernel is declared here and defined over there; the host stub and the code object come from
-// the defining unit, the launch and hipFuncSetAttribute in wavefront_table_impl.h go through the declaration. The exact flavour (core.hip) keeps the kernel
-// inline with the default scheduler.
+// LUM_SHADOW_KERNEL_EXTERN=1 (a flavour's main unit: wavefront_fast.hip, core.hip): the kernel is declared here and defined in wavefront_<flavour>_shadow.hip; the
+// host stub and the code object come from the defining unit, the launch and hipFuncSetAttribute in wavefront_table_impl.h go through the declaration. The
+// scheduler reorders instructions and changes none: the exact flavour's kernel stays bit-identical to the oracle.
 #pragma once
 
 #include "dev_trace.h"

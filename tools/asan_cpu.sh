@@ -11,7 +11,7 @@ for s in scene bvh_build loaders api utils_api output; do
       -c $ROOT/luminary_amd/csrc/host/$s.cpp -o $OUT/$s.o &
 done
 wait
-cp $ROOT/luminary_amd/lib/obj/embed.o $ROOT/luminary_amd/lib/obj/core.hip.o $ROOT/luminary_amd/lib/obj/lbvh.hip.o $ROOT/luminary_amd/lib/obj/wavefront_fast.hip.o $ROOT/luminary_amd/lib/obj/wavefront_fast_shadow.hip.o $OUT/
+cp $ROOT/luminary_amd/lib/obj/embed.o $ROOT/luminary_amd/lib/obj/core.hip.o $ROOT/luminary_amd/lib/obj/lbvh.hip.o $ROOT/luminary_amd/lib/obj/wavefront_fast.hip.o $ROOT/luminary_amd/lib/obj/wavefront_fast_shadow.hip.o $ROOT/luminary_amd/lib/obj/wavefront_exact_shadow.hip.o $OUT/
 ${ROCM_PATH:-/opt/rocm}/bin/hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address,undefined $OUT/*.o -lz -L ${ROCM_PATH:-/opt/rocm}/lib -lrccl -o $OUT/libluminary_amd.so
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0 UBSAN_OPTIONS=print_stacktrace=1 LUM_LIB=$OUT/libluminary_amd.so \
   python -m pytest $ROOT/tests -x -q -m "not gpu" --deselect $ROOT/tests/test_distributed_cpu.py
