@@ -2879,7 +2879,7 @@ int lumc_frame_assemble_all(LumContext** ctxs, int n, uint32_t frame_pixels, int
 // ---- tile gather: the frame assembled from the ranks' own pixels instead of a reduce over whole frames ----
 // Every pixel has one owner, so summing the ranks' zero-padded full frames (lumc_frame_assemble: 16 bytes per FRAME pixel from every rank, 133 MB per
 // rank at 4K) moves `world` times what is needed: a rank's contribution is the 16 bytes of each pixel it OWNS. Where the ranks' pixel sets are the tile
-// deal of lumc_tile_pixels (32 x 32 tiles dealt round-robin - what bench.py and the host API's tiled render loop use), every rank can compute every other
+// deal of lumc_tile_pixels (32 x 32 tiles dealt by lumc_tile_owner's lattice - what bench.py and the host API's tiled render loop use), every rank can compute every other
 // rank's pixel list, so nothing but the sums travels: each rank packs its [3][P] + [P] accumulators into a [4][M] buffer (M = the largest tile share,
 // zero padded: the deal is even to within one tile), ONE ncclGather brings the `world` buffers to the root, and a scatter kernel on the root puts every
 // value at its pixel. Reference: device_result_interface.c:107-299 (sample partition, sums staged through pinned host memory).
