@@ -405,3 +405,31 @@ def test_an_hdri_bake_of_another_size_leaves_the_gather_buffers_alone():
     finally:
         core.close()
     assert np.array_equal(first[0], second[0]) and np.array_equal(first[1], second[1])
+
+
+def test_the_deal_on_random_frames_and_rank_counts():
+    """Property test of the lattice deal (C library and Python twin): for random frame sizes, tile sizes and rank counts every pixel has exactly one owner, the
+    two implementations agree rank by rank, the share sizes sum to the frame, and no rank is more than two tiles short of the largest share."""
+    from hypothesis import given, settings, strategies as st
+    from luminary_amd.distributed import tile_owner, tile_share_counts
+
+    @settings(max_examples=60, deadline=None)
+    @given(w=st.integers(1, 700), h=st.integers(1, 500), world=st.integers(1, 16), tile=st.sampled_from([4, 8, 16, 32, 64]))
+    def check(w, h, world, tile):
+        seen = np.zeros(w * h, dtype=np.int32)
+        counts = []
+        for rank in range(world):
+            px = Core.tile_pixels(w, h, rank, world, tile)
+            assert np.array_equal(px, tile_pixels(w, h, rank, world, tile))
+            seen[px] += 1
+            counts.append(int(px.size))
+        assert (seen == 1).all()
+        assert counts == tile_share_counts(w, h, world, tile)
+        tx, ty = (w + tile - 1) // tile, (h + tile - 1) // tile
+        if tx >= world and ty >= world:  # frames of at least world x world tiles: the lattice gives every rank every row and column
+            i, j = np.meshgrid(np.arange(tx), np.arange(ty), indexing="xy")
+            owner = tile_owner(i, j, tx, world)
+            per_rank = np.bincount(owner.ravel(), minlength=world)
+            assert per_rank.max() - per_rank.min() <= max(tx, ty), "tile counts of the ranks differ by less than one row or column of tiles"
+
+    check()
