@@ -142,6 +142,10 @@ class Core:
         """Fast flavour with the ambient reuse: the resolve of a depth rides in the next depth's shading kernel (lumc_set_fused_resolve; default on)."""
         self._call("lumc_set_fused_resolve", C.c_int(1 if on else 0))
 
+    def set_sobol_table(self, on):
+        """The shading kernel reads a pass's Sobol / Owen pairs from a table written once per pass instead of hashing (lumc_set_sobol_table; default on; bit-identical)."""
+        self._call("lumc_set_sobol_table", C.c_int(1 if on else 0))
+
     def set_ambient_reuse(self, mode):
         """-1 by flavour (fast: on, exact: off), 0 off, 1 on - in the exact flavour the reuse then only takes what it can prove and stays bit-identical (lumc_set_ambient_reuse)"""
         self._call("lumc_set_ambient_reuse", C.c_int(mode))

@@ -436,7 +436,8 @@ LUM_DEV LocalFrame local_frame(const DeviceScene& sc, const GeoContext& g) {
 struct BounceSample { V3 ray; Col weight; bool transparent_pass, microfacet_based; };
 
 // Three-technique resampled bounce (bsdf.cuh:138-301). `set` picks RandomSet::BSDF<set> (random.cuh:120-129).
-LUM_DEV BounceSample sample_bounce(const LocalFrame& lf, const GeoContext& g, const Sampler& smp, uint32_t set) {
+template <class Smp>
+LUM_DEV BounceSample sample_bounce(const LocalFrame& lf, const GeoContext& g, const Smp& smp, uint32_t set) {
   const MatParams& p = g.params;
   BounceSample out;
   const float opacity = p.opacity();

@@ -104,8 +104,8 @@ LUM_DEV f2 tree_importance_pair(const GeoContext& g, f2 power, f2 mx, f2 my, f2 
 // Two thirds of the pass are the eight reservoirs' updates (ris.cuh:138-148, per child and lane: accept = r < p; r = clamp(accept ? r / p : (r - p) / (1 - p))).
 // Both quotients are formed for two lanes at a time with packed multiplies - they do not depend on the comparison - and the comparison only selects:
 // the same operations on the same operands as the one-lane-at-a-time form, in 5.5 instead of 8 instructions per child and lane.
-template <class Ctx>
-LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler& smp) {
+template <class Ctx, class Smp>
+LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Smp& smp) {
   const RootHeader hp = (RootHeader) sc.light_tree_root;
   const uint4 h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
   const uint32_t num_root_lights = h.y >> 16, num_children = ((h.z >> 16) & 0xFFu) * 8u;
@@ -169,8 +169,8 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Sampler
 struct TreePick { uint32_t light_id; float weight; };
 
 // Descent of one lane through the 8-wide nodes (light_tree.cuh:257-320).
-template <class Ctx>
-LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const Ctx& g, const Sampler& smp, uint32_t lane, const TreeWork& w) {
+template <class Ctx, class Smp>
+LUM_DEV TreePick tree_postpass(const DeviceScene& sc, const Ctx& g, const Smp& smp, uint32_t lane, const TreeWork& w) {
   const uint32_t cont = w.cont[lane];
   const float cp = (cont >> 9) * (1.0f / 1048575.0f) * kLightTreeOutputs;
   TreePick r;
@@ -329,7 +329,8 @@ struct LightDirSample { V3 ray; Col weight; float probability; };
 LUM_DEV float light_dir_roughness(float r) { return lerpf(r, 1.0f, 0.04f); }
 LUM_DEV float light_dir_rr(float r) { return remap01(r, 0.5f, 0.1f); }
 
-LUM_DEV LightDirSample sample_light_direction(const LocalFrame& lf, const GeoContext& g, const Sampler& smp) {
+template <class Smp>
+LUM_DEV LightDirSample sample_light_direction(const LocalFrame& lf, const GeoContext& g, const Smp& smp) {
   LightDirSample out;
   out.ray = v3(0.0f, 0.0f, 1.0f); out.weight = splat(0.0f); out.probability = 0.0f;
   const MatParams& p = g.params;
@@ -419,7 +420,8 @@ LUM_DEV float light_direction_probability_terms(const MatParams& p, V3 Vl, const
 // ---- light sampling (light.cuh:84-159) ----
 struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum; };
 
-LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Sampler& smp, ShadeClock& clock, const StagedLights& staged) {
+template <class Smp>
+LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Smp& smp, ShadeClock& clock, const StagedLights& staged) {
   LUM_STAT(14, 15);
   const TreeWork work = tree_prepass(sc, g, smp);
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));

@@ -61,10 +61,24 @@ LUM_DEV float clamp_random(float r) { return fminf(fmaxf(r, 0.0f), bitsf(0x3F7FF
 #ifndef LUM_SCALAR_SOBOL
 #define LUM_SCALAR_SOBOL 0  // measured (profiles/r05_ab_experiments.txt): k_shade +0.5 ... +3 % - off
 #endif
-struct Sampler {
+// The pass's Sobol table (round 5): the Sobol / Owen part of a random number is a function of (sample id, dimension) alone, and a pass of lumc_render holds a few
+// dozen consecutive sample ids and (depths x kRndTargetCount) dimensions. k_sobol_table (kernels.h) writes all of them once per pass - a megabyte - and the
+// k_shade<..., kTable = true> instances read the pair they want (the lanes of a wave mostly ask for one line) instead of running three Laine-Karras hashes per
+// number. Same integer function, so not a bit changes; the exact flavour's parity tests run through the table. Passes without one (the adaptive sampler's, whose
+// ids differ by pixel; the undersampling preview; more than kSobolTableMaxSamples ids; LUM_SOBOL_TABLE_RT=0) launch the kTable = false instances, which hold no
+// table code. Measured (profiles/r05_ab_experiments.txt): k_shade -4.7 %, +2.2 % samples/s on the hall; one kernel with a run-time branch between the two forms
+// gained half of that and lost 3 % when the hash ran.
+constexpr uint32_t kSobolTableMaxSamples = 256u;  // sample ids per pass a table is built for (11 MB at 8 bounces); larger passes hash
+template <bool kTable>
+struct SamplerT {
   const uint32_t* bluenoise;
   uint32_t px, py, sample_id, depth;
   bool uniform = false;  // every active lane of the wave holds this sample id (detect_uniform(); wave-uniform)
+  const uint8_t* table = nullptr;  // kTable: this depth's slab of the pass's table, rows of table_row bytes per target (wave-uniform)
+  uint32_t table_row = 0, table_lane = 0;  // bytes per row; this lane's byte offset in a row (8 x (sample id - the pass's first))
+  LUM_DEV void use_table(const uint2* slab, uint32_t stride, uint32_t first_sample) {
+    if (kTable) { table = (const uint8_t*) slab; table_row = stride * 8u; table_lane = (sample_id - first_sample) * 8u; }
+  }
   LUM_DEV void detect_uniform() {
 #if LUM_SCALAR_SOBOL
     uniform = __ballot(sample_id != (uint32_t) __builtin_amdgcn_readfirstlane((int) sample_id)) == 0ull;
@@ -86,6 +100,11 @@ struct Sampler {
     }
     else
 #endif
+    if (kTable && d == depth) {
+      const uint2 t = *(const uint2*) (table + (size_t) target * table_row + table_lane);
+      q = U2{t.x, t.y};
+    }
+    else
       q = sobol_owen(sample_id, dim);
     const uint32_t ox = (1u + dim) * 3242174889u, oy = (1u + dim) * 2447445413u;
     const uint32_t texel = bluenoise[((x + (ox >> 24)) & 0xFFu) + ((y + (oy >> 24)) & 0xFFu) * 256u];
@@ -96,5 +115,6 @@ struct Sampler {
   LUM_DEV F2 next2(uint32_t target) const { const U2 q = raw2(target); return F2{unit_float(q.x), unit_float(q.y)}; }
   LUM_DEV float next1(uint32_t target) const { return unit_float(raw2(target).x); }
 };
+using Sampler = SamplerT<false>;
 
 LUM_NS_END

@@ -190,6 +190,10 @@ struct DeviceScene {
   // entries beyond the LDS ones. Null in other builds.
   uint4* pool_state;
   unsigned long long* pool_stack;
+  // the pass's Sobol / Owen table (dev_sampler.h LUM_SOBOL_TABLE, k_sobol_table): entry (dimension, sample) at [dimension * sobol_stride + (sample - sobol_first)],
+  // dimensions 0 .. (max_ray_depth + 1) * kRndTargetCount - 1; nullptr in passes without one (set per pass on the host's copy, wavefront_depths)
+  const uint2* sobol_table;
+  uint32_t sobol_first, sobol_count, sobol_stride;
 };
 
 // Path state, one entry per live path, structure-of-arrays of 16-byte words (coalesced 16 B/lane accesses).

@@ -575,7 +575,8 @@ LUM_DEV float sun_bsdf_pdf(const GeoContext& g, V3 L, float reflection_prob, flo
 }
 // direct_lighting_sun_create_task + direct_lighting_sun_direct: two candidate directions (BSDF sample, sun solid angle), one kept by
 // resampling. Returns false when there is nothing to trace.
-LUM_DEV bool sample_sun(const DeviceScene& sc, const SkyView& sky, const LocalFrame& lf, const GeoContext& g, const Sampler& smp, Col& light_out, V3& dir_out) {
+template <class Smp>
+LUM_DEV bool sample_sun(const DeviceScene& sc, const SkyView& sky, const LocalFrame& lf, const GeoContext& g, const Smp& smp, Col& light_out, V3& dir_out) {
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));  // bsdf_evaluate analyses the direction in world space, like sample_light
   const V3 sky_pos = world_to_sky(sky, g.position);
   const bool sun_below_horizon = sph_hit_p0(normalize(sky.sun_pos - sky_pos), sky_pos, kSkyEarthRadius);

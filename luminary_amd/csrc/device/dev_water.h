@@ -114,8 +114,8 @@ LUM_DEV CausticsDomain caustics_get_domain(const DeviceScene& sc, const SkyView&
   d.area = length(cross(d.edge1, d.edge2));
   return d;
 }
-template <class Ctx>
-LUM_DEV bool caustics_find_connection_point(const DeviceScene& sc, const SkyView& sky, const Ctx& c, const Sampler& smp, uint32_t rnd_initial, const CausticsDomain& d,
+template <class Ctx, class Smp>
+LUM_DEV bool caustics_find_connection_point(const DeviceScene& sc, const SkyView& sky, const Ctx& c, const Smp& smp, uint32_t rnd_initial, const CausticsDomain& d,
                                             uint32_t iteration, uint32_t num_iterations, V3& point, float& sample_weight) {  // caustics.cuh:125-163, refraction
   if (d.fast_path) { point = d.base; sample_weight = d.area; return true; }
   const F2 r = smp.next2(rnd_initial + iteration);
@@ -133,8 +133,8 @@ LUM_DEV bool caustics_find_connection_point(const DeviceScene& sc, const SkyView
   return true;
 }
 // direct_lighting_sun_caustic; `set`: the context's LIGHT_SUN random set (0 surface / particle, 1 volume)
-template <class Ctx>
-LUM_DEV bool sun_caustic_sample(const DeviceScene& sc, const SkyView& sky, const Ctx& c, const Sampler& smp, uint32_t set, uint32_t volume_type, uint32_t second_volume,
+template <class Ctx, class Smp>
+LUM_DEV bool sun_caustic_sample(const DeviceScene& sc, const SkyView& sky, const Ctx& c, const Smp& smp, uint32_t set, uint32_t volume_type, uint32_t second_volume,
                                 Col& light_out, V3& dir_out) {
   const uint32_t rnd_initial = 81u + 128u * set, rnd_resampling = 338u + set, rnd_sun_ray = 341u + set;  // CAUSTIC_INITIAL / _RESAMPLING / _SUN_RAY
   const V3 sky_pos = world_to_sky(sky, c.position);

@@ -378,7 +378,7 @@ LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const Ne
 // cannot decide (`fallback`: their ambient ray is queued into its own item arrays, traced by a small second pass, resolved by k_resolve_listed - for those
 // the vertex's sum lands after the next depth's emission: the fast flavour's rounding, not the exact flavour's, which never runs this).
 // (struct FusedResolve: dev_scene.h)
-template <uint32_t kSkyMode, bool kWater, int kStage = 0>
+template <uint32_t kSkyMode, bool kWater, int kStage = 0, bool kTable = false>
 __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kStage == 2 ? LUM_SHADE_STAGE2_WAVES : (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse, const FusedResolve* __restrict__ fused_dev,
                                                                     uint32_t fused_flags) {
@@ -551,8 +551,9 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         if (kStage != 1) vertices++;
         const V3 origin = v3(o4.x, o4.y, o4.z), ray = v3(d4.x, d4.y, d4.z);
         const V3 hit_origin = origin + ray * o4.w;
-        Sampler smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
+        SamplerT<kTable> smp{sc.bluenoise_2d, hid.z & 0xFFFFu, hid.z >> 16, path_sample_id(hid.w), depth_const};
         smp.detect_uniform();
+        smp.use_table(sc.sobol_table + (size_t) depth_const * kRndTargetCount * sc.sobol_stride, sc.sobol_stride, sc.sobol_first);  // (kTable: the pass has one)
         const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i] & kHitTriMask, aux.z);
         // the volume the vertex is in: without an ocean the stack holds the fog or nothing for the whole path
         const uint32_t top_volume = kWater ? volume_stack_peek(hid.w, false) : (sc.fog_active ? (uint32_t) kVolumeFog : (uint32_t) kVolumeNone);
@@ -2155,6 +2156,15 @@ __global__ LUM_TRACE_BOUNDS void k_trace_rays(DeviceScene sc, uint32_t n, const 
   q.origins = origins; q.dirs = dirs; q.ignore = ignore; q.out = out;
   LUM_TRACE_ITEMS(sc, n, cursor, q, st, rays, lds_nodes);
   flush_stats(counters, st, rays, kCntTrace, kCntNodes, kCntTris, kCntNodesLds);
+}
+
+// The Sobol / Owen pairs of one pass (dev_sampler.h LUM_SOBOL_TABLE): one thread per (dimension, sample id).
+__global__ __launch_bounds__(256) void k_sobol_table(uint2* __restrict__ table, uint32_t first_sample, uint32_t count, uint32_t stride, uint32_t dims) {
+  const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t dim = t / stride, s = t - dim * stride;
+  if (dim >= dims || s >= count) return;
+  const U2 q = sobol_owen(first_sample + s, dim);
+  table[t] = make_uint2(q.x, q.y);
 }
 
 #if !LUM_FAST  // flavour-neutral: compiled once, in the exact translation unit

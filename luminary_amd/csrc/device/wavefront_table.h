@@ -17,6 +17,8 @@ struct WavefrontKernels {
   int (*set_ray_kernel_lds)(size_t bytes);
   // fills this flavour's table of sampler seeds on the current device (dev_sampler.h); returns a hipError_t
   int (*init_sampler_seeds)();
+  // the Sobol / Owen pairs of a pass's sample ids for `dims` dimensions, rows of `stride` entries (dev_sampler.h LUM_SOBOL_TABLE)
+  void (*sobol_table)(hipStream_t s, uint2* table, uint32_t first_sample, uint32_t count, uint32_t stride, uint32_t dims);
   void (*generate)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count);
   void (*generate_adaptive)(uint32_t grid, hipStream_t s, const DeviceScene& sc, const AdaptiveView& a, const AdaptivePass& pass, const PathQueue& q, float4* results,
                             uint32_t* count);

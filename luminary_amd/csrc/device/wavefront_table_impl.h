@@ -33,6 +33,9 @@ static int init_sampler_seeds() {
   }
   return (int) hipMemcpyToSymbol(HIP_SYMBOL(g_sampler_seeds), seeds.data(), sizeof(uint32_t) * kSeedTableSize);
 }
+static void sobol_table(hipStream_t s, uint2* table, uint32_t first_sample, uint32_t count, uint32_t stride, uint32_t dims) {
+  hipLaunchKernelGGL(k_sobol_table, dim3((dims * stride + 255u) / 256u), dim3(256), 0, s, table, first_sample, count, stride, dims);
+}
 static void generate(uint32_t grid, hipStream_t s, const DeviceScene& sc, const PassParams& pp, const PathQueue& q, float4* results, uint32_t* count) {
   hipLaunchKernelGGL(k_generate, dim3(grid), dim3(kBlock), 0, s, sc, pp, q, results, count);
 }
@@ -61,6 +64,10 @@ static void shade(uint32_t grid, hipStream_t s, const DeviceScene& sc, const Pat
 #else
   auto* k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false> : k_shade<kSkyConstantColor, false>;
   if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true> : k_shade<kSkyConstantColor, true>;
+  if (sc.sobol_table) {  // the pass has a Sobol table (dev_sampler.h): the instances that read it instead of hashing
+    k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, false, 0, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, false, 0, true> : k_shade<kSkyConstantColor, false, 0, true>;
+    if (sc.ocean_active) k = sc.sky_mode == kSkyDefault ? k_shade<kSkyDefault, true, 0, true> : sc.sky_mode == kSkyHdri ? k_shade<kSkyHdri, true, 0, true> : k_shade<kSkyConstantColor, true, 0, true>;
+  }
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), 0, s, sc, in, out, nee, sq, results, ctrl, depth_const, counters, ambient_reuse, fused_dev, fused_flags);
 #endif
 }
@@ -136,7 +143,7 @@ static void trace_rays(uint32_t grid, size_t lds, hipStream_t s, const DeviceSce
   hipLaunchKernelGGL(k_trace_rays, dim3(grid), dim3(kTraceBlock), lds, s, sc, n, origins, dirs, ignore, out, cursor, counters, lds_nodes);
 }
 
-static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, init_sampler_seeds, generate,    generate_adaptive, trace,  sky_inscattering, shade,
+static const WavefrontKernels kTable = {LUM_FLAVOUR_NAME, (uint32_t) kTraceBlock, set_ray_kernel_lds, init_sampler_seeds, sobol_table, generate,    generate_adaptive, trace,  sky_inscattering, shade,
                                         shade_debug,      sky,              light_query,        shadow_rays, resolve, resolve_reuse, resolve_listed, resolve_ended, LUM_FAST && !LUM_SHADE_STAGED, volume_inscatter, volume_resolve, volume_events, volume_bounce, trace_particles, particle_shade, trace_ocean, ocean_shade, clouds_list, clouds_march, clouds, trace_rays};
 
 }  // namespace table

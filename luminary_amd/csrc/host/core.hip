@@ -60,6 +60,9 @@ struct LumContext {
   void* fused_block = nullptr;    // what that needs beyond the usual work buffers: a third path queue, the parent words, a second set of NEE records, the fallback rays' items
   bool fused_records_stale = false;  // a queue's planes changed places (ray-sorting mode 3) since the records were written
   uint32_t fused_capacity = 0, fused_refused_capacity = 0;  // (the capacity its allocation last failed for: not tried again)
+  uint2* d_sobol = nullptr;         // the pass's Sobol / Owen table (dev_sampler.h LUM_SOBOL_TABLE; wavefront_depths fills it)
+  size_t sobol_entries = 0;
+  int sobol_table = 1;              // LUM_SOBOL_TABLE_RT=0: the sampler hashes every number itself
   uint32_t* d_ended = nullptr;      // a depth's vertices that no entry continues (k_shade lists them, k_resolve_ended resolves them)
   FusedResolve* d_fused = nullptr;  // six records in device memory: the previous depth's queue (three buffers) and NEE records (two) by depth % 6
   NeeQueue nee2{};
@@ -283,6 +286,8 @@ void free_work(LumContext* ctx) {
   // the reorder pass's planes (ray-sorting mode 3) trade places with the queues' own: they go with them
   for (int k = 0; k < 4; k++) { if (ctx->sort_planes[k]) (void) hipFree(ctx->sort_planes[k]); ctx->sort_planes[k] = nullptr; }
   ctx->sort_queue = PathQueue{}; ctx->sort_queue_capacity = 0;
+  if (ctx->d_sobol) (void) hipFree(ctx->d_sobol);
+  ctx->d_sobol = nullptr; ctx->sobol_entries = 0;
 }
 
 int ensure_work(LumContext* ctx, uint32_t paths) {
@@ -622,6 +627,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_AMBIENT_REUSE")) ctx->ambient_reuse = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("LUM_FUSED_RESOLVE")) ctx->fused_resolve = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("LUM_SHADE_GRID")) ctx->shade_grid_rounds = (uint32_t) atoi(e);
+  if (const char* e = getenv("LUM_SOBOL_TABLE_RT")) ctx->sobol_table = atoi(e) != 0 ? 1 : 0;
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -1842,9 +1848,26 @@ static bool ambient_reuse_active(const LumContext* ctx) {
 }
 
 // The depth loop of one wavefront pass over the paths k_generate* left in queue[0] (at most N of them, counted on the device).
-static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N) {
-  const DeviceScene& sc = ctx->scene;
+// `first_sample`, `sample_count`: the pass's sample ids when they are one contiguous range for every pixel (lumc_render), 0 otherwise.
+static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N, uint32_t first_sample = 0, uint32_t sample_count = 0) {
+  DeviceScene sc = ctx->scene;
   const uint32_t max_depth = sc.max_ray_depth;
+  sc.sobol_table = nullptr;
+  if (ctx->sobol_table && sample_count > 0 && sample_count <= kSobolTableMaxSamples && sc.shading_mode == 0u) {
+    // the Sobol / Owen pairs of this pass's sample ids for every dimension k_shade can ask for (dev_sampler.h LUM_SOBOL_TABLE): 1.3 MB at 32 ids and 8 bounces
+    const uint32_t stride = (sample_count + 15u) & ~15u, dims = (max_depth + 1u) * kRndTargetCount;
+    const size_t entries = (size_t) stride * dims;
+    if (ctx->sobol_entries < entries) {
+      if (ctx->d_sobol) (void) hipFree(ctx->d_sobol);
+      ctx->d_sobol = nullptr; ctx->sobol_entries = 0;
+      if (hipMalloc((void**) &ctx->d_sobol, entries * sizeof(uint2)) == hipSuccess) ctx->sobol_entries = entries;
+      else (void) hipGetLastError();  // no room: the sampler hashes
+    }
+    if (ctx->d_sobol) {
+      ctx->wf->sobol_table(stream, ctx->d_sobol, first_sample, sample_count, stride, dims);
+      sc.sobol_table = ctx->d_sobol; sc.sobol_first = first_sample; sc.sobol_count = sample_count; sc.sobol_stride = stride;
+    }
+  }
   const size_t lds_dyn = (size_t) ctx->lds_nodes * kNodeBytes + LUM_LDS_STACK_BYTES;
   int cur = 0;
   const WavefrontKernels& wf = *ctx->wf;
@@ -2042,7 +2065,7 @@ int lumc_render(LumContext* ctx, uint32_t first_sample, uint32_t num_samples, ui
       Launch l(ctx, stream, LUMC_KERNEL_GENERATE);
       ctx->wf->generate(grid_for(N), stream, sc, pp, ctx->queue[0], ctx->d_results, ctx->d_ctrl + kCtlPaths);
     }
-    if (wavefront_depths(ctx, stream, N)) return 1;
+    if (wavefront_depths(ctx, stream, N, first_sample + done, batch)) return 1;
     {
       Launch l(ctx, stream, LUMC_KERNEL_ACCUMULATE);
       hipLaunchKernelGGL(k_accumulate, dim3(grid_for(P)), dim3(kBlock), 0, stream, (const float4*) ctx->d_results, P, batch, d_fm, d_sm);
@@ -3162,6 +3185,11 @@ int lumc_set_flavour(LumContext* ctx, int flavour) {
 int lumc_set_fused_resolve(LumContext* ctx, int on) {
   if (!ctx) return 1;
   ctx->fused_resolve = on != 0 ? 1 : 0;
+  return 0;
+}
+int lumc_set_sobol_table(LumContext* ctx, int on) {
+  if (!ctx) return 1;
+  ctx->sobol_table = on != 0 ? 1 : 0;
   return 0;
 }
 int lumc_set_ambient_reuse(LumContext* ctx, int mode) {
