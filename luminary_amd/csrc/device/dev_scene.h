@@ -298,7 +298,8 @@ enum CtrlWord : uint32_t {
   kCtlVolumeShift = 16u, kCtlVolumeShadowItems = kCtlShadowItems + kCtlVolumeShift, kCtlVolumeShadowCursor = kCtlShadowCursor + kCtlVolumeShift,
   kCtlVolumeItems = 2u * LUM_CTL_LINE + 2u,
   kCtlParticleCursor = LUM_CTL_LINE + 8u,  // work cursor of the particle pass of the closest-hit kernel (8 words, like the other cursors)
-  kCtlCloudItems = 2u * LUM_CTL_LINE + 3u, kCtlCloudCursor = LUM_CTL_LINE + 24u  // the cloud marches of a depth: their number and the persistent kernel's cursor
+  kCtlCloudItems = 2u * LUM_CTL_LINE + 3u, kCtlCloudCursor = LUM_CTL_LINE + 24u,  // the cloud marches of a depth: their number and the persistent kernel's cursor
+  kCtlShadeCursor = 3u * LUM_CTL_LINE + 16u  // k_shade's input cursor (LUM_SHADE_DYNAMIC, kernels.h): its waves take the depth's queue entries in chunks
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 

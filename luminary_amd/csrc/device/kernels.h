@@ -378,6 +378,10 @@ LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const Ne
 // cannot decide (`fallback`: their ambient ray is queued into its own item arrays, traced by a small second pass, resolved by k_resolve_listed - for those
 // the vertex's sum lands after the next depth's emission: the fast flavour's rounding, not the exact flavour's, which never runs this).
 // (struct FusedResolve: dev_scene.h)
+#ifndef LUM_SHADE_DYNAMIC
+#define LUM_SHADE_DYNAMIC (!LUM_SHADE_STAGED)  // k_shade's waves take their input through a cursor (the staged experiment's two kernels would share it: fixed shares there)
+#endif
+constexpr uint32_t kShadeChunkRounds = 16u;  // x 64 queue entries per bump of the cursor at most: ~45 000 atomics on the word per launch of 42 M entries
 template <uint32_t kSkyMode, bool kWater, int kStage = 0, bool kTable = false>
 __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kStage == 2 ? LUM_SHADE_STAGE2_WAVES : (kSkyMode == kSkyConstantColor && !kWater) ? LUM_SHADE_WAVES_CONSTANT_SKY : LUM_SHADE_WAVES) void k_shade(DeviceScene sc, PathQueue in, PathQueue out, NeeQueue nee, ShadowQueue sq, float4* results,
                                                                     uint32_t* ctrl, uint32_t depth_const, uint64_t* counters, uint32_t ambient_reuse, const FusedResolve* __restrict__ fused_dev,
@@ -396,7 +400,29 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   const bool lights_present = sc.light_tree_root != nullptr && sc.num_lights > 0;
   const Col sky = (sc.sky_mode == kSkyConstantColor) ? col(sc.sky_constant_color[0], sc.sky_constant_color[1], sc.sky_constant_color[2]) : splat(0.0f);
   uint32_t vertices = 0;
+#if LUM_SHADE_DYNAMIC
+  // Input by cursor: a wave takes the depth's queue entries in chunks through one atomic per chunk, fetched a chunk ahead, until the queue is used up. With a
+  // fixed share per wave (the grid-stride loop below) every wave of the grid ends on a partial batch of surface hits - one batch time per wave, 0.4 ms of a
+  // 12.7 ms launch with 8 workgroups per resident place, measured as the intercept of time against pass size - and the more waves, the better the balance: with
+  // the cursor the balance is the cursor's and the grid is the resident set (core.hip shade_grid). Chunks are guided: half of an equal share of what is left
+  // (as far as the wave has seen the cursor), between 1 and kShadeChunkRounds rounds of 64 entries - long chunks while the queue is long (few atomics on one
+  // word), single rounds at its end and in the short queues of deep depths, where a fixed 16 rounds left most of the chip without work (measured: +8 % on the
+  // scan's and the Example-class scene's k_shade).
+  uint32_t* const cursor = ctrl + kCtlShadeCursor;
+  const uint32_t share_div = gridDim.x * (kBlock / 64u) * 2u * 64u;  // entries per round and wave, twice
+  auto guided = [&](uint32_t seen) -> uint32_t { return 64u * min(max((seen < n ? n - seen : 0u) / share_div, 1u), kShadeChunkRounds); };
+  uint32_t chunk_len = guided(0u), next_len = chunk_len;
+  uint32_t grabbed = 0u;  // lane 0: the chunk after next (the atomic's result is only looked at when the current chunk ends)
+  if (lane == 0u) grabbed = atomicAdd(cursor, chunk_len);
+  uint32_t chunk = (uint32_t) __builtin_amdgcn_readfirstlane((int) grabbed), chunk_round = 0u;
+  // a workgroup that only starts when the queue is used up (the grid is a little larger than the resident set, so that every place is taken from the start
+  // wherever the dispatcher puts the workgroups) leaves before it stages anything
+  if (!__syncthreads_or((int) (chunk < n))) return;
+  next_len = guided(chunk + chunk_len);
+  if (lane == 0u) grabbed = atomicAdd(cursor, next_len);
+#else
   const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+#endif
   // Paths that left the scene only add the sky term; the surface vertices are two orders of magnitude more work. A wave therefore
   // collects the indices of its surface hits in LDS and shades them 64 at a time, so that misses do not leave lanes idle during the
   // expensive part (the reference sorts tasks by hit type for the same reason, cuda/kernels.cuh:391-484).
@@ -423,13 +449,36 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   // fused resolve: an entry's parent word and slot are fetched one round ahead (two registers across the batch in between: one dependent round trip less per round)
   uint32_t parent_ahead = 0u, slot_ahead = 0u;
   if (resolve_parents) {
+#if LUM_SHADE_DYNAMIC
+    const uint32_t i0 = chunk + lane;
+#else
     const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
+#endif
     if (i0 < n) { parent_ahead = in.parent[i0]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i0])[3]); }
   }
   for (uint32_t round = 0;; round++) {
+#if LUM_SHADE_DYNAMIC
+    const bool input_done = chunk >= n;
+#else
     const bool input_done = round >= rounds;
+#endif
     if (!input_done) {
+#if LUM_SHADE_DYNAMIC
+      const uint32_t i = chunk + chunk_round * 64u + lane;
+      if (++chunk_round * 64u == chunk_len) {  // on to the chunk fetched ahead, and one more on its way
+        chunk_round = 0u;
+        chunk = (uint32_t) __builtin_amdgcn_readfirstlane((int) grabbed);
+        chunk_len = next_len;
+        next_len = guided(chunk + chunk_len);
+        if (lane == 0u) grabbed = atomicAdd(cursor, next_len);
+      }
+      const uint32_t i_ahead = chunk + chunk_round * 64u + lane;  // (>= n once the queue is used up)
+      const bool have_ahead = true;
+#else
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      const uint32_t i_ahead = ((round + 1u) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
+      const bool have_ahead = round + 1u < rounds;
+#endif
       bool is_hit = false, is_sky = false;
       if (resolve_parents) {  // the vertex this entry continues: its sum, before the entry's own emission or sky term
         const FusedResolve& fused = *fused_dev;
@@ -438,8 +487,7 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
         const uint32_t p = parent_ahead, slot = slot_ahead;
         {
-          const uint32_t i_ahead = ((round + 1u) * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
-          if (round + 1u < rounds && i_ahead < n) { parent_ahead = in.parent[i_ahead]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i_ahead])[3]); }
+          if (have_ahead && i_ahead < n) { parent_ahead = in.parent[i_ahead]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i_ahead])[3]); }
         }
         if (i < n) {
           ip = p & kParentMask;

@@ -55,7 +55,7 @@ struct LumContext {
   bool has_scene = false;
   uint64_t bvh_stats[4] = {0, 0, 0, 0};
   int ambient_reuse = -1;         // -1 by flavour (fast: on), 0 off, 1 on (lumc_set_ambient_reuse; LUM_AMBIENT_REUSE)
-  uint32_t shade_grid_rounds = 8;  // k_shade's grid as a multiple of its resident set (0: the common 2048-workgroup cap); LUM_SHADE_GRID
+  uint32_t shade_grid_rounds = LUM_SHADE_DYNAMIC ? 2 : 8;  // k_shade's grid as a multiple of its resident set (0: the common 2048-workgroup cap); LUM_SHADE_GRID
   int fused_resolve = 1;          // with the fast flavour's ambient reuse: k_shade resolves the previous depth's vertices itself (lumc_set_fused_resolve; LUM_FUSED_RESOLVE)
   void* fused_block = nullptr;    // what that needs beyond the usual work buffers: a third path queue, the parent words, a second set of NEE records, the fallback rays' items
   bool fused_records_stale = false;  // a queue's planes changed places (ray-sorting mode 3) since the records were written
@@ -413,8 +413,16 @@ inline uint32_t shade_grid(const LumContext* ctx, uint32_t n) {
   const uint32_t blocks = (n + kBlock - 1) / kBlock;
   const uint32_t resident = ctx->trace_blocks * 3u;  // trace_blocks = the device's CUs (one persistent ray workgroup each)
   // (not with an ocean: k_shade<.., ocean> keeps a scratch frame and its workgroups cost more to start - Example-class scene with an ocean, 8 rounds: shade +2 %)
+#if LUM_SHADE_DYNAMIC
+  // input by cursor (kernels.h): twice the resident set. The second half only starts when the queue is used up and leaves at once; what it buys is that every
+  // place is taken from the start (hall, k_shade per 3 steps: fixed shares 345 ms | cursor, 1 x resident 337 | 2 x: 333 | 3 x: 331 | 4 x: 332; the scan and
+  // the Example-class scene, whose launches are short, are level at 1-2 x and lose 3-5 % at 3-4 x: profiles/r05_ab_experiments.txt). LUM_SHADE_GRID=<rounds>.
+  const uint32_t rounds = ctx->shade_grid_rounds;
+  const uint32_t cap = resident * (rounds ? rounds : 1u);
+#else
   const uint32_t rounds = ctx->scene.ocean_active ? 0u : ctx->shade_grid_rounds;
   const uint32_t cap = rounds ? resident * rounds : 2048u;
+#endif
   return blocks < 1 ? 1 : std::min(blocks, cap);
 }
 

@@ -81,7 +81,7 @@ def test_register_budgets_of_the_hot_kernels():
         assert table[k]["occ"] == 4 and table[k]["vgpr"] <= 128 and table[k]["spill"] <= 16, (k, table[k])
     for with_table in ("true", "false"):  # constant sky, no ocean, the whole vertex in one kernel (stage 0: the product); with the pass's Sobol table and hashing
         shade = table["lum::fast::k_shade<2u, false, 0, %s>" % with_table]
-        assert shade["occ"] == 3 and shade["spill"] <= 8, shade
+        assert shade["occ"] == 3 and shade["spill"] <= 12, shade  # (10 with the input cursor's four wave-uniform words; measured faster all the same)
     assert table["lum::fast::k_clouds"]["occ"] == 4
     for k, r in table.items():
         if k.startswith("lum::fast::k_") and "occ" in r:
