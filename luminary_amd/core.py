@@ -140,7 +140,7 @@ class Core:
 
     def set_fused_resolve(self, on):
         """Fast flavour with the ambient reuse: the resolve of a depth rides in the next depth's shading kernel (lumc_set_fused_resolve; default on)."""
-        self._call("lumc_set_fused_resolve", C.c_int(1 if on else 0))
+        self._call("lumc_set_fused_resolve", C.c_int(int(on)))  # (2: with k_resolve_ended as a kernel of its own)
 
     def set_sobol_table(self, on):
         """The shading kernel reads a pass's Sobol / Owen pairs from a table written once per pass instead of hashing (lumc_set_sobol_table; default on; bit-identical)."""

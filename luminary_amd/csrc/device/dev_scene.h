@@ -237,6 +237,7 @@ struct FusedResolve {
   NeeQueue nee_prev;     // its NEE records
   ShadowQueue fallback;  // item arrays of the undecided samples' rays; vis = the visibility words of depth d - 1, light_items = the list of their vertices
   uint32_t* ended;       // out: the vertices of depth d that no entry of depth d + 1 continues (counted in kCtlSkyItems: the procedural sky's list does not exist in this mode)
+  const uint32_t* ended_prev;  // in: that list of depth d - 1 (the other of two buffers): k_shade of depth d resolves them after its own entries (fused_flags & 4)
 };
 
 // What the fog scatters into the rays of one depth (k_volume_inscatter -> visibility rays -> k_volume_resolve), indexed like the path queue.

@@ -374,7 +374,8 @@ LUM_DEV void resolve_vertex(const DeviceScene& sc, const PathQueue& in, const Ne
 // path entry knows the vertex it continues (PathQueue::parent, written with the survivor) and, before anything else touches its result slot, forms that
 // vertex's sum from the previous depth's records (`nee_prev`, `prev`: the queues of three and the NEE records of two depths are kept) and its own closest
 // hit's word - the same loads, now under the other waves' candidate loops. The per-path order of the sums is the usual one (vertex d - 1, then emission or sky of
-// depth d). What stays outside: vertices whose path ended (k_resolve_ended after the depth's visibility pass: no entry continues them) and samples the hit
+// depth d). Vertices whose path ended have no entry: k_shade lists them, and the next depth's k_shade takes the list as further input (fused_flags & 4; round 4
+// ran k_resolve_ended after the depth's visibility pass, kept behind lumc_set_fused_resolve(2)). What stays outside: samples the hit
 // cannot decide (`fallback`: their ambient ray is queued into its own item arrays, traced by a small second pass, resolved by k_resolve_listed - for those
 // the vertex's sum lands after the next depth's emission: the fast flavour's rounding, not the exact flavour's, which never runs this).
 // (struct FusedResolve: dev_scene.h)
@@ -388,6 +389,9 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
                                                                     uint32_t fused_flags) {
   const uint32_t n = ctrl[kCtlPaths];
   uint32_t* count_out = ctrl + kCtlStride + kCtlPaths;
+  // fused resolve, fused_flags & 4: the previous depth's vertices that no entry continues (its k_shade listed them) are input too - entries n .. n_input - 1 have
+  // a parent and nothing else - instead of a kernel of their own after that depth's visibility pass (k_resolve_ended), which only waited for memory
+  const uint32_t n_input = n + ((LUM_SHADE_DYNAMIC && LUM_FAST && kStage == 0 && !kWater && (fused_flags & 5u) == 5u) ? (ctrl - kCtlStride)[kCtlSkyItems] : 0u);
   // (the fast flavour only: the exact flavour's sums land in the reference's order for every vertex, its kernels do not carry the code)
   // (its pointers come through memory, read where they are used: as kernel arguments they sat in scalar registers for the whole kernel, and the spills that
   // caused put 27 more lane reads into every iteration of the candidate loop)
@@ -408,20 +412,35 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   // (as far as the wave has seen the cursor), between 1 and kShadeChunkRounds rounds of 64 entries - long chunks while the queue is long (few atomics on one
   // word), single rounds at its end and in the short queues of deep depths, where a fixed 16 rounds left most of the chip without work (measured: +8 % on the
   // scan's and the Example-class scene's k_shade).
+  // The cursor runs over a schedule of rounds of 64 entries: the queue's rounds with the rounds of the listed vertices (n .. n_input - 1: only a resolve, i.e.
+  // only memory latency) spread evenly between them, one after every `every` of the queue's - at the queue's end they cost more than the kernel they replace
+  // (all waves reach them together, with nothing to compute beside them: hall k_shade +9.5 ms per 3 steps for a kernel of 11.8).
   uint32_t* const cursor = ctrl + kCtlShadeCursor;
+  const uint32_t n_listed = n_input - n, rounds_q = (n + 63u) / 64u, rounds_l = (n_listed + 63u) / 64u;
+  const uint32_t every = rounds_l ? max(rounds_q / rounds_l, 1u) : 0u, groups = rounds_l ? min(rounds_l, rounds_q / every) : 0u;
+  const uint32_t n_sched = (rounds_q + rounds_l) * 64u;
+  auto entry_at = [&](uint32_t pos) -> uint32_t {  // the lane's entry at position `pos` of the schedule (wave-uniform, a multiple of 64): < n a queue entry, < n_input a listed vertex, else none
+    const uint32_t t = pos / 64u, mixed = groups * (every + 1u);
+    uint32_t base;
+    bool listed;
+    if (t < mixed) { const uint32_t g = t / (every + 1u), o = t - g * (every + 1u); listed = o == every; base = listed ? g : g * every + o; }
+    else { const uint32_t r = t - mixed, left = rounds_q - groups * every; listed = r >= left; base = listed ? groups + (r - left) : groups * every + r; }
+    const uint32_t e = base * 64u + lane;
+    return listed ? (e < n_listed ? n + e : 0xFFFFFFFFu) : (e < n ? e : 0xFFFFFFFFu);
+  };
   const uint32_t share_div = gridDim.x * (kBlock / 64u) * 2u * 64u;  // entries per round and wave, twice
-  auto guided = [&](uint32_t seen) -> uint32_t { return 64u * min(max((seen < n ? n - seen : 0u) / share_div, 1u), kShadeChunkRounds); };
+  auto guided = [&](uint32_t seen) -> uint32_t { return 64u * min(max((seen < n_sched ? n_sched - seen : 0u) / share_div, 1u), kShadeChunkRounds); };
   uint32_t chunk_len = guided(0u), next_len = chunk_len;
   uint32_t grabbed = 0u;  // lane 0: the chunk after next (the atomic's result is only looked at when the current chunk ends)
   if (lane == 0u) grabbed = atomicAdd(cursor, chunk_len);
   uint32_t chunk = (uint32_t) __builtin_amdgcn_readfirstlane((int) grabbed), chunk_round = 0u;
   // a workgroup that only starts when the queue is used up (the grid is a little larger than the resident set, so that every place is taken from the start
   // wherever the dispatcher puts the workgroups) leaves before it stages anything
-  if (!__syncthreads_or((int) (chunk < n))) return;
+  if (!__syncthreads_or((int) (chunk < n_sched))) return;
   next_len = guided(chunk + chunk_len);
   if (lane == 0u) grabbed = atomicAdd(cursor, next_len);
 #else
-  const uint32_t rounds = (n + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
+  const uint32_t rounds = (n_input + gridDim.x * kBlock - 1) / (gridDim.x * kBlock);
 #endif
   // Paths that left the scene only add the sky term; the surface vertices are two orders of magnitude more work. A wave therefore
   // collects the indices of its surface hits in LDS and shades them 64 at a time, so that misses do not leave lanes idle during the
@@ -450,21 +469,22 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
   uint32_t parent_ahead = 0u, slot_ahead = 0u;
   if (resolve_parents) {
 #if LUM_SHADE_DYNAMIC
-    const uint32_t i0 = chunk + lane;
+    const uint32_t i0 = entry_at(chunk);
 #else
     const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x;
 #endif
     if (i0 < n) { parent_ahead = in.parent[i0]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i0])[3]); }
+    else if (i0 < n_input) parent_ahead = fused_dev->ended_prev[i0 - n];
   }
   for (uint32_t round = 0;; round++) {
 #if LUM_SHADE_DYNAMIC
-    const bool input_done = chunk >= n;
+    const bool input_done = chunk >= n_sched;
 #else
     const bool input_done = round >= rounds;
 #endif
     if (!input_done) {
 #if LUM_SHADE_DYNAMIC
-      const uint32_t i = chunk + chunk_round * 64u + lane;
+      const uint32_t i = entry_at(chunk + chunk_round * 64u);
       if (++chunk_round * 64u == chunk_len) {  // on to the chunk fetched ahead, and one more on its way
         chunk_round = 0u;
         chunk = (uint32_t) __builtin_amdgcn_readfirstlane((int) grabbed);
@@ -472,7 +492,7 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         next_len = guided(chunk + chunk_len);
         if (lane == 0u) grabbed = atomicAdd(cursor, next_len);
       }
-      const uint32_t i_ahead = chunk + chunk_round * 64u + lane;  // (>= n once the queue is used up)
+      const uint32_t i_ahead = entry_at(chunk + chunk_round * 64u);  // (none once the schedule is used up)
       const bool have_ahead = true;
 #else
       const uint32_t i = (round * gridDim.x + blockIdx.x) * kBlock + threadIdx.x;
@@ -485,14 +505,17 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         bool undecided = false;
         uint32_t ip = 0;
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t p = parent_ahead, slot = slot_ahead;
+        const uint32_t p = parent_ahead;
+        uint32_t slot = slot_ahead;
         {
           if (have_ahead && i_ahead < n) { parent_ahead = in.parent[i_ahead]; slot_ahead = fbits(reinterpret_cast<const float*>(&in.dir_slot[i_ahead])[3]); }
+          else if (have_ahead && i_ahead < n_input) parent_ahead = fused.ended_prev[i_ahead - n];  // (its slot: with the vertex's records below)
         }
-        if (i < n) {
+        if (i < n_input) {
           ip = p & kParentMask;
           // resolve_records<2> for a plain scene (no fog, no ocean: the reuse's condition), written out: the records, then - together - the hit word of a
           // deferred sample, the visibility words that matter and the result slot; the sums in the reference's order
+          if (i >= n) slot = fbits(reinterpret_cast<const float*>(&fused.prev.dir_slot[ip])[3]);  // a listed vertex: the result slot from its own queue entry
           const uint4 paux = ld_stream(&fused.prev.aux[ip]);
           const float4 cl = ld_stream(&fused.nee_prev.geo_color_light[ip]), lc = ld_stream(&fused.nee_prev.bsdf_weight_sum[ip]);
           amb = ld_stream(&fused.nee_prev.ambient[ip]);

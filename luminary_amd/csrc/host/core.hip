@@ -63,7 +63,8 @@ struct LumContext {
   uint2* d_sobol = nullptr;         // the pass's Sobol / Owen table (dev_sampler.h LUM_SOBOL_TABLE; wavefront_depths fills it)
   size_t sobol_entries = 0;
   int sobol_table = 1;              // LUM_SOBOL_TABLE_RT=0: the sampler hashes every number itself
-  uint32_t* d_ended = nullptr;      // a depth's vertices that no entry continues (k_shade lists them, k_resolve_ended resolves them)
+  uint32_t* d_ended[2] = {nullptr, nullptr};  // a depth's vertices that no entry continues, by the depth's parity (k_shade lists them; the next depth's k_shade resolves them, or k_resolve_ended)
+  int fused_ended = 1;              // ... the next depth's k_shade (1) or k_resolve_ended after the depth's visibility pass (0; LUM_FUSED_ENDED=0)
   FusedResolve* d_fused = nullptr;  // six records in device memory: the previous depth's queue (three buffers) and NEE records (two) by depth % 6
   NeeQueue nee2{};
   ShadowQueue fallback{};
@@ -362,7 +363,8 @@ int upload_fused_records(LumContext* ctx, hipStream_t stream) {
     by_depth[d].prev = ctx->queue[(d + 2) % 3];
     by_depth[d].nee_prev = (d & 1) ? ctx->nee : ctx->nee2;
     by_depth[d].fallback = ctx->fallback;
-    by_depth[d].ended = ctx->d_ended;
+    by_depth[d].ended = ctx->d_ended[d & 1];
+    by_depth[d].ended_prev = ctx->d_ended[(d & 1) ^ 1];
   }
   HIP_TRY(ctx, hipStreamSynchronize(stream));  // a pass still reading the old records on a non-blocking stream is not ordered against the null-stream copy below
   HIP_TRY(ctx, hipMemcpy(ctx->d_fused, by_depth, sizeof(by_depth), hipMemcpyHostToDevice));
@@ -375,7 +377,7 @@ int ensure_fused(LumContext* ctx, hipStream_t stream) {
   if (ctx->fused_block) (void) hipFree(ctx->fused_block);
   ctx->fused_block = nullptr; ctx->fused_capacity = 0;
   const size_t n = ctx->capacity;
-  const size_t bytes = n * (68 + 3 * 4 + 84 + 48 + 4 + 4) + 26 * 256 + 6 * sizeof(FusedResolve);
+  const size_t bytes = n * (68 + 3 * 4 + 84 + 48 + 4 + 2 * 4) + 27 * 256 + 6 * sizeof(FusedResolve);
   if (hipMalloc(&ctx->fused_block, bytes) != hipSuccess) { ctx->fused_block = nullptr; ctx->fused_refused_capacity = ctx->capacity; return 1; }
   char* p = (char*) ctx->fused_block;
   auto take = [&](size_t sz) { char* r = p; p += (sz + 255) & ~(size_t) 255; return r; };
@@ -392,7 +394,7 @@ int ensure_fused(LumContext* ctx, hipStream_t stream) {
   f.light_items = (uint32_t*) take(n * 4);
   f.vis = ctx->shadow.vis;  // the undecided samples' answers go where the depth's own ambient answers went: kind 2 of the previous depth's words
   f.capacity = ctx->shadow.capacity;
-  ctx->d_ended = (uint32_t*) take(n * 4);
+  ctx->d_ended[0] = (uint32_t*) take(n * 4); ctx->d_ended[1] = (uint32_t*) take(n * 4);
   ctx->d_fused = (FusedResolve*) take(6 * sizeof(FusedResolve));
   ctx->fused_capacity = ctx->capacity;
   return upload_fused_records(ctx, stream);
@@ -636,6 +638,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_FUSED_RESOLVE")) ctx->fused_resolve = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("LUM_SHADE_GRID")) ctx->shade_grid_rounds = (uint32_t) atoi(e);
   if (const char* e = getenv("LUM_SOBOL_TABLE_RT")) ctx->sobol_table = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("LUM_FUSED_ENDED")) ctx->fused_ended = atoi(e) != 0 ? 1 : 0;
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -1991,7 +1994,8 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N, uin
     {
       Launch l(ctx, stream, LUMC_KERNEL_SHADE);
       wf.shade(shade_grid(ctx, N), stream, sc, ctx->queue[cur], ctx->queue[next_q], nee, ctx->shadow, ctx->d_results, ctrl, depth_const, ctx->d_counters,
-               (reuse && depth < max_depth) ? 1u : 0u, fused ? ctx->d_fused + depth % 6u : nullptr, fused ? ((depth > 0 ? 1u : 0u) | (depth < max_depth ? 2u : 0u)) : 0u);
+               (reuse && depth < max_depth) ? 1u : 0u, fused ? ctx->d_fused + depth % 6u : nullptr,
+               fused ? ((depth > 0 ? 1u : 0u) | (depth < max_depth ? 2u : 0u) | (ctx->fused_ended ? 4u : 0u)) : 0u);
     }
     if (fused && depth > 0) {  // the samples of depth - 1 their paths' closest hits could not decide: traced now, their vertices resolved (before this depth's visibility pass reuses the words)
       {
@@ -2029,9 +2033,11 @@ static int wavefront_depths(LumContext* ctx, hipStream_t stream, uint32_t N, uin
       Launch l(ctx, stream, LUMC_KERNEL_SHADOW);
       wf.shadow_rays(grid_persistent(ctx, N), lds_dyn, stream, sc, ctx->shadow, shadow_order, ctrl, ctx->d_counters, ctx->lds_nodes);
     }
-    if (fused && depth < max_depth) {  // the vertices no entry of the next depth continues; the others are resolved by those entries, in k_shade
-      Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
-      wf.resolve_ended(std::min<uint32_t>(grid_for(N), 4096u), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, ctx->d_ended);
+    if (fused && depth < max_depth) {  // the vertices no entry of the next depth continues; the others are resolved by those entries, in k_shade - and so are these, as its last input (fused_flags & 4)
+      if (!ctx->fused_ended) {
+        Launch l(ctx, stream, LUMC_KERNEL_RESOLVE);
+        wf.resolve_ended(std::min<uint32_t>(grid_for(N), 4096u), stream, sc, ctx->queue[cur], nee, ctx->shadow, ctx->d_results, (const uint32_t*) ctrl, ctx->d_ended[depth & 1u]);
+      }
     }
     else if (reuse && depth < max_depth) resolve_pending = true;
     else {
@@ -3193,6 +3199,7 @@ int lumc_set_flavour(LumContext* ctx, int flavour) {
 int lumc_set_fused_resolve(LumContext* ctx, int on) {
   if (!ctx) return 1;
   ctx->fused_resolve = on != 0 ? 1 : 0;
+  ctx->fused_ended = on == 2 ? 0 : 1;  // 2: the vertices whose path ended keep their own kernel (k_resolve_ended) - for comparison
   return 0;
 }
 int lumc_set_sobol_table(LumContext* ctx, int on) {

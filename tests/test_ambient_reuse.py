@@ -136,11 +136,19 @@ def test_the_fused_resolve_gives_the_separate_kernels_sums(name, tmp_path):
         fm0, sm0, c0 = _render(core, -1)
         core.set_fused_resolve(True)
         fm1, sm1, c1 = _render(core, -1)
+        core.set_fused_resolve(2)   # the ended paths' vertices by k_resolve_ended instead of by the next depth's shading kernel: the same sums per result slot
+        fm3, sm3, c3 = _render(core, -1)
         core.set_fused_resolve(False)
         fm2, _, _ = _render(core, -1)
     finally:
         core.close()
     assert np.array_equal(fm0, fm2)
+    assert list(c3) == list(c1)
+    # (k_resolve_ended forms a vertex's sum through resolve_records, the shading kernel through the written-out form: under the fast flavour's contraction a
+    # product with a fractional visibility - transparent or cut-out occluders - may round once less in one of them)
+    assert np.allclose(fm3, fm1, rtol=2e-6, atol=1e-7) and np.allclose(sm3, sm1, rtol=4e-6, atol=1e-7)
+    if name in ("cornell", "example", "no_lights"):
+        assert np.array_equal(fm3, fm1) and np.array_equal(sm3, sm1), "opaque scenes: every visibility is 0 or 1, the sums are the same bits"
     assert list(c1) == list(c0), "the same rays, vertices and fallbacks either way"
     assert c1[CNT_AMBIENT_DEFERRED] > 0
     if c1[CNT_AMBIENT_FALLBACK] == 0:
