@@ -199,6 +199,55 @@ def test_the_fused_resolve_over_depths_pixel_subsets_and_growing_passes(tmp_path
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dark", "bright"])
+def test_the_ended_paths_vertices_in_the_next_depths_shading_kernel_at_extreme_ratios(kind, tmp_path):
+    """k_shade of depth d + 1 takes depth d's ended vertices as further input, their rounds spread between its queue's rounds (kernels.h entry_at). Dark walls: almost
+    every path ends at its first vertices, so the listed vertices outnumber the queue's entries (one listed round per queue round, and a tail of listed rounds); bright
+    walls and no roulette to speak of: hardly any path ends early (many queue rounds per listed round, and depths without a single listed vertex). Against the
+    separate kernels, bit for bit (opaque scene), for pass sizes that leave partial rounds."""
+    host = scenes.cornell_host(str(tmp_path), 80, 56, 6)
+    sky = host.get_sky()
+    sky.constant_color.r, sky.constant_color.g, sky.constant_color.b = 0.5, 0.6, 0.8
+    host.set_sky(sky)
+    for i in range(8):
+        try:
+            m = host.get_material(i)
+        except Exception:  # noqa: BLE001 - past the scene's last material
+            break
+        if m.emission_active:
+            continue
+        v = 0.02 if kind == "dark" else 0.98
+        m.albedo.r, m.albedo.g, m.albedo.b = v, v, v
+        host.set_material(i, m)
+    if kind == "bright":
+        cam = host.get_camera()
+        cam.russian_roulette_threshold = 1e-6
+        host.set_camera(cam)
+    view = oracle_lib.with_luts(host.device_scene())
+    core = Core(0)
+    try:
+        core.set_flavour("fast")
+        core.upload(view)
+        frames = {}
+        for mode in (0, 1, 2):
+            core.set_fused_resolve(mode)
+            out = []
+            for spp, batch in ((5, 5), (3, 1), (7, 4)):
+                core.set_pixels(None)
+                core.reset_counters()
+                core.render(0, spp, samples_per_pass=batch)
+                out.append((core.accumulators()[0].copy(), list(core.counters())))
+            frames[mode] = out
+    finally:
+        core.close()
+    for a, b, c in zip(frames[0], frames[1], frames[2]):
+        assert a[1] == b[1] == c[1]
+        assert b[1][CNT_AMBIENT_FALLBACK] == 0
+        assert np.array_equal(a[0], b[0]) and np.array_equal(c[0], b[0])
+        assert np.isfinite(b[0]).all() and float(b[0].sum()) > 0.0
+
+
+@pytest.mark.gpu
 def test_default_by_flavour_and_scene(tmp_path):
     """fast: on for plain scenes; off with fog / under the procedural sky / with ray sorting; exact: off unless asked for."""
     from luminary_amd import SKY_MODE_DEFAULT
