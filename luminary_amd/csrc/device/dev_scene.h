@@ -94,6 +94,10 @@ constexpr uint32_t kBvhTriNoTexture = 0xFFFFFFFFu;
 constexpr uint32_t kBvhTriOpaque = 0xFFFFFFFEu;
 static_assert(sizeof(BvhTri) == 48, "48 bytes per triangle");
 
+#ifndef LUM_PHASE_QUEUES
+#define LUM_PHASE_QUEUES 0  // 1: k_trace / k_shadow_rays keep their rays in per-wave LDS pools and regroup them by phase (dev_trace_pool.h)
+#endif
+
 struct DeviceScene {
   // geometry
   const uint32_t* mesh_tri_offset;
@@ -186,10 +190,12 @@ struct DeviceScene {
   const BvhTri* particle_tris;
   const float4* particle_leaves;
   uint32_t particle_tlas_num_nodes, particle_num_leaves;
-  // LUM_PHASE_QUEUES (dev_trace_pool.h): per workgroup of the persistent ray kernels and per pool slot, what does not fit LDS - 4 x 16 bytes of query state, the stack
-  // entries beyond the LDS ones. Null in other builds.
+#if LUM_PHASE_QUEUES
+  // dev_trace_pool.h: per workgroup of the persistent ray kernels and per pool slot, what does not fit LDS - 4 x 16 bytes of query state, the stack
+  // entries beyond the LDS ones. Only the variant build carries the fields (tools/check_variants.sh compiles it).
   uint4* pool_state;
   unsigned long long* pool_stack;
+#endif
   // the pass's Sobol / Owen table (dev_sampler.h LUM_SOBOL_TABLE, k_sobol_table): entry (dimension, sample) at [dimension * sobol_stride + (sample - sobol_first)],
   // dimensions 0 .. (max_ray_depth + 1) * kRndTargetCount - 1; nullptr in passes without one (set per pass on the host's copy, wavefront_depths)
   const uint2* sobol_table;
@@ -304,9 +310,6 @@ enum CtrlWord : uint32_t {
 };
 static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second half of the 32-word lines");
 
-#ifndef LUM_PHASE_QUEUES
-#define LUM_PHASE_QUEUES 0  // 1: k_trace / k_shadow_rays keep their rays in per-wave LDS pools and regroup them by phase (dev_trace_pool.h)
-#endif
 #if LUM_PHASE_QUEUES
 #ifndef LUM_TRACE_BLOCK
 #define LUM_TRACE_BLOCK 1024

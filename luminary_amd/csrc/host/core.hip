@@ -64,7 +64,10 @@ struct LumContext {
   size_t sobol_entries = 0;
   int sobol_table = 1;              // LUM_SOBOL_TABLE_RT=0: the sampler hashes every number itself
   uint32_t* d_ended[2] = {nullptr, nullptr};  // a depth's vertices that no entry continues, by the depth's parity (k_shade lists them; the next depth's k_shade resolves them, or k_resolve_ended)
-  int fused_ended = 1;              // ... the next depth's k_shade (1) or k_resolve_ended after the depth's visibility pass (0; LUM_FUSED_ENDED=0)
+  // ... the next depth's k_shade (1) or k_resolve_ended after the depth's visibility pass (0; LUM_FUSED_ENDED=0). k_shade only takes the listed vertices
+  // when its input comes through the cursor (kernels.h: LUM_SHADE_DYNAMIC): a build without it keeps the separate kernel, whatever is asked for.
+  int fused_ended = LUM_SHADE_DYNAMIC ? 1 : 0;
+  int fused_ended_default = LUM_SHADE_DYNAMIC ? 1 : 0;  // what lumc_set_fused_resolve(1) goes back to (the environment's choice, if any)
   FusedResolve* d_fused = nullptr;  // six records in device memory: the previous depth's queue (three buffers) and NEE records (two) by depth % 6
   NeeQueue nee2{};
   ShadowQueue fallback{};
@@ -638,7 +641,7 @@ int lumc_context_create(int device_ordinal, LumContext** out) {
   if (const char* e = getenv("LUM_FUSED_RESOLVE")) ctx->fused_resolve = atoi(e) != 0 ? 1 : 0;
   if (const char* e = getenv("LUM_SHADE_GRID")) ctx->shade_grid_rounds = (uint32_t) atoi(e);
   if (const char* e = getenv("LUM_SOBOL_TABLE_RT")) ctx->sobol_table = atoi(e) != 0 ? 1 : 0;
-  if (const char* e = getenv("LUM_FUSED_ENDED")) ctx->fused_ended = atoi(e) != 0 ? 1 : 0;
+  if (const char* e = getenv("LUM_FUSED_ENDED")) ctx->fused_ended = ctx->fused_ended_default = (LUM_SHADE_DYNAMIC && atoi(e) != 0) ? 1 : 0;
   if (const char* f = getenv("LUM_FLAVOUR")) ctx->wf = (std::strcmp(f, "exact") == 0) ? wavefront_kernels_exact() : wavefront_kernels_fast();
   *out = ctx;
   int count = 0;
@@ -2763,14 +2766,19 @@ int lumc_device_count(void) {
 
 // The tile deal ("block -> GPU by interleaved round-robin for load balance"). Round 5: a rank-1 lattice instead of t % world over the
 // row-major grid. The old deal is periodic in x with period `world` tiles whenever the tile row length is a multiple of `world` - at 3840 px (120 tiles)
-// and 8 ranks every rank owned vertical 32-pixel stripes. Now tile (x, y) belongs to rank (x + k * y) % world, with k chosen so that a rank's tiles form
-// the most isotropic lattice: k maximises the shortest distance between two tiles of one rank (world 8: k = 3, nearest own tiles at (2, 2) and (1, -3);
-// world 4: k = 2; world 2: the checkerboard). Every rank's share is spread over the frame at the scale of 2-3 tiles in every direction, whatever the
-// frame's width. LUM_TILE_DEAL=rowmajor restores t % world (A/B of the load-balance table, profiles/r05_load_balance.json).
+// and 8 ranks every rank owned vertical 32-pixel stripes. Now tile (x, y) belongs to rank (x + k * y) % world, with k chosen among the steps COPRIME to
+// `world` so that a rank's tiles form the most isotropic lattice: k maximises the shortest distance between two tiles of one rank (world 8: k = 3, nearest
+// own tiles at (2, 2) and (1, -3); world 2: the checkerboard; world 4 and 6: k = 1, the diagonals). Coprime (round 6, advisor): the row offset k * y then
+// runs through every residue, so the tiles a row has beyond a multiple of `world` go to every rank in turn - with k = 2 at 4 ranks (round 5's choice, more
+// isotropic) they always went to the same half (1376 x 1080: max / mean share 1.023). Balance bound: over any `world` consecutive tile rows every rank owns
+// the same number of tiles; a frame's shares differ by at most (tiles_y % world) tiles (+ the clipped tiles of the right and bottom edge).
+// LUM_TILE_DEAL=rowmajor restores t % world (A/B of the load-balance table, profiles/r05_load_balance.json).
 uint32_t lumc_tile_lattice_step(uint32_t world) {
   if (world < 2) return 0;
+  auto gcd = [](uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; };
   uint32_t best_k = 1; int64_t best = -1;
   for (uint32_t k = 1; k < world; k++) {
+    if (gcd(k, world) != 1u) continue;
     int64_t shortest = INT64_MAX;
     for (int64_t b = -(int64_t) world; b <= (int64_t) world; b++)
       for (int64_t a = -(int64_t) world; a <= (int64_t) world; a++) {
@@ -2787,14 +2795,24 @@ static bool tile_deal_rowmajor() {
   return v;
 }
 
+// the step of a world size, computed once per size (the search is cubic in `world`; the host's render threads call this concurrently)
+static uint32_t tile_lattice_step_cached(uint32_t world) {
+  static uint32_t step_of[65];
+  static std::once_flag once;
+  std::call_once(once, [] { for (uint32_t w = 0; w <= 64; w++) step_of[w] = lumc_tile_lattice_step(w); });
+  if (world <= 64) return step_of[world];
+  static std::mutex m;
+  static std::map<uint32_t, uint32_t> beyond;
+  std::lock_guard<std::mutex> lock(m);
+  auto it = beyond.find(world);
+  if (it == beyond.end()) it = beyond.emplace(world, lumc_tile_lattice_step(world)).first;
+  return it->second;
+}
+
 uint32_t lumc_tile_owner(uint32_t tile_x, uint32_t tile_y, uint32_t tiles_x, uint32_t world) {
   if (world < 2) return 0;
   if (tile_deal_rowmajor()) return (uint32_t) (((uint64_t) tile_y * tiles_x + tile_x) % world);
-  static uint32_t step_of[65];
-  static std::once_flag once;
-  std::call_once(once, [] { for (uint32_t w = 0; w <= 64; w++) step_of[w] = lumc_tile_lattice_step(w); });  // (the host's render threads call this concurrently)
-  const uint32_t k = world <= 64 ? step_of[world] : lumc_tile_lattice_step(world);
-  return (uint32_t) (((uint64_t) tile_x + (uint64_t) k * tile_y) % world);
+  return (uint32_t) (((uint64_t) tile_x + (uint64_t) tile_lattice_step_cached(world) * tile_y) % world);
 }
 
 // Writes the rank's pixel indices (x + y * width): its tiles in row-major tile order, rows within a tile; `out` may be NULL to query the count.
@@ -2918,7 +2936,7 @@ int lumc_frame_assemble_all(LumContext** ctxs, int n, uint32_t frame_pixels, int
 // rank at 4K) moves `world` times what is needed: a rank's contribution is the 16 bytes of each pixel it OWNS. Where the ranks' pixel sets are the tile
 // deal of lumc_tile_pixels (32 x 32 tiles dealt by lumc_tile_owner's lattice - what bench.py and the host API's tiled render loop use), every rank can compute every other
 // rank's pixel list, so nothing but the sums travels: each rank packs its [3][P] + [P] accumulators into a [4][M] buffer (M = the largest tile share,
-// zero padded: the deal is even to within one tile), ONE ncclGather brings the `world` buffers to the root, and a scatter kernel on the root puts every
+// zero padded: the deal's shares differ by at most tiles_y % world tiles, see lumc_tile_lattice_step), ONE ncclGather brings the `world` buffers to the root, and a scatter kernel on the root puts every
 // value at its pixel. Reference: device_result_interface.c:107-299 (sample partition, sums staged through pinned host memory).
 namespace {
 __global__ __launch_bounds__(256) void k_gather_pack(const float* __restrict__ fm, const float* __restrict__ sm, uint32_t n, uint32_t stride, float* __restrict__ send) {
@@ -3199,7 +3217,7 @@ int lumc_set_flavour(LumContext* ctx, int flavour) {
 int lumc_set_fused_resolve(LumContext* ctx, int on) {
   if (!ctx) return 1;
   ctx->fused_resolve = on != 0 ? 1 : 0;
-  ctx->fused_ended = on == 2 ? 0 : 1;  // 2: the vertices whose path ended keep their own kernel (k_resolve_ended) - for comparison
+  ctx->fused_ended = on == 2 ? 0 : ctx->fused_ended_default;  // 2: the vertices whose path ended keep their own kernel (k_resolve_ended) - for comparison; 1: the context's default (LUM_FUSED_ENDED, LUM_SHADE_DYNAMIC)
   return 0;
 }
 int lumc_set_sobol_table(LumContext* ctx, int on) {

@@ -10,7 +10,9 @@ import numpy as np
 
 def tile_lattice_step(world):
     """The step k of the deal (== lumc_tile_lattice_step): tile (x, y) belongs to rank (x + k*y) % world; k maximises the shortest distance
-    between two tiles of one rank (ties: the smallest k), so a rank's tiles form the most isotropic lattice (8 ranks: k = 3)."""
+    between two tiles of one rank among the steps coprime to `world` (ties: the smallest k), so a rank's tiles form the most isotropic lattice
+    (8 ranks: k = 3) and the tiles a row has beyond a multiple of `world` go to every rank in turn (shares differ by at most tiles_y % world tiles)."""
+    import math
     if world < 2:
         return 0
     best_k, best = 1, -1
@@ -18,6 +20,8 @@ def tile_lattice_step(world):
     a, b = np.meshgrid(r, r, indexing="xy")
     d2 = a * a + b * b
     for k in range(1, world):
+        if math.gcd(k, world) != 1:
+            continue
         ok = ((a + k * b) % world == 0) & (d2 > 0)
         shortest = int(d2[ok].min())
         if shortest > best:
