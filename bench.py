@@ -10,9 +10,10 @@ Example-class scene (config 2) and the 10 M-triangle scan (config 5's scene) are
 same JSON line (`--secondary none` skips them).
 
 Step   = one wavefront pass per GPU: every rank takes its pixels of the 1920x1080 frame through all 9 depth passes (8 bounces) for
-         --samples-per-pass (default 32) x N sample ids, i.e. 1920*1080*32 = 66 M paths (33 GB of queues) per GPU and step whatever N is
-         (weak scaling: the frame gains 32*N samples per step). Deep bounces keep few paths alive, so many sample ids share a pass to keep
-         256 CUs busy: 4 / 8 / 16 / 32 ids per pass give 2610 / 2769 / 2861 / 2907 Mrays/s on the hall (profiles/r02_ab_experiments.txt).
+         --samples-per-pass (default 64) x N sample ids, i.e. 1920*1080*64 = 133 M paths (66 GB of queues, under a quarter of the 288 GB) per GPU and
+         step whatever N is (weak scaling: the frame gains 64*N samples per step). Deep bounces keep few paths alive, so many sample ids share a pass to
+         keep 256 CUs busy: 4 / 8 / 16 / 32 ids per pass gave 2610 / 2769 / 2861 / 2907 Mrays/s on the hall (profiles/r02_ab_experiments.txt); rounds 2-5
+         were quoted at 32, round 6 moved to 64 (same box, 32 -> 64: hall +2.1 %, Example-class +10.7 %, scan +14 % samples/s; profiles/r06_ab_experiments.txt).
 Rays   = closest-hit rays + executed shadow rays + light-BVH queries (SURVEY.md §8d counting rule), counted on the device.
 N > 1  = the frame is cut into 32x32 tiles dealt to the ranks by a lattice - tile (x, y) -> rank (x + k y) % N - (weak data-parallel over pixels, no collective while
          rendering); each rank accumulates its own pixels and ONE RCCL collective at the end assembles the frame moments on rank 0: a gather of
@@ -462,7 +463,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--bounces", type=int, default=8)
-    ap.add_argument("--samples-per-pass", type=int, default=32, help="sample ids per wavefront pass = per step")
+    ap.add_argument("--samples-per-pass", type=int, default=64, help="sample ids per wavefront pass = per step")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU baseline work (0 = skip)")
     ap.add_argument("--flavour", default=None, choices=["fast", "exact"], help="arithmetic flavour of the device code (default: the library's, fast)")
     ap.add_argument("--reduce", default="cabi", choices=["cabi", "cabi-reduce", "torch"],

@@ -89,7 +89,8 @@ def build(force=False, verbose=False, variant=None):
     objs = []
     for s in HOST_SOURCES:
         o = os.path.join(OBJ_DIR, os.path.basename(s) + ".o")
-        _run(["g++", *COMMON, *EXACT, "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, s), "-o", o])
+        # (the -D switches of an experiment reach the host sources too: constants like LUM_LEAF_MAX are shared with the builders there)
+        _run(["g++", *COMMON, *EXACT, *[f for f in EXTRA if f.startswith("-D")], "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROCM, "include"), "-c", os.path.join(CSRC, s), "-o", o])
         objs.append(o)
     bn = os.path.join(ROOT, "data", "bluenoise_2D.bin")
     o = os.path.join(OBJ_DIR, "embed.o")

@@ -80,7 +80,16 @@ constexpr uint32_t kNodeBytes = LUM_BVH4Q ? 64u : 128u, kNodeShift = LUM_BVH4Q ?
 
 constexpr uint32_t kBvhEmpty      = 0xFFFFFFFFu;
 constexpr uint32_t kBvhLeafBit    = 0x80000000u;
-constexpr uint32_t kBvhLeafMaxTri = 4;
+// Most triangles of a leaf: the builders' limit AND the size of the ray kernels' leaf registers (3 x float4 per slot). Rounds 1-5: 4. Round 6: 2 - the
+// CPU model (tools/bvh_quality.cpp, hall) says 8.1 -> 4.6 triangle tests per closest-hit ray for 17.3 -> 18.2 node visits, and the kernels shed the 24
+// registers of two slots: k_trace 128 VGPRs + 12 spilled -> 114, none spilled; k_shadow_rays 128 + 4 -> 110. With the optimal 4-wide collapse (bvh_build.cpp
+// CollapsePlan), same box: hall k_trace -3.7 %, k_shadow_rays -3.2 %, +1.75 % samples/s; scan +1.7 %; Example-class +3.7 % (profiles/r06_ab_experiments.txt).
+// Leaves of two with registers for four (LUM_BVH_MAX_LEAF=2 on the old build) gain nothing: the registers are what pays.
+#ifndef LUM_LEAF_MAX
+#define LUM_LEAF_MAX 2
+#endif
+constexpr uint32_t kBvhLeafMaxTri = LUM_LEAF_MAX;
+static_assert(LUM_LEAF_MAX >= 1 && LUM_LEAF_MAX <= 8, "a leaf's triangle count travels in 3 bits");
 
 // Triangle in traversal order, 48 bytes: v0.xyz + id | e1.xyz + scene index | e2.xyz (edges precomputed with the same float
 // subtraction the reference's intersection code performs, so hit distances are identical). `id` is the triangle id inside its

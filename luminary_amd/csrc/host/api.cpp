@@ -886,12 +886,13 @@ LuminaryResult produce_outputs(LuminaryHost* h, PreviewState preview = PreviewSt
 namespace {
 // Sample ids per wavefront pass of the render loop. Deep bounces keep few paths alive, so many ids share a pass to keep 256 CUs busy (hall +5 %,
 // Example-class +26 %, scan +35 % from 8 to 32, profiles/r02_ab_experiments.txt) - but a pass is also the latency of the next image, so a frame
-// that is being watched (recurring outputs) keeps 8. Bounded by the work buffers: at most 64 M paths (about 32 GB of queues) per pass.
+// that is being watched (recurring outputs) keeps 8. Round 6: 64 ids for a frame nobody watches (same box, 32 -> 64: hall +2.1 %, Example-class +10.7 %,
+// scan +14 % samples/s, profiles/r06_ab_experiments.txt). Bounded by the work buffers: at most 128 M paths (about 64 GB of queues, a fifth of the 288 GB) per pass.
 uint32_t pass_size(LuminaryHost* h) {
-  const uint32_t want = h->outputs.properties().enabled ? 8u : 32u;
+  const uint32_t want = h->outputs.properties().enabled ? 8u : 64u;
   const LuminaryRendererSettings& st = h->scene.settings;
   const uint64_t pixels = std::max<uint64_t>((uint64_t) (st.width << st.supersampling) * (st.height << st.supersampling), 1u);
-  const uint64_t fit = std::max<uint64_t>((64ull << 20) / pixels, 1u);
+  const uint64_t fit = std::max<uint64_t>((128ull << 20) / pixels, 1u);
   return (uint32_t) std::min<uint64_t>(want, fit);
 }
 

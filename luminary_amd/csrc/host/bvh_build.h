@@ -17,6 +17,9 @@ struct Bvh4 {
   std::vector<Bvh4Node> nodes;   // nodes[0] is the root and always an inner node
   std::vector<uint32_t> prims;   // primitive ids in leaf order; leaves reference ranges of this array
   uint32_t max_depth = 0;
+  // test support (lumc_host_bvh_probe): the cost the collapse plan reports for the root (sum of the surviving binary nodes' half areas), and - for trees of at
+  // most 20 binary inner nodes, LUM_BVH_COLLAPSE_BRUTE=1 - the cheapest of ALL valid choices of surviving nodes, found by trying every subset
+  double plan_cost = 0.0, brute_cost = -1.0;
 };
 
 // Builds a BVH4 over `count` boxes. Leaves hold at most `max_leaf` (<= kBvhLeafMaxTri) primitives. The tree has at most

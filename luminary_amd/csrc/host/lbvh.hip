@@ -16,6 +16,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <cfloat>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <algorithm>
@@ -122,10 +123,39 @@ __device__ __forceinline__ float half_area(const BinBox& b) {
 
 struct CollapseItem { int bin; uint32_t node4; };
 
+// ---- which binary nodes become 4-wide nodes: the optimal cut (bvh_build.cpp CollapsePlan, the same expressions in the same order: the host builder's trees) ----
+// F[b] = (the cheapest way to hand b's subtree to a parent that has 1, 2, 3, 4 slots for it); leaves (at most max_leaf primitives): 0. A node's values need its
+// children's, so the plan is made in passes over all nodes: pass p finishes the nodes whose children were finished before p (as many passes as the binary tree is
+// high, each a few microseconds); `done_pass` says in which pass a node was finished, so that a value written in this pass is never read in it.
+constexpr int kPlanPending = 0x7FFFFFFF;
+__global__ void k_plan_init(int total, const int2* __restrict__ ranges, uint32_t max_leaf, int* __restrict__ done_pass, float4* __restrict__ F) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total) return;
+  const bool leaf = (uint32_t) (ranges[b].y - ranges[b].x + 1) <= max_leaf;
+  done_pass[b] = leaf ? 0 : kPlanPending;
+  F[b] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+__global__ void k_plan_pass(int total, const int2* __restrict__ children, const BinBox* __restrict__ node_box, int pass, int* __restrict__ done_pass, float4* __restrict__ F) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= total || done_pass[b] != kPlanPending) return;
+  const int2 c = children[b];
+  if (done_pass[c.x] >= pass || done_pass[c.y] >= pass) return;
+  const float4 l4 = F[c.x], r4 = F[c.y];
+  const float L[4] = {l4.x, l4.y, l4.z, l4.w}, R[4] = {r4.x, r4.y, r4.z, r4.w};
+  float G[5] = {0.0f, 0.0f, FLT_MAX, FLT_MAX, FLT_MAX};
+  for (int k = 2; k <= 4; k++)
+    for (int a = 1; a < k; a++) G[k] = fminf(G[k], L[a - 1] + R[k - a - 1]);
+  const float f0 = half_area(node_box[b]) + G[4];
+  F[b] = make_float4(f0, fminf(f0, G[2]), fminf(f0, G[3]), fminf(f0, G[4]));
+  done_pass[b] = pass;
+}
+__device__ __forceinline__ float plan_f(const float4* __restrict__ F, int b, int k) { const float4 f = F[b]; return k == 1 ? f.x : k == 2 ? f.y : k == 3 ? f.z : f.w; }
+
 // One 4-wide node per queue entry. Children that stay inner nodes get consecutive new indices and go to the next level's queue.
+// F == nullptr: the greedy rule of rounds 1-5 (the child with the largest box is opened until four are reached; LUM_BVH_COLLAPSE=0).
 __global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const int2* __restrict__ ranges, const BinBox* __restrict__ node_box, uint32_t max_leaf,
                                 const CollapseItem* __restrict__ in, uint32_t in_count, CollapseItem* __restrict__ out, uint32_t* __restrict__ out_count,
-                                uint32_t* __restrict__ node_count, Bvh4Node* __restrict__ nodes) {
+                                uint32_t* __restrict__ node_count, Bvh4Node* __restrict__ nodes, const float4* __restrict__ F) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= in_count) return;
   const CollapseItem item = in[q];
@@ -134,19 +164,38 @@ __global__ void k_lbvh_collapse(int n, const int2* __restrict__ children, const 
   int kids[4];
   int nk = 0;
   if (is_leaf(item.bin)) kids[nk++] = item.bin;  // whole mesh fits one leaf: root with a single leaf child
-  else { const int2 c = children[item.bin]; kids[nk++] = c.x; kids[nk++] = c.y; }
-  while (nk < 4) {
-    int pick = -1;
-    float best = -1.0f;
-    for (int k = 0; k < nk; k++) {
-      if (is_leaf(kids[k])) continue;
-      const float a = half_area(node_box[kids[k]]);
-      if (a > best) { best = a; pick = k; }
+  else if (F) {
+    // CollapsePlan::split / cut without recursion: (node, slots, must be opened), left pieces before right ones
+    int st_node[4], st_k[4]; bool st_open[4];
+    int sp = 0;
+    st_node[sp] = item.bin; st_k[sp] = 4; st_open[sp] = true; sp++;
+    while (sp > 0) {
+      sp--;
+      const int b = st_node[sp], k = st_k[sp];
+      const bool open = st_open[sp];
+      if (!open && (is_leaf(b) || k == 1 || plan_f(F, b, k) == plan_f(F, b, 1))) { kids[nk++] = b; continue; }
+      const int2 c = children[b];
+      int best_a = 1; float best = FLT_MAX;
+      for (int a = 1; a < k; a++) { const float cost = plan_f(F, c.x, a) + plan_f(F, c.y, k - a); if (cost < best) { best = cost; best_a = a; } }
+      st_node[sp] = c.y; st_k[sp] = k - best_a; st_open[sp] = false; sp++;
+      st_node[sp] = c.x; st_k[sp] = best_a; st_open[sp] = false; sp++;
     }
-    if (pick < 0) break;
-    const int2 c = children[kids[pick]];
-    kids[pick] = c.x;
-    kids[nk++] = c.y;
+  }
+  else {
+    const int2 c = children[item.bin]; kids[nk++] = c.x; kids[nk++] = c.y;
+    while (nk < 4) {
+      int pick = -1;
+      float best = -1.0f;
+      for (int k = 0; k < nk; k++) {
+        if (is_leaf(kids[k])) continue;
+        const float a = half_area(node_box[kids[k]]);
+        if (a > best) { best = a; pick = k; }
+      }
+      if (pick < 0) break;
+      const int2 c2 = children[kids[pick]];
+      kids[pick] = c2.x;
+      kids[nk++] = c2.y;
+    }
   }
   uint32_t inner = 0;
   for (int k = 0; k < nk; k++) inner += is_leaf(kids[k]) ? 0u : 1u;
@@ -272,6 +321,23 @@ __global__ void k_ploc_ranges(int n, const int2* __restrict__ children, const in
 
 #define LBVH_TRY(expr) do { if ((expr) != hipSuccess) { ok = false; goto done; } } while (0)
 
+bool collapse_rule_optimal() { const char* e = std::getenv("LUM_BVH_COLLAPSE"); return !e || std::atoi(e) != 0; }  // as the host builder's (bvh_build.cpp collapse)
+
+// Fills F (see k_plan_pass) for the binary tree of `total` nodes whose root is node 0. False: a HIP call failed, or the tree is higher than any tree the builders make.
+bool make_collapse_plan(int total, const int2* d_children, const int2* d_ranges, const BinBox* d_node_box, uint32_t max_leaf, int* d_done, float4* d_F) {
+  const int threads = 256, blocks = (total + threads - 1) / threads;
+  hipLaunchKernelGGL(k_plan_init, dim3(blocks), dim3(threads), 0, 0, total, d_ranges, max_leaf, d_done, d_F);
+  for (int pass = 1; pass <= 4096; pass++) {
+    hipLaunchKernelGGL(k_plan_pass, dim3(blocks), dim3(threads), 0, 0, total, d_children, d_node_box, pass, d_done, d_F);
+    if ((pass & 3) == 0 || pass < 4) {  // (a look every fourth pass: the download costs as much as a pass)
+      int root = kPlanPending;
+      if (hipMemcpy(&root, d_done, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return false;
+      if (root != kPlanPending) return true;
+    }
+  }
+  return false;
+}
+
 }  // namespace
 
 namespace {
@@ -296,6 +362,8 @@ Bvh4 build_on_device(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
   size_t scan_bytes = 0;
   CollapseItem* d_queue[2] = {nullptr, nullptr};
   Bvh4Node* d_nodes = nullptr;
+  int* d_plan_done = nullptr; float4* d_plan = nullptr;
+  const bool optimal = collapse_rule_optimal();
   void* d_temp = nullptr;
   size_t temp_bytes = 0;
   bool ok = true;
@@ -369,11 +437,18 @@ Bvh4 build_on_device(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
     const uint32_t init[4] = {0u, 1u, 0u, 0u};  // [0] next level's queue length, [1] nodes allocated
     LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
   }
+  if (optimal) {
+    const int total = 2 * n - 1;
+    LBVH_TRY(hipMalloc((void**) &d_plan_done, sizeof(int) * (size_t) total));
+    LBVH_TRY(hipMalloc((void**) &d_plan, sizeof(float4) * (size_t) total));
+    if (!make_collapse_plan(total, d_children, d_ranges, d_node_box, max_leaf, d_plan_done, d_plan)) { ok = false; goto done; }
+  }
   for (int cur = 0; level_count > 0; cur ^= 1) {
     depth++;
     if (depth > max_depth) { ok = false; goto done; }  // deeper than the traversal stack allows: the caller falls back to the host builder
     hipLaunchKernelGGL(k_lbvh_collapse, dim3((level_count + threads - 1) / threads), dim3(threads), 0, 0, n, (const int2*) d_children, (const int2*) d_ranges,
-                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[cur], level_count, d_queue[cur ^ 1], d_counters, d_counters + 1, d_nodes);
+                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[cur], level_count, d_queue[cur ^ 1], d_counters, d_counters + 1, d_nodes,
+                       (const float4*) d_plan);
     uint32_t host_counters[2];
     LBVH_TRY(hipMemcpy(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost));
     level_count = host_counters[0];
@@ -389,7 +464,7 @@ Bvh4 build_on_device(const Aabb* boxes, uint32_t count, uint32_t max_leaf, uint3
 done:
   {
     void* bufs[] = {d_boxes, d_node_box, d_codes, d_codes_sorted, d_ids, d_ids_sorted, d_arrivals, d_counters, d_children, d_ranges, d_parent, d_queue[0], d_queue[1], d_nodes, d_temp,
-                    d_count, d_prims, d_clusters[0], d_clusters[1], d_nearest, d_flags, d_offsets, d_totals, d_scan_temp};
+                    d_count, d_prims, d_clusters[0], d_clusters[1], d_nearest, d_flags, d_offsets, d_totals, d_scan_temp, d_plan_done, d_plan};
     for (void* b : bufs) if (b) (void) hipFree(b);
   }
   if (!ok) return Bvh4();
@@ -619,6 +694,8 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
   uint32_t* d_flags = nullptr; uint32_t* d_offsets = nullptr; uint32_t* d_counters = nullptr; void* d_scan_temp = nullptr;
   int2* d_children = nullptr; int2* d_ranges = nullptr; BinBox* d_node_box = nullptr;
   CollapseItem* d_queue[2] = {nullptr, nullptr}; Bvh4Node* d_nodes = nullptr;
+  int* d_plan_done = nullptr; float4* d_plan = nullptr;
+  const bool optimal = collapse_rule_optimal();
   char* d_pool = nullptr;
   size_t scan_bytes = 0;
   bool ok = true;
@@ -639,7 +716,9 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
     const size_t o_flags = reserve(sizeof(uint32_t) * n), o_offsets = reserve(sizeof(uint32_t) * n), o_counters = reserve(sizeof(uint32_t) * 4);
     const size_t o_children = reserve(sizeof(int2) * max_nodes2), o_ranges = reserve(sizeof(int2) * max_nodes2), o_node_box = reserve(sizeof(BinBox) * max_nodes2);
     const size_t o_nodes = reserve(sizeof(Bvh4Node) * max_nodes4), o_scan = reserve(scan_bytes ? scan_bytes : 16);
+    const size_t o_plan_done = reserve(optimal ? sizeof(int) * max_nodes2 : 0), o_plan = reserve(optimal ? sizeof(float4) * max_nodes2 : 0);
     LBVH_TRY(hipMalloc((void**) &d_pool, total));
+    if (optimal) { d_plan_done = (int*) (d_pool + o_plan_done); d_plan = (float4*) (d_pool + o_plan); }
     for (int k = 0; k < 2; k++) {
       d_boxes[k] = (BinBox*) (d_pool + o_boxes[k]); d_ids[k] = (uint32_t*) (d_pool + o_ids[k]); d_owner[k] = (int*) (d_pool + o_owner[k]);
       d_active[k] = (int*) (d_pool + o_active[k]); d_queue[k] = (CollapseItem*) (d_pool + o_queue[k]);
@@ -707,11 +786,13 @@ Bvh4 build_bvh4_sah_gpu(const Aabb* boxes, uint32_t count, uint32_t max_leaf, ui
     const uint32_t init[4] = {0u, 1u, 0u, 0u};
     LBVH_TRY(hipMemcpy(d_counters, init, sizeof(init), hipMemcpyHostToDevice));
   }
+  if (optimal && !make_collapse_plan((int) nodes_allocated, d_children, d_ranges, d_node_box, max_leaf, d_plan_done, d_plan)) { ok = false; goto done; }
   for (int q = 0; level_count > 0; q ^= 1) {
     depth++;
     if (depth > max_depth) { ok = false; goto done; }
     hipLaunchKernelGGL(k_lbvh_collapse, dim3((level_count + threads - 1) / threads), dim3(threads), 0, 0, (int) n, (const int2*) d_children, (const int2*) d_ranges,
-                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[q], level_count, d_queue[q ^ 1], d_counters, d_counters + 1, d_nodes);
+                       (const BinBox*) d_node_box, max_leaf, (const CollapseItem*) d_queue[q], level_count, d_queue[q ^ 1], d_counters, d_counters + 1, d_nodes,
+                       (const float4*) d_plan);
     uint32_t host_counters[2];
     LBVH_TRY(hipMemcpy(host_counters, d_counters, sizeof(host_counters), hipMemcpyDeviceToHost));
     level_count = host_counters[0];

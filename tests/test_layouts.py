@@ -58,7 +58,7 @@ def test_rendering_without_gpu_fails_loudly():
 def test_register_budgets_of_the_hot_kernels():
     """The occupancy the measurements in DESIGN.md section 4 / 8 rest on, read from the compiler's resource report of the last build
     (luminary_amd/lib/obj/kernel_resource_usage.txt): the fast flavour's ray kernels fit 128 registers (4 waves per SIMD, one 1024-thread workgroup per
-    CU) without spilling more than a handful, k_shade<constant sky> runs at 3 waves, k_clouds at 4, and no shading kernel falls to a single wave."""
+    CU) without spilling (since round 6's two-triangle leaves), k_shade<constant sky> runs at 3 waves, k_clouds at 4, and no shading kernel falls to a single wave."""
     import subprocess
     path = os.path.join(ROOT, "luminary_amd", "lib", "obj", "kernel_resource_usage.txt")
     assert os.path.exists(path), "run `python -m luminary_amd.build` first"
@@ -77,8 +77,9 @@ def test_register_budgets_of_the_hot_kernels():
                 cur[short] = int(m.group(1))
     names = subprocess.run(["c++filt"] + [r["name"] for r in rows], capture_output=True, text=True).stdout.split("\n")
     table = {re.sub(r"\(.*", "", n).replace("void ", ""): r for r, n in zip(rows, names)}
-    for k in ("lum::fast::k_trace", "lum::fast::k_shadow_rays", "lum::fast::k_trace_particles"):
-        assert table[k]["occ"] == 4 and table[k]["vgpr"] <= 128 and table[k]["spill"] <= 16, (k, table[k])
+    # round 6: leaves of at most two triangles (LUM_LEAF_MAX) took 24 registers out of the ray kernels - nothing is spilled any more (k_trace: 128 + 12 spilled before)
+    for k in ("lum::fast::k_trace", "lum::fast::k_shadow_rays", "lum::fast::k_trace_particles", "lum::exact::k_trace", "lum::exact::k_shadow_rays"):
+        assert table[k]["occ"] >= 4 and table[k]["vgpr"] <= 120 and table[k]["spill"] == 0, (k, table[k])
     for with_table in ("true", "false"):  # constant sky, no ocean, the whole vertex in one kernel (stage 0: the product); with the pass's Sobol table and hashing
         shade = table["lum::fast::k_shade<2u, false, 0, %s>" % with_table]
         assert shade["occ"] == 3 and shade["spill"] <= 12, shade  # (10 with the input cursor's four wave-uniform words; measured faster all the same)

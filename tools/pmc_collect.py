@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--workloads", default="hall,example,scan")
     ap.add_argument("--flavour", default=None)
     ap.add_argument("--calib", action="store_true")
-    ap.add_argument("--spp", type=int, default=32)
+    ap.add_argument("--spp", type=int, default=64)  # bench.py's default
     ap.add_argument("--extra", default="", help="extra bench.py arguments for every workload (e.g. '--clouds'): feature frames instead of the BASELINE ones")
     ap.add_argument("--passes", default="", help="comma-separated subset of the counter groups (fetch,write,tcc,ea,sq,ta,tcp,sq2); default: all")
     ap.add_argument("--label", default="", help="suffix of the workload keys when --extra is given (e.g. 'clouds' -> 'example+clouds')")
