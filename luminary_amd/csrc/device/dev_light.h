@@ -437,9 +437,21 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
 #ifndef LUM_ABLATE_LANES
 #define LUM_ABLATE_LANES kLightTreeOutputs  // measurement only: fewer resampling lanes evaluated (results are wrong)
 #endif
+  // Experiment (LUM_PREFETCH_RANDOM): a candidate's random pair is a table word and a blue-noise texel - two gathers the iteration waits for right at its top. With the
+  // switch the pair of candidate l + 1 is requested while candidate l is worked on (the raw integers: two registers live across the loop body).
+#ifndef LUM_PREFETCH_RANDOM
+#define LUM_PREFETCH_RANDOM 0
+#endif
+#if LUM_PREFETCH_RANDOM
+  U2 next_pair = smp.raw2(kRndLightGeoRay);
+#endif
 #pragma nounroll
   for (uint32_t lane = 0; lane < LUM_ABLATE_LANES; lane++) {
     LUM_STAT(8, 9);
+#if LUM_PREFETCH_RANDOM
+    const U2 this_pair = next_pair;
+    next_pair = smp.raw2(kRndLightGeoRay + min(lane + 1u, (uint32_t) kLightTreeOutputs - 1u));
+#endif
     const TreePick pick = tree_postpass(sc, g, smp, lane, work);
     if (pick.light_id == kLightIdInvalid) continue;
 #if LUM_LDS_LIGHTS
@@ -452,7 +464,12 @@ LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, con
     const TriLight& tl = entry.tri;
     if (handle.x == g.instance_id && handle.y == g.tri_id) continue;
     V3 ray; float sa;
-    if (!sample_tri_solid_angle(g.position, tl, smp.next2(kRndLightGeoRay + lane), ray, sa)) continue;
+#if LUM_PREFETCH_RANDOM
+    const F2 pair = F2{unit_float(this_pair.x), unit_float(this_pair.y)};
+#else
+    const F2 pair = smp.next2(kRndLightGeoRay + lane);
+#endif
+    if (!sample_tri_solid_angle(g.position, tl, pair, ray, sa)) continue;
     F2 uv;
     const float dist = intersect_triangle(tl.vertex, tl.edge1, tl.edge2, g.position, ray, uv);
     if (dist == kFltMax) continue;

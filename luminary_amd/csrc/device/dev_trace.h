@@ -891,9 +891,12 @@ struct ClosestState {
   uint32_t ign_inst, ign_tri;
   Hit best;
   LUM_DEV void begin(bool ignore, uint32_t inst, uint32_t tri) { use_ignore = ignore; cutout = false; ign_inst = inst; ign_tri = tri; best = Hit{kHitSky, 0u, kFltMax, 0u}; }
+#ifndef LUM_CLOSEST_ALL_SLOTS
+#define LUM_CLOSEST_ALL_SLOTS 0  // 1: the closest-hit rays fetch every leaf slot unconditionally, as the visibility rays do (LeafTris::load)
+#endif
   LUM_DEV bool on_tris(const DeviceScene& sc, uint32_t inst, uint32_t first, uint32_t count, V3 o, V3 d, float& tmax, RayStats& st) {
     LeafTris lt;
-    lt.load<false>(sc.blas_tris, first, count);
+    lt.load<LUM_CLOSEST_ALL_SLOTS != 0>(sc.blas_tris, first, count);
 #pragma unroll
     for (uint32_t j = 0; j < kBvhLeafMaxTri; j++) {
       if (j >= count) break;
