@@ -90,12 +90,22 @@ LUM_DEV f2 tree_importance_pair(const GeoContext& g, f2 power, f2 mx, f2 my, f2 
   const f2 dist_sq = px * px + py * py + pz * pz;
   const f2 variance = sd * sd;
   const f2 denom = dist_sq + variance;
+#if LUM_FAST
+  // one v_rsq_f32 per child instead of v_rcp_f32 and v_sqrt_f32 (quarter-rate instructions, 64 children per vertex): 1 / x = rsq(x)^2
+  const f2 rs = f2{__builtin_amdgcn_rsqf(denom.x), __builtin_amdgcn_rsqf(denom.y)};
+  const f2 inv = rs * rs;
+#else
   const f2 inv = f2{1.0f / denom.x, 1.0f / denom.y};
+#endif
   const f2 r = power * inv;
   if ((g.params.flags & kMatSubstrateMask) == kMatTranslucent) return r;
   const f2 t = variance * inv;
   const f2 d = px * g.normal.x + py * g.normal.y + pz * g.normal.z;
+#if LUM_FAST
+  const f2 ndl = d * rs;
+#else
   const f2 ndl = d * f2{sqrtf(inv.x), sqrtf(inv.y)};
+#endif
   const f2 NdotL = f2{saturate(ndl.x), saturate(ndl.y)};
   return r * (NdotL * (1.0f - t) + t);
 }
@@ -104,13 +114,38 @@ LUM_DEV f2 tree_importance_pair(const GeoContext& g, f2 power, f2 mx, f2 my, f2 
 // Two thirds of the pass are the eight reservoirs' updates (ris.cuh:138-148, per child and lane: accept = r < p; r = clamp(accept ? r / p : (r - p) / (1 - p))).
 // Both quotients are formed for two lanes at a time with packed multiplies - they do not depend on the comparison - and the comparison only selects:
 // the same operations on the same operands as the one-lane-at-a-time form, in 5.5 instead of 8 instructions per child and lane.
+// Round 6, measured by ablation (one lane instead of eight: k_shade -30 % on the hall, whose 64 lights are all root children - profiles/r06_ab_experiments.txt): the
+// seven other lanes' updates are the largest single item of k_shade, more than the eight candidates' sampling and BSDF work together (four candidates instead of
+// eight: -13 %). Two changes since:
+//  * both flavours: the clamp after the update is an upper bound only. The selected value is never negative - an accepted r is multiplied by a positive
+//    reciprocal, a rejected one has r >= p, and r - p is exact or rounds to a non-negative number - so max(x, 0) never acts and v_min replaces v_med3. Same bits.
+//  * fast flavour: the scan in threshold form (LUM_ROOT_THRESHOLD). With W_c the running sum after child c, and for a lane whose last accepted child left it the
+//    random r0 at running sum W0: the rejections of children a .. b telescope to r_b = (r0 W_b - (W_b - W0)) / W0, so the lane accepts child c exactly when
+//    t W_c > 1 with t = (1 - r0) / W0 - a constant of the lane until it accepts again - and an accepted child turns t into (t W_c - 1) * W_{c-1} / (w_c W_c),
+//    whose second factor is the same for all eight lanes. Per child and lane: one packed fma and one packed multiply for two lanes, a comparison and three
+//    selects, nothing for the rejected random number - 4 + 2 x 0.5 instead of 5 + 3 x 0.5 instructions, none of them a v_med3. In real arithmetic the picks
+//    are the reference's; in binary32 the two forms agree with real arithmetic equally often (the scan is an expanding map - every accepted child multiplies the
+//    lane's rounding error by 1 / p - so ~5 % of all 64-child scans end on another child than real arithmetic's in EITHER form, and in any build that rounds a
+//    reciprocal differently: tests/test_root_pass_forms.py). The exact flavour keeps the reference's operation order and stays bit-identical to the oracle.
+#ifndef LUM_ROOT_THRESHOLD
+#define LUM_ROOT_THRESHOLD LUM_FAST
+#endif
+// ... and with it (LUM_ROOT_KEY) the picked child and its importance travel in ONE word per lane - the importance's bits with the child's index (< 128) in place of the
+// seven lowest mantissa bits - so that an accepted child costs two selects (threshold constant, key) instead of three. The importance only serves the lane's
+// selection probability, which is quantised to 20 bits right after the scan (light_tree.cuh:176-183); 16 mantissa bits of it move that probability by at most 2^-16 of itself.
+// Measured (hall, same box, profiles/r06_ab_experiments.txt): threshold form k_shade -4.9 %, with the key another -1.9 % (+2.4 % and +0.8 % samples/s). LUM_ROOT_KEY=2 - the
+// selects as integer instructions on vector registers, below - is level with 1 (the compiler then issues the packed products one lane at a time): kept as a record.
+#ifndef LUM_ROOT_KEY
+#define LUM_ROOT_KEY LUM_ROOT_THRESHOLD
+#endif
+LUM_DEV float clamp_random_top(float r) { return fminf(r, bitsf(0x3F7FFFFFu)); }  // clamp_random for r >= 0
 template <class Ctx, class Smp>
 LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Smp& smp) {
   const RootHeader hp = (RootHeader) sc.light_tree_root;
   const uint4 h = make_uint4(hp[0], hp[1], hp[2], hp[3]);
   const uint32_t num_root_lights = h.y >> 16, num_children = ((h.z >> 16) & 0xFFu) * 8u;
   const RootTable table = (RootTable) sc.light_root_children;
-  f2 lane_random[kLightTreeOutputs / 2];
+  f2 lane_random[kLightTreeOutputs / 2];  // LUM_ROOT_THRESHOLD: the lane's random number until its first child, its threshold constant t from then on
   float lane_target[kLightTreeOutputs];
   uint32_t lane_pick[kLightTreeOutputs];
 #pragma unroll
@@ -127,6 +162,62 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Smp& sm
 #pragma unroll
     for (uint32_t k = 0; k < 2; k++) {
       const float target = (power[k] == 0.0f) ? 0.0f : fmaxf(imp[k], 0.0f);
+#if LUM_ROOT_THRESHOLD
+      if (!(target > 0.0f)) continue;
+      const float before = total;
+      total += target;
+      sum += target;
+      if (before == 0.0f) {  // the vertex's first child with any importance: probability 1, every lane takes it and keeps its random number
+        const float inv = 1.0f / target;
+#pragma unroll
+        for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
+          lane_random[l >> 1][l & 1] = (1.0f - lane_random[l >> 1][l & 1]) * inv;
+#if LUM_ROOT_KEY
+          lane_pick[l] = (fbits(target) & 0xFFFFFF80u) | (c + k);
+#else
+          lane_target[l] = target;
+          lane_pick[l] = c + k;
+#endif
+        }
+        continue;
+      }
+#if LUM_ROOT_KEY
+      const uint32_t key = (fbits(target) & 0xFFFFFF80u) | (c + k);
+#endif
+      const float step = before / (target * total);  // W_{c-1} / (w_c W_c)
+      const f2 w2 = f2{total, total}, s2 = f2{step, step};
+#pragma unroll
+      for (uint32_t q = 0; q < ((LUM_ABLATE_LIGHT & 4) ? 1u : kLightTreeOutputs / 2); q++) {
+        const f2 excess = lane_random[q] * w2 - 1.0f;  // t W_c - 1 (one packed fma under the fast flavour's contraction): positive = accepted
+        const f2 next = excess * s2;
+#pragma unroll
+        for (uint32_t hlf = 0; hlf < 2; hlf++) {
+          const uint32_t l = 2 * q + hlf;
+#if LUM_ROOT_KEY == 2
+          // No comparison and no select: a rejected child's `next` is negative (or -0), and as an unsigned word a negative float is larger than every positive one - the
+          // unsigned minimum keeps the lane's constant unless the child was accepted (an accepted child's constant is the smaller one: t' <= 1 / W_c < t) - and the
+          // same sign, spread over a word, is the bit mask of the key's select (v_ashrrev_i32, v_bfi_b32, v_min_u32: three vector instructions on vector registers,
+          // where a comparison writes a scalar mask that three selects then wait two cycles for). t W_c = 1 exactly counts as accepted here.
+          // (as instructions: written as C the compiler turns the mask back into a comparison and a select, and splits the packed products)
+          uint32_t rejected;
+          asm("v_ashrrev_i32 %0, 31, %1" : "=v"(rejected) : "v"(next[hlf]));
+          asm("v_bfi_b32 %0, %1, %0, %2" : "+v"(lane_pick[l]) : "v"(rejected), "v"(key));
+          float kept = lane_random[q][hlf];
+          asm("v_min_u32 %0, %0, %1" : "+v"(kept) : "v"(next[hlf]));
+          lane_random[q][hlf] = kept;
+          continue;
+#endif
+          const bool accept = excess[hlf] > 0.0f;
+#if LUM_ROOT_KEY
+          lane_pick[l] = accept ? key : lane_pick[l];
+#else
+          lane_target[l] = accept ? target : lane_target[l];
+          lane_pick[l] = accept ? c + k : lane_pick[l];
+#endif
+          lane_random[q][hlf] = accept ? next[hlf] : lane_random[q][hlf];
+        }
+      }
+#else
       total += target;
       const float prob = (target > 0.0f) ? target / total : 0.0f;
       if (prob == 0.0f) continue;
@@ -147,13 +238,21 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Smp& sm
           const bool accept = lane_random[q][hlf] < prob;
           lane_target[l] = accept ? target : lane_target[l];  // (evaluating the picked child's importance again after the scan instead costs more in spills than this select)
           lane_pick[l] = accept ? c + k : lane_pick[l];
-          lane_random[q][hlf] = clamp_random(accept ? if_accepted[hlf] : if_rejected[hlf]);
+          lane_random[q][hlf] = clamp_random_top(accept ? if_accepted[hlf] : if_rejected[hlf]);
         }
       }
+#endif
     }
   }
   TreeWork w;
   w.root_sum = sum * (bfloat_unpack(h.z) / 65535.0f);
+#if LUM_ROOT_THRESHOLD && LUM_ROOT_KEY
+#pragma unroll
+  for (uint32_t l = 0; l < kLightTreeOutputs; l++) {  // (a lane that met no child keeps key 0: child 0, importance 0 - as the separate words would say)
+    lane_target[l] = bitsf(lane_pick[l] & 0xFFFFFF80u);
+    lane_pick[l] &= 0x7Fu;
+  }
+#endif
 #pragma unroll
   for (uint32_t l = 0; l < kLightTreeOutputs; l++) {
     const bool is_light = lane_pick[l] < num_root_lights;

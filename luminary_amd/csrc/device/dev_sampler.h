@@ -68,7 +68,8 @@ LUM_DEV float clamp_random(float r) { return fminf(fmaxf(r, 0.0f), bitsf(0x3F7FF
 // ids differ by pixel; the undersampling preview; more than kSobolTableMaxSamples ids; LUM_SOBOL_TABLE_RT=0) launch the kTable = false instances, which hold no
 // table code. Measured (profiles/r05_ab_experiments.txt): k_shade -4.7 %, +2.2 % samples/s on the hall; one kernel with a run-time branch between the two forms
 // gained half of that and lost 3 % when the hash ran.
-constexpr uint32_t kSobolTableMaxSamples = 256u;  // sample ids per pass a table is built for (11 MB at 8 bounces); larger passes hash
+constexpr uint32_t kSobolTableMaxSamples = 1024u;  // sample ids per pass a table is built for (42 MB at 8 bounces; a depth's slab - what one k_shade launch reads - 4.7 MB);
+                                                  // larger passes hash. Round 6: 256 -> 1024, because bench.py's pass is 64 ids x the number of ranks (512 at 8 GPUs)
 template <bool kTable>
 struct SamplerT {
   const uint32_t* bluenoise;

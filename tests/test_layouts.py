@@ -56,7 +56,7 @@ def test_rendering_without_gpu_fails_loudly():
 
 
 def test_register_budgets_of_the_hot_kernels():
-    """The occupancy the measurements in DESIGN.md section 4 / 8 rest on, read from the compiler's resource report of the last build
+    """The occupancy the measurements in DESIGN.md section 4 (and docs/HISTORY.md) rest on, read from the compiler's resource report of the last build
     (luminary_amd/lib/obj/kernel_resource_usage.txt): the fast flavour's ray kernels fit 128 registers (4 waves per SIMD, one 1024-thread workgroup per
     CU) without spilling (since round 6's two-triangle leaves), k_shade<constant sky> runs at 3 waves, k_clouds at 4, and no shading kernel falls to a single wave."""
     import subprocess

@@ -73,7 +73,7 @@ def test_large_passes_pixel_subsets_and_depth_zero(tmp_path):
     core = Core(0)
     try:
         core.upload(view)   # the suite's flavour: exact
-        for first, count, batch in [(0, 300, 300), (7, 256, 256), (1000, 40, 16), (3, 2, 1)]:
+        for first, count, batch in [(0, 1100, 1100), (7, 1024, 1024), (0, 300, 300), (1000, 40, 16), (3, 2, 1)]:
             fm0, sm0, c0 = _frame(core, False, first, count, batch)
             fm1, sm1, c1 = _frame(core, True, first, count, batch)
             assert c1 == c0 and np.array_equal(fm1, fm0) and np.array_equal(sm1, sm0), (first, count, batch)
