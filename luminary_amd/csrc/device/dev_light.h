@@ -519,12 +519,45 @@ LUM_DEV float light_direction_probability_terms(const MatParams& p, V3 Vl, const
 // ---- light sampling (light.cuh:84-159) ----
 struct LightSample { uint32_t light_id; V3 ray; Col color; float dist, root_sum; };
 
+// Measurement switch LUM_DUP (bit mask; profiles/r06_ab_experiments.txt "what the parts of k_shade cost"): the named part of a vertex's work is done TWICE - the second time
+// on inputs the compiler cannot see through, its results handed to an empty asm statement - so that the part's cost shows as the kernel's extra time while every result,
+// every path and every other kernel stay what they are. (Leaving a part OUT - the LUM_ABLATE switches - also removes whatever only it kept alive, and changes the paths.)
+//   1 the light tree's root pass   2 the candidate loop   4 the surface context   8 the bounce sample   16 the BSDF-driven light direction   32 the local frame
+#ifndef LUM_DUP
+#define LUM_DUP 0
+#endif
+LUM_DEV void dup_sink(float x) { asm volatile("" :: "v"(x)); }
+LUM_DEV void dup_sink(uint32_t x) { asm volatile("" :: "v"(x)); }
+LUM_DEV void dup_sink(V3 a) { asm volatile("" :: "v"(a.x), "v"(a.y), "v"(a.z)); }
+LUM_DEV void dup_sink(Col a) { asm volatile("" :: "v"(a.r), "v"(a.g), "v"(a.b)); }
+LUM_DEV GeoContext dup_launder(GeoContext g) { asm volatile("" : "+v"(g.position.x), "+v"(g.position.y), "+v"(g.position.z), "+v"(g.normal.x), "+v"(g.V.x)); return g; }
+
+template <class Smp>
+LUM_DEV LightSample light_candidates(const DeviceScene& sc, const GeoContext& g, const Smp& smp, ShadeClock& clock, const StagedLights& staged, const TreeWork& work,
+                                     const Energy& energy);
 template <class Smp>
 LUM_DEV LightSample sample_light(const DeviceScene& sc, const GeoContext& g, const Smp& smp, ShadeClock& clock, const StagedLights& staged) {
   LUM_STAT(14, 15);
   const TreeWork work = tree_prepass(sc, g, smp);
+  if (LUM_DUP & 1) {
+    const TreeWork again = tree_prepass(sc, dup_launder(g), smp);
+#pragma unroll
+    for (uint32_t l = 0; l < kLightTreeOutputs; l++) dup_sink(again.cont[l]);
+    dup_sink(again.root_sum);
+  }
   const Energy energy = energy_terms(sc, g.params, world_ndotv(g));
   LUM_LAP(clock, 1);
+  if (LUM_DUP & 2) {
+    TreeWork w2 = work;
+    asm volatile("" : "+v"(w2.cont[0]), "+v"(w2.root_sum));
+    const LightSample again = light_candidates(sc, dup_launder(g), smp, clock, staged, w2, energy);
+    dup_sink(again.light_id); dup_sink(again.ray); dup_sink(again.color); dup_sink(again.dist);
+  }
+  return light_candidates(sc, g, smp, clock, staged, work, energy);
+}
+template <class Smp>
+LUM_DEV LightSample light_candidates(const DeviceScene& sc, const GeoContext& g, const Smp& smp, ShadeClock& clock, const StagedLights& staged, const TreeWork& work,
+                                     const Energy& energy) {
   LightSample out;
   out.light_id = kLightIdInvalid; out.ray = v3(0.0f, 0.0f, 0.0f); out.color = splat(0.0f); out.dist = 0.0f;
   Reservoir rv;

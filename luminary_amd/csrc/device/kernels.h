@@ -626,6 +626,12 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         smp.detect_uniform();
         smp.use_table(sc.sobol_table + (size_t) depth_const * kRndTargetCount * sc.sobol_stride, sc.sobol_stride, sc.sobol_first);  // (kTable: the pass has one)
         const GeoContext g = build_context(sc, hit_origin, ray, state, hid.x, hid.y, in.hit_scene_tri[i] & kHitTriMask, aux.z);
+        if (LUM_DUP & 4) {  // (measurement: see LUM_DUP in dev_light.h)
+          V3 ho = hit_origin; uint32_t tri = hid.y;
+          asm volatile("" : "+v"(ho.x), "+v"(ho.y), "+v"(tri));
+          const GeoContext again = build_context(sc, ho, ray, state, hid.x, tri, in.hit_scene_tri[i] & kHitTriMask, aux.z);
+          dup_sink(again.position); dup_sink(again.normal); dup_sink(again.V); dup_sink(again.params.roughness()); dup_sink(again.params.emission()); dup_sink(again.face_normal_packed);
+        }
         // the volume the vertex is in: without an ocean the stack holds the fog or nothing for the whole path
         const uint32_t top_volume = kWater ? volume_stack_peek(hid.w, false) : (sc.fog_active ? (uint32_t) kVolumeFog : (uint32_t) kVolumeNone);
         const uint32_t second_volume = kWater ? volume_stack_peek(hid.w, true) : (uint32_t) kVolumeNone;
@@ -663,10 +669,12 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         else {
         // the shading frame is formed after the light sampling: its thirteen registers need not live through the candidate loop
         const LocalFrame lf = local_frame(sc, g);
+        if (LUM_DUP & 32) { const LocalFrame again = local_frame(sc, dup_launder(g)); dup_sink(again.V); dup_sink(again.face_normal); dup_sink(again.to_z.x); dup_sink(again.energy.conductor); dup_sink(again.energy.glossy); dup_sink(again.energy.dielectric); }
         if (geo_allowed) {
           LightDirSample lb;
           if (LUM_ABLATE & 2) { lb.ray = v3(0.0f, 0.0f, 1.0f); lb.weight = splat(0.0f); lb.probability = 0.0f; }
           else lb = sample_light_direction(lf, g, smp);
+          if (LUM_DUP & 16) { const LightDirSample again = sample_light_direction(lf, dup_launder(g), smp); dup_sink(again.ray); dup_sink(again.weight); dup_sink(again.probability); }
           bs_rp = make_float4(lb.ray.x, lb.ray.y, lb.ray.z, lb.probability);
           if (lb.probability != 0.0f) {
             want_lq = true;
@@ -677,6 +685,7 @@ __global__ __launch_bounds__(kBlock, kStage == 1 ? LUM_SHADE_STAGE1_WAVES : kSta
         BounceSample bounce;
         if (LUM_ABLATE & 4) { bounce.ray = g.normal; bounce.weight = splat(0.5f); bounce.transparent_pass = false; bounce.microfacet_based = false; }
         else bounce = sample_bounce(lf, g, smp, 0);
+        if (LUM_DUP & 8) { const BounceSample again = sample_bounce(lf, dup_launder(g), smp, 0); dup_sink(again.ray); dup_sink(again.weight); dup_sink((uint32_t) again.transparent_pass); }
         uint4 amb = make_uint4(0u, 0u, 0u, 0u);
         if (kSkyMode != kSkyDefault) {  // ambient: the bounce direction doubles as the sample (direct_lighting.cuh:388-405)
           const Col ambient = (kSkyMode == kSkyHdri) ? sky_hdri_color(sc, g.position, bounce.ray, 0u) : sky;
