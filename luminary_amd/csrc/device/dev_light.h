@@ -161,7 +161,14 @@ LUM_DEV TreeWork tree_prepass(const DeviceScene& sc, const Ctx& g, const Smp& sm
     const f2 imp = tree_importance_pair(g, power, f2{e[0], e[8]}, f2{e[1], e[9]}, f2{e[2], e[10]}, f2{e[3], e[11]});
 #pragma unroll
     for (uint32_t k = 0; k < 2; k++) {
+#if LUM_ROOT_THRESHOLD
+      // (a child without power has importance power * ... = 0, or NaN where the vertex sits on its mean with no variance, and v_max_f32 drops a NaN operand:
+      //  the reference's separate test for power 0 selects what the maximum already gives; one raw v_max instead of a canonicalising pair, a comparison and a select)
+      float target;
+      asm("v_max_f32 %0, 0, %1" : "=v"(target) : "v"(imp[k]));
+#else
       const float target = (power[k] == 0.0f) ? 0.0f : fmaxf(imp[k], 0.0f);
+#endif
 #if LUM_ROOT_THRESHOLD
       if (!(target > 0.0f)) continue;
       const float before = total;
