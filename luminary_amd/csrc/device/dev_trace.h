@@ -8,8 +8,9 @@
 // Results do not depend on traversal order: ties are broken by (t, instance, triangle) and the light pick is a function of
 // the candidate set only (see light_query).
 //
-// Execution model (gfx950; counters of rounds 4-5, profiles/pmc_counters.json, profiles/r05_ab_experiments.txt, DESIGN.md sections 0 and 4): one ray per lane,
-// persistent waves, one workgroup of 1024 threads = 16 waves per CU = 4 waves per SIMD (128 VGPRs) in BOTH flavours since round 4. On the hall a closest-hit
+// Execution model (gfx950; the counters quoted here are rounds 4-5's, profiles/r05_ab_experiments.txt; the current ones: profiles/pmc_counters.json and DESIGN.md section 0): one ray per lane,
+// persistent waves, one workgroup of 1024 threads = 16 waves per CU = 4 waves per SIMD in BOTH flavours since round 4 - 114 / 110 VGPRs and nothing spilled since round 6's
+// two-triangle leaves (LUM_LEAF_MAX, dev_scene.h: the leaf registers are 3 x float4 per slot; with four slots k_trace sat at 128 + 12 spilled). On the hall a closest-hit
 // launch runs at a VALU lane utilisation of 0.45 (visibility: 0.53), its waves wait 0.56 (0.61) of their cycles, and the vector-memory address unit is busy 0.71
 // of the launch: a divergent 16-byte lane load costs it one cycle per LANE (7 per node visit that misses the staged top, 3 per triangle), whatever the number of
 // wave instructions that carry them. The kernels sit between the two: every variant that removed lane loads added instructions and became issue-bound (64-byte
@@ -18,6 +19,7 @@
 // of vector instructions and run 25-80 % slower, because twice the rays per CU halve each ray's share of LDS (stack bottoms, staged nodes). Memory bandwidth is
 // not the limit (0.52 / 0.38 of 8 TB/s memory-side), latency as such neither (an L1->L2 read returns after ~400 cycles, a tenth of a wave iteration).
 // What an iteration costs:
+//   * (a leaf = at most two triangles, 3 x 16-byte loads each; trees: the builders' binary SAH tree cut into 4-wide nodes by a dynamic programme, bvh_build.cpp CollapsePlan)
 //   * one node visit = 7 x 16-byte loads (near/far planes picked by the ray's direction signs, so no per-axis min/max),
 //     24 fma, v_max3/v_min3, a 5-comparator sorting network on (entry distance, child) pairs and conditional pushes: ~110 vector instructions;
 //   * every wave iteration runs ONE phase - node visit, instance entry or triangle tests - chosen by a vote over its lanes, so a
@@ -534,13 +536,13 @@ LUM_DEV void stack_push(S& stk, int& sp, E& top, E e) { stk.store(sp, top); sp++
 LUM_DEV float4 tri_f4(const BvhTri* tris, uint32_t index, uint32_t word) { return reinterpret_cast<const float4*>(tris + index)[word]; }
 
 // All triangles of a leaf are fetched before the first test, so a leaf costs one memory round trip instead of one per triangle.
-// The twelve loads are unconditional - slots beyond the leaf's count re-read its last triangle (same cache lines, nothing new is fetched): with a
+// The loads (3 per slot; twelve with the four slots of rounds 1-5, six since round 6) are unconditional - slots beyond the leaf's count re-read its last triangle (same cache lines, nothing new is fetched): with a
 // branch per slot the compiler parked the slots in other registers behind `s_waitcnt`s of their own, and a four-triangle leaf waited for memory
 // up to four times in a row (measured: 9.5 us per triangle phase of a wave against 2 us per node phase).
 struct LeafTris {
   float4 a[kBvhLeafMaxTri], b[kBvhLeafMaxTri], c[kBvhLeafMaxTri];
   // kAllSlots: slots beyond the leaf's count re-read its last triangle (see above); otherwise a branch per slot. Measured on the hall, same box: the
-  // visibility kernel 386 -> 374 ms per 3 steps with all slots, the closest-hit kernel 215 -> 221 - each query type takes what suits it.
+  // visibility kernel 386 -> 374 ms per 3 steps with all slots, the closest-hit kernel 215 -> 221 - each query type takes what suits it (round 6, two slots: closest-hit +2.2 % with all slots).
   template <bool kAllSlots>
   LUM_DEV void load(const BvhTri* __restrict__ tris, uint32_t first, uint32_t count) {
 #pragma unroll
