@@ -144,16 +144,17 @@ def test_bench_does_not_price_kernels_with_counters_of_another_build(monkeypatch
     with; bench.py derives counter-based figures only when both match its own - otherwise the record is flagged stale and `traffic` / `frac` stay
     null (never an inferred bound)."""
     import bench
-    recorded = bench.pmc_record("hall", 32, "fast", 0)
+    SPP = 64  # bench.py's default pass (round 6; tools/pmc_collect.py collects at the same size)
+    recorded = bench.pmc_record("hall", SPP, "fast", 0)
     if recorded is None:
         pytest.skip("no counter record for the hall in profiles/pmc_counters.json")
     then = int(recorded.get("lds_stack_bytes", 0))
     monkeypatch.setattr(bench, "source_hash", lambda: recorded.get("source_hash"))
-    assert bench.pmc_record("hall", 32, "fast", then)["_stale"] is False
-    assert bench.pmc_record("hall", 32, "fast", then + 4096)["_stale"] is True
+    assert bench.pmc_record("hall", SPP, "fast", then)["_stale"] is False
+    assert bench.pmc_record("hall", SPP, "fast", then + 4096)["_stale"] is True
     monkeypatch.setattr(bench, "source_hash", lambda: "another tree")
-    assert bench.pmc_record("hall", 32, "fast", then)["_stale"] is True
-    assert bench.pmc_record("hall", 32, "exact", then) is None or bench.pmc_record("hall", 32, "exact", then).get("flavour") == "exact"
+    assert bench.pmc_record("hall", SPP, "fast", then)["_stale"] is True
+    assert bench.pmc_record("hall", SPP, "exact", then) is None or bench.pmc_record("hall", SPP, "exact", then).get("flavour") == "exact"
 
 
 def _adaptive_rates(host):
