@@ -25,6 +25,14 @@ VARIANTS=(
   "shade_staged:-DLUM_SHADE_STAGED=1:"
   "shade_static:-DLUM_SHADE_DYNAMIC=0:core"
   "phase_stats:-DLUM_PHASE_STATS:core"
+  "leaf4:-DLUM_LEAF_MAX=4:core"
+  "root_reference_form:-DLUM_ROOT_THRESHOLD=0:"
+  "root_threshold_no_key:-DLUM_ROOT_KEY=0:"
+  "root_integer_selects:-DLUM_ROOT_KEY=2:"
+  "closest_all_slots:-DLUM_CLOSEST_ALL_SLOTS=1:"
+  "prefetch_random:-DLUM_PREFETCH_RANDOM=1:"
+  "dup_all:-DLUM_DUP=63:"
+  "ablate_all:-DLUM_ABLATE=7 -DLUM_ABLATE_LIGHT=7:"
 )
 one() {
   local name=${1%%:*} rest=${1#*:}
