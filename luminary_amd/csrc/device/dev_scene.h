@@ -333,7 +333,12 @@ static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second ha
 #define LUM_LDS_STACK_BYTES ((LUM_POOL_STACK_ENTRIES * 8u + 48u + 4u) * LUM_POOL_SLOTS * (LUM_TRACE_BLOCK / 64u))
 #endif
 #ifndef LUM_LDS_STACK_BYTES
-#define LUM_LDS_STACK_BYTES 65536u  // of a ray workgroup's LDS: bytes that hold the oldest entries of its lanes' traversal stacks instead of tree nodes (0: stacks in scratch)
+// Of a ray workgroup's LDS: bytes that hold the oldest entries of its lanes' traversal stacks instead of tree nodes (0: stacks in scratch). Rounds 2-5: 64 KB (8 closest-hit /
+// 16 visibility entries per lane beside 704 staged nodes; round 3 measured 96 KB at 0 / +1 %). Round 6, with the deeper two-triangle-leaf trees: 96 KB (12 / 24 entries, 448 nodes) -
+// same box, 48 / 64 / 80 / 96 / 112 KB: hall k_trace 418 / 409 / 409 / 409 / 411 ms per 3 steps (samples/s -0.1 % at 96 KB: noise), the 10 M-triangle scan 127 / 116.5 / 110.6 /
+// 108.1 / 107.3 (+3.2 % samples/s at 96 KB), Example-class level up to 96 KB and -1.2 % at 112 (profiles/r06_ab_experiments.txt): what a big tree's rays push past the LDS entries
+// goes to scratch, i.e. through the same memory path as the nodes they are looking for.
+#define LUM_LDS_STACK_BYTES 98304u
 #endif
 constexpr uint32_t kRayBlockMax = 1024u;  // the ray kernels' largest workgroup: a lane's share of the LDS stack area is sized for it
 

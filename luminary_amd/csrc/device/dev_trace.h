@@ -25,8 +25,8 @@
 //   * every wave iteration runs ONE phase - node visit, instance entry or triangle tests - chosen by a vote over its lanes, so a
 //     lane that holds a leaf does not wait for the slowest lane of the wave to find one (plain while-while: 0.33-0.41 lane occupancy);
 //   * persistent waves fetch rays from a global cursor and refill idle lanes when too few are still traversing;
-//   * the first nodes of the array (breadth-first across both levels; 704 of them beside 64 KB of stack bottoms) are staged in LDS by every workgroup, the
-//     oldest 8 stack entries of every lane live there too: LDS hit rate of the node visits 0.62 / 0.72.
+//   * the first nodes of the array (breadth-first across both levels; 448 of them beside 96 KB of stack bottoms since round 6, 704 beside 64 KB before) are staged in LDS by
+//     every workgroup, the oldest 12 (visibility rays: 24) stack entries of every lane live there too: LDS hit rate of the node visits 0.62 / 0.72 with the 704.
 // Structural alternatives that were built and measured, and lost (profiles/r0*_ab_experiments.txt): 8-wide quantised nodes with a sorting network (twice),
 // 64-byte quantised 4-wide nodes, dual-node visits, speculative traversal past a leaf (LUM_SPECULATE, round 4: +7 % node visits, +16-19 % time),
 // physical ray reordering between bounces, per-XCD work ranges, LDS-DMA prefetch, rays regrouped by phase through LDS (round 5, above), an MFMA slab test for packets
