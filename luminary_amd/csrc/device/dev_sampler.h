@@ -108,7 +108,15 @@ struct SamplerT {
     else
       q = sobol_owen(sample_id, dim);
     const uint32_t ox = (1u + dim) * 3242174889u, oy = (1u + dim) * 2447445413u;
+#ifndef LUM_ABLATE_RNG
+#define LUM_ABLATE_RNG 0  // measurement only (wrong images): 1 no blue-noise texel fetch, 2 no table / hash for the Sobol pair either - what the random numbers' gathers cost a kernel
+#endif
+#if LUM_ABLATE_RNG
+    const uint32_t texel = (x * 0x9E3779B9u + y * 0x85EBCA6Bu + dim * 0xC2B2AE35u) | 1u;
+    if (LUM_ABLATE_RNG & 2) { q.x = texel * 0x27D4EB2Fu; q.y = texel * 0x165667B1u; }
+#else
     const uint32_t texel = bluenoise[((x + (ox >> 24)) & 0xFFu) + ((y + (oy >> 24)) & 0xFFu) * 256u];
+#endif
     q.x += texel & 0xFFFF0000u;
     q.y += texel << 16;
     return q;
