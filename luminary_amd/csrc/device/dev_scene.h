@@ -340,7 +340,10 @@ static_assert(LUM_CTL_LINE >= 32u, "the fog's control words sit in the second ha
 // goes to scratch, i.e. through the same memory path as the nodes they are looking for.
 #define LUM_LDS_STACK_BYTES 98304u
 #endif
-constexpr uint32_t kRayBlockMax = 1024u;  // the ray kernels' largest workgroup: a lane's share of the LDS stack area is sized for it
+#ifndef LUM_RAY_BLOCK_MAX
+#define LUM_RAY_BLOCK_MAX 1024u
+#endif
+constexpr uint32_t kRayBlockMax = LUM_RAY_BLOCK_MAX;  // the ray kernels' largest workgroup: a lane's share of the LDS stack area is sized for it
 
 enum Counter : uint32_t { kCntTrace = 0, kCntShadow, kCntLightBvh, kCntVertices, kCntNodes, kCntTris, kCntNodesShadow, kCntTrisShadow, kCntNodesLight, kCntTrisLight, kCntNodesLds,
                          kCntNodesLdsShadow,
