@@ -79,3 +79,34 @@ def test_the_optimal_cut_against_exhaustion_on_small_trees(kind, monkeypatch):
             if t["leaves"] > 1:  # (a set that fits one leaf has no binary inner node: the plan is empty, the tree a root with one leaf child)
                 assert abs(t["area"] - t["plan"]) <= 2e-3 * max(t["plan"], 1e-30), "the tree that was built costs what the plan said (the stored boxes are padded)"
     assert tried >= 40
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("builder", ["sah", "sah_gpu", "lbvh", "ploc"])
+def test_the_image_does_not_depend_on_the_collapse_rule(builder, monkeypatch):
+    """Greedy rule against optimal cut, through every builder (host: bvh_build.cpp collapse; GPU: lbvh.hip k_plan_pass + k_lbvh_collapse): the trees differ - fewer,
+    fuller nodes under the optimal cut - and the image, the closest hits and the oracle's image are the same bits (hits are resolved by (t, instance, triangle),
+    never by traversal order). LUM_BVH_SHARE=0: every upload builds its own trees."""
+    import oracle_lib
+    from luminary_amd import scenes
+    from luminary_amd.core import Core
+    monkeypatch.setenv("LUM_BVH_SHARE", "0")
+    host = scenes.example_scene(96, 54, 6, sphere_segments=12, ground_res=32, num_objects=24, num_lights=6)
+    view = oracle_lib.with_luts(host.device_scene())
+    ofm, osm, _ = oracle_lib.render(view, 0, 2)
+    nodes, frames = {}, {}
+    for rule in ("0", "1"):
+        monkeypatch.setenv("LUM_BVH_COLLAPSE", rule)
+        core = Core(0)
+        try:
+            core.set_bvh_builder(builder)
+            core.upload(view)
+            nodes[rule] = core.bvh_stats()[0]
+            core.set_pixels(None)
+            core.render(0, 2, samples_per_pass=2)
+            frames[rule] = core.accumulators()
+        finally:
+            core.close()
+    assert nodes["1"] < nodes["0"], "the optimal cut needs fewer 4-wide nodes: %r" % (nodes,)
+    for rule in ("0", "1"):
+        assert np.array_equal(frames[rule][0], ofm) and np.array_equal(frames[rule][1], osm), "collapse rule %s, builder %s" % (rule, builder)
