@@ -1,7 +1,7 @@
 #!/bin/sh
 # The host layer under AddressSanitizer + UBSan on the CPU (GPU AddressSanitizer is not available on the pool): the six host C++ files rebuilt with
 # -fsanitize=address,undefined, linked with the product's own HIP objects, and the CPU test suite run against that library (LUM_LIB).
-#   python -m luminary_amd.build && sh tools/asan_cpu.sh          round 4: 152 CPU tests, no report
+#   python -m luminary_amd.build && sh tools/asan_cpu.sh          round 4: 152 CPU tests, no report; round 6: 202 (incl. the collapse plan and its exhaustive check), no report
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/lum_asan
