@@ -33,7 +33,7 @@ print("rays %d  node visits %d  triangle tests %d" % (rays, nodes, tris))
 print("node phase:     %10d wave iterations, lane occupancy %.3f" % (node_it, nodes / (64.0 * max(node_it, 1))))
 print("pop:            %10d wave iterations, lane occupancy %.3f" % (pop_it, pop_l / (64.0 * max(pop_it, 1))))
 print("instance entry: %10d wave iterations, lane occupancy %.3f" % (inst_it, inst_l / (64.0 * max(inst_it, 1))))
-print("triangle phase: %10d wave iterations, lane occupancy %.3f, triangle slots used %.3f of 4" % (tri_it, tri_l / (64.0 * max(tri_it, 1)), tris / max(tri_l, 1)))
+print("triangle phase: %10d wave iterations, lane occupancy %.3f, triangle slots used %.3f of %d" % (tri_it, tri_l / (64.0 * max(tri_it, 1)), tris / max(tri_l, 1), int(lib.lumc_leaf_max_triangles())))
 print("outer iterations (refill checks): %d" % outer)
 print("per ray: %.2f node, %.2f instance, %.2f leaf visits" % (nodes / rays, inst_l / rays, tri_l / rays))
 if core.flavour == "fast" and hasattr(lib, "lumc_debug_phase_times_fast"):
